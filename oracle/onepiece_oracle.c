@@ -1,0 +1,813 @@
+/*
+ * onepiece_oracle.c -- CPU restatement (plain C99) of the OnePiece TSDF-fusion + ICP hot path.
+ * TEST INFRASTRUCTURE ONLY; see onepiece_oracle.h for the rules and the parity status
+ * ("parity unpinned" against the compiled reference; pinned against Eigen/Sophus golden vectors
+ * and the SURVEY.md reference-run statistics).
+ *
+ * Build: gcc -O3 -msse4.2 -ffp-contract=off -fopenmp (the reference's flags, CMakeLists.txt:149-150,
+ * plus -ffp-contract=off so no fused multiply-add can appear: the reference is built for SSE4.2,
+ * which has none).  Every float expression below keeps the reference's operand order and
+ * intermediate rounding; citations are file:line under /root/reference/src unless stated.
+ */
+#include "onepiece_oracle.h"
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CUBE 8
+#define NVOX 512
+
+/* ------------------------------------------------------------------------------------------ */
+/* Eigen 3.3.7 fixed-size semantics used all over the reference                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* 3-term reduction: Eigen's redux_novec_unroller splits [0,3) as {0} + {1,2}
+ * (3rdparty/Eigen/Eigen/src/Core/Redux.h, HalfLength = Length/2). */
+static inline float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+static inline float dot3(const float *a, const float *b) {
+    return sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]);
+}
+
+/* Matrix4f * Vector4f(x,y,z,1): coefficient-based packet product accumulating column by column,
+ * ((c0*x + c1*y) + c2*z) + c3*1 (3rdparty/Eigen/Eigen/src/Core/ProductEvaluators.h:626-632). */
+static inline void mat4_mul_p1(const float *M, float x, float y, float z, float out[4]) {
+    for (int r = 0; r < 4; ++r)
+        out[r] = ((M[r * 4 + 0] * x + M[r * 4 + 1] * y) + M[r * 4 + 2] * z) + M[r * 4 + 3] * 1.0f;
+}
+
+/* ---- 4x4 float inverse, SSE cofactor kernel restated lane by lane -------------------------- */
+typedef struct { float v[4]; } q4;
+static inline q4 q_shuf(q4 a, q4 b, int imm) { /* _mm_shuffle_ps */
+    q4 r = {{a.v[imm & 3], a.v[(imm >> 2) & 3], b.v[(imm >> 4) & 3], b.v[(imm >> 6) & 3]}};
+    return r;
+}
+static inline q4 q_movelh(q4 a, q4 b) { q4 r = {{a.v[0], a.v[1], b.v[0], b.v[1]}}; return r; }
+static inline q4 q_movehl(q4 a, q4 b) { q4 r = {{b.v[2], b.v[3], a.v[2], a.v[3]}}; return r; }
+static inline q4 q_mul(q4 a, q4 b) { q4 r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] * b.v[i]; return r; }
+static inline q4 q_add(q4 a, q4 b) { q4 r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+static inline q4 q_sub(q4 a, q4 b) { q4 r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] - b.v[i]; return r; }
+static inline q4 q_sub_ss(q4 a, q4 b) { a.v[0] = a.v[0] - b.v[0]; return a; }
+static inline q4 q_add_ss(q4 a, q4 b) { a.v[0] = a.v[0] + b.v[0]; return a; }
+static inline q4 q_mul_ss(q4 a, q4 b) { a.v[0] = a.v[0] * b.v[0]; return a; }
+static inline q4 q_bcast0(q4 a) { q4 r = {{a.v[0], a.v[0], a.v[0], a.v[0]}}; return r; }
+
+void orc_mat4_inverse(const float m[16], float out[16]) {
+    /* Column-major registers L1..L4 = columns (the reference's Matrix4f is column-major and
+     * StorageOrdersMatch is true; Inverse_SSE.h:50-73).  m is row-major here: col c = m[r*4+c]. */
+    q4 L1 = {{m[0], m[4], m[8], m[12]}}, L2 = {{m[1], m[5], m[9], m[13]}};
+    q4 L3 = {{m[2], m[6], m[10], m[14]}}, L4 = {{m[3], m[7], m[11], m[15]}};
+    q4 A = q_movelh(L1, L2), B = q_movehl(L2, L1), C = q_movelh(L3, L4), D = q_movehl(L4, L3);
+    q4 AB, DC, dA, dB, dC, dD, d, iA, iB, iC, iD, d1, d2, det, rd;
+    /* Inverse_SSE.h:82-87 */
+    AB = q_mul(q_shuf(A, A, 0x0F), B);
+    AB = q_sub(AB, q_mul(q_shuf(A, A, 0xA5), q_shuf(B, B, 0x4E)));
+    DC = q_mul(q_shuf(D, D, 0x0F), C);
+    DC = q_sub(DC, q_mul(q_shuf(D, D, 0xA5), q_shuf(C, C, 0x4E)));
+    /* :89-101 sub-determinants */
+    dA = q_mul(q_shuf(A, A, 0x5F), A); dA = q_sub_ss(dA, q_movehl(dA, dA));
+    dB = q_mul(q_shuf(B, B, 0x5F), B); dB = q_sub_ss(dB, q_movehl(dB, dB));
+    dC = q_mul(q_shuf(C, C, 0x5F), C); dC = q_sub_ss(dC, q_movehl(dC, dC));
+    dD = q_mul(q_shuf(D, D, 0x5F), D); dD = q_sub_ss(dD, q_movehl(dD, dD));
+    /* :103-111 */
+    d = q_mul(q_shuf(DC, DC, 0xD8), AB);
+    iD = q_mul(q_shuf(C, C, 0xA0), q_movelh(AB, AB));
+    iD = q_add(iD, q_mul(q_shuf(C, C, 0xF5), q_movehl(AB, AB)));
+    iA = q_mul(q_shuf(B, B, 0xA0), q_movelh(DC, DC));
+    iA = q_add(iA, q_mul(q_shuf(B, B, 0xF5), q_movehl(DC, DC)));
+    /* :113-117 */
+    d = q_add(d, q_movehl(d, d));
+    d = q_add_ss(d, q_shuf(d, d, 1));
+    d1 = q_mul_ss(dA, dD);
+    d2 = q_mul_ss(dB, dC);
+    /* :119-123 */
+    iD = q_sub(q_mul(D, q_bcast0(dA)), iD);
+    iA = q_sub(q_mul(A, q_bcast0(dD)), iA);
+    /* :125-127: det, true division for the reciprocal */
+    det = q_sub_ss(q_add_ss(d1, d2), d);
+    rd = det; rd.v[0] = 1.0f / det.v[0];
+    /* :133-138 */
+    iB = q_mul(D, q_shuf(AB, AB, 0x33));
+    iB = q_sub(iB, q_mul(q_shuf(D, D, 0xB1), q_shuf(AB, AB, 0x66)));
+    iC = q_mul(A, q_shuf(DC, DC, 0x33));
+    iC = q_sub(iC, q_mul(q_shuf(A, A, 0xB1), q_shuf(DC, DC, 0x66)));
+    /* :140-141 sign mask (+,-,-,+) */
+    rd = q_bcast0(rd); rd.v[1] = -rd.v[1]; rd.v[2] = -rd.v[2];
+    /* :143-147 */
+    iB = q_sub(q_mul(C, q_bcast0(dB)), iB);
+    iC = q_sub(q_mul(B, q_bcast0(dC)), iC);
+    /* :149-153 */
+    iA = q_mul(rd, iA); iB = q_mul(rd, iB); iC = q_mul(rd, iC); iD = q_mul(rd, iD);
+    /* :155-160 result columns */
+    q4 c0 = q_shuf(iA, iB, 0x77), c1 = q_shuf(iA, iB, 0x22);
+    q4 c2 = q_shuf(iC, iD, 0x77), c3 = q_shuf(iC, iD, 0x22);
+    for (int r = 0; r < 4; ++r) {
+        out[r * 4 + 0] = c0.v[r]; out[r * 4 + 1] = c1.v[r];
+        out[r * 4 + 2] = c2.v[r]; out[r * 4 + 3] = c3.v[r];
+    }
+}
+
+/* Geometry/Geometry.h:101-112: ints are converted to size_t (sign-extended), 64-bit wrapping
+ * multiply, precedence (x*p1) ^ (y*p2) ^ (z*p3). */
+uint64_t orc_hash(int x, int y, int z) {
+    return ((uint64_t)(int64_t)x * 73856093ULL) ^ ((uint64_t)(int64_t)y * 19349663ULL) ^
+           ((uint64_t)(int64_t)z * 83492791ULL);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Frustum                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Geometry/Geometry.cpp:165-171 */
+static void get_plane(const float *p1, const float *p2, const float *p3, float *plane) {
+    float a[3], b[3], n[3];
+    for (int i = 0; i < 3; ++i) { a[i] = p2[i] - p1[i]; b[i] = p3[i] - p1[i]; }
+    n[0] = a[1] * b[2] - a[2] * b[1];
+    n[1] = a[2] * b[0] - a[0] * b[2];
+    n[2] = a[0] * b[1] - a[1] * b[0];
+    float z = sum3(n[0] * n[0], n[1] * n[1], n[2] * n[2]);
+    if (z > 0.0f) { float s = sqrtf(z); n[0] = n[0] / s; n[1] = n[1] / s; n[2] = n[2] / s; }
+    double d = -dot3(p1, n);
+    plane[0] = n[0]; plane[1] = n[1]; plane[2] = n[2]; plane[3] = (float)d;
+}
+
+void orc_frustum_planes(const orc_camera *cam, const float pose[16], float far_d, float near_d,
+                        float planes[24]) {
+    /* Frustum.cpp:7-25.  atan2/tan are the double C functions (unqualified calls with only
+     * <cmath> in scope resolve to ::atan2(double,double)); results are rounded to float. */
+    float fx = cam->fx, fy = cam->fy, cy = cam->cy;
+    float height = (float)cam->height, width = (float)cam->width;
+    float right[3] = {pose[0], pose[4], pose[8]};
+    float up[3] = {-pose[1], -pose[5], -pose[9]};
+    float fwd[3] = {pose[2], pose[6], pose[10]};
+    float pos[3] = {pose[3], pose[7], pose[11]};
+    float aspect = (fy * width) / (fx * height);
+    float fov = (float)(atan2((double)cy, (double)fy) + atan2((double)(height - cy), (double)fy));
+    /* Frustum.cpp:26-46 */
+    float angle_tangent = (float)tan((double)(fov / 2));
+    float height_far = angle_tangent * far_d, width_far = height_far * aspect;
+    float height_near = angle_tangent * near_d, width_near = height_near * aspect;
+    float fc[3], nc[3], ftl[3], ftr[3], fbl[3], fbr[3], ntl[3], ntr[3], nbl[3], nbr[3];
+    for (int i = 0; i < 3; ++i) {
+        fc[i] = pos[i] + fwd[i] * far_d;
+        ftl[i] = (fc[i] + up[i] * height_far) - right[i] * width_far;
+        ftr[i] = (fc[i] + up[i] * height_far) + right[i] * width_far;
+        fbl[i] = (fc[i] - up[i] * height_far) - right[i] * width_far;
+        fbr[i] = (fc[i] - up[i] * height_far) + right[i] * width_far;
+        nc[i] = pos[i] + fwd[i] * near_d;
+        ntl[i] = (nc[i] + up[i] * height_near) - right[i] * width_near;
+        ntr[i] = (nc[i] + up[i] * height_near) + right[i] * width_near;
+        nbl[i] = (nc[i] - up[i] * height_near) - right[i] * width_near;
+        nbr[i] = (nc[i] - up[i] * height_near) + right[i] * width_near;
+    }
+    get_plane(ntl, ftl, ntr, planes + 0);   /* top    */
+    get_plane(ftl, ntl, fbl, planes + 4);   /* left   */
+    get_plane(ntr, ftr, nbr, planes + 8);   /* right  */
+    get_plane(nbr, fbl, nbl, planes + 12);  /* bottom */
+    get_plane(nbl, ntl, nbr, planes + 16);  /* near   */
+    get_plane(ftr, ftl, fbr, planes + 20);  /* far    */
+}
+
+/* Frustum.h:74-103, including the early "distance == 0 -> true". */
+static int frustum_contains(const float planes[24], const float *p) {
+    for (int k = 0; k < 6; ++k) {
+        float distance = dot3(planes + 4 * k, p) + planes[4 * k + 3];
+        if (distance < 0) return 0;
+        if (distance == 0) return 1;
+    }
+    return 1;
+}
+
+static inline float depth_at(const void *depth, int is_u16, float depth_scale, size_t idx) {
+    /* Integrator.cpp:26-29 */
+    if (!is_u16) return ((const float *)depth)[idx];
+    return ((const unsigned short *)depth)[idx] / depth_scale;
+}
+
+size_t orc_compute_bounding(const orc_camera *cam, const void *depth, int is_u16,
+                            const float pose[16], float far_d, float near_d, float max_pos[3],
+                            float min_pos[3]) {
+    float planes[24];
+    orc_frustum_planes(cam, pose, far_d, near_d, planes);
+    for (int i = 0; i < 3; ++i) { max_pos[i] = -FLT_MAX; min_pos[i] = FLT_MAX; }
+    float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
+    size_t inside = 0;
+    for (int i = 0; i < cam->height; ++i)
+        for (int j = 0; j < cam->width; ++j) {
+            float z = depth_at(depth, is_u16, cam->depth_scale, (size_t)i * cam->width + j);
+            if (!(z > 0)) continue;
+            /* PointCloud.cpp:90-93 */
+            float x = (j - cx) * z / fx;
+            float y = (i - cy) * z / fy;
+            /* Geometry.cpp:19-27 */
+            float q[4], p[3];
+            mat4_mul_p1(pose, x, y, z, q);
+            p[0] = q[0] / q[3]; p[1] = q[1] / q[3]; p[2] = q[2] / q[3];
+            if (frustum_contains(planes, p)) {
+                ++inside;
+                for (int c = 0; c < 3; ++c) {
+                    max_pos[c] = p[c] > max_pos[c] ? p[c] : max_pos[c]; /* std::max(p, max) */
+                    min_pos[c] = p[c] < min_pos[c] ? p[c] : min_pos[c];
+                }
+            }
+        }
+    return inside;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Projection / GetSDF                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Integrator.cpp:20-21,61-62: (((f*X)/Z) + 0.5) + c with the 0.5 literal promoting to double, then
+ * truncation toward zero.  Non-finite / out-of-int-range values are UB in C++; x86 cvttsd2si
+ * yields INT_MIN, which fails the u >= 0 test, so they are rejected here too. */
+static inline int project(float f, float X, float Z, float c) {
+    double t = (double)((f * X) / Z) + 0.5 + (double)c;
+    if (!(t > -2147483649.0 && t < 2147483648.0)) return INT_MIN;
+    return (int)t;
+}
+
+float orc_get_sdf(const orc_camera *cam, const float p[3], const float pose_inv[16],
+                  const void *depth, int is_u16) {
+    float q[4];
+    mat4_mul_p1(pose_inv, p[0], p[1], p[2], q);
+    int u = project(cam->fx, q[0], q[2], cam->cx);
+    int v = project(cam->fy, q[1], q[2], cam->cy);
+    if (v < 0 || v >= cam->height || u < 0 || u >= cam->width) return 999;
+    float d = depth_at(depth, is_u16, cam->depth_scale, (size_t)v * cam->width + u);
+    if (d <= 0) return 999;
+    return d - q[2];
+}
+
+void orc_cube_id(float res, const float p[3], int id[3]) {
+    /* VoxelCube.h:63-74 */
+    for (int i = 0; i < 3; ++i) {
+        int pb = (int)floorf(p[i] / res);
+        id[i] = (int)floor((pb + 0.0) / CUBE);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Volume = hash map of 8^3 blocks (std::unordered_map<CubeID,VoxelCube>, CubeHandler.h:22)    */
+/* ------------------------------------------------------------------------------------------ */
+struct orc_volume {
+    orc_camera cam;
+    float res, trunc, far_d, near_d;
+    float offset[NVOX][3]; /* VoxelCentroidOffSet, VoxelCube.h:48-61 */
+    size_t n, cap;         /* blocks */
+    int32_t *keys;         /* n x 3 */
+    float *vox;            /* n x 512 x 5 */
+    size_t tcap;           /* hash table capacity (power of two) */
+    int64_t *table;        /* block index or -1 */
+};
+
+static void vol_init_offsets(orc_volume *v) {
+    float half = v->res / 2;
+    for (size_t x = 0; x < CUBE; ++x)
+        for (size_t y = 0; y < CUBE; ++y)
+            for (size_t z = 0; z < CUBE; ++z) {
+                float *o = v->offset[x + y * CUBE + z * CUBE * CUBE];
+                o[0] = x * v->res + half; o[1] = y * v->res + half; o[2] = z * v->res + half;
+            }
+}
+
+orc_volume *orc_volume_create(const orc_camera *cam, float voxel_res, float trunc, float far_d,
+                              float near_d) {
+    orc_volume *v = (orc_volume *)calloc(1, sizeof(*v));
+    v->cam = *cam; v->res = voxel_res; v->trunc = trunc; v->far_d = far_d; v->near_d = near_d;
+    vol_init_offsets(v);
+    v->tcap = 1 << 16;
+    v->table = (int64_t *)malloc(v->tcap * sizeof(int64_t));
+    memset(v->table, 0xff, v->tcap * sizeof(int64_t));
+    return v;
+}
+void orc_volume_clear(orc_volume *v) {
+    v->n = 0;
+    memset(v->table, 0xff, v->tcap * sizeof(int64_t));
+}
+void orc_volume_destroy(orc_volume *v) {
+    if (!v) return;
+    free(v->keys); free(v->vox); free(v->table); free(v);
+}
+size_t orc_volume_block_count(const orc_volume *v) { return v->n; }
+
+static int64_t vol_find(const orc_volume *v, int x, int y, int z) {
+    size_t mask = v->tcap - 1, h = (size_t)orc_hash(x, y, z) & mask;
+    for (;;) {
+        int64_t b = v->table[h];
+        if (b < 0) return -1;
+        const int32_t *k = v->keys + 3 * b;
+        if (k[0] == x && k[1] == y && k[2] == z) return b;
+        h = (h + 1) & mask;
+    }
+}
+static void vol_table_put(orc_volume *v, int64_t b) {
+    const int32_t *k = v->keys + 3 * b;
+    size_t mask = v->tcap - 1, h = (size_t)orc_hash(k[0], k[1], k[2]) & mask;
+    while (v->table[h] >= 0) h = (h + 1) & mask;
+    v->table[h] = b;
+}
+/* VoxelCube(id): 512 default TSDFVoxel {sdf 999, w 0, color -1} (TSDFVoxel.h:79-81). */
+static int64_t vol_add(orc_volume *v, int x, int y, int z) {
+    if (v->n == v->cap) {
+        v->cap = v->cap ? v->cap * 2 : 1024;
+        v->keys = (int32_t *)realloc(v->keys, v->cap * 3 * sizeof(int32_t));
+        v->vox = (float *)realloc(v->vox, v->cap * NVOX * 5 * sizeof(float));
+    }
+    int64_t b = (int64_t)v->n++;
+    v->keys[3 * b] = x; v->keys[3 * b + 1] = y; v->keys[3 * b + 2] = z;
+    float *p = v->vox + (size_t)b * NVOX * 5;
+    for (int i = 0; i < NVOX; ++i, p += 5) { p[0] = 999; p[1] = 0; p[2] = p[3] = p[4] = -1; }
+    if (v->n * 2 > v->tcap) {
+        v->tcap *= 2;
+        v->table = (int64_t *)realloc(v->table, v->tcap * sizeof(int64_t));
+        memset(v->table, 0xff, v->tcap * sizeof(int64_t));
+        for (size_t i = 0; i < v->n; ++i) vol_table_put(v, (int64_t)i);
+    } else
+        vol_table_put(v, b);
+    return b;
+}
+
+static const int kCornerVoxel[8] = {0, 7, 56, 63, 448, 455, 504, 511}; /* CubeHandler.cpp:158-162 */
+
+size_t orc_volume_prepare_cubes(orc_volume *v, const void *depth, int is_u16, const float pose[16],
+                                int32_t *ids, size_t cap, size_t *n_candidates) {
+    float maxp[3], minp[3], pose_inv[16];
+    size_t inside = orc_compute_bounding(&v->cam, depth, is_u16, pose, v->far_d, v->near_d, maxp, minp);
+    if (n_candidates) *n_candidates = 0;
+    if (inside == 0) return 0; /* the reference would loop over an undefined range; defined as empty */
+    int maxid[3], minid[3];
+    orc_cube_id(v->res, maxp, maxid);
+    orc_cube_id(v->res, minp, minid);
+    orc_mat4_inverse(pose, pose_inv); /* Integrator.cpp:18 (recomputed per call there) */
+    float cube_res = v->res * CUBE;   /* CubeHandler.cpp:164 */
+    size_t n = 0, ncand = 0;
+    for (int i = minid[0] - 1; i <= maxid[0] + 1; ++i)
+        for (int j = minid[1] - 1; j <= maxid[1] + 1; ++j)
+            for (int k = minid[2] - 1; k <= maxid[2] + 1; ++k) {
+                ++ncand;
+                float min_sdf = FLT_MAX;
+                for (int c = 0; c < 8; ++c) {
+                    const float *o = v->offset[kCornerVoxel[c]];
+                    float p[3] = {i * cube_res + o[0], j * cube_res + o[1], k * cube_res + o[2]};
+                    float sdf = orc_get_sdf(&v->cam, p, pose_inv, depth, is_u16);
+                    if (min_sdf > fabsf(sdf)) min_sdf = fabsf(sdf);
+                }
+                if (min_sdf < v->trunc) {
+                    if (vol_find(v, i, j, k) < 0) vol_add(v, i, j, k);
+                    if (ids && n < cap) { ids[3 * n] = i; ids[3 * n + 1] = j; ids[3 * n + 2] = k; }
+                    ++n;
+                }
+            }
+    if (n_candidates) *n_candidates = ncand;
+    return n;
+}
+
+/* Integrator.cpp:36-94 for one block; returns the number of voxels updated. */
+static uint64_t integrate_block(orc_volume *v, int64_t b, const void *depth, int is_u16,
+                                const uint8_t *rgb, const float pose_inv[16]) {
+    const orc_camera *cam = &v->cam;
+    const int32_t *id = v->keys + 3 * b;
+    float *vox = v->vox + (size_t)b * NVOX * 5;
+    /* VoxelCube.h:75-80: Point3(id) * CUBE_SIZE * VoxelResolution, left to right */
+    float start[3] = {((float)id[0] * (float)CUBE) * v->res, ((float)id[1] * (float)CUBE) * v->res,
+                      ((float)id[2] * (float)CUBE) * v->res};
+    uint64_t updated = 0;
+    for (int vid = 0; vid < NVOX; ++vid) {
+        const float *o = v->offset[vid];
+        float q[4];
+        mat4_mul_p1(pose_inv, start[0] + o[0], start[1] + o[1], start[2] + o[2], q);
+        int u = project(cam->fx, q[0], q[2], cam->cx);
+        int w = project(cam->fy, q[1], q[2], cam->cy);
+        if (w < 0 || w >= cam->height || u < 0 || u >= cam->width) continue;
+        size_t pix = (size_t)w * cam->width + u;
+        float d = depth_at(depth, is_u16, cam->depth_scale, pix);
+        if (d <= 0) continue;
+        float new_sdf = d - q[2];
+        if (fabsf(new_sdf) < v->trunc) {
+            ++updated;
+            float c[3] = {rgb[3 * pix] / 255.0f, rgb[3 * pix + 1] / 255.0f, rgb[3 * pix + 2] / 255.0f};
+            float *t = vox + 5 * vid;
+            int valid = !(t[0] >= 1 || t[1] <= 0); /* TSDFVoxel.h:75-78 */
+            if (valid) {
+                /* TSDFVoxel.h:24-39 with other = (new_sdf, 1.0, c) */
+                float wsum = t[1] + 1.0f;
+                if (wsum != 0) {
+                    float s = (t[1] * t[0] + 1.0f * new_sdf) / wsum;
+                    float c0 = (t[1] * t[2] + 1.0f * c[0]) / wsum;
+                    float c1 = (t[1] * t[3] + 1.0f * c[1]) / wsum;
+                    float c2 = (t[1] * t[4] + 1.0f * c[2]) / wsum;
+                    t[0] = s; t[2] = c0; t[3] = c1; t[4] = c2;
+                } else { t[0] = 999; t[2] = t[3] = t[4] = -1; }
+                t[1] = wsum;
+            } else {
+                t[0] = new_sdf; t[1] = 1.0f; t[2] = c[0]; t[3] = c[1]; t[4] = c[2];
+            }
+        }
+    }
+    return updated;
+}
+
+size_t orc_volume_integrate(orc_volume *v, const void *depth, int is_u16, const uint8_t *rgb,
+                            const float pose[16], uint64_t *n_visited, uint64_t *n_updated) {
+    size_t cap = 1 << 16, n;
+    int32_t *ids = (int32_t *)malloc(cap * 3 * sizeof(int32_t));
+    n = orc_volume_prepare_cubes(v, depth, is_u16, pose, ids, cap, NULL);
+    if (n > cap) {
+        /* re-run selection with a big enough list; blocks are already allocated so this is pure */
+        cap = n; ids = (int32_t *)realloc(ids, cap * 3 * sizeof(int32_t));
+        n = orc_volume_prepare_cubes(v, depth, is_u16, pose, ids, cap, NULL);
+    }
+    float pose_inv[16];
+    orc_mat4_inverse(pose, pose_inv); /* Integrator.cpp:48 */
+    uint64_t upd = 0;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t b = vol_find(v, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+        upd += integrate_block(v, b, depth, is_u16, rgb, pose_inv);
+    }
+    free(ids);
+    if (n_visited) *n_visited = (uint64_t)n * NVOX;
+    if (n_updated) *n_updated = upd;
+    return n;
+}
+
+size_t orc_volume_export(const orc_volume *v, int32_t *keys, float *voxels, size_t cap) {
+    size_t n = v->n < cap ? v->n : cap;
+    if (keys) memcpy(keys, v->keys, n * 3 * sizeof(int32_t));
+    if (voxels) memcpy(voxels, v->vox, n * NVOX * 5 * sizeof(float));
+    return v->n;
+}
+
+void orc_volume_import(orc_volume *v, const int32_t *keys, const float *voxels, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        int64_t b = vol_find(v, keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]);
+        if (b < 0) b = vol_add(v, keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]);
+        memcpy(v->vox + (size_t)b * NVOX * 5, voxels + i * NVOX * 5, NVOX * 5 * sizeof(float));
+    }
+}
+
+/* TSDFVoxel::operator+ (TSDFVoxel.h:24-39), general weights. */
+static void voxel_add(float *a, const float *b) {
+    if (a[1] == 0) { memcpy(a, b, 5 * sizeof(float)); return; }
+    if (b[1] == 0) return;
+    float w = a[1] + b[1];
+    if (w != 0) {
+        float s = (a[1] * a[0] + b[1] * b[0]) / w;
+        float c0 = (a[1] * a[2] + b[1] * b[2]) / w;
+        float c1 = (a[1] * a[3] + b[1] * b[3]) / w;
+        float c2 = (a[1] * a[4] + b[1] * b[4]) / w;
+        a[0] = s; a[2] = c0; a[3] = c1; a[4] = c2;
+    } else { a[0] = 999; a[2] = a[3] = a[4] = -1; }
+    a[1] = w;
+}
+
+int orc_volume_merge(orc_volume *dst, const orc_volume *src) {
+    if (dst->res != src->res) return 1; /* CubeHandler.h:147-151 */
+    for (size_t i = 0; i < src->n; ++i) {
+        const int32_t *k = src->keys + 3 * i;
+        const float *sv = src->vox + i * NVOX * 5;
+        int64_t b = vol_find(dst, k[0], k[1], k[2]);
+        if (b < 0) {
+            b = vol_add(dst, k[0], k[1], k[2]);
+            memcpy(dst->vox + (size_t)b * NVOX * 5, sv, NVOX * 5 * sizeof(float));
+        } else {
+            float *dv = dst->vox + (size_t)b * NVOX * 5;
+            for (int j = 0; j < NVOX; ++j) voxel_add(dv + 5 * j, sv + 5 * j);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Registration                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+size_t orc_load_from_depth(const orc_camera *cam, const void *depth, int is_u16, float *xyz) {
+    size_t cnt = 0;
+    for (int i = 0; i < cam->height; ++i)
+        for (int j = 0; j < cam->width; ++j) {
+            float z = depth_at(depth, is_u16, cam->depth_scale, (size_t)i * cam->width + j);
+            if (z > 0) {
+                xyz[3 * cnt] = (j - cam->cx) * z / cam->fx;
+                xyz[3 * cnt + 1] = (i - cam->cy) * z / cam->fy;
+                xyz[3 * cnt + 2] = z;
+                ++cnt;
+            }
+        }
+    return cnt;
+}
+
+/* Sophus SE3::exp (3rdparty/Sophus/sophus/se3.hpp:468-489, so3.hpp:388-414): x[0:3] = upsilon,
+ * x[3:6] = omega.  Evaluated in double with the closed forms, rounded to float at the end
+ * (the reference evaluates in float through a unit quaternion; agreement is ~1e-7). */
+void orc_se3_exp(const float x[6], float T[16]) {
+    double w[3] = {x[3], x[4], x[5]}, u[3] = {x[0], x[1], x[2]};
+    double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double a, b, c; /* R = I + a W + b W^2 ; V = I + b W + c W^2 */
+    if (th < 1e-5) {
+        a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th);
+    }
+    double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, W2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += W[i * 3 + k] * W[k * 3 + j];
+            W2[i * 3 + j] = s;
+        }
+    for (int i = 0; i < 3; ++i) {
+        double t = 0;
+        for (int j = 0; j < 3; ++j) {
+            double I = i == j ? 1.0 : 0.0;
+            T[i * 4 + j] = (float)(I + a * W[i * 3 + j] + b * W2[i * 3 + j]);
+            t += (I + b * W[i * 3 + j] + c * W2[i * 3 + j]) * u[j];
+        }
+        T[i * 4 + 3] = (float)t;
+    }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+}
+
+/* Cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (double). A is destroyed,
+ * V columns are eigenvectors, diag(A) the eigenvalues. */
+static void jacobi_sym(double *A, double *V, int n) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+/* x = JacobiSVD(JTJ).solve(-JTr) (ICP.cpp:137-138).  JTJ is symmetric PSD, so its SVD is its
+ * eigen-decomposition; Eigen's solve() drops singular values <= eps*diagSize*max (float eps). */
+void orc_solve6(const float JTJ[36], const float JTr[6], float x[6]) {
+    double A[36], V[36], y[6];
+    for (int i = 0; i < 36; ++i) A[i] = JTJ[i];
+    for (int i = 0; i < 6; ++i) /* symmetrise against float accumulation noise */
+        for (int j = i + 1; j < 6; ++j) A[i * 6 + j] = A[j * 6 + i] = 0.5 * (A[i * 6 + j] + A[j * 6 + i]);
+    jacobi_sym(A, V, 6);
+    double smax = 0;
+    for (int i = 0; i < 6; ++i) if (fabs(A[i * 7]) > smax) smax = fabs(A[i * 7]);
+    double thr = smax * 6.0 * (double)FLT_EPSILON;
+    for (int k = 0; k < 6; ++k) {
+        double s = 0;
+        for (int i = 0; i < 6; ++i) s += V[i * 6 + k] * (-(double)JTr[i]);
+        y[k] = fabs(A[k * 7]) > thr ? s / A[k * 7] : 0.0;
+    }
+    for (int i = 0; i < 6; ++i) {
+        double s = 0;
+        for (int k = 0; k < 6; ++k) s += V[i * 6 + k] * y[k];
+        x[i] = (float)s;
+    }
+}
+
+/* Geometry.cpp:107-151 (Kabsch).  Sums in float in the reference's order; the 3x3 SVD is
+ * obtained from the eigen-decomposition of W^T W in double (R = V U^T with det fix). */
+void orc_kabsch(const float *pairs, size_t n, float T[16]) {
+    float ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0}, W[9] = {0};
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) { ms[c] += pairs[6 * i + c]; mt[c] += pairs[6 * i + 3 + c]; }
+    for (int c = 0; c < 3; ++c) { ms[c] /= (float)n; mt[c] /= (float)n; }
+    for (size_t i = 0; i < n; ++i) {
+        float a[3], b[3];
+        for (int c = 0; c < 3; ++c) { a[c] = pairs[6 * i + c] - ms[c]; b[c] = pairs[6 * i + 3 + c] - mt[c]; }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) W[r * 3 + c] += a[r] * b[c];
+    }
+    /* W = U S V^T.  R = V U^T (det-fixed) is the orthogonal polar factor of W^T:
+     * W^T W = V S^2 V^T; U = W V S^-1. */
+    double A[9], V[9], S[3], U[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += (double)W[k * 3 + i] * (double)W[k * 3 + j];
+            A[i * 3 + j] = s;
+        }
+    jacobi_sym(A, V, 3);
+    /* sort singular values descending (JacobiSVD order) */
+    int ord[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (A[ord[j] * 4] > A[ord[i] * 4]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double Vs[9];
+    for (int k = 0; k < 3; ++k) {
+        S[k] = sqrt(A[ord[k] * 4] > 0 ? A[ord[k] * 4] : 0);
+        for (int i = 0; i < 3; ++i) Vs[i * 3 + k] = V[i * 3 + ord[k]];
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 3; ++i) {
+            double s = 0;
+            for (int j = 0; j < 3; ++j) s += (double)W[i * 3 + j] * Vs[j * 3 + k];
+            U[i * 3 + k] = S[k] > 1e-300 ? s / S[k] : 0;
+        }
+    /* if the smallest singular value is ~0, complete U's last column by a cross product */
+    if (S[2] <= 1e-12 * (S[0] > 0 ? S[0] : 1)) {
+        U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+        U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+        U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+    }
+    double R[9];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += Vs[i * 3 + k] * U[j * 3 + k];
+                R[i * 3 + j] = s;
+            }
+        double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+                     R[2] * (R[3] * R[7] - R[4] * R[6]);
+        if (det >= 0) break;
+        for (int i = 0; i < 3; ++i) Vs[i * 3 + 2] = -Vs[i * 3 + 2]; /* Geometry.cpp:139-144 */
+    }
+    memset(T, 0, 16 * sizeof(float));
+    for (int i = 0; i < 3; ++i) {
+        double s = 0;
+        for (int j = 0; j < 3; ++j) { T[i * 4 + j] = (float)R[i * 3 + j]; s += R[i * 3 + j] * ms[j]; }
+        T[i * 4 + 3] = (float)(mt[i] - s);
+    }
+    T[15] = 1;
+}
+
+/* ICP.cpp:108-144 */
+void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
+                      const int32_t *inliers, size_t n, float T[16], float JTJ[36], float JTr[6]) {
+    float jtj[36] = {0}, jtr[6] = {0};
+    for (size_t i = 0; i < n; ++i) {
+        const float *s = src + 3 * inliers[2 * i], *t = tgt + 3 * inliers[2 * i + 1];
+        const float *nn = tgt_n + 3 * inliers[2 * i + 1];
+        double r = (double)(dot3(nn, s) - dot3(nn, t)); /* float dots, float difference -> double */
+        float row[6] = {nn[0], nn[1], nn[2], s[1] * nn[2] - s[2] * nn[1], s[2] * nn[0] - s[0] * nn[2],
+                        s[0] * nn[1] - s[1] * nn[0]};
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) jtj[a * 6 + b] += row[a] * row[b];
+            jtr[a] += (float)r * row[a];
+        }
+    }
+    float x[6];
+    orc_solve6(jtj, jtr, x);
+    orc_se3_exp(x, T);
+    if (JTJ) memcpy(JTJ, jtj, sizeof(jtj));
+    if (JTr) memcpy(JTr, jtr, sizeof(jtr));
+}
+
+/* ---- exact 1-NN: kd-tree (the reference uses nanoflann 1.3.2, exact, eps = 0) -------------- */
+typedef struct { int left, right, axis, lo, hi; float split; } kdnode;
+typedef struct { const float *pts; int *idx; kdnode *nodes; int n_nodes; } kdtree;
+
+static int kd_build(kdtree *t, int lo, int hi) {
+    int id = t->n_nodes++;
+    kdnode *nd = &t->nodes[id];
+    nd->lo = lo; nd->hi = hi; nd->left = nd->right = -1; nd->axis = -1;
+    if (hi - lo <= 10) return id; /* leaf size 10 as nanoflann's default in KDTree.h:86-92 */
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = lo; i < hi; ++i)
+        for (int c = 0; c < 3; ++c) {
+            float v = t->pts[3 * t->idx[i] + c];
+            if (v < mn[c]) mn[c] = v;
+            if (v > mx[c]) mx[c] = v;
+        }
+    int ax = 0;
+    if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+    if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+    float split = 0.5f * (mn[ax] + mx[ax]);
+    int i = lo, j = hi - 1;
+    while (i <= j) {
+        if (t->pts[3 * t->idx[i] + ax] < split) ++i;
+        else { int tmp = t->idx[i]; t->idx[i] = t->idx[j]; t->idx[j] = tmp; --j; }
+    }
+    if (i == lo || i == hi) return id; /* degenerate: keep as a (large) leaf */
+    t->nodes[id].axis = ax; t->nodes[id].split = split;
+    int l = kd_build(t, lo, i);
+    int r = kd_build(t, i, hi);
+    t->nodes[id].left = l; t->nodes[id].right = r;
+    return id;
+}
+static void kd_query(const kdtree *t, int id, const float *q, float *best_d, int *best_i) {
+    const kdnode *nd = &t->nodes[id];
+    if (nd->axis < 0) {
+        for (int i = nd->lo; i < nd->hi; ++i) {
+            const float *p = t->pts + 3 * t->idx[i];
+            float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+            float d = dx * dx + dy * dy + dz * dz;
+            if (d < *best_d || (d == *best_d && t->idx[i] < *best_i)) { *best_d = d; *best_i = t->idx[i]; }
+        }
+        return;
+    }
+    float diff = q[nd->axis] - nd->split;
+    int first = diff < 0 ? nd->left : nd->right, second = diff < 0 ? nd->right : nd->left;
+    kd_query(t, first, q, best_d, best_i);
+    if (diff * diff <= *best_d) kd_query(t, second, q, best_d, best_i);
+}
+
+/* ICP.cpp:9-30 */
+static double count_inliers(const float *src, const float *tgt, const int *corr, size_t n,
+                            const float T[16], double threshold, int32_t *inliers, size_t *n_inl) {
+    double sum_error = 0, thr2 = threshold * threshold;
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (corr[i] == -1) continue;
+        const float *s = src + 3 * i, *t = tgt + 3 * corr[i];
+        float d[3];
+        for (int r = 0; r < 3; ++r) /* (R*s + t) - target, Matrix3f*Vector3f coefficient = p0+(p1+p2) */
+            d[r] = (sum3(T[r * 4] * s[0], T[r * 4 + 1] * s[1], T[r * 4 + 2] * s[2]) + T[r * 4 + 3]) - t[r];
+        double e = (double)sum3(d[0] * d[0], d[1] * d[1], d[2] * d[2]);
+        if (e < thr2) {
+            inliers[2 * m] = (int32_t)i; inliers[2 * m + 1] = corr[i]; ++m;
+            sum_error += e;
+        }
+    }
+    *n_inl = m;
+    return sqrt(sum_error / (double)m);
+}
+
+static void mat4_mul(const float *A, const float *B, float *C) { /* Matrix4f*Matrix4f, column accumulate */
+    float out[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            out[r * 4 + c] = ((A[r * 4] * B[c] + A[r * 4 + 1] * B[4 + c]) + A[r * 4 + 2] * B[8 + c]) +
+                             A[r * 4 + 3] * B[12 + c];
+    memcpy(C, out, sizeof(out));
+}
+
+int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt, size_t n_tgt,
+            const float *tgt_normals, const float init_T[16], int max_iter, double threshold,
+            orc_icp_result *res, int32_t *inlier_pairs, int32_t *per_iter_inliers,
+            float *per_iter_T) {
+    if (point_to_plane && !tgt_normals) return 1; /* ICP.cpp:159-163 */
+    kdtree t;
+    t.pts = tgt; t.idx = (int *)malloc(n_tgt * sizeof(int));
+    t.nodes = (kdnode *)malloc((2 * n_tgt + 2) * sizeof(kdnode)); t.n_nodes = 0;
+    for (size_t i = 0; i < n_tgt; ++i) t.idx[i] = (int)i;
+    if (n_tgt) kd_build(&t, 0, (int)n_tgt);
+    float start_T[16];
+    memcpy(start_T, init_T, sizeof(start_T));
+    int *corr = (int *)malloc(n_src * sizeof(int));
+    float *tp = (float *)malloc(n_src * 3 * sizeof(float));
+    int32_t *inl = (int32_t *)malloc(n_src * 2 * sizeof(int32_t));
+    float *pairs = (float *)malloc(n_src * 6 * sizeof(float));
+    size_t n_inl = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        for (size_t i = 0; i < n_src; ++i) { /* ICP.cpp:182-183, Geometry.cpp:19-27 */
+            float q[4];
+            mat4_mul_p1(start_T, src[3 * i], src[3 * i + 1], src[3 * i + 2], q);
+            tp[3 * i] = q[0] / q[3]; tp[3 * i + 1] = q[1] / q[3]; tp[3 * i + 2] = q[2] / q[3];
+        }
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)n_src; ++i) { /* ICP.cpp:184-192 */
+            float bd = FLT_MAX; int bi = -1;
+            if (n_tgt) kd_query(&t, 0, tp + 3 * i, &bd, &bi);
+            corr[i] = bi;
+        }
+        count_inliers(src, tgt, corr, n_src, start_T, threshold, inl, &n_inl); /* ICP.cpp:193 */
+        float tmp_T[16];
+        if (point_to_plane) {
+            orc_p2plane_step(tp, tgt, tgt_normals, inl, n_inl, tmp_T, NULL, NULL); /* :195 */
+        } else {
+            for (size_t i = 0; i < n_inl; ++i) { /* ICP.cpp:73-78 */
+                memcpy(pairs + 6 * i, tp + 3 * inl[2 * i], 12);
+                memcpy(pairs + 6 * i + 3, tgt + 3 * inl[2 * i + 1], 12);
+            }
+            orc_kabsch(pairs, n_inl, tmp_T);
+        }
+        mat4_mul(tmp_T, start_T, start_T); /* :198 */
+        if (per_iter_inliers) per_iter_inliers[it] = (int32_t)n_inl;
+        if (per_iter_T) memcpy(per_iter_T + 16 * it, start_T, sizeof(start_T));
+    }
+    /* ICP.cpp:206-221.  corr is the last iteration's NN set (not recomputed). */
+    res->rmse = count_inliers(src, tgt, corr, n_src, start_T, threshold, inl, &n_inl);
+    res->n_inliers = n_inl;
+    res->iterations = max_iter;
+    memcpy(res->last_T, start_T, sizeof(start_T));
+    for (size_t i = 0; i < n_inl; ++i) {
+        memcpy(pairs + 6 * i, src + 3 * inl[2 * i], 12);
+        memcpy(pairs + 6 * i + 3, tgt + 3 * inl[2 * i + 1], 12);
+    }
+    orc_kabsch(pairs, n_inl, res->T);
+    if (inlier_pairs) memcpy(inlier_pairs, inl, n_inl * 2 * sizeof(int32_t));
+    free(corr); free(tp); free(inl); free(pairs); free(t.idx); free(t.nodes);
+    return 0;
+}

@@ -1,0 +1,110 @@
+/*
+ * onepiece_oracle.h -- CPU restatement (plain C) of the OnePiece TSDF-fusion + ICP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (onepiece_amd/, include/) may link,
+ * import or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and only as the checker / the timed CPU baseline.
+ *
+ * PARITY STATUS: "parity unpinned" against the compiled reference.  The reference hot-path
+ * translation units all include <opencv2/...> (src/Geometry/Geometry.h:4-8), OpenCV is neither
+ * vendored nor installed, and building the reference against stand-in headers is not allowed, so
+ * the reference itself cannot be run here.  The reference ships no tests/golden vectors
+ * (SURVEY.md section 4).  What this restatement IS pinned against:
+ *   - the reference's vendored third-party arithmetic (Eigen 3.3.7 4x4 SSE inverse, fixed-size
+ *     product / dot evaluation order, JacobiSVD solve, Sophus SE3::exp), through golden vectors
+ *     generated in the build container by oracle/tools/gen_eigen_golden.cpp and committed under
+ *     tests/golden/;
+ *   - the VoxelGridHasher known answers in SURVEY.md A.8;
+ *   - the reference-run statistics recorded in SURVEY.md Appendix B / section 6 (block count,
+ *     observed-voxel count, weight sum, XOR of key hashes for the 5-frame "wall" scene).
+ *
+ * All matrices cross this API as ROW-MAJOR float[16].  Every function cites the reference
+ * file:line (relative to /root/reference/src) that it follows.
+ */
+#ifndef ONEPIECE_ORACLE_H
+#define ONEPIECE_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    float fx, fy, cx, cy;
+    int width, height;
+    float depth_scale;
+} orc_camera; /* Camera/Camera.h:13-131 */
+
+typedef struct orc_volume orc_volume;
+
+/* Eigen 3.3.7 LU/arch/Inverse_SSE.h:35-165 (what pose.inverse() runs, Integrator.cpp:18,48). */
+void orc_mat4_inverse(const float m[16], float out[16]);
+/* Geometry/Geometry.h:101-112 */
+uint64_t orc_hash(int x, int y, int z);
+/* Integration/Frustum.cpp:7-46, Geometry.cpp:165-171. planes: top,left,right,bottom,near,far. */
+void orc_frustum_planes(const orc_camera *cam, const float pose[16], float far_d, float near_d,
+                        float planes[24]);
+/* Integration/CubeHandler.cpp:116-145; returns number of points inside the frustum. */
+size_t orc_compute_bounding(const orc_camera *cam, const void *depth, int is_u16,
+                            const float pose[16], float far_d, float near_d, float max_pos[3],
+                            float min_pos[3]);
+/* Integration/Integrator.cpp:8-35 (pose_inv supplied). */
+float orc_get_sdf(const orc_camera *cam, const float p[3], const float pose_inv[16],
+                  const void *depth, int is_u16);
+/* Integration/VoxelCube.h:63-74 */
+void orc_cube_id(float res, const float p[3], int id[3]);
+
+orc_volume *orc_volume_create(const orc_camera *cam, float voxel_res, float trunc, float far_d,
+                              float near_d);
+void orc_volume_destroy(orc_volume *v);
+void orc_volume_clear(orc_volume *v);
+size_t orc_volume_block_count(const orc_volume *v);
+/* Integration/CubeHandler.cpp:147-196: fills ids (n x 3, loop order), allocates blocks.
+ * Returns the list length (may exceed cap; only cap entries written).  n_candidates = bbox size. */
+size_t orc_volume_prepare_cubes(orc_volume *v, const void *depth, int is_u16, const float pose[16],
+                                int32_t *ids, size_t cap, size_t *n_candidates);
+/* Integration/CubeHandler.cpp:197-210 + Integrator.cpp:36-94.  rgb = 3 bytes / pixel in stored
+ * channel order.  Returns list length; *n_visited = 512*len, *n_updated = voxels passing the
+ * update predicate. */
+size_t orc_volume_integrate(orc_volume *v, const void *depth, int is_u16, const uint8_t *rgb,
+                            const float pose[16], uint64_t *n_visited, uint64_t *n_updated);
+/* Export in insertion order: keys n x 3 int32, voxels n x 512 x 5 float {sdf,w,c0,c1,c2}. */
+size_t orc_volume_export(const orc_volume *v, int32_t *keys, float *voxels, size_t cap);
+/* AddCube + overwrite (used to build volumes from arrays). */
+void orc_volume_import(orc_volume *v, const int32_t *keys, const float *voxels, size_t n);
+/* Integration/CubeHandler.h:145-167 */
+int orc_volume_merge(orc_volume *dst, const orc_volume *src);
+
+/* ---- Registration ---- */
+/* Geometry/PointCloud.cpp:72-100.  Returns count; xyz has room for w*h*3 floats. */
+size_t orc_load_from_depth(const orc_camera *cam, const void *depth, int is_u16, float *xyz);
+/* Geometry/Geometry.cpp:9-13 via Sophus SE3::exp (3rdparty/Sophus/sophus/se3.hpp). */
+void orc_se3_exp(const float x[6], float T[16]);
+/* Geometry/Geometry.cpp:107-151.  pairs: n x 6 floats (source xyz, target xyz). */
+void orc_kabsch(const float *pairs, size_t n, float T[16]);
+/* JacobiSVD(JTJ).solve(-JTr), ICP.cpp:137-138 (restated as symmetric Jacobi in double). */
+void orc_solve6(const float JTJ[36], const float JTr[6], float x[6]);
+/* Registration/ICP.cpp:108-144. inliers: n x 2 int32 (source id, target id). */
+void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
+                      const int32_t *inliers, size_t n, float T[16], float JTJ[36], float JTr[6]);
+
+typedef struct {
+    float T[16];          /* RegistrationResult::T (Kabsch over final inliers) */
+    float last_T[16];     /* accumulated start_T after the loop (not returned by the reference) */
+    double rmse;
+    size_t n_inliers;     /* size of correspondence_set_index */
+    int iterations;
+} orc_icp_result;
+
+/* Registration/ICP.cpp:146-224 (mode 1) and :31-107 (mode 0 = PointToPoint).
+ * inlier_pairs: room for n_src x 2 int32; per_iter_inliers: room for max_iter entries;
+ * per_iter_T: room for max_iter x 16 floats (start_T after each iteration); any may be NULL. */
+int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt, size_t n_tgt,
+            const float *tgt_normals, const float init_T[16], int max_iter, double threshold,
+            orc_icp_result *res, int32_t *inlier_pairs, int32_t *per_iter_inliers,
+            float *per_iter_T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,239 @@
+"""ctypes wrapper around oracle/libonepiece_oracle.so (the CPU restatement of the reference).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never from onepiece_amd/.  Parity status: see onepiece_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libonepiece_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("onepiece_oracle.c", "onepiece_oracle.h")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libonepiece_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("width", C.c_int), ("height", C.c_int), ("depth_scale", C.c_float)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("last_T", C.c_float * 16), ("rmse", C.c_double),
+                ("n_inliers", C.c_size_t), ("iterations", C.c_int)]
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_hash.restype = C.c_uint64
+        L.orc_hash.argtypes = [C.c_int] * 3
+        L.orc_mat4_inverse.argtypes = [_fp, _fp]
+        L.orc_frustum_planes.argtypes = [C.POINTER(Camera), _fp, C.c_float, C.c_float, _fp]
+        L.orc_compute_bounding.restype = C.c_size_t
+        L.orc_compute_bounding.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, _fp, C.c_float,
+                                           C.c_float, _fp, _fp]
+        L.orc_get_sdf.restype = C.c_float
+        L.orc_get_sdf.argtypes = [C.POINTER(Camera), _fp, _fp, C.c_void_p, C.c_int]
+        L.orc_cube_id.argtypes = [C.c_float, _fp, C.POINTER(C.c_int)]
+        L.orc_volume_create.restype = C.c_void_p
+        L.orc_volume_create.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_volume_destroy.argtypes = [C.c_void_p]
+        L.orc_volume_clear.argtypes = [C.c_void_p]
+        L.orc_volume_block_count.restype = C.c_size_t
+        L.orc_volume_block_count.argtypes = [C.c_void_p]
+        L.orc_volume_prepare_cubes.restype = C.c_size_t
+        L.orc_volume_prepare_cubes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _fp, _ip, C.c_size_t,
+                                               C.POINTER(C.c_size_t)]
+        L.orc_volume_integrate.restype = C.c_size_t
+        L.orc_volume_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, _fp,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_volume_export.restype = C.c_size_t
+        L.orc_volume_export.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
+        L.orc_volume_import.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
+        L.orc_volume_merge.restype = C.c_int
+        L.orc_volume_merge.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_load_from_depth.restype = C.c_size_t
+        L.orc_load_from_depth.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, _fp]
+        L.orc_se3_exp.argtypes = [_fp, _fp]
+        L.orc_kabsch.argtypes = [_fp, C.c_size_t, _fp]
+        L.orc_solve6.argtypes = [_fp, _fp, _fp]
+        L.orc_p2plane_step.argtypes = [_fp, _fp, _fp, _ip, C.c_size_t, _fp, _fp, _fp]
+        L.orc_icp.restype = C.c_int
+        L.orc_icp.argtypes = [C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp, C.c_int,
+                              C.c_double, C.POINTER(IcpResult), _ip, _ip, _fp]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=_fp):
+    return a.ctypes.data_as(t)
+
+
+def make_camera(fx=514.817, fy=515.375, cx=318.771, cy=238.447, width=640, height=480,
+                depth_scale=1000.0):
+    """Default = OPEN3D_DATASET preset (Camera/Camera.h:94-104)."""
+    return Camera(fx, fy, cx, cy, width, height, depth_scale)
+
+
+def _depth_arg(depth):
+    depth = np.ascontiguousarray(depth)
+    if depth.dtype == np.uint16:
+        return depth, 1
+    return _f32(depth), 0
+
+
+def hash_key(x, y, z):
+    return int(lib().orc_hash(int(x), int(y), int(z)))
+
+
+def mat4_inverse(m):
+    m = _f32(m).reshape(16)
+    out = np.empty(16, np.float32)
+    lib().orc_mat4_inverse(_p(m), _p(out))
+    return out.reshape(4, 4)
+
+
+def frustum_planes(cam, pose, far=5.0, near=0.5):
+    pose = _f32(pose).reshape(16)
+    out = np.empty(24, np.float32)
+    lib().orc_frustum_planes(C.byref(cam), _p(pose), far, near, _p(out))
+    return out.reshape(6, 4)
+
+
+def compute_bounding(cam, depth, pose, far=5.0, near=0.5):
+    d, u16 = _depth_arg(depth)
+    pose = _f32(pose).reshape(16)
+    mx, mn = np.empty(3, np.float32), np.empty(3, np.float32)
+    n = lib().orc_compute_bounding(C.byref(cam), d.ctypes.data, u16, _p(pose), far, near, _p(mx), _p(mn))
+    return mx, mn, int(n)
+
+
+def se3_exp(x):
+    x = _f32(x).reshape(6)
+    T = np.empty(16, np.float32)
+    lib().orc_se3_exp(_p(x), _p(T))
+    return T.reshape(4, 4)
+
+
+def kabsch(src, tgt):
+    pairs = _f32(np.concatenate([_f32(src).reshape(-1, 3), _f32(tgt).reshape(-1, 3)], axis=1))
+    T = np.empty(16, np.float32)
+    lib().orc_kabsch(_p(pairs), pairs.shape[0], _p(T))
+    return T.reshape(4, 4)
+
+
+def solve6(JTJ, JTr):
+    a, b = _f32(JTJ).reshape(36), _f32(JTr).reshape(6)
+    x = np.empty(6, np.float32)
+    lib().orc_solve6(_p(a), _p(b), _p(x))
+    return x
+
+
+def load_from_depth(cam, depth):
+    d, u16 = _depth_arg(depth)
+    xyz = np.empty((cam.width * cam.height, 3), np.float32)
+    n = lib().orc_load_from_depth(C.byref(cam), d.ctypes.data, u16, _p(xyz))
+    return xyz[:n].copy()
+
+
+class Volume:
+    """Mirror of integration::CubeHandler restricted to the hot path (CubeHandler.h:24-366)."""
+
+    def __init__(self, cam=None, voxel_res=0.01, trunc=0.1, far=5.0, near=0.5):
+        self.cam = cam or make_camera()
+        self._h = lib().orc_volume_create(C.byref(self.cam), voxel_res, trunc, far, near)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_volume_destroy(self._h)
+            self._h = None
+
+    def clear(self):
+        lib().orc_volume_clear(self._h)
+
+    def block_count(self):
+        return int(lib().orc_volume_block_count(self._h))
+
+    def prepare_cubes(self, depth, pose):
+        d, u16 = _depth_arg(depth)
+        pose = _f32(pose).reshape(16)
+        cap = 1 << 17
+        while True:
+            ids = np.empty((cap, 3), np.int32)
+            nc = C.c_size_t(0)
+            n = lib().orc_volume_prepare_cubes(self._h, d.ctypes.data, u16, _p(pose), _p(ids, _ip),
+                                               cap, C.byref(nc))
+            if n <= cap:
+                return ids[:n].copy(), int(nc.value)
+            cap = int(n)
+
+    def integrate(self, depth, rgb, pose):
+        d, u16 = _depth_arg(depth)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        pose = _f32(pose).reshape(16)
+        nv, nu = C.c_uint64(0), C.c_uint64(0)
+        n = lib().orc_volume_integrate(self._h, d.ctypes.data, u16, rgb.ctypes.data, _p(pose),
+                                       C.byref(nv), C.byref(nu))
+        return int(n), int(nv.value), int(nu.value)
+
+    def export(self, sort=True):
+        n = self.block_count()
+        keys = np.empty((n, 3), np.int32)
+        vox = np.empty((n, 512, 5), np.float32)
+        lib().orc_volume_export(self._h, _p(keys, _ip), _p(vox), n)
+        if sort and n:
+            order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+            keys, vox = keys[order], vox[order]
+        return keys, vox
+
+    def load(self, keys, vox):
+        keys = np.ascontiguousarray(keys, np.int32)
+        vox = _f32(vox)
+        lib().orc_volume_import(self._h, _p(keys, _ip), _p(vox), keys.shape[0])
+
+    def merge(self, other):
+        return int(lib().orc_volume_merge(self._h, other._h))
+
+
+def icp(src, tgt, tgt_normals=None, init_T=None, max_iter=30, threshold=0.2, point_to_plane=True):
+    """registration::PointToPlane / PointToPoint (ICP.cpp:146-224 / :31-107)."""
+    src, tgt = _f32(src).reshape(-1, 3), _f32(tgt).reshape(-1, 3)
+    nrm = _f32(tgt_normals).reshape(-1, 3) if tgt_normals is not None else None
+    T0 = _f32(np.eye(4) if init_T is None else init_T).reshape(16)
+    res = IcpResult()
+    pairs = np.empty((max(len(src), 1), 2), np.int32)
+    per_n = np.zeros(max(max_iter, 1), np.int32)
+    per_T = np.zeros((max(max_iter, 1), 16), np.float32)
+    rc = lib().orc_icp(1 if point_to_plane else 0, _p(src), len(src), _p(tgt), len(tgt),
+                       _p(nrm) if nrm is not None else None, _p(T0), max_iter, threshold,
+                       C.byref(res), _p(pairs, _ip), _p(per_n, _ip), _p(per_T))
+    if rc:
+        return None
+    n = int(res.n_inliers)
+    return {"T": np.array(res.T, np.float32).reshape(4, 4),
+            "last_T": np.array(res.last_T, np.float32).reshape(4, 4),
+            "rmse": float(res.rmse), "pairs": pairs[:n].copy(),
+            "per_iter_inliers": per_n[:max_iter].copy(),
+            "per_iter_T": per_T[:max_iter].reshape(-1, 4, 4).copy()}
