@@ -1,0 +1,186 @@
+/*
+ * onepiece_hip.h -- C-ABI of the MI355X (gfx950) implementation of OnePiece's TSDF-fusion + ICP
+ * hot path.  This is the drop-in boundary: the reference has no FFI layer (its boundary is the C++
+ * header surface one_piece::integration::CubeHandler / one_piece::registration::PointToPlane), so
+ * every entry point below names the reference declaration (file:line under /root/reference/src)
+ * whose work it replaces; the C++ shim that re-exposes the reference's class surface on top of
+ * these calls is host/onepiece_shim.hpp, and INTEGRATION.md shows how a maintainer wires it in.
+ *
+ * Conventions
+ *   - extern "C", POD only, caller-allocated outputs, int return: 0 = OP_OK, otherwise an
+ *     op_status; op_last_error() returns a thread-local description of the last failure.
+ *   - All 4x4 matrices are ROW-MAJOR float[16] (the shim transposes Eigen's column-major storage).
+ *   - Images: depth is float32 metres (OP_DEPTH_F32, cv CV_32FC1) or uint16 / depth_scale
+ *     (OP_DEPTH_U16, cv CV_16UC1), row-major width x height; colour is 3 bytes / pixel in stored
+ *     channel order (cv CV_8UC3).  `mem` says where image/point buffers live: OP_MEM_HOST buffers
+ *     are copied to the device by the call, OP_MEM_DEVICE buffers are used in place and must stay
+ *     valid until op_volume_sync()/the next synchronising call.
+ *   - A volume owns one HIP stream.  op_volume_integrate() only enqueues work; every accessor that
+ *     returns data synchronises first (SURVEY.md 8b "Threading").
+ *   - There is NO CPU fallback: every compute entry point fails with OP_ERR_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef ONEPIECE_HIP_H
+#define ONEPIECE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OP_ABI_VERSION 1
+
+typedef enum {
+    OP_OK = 0,
+    OP_ERR_INVALID = 1,      /* bad argument */
+    OP_ERR_NO_DEVICE = 2,    /* no usable HIP device / HIP runtime error */
+    OP_ERR_CAPACITY = 3,     /* block pool or hash table exhausted (create with more max_blocks) */
+    OP_ERR_MISMATCH = 4,     /* e.g. Merge of volumes with different voxel resolution */
+    OP_ERR_NO_NORMALS = 5,   /* PointToPlane without target normals (ICP.cpp:159-163) */
+    OP_ERR_HIP = 6
+} op_status;
+
+enum { OP_DEPTH_F32 = 0, OP_DEPTH_U16 = 1 };
+enum { OP_MEM_HOST = 0, OP_MEM_DEVICE = 1 };
+enum { OP_ICP_POINT_TO_POINT = 0, OP_ICP_POINT_TO_PLANE = 1 };
+
+/* camera::PinholeCamera (Camera/Camera.h:13-131) as a POD. */
+typedef struct {
+    float fx, fy, cx, cy;
+    int32_t width, height;
+    float depth_scale;
+} op_camera;
+
+typedef struct op_volume op_volume; /* device-resident integration::CubeHandler state */
+typedef struct op_icp op_icp;       /* device-resident target cloud + search grid */
+
+/* ---- library ----------------------------------------------------------------------------- */
+int op_abi_version(void);
+const char *op_last_error(void);
+int op_device_count(int *count);
+/* OPEN3D_DATASET / TUM_DATASET presets, Camera/Camera.h:76-104.  type: 0 = TUM, 1 = OPEN3D. */
+int op_camera_preset(int type, op_camera *out);
+
+/* ---- host-side geometry used on the path (bit-faithful to the reference's Eigen build) ---- */
+/* geometry::TransformationMatrix::inverse() as Eigen 3.3.7 evaluates it with -msse4.2
+ * (Integrator.cpp:18,48; 3rdparty/Eigen/Eigen/src/LU/arch/Inverse_SSE.h:35-165). */
+int op_mat4_inverse(const float m[16], float out[16]);
+/* geometry::VoxelGridHasher::operator() (Geometry/Geometry.h:101-112). */
+uint64_t op_hash_key(int32_t x, int32_t y, int32_t z);
+/* Frustum::ComputeFromCamera (Integration/Frustum.cpp:7-46): planes top,left,right,bottom,near,far. */
+int op_frustum_planes(const op_camera *cam, const float pose[16], float far_dist, float near_dist,
+                      float planes[24]);
+/* geometry::Se3ToSE3 (Geometry/Geometry.cpp:9-13). */
+int op_se3_exp(const float x[6], float T[16]);
+
+/* ---- integration::CubeHandler (Integration/CubeHandler.h:24-366) ------------------------- */
+/* CubeHandler(const PinholeCamera&) + SetVoxelResolution + SetTruncation + SetFar/NearPlane.
+ * max_blocks sizes the device block pool (10 KiB per 8^3 block) and hash table; 0 = default. */
+int op_volume_create(const op_camera *cam, float voxel_res, float truncation, float far_dist,
+                     float near_dist, int device, uint64_t max_blocks, op_volume **out);
+int op_volume_destroy(op_volume *v);
+int op_volume_set_resolution(op_volume *v, float voxel_res);  /* CubeHandler.h:36-39 */
+int op_volume_set_truncation(op_volume *v, float truncation); /* CubeHandler.h:141-144 */
+int op_volume_set_camera(op_volume *v, const op_camera *cam); /* CubeHandler.h:137-140 */
+int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* CubeHandler.h:339-346 */
+int op_volume_clear(op_volume *v);                            /* CubeHandler.h:133-136 */
+int op_volume_sync(op_volume *v);
+int op_volume_block_count(op_volume *v, size_t *n);
+int op_volume_has_cube(op_volume *v, int32_t x, int32_t y, int32_t z, int *present); /* :129-132 */
+/* Raw HIP stream handle of the volume (hipStream_t), for callers that time with HIP events. */
+int op_volume_stream(op_volume *v, void **stream);
+
+/* CubeHandler::ComputeBounding (CubeHandler.cpp:116-145). */
+int op_volume_compute_bounding(op_volume *v, const void *depth, int depth_fmt, int mem,
+                               const float pose[16], float max_pos[3], float min_pos[3],
+                               size_t *n_inside);
+/* CubeHandler::PrepareCubes (CubeHandler.cpp:147-196): selects + allocates blocks; ids_xyz gets the
+ * cube_id_list in the reference's i,j,k loop order (n x 3).  *n is the full list length even when
+ * it exceeds cap.  pose_inv may be NULL (then op_mat4_inverse(pose) is used). */
+int op_volume_prepare_cubes(op_volume *v, const void *depth, int depth_fmt, int mem,
+                            const float pose[16], const float *pose_inv, int32_t *ids_xyz,
+                            size_t cap, size_t *n, size_t *n_candidates);
+/* CubeHandler::IntegrateImage(depth, rgb, pose) (CubeHandler.cpp:197-210 -> Integrator.cpp:36-94).
+ * Asynchronous on the volume's stream. */
+int op_volume_integrate(op_volume *v, const void *depth, int depth_fmt, const uint8_t *rgb,
+                        int mem, const float pose[16], const float *pose_inv);
+/* Multi-frame form of the same call for frames already resident on the device: frame f uses
+ * depth + f*depth_stride_bytes, rgb + f*rgb_stride_bytes, poses + 16*f.  Results are identical to
+ * n_frames sequential op_volume_integrate calls (frames are applied in order). */
+int op_volume_integrate_sequence(op_volume *v, const void *depth, size_t depth_stride_bytes,
+                                 int depth_fmt, const uint8_t *rgb, size_t rgb_stride_bytes,
+                                 const float *poses, size_t n_frames);
+/* Counters since create/clear (synchronises): frames integrated, sum over frames of
+ * len(cube_id_list), of voxels visited (512 x len) and of voxels that passed the update predicate
+ * (Integrator.cpp:63,70,74). */
+int op_volume_stats(op_volume *v, uint64_t *frames, uint64_t *blocks_selected, uint64_t *voxels_visited,
+                    uint64_t *voxels_updated);
+
+/* Measurement hook (no reference counterpart): with sample_every = k > 0, every k-th integrated
+ * frame is bracketed by HIP events on the volume's stream.  profile_read synchronises and returns
+ * the summed durations in ms of the three kernels of a frame -- [0] ComputeBounding (K1),
+ * [1] PrepareCubes (K2), [2] Integrator::IntegrateImage (K3) -- over n_samples sampled frames. */
+int op_volume_profile_enable(op_volume *v, int sample_every);
+int op_volume_profile_read(op_volume *v, double ms_sum[3], uint64_t *n_samples);
+
+/* CubeHandler::GetCubeMap (CubeHandler.h:347-350): keys n x 3 int32; voxels n x 512 x 5 float in
+ * the reference's TSDFVoxel member order {sdf, weight, color[0..2]}, voxel index x + 8y + 64z. */
+int op_volume_download(op_volume *v, int32_t *keys_xyz, float *voxels_aos, size_t cap, size_t *n);
+/* CubeHandler::SetCubeMap / AddCube + assignment (CubeHandler.h:185-198,351-356). */
+int op_volume_upload(op_volume *v, const int32_t *keys_xyz, const float *voxels_aos, size_t n);
+/* CubeHandler::Merge(const CubeHandler&) (CubeHandler.h:145-167), both volumes on one device. */
+int op_volume_merge(op_volume *dst, op_volume *src);
+
+/* Frame-sharded multi-GPU merge (the distributed form of CubeHandler::Merge; DESIGN.md "Multi-GPU").
+ * All pointers are DEVICE pointers on the volume's device.
+ *   keys_device : copy this volume's block keys (n x 3 int32) into d_keys.
+ *   pack_sum    : for the n_union keys (any order) write sum-form voxels
+ *                 [w*sdf, w, w*c0, w*c1, w*c2] x 512 per block, SoA planes per block
+ *                 (5 x 512 floats), zeros where this volume has no block / w == 0.
+ *   unpack_sum  : replace the volume's content by the normalised reduction result. */
+int op_volume_keys_device(op_volume *v, int32_t *d_keys, size_t cap, size_t *n);
+int op_volume_pack_sum(op_volume *v, const int32_t *d_union_keys, size_t n_union, float *d_out);
+int op_volume_unpack_sum(op_volume *v, const int32_t *d_union_keys, size_t n_union,
+                         const float *d_sum);
+
+/* ---- registration (Registration/ICP.h:13-26, RegistrationResult.h:9-16) ------------------- */
+typedef struct {
+    float T[16];        /* RegistrationResult::T: Kabsch over the final inlier set (ICP.cpp:221) */
+    float last_T[16];   /* accumulated start_T after the last iteration (ICP.cpp:198) */
+    double rmse;        /* RegistrationResult::rmse (ICP.cpp:206) */
+    uint64_t n_inliers; /* correspondence_set_index.size() */
+    int32_t iterations;
+} op_icp_result;
+
+/* Builds the device search structure over the target cloud (replaces KDTree::BuildTree,
+ * ICP.cpp:172-173).  threshold = ICPParameter::threshold (max correspondence distance). */
+int op_icp_create(const float *tgt_xyz, const float *tgt_normals, size_t m, double threshold,
+                  int mem, int device, op_icp **out);
+int op_icp_destroy(op_icp *icp);
+int op_icp_set_source(op_icp *icp, const float *src_xyz, size_t n, int mem);
+/* One loop body of ICP.cpp:177-199 without the solve: transform by T, 1-NN, CountInliers and the
+ * normal-equation sums.  mode PLANE: sums[0..35] = JTJ (row-major 6x6), sums[36..41] = JTr.
+ * mode POINT: sums[0..2] = sum s', [3..5] = sum t, [6..14] = sum s' t^T (row-major), s' = T*s. */
+int op_icp_iterate(op_icp *icp, const float T[16], int mode, double sums[42], uint64_t *n_inliers,
+                   double *sum_sq_err);
+/* registration::PointToPlane / PointToPoint end to end (ICP.cpp:146-224 / :31-107).
+ * pairs (cap x 2 int32: source id, target id, ascending source id), per_iter_inliers (max_iter)
+ * and per_iter_T (max_iter x 16) may be NULL. */
+int op_icp_run(op_icp *icp, int mode, const float init_T[16], int max_iteration,
+               op_icp_result *result, int32_t *pairs, size_t pairs_cap, int32_t *per_iter_inliers,
+               float *per_iter_T);
+/* Convenience: create + set_source + run + destroy with host buffers. */
+int op_icp_register(int mode, const float *src_xyz, size_t n, const float *tgt_xyz,
+                    const float *tgt_normals, size_t m, const float init_T[16], int max_iteration,
+                    double threshold, int device, op_icp_result *result, int32_t *pairs,
+                    size_t pairs_cap);
+/* PointCloud::LoadFromDepth (Geometry/PointCloud.cpp:72-100) on the device: xyz_out (mem) gets the
+ * compacted row-major-ordered points; *n the count. */
+int op_points_from_depth(const op_camera *cam, const void *depth, int depth_fmt, int mem, int device,
+                         float *xyz_out, size_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONEPIECE_HIP_H */

@@ -1,0 +1,140 @@
+"""ctypes loader for libonepiece_hip.so (the C-ABI of include/onepiece_hip.h).
+
+The library is the product: there is no Python/CPU fallback.  `load()` raises if the shared
+object is missing (run `python -c "import __graft_entry__ as g; g.build()"` or `make -C
+onepiece_amd/csrc`), and every compute entry point of the library itself fails with
+OP_ERR_NO_DEVICE when no gfx950 GPU is usable.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libonepiece_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class OnePieceHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("onepiece_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Camera(C.Structure):
+    """op_camera == camera::PinholeCamera (Camera/Camera.h:13-131) as a POD."""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32), ("depth_scale", C.c_float)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("last_T", C.c_float * 16), ("rmse", C.c_double),
+                ("n_inliers", C.c_uint64), ("iterations", C.c_int32)]
+
+
+OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
+OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
+OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
+OP_ERR_NO_DEVICE, OP_ERR_CAPACITY, OP_ERR_MISMATCH, OP_ERR_NO_NORMALS = 2, 3, 4, 5
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+_szp = C.POINTER(C.c_size_t)
+_u64p = C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes); every symbol include/onepiece_hip.h declares
+SIGNATURES = {
+    "op_abi_version": (C.c_int, []),
+    "op_last_error": (C.c_char_p, []),
+    "op_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "op_camera_preset": (C.c_int, [C.c_int, C.POINTER(Camera)]),
+    "op_mat4_inverse": (C.c_int, [_fp, _fp]),
+    "op_hash_key": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32]),
+    "op_frustum_planes": (C.c_int, [C.POINTER(Camera), _fp, C.c_float, C.c_float, _fp]),
+    "op_se3_exp": (C.c_int, [_fp, _fp]),
+    "op_volume_create": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_int, C.c_uint64, C.POINTER(_vp)]),
+    "op_volume_destroy": (C.c_int, [_vp]),
+    "op_volume_set_resolution": (C.c_int, [_vp, C.c_float]),
+    "op_volume_set_truncation": (C.c_int, [_vp, C.c_float]),
+    "op_volume_set_camera": (C.c_int, [_vp, C.POINTER(Camera)]),
+    "op_volume_set_near_far": (C.c_int, [_vp, C.c_float, C.c_float]),
+    "op_volume_clear": (C.c_int, [_vp]),
+    "op_volume_sync": (C.c_int, [_vp]),
+    "op_volume_block_count": (C.c_int, [_vp, _szp]),
+    "op_volume_has_cube": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int)]),
+    "op_volume_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "op_volume_compute_bounding": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _fp, _fp, _fp, _szp]),
+    "op_volume_prepare_cubes": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _fp, _fp, _ip, C.c_size_t,
+                                          _szp, _szp]),
+    "op_volume_integrate": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _fp, _fp]),
+    "op_volume_integrate_sequence": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, _fp,
+                                               C.c_size_t]),
+    "op_volume_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
+    "op_volume_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "op_volume_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), _u64p]),
+    "op_volume_download": (C.c_int, [_vp, _ip, _fp, C.c_size_t, _szp]),
+    "op_volume_upload": (C.c_int, [_vp, _ip, _fp, C.c_size_t]),
+    "op_volume_merge": (C.c_int, [_vp, _vp]),
+    "op_volume_keys_device": (C.c_int, [_vp, _vp, C.c_size_t, _szp]),
+    "op_volume_pack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "op_volume_unpack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "op_icp_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "op_icp_destroy": (C.c_int, [_vp]),
+    "op_icp_set_source": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
+    "op_icp_iterate": (C.c_int, [_vp, _fp, C.c_int, C.POINTER(C.c_double), _u64p,
+                                 C.POINTER(C.c_double)]),
+    "op_icp_run": (C.c_int, [_vp, C.c_int, _fp, C.c_int, C.POINTER(IcpResult), _ip, C.c_size_t, _ip,
+                             _fp]),
+    "op_icp_register": (C.c_int, [C.c_int, _fp, C.c_size_t, _fp, _fp, C.c_size_t, _fp, C.c_int,
+                                  C.c_double, C.c_int, C.POINTER(IcpResult), _ip, C.c_size_t]),
+    "op_points_from_depth": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, C.c_int, C.c_int, _vp, _szp]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(_HERE, "..", "include", "onepiece_hip.h")]
+    if (not force and os.path.exists(SO_PATH)
+            and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return SO_PATH
+    subprocess.check_call(["make", "-C", CSRC, "-B"])
+    return SO_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise OnePieceHipError(-1, "libonepiece_hip.so is not built (%s); there is no fallback path. "
+                               "Run __graft_entry__.build() or `make -C onepiece_amd/csrc`." % SO_PATH)
+    try:
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64; if ours (from /opt/rocm)
+        # were loaded first, torch would later fail with "No HIP GPUs are available".  Importing
+        # torch first makes libonepiece_hip.so bind to the runtime torch uses, so device pointers
+        # and streams are shared.  (C/C++ callers without torch simply use /opt/rocm's runtime.)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OnePieceHipError(rc, load().op_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().op_device_count(C.byref(n)))
+    return n.value

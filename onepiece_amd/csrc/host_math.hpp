@@ -1,0 +1,266 @@
+// host_math.hpp -- host-side (CPU) geometry that sits on the hot path between kernels.
+//
+// These are the few scalar computations the reference performs once per frame / once per ICP
+// iteration with Eigen + Sophus on the host (pose inverse, frustum planes, 6x6 solve, SE3 exp,
+// Kabsch).  north_star keeps them on the host; they are written here without Eigen so that the
+// C-ABI library is self-contained, and in the operation order of the reference's Eigen 3.3.7 /
+// -msse4.2 build wherever bit-exactness matters (pose inverse and frustum planes feed block
+// selection, which must be bit-exact).  The translation unit is compiled with -ffp-contract=off.
+//
+// Reference citations are file:line under /root/reference/src (or 3rdparty/...).
+#pragma once
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace op_host {
+
+// ---- Eigen fixed-size evaluation orders (3rdparty/Eigen/Eigen/src/Core/Redux.h,
+//      ProductEvaluators.h:626-632): 3-term sums associate as a0 + (a1 + a2); a 4x4 * (x,y,z,1)
+//      product accumulates column by column.
+inline float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+inline float dot3(const float* a, const float* b) { return sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }
+
+// ---- 4x4 inverse: the SSE cofactor kernel of Eigen 3.3.7 (LU/arch/Inverse_SSE.h:35-165), written
+//      as explicit lane arithmetic.  Lane vectors are std::array-like PODs.
+struct V4 { float a, b, c, d; };
+inline V4 mul(V4 x, V4 y) { return {x.a * y.a, x.b * y.b, x.c * y.c, x.d * y.d}; }
+inline V4 add(V4 x, V4 y) { return {x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d}; }
+inline V4 sub(V4 x, V4 y) { return {x.a - y.a, x.b - y.b, x.c - y.c, x.d - y.d}; }
+inline V4 splat(float s) { return {s, s, s, s}; }
+
+inline void mat4_inverse(const float m[16], float out[16]) {
+    // 2x2 sub-blocks as the kernel holds them for a column-major source (Inverse_SSE.h:68-73):
+    // A = (m00,m10,m01,m11)  B = (m20,m30,m21,m31)  C = (m02,m12,m03,m13)  D = (m22,m32,m23,m33)
+    const V4 A{m[0], m[4], m[1], m[5]}, B{m[8], m[12], m[9], m[13]};
+    const V4 C{m[2], m[6], m[3], m[7]}, D{m[10], m[14], m[11], m[15]};
+    // AB = A# * B, DC = D# * C (:82-87)
+    V4 AB = sub(mul(V4{A.d, A.d, A.a, A.a}, B), mul(V4{A.b, A.b, A.c, A.c}, V4{B.c, B.d, B.a, B.b}));
+    V4 DC = sub(mul(V4{D.d, D.d, D.a, D.a}, C), mul(V4{D.b, D.b, D.c, D.c}, V4{C.c, C.d, C.a, C.b}));
+    // 2x2 determinants (:89-101): lane0 of (x.d*x.a) - (x.b*x.c)
+    const float dA = A.d * A.a - A.b * A.c, dB = B.d * B.a - B.b * B.c;
+    const float dC = C.d * C.a - C.b * C.c, dD = D.d * D.a - D.b * D.c;
+    // d = trace(AB*DC) (:103-104,113-115)
+    V4 d4 = mul(V4{DC.a, DC.c, DC.b, DC.d}, AB);
+    const float tr = (d4.a + d4.c) + (d4.b + d4.d);
+    // iD = C*A#*B, iA = B*D#*C (:106-111)
+    V4 iD = add(mul(V4{C.a, C.a, C.c, C.c}, V4{AB.a, AB.b, AB.a, AB.b}),
+                mul(V4{C.b, C.b, C.d, C.d}, V4{AB.c, AB.d, AB.c, AB.d}));
+    V4 iA = add(mul(V4{B.a, B.a, B.c, B.c}, V4{DC.a, DC.b, DC.a, DC.b}),
+                mul(V4{B.b, B.b, B.d, B.d}, V4{DC.c, DC.d, DC.c, DC.d}));
+    const float d1 = dA * dD, d2 = dB * dC; // (:116-117)
+    iD = sub(mul(D, splat(dA)), iD);        // (:119-120)
+    iA = sub(mul(A, splat(dD)), iA);        // (:122-123)
+    const float det = (d1 + d2) - tr;       // (:125-126)
+    const float rd = 1.0f / det;            // _mm_div_ss(1, det) (:127)
+    // iB = D*(A#B)#, iC = A*(D#C)# (:133-138)
+    V4 iB = sub(mul(D, V4{AB.d, AB.a, AB.d, AB.a}), mul(V4{D.b, D.a, D.d, D.c}, V4{AB.c, AB.b, AB.c, AB.b}));
+    V4 iC = sub(mul(A, V4{DC.d, DC.a, DC.d, DC.a}), mul(V4{A.b, A.a, A.d, A.c}, V4{DC.c, DC.b, DC.c, DC.b}));
+    const V4 rds{rd, -rd, -rd, rd};          // sign mask PNNP (:140-141)
+    iB = sub(mul(C, splat(dB)), iB);         // (:143-144)
+    iC = sub(mul(B, splat(dC)), iC);         // (:146-147)
+    iA = mul(rds, iA); iB = mul(rds, iB); iC = mul(rds, iC); iD = mul(rds, iD); // (:149-153)
+    // result columns (:155-160): col0 = (iA.d,iA.b,iB.d,iB.b) col1 = (iA.c,iA.a,iB.c,iB.a) etc.
+    const float c0[4] = {iA.d, iA.b, iB.d, iB.b}, c1[4] = {iA.c, iA.a, iB.c, iB.a};
+    const float c2[4] = {iC.d, iC.b, iD.d, iD.b}, c3[4] = {iC.c, iC.a, iD.c, iD.a};
+    for (int r = 0; r < 4; ++r) {
+        out[r * 4 + 0] = c0[r]; out[r * 4 + 1] = c1[r]; out[r * 4 + 2] = c2[r]; out[r * 4 + 3] = c3[r];
+    }
+}
+
+// ---- Frustum (Integration/Frustum.cpp:7-46; GetPlane Geometry/Geometry.cpp:165-171).
+inline void plane_from_points(const float* p1, const float* p2, const float* p3, float* plane) {
+    float e1[3], e2[3], n[3];
+    for (int i = 0; i < 3; ++i) { e1[i] = p2[i] - p1[i]; e2[i] = p3[i] - p1[i]; }
+    n[0] = e1[1] * e2[2] - e1[2] * e2[1];
+    n[1] = e1[2] * e2[0] - e1[0] * e2[2];
+    n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    const float len2 = sum3(n[0] * n[0], n[1] * n[1], n[2] * n[2]);
+    if (len2 > 0.0f) { const float len = std::sqrt(len2); n[0] /= len; n[1] /= len; n[2] /= len; }
+    const double d = -dot3(p1, n);
+    plane[0] = n[0]; plane[1] = n[1]; plane[2] = n[2]; plane[3] = static_cast<float>(d);
+}
+
+struct CameraPOD { float fx, fy, cx, cy; int32_t width, height; float depth_scale; };
+
+// planes: top, left, right, bottom, near, far -- the order Frustum::ContainPoint tests them in
+// (Integration/Frustum.h:74-103).
+inline void frustum_planes(const CameraPOD& cam, const float pose[16], float far_d, float near_d, float planes[24]) {
+    const float height = static_cast<float>(cam.height), width = static_cast<float>(cam.width);
+    const float right[3] = {pose[0], pose[4], pose[8]};
+    const float up[3] = {-pose[1], -pose[5], -pose[9]};
+    const float fwd[3] = {pose[2], pose[6], pose[10]};
+    const float pos[3] = {pose[3], pose[7], pose[11]};
+    const float aspect = (cam.fy * width) / (cam.fx * height);
+    // atan2 / tan: the reference calls the unqualified C functions on floats -> double versions.
+    const float fov = static_cast<float>(std::atan2(static_cast<double>(cam.cy), static_cast<double>(cam.fy)) +
+                                         std::atan2(static_cast<double>(height - cam.cy), static_cast<double>(cam.fy)));
+    const float tangent = static_cast<float>(std::tan(static_cast<double>(fov / 2)));
+    const float hf = tangent * far_d, wf = hf * aspect, hn = tangent * near_d, wn = hn * aspect;
+    float corner[8][3]; // ftl ftr fbl fbr ntl ntr nbl nbr
+    for (int i = 0; i < 3; ++i) {
+        const float fc = pos[i] + fwd[i] * far_d, nc = pos[i] + fwd[i] * near_d;
+        corner[0][i] = (fc + up[i] * hf) - right[i] * wf;
+        corner[1][i] = (fc + up[i] * hf) + right[i] * wf;
+        corner[2][i] = (fc - up[i] * hf) - right[i] * wf;
+        corner[3][i] = (fc - up[i] * hf) + right[i] * wf;
+        corner[4][i] = (nc + up[i] * hn) - right[i] * wn;
+        corner[5][i] = (nc + up[i] * hn) + right[i] * wn;
+        corner[6][i] = (nc - up[i] * hn) - right[i] * wn;
+        corner[7][i] = (nc - up[i] * hn) + right[i] * wn;
+    }
+    const float *ftl = corner[0], *ftr = corner[1], *fbl = corner[2], *fbr = corner[3];
+    const float *ntl = corner[4], *ntr = corner[5], *nbl = corner[6], *nbr = corner[7];
+    plane_from_points(ntl, ftl, ntr, planes + 0);  // top
+    plane_from_points(ftl, ntl, fbl, planes + 4);  // left
+    plane_from_points(ntr, ftr, nbr, planes + 8);  // right
+    plane_from_points(nbr, fbl, nbl, planes + 12); // bottom
+    plane_from_points(nbl, ntl, nbr, planes + 16); // near
+    plane_from_points(ftr, ftl, fbr, planes + 20); // far
+}
+
+// ---- SE3 exponential, Sophus convention x = (upsilon, omega) (3rdparty/Sophus/sophus/se3.hpp:468-489).
+inline void se3_exp(const float x[6], float T[16]) {
+    const double w[3] = {x[3], x[4], x[5]}, u[3] = {x[0], x[1], x[2]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    double a, b, c; // R = I + a W + b W^2, V = I + b W + c W^2
+    if (th < 1e-5) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0; }
+    else { a = std::sin(th) / th; b = (1.0 - std::cos(th)) / th2; c = (th - std::sin(th)) / (th2 * th); }
+    const double W[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+    double W2[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W2[i][j] = W[i][0] * W[0][j] + W[i][1] * W[1][j] + W[i][2] * W[2][j];
+    for (int i = 0; i < 3; ++i) {
+        double t = 0;
+        for (int j = 0; j < 3; ++j) {
+            const double I = i == j ? 1.0 : 0.0;
+            T[i * 4 + j] = static_cast<float>(I + a * W[i][j] + b * W2[i][j]);
+            t += (I + b * W[i][j] + c * W2[i][j]) * u[j];
+        }
+        T[i * 4 + 3] = static_cast<float>(t);
+    }
+    T[12] = T[13] = T[14] = 0.0f; T[15] = 1.0f;
+}
+
+// ---- symmetric eigen-decomposition (cyclic Jacobi), N <= 6, double.
+template <int N>
+inline void sym_eig(double A[N][N], double V[N][N]) {
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < N; ++i)
+            for (int j = i + 1; j < N; ++j) off += A[i][j] * A[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < N; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                const double apq = A[p][q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                const double cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+                for (int k = 0; k < N; ++k) {
+                    const double kp = A[k][p], kq = A[k][q];
+                    A[k][p] = cs * kp - sn * kq; A[k][q] = sn * kp + cs * kq;
+                }
+                for (int k = 0; k < N; ++k) {
+                    const double pk = A[p][k], qk = A[q][k];
+                    A[p][k] = cs * pk - sn * qk; A[q][k] = sn * pk + cs * qk;
+                }
+                for (int k = 0; k < N; ++k) {
+                    const double kp = V[k][p], kq = V[k][q];
+                    V[k][p] = cs * kp - sn * kq; V[k][q] = sn * kp + cs * kq;
+                }
+            }
+    }
+}
+
+// x = JacobiSVD(JTJ).solve(-JTr) (Registration/ICP.cpp:137-138): minimum-norm least squares with
+// Eigen's default rank threshold (singular values <= eps_float * 6 * max are dropped).
+inline void solve6_psd(const double JTJ[36], const double JTr[6], float x[6]) {
+    double A[6][6], V[6][6], y[6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (JTJ[i * 6 + j] + JTJ[j * 6 + i]);
+    sym_eig<6>(A, V);
+    double smax = 0;
+    for (int i = 0; i < 6; ++i) smax = std::fabs(A[i][i]) > smax ? std::fabs(A[i][i]) : smax;
+    const double thr = smax * 6.0 * static_cast<double>(FLT_EPSILON);
+    for (int k = 0; k < 6; ++k) {
+        double s = 0;
+        for (int i = 0; i < 6; ++i) s += V[i][k] * (-JTr[i]);
+        y[k] = std::fabs(A[k][k]) > thr ? s / A[k][k] : 0.0;
+    }
+    for (int i = 0; i < 6; ++i) {
+        double s = 0;
+        for (int k = 0; k < 6; ++k) s += V[i][k] * y[k];
+        x[i] = static_cast<float>(s);
+    }
+}
+
+// Kabsch from sufficient statistics (Geometry/Geometry.cpp:107-151): n, sum s, sum t, sum s t^T.
+// W = sum (s - ms)(t - mt)^T = sum s t^T - n ms mt^T.  R = V U^T (det-fixed), t = mt - R ms.
+inline void kabsch_from_sums(double n, const double ss[3], const double st[3], const double sst[9], float T[16]) {
+    double ms[3], mt[3], W[3][3];
+    for (int i = 0; i < 3; ++i) { ms[i] = ss[i] / n; mt[i] = st[i] / n; }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W[i][j] = sst[i * 3 + j] - n * ms[i] * mt[j];
+    double A[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = W[0][i] * W[0][j] + W[1][i] * W[1][j] + W[2][i] * W[2][j];
+    sym_eig<3>(A, V);
+    int ord[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (A[ord[j]][ord[j]] > A[ord[i]][ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double Vs[3][3], S[3], U[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const double ev = A[ord[k]][ord[k]];
+        S[k] = std::sqrt(ev > 0 ? ev : 0);
+        for (int i = 0; i < 3; ++i) Vs[i][k] = V[i][ord[k]];
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 3; ++i) {
+            const double s = W[i][0] * Vs[0][k] + W[i][1] * Vs[1][k] + W[i][2] * Vs[2][k];
+            U[i][k] = S[k] > 1e-300 ? s / S[k] : 0.0;
+        }
+    if (S[2] <= 1e-12 * (S[0] > 0 ? S[0] : 1.0)) { // rank-deficient: complete U by a cross product
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+    double R[3][3];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[i][j] = Vs[i][0] * U[j][0] + Vs[i][1] * U[j][1] + Vs[i][2] * U[j][2];
+        const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) -
+                           R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                           R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+        if (det >= 0) break;
+        for (int i = 0; i < 3; ++i) Vs[i][2] = -Vs[i][2]; // Geometry.cpp:139-144
+    }
+    std::memset(T, 0, 16 * sizeof(float));
+    for (int i = 0; i < 3; ++i) {
+        double s = 0;
+        for (int j = 0; j < 3; ++j) { T[i * 4 + j] = static_cast<float>(R[i][j]); s += R[i][j] * ms[j]; }
+        T[i * 4 + 3] = static_cast<float>(mt[i] - s);
+    }
+    T[15] = 1.0f;
+}
+
+// Matrix4f * Matrix4f (start_T = tmp_T * start_T, ICP.cpp:198), column-accumulating product.
+inline void mat4_mul(const float* A, const float* B, float* C) {
+    float out[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            out[r * 4 + c] = ((A[r * 4] * B[c] + A[r * 4 + 1] * B[4 + c]) + A[r * 4 + 2] * B[8 + c]) + A[r * 4 + 3] * B[12 + c];
+    std::memcpy(C, out, sizeof(out));
+}
+
+inline uint64_t hash_key(int32_t x, int32_t y, int32_t z) { // Geometry/Geometry.h:101-112
+    return (static_cast<uint64_t>(static_cast<int64_t>(x)) * 73856093ULL) ^
+           (static_cast<uint64_t>(static_cast<int64_t>(y)) * 19349663ULL) ^
+           (static_cast<uint64_t>(static_cast<int64_t>(z)) * 83492791ULL);
+}
+
+} // namespace op_host

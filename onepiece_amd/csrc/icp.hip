@@ -1,0 +1,626 @@
+// icp.hip -- point-to-plane / point-to-point ICP for gfx950 (MI355X) and the C-ABI entry points
+// op_icp_* / op_points_from_depth declared in include/onepiece_hip.h.
+//
+// What it replaces (file:line under /root/reference/src):
+//   registration::PointToPlane                       Registration/ICP.cpp:146-224
+//   registration::PointToPoint                       Registration/ICP.cpp:31-107
+//   geometry::TransformPoints + KDTree 1-NN          Registration/ICP.cpp:182-192, Geometry/KDTree.h:167-196
+//   CountInliers                                     Registration/ICP.cpp:9-30
+//   EstimateRigidTransformationPointToPlane (sums)   Registration/ICP.cpp:121-136
+//   geometry::EstimateRigidTransformation (sums)     Geometry/Geometry.cpp:122-133
+//   PointCloud::LoadFromDepth                        Geometry/PointCloud.cpp:72-100
+//
+// Design (DESIGN.md "ICP"): the reference's exact 1-NN is only ever consumed through
+// CountInliers, which discards correspondences farther than `threshold`; a uniform grid over the
+// target with cell >= threshold and a 27-cell scan therefore yields the identical inlier set.  The
+// target is counting-sorted by cell into float4 records (xyz + original index) so candidate reads
+// are contiguous 16-byte loads.  One kernel per iteration fuses transform + NN + inlier test + the
+// normal-equation contributions; the 27 (plane) / 15 (point) sums are reduced in fp64 with
+// wave64 shuffles, then LDS across the 4 waves of a workgroup, then one tiny second-pass kernel.
+// The 6x6 solve / SE3 exp / Kabsch stay on the host (host_math.hpp) exactly as north_star asks;
+// this accumulation is 2*27*N flops -- not a dense contraction, so no MFMA.
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "host_math.hpp"
+
+namespace {
+
+using op::fail;
+
+constexpr int kNSums = 32;      // doubles per partial: sums[0..26], [27] = sum_sq_err, [28] = inlier count
+constexpr int kIterThreads = 256;
+constexpr unsigned long long kMaxCells = 1ull << 26;
+
+struct Grid {
+    float ox, oy, oz, inv_cell; // origin and 1/cell
+    int gx, gy, gz;
+};
+
+struct Mat4 { float m[16]; };
+
+__device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+
+__device__ __forceinline__ unsigned enc_f(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float dec_f(unsigned e) {
+    const unsigned b = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int cell_coord(float p, float o, float inv, int g) {
+    int c = (int)floorf((p - o) * inv);
+    return c < 0 ? 0 : (c >= g ? g - 1 : c);
+}
+
+// ---- target grid build ----------------------------------------------------------------------
+__global__ void k_bbox(const float* __restrict__ xyz, size_t m, unsigned* __restrict__ box /*max3,min3*/) {
+    float mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}, mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x)
+        for (int c = 0; c < 3; ++c) {
+            const float v = xyz[3 * i + c];
+            if (v == v) { mx[c] = fmaxf(mx[c], v); mn[c] = fminf(mn[c], v); }
+        }
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&box[c], enc_f(mx[c]));
+            atomicMin(&box[3 + c], enc_f(mn[c]));
+        }
+    }
+}
+
+__global__ void k_cell_count(const float* __restrict__ xyz, size_t m, Grid g, unsigned* __restrict__ count) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!(x == x && y == y && z == z)) return;
+    const int cx = cell_coord(x, g.ox, g.inv_cell, g.gx), cy = cell_coord(y, g.oy, g.inv_cell, g.gy),
+              cz = cell_coord(z, g.oz, g.inv_cell, g.gz);
+    atomicAdd(&count[((size_t)cz * g.gy + cy) * g.gx + cx], 1u);
+}
+
+// Exclusive scan of the cell counts in cell order, so that x-adjacent cells own adjacent ranges of
+// the sorted target (the 27-cell scan then touches 9 contiguous runs).  Three small kernels:
+// per-workgroup totals -> scan of totals (one workgroup) -> per-element offsets.
+constexpr int kScanWg = 1024; // elements per workgroup (256 threads x 4)
+__global__ __launch_bounds__(256) void k_scan_totals(const unsigned* __restrict__ count, size_t n, unsigned* __restrict__ totals) {
+    __shared__ unsigned s[4];
+    const size_t base = (size_t)blockIdx.x * kScanWg + threadIdx.x * 4;
+    unsigned t = 0;
+    for (int k = 0; k < 4; ++k) t += base + k < n ? count[base + k] : 0u;
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) totals[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_of_totals(unsigned* __restrict__ totals, size_t n) {
+    // single workgroup, sequential over tiles of 1024
+    __shared__ unsigned s[1024];
+    __shared__ unsigned carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < n; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const unsigned v = i < n ? totals[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+            const unsigned add = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n) totals[i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const unsigned* __restrict__ count, size_t n, const unsigned* __restrict__ totals,
+                                                    unsigned* __restrict__ start) {
+    __shared__ unsigned s[4];
+    const size_t base = (size_t)blockIdx.x * kScanWg + threadIdx.x * 4;
+    unsigned c[4], t = 0;
+    for (int k = 0; k < 4; ++k) { c[k] = base + k < n ? count[base + k] : 0u; t += c[k]; }
+    // exclusive scan of t across the workgroup
+    unsigned incl = t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s[wave] = incl;
+    __syncthreads();
+    unsigned off = totals[blockIdx.x] + incl - t;
+    for (int w = 0; w < wave; ++w) off += s[w];
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) start[base + k] = off;
+        off += c[k];
+    }
+}
+
+__global__ void k_cell_scatter(const float* __restrict__ xyz, const float* __restrict__ nrm, size_t m, Grid g,
+                               const unsigned* __restrict__ start, unsigned* __restrict__ fill, float4* __restrict__ sorted,
+                               float4* __restrict__ sorted_n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!(x == x && y == y && z == z)) return;
+    const int cx = cell_coord(x, g.ox, g.inv_cell, g.gx), cy = cell_coord(y, g.oy, g.inv_cell, g.gy),
+              cz = cell_coord(z, g.oz, g.inv_cell, g.gz);
+    const size_t c = ((size_t)cz * g.gy + cy) * g.gx + cx;
+    const unsigned pos = start[c] + atomicAdd(&fill[c], 1u);
+    sorted[pos] = make_float4(x, y, z, __int_as_float((int)i));
+    if (nrm) sorted_n[pos] = make_float4(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2], 0.0f);
+}
+
+// ---- per-iteration kernel ----------------------------------------------------------------------
+// MODE 1 (plane): sums[0..20] = upper triangle of JTJ (row-major), [21..26] = JTr.
+// MODE 0 (point): sums[0..2] = sum s', [3..5] = sum t, [6..14] = sum s' t^T.
+// MODE 2 (final): like MODE 0 but over the ORIGINAL source points and the stored nn[] (no search).
+template <int MODE>
+__global__ __launch_bounds__(kIterThreads) void k_icp_iter(Mat4 T, const float* __restrict__ src, size_t n, Grid g,
+                                                           const unsigned* __restrict__ cell_start, const unsigned* __restrict__ cell_count,
+                                                           const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
+                                                           const float* __restrict__ tgt_orig, double thr2, int* __restrict__ nn,
+                                                           int* __restrict__ inl, double* __restrict__ partials) {
+    __shared__ double s_red[kIterThreads / 64][kNSums];
+    double acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s0 = src[3 * i], s1 = src[3 * i + 1], s2 = src[3 * i + 2];
+        const float* M = T.m;
+        float tp0 = 0, tp1 = 0, tp2 = 0;
+        int best = -1;
+        float t0 = 0, t1 = 0, t2 = 0, n0 = 0, n1 = 0, n2 = 0;
+        if (MODE != 2) {
+            // TransformPoints (Geometry.cpp:19-27): 4x4 * (s,1), then divide by w
+            const float q0 = ((M[0] * s0 + M[1] * s1) + M[2] * s2) + M[3] * 1.0f;
+            const float q1 = ((M[4] * s0 + M[5] * s1) + M[6] * s2) + M[7] * 1.0f;
+            const float q2 = ((M[8] * s0 + M[9] * s1) + M[10] * s2) + M[11] * 1.0f;
+            const float q3 = ((M[12] * s0 + M[13] * s1) + M[14] * s2) + M[15] * 1.0f;
+            tp0 = q0 / q3; tp1 = q1 / q3; tp2 = q2 / q3;
+            // exact 1-NN restricted to the 27 cells around the query (see header comment)
+            float best_d = FLT_MAX;
+            int best_pos = -1;
+            if (tp0 == tp0 && tp1 == tp1 && tp2 == tp2) {
+                const int cx = (int)floorf((tp0 - g.ox) * g.inv_cell), cy = (int)floorf((tp1 - g.oy) * g.inv_cell),
+                          cz = (int)floorf((tp2 - g.oz) * g.inv_cell);
+                const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, g.gx - 1);
+                if (x_lo <= x_hi)
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        const int z = cz + dz;
+                        if (z < 0 || z >= g.gz) continue;
+                        for (int dy = -1; dy <= 1; ++dy) {
+                            const int y = cy + dy;
+                            if (y < 0 || y >= g.gy) continue;
+                            const size_t row = ((size_t)z * g.gy + y) * g.gx;
+                            // cells x_lo..x_hi own one contiguous run of the sorted target
+                            const unsigned beg = cell_start[row + x_lo];
+                            const unsigned end = cell_start[row + x_hi] + cell_count[row + x_hi];
+                            for (unsigned p = beg; p < end; ++p) {
+                                const float4 c = tgt[p];
+                                const float dx = tp0 - c.x, dyy = tp1 - c.y, dzz = tp2 - c.z;
+                                const float d = dx * dx + dyy * dyy + dzz * dzz;
+                                const int ci = __float_as_int(c.w);
+                                if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)p; }
+                            }
+                        }
+                    }
+            }
+            nn[i] = best;
+            if (best >= 0) {
+                const float4 c = tgt[best_pos];
+                t0 = c.x; t1 = c.y; t2 = c.z;
+                if (MODE == 1) { const float4 nv = tgt_n[best_pos]; n0 = nv.x; n1 = nv.y; n2 = nv.z; }
+            }
+        } else {
+            best = nn[i];
+            if (best >= 0) { t0 = tgt_orig[3 * best]; t1 = tgt_orig[3 * best + 1]; t2 = tgt_orig[3 * best + 2]; }
+        }
+        bool inlier = false;
+        if (best >= 0) {
+            // CountInliers (ICP.cpp:15-23): ||(R s + t) - target||^2 in float, compared in double
+            const float d0 = (sum3(M[0] * s0, M[1] * s1, M[2] * s2) + M[3]) - t0;
+            const float d1 = (sum3(M[4] * s0, M[5] * s1, M[6] * s2) + M[7]) - t1;
+            const float d2 = (sum3(M[8] * s0, M[9] * s1, M[10] * s2) + M[11]) - t2;
+            const double e = (double)sum3(d0 * d0, d1 * d1, d2 * d2);
+            if (e < thr2) {
+                inlier = true;
+                acc[27] += e;
+                acc[28] += 1.0;
+                if (MODE == 1) {
+                    // ICP.cpp:121-136: row = [n ; s' x n], r = n.s' - n.t
+                    const float r = sum3(n0 * tp0, n1 * tp1, n2 * tp2) - sum3(n0 * t0, n1 * t1, n2 * t2);
+                    const float row[6] = {n0, n1, n2, tp1 * n2 - tp2 * n1, tp2 * n0 - tp0 * n2, tp0 * n1 - tp1 * n0};
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = a; b < 6; ++b) acc[k++] += (double)(row[a] * row[b]);
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(r * row[a]);
+                } else {
+                    const float a0 = MODE == 0 ? tp0 : s0, a1 = MODE == 0 ? tp1 : s1, a2 = MODE == 0 ? tp2 : s2;
+                    acc[0] += a0; acc[1] += a1; acc[2] += a2;
+                    acc[3] += t0; acc[4] += t1; acc[5] += t2;
+                    acc[6] += (double)a0 * t0; acc[7] += (double)a0 * t1; acc[8] += (double)a0 * t2;
+                    acc[9] += (double)a1 * t0; acc[10] += (double)a1 * t1; acc[11] += (double)a1 * t2;
+                    acc[12] += (double)a2 * t0; acc[13] += (double)a2 * t1; acc[14] += (double)a2 * t2;
+                }
+            }
+        }
+        if (inl) inl[i] = inlier ? best : -1;
+    }
+    // wave64 shuffle reduction, then LDS across the workgroup's waves, one partial per workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 29; ++k) {
+        if (MODE != 1 && k >= 15 && k < 27) continue;
+        const double v = wave_sum_d(acc[k]);
+        if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        double v = 0;
+        if (!(MODE != 1 && threadIdx.x >= 15 && threadIdx.x < 27))
+            for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_final_reduce(const double* __restrict__ partials, int n_partials, double* __restrict__ out) {
+    __shared__ double s[8][kNSums];
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5; // 8 groups x 32 sums
+    double v = 0;
+    for (int p = grp; p < n_partials; p += 8) v += partials[(size_t)p * kNSums + k];
+    s[grp][k] = v;
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double t = 0;
+        for (int gI = 0; gI < 8; ++gI) t += s[gI][threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
+// ---- LoadFromDepth with order-preserving compaction --------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_count(const void* __restrict__ depth, int is_u16, float depth_scale, size_t npix,
+                                                     unsigned* __restrict__ count) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float z = is_u16 ? (float)((const unsigned short*)depth)[i] / depth_scale : ((const float*)depth)[i];
+    count[i] = z > 0 ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_depth_scatter(const void* __restrict__ depth, int is_u16, op_camera cam, size_t npix,
+                                                       const unsigned* __restrict__ start, float* __restrict__ xyz) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float z = is_u16 ? (float)((const unsigned short*)depth)[i] / cam.depth_scale : ((const float*)depth)[i];
+    if (!(z > 0)) return;
+    const int r = (int)(i / cam.width), c = (int)(i - (size_t)r * cam.width);
+    const unsigned p = start[i];
+    xyz[3 * p] = ((float)c - cam.cx) * z / cam.fx; // PointCloud.cpp:90-93
+    xyz[3 * p + 1] = ((float)r - cam.cy) * z / cam.fy;
+    xyz[3 * p + 2] = z;
+}
+
+int device_exclusive_scan(const unsigned* d_count, size_t n, unsigned* d_start, hipStream_t stream, unsigned* total_out) {
+    const size_t nwg = (n + kScanWg - 1) / kScanWg;
+    unsigned* d_tot = nullptr;
+    OP_HIP(hipMalloc((void**)&d_tot, (nwg + 1) * sizeof(unsigned)));
+    hipLaunchKernelGGL(k_scan_totals, dim3((unsigned)nwg), dim3(256), 0, stream, d_count, n, d_tot);
+    hipLaunchKernelGGL(k_scan_of_totals, dim3(1), dim3(1024), 0, stream, d_tot, nwg);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nwg), dim3(256), 0, stream, d_count, n, (const unsigned*)d_tot, d_start);
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e == hipSuccess && total_out) {
+        unsigned last_start = 0, last_count = 0;
+        e = hipMemcpy(&last_start, d_start + (n - 1), 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&last_count, d_count + (n - 1), 4, hipMemcpyDeviceToHost);
+        *total_out = last_start + last_count;
+    }
+    (void)hipFree(d_tot);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "scan failed: %s", hipGetErrorString(e));
+    return OP_OK;
+}
+
+} // namespace
+
+struct op_icp {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t m = 0, n = 0;
+    double threshold = 0;
+    bool has_normals = false;
+    Grid grid{};
+    size_t ncell = 0;
+    float* tgt_orig = nullptr; // m x 3 (original order)
+    float4* tgt = nullptr;     // sorted by cell
+    float4* tgt_n = nullptr;
+    unsigned *cell_start = nullptr, *cell_count = nullptr;
+    float* src = nullptr;
+    size_t src_cap = 0;
+    int *nn = nullptr, *inl = nullptr;
+    double *partials = nullptr, *result = nullptr;
+    int n_wg = 0;
+};
+
+namespace {
+
+template <int MODE>
+void launch_iter(op_icp* c, const float T[16], bool write_inl) {
+    Mat4 M;
+    std::memcpy(M.m, T, sizeof(M.m));
+    hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, M, (const float*)c->src, c->n, c->grid,
+                       (const unsigned*)c->cell_start, (const unsigned*)c->cell_count, (const float4*)c->tgt, (const float4*)c->tgt_n,
+                       (const float*)c->tgt_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials);
+    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(256), 0, c->stream, (const double*)c->partials, c->n_wg, c->result);
+}
+
+// runs one fused pass and fetches the 32 reduced doubles
+int run_pass(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]) {
+    if (mode == 1) launch_iter<1>(c, T, write_inl);
+    else if (mode == 0) launch_iter<0>(c, T, write_inl);
+    else launch_iter<2>(c, T, write_inl);
+    OP_HIP(hipGetLastError());
+    OP_HIP(hipMemcpyAsync(out, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OP_HIP(hipStreamSynchronize(c->stream));
+    return OP_OK;
+}
+
+void expand_plane_sums(const double in[kNSums], double JTJ[36], double JTr[6]) {
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) { JTJ[a * 6 + b] = in[k]; JTJ[b * 6 + a] = in[k]; ++k; }
+    for (int a = 0; a < 6; ++a) JTr[a] = in[21 + a];
+}
+
+} // namespace
+
+extern "C" {
+
+int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, double threshold, int mem, int device, op_icp** out) {
+    if (!out) return fail(OP_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!tgt_xyz && m) return fail(OP_ERR_INVALID, "null target");
+    if (!(threshold > 0)) return fail(OP_ERR_INVALID, "threshold must be > 0");
+    if (m > (size_t)INT_MAX) return fail(OP_ERR_INVALID, "target too large");
+    OP_TRY(op::use_device(device));
+    op_icp* c = new op_icp();
+    c->device = device; c->m = m; c->threshold = threshold; c->has_normals = tgt_normals != nullptr;
+    auto bail = [&](int rc) { op_icp_destroy(c); return rc; };
+#define OP_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(OP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+    OP_HIP_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t m1 = m ? m : 1;
+    OP_HIP_C(hipMalloc((void**)&c->tgt_orig, m1 * 3 * sizeof(float)));
+    OP_HIP_C(hipMalloc((void**)&c->tgt, m1 * sizeof(float4)));
+    float* d_nrm = nullptr;
+    const hipMemcpyKind kind = mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (m) OP_HIP_C(hipMemcpy(c->tgt_orig, tgt_xyz, m * 3 * sizeof(float), kind));
+    if (c->has_normals) {
+        OP_HIP_C(hipMalloc((void**)&c->tgt_n, m1 * sizeof(float4)));
+        OP_HIP_C(hipMalloc((void**)&d_nrm, m1 * 3 * sizeof(float)));
+        if (m) OP_HIP_C(hipMemcpy(d_nrm, tgt_normals, m * 3 * sizeof(float), kind));
+    }
+    // bounding box -> grid
+    unsigned* d_box = nullptr;
+    OP_HIP_C(hipMalloc((void**)&d_box, 6 * sizeof(unsigned)));
+    unsigned init[6] = {0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    OP_HIP_C(hipMemcpy(d_box, init, sizeof(init), hipMemcpyHostToDevice));
+    if (m) hipLaunchKernelGGL(k_bbox, dim3(512), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, d_box);
+    OP_HIP_C(hipStreamSynchronize(c->stream));
+    unsigned box[6];
+    OP_HIP_C(hipMemcpy(box, d_box, sizeof(box), hipMemcpyDeviceToHost));
+    (void)hipFree(d_box);
+    float mx[3], mn[3];
+    for (int k = 0; k < 3; ++k) { mx[k] = dec_f(box[k]); mn[k] = dec_f(box[3 + k]); }
+    if (!m || !(mx[0] >= mn[0])) { for (int k = 0; k < 3; ++k) { mx[k] = 0; mn[k] = 0; } }
+    // cell >= threshold (slightly larger so that float rounding of the cell index cannot hide a
+    // neighbour closer than threshold); grow it if the grid would exceed kMaxCells
+    double cell = threshold * 1.001;
+    for (;;) {
+        unsigned long long tot = 1;
+        for (int k = 0; k < 3; ++k) tot *= (unsigned long long)std::floor((mx[k] - mn[k]) / cell) + 2ull;
+        if (tot <= kMaxCells) break;
+        cell *= 1.26;
+    }
+    c->grid.ox = mn[0]; c->grid.oy = mn[1]; c->grid.oz = mn[2];
+    c->grid.inv_cell = (float)(1.0 / cell);
+    c->grid.gx = (int)std::floor((mx[0] - mn[0]) / cell) + 2;
+    c->grid.gy = (int)std::floor((mx[1] - mn[1]) / cell) + 2;
+    c->grid.gz = (int)std::floor((mx[2] - mn[2]) / cell) + 2;
+    c->ncell = (size_t)c->grid.gx * c->grid.gy * c->grid.gz;
+    OP_HIP_C(hipMalloc((void**)&c->cell_start, c->ncell * sizeof(unsigned)));
+    OP_HIP_C(hipMalloc((void**)&c->cell_count, c->ncell * sizeof(unsigned)));
+    unsigned* d_fill = nullptr;
+    OP_HIP_C(hipMalloc((void**)&d_fill, c->ncell * sizeof(unsigned)));
+    OP_HIP_C(hipMemsetAsync(c->cell_count, 0, c->ncell * sizeof(unsigned), c->stream));
+    OP_HIP_C(hipMemsetAsync(d_fill, 0, c->ncell * sizeof(unsigned), c->stream));
+    if (m) hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, c->grid, c->cell_count);
+    int rc = device_exclusive_scan(c->cell_count, c->ncell, c->cell_start, c->stream, nullptr);
+    if (rc != OP_OK) { (void)hipFree(d_fill); if (d_nrm) (void)hipFree(d_nrm); return bail(rc); }
+    if (m) hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, (const float*)d_nrm, m,
+                              c->grid, (const unsigned*)c->cell_start, d_fill, c->tgt, c->tgt_n);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_fill);
+    if (d_nrm) (void)hipFree(d_nrm);
+    if (e != hipSuccess) return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e)));
+    OP_HIP_C(hipMalloc((void**)&c->result, kNSums * sizeof(double)));
+#undef OP_HIP_C
+    *out = c;
+    return OP_OK;
+}
+
+int op_icp_destroy(op_icp* c) {
+    if (!c) return OP_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->tgt_orig, c->tgt, c->tgt_n, c->cell_start, c->cell_count, c->src, c->nn, c->inl, c->partials, c->result};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return OP_OK;
+}
+
+int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
+    if (!c) return fail(OP_ERR_INVALID, "null icp");
+    OP_HIP(hipSetDevice(c->device));
+    if (!src_xyz && n) return fail(OP_ERR_INVALID, "null source");
+    if (n > c->src_cap) {
+        void* old[] = {c->src, c->nn, c->inl, c->partials};
+        for (void* p : old)
+            if (p) OP_HIP(hipFree(p));
+        c->src = nullptr; c->nn = nullptr; c->inl = nullptr; c->partials = nullptr;
+        OP_HIP(hipMalloc((void**)&c->src, n * 3 * sizeof(float)));
+        OP_HIP(hipMalloc((void**)&c->nn, n * sizeof(int)));
+        OP_HIP(hipMalloc((void**)&c->inl, n * sizeof(int)));
+        c->src_cap = n;
+    }
+    c->n = n;
+    if (n) OP_HIP(hipMemcpy(c->src, src_xyz, n * 3 * sizeof(float), mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    int wg = (int)((n + kIterThreads - 1) / kIterThreads);
+    if (wg > 2048) wg = 2048;
+    if (wg < 1) wg = 1;
+    if (!c->partials || wg != c->n_wg) {
+        if (c->partials) OP_HIP(hipFree(c->partials));
+        OP_HIP(hipMalloc((void**)&c->partials, (size_t)2048 * kNSums * sizeof(double)));
+    }
+    c->n_wg = wg;
+    return OP_OK;
+}
+
+int op_icp_iterate(op_icp* c, const float T[16], int mode, double sums[42], uint64_t* n_inliers, double* sum_sq_err) {
+    if (!c || !T || !sums) return fail(OP_ERR_INVALID, "null argument");
+    OP_HIP(hipSetDevice(c->device));
+    if (!c->src && c->n) return fail(OP_ERR_INVALID, "op_icp_set_source has not been called");
+    if (mode == OP_ICP_POINT_TO_PLANE && !c->has_normals)
+        return fail(OP_ERR_NO_NORMALS, "[ERROR]::[ICPPointToPlane]::target point cloud need to have normals.");
+    double r[kNSums];
+    OP_TRY(run_pass(c, mode == OP_ICP_POINT_TO_PLANE ? 1 : 0, T, false, r));
+    std::memset(sums, 0, 42 * sizeof(double));
+    if (mode == OP_ICP_POINT_TO_PLANE) expand_plane_sums(r, sums, sums + 36);
+    else std::memcpy(sums, r, 15 * sizeof(double));
+    if (n_inliers) *n_inliers = (uint64_t)(r[28] + 0.5);
+    if (sum_sq_err) *sum_sq_err = r[27];
+    return OP_OK;
+}
+
+int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap,
+               int32_t* per_iter_inliers, float* per_iter_T) {
+    if (!c || !init_T || !result) return fail(OP_ERR_INVALID, "null argument");
+    OP_HIP(hipSetDevice(c->device));
+    if (mode == OP_ICP_POINT_TO_PLANE && !c->has_normals) // ICP.cpp:159-163: error line + default result
+        return fail(OP_ERR_NO_NORMALS, "[ERROR]::[ICPPointToPlane]::target point cloud need to have normals.");
+    if (!c->src && c->n) return fail(OP_ERR_INVALID, "op_icp_set_source has not been called");
+    float start_T[16], tmp_T[16];
+    std::memcpy(start_T, init_T, sizeof(start_T));
+    double r[kNSums];
+    if (max_iteration <= 0 && c->n) OP_HIP(hipMemset(c->nn, 0xff, c->n * sizeof(int))); // corresponding_index stays -1
+    for (int it = 0; it < max_iteration; ++it) {
+        OP_TRY(run_pass(c, mode == OP_ICP_POINT_TO_PLANE ? 1 : 0, start_T, false, r));
+        if (mode == OP_ICP_POINT_TO_PLANE) {
+            double JTJ[36], JTr[6];
+            float x[6];
+            expand_plane_sums(r, JTJ, JTr);
+            op_host::solve6_psd(JTJ, JTr, x);      // ICP.cpp:137-138
+            op_host::se3_exp(x, tmp_T);            // ICP.cpp:143
+        } else {
+            op_host::kabsch_from_sums(r[28], r, r + 3, r + 6, tmp_T); // ICP.cpp:79
+        }
+        op_host::mat4_mul(tmp_T, start_T, start_T); // ICP.cpp:198
+        if (per_iter_inliers) per_iter_inliers[it] = (int32_t)(r[28] + 0.5);
+        if (per_iter_T) std::memcpy(per_iter_T + 16 * it, start_T, sizeof(start_T));
+    }
+    // ICP.cpp:206-221: CountInliers with the final start_T over the last NN set, then Kabsch over
+    // (original source, target) pairs
+    OP_TRY(run_pass(c, 2, start_T, true, r));
+    const double n_inl = r[28];
+    result->n_inliers = (uint64_t)(n_inl + 0.5);
+    result->rmse = std::sqrt(r[27] / n_inl);
+    result->iterations = max_iteration;
+    std::memcpy(result->last_T, start_T, sizeof(start_T));
+    op_host::kabsch_from_sums(n_inl, r, r + 3, r + 6, result->T);
+    if (pairs && c->n) {
+        std::vector<int> inl(c->n);
+        OP_HIP(hipMemcpy(inl.data(), c->inl, c->n * sizeof(int), hipMemcpyDeviceToHost));
+        size_t k = 0;
+        for (size_t i = 0; i < c->n && k < pairs_cap; ++i)
+            if (inl[i] >= 0) { pairs[2 * k] = (int32_t)i; pairs[2 * k + 1] = inl[i]; ++k; }
+    }
+    return OP_OK;
+}
+
+int op_icp_register(int mode, const float* src_xyz, size_t n, const float* tgt_xyz, const float* tgt_normals, size_t m, const float init_T[16],
+                    int max_iteration, double threshold, int device, op_icp_result* result, int32_t* pairs, size_t pairs_cap) {
+    if (mode == OP_ICP_POINT_TO_PLANE && !tgt_normals)
+        return fail(OP_ERR_NO_NORMALS, "[ERROR]::[ICPPointToPlane]::target point cloud need to have normals.");
+    op_icp* c = nullptr;
+    OP_TRY(op_icp_create(tgt_xyz, tgt_normals, m, threshold, OP_MEM_HOST, device, &c));
+    int rc = op_icp_set_source(c, src_xyz, n, OP_MEM_HOST);
+    if (rc == OP_OK) rc = op_icp_run(c, mode, init_T, max_iteration, result, pairs, pairs_cap, nullptr, nullptr);
+    op_icp_destroy(c);
+    return rc;
+}
+
+int op_points_from_depth(const op_camera* cam, const void* depth, int depth_fmt, int mem, int device, float* xyz_out, size_t* n) {
+    if (!cam || !depth || !xyz_out || !n) return fail(OP_ERR_INVALID, "null argument");
+    if (cam->width <= 0 || cam->height <= 0) return fail(OP_ERR_INVALID, "invalid camera");
+    OP_TRY(op::use_device(device));
+    const size_t npix = (size_t)cam->width * cam->height;
+    const size_t dbytes = npix * (depth_fmt == OP_DEPTH_U16 ? 2 : 4);
+    void* d_depth = nullptr;
+    unsigned *d_count = nullptr, *d_start = nullptr;
+    float* d_xyz = nullptr;
+    int rc = OP_OK;
+    hipError_t e = hipSuccess;
+    const void* dsrc = depth;
+    if (mem == OP_MEM_HOST) {
+        e = hipMalloc(&d_depth, dbytes);
+        if (e == hipSuccess) e = hipMemcpy(d_depth, depth, dbytes, hipMemcpyHostToDevice);
+        dsrc = d_depth;
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&d_count, npix * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_start, npix * 4);
+    if (e == hipSuccess && mem == OP_MEM_HOST) e = hipMalloc((void**)&d_xyz, npix * 12);
+    unsigned total = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_depth_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, nullptr, dsrc, depth_fmt == OP_DEPTH_U16,
+                           cam->depth_scale, npix, d_count);
+        rc = device_exclusive_scan(d_count, npix, d_start, nullptr, &total);
+        if (rc == OP_OK) {
+            float* dst = mem == OP_MEM_HOST ? d_xyz : xyz_out;
+            hipLaunchKernelGGL(k_depth_scatter, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, nullptr, dsrc, depth_fmt == OP_DEPTH_U16, *cam,
+                               npix, (const unsigned*)d_start, dst);
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess && mem == OP_MEM_HOST && total) e = hipMemcpy(xyz_out, d_xyz, (size_t)total * 12, hipMemcpyDeviceToHost);
+        }
+    }
+    if (d_depth) (void)hipFree(d_depth);
+    if (d_count) (void)hipFree(d_count);
+    if (d_start) (void)hipFree(d_start);
+    if (d_xyz) (void)hipFree(d_xyz);
+    if (rc != OP_OK) return rc;
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "points_from_depth failed: %s", hipGetErrorString(e));
+    *n = total;
+    return OP_OK;
+}
+
+} // extern "C"

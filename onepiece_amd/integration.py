@@ -1,0 +1,255 @@
+"""Host-side mirror of one_piece::integration::CubeHandler over the C-ABI (include/onepiece_hip.h).
+
+Same method names, argument meaning and error behaviour as the reference class
+(/root/reference/src/Integration/CubeHandler.h:24-366) for the hot path, so the parity tests read
+like the reference's own usage (example/ImageSequenceIntegration.cpp:27-42).  This module contains
+no arithmetic of its own: every method forwards to libonepiece_hip.so, which fails loudly when no
+GPU / no built library is present.
+
+Images are numpy arrays (host, copied by the call) or torch CUDA tensors (used in place).  Poses
+are 4x4 camera-to-world matrices (row-major numpy, i.e. `pose[r, c]` == Eigen `pose(r, c)`).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import Camera
+
+
+def PinholeCamera(camera_type="OPEN3D_DATASET"):
+    """camera::PinholeCamera presets (Camera/Camera.h:76-104); default ctor = OPEN3D_DATASET."""
+    cam = Camera()
+    L.check(L.load().op_camera_preset({"TUM_DATASET": 0, "OPEN3D_DATASET": 1}[camera_type], C.byref(cam)))
+    return cam
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _image_arg(img, kind):
+    """-> (pointer, fmt, mem, keepalive).  kind: 'depth' | 'rgb'."""
+    if hasattr(img, "data_ptr"):  # torch tensor
+        if not img.is_cuda or not img.is_contiguous():
+            raise ValueError("torch images must be contiguous CUDA tensors")
+        import torch
+        if kind == "depth":
+            if img.dtype == torch.float32:
+                fmt = L.OP_DEPTH_F32
+            elif img.dtype in (torch.uint16, torch.int16):
+                fmt = L.OP_DEPTH_U16
+            else:
+                raise ValueError("depth must be float32 (CV_32FC1) or uint16 (CV_16UC1)")
+        else:
+            if img.dtype != torch.uint8:
+                raise ValueError("rgb must be uint8 (CV_8UC3)")
+            fmt = 0
+        return C.c_void_p(img.data_ptr()), fmt, L.OP_MEM_DEVICE, img
+    a = np.ascontiguousarray(img)
+    if kind == "depth":
+        if a.dtype == np.uint16:
+            fmt = L.OP_DEPTH_U16
+        else:
+            a = _f32(a)
+            fmt = L.OP_DEPTH_F32
+    else:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        fmt = 0
+    return C.c_void_p(a.ctypes.data), fmt, L.OP_MEM_HOST, a
+
+
+class CubeHandler:
+    """integration::CubeHandler: the voxel-block-hashed TSDF volume, resident on one MI355X."""
+
+    def __init__(self, camera=None, device=0, max_blocks=0):
+        self._lib = L.load()
+        self.camera = camera if camera is not None else PinholeCamera()
+        self.device = device
+        self._h = C.c_void_p()
+        # defaults: VoxelResolution 0.01 (VoxelCube.h:27), truncation 0.1 (Integrator.h:23),
+        # far 5.0 / near 0.5 (CubeHandler.h:363-364)
+        self._res, self._trunc, self._far, self._near = 0.01, 0.1, 5.0, 0.5
+        L.check(self._lib.op_volume_create(C.byref(self.camera), self._res, self._trunc, self._far,
+                                           self._near, device, max_blocks, C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.op_volume_destroy(h)
+            self._h = None
+
+    # -- configuration (CubeHandler.h:36-39,137-144,339-346)
+    def SetVoxelResolution(self, resolution):
+        self._res = float(resolution)
+        L.check(self._lib.op_volume_set_resolution(self._h, self._res))
+
+    def SetTruncation(self, trunc):
+        self._trunc = float(trunc)
+        L.check(self._lib.op_volume_set_truncation(self._h, self._trunc))
+
+    def SetCamera(self, camera):
+        self.camera = camera
+        L.check(self._lib.op_volume_set_camera(self._h, C.byref(camera)))
+
+    def SetFarPlane(self, far):
+        self._far = float(far)
+        L.check(self._lib.op_volume_set_near_far(self._h, self._near, self._far))
+
+    def SetNearPlane(self, near):
+        self._near = float(near)
+        L.check(self._lib.op_volume_set_near_far(self._h, self._near, self._far))
+
+    def Clear(self):
+        L.check(self._lib.op_volume_clear(self._h))
+
+    # -- the hot path
+    def ComputeBounding(self, depth, pose):
+        """CubeHandler.cpp:116-145 -> (max_pos, min_pos, n_points_inside_frustum)."""
+        p, fmt, mem, _keep = _image_arg(depth, "depth")
+        pose = _f32(pose).reshape(16)
+        mx, mn, n = np.empty(3, np.float32), np.empty(3, np.float32), C.c_size_t(0)
+        L.check(self._lib.op_volume_compute_bounding(self._h, p, fmt, mem, _fp(pose), _fp(mx), _fp(mn), C.byref(n)))
+        return mx, mn, int(n.value)
+
+    def PrepareCubes(self, depth, pose, pose_inv=None, return_candidates=False):
+        """CubeHandler.cpp:147-196 -> cube_id_list (n x 3 int32, reference loop order)."""
+        p, fmt, mem, _keep = _image_arg(depth, "depth")
+        pose = _f32(pose).reshape(16)
+        pinv = _f32(pose_inv).reshape(16) if pose_inv is not None else None
+        cap = 1 << 16
+        while True:
+            ids = np.empty((cap, 3), np.int32)
+            n, nc = C.c_size_t(0), C.c_size_t(0)
+            L.check(self._lib.op_volume_prepare_cubes(self._h, p, fmt, mem, _fp(pose), _fp(pinv) if pinv is not None else None,
+                                                      _ip(ids), cap, C.byref(n), C.byref(nc)))
+            if n.value <= cap:
+                out = ids[:n.value].copy()
+                return (out, int(nc.value)) if return_candidates else out
+            cap = int(n.value)
+
+    def IntegrateImage(self, depth, rgb, pose, pose_inv=None):
+        """CubeHandler.cpp:197-210.  Asynchronous; any accessor below synchronises."""
+        pd, fmt, mem, _k1 = _image_arg(depth, "depth")
+        pr, _f, mem2, _k2 = _image_arg(rgb, "rgb")
+        if mem != mem2:
+            raise ValueError("depth and rgb must both be host arrays or both be device tensors")
+        pose = _f32(pose).reshape(16)
+        pinv = _f32(pose_inv).reshape(16) if pose_inv is not None else None
+        L.check(self._lib.op_volume_integrate(self._h, pd, fmt, pr, mem, _fp(pose), _fp(pinv) if pinv is not None else None))
+        if mem == L.OP_MEM_HOST:
+            # host buffers are borrowed for the call only (SURVEY 8b "Ownership")
+            self.Synchronize()
+
+    def IntegrateSequence(self, depth, rgb, poses):
+        """n frames resident on the device (torch tensors [n,h,w] / [n,h,w,3]); identical to n
+        IntegrateImage calls in order (example/ImageSequenceIntegration.cpp:27-42)."""
+        n = depth.shape[0]
+        pd, fmt, mem, _k1 = _image_arg(depth, "depth")
+        pr, _f, mem2, _k2 = _image_arg(rgb, "rgb")
+        if mem != L.OP_MEM_DEVICE or mem2 != L.OP_MEM_DEVICE:
+            raise ValueError("IntegrateSequence needs device-resident frames")
+        poses = _f32(poses).reshape(n, 16)
+        npx = self.camera.width * self.camera.height
+        dstride = npx * (2 if fmt == L.OP_DEPTH_U16 else 4)
+        L.check(self._lib.op_volume_integrate_sequence(self._h, pd, dstride, fmt, pr, npx * 3, _fp(poses), n))
+
+    def Synchronize(self):
+        L.check(self._lib.op_volume_sync(self._h))
+
+    def Stream(self):
+        s = C.c_void_p()
+        L.check(self._lib.op_volume_stream(self._h, C.byref(s)))
+        return s.value
+
+    def Stats(self):
+        f, b, vis, upd = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib.op_volume_stats(self._h, C.byref(f), C.byref(b), C.byref(vis), C.byref(upd)))
+        return {"frames": f.value, "blocks_selected": b.value, "voxels_visited": vis.value, "voxels_updated": upd.value}
+
+    def ProfileEnable(self, sample_every=1):
+        """HIP-event timing of K1/K2/K3 on the volume's own stream (measurement hook)."""
+        L.check(self._lib.op_volume_profile_enable(self._h, int(sample_every)))
+
+    def ProfileRead(self):
+        ms = (C.c_double * 3)()
+        n = C.c_uint64(0)
+        L.check(self._lib.op_volume_profile_read(self._h, ms, C.byref(n)))
+        n = int(n.value)
+        names = ("bounding_ms", "select_ms", "integrate_ms")
+        return {"samples": n, **{k: (ms[i] / n if n else float("nan")) for i, k in enumerate(names)}}
+
+    # -- accessors (all synchronise)
+    def BlockCount(self):
+        n = C.c_size_t(0)
+        L.check(self._lib.op_volume_block_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def HasCube(self, cube_id):
+        r = C.c_int(0)
+        L.check(self._lib.op_volume_has_cube(self._h, int(cube_id[0]), int(cube_id[1]), int(cube_id[2]), C.byref(r)))
+        return bool(r.value)
+
+    def GetCubeMap(self, sort=True):
+        """CubeHandler.h:347-350 -> (keys n x 3 int32, voxels n x 512 x 5 float32 {sdf,w,c0,c1,c2}).
+        The reference map's iteration order is unspecified; keys come back sorted (x, y, z)."""
+        n = self.BlockCount()
+        keys = np.empty((n, 3), np.int32)
+        vox = np.empty((n, 512, 5), np.float32)
+        got = C.c_size_t(0)
+        L.check(self._lib.op_volume_download(self._h, _ip(keys), _fp(vox), n, C.byref(got)))
+        if sort and n:
+            order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+            keys, vox = keys[order], vox[order]
+        return keys, vox
+
+    def SetCubeMap(self, keys, voxels):
+        """CubeHandler.h:351-356."""
+        self.Clear()
+        self.AddCubes(keys, voxels)
+
+    def AddCubes(self, keys, voxels):
+        keys = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)
+        voxels = _f32(voxels).reshape(-1, 512, 5)
+        L.check(self._lib.op_volume_upload(self._h, _ip(keys), _fp(voxels), keys.shape[0]))
+
+    def Merge(self, another):
+        """CubeHandler.h:145-167: mismatching resolution -> warning line, no change."""
+        rc = self._lib.op_volume_merge(self._h, another._h)
+        if rc == L.OP_ERR_MISMATCH:
+            print(self._lib.op_last_error().decode())
+            return
+        L.check(rc)
+
+    def GetCubeID(self, point):
+        """CubeHandler.h:185-189 / VoxelCube.h:63-74 (float floor, then floor-div by 8)."""
+        p = _f32(point)
+        pb = np.floor(p / np.float32(self._res)).astype(np.int64)
+        return (pb >> 3).astype(np.int32)
+
+
+def hash_key(x, y, z):
+    """geometry::VoxelGridHasher (Geometry/Geometry.h:101-112)."""
+    return int(L.load().op_hash_key(int(x), int(y), int(z)))
+
+
+def mat4_inverse(m):
+    m = _f32(m).reshape(16)
+    out = np.empty(16, np.float32)
+    L.check(L.load().op_mat4_inverse(_fp(m), _fp(out)))
+    return out.reshape(4, 4)
+
+
+def frustum_planes(camera, pose, far=5.0, near=0.5):
+    pose = _f32(pose).reshape(16)
+    out = np.empty(24, np.float32)
+    L.check(L.load().op_frustum_planes(C.byref(camera), _fp(pose), far, near, _fp(out)))
+    return out.reshape(6, 4)

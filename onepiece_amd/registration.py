@@ -1,0 +1,122 @@
+"""Host-side mirror of one_piece::registration (ICP) over the C-ABI (include/onepiece_hip.h).
+
+Same names, argument meaning and error behaviour as /root/reference/src/Registration/ICP.h:13-26
+and RegistrationResult.h:9-16.  No arithmetic happens here: the loop, the 6x6 solve and the Kabsch
+finish run inside libonepiece_hip.so (kernels in csrc/icp.hip, host solve in csrc/host_math.hpp).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class ICPParameter:
+    """registration::ICPParameter (ICP.h:13-19)."""
+
+    def __init__(self, max_iteration=30, threshold=0.2, scaling=1.0):
+        self.max_iteration = max_iteration
+        self.threshold = threshold
+        self.scaling = scaling
+
+
+class PointCloud:
+    """The part of geometry::PointCloud the ICP path reads: points, normals, HasNormals()."""
+
+    def __init__(self, points, normals=None):
+        self.points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+
+    def HasNormals(self):
+        return self.normals is not None and len(self.normals) == len(self.points) and len(self.points) > 0
+
+    @staticmethod
+    def LoadFromDepth(depth, camera, device=0):
+        """PointCloud::LoadFromDepth (Geometry/PointCloud.cpp:72-100), computed on the GPU."""
+        from .integration import _image_arg
+        p, fmt, mem, _keep = _image_arg(depth, "depth")
+        if mem != L.OP_MEM_HOST:
+            raise ValueError("LoadFromDepth mirror takes host images")
+        xyz = np.empty((camera.width * camera.height, 3), np.float32)
+        n = C.c_size_t(0)
+        L.check(L.load().op_points_from_depth(C.byref(camera), p, fmt, mem, device, C.c_void_p(xyz.ctypes.data), C.byref(n)))
+        return PointCloud(xyz[:n.value].copy())
+
+
+class RegistrationResult:
+    """registration::RegistrationResult (RegistrationResult.h:9-16)."""
+
+    def __init__(self):
+        self.T = np.zeros((4, 4), np.float32)  # uninitialised in the reference when ICP refuses to run
+        self.correspondence_set_index = np.zeros((0, 2), np.int32)
+        self.correspondence_set = np.zeros((0, 2, 3), np.float32)
+        self.rmse = float("nan")
+        # extras (not in the reference struct): accumulated start_T and per-iteration trace
+        self.last_T = None
+        self.per_iter_inliers = None
+        self.per_iter_T = None
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _run(mode, source, target, init_T, icp_para, device):
+    lib = L.load()
+    res = RegistrationResult()
+    # ICP.cpp:150-163: scaling != 1 or missing normals -> error line, default result
+    if mode == L.OP_ICP_POINT_TO_PLANE and (not target.HasNormals() or icp_para.scaling != 1):
+        print("[ERROR]::[ICPPointToPlane]::target point cloud need to have normals.")
+        return res
+    src = source.points
+    tgt = target.points
+    if icp_para.scaling != 1:  # ICP.cpp:37-43 (PointToPoint only)
+        src = (src * np.float32(icp_para.scaling)).astype(np.float32)
+        tgt = (tgt * np.float32(icp_para.scaling)).astype(np.float32)
+    T0 = np.ascontiguousarray(np.eye(4) if init_T is None else init_T, np.float32).reshape(16)
+    h = C.c_void_p()
+    nrm = target.normals if mode == L.OP_ICP_POINT_TO_PLANE else None
+    L.check(lib.op_icp_create(C.c_void_p(tgt.ctypes.data), C.c_void_p(nrm.ctypes.data) if nrm is not None else None,
+                              len(tgt), float(icp_para.threshold), L.OP_MEM_HOST, device, C.byref(h)))
+    try:
+        L.check(lib.op_icp_set_source(h, C.c_void_p(src.ctypes.data), len(src), L.OP_MEM_HOST))
+        out = L.IcpResult()
+        iters = max(int(icp_para.max_iteration), 0)
+        pairs = np.empty((max(len(src), 1), 2), np.int32)
+        per_n = np.zeros(max(iters, 1), np.int32)
+        per_T = np.zeros((max(iters, 1), 16), np.float32)
+        L.check(lib.op_icp_run(h, mode, _fp(T0), iters, C.byref(out), pairs.ctypes.data_as(C.POINTER(C.c_int32)),
+                               len(pairs), per_n.ctypes.data_as(C.POINTER(C.c_int32)), _fp(per_T)))
+    finally:
+        lib.op_icp_destroy(h)
+    n = int(out.n_inliers)
+    res.T = np.array(out.T, np.float32).reshape(4, 4)
+    if icp_para.scaling != 1:
+        # ICP.cpp:207-221 un-scales the clouds before the final Kabsch: same R, translation / scaling
+        res.T[:3, 3] = res.T[:3, 3] / np.float32(icp_para.scaling)
+    res.last_T = np.array(out.last_T, np.float32).reshape(4, 4)
+    res.rmse = float(out.rmse)
+    res.correspondence_set_index = pairs[:n].copy()
+    # ICP.cpp:215-219: pairs of (source point, target point) in the caller's (unscaled) units
+    res.correspondence_set = np.stack([source.points[pairs[:n, 0]], target.points[pairs[:n, 1]]], axis=1)
+    res.per_iter_inliers = per_n[:iters].copy()
+    res.per_iter_T = per_T[:iters].reshape(-1, 4, 4).copy()
+    return res
+
+
+def PointToPlane(source, target, init_T=None, icp_para=None, device=0):
+    """registration::PointToPlane (ICP.cpp:146-224)."""
+    return _run(L.OP_ICP_POINT_TO_PLANE, source, target, init_T, icp_para or ICPParameter(), device)
+
+
+def PointToPoint(source, target, init_T=None, icp_para=None, device=0):
+    """registration::PointToPoint (ICP.cpp:31-107)."""
+    return _run(L.OP_ICP_POINT_TO_POINT, source, target, init_T, icp_para or ICPParameter(), device)
+
+
+def Se3ToSE3(x):
+    """geometry::Se3ToSE3 (Geometry/Geometry.cpp:9-13)."""
+    x = np.ascontiguousarray(x, np.float32).reshape(6)
+    T = np.empty(16, np.float32)
+    L.check(L.load().op_se3_exp(_fp(x), _fp(T)))
+    return T.reshape(4, 4)
