@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X TSDF-fusion + ICP hot path.
+
+Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
+launched by torch.distributed.run, one rank per GPU over RCCL.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[2], "ImageSequenceIntegration"): every rank fuses K steps x F
+frames (default 10 x 100 = the 1000-frame sequence) of the synthetic 640x480 room sequence into
+its own 5 mm voxel-block-hashed TSDF volume, frames already resident in HBM, starting from an
+empty volume.  A "step" is one pass of the hot path (ComputeBounding -> PrepareCubes -> Integrate
+for each frame) over one batch of F frames.  For N > 1 frames are sharded contiguously (rank r
+fuses global frames [r*K*F, (r+1)*K*F)), there is no communication during fusion, and the timed
+region ends with the single RCCL reduce that merges the per-GPU block hashes (weak scaling).
+value = frames fused by all ranks / max-over-ranks wall time.
+
+Extra objects on the JSON line: roofline (integrate kernel, HIP-event timed on the volume's own
+stream, against 8 TB/s HBM), cpu_baseline (the CPU oracle = port of the reference path, timed on
+this box's host cores on a bounded sample of the same frames; N=1, rank 0 only), parity (the GPU
+volume for that sample compared bit-for-bit with the oracle's), icp (iterations/s at 307 200 points).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+W, H = 640, 480
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=100)
+    ap.add_argument("--voxel", type=float, default=0.005)
+    ap.add_argument("--cpu-sample-frames", type=int, default=40, help="frames of the workload the CPU baseline fuses (~0.25 s each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-icp", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=4, help="HIP-event sample rate for the roofline (every k-th frame)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch N>1 with torch.distributed.run" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from onepiece_amd import integration as I, synthetic as S, distributed as D
+
+    K, Wm, F = args.steps, args.warmup, args.frames_per_step
+    n_local = K * F
+    first = rank * n_local  # contiguous shard of the global sequence
+    # ---- inputs: generated straight into HBM, not timed
+    depth, rgb, poses = S.room_sequence_torch(first, n_local, dev)
+    torch.cuda.synchronize()
+
+    max_blocks = 1 << 19  # 5 GiB pool; the 1000-frame room needs ~1e5 blocks
+    hv = I.CubeHandler(device=local_rank, max_blocks=max_blocks)
+    hv.SetVoxelResolution(args.voxel)
+    ops = D.HipVolumeOps(hv, dev)
+
+    def barrier():
+        hv.Synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup: W untimed steps (+ one merge so RCCL is initialised), then start from empty
+    for w in range(Wm):
+        s = (w % K) * F
+        hv.IntegrateSequence(depth[s:s + F], rgb[s:s + F], poses[s:s + F])
+    hv.Synchronize()
+    if world > 1:
+        D.merge_volumes(ops, root=0)
+    hv.Clear()
+    hv.ProfileEnable(args.profile_every)
+
+    # ---- timed region: exactly K steps (+ the final merge for N > 1)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        s = k * F
+        hv.IntegrateSequence(depth[s:s + F], rgb[s:s + F], poses[s:s + F])
+    hv.Synchronize()
+    t_fuse = time.perf_counter() - t0
+    stats = hv.Stats()  # per-rank counters, read before the merge rewrites the root volume
+    n_union = None
+    if world > 1:
+        n_union = D.merge_volumes(ops, root=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = hv.ProfileRead()
+    hv.ProfileEnable(0)
+
+    tmax = torch.tensor([dt, t_fuse], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max, t_fuse_max = float(tmax[0]), float(tmax[1])
+    total_frames = n_local * world
+
+    out = None
+    if rank == 0:
+        n_upd_frame = stats["voxels_updated"] / max(stats["frames"], 1)
+        alg_bytes = 40.0 * n_upd_frame + 7.0 * W * H  # B_frame = 40*N_upd + 7*W*H
+        k3_s = prof["integrate_ms"] * 1e-3
+        achieved = alg_bytes / k3_s / 1e9 if k3_s > 0 else float("nan")
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_integrate.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "RGB-D frames/sec fused (640x480, 5 mm voxel TSDF)",
+            "value": total_frames / dt_max,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": dt_max / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ImageSequenceIntegration: %d-frame synthetic 640x480 room sequence per GPU, %.4g m voxel, "
+                                   "trunc 0.1 m, frames resident in HBM" % (n_local, args.voxel),
+                       "frames_per_step": F, "frames_per_gpu": n_local, "sharding": "contiguous frames per GPU, one RCCL reduce at end",
+                       "voxel_m": args.voxel},
+            "fusion_only_frames_per_s": total_frames / t_fuse_max,
+            "merge_union_blocks": n_union,
+            "per_frame": {"blocks_selected": stats["blocks_selected"] / max(stats["frames"], 1),
+                          "voxels_visited": stats["voxels_visited"] / max(stats["frames"], 1),
+                          "voxels_updated": n_upd_frame, "final_blocks_rank0": hv.BlockCount()},
+            "kernels_ms": {"bounding": prof["bounding_ms"], "select": prof["select_ms"], "integrate": prof["integrate_ms"],
+                           "event_samples": prof["samples"]},
+            "roofline": {"kernel": "k_integrate (Integrator::IntegrateImage)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prof["integrate_ms"], "traffic": traffic},
+        }
+
+    # ---- CPU baseline + parity on a bounded sample of the SAME frames (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        ns = min(args.cpu_sample_frames, n_local)
+        dn, cn = depth[:ns].cpu().numpy(), rgb[:ns].cpu().numpy()
+        ov = O.Volume(voxel_res=args.voxel)
+        t = time.perf_counter()
+        for i in range(ns):
+            ov.integrate(dn[i], cn[i], poses[i])
+        cpu_dt = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": ns / cpu_dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "first %d frames of the same sequence fused by oracle/onepiece_oracle.c "
+                                         "(the reference's integrate path is serial), host has %d cores" % (ns, os.cpu_count())}
+        # parity at the benchmark's own sizes: same sample through the HIP path, compared bit for bit
+        hv2 = I.CubeHandler(device=local_rank, max_blocks=1 << 17)
+        hv2.SetVoxelResolution(args.voxel)
+        hv2.IntegrateSequence(depth[:ns], rgb[:ns], poses[:ns])
+        hk, hvx = hv2.GetCubeMap()
+        ok, ovx = ov.export()
+        keys_equal = hk.shape == ok.shape and bool(np.array_equal(hk, ok))
+        out["parity"] = {"sample_frames": ns, "blocks": int(len(ok)), "keys_equal": keys_equal,
+                         "voxels_bit_equal": bool(keys_equal and np.array_equal(hvx.view(np.uint32), ovx.view(np.uint32)))}
+        del hv2
+
+    # ---- ICP iterations/s (second half of BASELINE.json's metric; configs[1]); replicas only, rank 0 reports
+    if rank == 0 and not args.no_icp:
+        from onepiece_amd import registration as R
+        import ctypes as C
+        from onepiece_amd import _lib as L
+        lib = L.load()
+        cam = hv.camera
+        d0, d1 = depth[0].cpu().numpy(), depth[1].cpu().numpy()
+        tgt = R.PointCloud.LoadFromDepth(d0, cam, device=local_rank).points
+        src = R.PointCloud.LoadFromDepth(d1, cam, device=local_rank).points
+        nrm = S.image_normals(d0, cam.fx, cam.fy, cam.cx, cam.cy)
+        h = C.c_void_p()
+        L.check(lib.op_icp_create(C.c_void_p(tgt.ctypes.data), C.c_void_p(nrm.ctypes.data), len(tgt), 0.01, L.OP_MEM_HOST, local_rank, C.byref(h)))
+        L.check(lib.op_icp_set_source(h, C.c_void_p(src.ctypes.data), len(src), L.OP_MEM_HOST))
+        res = L.IcpResult()
+        T0 = np.eye(4, dtype=np.float32).reshape(16)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        L.check(lib.op_icp_run(h, 1, fp(T0), 5, C.byref(res), None, 0, None, None))  # warm
+        iters = 60
+        t = time.perf_counter()
+        L.check(lib.op_icp_run(h, 1, fp(T0), iters, C.byref(res), None, 0, None, None))
+        gpu_it_s = iters / (time.perf_counter() - t)
+        lib.op_icp_destroy(h)
+        out["icp"] = {"iters_per_s": gpu_it_s, "points": int(len(src)), "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31)",
+                      "final_inliers": int(res.n_inliers)}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            t = time.perf_counter()
+            ref = O.icp(src, tgt, nrm, None, 10, 0.01, True)
+            cpu_it_s = 10 / (time.perf_counter() - t)
+            out["cpu_baseline"]["icp_iters_per_s"] = cpu_it_s
+            out["cpu_baseline"]["icp_threads"] = os.cpu_count()
+            g = np.array(res.T, np.float32).reshape(4, 4)
+            out["icp"]["note"] = "cpu oracle (kd-tree NN, OpenMP over %d threads) timed on the same clouds" % os.cpu_count()
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

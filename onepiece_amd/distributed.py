@@ -1,0 +1,100 @@
+"""Frame-sharded multi-GPU fusion: shard frames across ranks, fuse locally with zero communication,
+merge the per-GPU voxel-block hashes once at the end with a single RCCL reduce.
+
+This is the distributed form of CubeHandler::Merge (/root/reference/src/Integration/CubeHandler.h:
+145-167): key union + per-voxel weighted mean.  The reference has no communication layer; the
+exchange below is designed for xGMI:
+
+  1. all_gather the per-rank block counts and (padded) int32x3 key arrays    -- 12 B / block
+  2. every rank builds the same sorted union of keys (deterministic, no communication)
+  3. each rank packs its blocks into union order in SUM form [w*sdf, w, w*c0, w*c1, w*c2]
+     (HIP kernel k_pack_sum; zeros where the rank has no data)               -- 10 KiB / block
+  4. ONE reduce(SUM, fp32) to the root over RCCL                              -- the only bulk transfer
+  5. the root normalises back to mean form (HIP kernel k_unpack_sum).
+
+With 2 ranks step 3-5 evaluate exactly TSDFVoxel::operator+ ((w1*s1 + w2*s2)/(w1+w2)); with more
+ranks the summation order differs from a sequential Merge chain only in fp32 rounding (weights and
+keys stay exact).  ICP does not shard (one pose chain): replicas only.
+
+The collective logic is backend-neutral: `ops` supplies the three device steps.  HipVolumeOps is
+the product implementation (C-ABI kernels); tests drive the same merge_volumes() over gloo with a
+CPU stand-in to cover the world_size > 1 control flow without GPUs.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous frame chunk of `rank` (keeps each GPU's volume spatially compact)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HipVolumeOps:
+    """Device steps of the merge for an integration.CubeHandler (torch tensors on its GPU)."""
+
+    def __init__(self, handler, device):
+        self.h = handler
+        self.device = device
+
+    def keys(self):
+        import torch
+        n = self.h.BlockCount()
+        t = torch.empty((max(n, 1), 3), dtype=torch.int32, device=self.device)
+        got = C.c_size_t(0)
+        L.check(L.load().op_volume_keys_device(self.h._h, C.c_void_p(t.data_ptr()), n, C.byref(got)))
+        return t[:n]
+
+    def pack_sum(self, union_keys):
+        import torch
+        n = union_keys.shape[0]
+        out = torch.empty((max(n, 1), 5, 512), dtype=torch.float32, device=self.device)
+        L.check(L.load().op_volume_pack_sum(self.h._h, C.c_void_p(union_keys.data_ptr()), n, C.c_void_p(out.data_ptr())))
+        return out[:n]
+
+    def unpack_sum(self, union_keys, summed):
+        n = union_keys.shape[0]
+        L.check(L.load().op_volume_unpack_sum(self.h._h, C.c_void_p(union_keys.data_ptr()), n, C.c_void_p(summed.data_ptr())))
+
+
+def merge_volumes(ops, root=0, group=None):
+    """Merge every rank's volume into `root`'s.  Returns the number of union blocks.
+
+    Works with world_size == 1 (no-op apart from the pack/normalise round trip being skipped).
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(ops.keys().shape[0])
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    keys = ops.keys().contiguous()
+    dev = keys.device
+    # 1. counts, then padded keys
+    cnt = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    counts = [int(c.item()) for c in cnts]
+    mx = max(max(counts), 1)
+    padded = torch.zeros((mx, 3), dtype=torch.int32, device=dev)
+    padded[:keys.shape[0]] = keys
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded, group=group)
+    allk = torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
+    # 2. identical sorted union on every rank
+    union = torch.unique(allk, dim=0).contiguous() if allk.shape[0] else allk
+    n_union = int(union.shape[0])
+    if n_union == 0:
+        return 0
+    # 3.-4. sum-form pack, one reduce to the root
+    packed = ops.pack_sum(union).contiguous()
+    dist.reduce(packed, dst=root, op=dist.ReduceOp.SUM, group=group)
+    # 5. normalise on the root
+    if rank == root:
+        ops.unpack_sum(union, packed)
+    return n_union

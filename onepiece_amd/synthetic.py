@@ -144,3 +144,20 @@ def room_sequence_torch(first, count, device):
         d, c, p = room_frame(first + k, xp=torch, device=device)
         depth[k], rgb[k], poses[k] = d, c, p
     return depth, rgb, poses
+
+
+def image_normals(depth, fx=FX, fy=FY, cx=CX, cy=CY):
+    """Per-pixel normals from image-space cross products of the back-projected depth (an INPUT
+    generator for ICP tests/bench: any unit normals are valid input to PointToPlane).  Returns the
+    normals of the pixels with depth > 0 in row-major order, matching LoadFromDepth's compaction."""
+    h, w = depth.shape
+    u = np.arange(w, dtype=np.float32)[None, :]
+    v = np.arange(h, dtype=np.float32)[:, None]
+    P = np.stack([(u - np.float32(cx)) * depth / np.float32(fx), (v - np.float32(cy)) * depth / np.float32(fy), depth], axis=-1)
+    du = np.zeros_like(P)
+    dv = np.zeros_like(P)
+    du[:, 1:-1] = P[:, 2:] - P[:, :-2]; du[:, 0] = P[:, 1] - P[:, 0]; du[:, -1] = P[:, -1] - P[:, -2]
+    dv[1:-1] = P[2:] - P[:-2]; dv[0] = P[1] - P[0]; dv[-1] = P[-1] - P[-2]
+    n = np.cross(du, dv)
+    n /= np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-12)
+    return np.ascontiguousarray(n.reshape(-1, 3)[depth.reshape(-1) > 0], np.float32)

@@ -1,0 +1,127 @@
+"""world_size-2 gloo coverage of the frame-sharded merge (onepiece_amd.distributed.merge_volumes).
+
+The collective control flow (count/key all_gather, deterministic union, sum-form pack, ONE reduce,
+normalise on the root) is backend-neutral; here its three device steps are stood in for by numpy
+over oracle volumes so the N > 1 path runs on CPU.  The result must equal CubeHandler::Merge of the
+two shards (oracle) -- keys and weights exactly, sdf/colour within 1e-4 (sum-form rounding).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleVolumeOps:
+    """CPU stand-in for distributed.HipVolumeOps (same three steps, numpy arithmetic)."""
+
+    def __init__(self, vol):
+        self.vol = vol
+
+    def keys(self):
+        import torch
+        k, _ = self.vol.export()
+        return torch.from_numpy(k.copy())
+
+    def pack_sum(self, union_keys):
+        import torch
+        k, v = self.vol.export()
+        index = {tuple(r): i for i, r in enumerate(k.tolist())}
+        out = np.zeros((union_keys.shape[0], 5, 512), np.float32)
+        for j, r in enumerate(union_keys.tolist()):
+            i = index.get(tuple(r))
+            if i is None:
+                continue
+            w = v[i, :, 1]
+            m = w > 0
+            out[j, 1, m] = w[m]
+            out[j, 0, m] = w[m] * v[i, m, 0]
+            for c in range(3):
+                out[j, 2 + c, m] = w[m] * v[i, m, 2 + c]
+        return torch.from_numpy(out)
+
+    def unpack_sum(self, union_keys, summed):
+        s = summed.numpy()
+        n = s.shape[0]
+        vox = np.empty((n, 512, 5), np.float32)
+        w = s[:, 1, :]
+        m = w > 0
+        safe = np.where(m, w, 1).astype(np.float32)
+        vox[:, :, 1] = np.where(m, w, 0)
+        vox[:, :, 0] = np.where(m, s[:, 0, :] / safe, 999)
+        for c in range(3):
+            vox[:, :, 2 + c] = np.where(m, s[:, 2 + c, :] / safe, -1)
+        self.vol.clear()
+        self.vol.load(union_keys.numpy().astype(np.int32), vox)
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from onepiece_amd import distributed as D, synthetic as S
+    from helpers import small_camera
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cam = small_camera(4)
+    frames = [0, 25, 50, 75, 100, 125]
+    lo, hi = D.shard_range(len(frames), rank, world)
+    vol = O.Volume(O.make_camera(*cam), voxel_res=0.02)
+    for i in frames[lo:hi]:
+        pose = S.room_pose(i)
+        d, c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+        vol.integrate(d, c, pose)
+    k, v = vol.export()
+    np.savez(os.path.join(outdir, "shard%d.npz" % rank), k=k, v=v)
+    n_union = D.merge_volumes(OracleVolumeOps(vol), root=0)
+    if rank == 0:
+        k, v = vol.export()
+        np.savez(os.path.join(outdir, "merged.npz"), k=k, v=v, n_union=n_union)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from onepiece_amd import distributed as D
+    for n, w in [(8000, 8), (10, 3), (2, 4), (0, 2)]:
+        spans = [D.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_two_rank_gloo_merge_equals_reference_merge(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from helpers import small_camera
+    cam = oracle.make_camera(*small_camera(4))
+    a, b = oracle.Volume(cam, voxel_res=0.02), oracle.Volume(cam, voxel_res=0.02)
+    s0, s1 = np.load(tmp_path / "shard0.npz"), np.load(tmp_path / "shard1.npz")
+    a.load(s0["k"], s0["v"]); b.load(s1["k"], s1["v"])
+    assert a.merge(b) == 0  # CubeHandler::Merge (CubeHandler.h:145-167)
+    rk, rv = a.export()
+    m = np.load(tmp_path / "merged.npz")
+    assert int(m["n_union"]) == len(rk)
+    assert np.array_equal(m["k"], rk), "merged key set differs from CubeHandler::Merge"
+    assert np.array_equal(m["v"][:, :, 1], rv[:, :, 1]), "weights must be exact"
+    seen = rv[:, :, 1] > 0
+    assert np.abs(m["v"][:, :, 0] - rv[:, :, 0])[seen].max() <= 1e-4 * 0.1
+    assert np.abs(m["v"][:, :, 2:] - rv[:, :, 2:])[seen].max() <= 1e-4
+    assert np.array_equal(m["v"][~seen], rv[~seen])  # untouched voxels keep the {999, 0, -1} sentinel
+    # both shards really contributed and really overlapped
+    k0 = {tuple(r) for r in s0["k"].tolist()}; k1 = {tuple(r) for r in s1["k"].tolist()}
+    assert k0 - k1 and k1 - k0 and k0 & k1
