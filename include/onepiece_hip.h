@@ -3,8 +3,8 @@
  * hot path.  This is the drop-in boundary: the reference has no FFI layer (its boundary is the C++
  * header surface one_piece::integration::CubeHandler / one_piece::registration::PointToPlane), so
  * every entry point below names the reference declaration (file:line under /root/reference/src)
- * whose work it replaces; the C++ shim that re-exposes the reference's class surface on top of
- * these calls is host/onepiece_shim.hpp, and INTEGRATION.md shows how a maintainer wires it in.
+ * whose work it replaces; INTEGRATION.md shows the forwarding calls a maintainer adds inside the
+ * reference's CubeHandler / ICP to bind them.
  *
  * Conventions
  *   - extern "C", POD only, caller-allocated outputs, int return: 0 = OP_OK, otherwise an

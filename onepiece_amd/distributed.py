@@ -94,6 +94,10 @@ def merge_volumes(ops, root=0, group=None):
     # 3.-4. sum-form pack, one reduce to the root
     packed = ops.pack_sum(union).contiguous()
     dist.reduce(packed, dst=root, op=dist.ReduceOp.SUM, group=group)
+    if packed.is_cuda:
+        # the collective is ordered on torch's stream; the volume's kernels run on the volume's own
+        # stream, so finish the reduce before handing the buffer to k_unpack_sum
+        torch.cuda.current_stream(packed.device).synchronize()
     # 5. normalise on the root
     if rank == root:
         ops.unpack_sum(union, packed)

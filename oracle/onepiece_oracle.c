@@ -652,10 +652,16 @@ void orc_kabsch(const float *pairs, size_t n, float T[16]) {
     T[15] = 1;
 }
 
+/* Diagnostic switch (NOT reference behaviour): accumulate JTJ/JTr in double instead of the
+ * reference's float, to measure how much of a pose difference is the reference's own rounding. */
+static int g_accumulate_double = 0;
+void orc_set_accumulate_double(int on) { g_accumulate_double = on; }
+
 /* ICP.cpp:108-144 */
 void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
                       const int32_t *inliers, size_t n, float T[16], float JTJ[36], float JTr[6]) {
     float jtj[36] = {0}, jtr[6] = {0};
+    double djtj[36] = {0}, djtr[6] = {0};
     for (size_t i = 0; i < n; ++i) {
         const float *s = src + 3 * inliers[2 * i], *t = tgt + 3 * inliers[2 * i + 1];
         const float *nn = tgt_n + 3 * inliers[2 * i + 1];
@@ -663,9 +669,14 @@ void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
         float row[6] = {nn[0], nn[1], nn[2], s[1] * nn[2] - s[2] * nn[1], s[2] * nn[0] - s[0] * nn[2],
                         s[0] * nn[1] - s[1] * nn[0]};
         for (int a = 0; a < 6; ++a) {
-            for (int b = 0; b < 6; ++b) jtj[a * 6 + b] += row[a] * row[b];
+            for (int b = 0; b < 6; ++b) { jtj[a * 6 + b] += row[a] * row[b]; djtj[a * 6 + b] += (double)(row[a] * row[b]); }
             jtr[a] += (float)r * row[a];
+            djtr[a] += (double)((float)r * row[a]);
         }
+    }
+    if (g_accumulate_double) {
+        for (int a = 0; a < 36; ++a) jtj[a] = (float)djtj[a];
+        for (int a = 0; a < 6; ++a) jtr[a] = (float)djtr[a];
     }
     float x[6];
     orc_solve6(jtj, jtr, x);

@@ -88,6 +88,9 @@ void orc_solve6(const float JTJ[36], const float JTr[6], float x[6]);
 void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
                       const int32_t *inliers, size_t n, float T[16], float JTJ[36], float JTr[6]);
 
+/* Diagnostic only: 1 = accumulate the normal equations in double (the reference uses float). */
+void orc_set_accumulate_double(int on);
+
 typedef struct {
     float T[16];          /* RegistrationResult::T (Kabsch over final inliers) */
     float last_T[16];     /* accumulated start_T after the loop (not returned by the reference) */

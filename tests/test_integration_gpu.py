@@ -168,3 +168,31 @@ def test_device_resident_sequence_matches_per_frame(oracle):
     ka, va = hv_a.GetCubeMap(); kb, vb = hv_b.GetCubeMap()
     assert np.array_equal(ka, kb) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
     _compare(oracle, ov, hv_a)
+
+
+def test_sum_form_merge_kernels_match_reference_merge(oracle):
+    """The device steps of the multi-GPU merge (keys_device / pack_sum / unpack_sum) on one GPU:
+    two shards packed in union order, summed (what the RCCL reduce does), normalised on the 'root'.
+    Must equal CubeHandler::Merge of the shards: keys + weights exact, values within 1e-4."""
+    import torch
+    from onepiece_amd import distributed as D
+    dev = torch.device("cuda:0")
+    ov1, hv1 = _mk(oracle, 0.01)
+    ov2, hv2 = _mk(oracle, 0.01)
+    for i in (0, 15, 30):
+        d, rgb, pose = S.room_frame(i)
+        ov1.integrate(d, rgb, pose); hv1.IntegrateImage(d, rgb, pose)
+    for i in (45, 60):
+        d, rgb, pose = S.room_frame(i)
+        ov2.integrate(d, rgb, pose); hv2.IntegrateImage(d, rgb, pose)
+    o1, o2 = D.HipVolumeOps(hv1, dev), D.HipVolumeOps(hv2, dev)
+    k1, k2 = o1.keys(), o2.keys()
+    assert k1.shape[0] == hv1.BlockCount() and k2.shape[0] == hv2.BlockCount()
+    union = torch.unique(torch.cat([k1, k2]), dim=0).contiguous()
+    total = o1.pack_sum(union) + o2.pack_sum(union)
+    torch.cuda.synchronize()
+    o1.unpack_sum(union, total.contiguous())
+    assert ov1.merge(ov2) == 0
+    _compare(oracle, ov1, hv1, exact=False)
+    # world_size == 1 path of merge_volumes is a no-op that reports the block count
+    assert D.merge_volumes(o2) == hv2.BlockCount()

@@ -1,0 +1,52 @@
+// prof_driver.cpp -- torch-free driver of the C-ABI for rocprofv3 runs (PMC collection segfaults
+// when the profiled process is python+torch).  Reads a frame dump written by tools/dump_frames.py:
+//   int32 n, w, h;  then n x { float pose[16]; float depth[w*h]; uint8 rgb[w*h*3] }
+// uploads the frames to HBM once, then fuses them `reps` times into a fresh 5 mm volume.
+// Build: hipcc -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o gpurun_out/prof_driver
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "onepiece_hip.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, op_last_error()); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const char* path = argc > 1 ? argv[1] : "/tmp/frames.bin";
+    const int reps = argc > 2 ? atoi(argv[2]) : 1;
+    const float voxel = argc > 3 ? (float)atof(argv[3]) : 0.005f;
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror(path); return 1; }
+    int hdr[3];
+    if (fread(hdr, 4, 3, f) != 3) return 1;
+    const int n = hdr[0], w = hdr[1], h = hdr[2];
+    const size_t npx = (size_t)w * h;
+    std::vector<float> poses((size_t)n * 16), depth(npx * n);
+    std::vector<unsigned char> rgb(npx * 3 * n);
+    for (int i = 0; i < n; ++i) {
+        if (fread(&poses[(size_t)i * 16], 4, 16, f) != 16) return 1;
+        if (fread(&depth[npx * i], 4, npx, f) != npx) return 1;
+        if (fread(&rgb[npx * 3 * i], 1, npx * 3, f) != npx * 3) return 1;
+    }
+    fclose(f);
+    float* d_depth; unsigned char* d_rgb;
+    if (hipMalloc((void**)&d_depth, depth.size() * 4) != hipSuccess || hipMalloc((void**)&d_rgb, rgb.size()) != hipSuccess) return 1;
+    hipMemcpy(d_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_rgb, rgb.data(), rgb.size(), hipMemcpyHostToDevice);
+    op_camera cam; CK(op_camera_preset(1, &cam));
+    cam.width = w; cam.height = h;
+    op_volume* v; CK(op_volume_create(&cam, voxel, 0.1f, 5.0f, 0.5f, 0, 1u << 18, &v));
+    for (int r = 0; r < reps; ++r) {
+        CK(op_volume_clear(v));
+        auto t0 = std::chrono::steady_clock::now();
+        CK(op_volume_integrate_sequence(v, d_depth, npx * 4, OP_DEPTH_F32, d_rgb, npx * 3, poses.data(), (size_t)n));
+        CK(op_volume_sync(v));
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        uint64_t fr, sel, vis, upd; CK(op_volume_stats(v, &fr, &sel, &vis, &upd));
+        size_t nb; CK(op_volume_block_count(v, &nb));
+        printf("rep %d: %d frames %.3f ms/frame  sel/frame %.0f  upd/frame %.0f  blocks %zu\n", r, n, dt / n * 1e3, (double)sel / fr, (double)upd / fr, nb);
+    }
+    op_volume_destroy(v);
+    return 0;
+}
