@@ -71,6 +71,10 @@ uint64_t op_hash_key(int32_t x, int32_t y, int32_t z);
 /* Frustum::ComputeFromCamera (Integration/Frustum.cpp:7-46): planes top,left,right,bottom,near,far. */
 int op_frustum_planes(const op_camera *cam, const float pose[16], float far_dist, float near_dist,
                       float planes[24]);
+/* Test hook: the pixel rounding of Integrator.cpp:20-21 applied to a = fx*X/Z and c = cx.
+ * fast = 0: the reference's double formula; fast = 1: the fp32/integer evaluation the kernels use
+ * (valid when |c| >= 1 or c == 0).  Both return INT_MIN for values no int can hold. */
+int op_debug_project_px(float a, float c, int fast);
 /* geometry::Se3ToSE3 (Geometry/Geometry.cpp:9-13). */
 int op_se3_exp(const float x[6], float T[16]);
 
@@ -106,8 +110,9 @@ int op_volume_prepare_cubes(op_volume *v, const void *depth, int depth_fmt, int 
 int op_volume_integrate(op_volume *v, const void *depth, int depth_fmt, const uint8_t *rgb,
                         int mem, const float pose[16], const float *pose_inv);
 /* Multi-frame form of the same call for frames already resident on the device: frame f uses
- * depth + f*depth_stride_bytes, rgb + f*rgb_stride_bytes, poses + 16*f.  Results are identical to
- * n_frames sequential op_volume_integrate calls (frames are applied in order). */
+ * depth + f*depth_stride_bytes, rgb + f*rgb_stride_bytes, poses + 16*f.  Results are bit-identical
+ * to n_frames sequential op_volume_integrate calls: frames are fused in batches of up to 16 per
+ * kernel launch, and inside a batch every voxel applies its frames in order in registers. */
 int op_volume_integrate_sequence(op_volume *v, const void *depth, size_t depth_stride_bytes,
                                  int depth_fmt, const uint8_t *rgb, size_t rgb_stride_bytes,
                                  const float *poses, size_t n_frames);
@@ -117,12 +122,14 @@ int op_volume_integrate_sequence(op_volume *v, const void *depth, size_t depth_s
 int op_volume_stats(op_volume *v, uint64_t *frames, uint64_t *blocks_selected, uint64_t *voxels_visited,
                     uint64_t *voxels_updated);
 
-/* Measurement hook (no reference counterpart): with sample_every = k > 0, every k-th integrated
- * frame is bracketed by HIP events on the volume's stream.  profile_read synchronises and returns
- * the summed durations in ms of the three kernels of a frame -- [0] ComputeBounding (K1),
- * [1] PrepareCubes (K2), [2] Integrator::IntegrateImage (K3) -- over n_samples sampled frames. */
+/* Measurement hook (no reference counterpart): with sample_every = k > 0, every k-th launch group
+ * (one group = one op_volume_integrate call, or one batch of up to 16 frames of
+ * op_volume_integrate_sequence) is bracketed by HIP events on the volume's stream.  profile_read
+ * synchronises and returns the summed durations in ms of the three kernels -- [0] frame
+ * preparation + ComputeBounding (KA), [1] PrepareCubes (KB), [2] Integrator::IntegrateImage (KC) --
+ * over n_launches sampled groups covering n_frames frames. */
 int op_volume_profile_enable(op_volume *v, int sample_every);
-int op_volume_profile_read(op_volume *v, double ms_sum[3], uint64_t *n_samples);
+int op_volume_profile_read(op_volume *v, double ms_sum[3], uint64_t *n_launches, uint64_t *n_frames);
 
 /* CubeHandler::GetCubeMap (CubeHandler.h:347-350): keys n x 3 int32; voxels n x 512 x 5 float in
  * the reference's TSDFVoxel member order {sdf, weight, color[0..2]}, voxel index x + 8y + 64z. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "op_hash_key": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32]),
     "op_frustum_planes": (C.c_int, [C.POINTER(Camera), _fp, C.c_float, C.c_float, _fp]),
     "op_se3_exp": (C.c_int, [_fp, _fp]),
+    "op_debug_project_px": (C.c_int, [C.c_float, C.c_float, C.c_int]),
     "op_volume_create": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_uint64, C.POINTER(_vp)]),
     "op_volume_destroy": (C.c_int, [_vp]),
@@ -72,7 +73,7 @@ SIGNATURES = {
                                                C.c_size_t]),
     "op_volume_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "op_volume_profile_enable": (C.c_int, [_vp, C.c_int]),
-    "op_volume_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), _u64p]),
+    "op_volume_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), _u64p, _u64p]),
     "op_volume_download": (C.c_int, [_vp, _ip, _fp, C.c_size_t, _szp]),
     "op_volume_upload": (C.c_int, [_vp, _ip, _fp, C.c_size_t]),
     "op_volume_merge": (C.c_int, [_vp, _vp]),

@@ -34,6 +34,7 @@
 
 #include "common.hpp"
 #include "host_math.hpp"
+#include "px_round.hpp"
 
 namespace op {
 thread_local char g_last_error[512] = "";
@@ -45,39 +46,51 @@ using op::fail;
 
 constexpr int kVox = 512;            // voxels per block (CUBE_SIZE^3, VoxelCube.h:4)
 constexpr int kBlockFloats = 5 * kVox;
-constexpr int kEmpty = -1;           // table slot never used
-constexpr int kLocked = -2;          // slot reserved by an in-flight insert of another key
-constexpr int kDead = -3;            // reserved but the pool was full
-constexpr int kKeySentinel = INT_MIN;
-constexpr int kPixPerWg = 1024;      // K1: pixels per workgroup (256 threads x 4)
-constexpr int kSelectGrid = 1024;    // K2 persistent grid (256-thread workgroups)
-constexpr int kIntegrateGrid = 1024; // K3 persistent grid (512-thread workgroups, 4 per CU)
+constexpr unsigned long long kEmptyKey = ~0ULL; // table slot never used
+constexpr int kPending = -1;         // slot claimed, pool slot not published yet
+constexpr int kDead = -3;            // slot claimed but the pool was full
+constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 4)
+constexpr int kSelectGrid = 512;     // KB persistent grid.x (256-thread workgroups) per frame
+constexpr int kIntegrateGrid = 1024; // KC persistent grid (512-thread workgroups)
+constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
+#ifndef KC_MIN_WAVES
+#define KC_MIN_WAVES 4 // waves per SIMD the integrate kernel is compiled for (2 workgroups of 8 waves per CU)
+#endif
+constexpr int kCoordLimit = 1 << 20; // |block coordinate| < 2^20 (40 km at 4 cm blocks)
 
-struct FrameParams {
-    float pose[16];
-    float pose_inv[16];
-    float planes[24]; // top, left, right, bottom, near, far
+struct CamParams {
     float fx, fy, cx, cy, depth_scale, res, trunc;
     int width, height, depth_u16;
+    PxSplit sx, sy; // exact splits of cx, cy for the fp32 pixel-rounding path
+    int fast_px;    // both splits exact -> use px_round_sp, else the double formula
 };
+struct PoseFwd { float pose[16]; float planes[24]; }; // planes: top, left, right, bottom, near, far
+struct PoseInv { float m[12]; };                      // rows 0..2 of pose^-1
+struct BatchFwd { PoseFwd f[kMaxBatch]; };
+struct BatchInv { PoseInv f[kMaxBatch]; };
 
-struct FrameState {
-    unsigned n_sel;    // length of this frame's cube_id_list
-    unsigned overflow; // bit0: pool full, bit1: table full, bit2: candidate range too large
-    unsigned long long n_cand;
-    unsigned long long stat_frames, stat_sel;
-    float bbox[6]; // max xyz, min xyz of the last ComputeBounding
-    unsigned n_inside, pad;
+struct State {
+    unsigned n_batch;   // length of the batch block list
+    unsigned overflow;  // bit0 pool full, bit1 table full, bit2 bbox too large, bit3 coordinate range
+    unsigned n_rec;     // PrepareCubes record mode: entries in sel_list / sel_cand
+    unsigned pad;
+    unsigned long long stat_frames;
+    unsigned long long n_cand[kMaxBatch];
+    float bbox[kMaxBatch][6]; // max xyz, min xyz
+    unsigned n_inside[kMaxBatch];
 };
 
 struct VolView {
-    int4* table;
+    unsigned long long* tkeys; // packed block id or kEmptyKey
+    int* tvals;                // pool slot, kPending or kDead
     unsigned table_mask;
-    int* keys;
+    int* keys;                 // block id by pool slot
     float* pool;
     unsigned max_blocks;
     unsigned* n_blocks;
-    int* sel_list;
+    unsigned* bmask;           // per TABLE slot: which frames of the current batch selected the block
+    int* blist;                // table slots touched by the current batch
+    int* sel_list;             // record mode (PrepareCubes): table slot (translated to pool slot by k_finish_select) + candidate rank
     unsigned long long* sel_cand;
 };
 
@@ -88,33 +101,35 @@ __device__ __forceinline__ unsigned long long hash_key_dev(int x, int y, int z) 
     return ((unsigned long long)(long long)x * 73856093ULL) ^ ((unsigned long long)(long long)y * 19349663ULL) ^
            ((unsigned long long)(long long)z * 83492791ULL);
 }
+__device__ __forceinline__ unsigned long long pack_key(int x, int y, int z) {
+    return ((unsigned long long)(unsigned)(x + kCoordLimit) << 42) | ((unsigned long long)(unsigned)(y + kCoordLimit) << 21) |
+           (unsigned long long)(unsigned)(z + kCoordLimit);
+}
+__device__ __forceinline__ bool key_in_range(int x, int y, int z) {
+    return x >= -kCoordLimit && x < kCoordLimit && y >= -kCoordLimit && y < kCoordLimit && z >= -kCoordLimit && z < kCoordLimit;
+}
 
 // Eigen's 3-term reduction order a0 + (a1 + a2).
 __device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
 
-// Integrator.cpp:20-21: (((f*X)/Z) + 0.5) + c in double, truncated toward zero; values that do not
-// fit an int (UB on the CPU, INT_MIN from cvttsd2si) are mapped to INT_MIN and fail the bounds test.
-__device__ __forceinline__ int project_px(float f, float X, float Z, float c) {
-    const double t = (double)((f * X) / Z) + 0.5 + (double)c;
-    if (!(t > -2147483649.0 && t < 2147483648.0)) return INT_MIN;
-    return (int)t;
+// Integrator.cpp:20-21: int u = fx*X/Z + 0.5 + cx (see px_round.hpp for the exact semantics).
+template <bool FAST>
+__device__ __forceinline__ int project_px(float f, float X, float Z, float c, const PxSplit& sp) {
+    const float a = (f * X) / Z;
+    return FAST ? px_round_sp(a, sp) : px_round_dp(a, c);
 }
 
-__device__ __forceinline__ float depth_at(const void* depth, int is_u16, float depth_scale, size_t idx) {
-    if (!is_u16) return ((const float*)depth)[idx];
-    return (float)((const unsigned short*)depth)[idx] / depth_scale; // Integrator.cpp:29
-}
-
-// Integrator::GetSDF with pose_inv precomputed (Integrator.cpp:8-35).
-__device__ __forceinline__ float get_sdf(const FrameParams& P, const void* depth, float px, float py, float pz) {
-    const float* M = P.pose_inv;
+// Integrator::GetSDF with pose_inv precomputed (Integrator.cpp:8-35); depth comes from the packed
+// per-frame image {depth bits, rgba}.
+template <bool FAST>
+__device__ __forceinline__ float get_sdf(const CamParams& C, const float* M, const uint2* __restrict__ img, float px, float py, float pz) {
     const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
     const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
     const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-    const int u = project_px(P.fx, q0, q2, P.cx);
-    const int v = project_px(P.fy, q1, q2, P.cy);
-    if (v < 0 || v >= P.height || u < 0 || u >= P.width) return 999.0f;
-    const float d = depth_at(depth, P.depth_u16, P.depth_scale, (size_t)v * P.width + u);
+    const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
+    const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
+    if (v < 0 || v >= C.height || u < 0 || u >= C.width) return 999.0f;
+    const float d = __uint_as_float(img[(size_t)v * C.width + u].x);
     if (d <= 0) return 999.0f;
     return d - q2;
 }
@@ -132,40 +147,51 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
-// Looks `key` up; if absent reserves a slot (state kLocked) for it.  Returns the pool slot (>= 0)
-// when the block exists, otherwise -1 and *reserved = table slot (or -1 when the table is full).
-// Concurrent callers in one launch always carry distinct keys, so a locked slot belongs to some
-// other key and can be skipped.
-__device__ int table_find_or_reserve(const VolView& V, int x, int y, int z, int* reserved) {
+// Concurrent find-or-claim, wait-free.  The 64-bit packed key is claimed with one CAS, which also
+// publishes it, so concurrent claims of the SAME key (frames of one batch) simply agree on the
+// table slot.  Only the CAS winner allocates the pool block and stores its index in tvals[slot]
+// with a plain store: nobody reads tvals in the launch that inserts -- callers work with the TABLE
+// SLOT and translate slot -> pool block in the next kernel (kernel boundaries make it visible on
+// every XCD).  Returns the table slot, or -1 when the table is full (flagged in st->overflow).
+__device__ int table_claim(const VolView& V, State* st, int x, int y, int z, bool* created) {
+    *created = false;
+    const unsigned long long key = pack_key(x, y, z);
     unsigned s = (unsigned)hash_key_dev(x, y, z) & V.table_mask;
-    *reserved = -1;
     for (unsigned probe = 0; probe <= V.table_mask; ++probe, s = (s + 1) & V.table_mask) {
-        int4 e = V.table[s];
-        if (e.w == kEmpty) {
-            const int old = atomicCAS(&((int*)&V.table[s])[3], kEmpty, kLocked);
-            if (old == kEmpty) { *reserved = (int)s; return -1; }
-            continue; // somebody else (another key) took it
+        unsigned long long k = V.tkeys[s];
+        if (k == kEmptyKey) {
+            // (a stale cached "empty" is harmless: the CAS is resolved at the coherence point)
+            k = atomicCAS(&V.tkeys[s], kEmptyKey, key);
+            if (k == kEmptyKey) { // slot is ours: allocate a pool block
+                const unsigned idx = atomicAdd(V.n_blocks, 1u);
+                if (idx >= V.max_blocks) {
+                    atomicOr(&st->overflow, 1u);
+                    V.tvals[s] = kDead;
+                } else {
+                    V.keys[3 * idx] = x; V.keys[3 * idx + 1] = y; V.keys[3 * idx + 2] = z;
+                    V.tvals[s] = (int)idx;
+                }
+                *created = true;
+                return (int)s;
+            }
         }
-        if (e.w >= 0 && e.x == x && e.y == y && e.z == z) return e.w;
+        if (k == key) return (int)s;
     }
+    atomicOr(&st->overflow, 2u);
     return -1;
 }
 
+// Read-only lookup (no concurrent inserts running).
 __device__ int table_find(const VolView& V, int x, int y, int z) {
+    if (!key_in_range(x, y, z)) return -1;
+    const unsigned long long key = pack_key(x, y, z);
     unsigned s = (unsigned)hash_key_dev(x, y, z) & V.table_mask;
     for (unsigned probe = 0; probe <= V.table_mask; ++probe, s = (s + 1) & V.table_mask) {
-        const int4 e = V.table[s];
-        if (e.w == kEmpty) return -1;
-        if (e.w >= 0 && e.x == x && e.y == y && e.z == z) return e.w;
+        const unsigned long long k = V.tkeys[s];
+        if (k == kEmptyKey) return -1;
+        if (k == key) { const int v = V.tvals[s]; return v >= 0 ? v : -1; }
     }
     return -1;
-}
-
-__device__ __forceinline__ void table_publish(const VolView& V, int slot, int x, int y, int z, int pool_idx) {
-    int* e = (int*)&V.table[slot];
-    e[0] = x; e[1] = y; e[2] = z;
-    __threadfence();
-    atomicExch(&e[3], pool_idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,34 +206,55 @@ __global__ void k_fill_pool(float* pool, size_t first_block, size_t n_blocks) {
     }
 }
 
-__global__ void k_clear_table(int4* table, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        table[i] = make_int4(kKeySentinel, kKeySentinel, kKeySentinel, kEmpty);
+__global__ void k_clear_table(unsigned long long* tkeys, int* tvals, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        tkeys[i] = kEmptyKey;
+        tvals[i] = kPending;
+    }
+}
+
+// After a select-only launch (PrepareCubes API): clear the batch masks again and translate the
+// recorded table slots into pool slots.
+__global__ void k_finish_select(VolView V, const State* st) {
+    const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
+    const unsigned nr = st->n_rec < V.max_blocks ? st->n_rec : V.max_blocks;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) V.bmask[V.blist[i]] = 0u;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) V.sel_list[i] = V.tvals[V.sel_list[i]];
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: ComputeBounding (CubeHandler.cpp:116-145): back-project, transform, frustum test, min/max.
-// One partial result per workgroup (no atomics); K2 reduces the partials.
-// partial layout: [max x,y,z, min x,y,z, inside (as uint bits), pad] per workgroup.
+// KA: per-frame preparation = ComputeBounding (CubeHandler.cpp:116-145: back-project, transform,
+// frustum test, min/max) + packing of the frame into one {depth, rgba} record per pixel so that
+// the later gathers are single 8-byte loads.  grid = (ceil(W*H/1024), n_frames).
+// One bounding partial per workgroup (no atomics): [max x,y,z, min x,y,z, inside, pad].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bounding(FrameParams P, const void* __restrict__ depth, float* __restrict__ partial,
-                                                  FrameState* st) {
+__global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C, const void* __restrict__ depth, size_t depth_stride,
+                                                        const unsigned char* __restrict__ rgb, size_t rgb_stride,
+                                                        uint2* __restrict__ pimg, float* __restrict__ partial, State* st) {
     __shared__ float s_red[4][6];
     __shared__ unsigned s_cnt[4];
-    const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0) st->n_sel = 0; // new frame: empty cube_id_list
+    const int tid = threadIdx.x, f = blockIdx.y;
+    if (blockIdx.x == 0 && f == 0 && tid == 0) { st->n_batch = 0; st->n_rec = 0; } // new batch: empty lists
+    const PoseFwd& P = B.f[f];
+    const int npix = C.width * C.height;
+    const void* dptr = (const char*)depth + (size_t)f * depth_stride;
+    const unsigned char* cptr = rgb ? rgb + (size_t)f * rgb_stride : nullptr;
+    uint2* out = pimg + (size_t)f * npix;
     float mx0 = -FLT_MAX, mx1 = -FLT_MAX, mx2 = -FLT_MAX, mn0 = FLT_MAX, mn1 = FLT_MAX, mn2 = FLT_MAX;
     unsigned inside = 0;
-    const int npix = P.width * P.height;
 #pragma unroll
     for (int r = 0; r < kPixPerWg / 256; ++r) {
         const int pix = blockIdx.x * kPixPerWg + r * 256 + tid;
         if (pix >= npix) continue;
-        const float z = depth_at(depth, P.depth_u16, P.depth_scale, (size_t)pix);
+        // Integrator.cpp:26-29 / PointCloud.cpp:83-86: float depth, or uint16 / depth_scale
+        const float z = C.depth_u16 ? (float)((const unsigned short*)dptr)[pix] / C.depth_scale : ((const float*)dptr)[pix];
+        unsigned rgba = 0;
+        if (cptr) rgba = (unsigned)cptr[3 * (size_t)pix] | ((unsigned)cptr[3 * (size_t)pix + 1] << 8) | ((unsigned)cptr[3 * (size_t)pix + 2] << 16);
+        out[pix] = make_uint2(__float_as_uint(z), rgba);
         if (!(z > 0)) continue;
-        const int i = pix / P.width, j = pix - i * P.width;
-        const float x = ((float)j - P.cx) * z / P.fx; // PointCloud.cpp:90-93
-        const float y = ((float)i - P.cy) * z / P.fy;
+        const int i = pix / C.width, j = pix - i * C.width;
+        const float x = ((float)j - C.cx) * z / C.fx; // PointCloud.cpp:90-93
+        const float y = ((float)i - C.cy) * z / C.fy;
         const float* M = P.pose;                       // Geometry.cpp:19-27
         const float q0 = ((M[0] * x + M[1] * y) + M[2] * z) + M[3] * 1.0f;
         const float q1 = ((M[4] * x + M[5] * y) + M[6] * z) + M[7] * 1.0f;
@@ -237,34 +284,39 @@ __global__ __launch_bounds__(256) void k_bounding(FrameParams P, const void* __r
         s_cnt[wave] = inside;
     }
     __syncthreads();
+    float* pout = partial + ((size_t)f * gridDim.x + blockIdx.x) * 8;
     if (tid < 6) {
         float v = s_red[0][tid];
         for (int w = 1; w < 4; ++w) v = tid < 3 ? fmaxf(v, s_red[w][tid]) : fminf(v, s_red[w][tid]);
-        partial[blockIdx.x * 8 + tid] = v;
+        pout[tid] = v;
     } else if (tid == 6) {
-        ((unsigned*)partial)[blockIdx.x * 8 + 6] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        ((unsigned*)pout)[6] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: PrepareCubes (CubeHandler.cpp:147-196).  One thread per candidate block of the bbox +-1
-// range; 8 corner-voxel GetSDF probes; selected blocks are looked up / inserted in the hash table
-// and appended to the frame list.  List append and pool allocation are aggregated per workgroup
-// chunk (one atomic each per 256 candidates).
+// KB: PrepareCubes (CubeHandler.cpp:147-196) for every frame of the batch (blockIdx.y = frame).
+// One thread per candidate block of the bbox +-1 range; 8 corner-voxel GetSDF probes; a selected
+// block is looked up / inserted in the hash table, its batch mask gets the frame's bit, and the
+// first selection in the batch appends it to the batch list (append aggregated per workgroup chunk).
+// record != 0 (single-frame PrepareCubes API): also emits (pool slot, candidate rank) pairs.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_select(FrameParams P, VolView V, const void* __restrict__ depth,
-                                                const float* __restrict__ partial, int n_partial, FrameState* st) {
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg,
+                                                const float* __restrict__ partial, int n_partial, State* st, int record) {
     __shared__ float s_red[4][6];
     __shared__ unsigned s_cnt[4];
     __shared__ int s_range[6]; // i0, j0, k0, ni, nj, nk
-    __shared__ unsigned s_wsel[4], s_wnew[4], s_base[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned s_wa[4], s_wb[4], s_base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, f = blockIdx.y;
+    const float* M = B.f[f].m;
+    const uint2* img = pimg + (size_t)f * C.width * C.height;
 
-    // -- finish ComputeBounding: reduce the K1 partials (every workgroup does it redundantly)
+    // -- finish ComputeBounding: reduce KA's partials of this frame (every workgroup, redundantly)
     float mx0 = -FLT_MAX, mx1 = -FLT_MAX, mx2 = -FLT_MAX, mn0 = FLT_MAX, mn1 = FLT_MAX, mn2 = FLT_MAX;
     unsigned inside = 0;
     for (int g = tid; g < n_partial; g += 256) {
-        const float* p = partial + g * 8;
+        const float* p = partial + ((size_t)f * n_partial + g) * 8;
         mx0 = fmaxf(mx0, p[0]); mx1 = fmaxf(mx1, p[1]); mx2 = fmaxf(mx2, p[2]);
         mn0 = fminf(mn0, p[3]); mn1 = fminf(mn1, p[4]); mn2 = fminf(mn2, p[5]);
         inside += ((const unsigned*)p)[6];
@@ -292,15 +344,15 @@ __global__ __launch_bounds__(256) void k_select(FrameParams P, VolView V, const 
             for (int c = 0; c < 3; ++c) {
                 // GetCubeID (VoxelCube.h:63-74): floor(p/res) in float -> int, then
                 // floor((pb + 0.0)/8) in double == arithmetic shift by 3.
-                const int hi = ((int)floorf(b[c] / P.res)) >> 3;
-                const int lo = ((int)floorf(b[3 + c] / P.res)) >> 3;
+                const int hi = ((int)floorf(b[c] / C.res)) >> 3;
+                const int lo = ((int)floorf(b[3 + c] / C.res)) >> 3;
                 s_range[c] = lo - 1;
                 s_range[3 + c] = hi - lo + 3;
             }
         }
         if (blockIdx.x == 0) {
-            for (int c = 0; c < 6; ++c) st->bbox[c] = b[c];
-            st->n_inside = tot;
+            for (int c = 0; c < 6; ++c) st->bbox[f][c] = b[c];
+            st->n_inside[f] = tot;
         }
     }
     __syncthreads();
@@ -311,20 +363,21 @@ __global__ __launch_bounds__(256) void k_select(FrameParams P, VolView V, const 
         if (blockIdx.x == 0 && tid == 0) atomicOr(&st->overflow, 4u);
         ncand = 0;
     }
-    if (blockIdx.x == 0 && tid == 0) st->n_cand = ncand;
+    if (blockIdx.x == 0 && tid == 0) st->n_cand[f] = ncand;
 
-    const float cube_res = P.res * 8.0f; // CubeHandler.cpp:164
-    const float half = P.res / 2;        // VoxelCube.h:47
-    const float o_lo = 0.0f * P.res + half, o_hi = 7.0f * P.res + half; // VoxelCentroidOffSet of x = 0 / 7
+    const float cube_res = C.res * 8.0f; // CubeHandler.cpp:164
+    const float half = C.res / 2;        // VoxelCube.h:47
+    const float o_lo = 0.0f * C.res + half, o_hi = 7.0f * C.res + half; // VoxelCentroidOffSet of x = 0 / 7
+    const unsigned fbit = 1u << f;
 
     for (unsigned long long chunk = blockIdx.x; chunk * 256ULL < ncand; chunk += gridDim.x) {
         const unsigned long long c = chunk * 256ULL + tid;
-        bool sel = false, is_new = false;
-        int bi = 0, bj = 0, bk = 0, pool_idx = -1, slot = -1;
+        bool first = false, rec = false;
+        int pool_idx = -1;
         if (c < ncand) {
-            bk = k0 + (int)(c % (unsigned long long)nk);
-            bj = j0 + (int)((c / (unsigned long long)nk) % (unsigned long long)nj);
-            bi = i0 + (int)(c / (unsigned long long)(nk * nj));
+            const int bk = k0 + (int)(c % (unsigned long long)nk);
+            const int bj = j0 + (int)((c / (unsigned long long)nk) % (unsigned long long)nj);
+            const int bi = i0 + (int)(c / (unsigned long long)(nk * nj));
             const float bx = (float)bi * cube_res, by = (float)bj * cube_res, bz = (float)bk * cube_res;
             float min_sdf = FLT_MAX;
 #pragma unroll
@@ -332,119 +385,154 @@ __global__ __launch_bounds__(256) void k_select(FrameParams P, VolView V, const 
                 const float px = bx + ((corner & 1) ? o_hi : o_lo);
                 const float py = by + ((corner & 2) ? o_hi : o_lo);
                 const float pz = bz + ((corner & 4) ? o_hi : o_lo);
-                const float a = fabsf(get_sdf(P, depth, px, py, pz));
+                const float a = fabsf(get_sdf<FAST>(C, M, img, px, py, pz));
                 if (min_sdf > a) min_sdf = a;
             }
-            sel = min_sdf < P.trunc;
-            if (sel) {
-                pool_idx = table_find_or_reserve(V, bi, bj, bk, &slot);
-                is_new = pool_idx < 0;
-                if (is_new && slot < 0) { atomicOr(&st->overflow, 2u); sel = false; is_new = false; }
-            }
-        }
-        // workgroup-aggregated list append / pool allocation
-        const unsigned long long m_sel = __ballot(sel), m_new = __ballot(is_new);
-        const unsigned long long below = (1ULL << lane) - 1ULL;
-        unsigned r_sel = __popcll(m_sel & below), r_new = __popcll(m_new & below);
-        if (lane == 0) { s_wsel[wave] = __popcll(m_sel); s_wnew[wave] = __popcll(m_new); }
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned tsel = s_wsel[0] + s_wsel[1] + s_wsel[2] + s_wsel[3];
-            const unsigned tnew = s_wnew[0] + s_wnew[1] + s_wnew[2] + s_wnew[3];
-            s_base[0] = tsel ? atomicAdd(&st->n_sel, tsel) : 0u;
-            s_base[1] = tnew ? atomicAdd(V.n_blocks, tnew) : 0u;
-        }
-        __syncthreads();
-        for (int w = 0; w < wave; ++w) { r_sel += s_wsel[w]; r_new += s_wnew[w]; }
-        if (sel) {
-            if (is_new) {
-                const unsigned idx = s_base[1] + r_new;
-                if (idx < V.max_blocks) {
-                    pool_idx = (int)idx;
-                    V.keys[3 * idx] = bi; V.keys[3 * idx + 1] = bj; V.keys[3 * idx + 2] = bk;
-                    table_publish(V, slot, bi, bj, bk, pool_idx);
+            if (min_sdf < C.trunc) {
+                if (!key_in_range(bi, bj, bk)) {
+                    atomicOr(&st->overflow, 8u);
                 } else {
-                    atomicOr(&st->overflow, 1u);
-                    atomicExch(&((int*)&V.table[slot])[3], kDead);
-                    pool_idx = -1;
+                    bool created;
+                    pool_idx = table_claim(V, st, bi, bj, bk, &created); // table slot; KC translates it
+                    if (pool_idx >= 0) {
+                        first = atomicOr(&V.bmask[pool_idx], fbit) == 0u;
+                        rec = record != 0;
+                    }
                 }
             }
-            const unsigned pos = s_base[0] + r_sel;
-            if (pos < V.max_blocks) {
-                V.sel_list[pos] = pool_idx;
-                V.sel_cand[pos] = c;
-            }
         }
-        __syncthreads(); // s_wsel / s_base are reused by the next chunk
+        // workgroup-aggregated appends: batch list (first selection in this batch) and record list
+        const unsigned long long m_a = __ballot(first), m_b = __ballot(rec);
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        unsigned r_a = __popcll(m_a & below), r_b = __popcll(m_b & below);
+        if (lane == 0) { s_wa[wave] = __popcll(m_a); s_wb[wave] = __popcll(m_b); }
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned ta = s_wa[0] + s_wa[1] + s_wa[2] + s_wa[3];
+            const unsigned tb = s_wb[0] + s_wb[1] + s_wb[2] + s_wb[3];
+            s_base[0] = ta ? atomicAdd(&st->n_batch, ta) : 0u;
+            s_base[1] = tb ? atomicAdd(&st->n_rec, tb) : 0u;
+        }
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) { r_a += s_wa[w]; r_b += s_wb[w]; }
+        if (first) {
+            const unsigned pos = s_base[0] + r_a;
+            if (pos < V.max_blocks) V.blist[pos] = pool_idx;
+        }
+        if (rec) {
+            const unsigned pos = s_base[1] + r_b;
+            if (pos < V.max_blocks) { V.sel_list[pos] = pool_idx; V.sel_cand[pos] = c; }
+        }
+        __syncthreads(); // s_wa / s_base are reused by the next chunk
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: Integrator::IntegrateImage (Integrator.cpp:36-94) over the frame list.  One 512-thread
-// workgroup per block (thread = voxel, wave = z-slice), persistent grid striding over the list.
+// KC: Integrator::IntegrateImage (Integrator.cpp:36-94) for all frames of the batch.  One
+// 512-thread workgroup per block of the batch list (thread = voxel, wave = z-slice), persistent
+// grid.  The voxel is read ONCE, every frame that selected the block is applied to it in frame
+// order in registers (bit-identical to the reference's frame-by-frame running mean), and it is
+// written once -- HBM traffic per voxel drops from 40 B per frame to 40 B per batch.
+// All per-frame gathers ({depth, rgba} records) are issued before the first dependent use.
 // Block ownership is exclusive, so the read-modify-write needs no atomics.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_integrate(FrameParams P, VolView V, const void* __restrict__ depth,
-                                                   const unsigned char* __restrict__ rgb, FrameState* st,
-                                                   unsigned long long* __restrict__ upd_partial) {
+template <bool FAST>
+__global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
+                                                   int n_frames, unsigned long long* __restrict__ upd_partial,
+                                                   unsigned long long* __restrict__ sel_partial) {
     __shared__ unsigned s_upd[8];
-    const unsigned n = st->n_sel < V.max_blocks ? st->n_sel : V.max_blocks;
+    __shared__ float s_c255[256]; // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
+    const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
     const int vid = threadIdx.x;
-    const float half = P.res / 2;
+    if (vid < 256) s_c255[vid] = (float)vid / 255.0f;
+    __syncthreads();
+    const size_t npix = (size_t)C.width * C.height;
+    const float half = C.res / 2;
     // VoxelCentroidOffSet[vid] (VoxelCube.h:48-61): x*res + half with x = vid & 7 etc.
-    const float ox = (float)(vid & 7) * P.res + half;
-    const float oy = (float)((vid >> 3) & 7) * P.res + half;
-    const float oz = (float)(vid >> 6) * P.res + half;
-    const float* M = P.pose_inv;
-    unsigned upd = 0;
+    const float ox = (float)(vid & 7) * C.res + half;
+    const float oy = (float)((vid >> 3) & 7) * C.res + half;
+    const float oz = (float)(vid >> 6) * C.res + half;
+    // BatchInv B is the first kernel argument = offset 0 of the kernarg segment
+    const float __attribute__((address_space(4)))* kargs =
+        (const float __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)B;
+    unsigned upd = 0, sel = 0;
     for (unsigned b = blockIdx.x; b < n; b += gridDim.x) {
-        const int idx = V.sel_list[b];
+        const int idx = V.tvals[V.blist[b]];
         if (idx < 0) continue; // pool overflow (reported through st->overflow)
+        const unsigned mask = V.bmask[V.blist[b]];
+        sel += __popc(mask);
         const int kx = V.keys[3 * idx], ky = V.keys[3 * idx + 1], kz = V.keys[3 * idx + 2];
+        float* vox = V.pool + (size_t)idx * kBlockFloats + vid;
+        float s = vox[0], w = vox[kVox], c0 = vox[2 * kVox], c1 = vox[3 * kVox], c2 = vox[4 * kVox];
         // GetGlobalPoint (VoxelCube.h:75-80): Point3(id) * CUBE_SIZE * VoxelResolution + offset
-        const float px = ((float)kx * 8.0f) * P.res + ox;
-        const float py = ((float)ky * 8.0f) * P.res + oy;
-        const float pz = ((float)kz * 8.0f) * P.res + oz;
-        const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-        const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-        const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-        const int u = project_px(P.fx, q0, q2, P.cx);
-        const int v = project_px(P.fy, q1, q2, P.cy);
-        if (v < 0 || v >= P.height || u < 0 || u >= P.width) continue;
-        const size_t pix = (size_t)v * P.width + u;
-        const float d = depth_at(depth, P.depth_u16, P.depth_scale, pix);
-        if (d <= 0) continue;
-        const float new_sdf = d - q2;
-        if (fabsf(new_sdf) < P.trunc) {
-            ++upd;
-            const float c0 = (float)rgb[3 * pix] / 255.0f, c1 = (float)rgb[3 * pix + 1] / 255.0f,
-                        c2 = (float)rgb[3 * pix + 2] / 255.0f;
-            float* vox = V.pool + (size_t)idx * kBlockFloats + vid;
-            const float s = vox[0], w = vox[kVox];
-            if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
-                // TSDFVoxel::operator+ with other = (new_sdf, 1.0, c) (TSDFVoxel.h:24-39)
-                const float wsum = w + 1.0f;
-                const float o0 = vox[2 * kVox], o1 = vox[3 * kVox], o2 = vox[4 * kVox];
-                vox[0] = (w * s + 1.0f * new_sdf) / wsum;
-                vox[kVox] = wsum;
-                vox[2 * kVox] = (w * o0 + 1.0f * c0) / wsum;
-                vox[3 * kVox] = (w * o1 + 1.0f * c1) / wsum;
-                vox[4 * kVox] = (w * o2 + 1.0f * c2) / wsum;
-            } else {
-                vox[0] = new_sdf; vox[kVox] = 1.0f;
-                vox[2 * kVox] = c0; vox[3 * kVox] = c1; vox[4 * kVox] = c2;
+        const float px = ((float)kx * 8.0f) * C.res + ox;
+        const float py = ((float)ky * 8.0f) * C.res + oy;
+        const float pz = ((float)kz * 8.0f) * C.res + oz;
+        uint2 rec[kMaxBatch];
+        float zc[kMaxBatch];
+#pragma unroll
+        for (int f = 0; f < kMaxBatch; ++f) {
+            rec[f] = make_uint2(0u, 0u);
+            zc[f] = 0.0f;
+            if ((mask >> f) & 1u) { // wave-uniform
+                // pose^-1 of frame f, fetched with scalar loads from the kernarg segment right here:
+                // keeping all 16 matrices (192 SGPRs) live across the block loop makes the compiler
+                // spill SGPRs through v_writelane/v_readlane (15 % of the instruction stream).
+                const float __attribute__((address_space(4)))* M = kargs + f * 12;
+                asm volatile("" : "+s"(M));
+                const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+                const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+                const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+                const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
+                const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
+                zc[f] = q2;
+                if (!(v < 0 || v >= C.height || u < 0 || u >= C.width)) rec[f] = pimg[(size_t)f * npix + (size_t)v * C.width + u];
             }
         }
+        bool changed = false;
+#pragma unroll
+        for (int f = 0; f < kMaxBatch; ++f) {
+            if ((mask >> f) & 1u) {
+                const float d = __uint_as_float(rec[f].x); // off-image pixels carry d == 0 -> skipped like `continue`
+                if (d > 0) {
+                    const float new_sdf = d - zc[f];
+                    if (fabsf(new_sdf) < C.trunc) {
+                        ++upd;
+                        changed = true;
+                        const unsigned rgba = rec[f].y;
+                        const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
+                        if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
+                            // TSDFVoxel::operator+ with other = (new_sdf, 1.0, c) (TSDFVoxel.h:24-39)
+                            const float wsum = w + 1.0f;
+                            s = (w * s + 1.0f * new_sdf) / wsum;
+                            c0 = (w * c0 + 1.0f * n0) / wsum;
+                            c1 = (w * c1 + 1.0f * n1) / wsum;
+                            c2 = (w * c2 + 1.0f * n2) / wsum;
+                            w = wsum;
+                        } else {
+                            s = new_sdf; w = 1.0f; c0 = n0; c1 = n1; c2 = n2;
+                        }
+                    }
+                }
+            }
+        }
+        if (changed) { vox[0] = s; vox[kVox] = w; vox[2 * kVox] = c0; vox[3 * kVox] = c1; vox[4 * kVox] = c2; }
     }
-    // per-workgroup update counter (each workgroup owns its slot: no atomics)
+    // every wave has read its masks: now the owner workgroup clears them for the next batch
+    __syncthreads();
+    for (unsigned b = blockIdx.x; b < n; b += gridDim.x)
+        if (vid == 0) V.bmask[V.blist[b]] = 0u;
+    // per-workgroup counters (each workgroup owns its slot: no atomics)
     upd = wave_sum(upd);
     if ((vid & 63) == 0) s_upd[vid >> 6] = upd;
     __syncthreads();
     if (vid == 0) {
         unsigned t = 0;
-        for (int w = 0; w < 8; ++w) t += s_upd[w];
+        for (int k = 0; k < 8; ++k) t += s_upd[k];
         upd_partial[blockIdx.x] += t;
-        if (blockIdx.x == 0) { st->stat_frames += 1; st->stat_sel += n; }
+        sel_partial[blockIdx.x] += sel;
+        if (blockIdx.x == 0) st->stat_frames += (unsigned long long)n_frames;
     }
 }
 
@@ -460,37 +548,26 @@ __global__ __launch_bounds__(512) void k_export_aos(const float* __restrict__ po
     for (int p = 0; p < 5; ++p) dst[p] = src[p * kVox];
 }
 
-// insert (distinct) keys; slots[i] receives the pool slot of key i (existing or new)
-__global__ void k_insert_keys(VolView V, const int* __restrict__ keys, size_t n, int* __restrict__ slots, FrameState* st) {
+// insert keys; slots[i] receives the TABLE slot of key i, encoded -(slot+2) when newly created; the
+// consumers below translate it to the pool slot through tvals (next kernel => visible)
+__global__ void k_insert_keys(VolView V, const int* __restrict__ keys, size_t n, int* __restrict__ slots, State* st) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int x = keys[3 * i], y = keys[3 * i + 1], z = keys[3 * i + 2];
-    int slot;
-    int idx = table_find_or_reserve(V, x, y, z, &slot);
-    if (idx < 0) {
-        if (slot < 0) { atomicOr(&st->overflow, 2u); slots[i] = -1; return; }
-        const unsigned nb = atomicAdd(V.n_blocks, 1u);
-        if (nb >= V.max_blocks) {
-            atomicOr(&st->overflow, 1u);
-            atomicExch(&((int*)&V.table[slot])[3], kDead);
-            slots[i] = -1;
-            return;
-        }
-        idx = (int)nb;
-        V.keys[3 * idx] = x; V.keys[3 * idx + 1] = y; V.keys[3 * idx + 2] = z;
-        table_publish(V, slot, x, y, z, idx);
-        slots[i] = -(idx + 2); // encoded "newly created": <= -2
-        return;
-    }
-    slots[i] = idx;
+    if (!key_in_range(x, y, z)) { atomicOr(&st->overflow, 8u); slots[i] = -1; return; }
+    bool created;
+    const int slot = table_claim(V, st, x, y, z, &created);
+    slots[i] = slot < 0 ? -1 : (created ? -(slot + 2) : slot);
 }
 
 // AoS voxels -> pool planes for the given slots (SetCubeMap / AddCube + assignment)
 __global__ __launch_bounds__(512) void k_import_aos(float* __restrict__ pool, const int* __restrict__ slots,
-                                                    const float* __restrict__ in) {
+                                                    const int* __restrict__ tvals, const float* __restrict__ in) {
     int idx = slots[blockIdx.x];
     if (idx == -1) return;
     if (idx <= -2) idx = -(idx + 2);
+    idx = tvals[idx]; // table slot -> pool slot
+    if (idx < 0) return;
     const float* src = in + ((size_t)blockIdx.x * kVox + threadIdx.x) * 5;
     float* dst = pool + (size_t)idx * kBlockFloats + threadIdx.x;
 #pragma unroll
@@ -500,11 +577,13 @@ __global__ __launch_bounds__(512) void k_import_aos(float* __restrict__ pool, co
 // CubeHandler::Merge (CubeHandler.h:145-167): dst block (slots) += src block (TSDFVoxel::operator+,
 // general weights), or plain copy when the block was just created in dst.
 __global__ __launch_bounds__(512) void k_merge_blocks(float* __restrict__ dpool, const float* __restrict__ spool,
-                                                      const int* __restrict__ slots) {
+                                                      const int* __restrict__ slots, const int* __restrict__ tvals) {
     int idx = slots[blockIdx.x];
     if (idx == -1) return;
     const bool fresh = idx <= -2;
     if (fresh) idx = -(idx + 2);
+    idx = tvals[idx]; // table slot -> pool slot
+    if (idx < 0) return;
     const float* a = spool + (size_t)blockIdx.x * kBlockFloats + threadIdx.x; // src block i lives in src pool slot i
     float* t = dpool + (size_t)idx * kBlockFloats + threadIdx.x;
     const float bs = a[0], bw = a[kVox], b0 = a[2 * kVox], b1 = a[3 * kVox], b2 = a[4 * kVox];
@@ -546,10 +625,12 @@ __global__ __launch_bounds__(512) void k_pack_sum(VolView V, const int* __restri
 
 // K4b: normalise the reduced sums back to mean form into the (re-keyed) volume.
 __global__ __launch_bounds__(512) void k_unpack_sum(float* __restrict__ pool, const int* __restrict__ slots,
-                                                    const float* __restrict__ sum) {
+                                                    const int* __restrict__ tvals, const float* __restrict__ sum) {
     int idx = slots[blockIdx.x];
     if (idx == -1) return;
     if (idx <= -2) idx = -(idx + 2);
+    idx = tvals[idx]; // table slot -> pool slot
+    if (idx < 0) return;
     const float* a = sum + (size_t)blockIdx.x * kBlockFloats + threadIdx.x;
     float* t = pool + (size_t)idx * kBlockFloats + threadIdx.x;
     const float w = a[kVox];
@@ -579,29 +660,36 @@ struct op_volume {
     unsigned max_blocks = 0;
     unsigned table_size = 0;
     // device memory
-    int4* table = nullptr;
+    unsigned long long* tkeys = nullptr;
+    int* tvals = nullptr;
     int* keys = nullptr;
     float* pool = nullptr;
     unsigned* n_blocks = nullptr;
+    unsigned* bmask = nullptr;
+    int* blist = nullptr;
     int* sel_list = nullptr;
     unsigned long long* sel_cand = nullptr;
-    FrameState* state = nullptr;
-    float* partial = nullptr;
-    int n_partial_cap = 0;
+    State* state = nullptr;
+    float* partial = nullptr;   // kMaxBatch x g1 x 8
+    uint2* pimg = nullptr;      // kMaxBatch x W*H packed {depth, rgba}
+    size_t pimg_px = 0;
     unsigned long long* upd_partial = nullptr;
-    // optional per-kernel HIP-event timing (op_volume_profile_*): every `prof_every`-th frame gets
-    // four events on the volume's stream (before K1, after K1, after K2, after K3)
+    unsigned long long* sel_partial = nullptr;
+    // optional HIP-event timing (op_volume_profile_*): every `prof_every`-th batch gets four events
+    // on the volume's stream (before KA, after KA, after KB, after KC); prof_frames = frames per sample
     int prof_every = 0;
-    uint64_t prof_frame = 0;
-    std::vector<hipEvent_t> prof_events; // 4 per sampled frame
+    uint64_t prof_batch = 0;
+    std::vector<hipEvent_t> prof_events; // 4 per sampled batch
+    std::vector<int> prof_frames;
     void* img_depth = nullptr; // staging for host images
     unsigned char* img_rgb = nullptr;
     size_t img_cap_px = 0;
 
     VolView view() const {
         VolView V;
-        V.table = table; V.table_mask = table_size - 1; V.keys = keys; V.pool = pool;
-        V.max_blocks = max_blocks; V.n_blocks = n_blocks; V.sel_list = sel_list; V.sel_cand = sel_cand;
+        V.tkeys = tkeys; V.tvals = tvals; V.table_mask = table_size - 1; V.keys = keys; V.pool = pool;
+        V.max_blocks = max_blocks; V.n_blocks = n_blocks; V.bmask = bmask; V.blist = blist;
+        V.sel_list = sel_list; V.sel_cand = sel_cand;
         return V;
     }
 };
@@ -609,10 +697,12 @@ struct op_volume {
 namespace {
 
 int vol_reset(op_volume* v) {
-    hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, v->table, (size_t)v->table_size);
+    hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, v->tkeys, v->tvals, (size_t)v->table_size);
     OP_HIP(hipMemsetAsync(v->n_blocks, 0, sizeof(unsigned), v->stream));
-    OP_HIP(hipMemsetAsync(v->state, 0, sizeof(FrameState), v->stream));
+    OP_HIP(hipMemsetAsync(v->bmask, 0, sizeof(unsigned) * (size_t)v->table_size, v->stream));
+    OP_HIP(hipMemsetAsync(v->state, 0, sizeof(State), v->stream));
     OP_HIP(hipMemsetAsync(v->upd_partial, 0, sizeof(unsigned long long) * kIntegrateGrid, v->stream));
+    OP_HIP(hipMemsetAsync(v->sel_partial, 0, sizeof(unsigned long long) * kIntegrateGrid, v->stream));
     OP_HIP(hipGetLastError());
     return OP_OK;
 }
@@ -625,6 +715,7 @@ int vol_check(op_volume* v) {
     if (of & 1u) return fail(OP_ERR_CAPACITY, "block pool exhausted (max_blocks = %u); create the volume with a larger max_blocks", v->max_blocks);
     if (of & 2u) return fail(OP_ERR_CAPACITY, "hash table exhausted (size %u)", v->table_size);
     if (of & 4u) return fail(OP_ERR_INVALID, "frame bounding box spans more than 4096 blocks on an axis");
+    if (of & 8u) return fail(OP_ERR_INVALID, "block coordinate outside +-2^20 (not representable in the device hash key)");
     return OP_OK;
 }
 
@@ -654,47 +745,78 @@ int vol_stage_images(op_volume* v, const void** depth, int depth_fmt, const unsi
     return OP_OK;
 }
 
-void make_params(const op_volume* v, const float pose[16], const float* pose_inv, int depth_fmt, FrameParams* P) {
-    std::memcpy(P->pose, pose, sizeof(P->pose));
-    if (pose_inv) std::memcpy(P->pose_inv, pose_inv, sizeof(P->pose_inv));
-    else op_host::mat4_inverse(pose, P->pose_inv);
-    op_host::CameraPOD c{v->cam.fx, v->cam.fy, v->cam.cx, v->cam.cy, v->cam.width, v->cam.height, v->cam.depth_scale};
-    op_host::frustum_planes(c, pose, v->far_d, v->near_d, P->planes);
-    P->fx = v->cam.fx; P->fy = v->cam.fy; P->cx = v->cam.cx; P->cy = v->cam.cy;
-    P->depth_scale = v->cam.depth_scale; P->res = v->res; P->trunc = v->trunc;
-    P->width = v->cam.width; P->height = v->cam.height; P->depth_u16 = depth_fmt == OP_DEPTH_U16;
+CamParams cam_params(const op_volume* v, int depth_fmt) {
+    CamParams C;
+    C.fx = v->cam.fx; C.fy = v->cam.fy; C.cx = v->cam.cx; C.cy = v->cam.cy;
+    C.depth_scale = v->cam.depth_scale; C.res = v->res; C.trunc = v->trunc;
+    C.width = v->cam.width; C.height = v->cam.height; C.depth_u16 = depth_fmt == OP_DEPTH_U16;
+    C.sx = px_split(C.cx); C.sy = px_split(C.cy);
+    C.fast_px = C.sx.exact && C.sy.exact;
+    return C;
 }
 
-int vol_ensure_partials(op_volume* v, int n) {
-    if (n <= v->n_partial_cap) return OP_OK;
+// per-frame host work of the path: frustum planes (Frustum.cpp:7-46) and pose^-1 (Integrator.cpp:48)
+void frame_params(const op_volume* v, const float pose[16], const float* pose_inv, PoseFwd* fwd, PoseInv* inv) {
+    std::memcpy(fwd->pose, pose, sizeof(fwd->pose));
+    op_host::CameraPOD c{v->cam.fx, v->cam.fy, v->cam.cx, v->cam.cy, v->cam.width, v->cam.height, v->cam.depth_scale};
+    op_host::frustum_planes(c, pose, v->far_d, v->near_d, fwd->planes);
+    float full[16];
+    if (pose_inv) std::memcpy(full, pose_inv, sizeof(full));
+    else op_host::mat4_inverse(pose, full);
+    std::memcpy(inv->m, full, sizeof(inv->m));
+}
+
+int vol_ensure_frame_buffers(op_volume* v) {
+    const size_t npx = (size_t)v->cam.width * v->cam.height;
+    if (npx <= v->pimg_px) return OP_OK;
+    if (v->pimg) OP_HIP(hipFree(v->pimg));
     if (v->partial) OP_HIP(hipFree(v->partial));
-    OP_HIP(hipMalloc((void**)&v->partial, (size_t)n * 8 * sizeof(float)));
-    v->n_partial_cap = n;
+    v->pimg = nullptr; v->partial = nullptr; v->pimg_px = 0;
+    const size_t g1 = (npx + kPixPerWg - 1) / kPixPerWg;
+    OP_HIP(hipMalloc((void**)&v->pimg, (size_t)kMaxBatch * npx * sizeof(uint2)));
+    OP_HIP(hipMalloc((void**)&v->partial, (size_t)kMaxBatch * g1 * 8 * sizeof(float)));
+    v->pimg_px = npx;
     return OP_OK;
 }
 
-// enqueue K1 + K2 (+ K3) for one frame whose images are already on the device
-int vol_enqueue_frame(op_volume* v, const FrameParams& P, const void* d_depth, const unsigned char* d_rgb, bool integrate) {
-    const int npix = P.width * P.height;
+// Enqueue one batch (1..kMaxBatch frames whose images are on the device): KA, KB and, unless
+// select_only, KC.  No host synchronisation.
+int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, int nf, int depth_fmt, const void* d_depth, size_t depth_stride,
+                      const unsigned char* d_rgb, size_t rgb_stride, bool select_only, bool record) {
+    OP_TRY(vol_ensure_frame_buffers(v));
+    const CamParams C = cam_params(v, depth_fmt);
+    const int npix = C.width * C.height;
     const int g1 = (npix + kPixPerWg - 1) / kPixPerWg;
-    OP_TRY(vol_ensure_partials(v, g1));
     const VolView V = v->view();
-    const bool sample = integrate && v->prof_every > 0 && (v->prof_frame++ % (uint64_t)v->prof_every) == 0 &&
+    const bool sample = !select_only && v->prof_every > 0 && (v->prof_batch++ % (uint64_t)v->prof_every) == 0 &&
                         v->prof_events.size() < 4 * 65536;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (sample) {
         for (auto& e : ev) OP_HIP(hipEventCreate(&e));
         OP_HIP(hipEventRecord(ev[0], v->stream));
     }
-    hipLaunchKernelGGL(k_bounding, dim3(g1), dim3(256), 0, v->stream, P, d_depth, v->partial, v->state);
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, d_depth, depth_stride, d_rgb, rgb_stride, v->pimg,
+                       v->partial, v->state);
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
-    hipLaunchKernelGGL(k_select, dim3(kSelectGrid), dim3(256), 0, v->stream, P, V, d_depth, (const float*)v->partial, g1, v->state);
+    if (C.fast_px)
+        hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
+                           (const float*)v->partial, g1, v->state, record ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_select<false>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
+                           (const float*)v->partial, g1, v->state, record ? 1 : 0);
     if (sample) OP_HIP(hipEventRecord(ev[2], v->stream));
-    if (integrate)
-        hipLaunchKernelGGL(k_integrate, dim3(kIntegrateGrid), dim3(512), 0, v->stream, P, V, d_depth, d_rgb, v->state, v->upd_partial);
+    if (select_only)
+        hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, (const State*)v->state);
+    else if (C.fast_px)
+        hipLaunchKernelGGL(k_integrate<true>, dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, v->state, nf,
+                           v->upd_partial, v->sel_partial);
+    else
+        hipLaunchKernelGGL(k_integrate<false>, dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, v->state, nf,
+                           v->upd_partial, v->sel_partial);
     if (sample) {
         OP_HIP(hipEventRecord(ev[3], v->stream));
         for (auto e : ev) v->prof_events.push_back(e);
+        v->prof_frames.push_back(nf);
     }
     OP_HIP(hipGetLastError());
     return OP_OK;
@@ -745,6 +867,10 @@ int op_frustum_planes(const op_camera* cam, const float pose[16], float far_dist
     return OP_OK;
 }
 
+int op_debug_project_px(float a, float c, int fast) {
+    return fast ? px_round_sp(a, px_split(c)) : px_round_dp(a, c);
+}
+
 int op_se3_exp(const float x[6], float T[16]) {
     if (!x || !T) return fail(OP_ERR_INVALID, "null argument");
     op_host::se3_exp(x, T);
@@ -767,13 +893,17 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     auto cleanup = [&](int rc) { op_volume_destroy(v); return rc; };
 #define OP_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(OP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
     OP_HIP_C(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
-    OP_HIP_C(hipMalloc((void**)&v->table, sizeof(int4) * (size_t)v->table_size));
+    OP_HIP_C(hipMalloc((void**)&v->tkeys, sizeof(unsigned long long) * (size_t)v->table_size));
+    OP_HIP_C(hipMalloc((void**)&v->tvals, sizeof(int) * (size_t)v->table_size));
+    OP_HIP_C(hipMalloc((void**)&v->bmask, sizeof(unsigned) * (size_t)v->table_size));
+    OP_HIP_C(hipMalloc((void**)&v->blist, sizeof(int) * (size_t)v->max_blocks));
+    OP_HIP_C(hipMalloc((void**)&v->sel_partial, sizeof(unsigned long long) * kIntegrateGrid));
     OP_HIP_C(hipMalloc((void**)&v->keys, sizeof(int) * 3 * (size_t)v->max_blocks));
     OP_HIP_C(hipMalloc((void**)&v->pool, sizeof(float) * kBlockFloats * (size_t)v->max_blocks));
     OP_HIP_C(hipMalloc((void**)&v->n_blocks, sizeof(unsigned)));
     OP_HIP_C(hipMalloc((void**)&v->sel_list, sizeof(int) * (size_t)v->max_blocks));
     OP_HIP_C(hipMalloc((void**)&v->sel_cand, sizeof(unsigned long long) * (size_t)v->max_blocks));
-    OP_HIP_C(hipMalloc((void**)&v->state, sizeof(FrameState)));
+    OP_HIP_C(hipMalloc((void**)&v->state, sizeof(State)));
     OP_HIP_C(hipMalloc((void**)&v->upd_partial, sizeof(unsigned long long) * kIntegrateGrid));
 #undef OP_HIP_C
     hipLaunchKernelGGL(k_fill_pool, dim3(4096), dim3(256), 0, v->stream, v->pool, (size_t)0, (size_t)v->max_blocks);
@@ -789,8 +919,8 @@ int op_volume_destroy(op_volume* v) {
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
-    void* ptrs[] = {v->table, v->keys, v->pool, v->n_blocks, v->sel_list, v->sel_cand, v->state, v->partial,
-                    v->upd_partial, v->img_depth, v->img_rgb};
+    void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
+                    v->partial, v->pimg, v->upd_partial, v->sel_partial, v->img_depth, v->img_rgb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (v->stream) (void)hipStreamDestroy(v->stream);
@@ -863,11 +993,14 @@ int op_volume_compute_bounding(op_volume* v, const void* depth, int depth_fmt, i
     OP_VOL(v);
     if (!depth || !pose) return fail(OP_ERR_INVALID, "null argument");
     OP_TRY(vol_stage_images(v, &depth, depth_fmt, nullptr, mem));
-    FrameParams P;
-    make_params(v, pose, nullptr, depth_fmt, &P);
-    const int npix = P.width * P.height, g1 = (npix + kPixPerWg - 1) / kPixPerWg;
-    OP_TRY(vol_ensure_partials(v, g1));
-    hipLaunchKernelGGL(k_bounding, dim3(g1), dim3(256), 0, v->stream, P, depth, v->partial, v->state);
+    OP_TRY(vol_ensure_frame_buffers(v));
+    BatchFwd F;
+    BatchInv I;
+    frame_params(v, pose, nullptr, &F.f[0], &I.f[0]);
+    const CamParams C = cam_params(v, depth_fmt);
+    const int npix = C.width * C.height, g1 = (npix + kPixPerWg - 1) / kPixPerWg;
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, depth, (size_t)0, (const unsigned char*)nullptr, (size_t)0,
+                       v->pimg, v->partial, v->state);
     OP_HIP(hipGetLastError());
     OP_HIP(hipStreamSynchronize(v->stream));
     std::vector<float> part((size_t)g1 * 8);
@@ -894,15 +1027,16 @@ int op_volume_prepare_cubes(op_volume* v, const void* depth, int depth_fmt, int 
     OP_VOL(v);
     if (!depth || !pose) return fail(OP_ERR_INVALID, "null argument");
     OP_TRY(vol_stage_images(v, &depth, depth_fmt, nullptr, mem));
-    FrameParams P;
-    make_params(v, pose, pose_inv, depth_fmt, &P);
-    OP_TRY(vol_enqueue_frame(v, P, depth, nullptr, false));
+    BatchFwd F;
+    BatchInv I;
+    frame_params(v, pose, pose_inv, &F.f[0], &I.f[0]);
+    OP_TRY(vol_enqueue_batch(v, F, I, 1, depth_fmt, depth, 0, nullptr, 0, /*select_only=*/true, /*record=*/true));
     OP_TRY(vol_check(v));
-    FrameState st;
+    State st;
     OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
-    const size_t ns = st.n_sel;
+    const size_t ns = std::min((size_t)st.n_rec, (size_t)v->max_blocks);
     if (n) *n = ns;
-    if (n_candidates) *n_candidates = (size_t)st.n_cand;
+    if (n_candidates) *n_candidates = (size_t)st.n_cand[0];
     if (ids_xyz && ns) {
         std::vector<int> list(ns);
         std::vector<unsigned long long> cand(ns);
@@ -930,19 +1064,28 @@ int op_volume_integrate(op_volume* v, const void* depth, int depth_fmt, const ui
     if (!depth || !rgb || !pose) return fail(OP_ERR_INVALID, "null argument");
     const unsigned char* c = rgb;
     OP_TRY(vol_stage_images(v, &depth, depth_fmt, &c, mem));
-    FrameParams P;
-    make_params(v, pose, pose_inv, depth_fmt, &P);
-    return vol_enqueue_frame(v, P, depth, c, true);
+    BatchFwd F;
+    BatchInv I;
+    frame_params(v, pose, pose_inv, &F.f[0], &I.f[0]);
+    return vol_enqueue_batch(v, F, I, 1, depth_fmt, depth, 0, c, 0, false, false);
 }
 
 int op_volume_integrate_sequence(op_volume* v, const void* depth, size_t depth_stride_bytes, int depth_fmt, const uint8_t* rgb,
                                  size_t rgb_stride_bytes, const float* poses, size_t n_frames) {
     OP_VOL(v);
     if (!depth || !rgb || !poses) return fail(OP_ERR_INVALID, "null argument");
-    FrameParams P;
-    for (size_t f = 0; f < n_frames; ++f) {
-        make_params(v, poses + 16 * f, nullptr, depth_fmt, &P);
-        OP_TRY(vol_enqueue_frame(v, P, (const char*)depth + f * depth_stride_bytes, rgb + f * rgb_stride_bytes, true));
+    BatchFwd F;
+    BatchInv I;
+    // balanced batches (sizes differ by at most one): 100 frames -> 7 launches of 14-15 frames
+    // rather than 6 x 16 + 4, so no launch group is left with a poorly amortised tail
+    const size_t n_batches = (n_frames + kMaxBatch - 1) / kMaxBatch;
+    size_t f0 = 0;
+    for (size_t b = 0; b < n_batches; ++b) {
+        const int nf = (int)(n_frames / n_batches + (b < n_frames % n_batches ? 1 : 0));
+        for (int f = 0; f < nf; ++f) frame_params(v, poses + 16 * (f0 + f), nullptr, &F.f[f], &I.f[f]);
+        OP_TRY(vol_enqueue_batch(v, F, I, nf, depth_fmt, (const char*)depth + f0 * depth_stride_bytes, depth_stride_bytes,
+                                 rgb + f0 * rgb_stride_bytes, rgb_stride_bytes, false, false));
+        f0 += (size_t)nf;
     }
     return OP_OK;
 }
@@ -950,15 +1093,16 @@ int op_volume_integrate_sequence(op_volume* v, const void* depth, size_t depth_s
 int op_volume_stats(op_volume* v, uint64_t* frames, uint64_t* blocks_selected, uint64_t* voxels_visited, uint64_t* voxels_updated) {
     OP_VOL(v);
     OP_TRY(vol_check(v));
-    FrameState st;
+    State st;
     OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
-    std::vector<unsigned long long> part(kIntegrateGrid);
-    OP_HIP(hipMemcpy(part.data(), v->upd_partial, part.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long upd = 0;
-    for (auto p : part) upd += p;
+    std::vector<unsigned long long> part(2 * kIntegrateGrid);
+    OP_HIP(hipMemcpy(part.data(), v->upd_partial, kIntegrateGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    OP_HIP(hipMemcpy(part.data() + kIntegrateGrid, v->sel_partial, kIntegrateGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long upd = 0, sel = 0;
+    for (int i = 0; i < kIntegrateGrid; ++i) { upd += part[i]; sel += part[kIntegrateGrid + i]; }
     if (frames) *frames = st.stat_frames;
-    if (blocks_selected) *blocks_selected = st.stat_sel;
-    if (voxels_visited) *voxels_visited = st.stat_sel * (uint64_t)kVox;
+    if (blocks_selected) *blocks_selected = sel;
+    if (voxels_visited) *voxels_visited = sel * (uint64_t)kVox;
     if (voxels_updated) *voxels_updated = upd;
     return OP_OK;
 }
@@ -968,24 +1112,29 @@ int op_volume_profile_enable(op_volume* v, int sample_every) {
     OP_HIP(hipStreamSynchronize(v->stream));
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     v->prof_events.clear();
+    v->prof_frames.clear();
     v->prof_every = sample_every > 0 ? sample_every : 0;
-    v->prof_frame = 0;
+    v->prof_batch = 0;
     return OP_OK;
 }
 
-int op_volume_profile_read(op_volume* v, double ms_sum[3], uint64_t* n_samples) {
+int op_volume_profile_read(op_volume* v, double ms_sum[3], uint64_t* n_launches, uint64_t* n_frames) {
     OP_VOL(v);
-    if (!ms_sum || !n_samples) return fail(OP_ERR_INVALID, "null argument");
+    if (!ms_sum || !n_launches || !n_frames) return fail(OP_ERR_INVALID, "null argument");
     OP_HIP(hipStreamSynchronize(v->stream));
     ms_sum[0] = ms_sum[1] = ms_sum[2] = 0.0;
     const size_t n = v->prof_events.size() / 4;
-    for (size_t i = 0; i < n; ++i)
+    uint64_t frames = 0;
+    for (size_t i = 0; i < n; ++i) {
         for (int k = 0; k < 3; ++k) {
             float ms = 0.0f;
             OP_HIP(hipEventElapsedTime(&ms, v->prof_events[4 * i + k], v->prof_events[4 * i + k + 1]));
             ms_sum[k] += ms;
         }
-    *n_samples = n;
+        frames += (uint64_t)v->prof_frames[i];
+    }
+    *n_launches = n;
+    *n_frames = frames;
     return OP_OK;
 }
 
@@ -1060,7 +1209,7 @@ int op_volume_upload(op_volume* v, const int32_t* keys_xyz, const float* voxels_
         if (e == hipSuccess) e = hipMemcpy(d_vox, hv.data(), cnt * kBlockFloats * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_keys, cnt, d_slots, v->state);
-            hipLaunchKernelGGL(k_import_aos, dim3((unsigned)cnt), dim3(512), 0, v->stream, v->pool, (const int*)d_slots, (const float*)d_vox);
+            hipLaunchKernelGGL(k_import_aos, dim3((unsigned)cnt), dim3(512), 0, v->stream, v->pool, (const int*)d_slots, (const int*)v->tvals, (const float*)d_vox);
             e = hipStreamSynchronize(v->stream);
         }
         if (e != hipSuccess) rc = fail(OP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
@@ -1084,7 +1233,7 @@ int op_volume_merge(op_volume* dst, op_volume* src) {
     int* d_slots = nullptr;
     OP_HIP(hipMalloc((void**)&d_slots, (size_t)ns * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((ns + 255) / 256), dim3(256), 0, dst->stream, dst->view(), (const int*)src->keys, (size_t)ns, d_slots, dst->state);
-    hipLaunchKernelGGL(k_merge_blocks, dim3(ns), dim3(512), 0, dst->stream, dst->pool, (const float*)src->pool, (const int*)d_slots);
+    hipLaunchKernelGGL(k_merge_blocks, dim3(ns), dim3(512), 0, dst->stream, dst->pool, (const float*)src->pool, (const int*)d_slots, (const int*)dst->tvals);
     hipError_t e = hipStreamSynchronize(dst->stream);
     (void)hipFree(d_slots);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "merge failed: %s", hipGetErrorString(e));
@@ -1121,7 +1270,7 @@ int op_volume_unpack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_uni
     int* d_slots = nullptr;
     OP_HIP(hipMalloc((void**)&d_slots, n_union * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, d_slots, v->state);
-    hipLaunchKernelGGL(k_unpack_sum, dim3((unsigned)n_union), dim3(512), 0, v->stream, v->pool, (const int*)d_slots, d_sum);
+    hipLaunchKernelGGL(k_unpack_sum, dim3((unsigned)n_union), dim3(512), 0, v->stream, v->pool, (const int*)d_slots, (const int*)v->tvals, d_sum);
     hipError_t e = hipStreamSynchronize(v->stream);
     (void)hipFree(d_slots);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "unpack failed: %s", hipGetErrorString(e));

@@ -180,12 +180,13 @@ class CubeHandler:
         L.check(self._lib.op_volume_profile_enable(self._h, int(sample_every)))
 
     def ProfileRead(self):
+        """-> per-LAUNCH average ms of the three kernels + launches/frames covered by the samples."""
         ms = (C.c_double * 3)()
-        n = C.c_uint64(0)
-        L.check(self._lib.op_volume_profile_read(self._h, ms, C.byref(n)))
-        n = int(n.value)
-        names = ("bounding_ms", "select_ms", "integrate_ms")
-        return {"samples": n, **{k: (ms[i] / n if n else float("nan")) for i, k in enumerate(names)}}
+        n, nf = C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib.op_volume_profile_read(self._h, ms, C.byref(n), C.byref(nf)))
+        n, nf = int(n.value), int(nf.value)
+        names = ("prepare_ms", "select_ms", "integrate_ms")
+        return {"launches": n, "frames": nf, **{k: (ms[i] / n if n else float("nan")) for i, k in enumerate(names)}}
 
     # -- accessors (all synchronise)
     def BlockCount(self):

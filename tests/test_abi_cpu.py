@@ -98,3 +98,59 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), f
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "libonepiece_oracle" not in text and "dlopen" not in text, f
+
+
+def test_pixel_rounding_fast_path_equals_double_formula(hip):
+    """csrc/px_round.hpp: the fp32/integer pixel rounding the kernels use must give the same int as
+    the reference's double formula (Integrator.cpp:20-21) wherever the bounds test can pass, and
+    must reject exactly the same values elsewhere.  Host build of the same inline functions."""
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent(r'''
+        #include <cstdio>
+        #include <cstdint>
+        #include <cstring>
+        #include "px_round.hpp"
+        int main() {
+            float cs[12] = {318.771f, 238.447f, 318.6f, 255.3f, 79.69275f, 59.61175f, 0.0f, 756.24762f, 530.00418f, -3.25f, 1.0f, 99999.25f};
+            uint32_t st = 12345u; long bad = 0, n = 0;
+            auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st; };
+            if (px_split(99999.5f).exact || px_split(0.3f).exact) { printf("inexact splits must be refused\n"); return 2; }
+            for (int rep = 0; rep < 2; ++rep)
+            for (float& c : cs) {
+                if (rep == 1) c = 1.0f + (float)(rnd() >> 8) * (2000.0f / 16777216.0f); // random principal points
+                const PxSplit sp = px_split(c);
+                if (!sp.exact) { if (rep == 1) { n += 3500000 / 2; continue; } printf("split of %g not exact\n", c); return 2; }
+                for (long it = 0; it < 3500000 / 2; ++it) {
+                    float a; const int mode = it % 8;
+                    if (mode < 3) { uint32_t b = rnd(); memcpy(&a, &b, 4); }
+                    else if (mode < 6) { a = ((int)(rnd() >> 8) % 4000000 - 2000000) / 1000.0f; a += (float)(rnd() >> 9) * 1.1920929e-10f; }
+                    else { int k = (int)(rnd() >> 20) % 1400 - 700; float base = (float)((double)k - (double)c - 0.5 + (mode == 7 ? 1.0 : 0.0));
+                           int32_t bi; memcpy(&bi, &base, 4); bi += (int)(rnd() >> 28) - 8; memcpy(&a, &bi, 4); }
+                    const int r0 = px_round_dp(a, c), r1 = px_round_sp(a, sp); ++n;
+                    const bool rej0 = r0 < 0 || r0 >= 100000000, rej1 = r1 < 0 || r1 >= 100000000;
+                    if (!(r0 == r1 || (rej0 && rej1))) { if (bad < 5) printf("c=%g a=%.9g dp=%d sp=%d\n", c, a, r0, r1); ++bad; }
+                }
+            }
+            printf("%ld %ld\n", n, bad);
+            return bad != 0;
+        }
+    ''')
+    with tempfile.TemporaryDirectory() as td:
+        cpp = os.path.join(td, "t.cpp")
+        open(cpp, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "onepiece_amd", "csrc"), cpp, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout
+        n, bad = map(int, out.stdout.split()[-2:])
+        assert n == 2 * 12 * (3500000 // 2) and bad == 0
+    # and the library's own hook agrees with numpy's double evaluation on pixel-scale values
+    lib = hip.load()
+    rng = np.random.default_rng(3)
+    for c in (318.771, 238.447):
+        a = (rng.uniform(-700, 1400, 20000)).astype(np.float32)
+        ref = np.trunc(a.astype(np.float64) + 0.5 + np.float64(np.float32(c))).astype(np.int64)
+        got = np.array([lib.op_debug_project_px(float(x), float(np.float32(c)), 1) for x in a[:4000]])
+        assert np.array_equal(got, ref[:4000])
+    assert lib.op_debug_project_px(float("nan"), 318.771, 1) == -2**31 == lib.op_debug_project_px(float("nan"), 318.771, 0)
+    assert lib.op_debug_project_px(-0.6, 0.0, 1) == 0 == lib.op_debug_project_px(-0.6, 0.0, 0)   # (-1,0) truncates to 0

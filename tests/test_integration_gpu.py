@@ -196,3 +196,38 @@ def test_sum_form_merge_kernels_match_reference_merge(oracle):
     _compare(oracle, ov1, hv1, exact=False)
     # world_size == 1 path of merge_volumes is a no-op that reports the block count
     assert D.merge_volumes(o2) == hv2.BlockCount()
+
+
+def test_batched_sequence_over_batch_boundary_matches_oracle(oracle):
+    """37 device-resident frames = batches of 16 + 16 + 5 inside op_volume_integrate_sequence; a
+    voxel sees its frames in order inside a batch, so the result must stay bit-identical to the
+    oracle's frame-by-frame fusion.  Includes frames that revisit the same blocks."""
+    import torch
+    dev = torch.device("cuda:0")
+    depth, rgb, poses = S.room_sequence_torch(990, 37, dev)   # crosses the orbit wrap-around (frames 990..1026)
+    torch.cuda.synchronize()
+    ov, hv = _mk(oracle, 0.01)
+    hv.IntegrateSequence(depth, rgb, poses)
+    dn, cn = depth.cpu().numpy(), rgb.cpu().numpy()
+    sel = upd = 0
+    for k in range(37):
+        n, _vis, nu = ov.integrate(dn[k], cn[k], poses[k])
+        sel += n; upd += nu
+    st = hv.Stats()
+    assert st["frames"] == 37 and st["blocks_selected"] == sel and st["voxels_updated"] == upd
+    _compare(oracle, ov, hv)
+    # a second pass over the same frames (every voxel already valid) stays exact too
+    hv.IntegrateSequence(depth, rgb, poses)
+    for k in range(37):
+        ov.integrate(dn[k], cn[k], poses[k])
+    _compare(oracle, ov, hv)
+
+
+def test_prepare_cubes_leaves_no_pending_selection(oracle):
+    """PrepareCubes allocates blocks but must not leak its selection into the next IntegrateImage."""
+    ov, hv = _mk(oracle, 0.01)
+    d0, c0, p0 = S.room_frame(0)
+    d1, c1, p1 = S.room_frame(400)
+    ov.prepare_cubes(d0, p0); hv.PrepareCubes(d0, p0)
+    ov.integrate(d1, c1, p1); hv.IntegrateImage(d1, c1, p1)
+    _compare(oracle, ov, hv)

@@ -16,3 +16,6 @@ for rep in range(3):
     print("rep", rep, "frames", n, "ms/frame %.4f" % (dt / n * 1e3), "fps %.1f" % (n / dt), st, "blocks", hv.BlockCount())
     bytes_ = 40 * st["voxels_updated"] + 7 * 307200 * st["frames"]
     print("   algorithmic GB/s over whole path: %.1f" % (bytes_ / dt / 1e9))
+hv.Clear(); hv.ProfileEnable(1)
+hv.IntegrateSequence(depth, rgb, poses); hv.Synchronize()
+print(hv.ProfileRead())
