@@ -139,6 +139,22 @@ int op_volume_upload(op_volume *v, const int32_t *keys_xyz, const float *voxels_
 /* CubeHandler::Merge(const CubeHandler&) (CubeHandler.h:145-167), both volumes on one device. */
 int op_volume_merge(op_volume *dst, op_volume *src);
 
+/* CubeHandler::Transform (nearest = 0, trilinear ReadVoxelInterpolate, CubeHandler.h:242-298,
+ * VoxelCube.cpp:6-50) / CubeHandler::TransformNearest (nearest = 1, CubeHandler.h:299-338) on the
+ * device: returns a NEW volume on the same device (destroy it with op_volume_destroy).  T_inv may
+ * be NULL.  The reference's quirk is kept: TransformNearest's result has the default voxel
+ * resolution 0.01 and allocates its blocks with it.  max_blocks = 0 sizes the result automatically. */
+int op_volume_transform(op_volume *src, const float T[16], const float *T_inv, int nearest,
+                        uint64_t max_blocks, op_volume **out);
+int op_volume_resolution(op_volume *v, float *voxel_res);
+/* CubeHandler::GetPointCloud (CubeHandler.cpp:45-69): points and grey colours |sdf|/truncation
+ * (n x 3 floats each, host).  *n is the full count; xyz/colors may be NULL to query it. */
+int op_volume_point_cloud(op_volume *v, float *xyz, float *colors, size_t cap, size_t *n);
+/* CubeHandler::WriteToFile / ReadFromFile / ReadFromFileFloat (CubeHandler.h:40-128): the .map
+ * float-stream format (VoxelCube.h:128-193).  Blocks are written in pool order. */
+int op_volume_write_file(op_volume *v, const char *path);
+int op_volume_read_file(op_volume *v, const char *path, int legacy_float_format);
+
 /* Frame-sharded multi-GPU merge (the distributed form of CubeHandler::Merge; DESIGN.md "Multi-GPU").
  * All pointers are DEVICE pointers on the volume's device.
  *   keys_device : copy this volume's block keys (n x 3 int32) into d_keys.

@@ -641,6 +641,143 @@ __global__ __launch_bounds__(512) void k_unpack_sum(float* __restrict__ pool, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Volume resampling (CubeHandler::Transform / TransformNearest, CubeHandler.h:199-338) and
+// GetPointCloud (CubeHandler.cpp:45-69)
+// ---------------------------------------------------------------------------------------------
+struct Mat4 { float m[16]; };
+struct Vox5 { float s, w, c0, c1, c2; };
+
+__device__ __forceinline__ Vox5 default_voxel() { return Vox5{999.0f, 0.0f, -1.0f, -1.0f, -1.0f}; }
+
+// cube_map.find(GetCubeID(p)) + GetVoxel(GetVoxelID(p)) (VoxelCube.h:63-67,81-86); default voxel if absent
+__device__ Vox5 fetch_voxel(const VolView& S, int px, int py, int pz) {
+    const int cx = px >> 3, cy = py >> 3, cz = pz >> 3; // floor((p + 0.0) / 8)
+    const int idx = table_find(S, cx, cy, cz);
+    if (idx < 0) return default_voxel();
+    const int vid = (px - cx * 8) + (py - cy * 8) * 8 + (pz - cz * 8) * 64;
+    const float* t = S.pool + (size_t)idx * kBlockFloats + vid;
+    return Vox5{t[0], t[kVox], t[2 * kVox], t[3 * kVox], t[4 * kVox]};
+}
+// TSDFVoxel::operator*(float) (TSDFVoxel.h:56-67)
+__device__ __forceinline__ Vox5 vox_scale(const Vox5& a, float wgt) {
+    if (wgt == 0 || a.w == 0) return default_voxel();
+    return Vox5{a.s * wgt, a.w * wgt, a.c0 * wgt, a.c1 * wgt, a.c2 * wgt};
+}
+// TSDFVoxel::add (TSDFVoxel.h:40-51)
+__device__ __forceinline__ Vox5 vox_add_direct(const Vox5& a, const Vox5& b) {
+    if (a.w == 0) return b;
+    if (b.w == 0) return a;
+    return Vox5{a.s + b.s, a.w + b.w, a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2};
+}
+// one stage of ReadVoxelInterpolate (VoxelCube.cpp:17-20):
+// ((a * (1 - t)).add(b * t)) / ((1 - t) * (a.weight != 0) + t * (b.weight != 0))
+__device__ __forceinline__ Vox5 interp_stage(const Vox5& a, const Vox5& b, float t) {
+    if (!(a.w != 0 || b.w != 0)) return default_voxel();
+    const Vox5 sum = vox_add_direct(vox_scale(a, 1 - t), vox_scale(b, t));
+    const float d = (1 - t) * (float)(a.w != 0) + t * (float)(b.w != 0);
+    return vox_scale(sum, 1 / d); // operator/(w) = operator*(1 / w) (TSDFVoxel.h:68-71)
+}
+
+// pass 1: AddTransformedCube / AddTransformedCubeNearest (CubeHandler.h:199-241), executed with the
+// RESULT's CubePara (alloc_res).  One workgroup per source block.
+template <bool NEAREST>
+__global__ __launch_bounds__(512) void k_transform_alloc(VolView S, VolView D, State* dst_state, Mat4 T, float alloc_res) {
+    const int b = blockIdx.x, vid = threadIdx.x;
+    const int kx = S.keys[3 * b], ky = S.keys[3 * b + 1], kz = S.keys[3 * b + 2];
+    const float half = alloc_res / 2;
+    const float px = ((float)kx * 8.0f) * alloc_res + ((float)(vid & 7) * alloc_res + half);
+    const float py = ((float)ky * 8.0f) * alloc_res + ((float)((vid >> 3) & 7) * alloc_res + half);
+    const float pz = ((float)kz * 8.0f) * alloc_res + ((float)(vid >> 6) * alloc_res + half);
+    const float* M = T.m;
+    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+    const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+    const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+    const float q3 = ((M[12] * px + M[13] * py) + M[14] * pz) + M[15] * 1.0f;
+    const float n0 = NEAREST ? q0 / q3 : q0 / q3 - half, n1 = NEAREST ? q1 / q3 : q1 / q3 - half,
+                n2 = NEAREST ? q2 / q3 : q2 / q3 - half;
+    const int p0 = (int)floorf(n0 / alloc_res), p1 = (int)floorf(n1 / alloc_res), p2 = (int)floorf(n2 / alloc_res);
+    int lx = INT_MIN, ly = INT_MIN, lz = INT_MIN;
+#pragma unroll
+    for (int k = 0; k < (NEAREST ? 1 : 8); ++k) {
+        const int cx = (p0 + (k & 1)) >> 3, cy = (p1 + ((k >> 1) & 1)) >> 3, cz = (p2 + ((k >> 2) & 1)) >> 3;
+        if (cx == lx && cy == ly && cz == lz) continue;
+        lx = cx; ly = cy; lz = cz;
+        if (!key_in_range(cx, cy, cz)) { atomicOr(&dst_state->overflow, 8u); continue; }
+        bool created;
+        table_claim(D, dst_state, cx, cy, cz, &created); // AddCube
+    }
+}
+
+// pass 2: every voxel of the result reads the source through trans^-1 (CubeHandler.h:257-294 /
+// :312-334) with the SOURCE's CubePara (this->c_para).  One workgroup per result block; result
+// voxels are still default, so `voxels[voxel_id] += result` stores `result` (weight == 0 -> other).
+template <bool NEAREST>
+__global__ __launch_bounds__(512) void k_transform_fill(VolView S, VolView D, Mat4 Tinv, float src_res) {
+    const int b = blockIdx.x, vid = threadIdx.x;
+    const int kx = D.keys[3 * b], ky = D.keys[3 * b + 1], kz = D.keys[3 * b + 2];
+    const float half = src_res / 2;
+    const float px = ((float)kx * 8.0f) * src_res + ((float)(vid & 7) * src_res + half);
+    const float py = ((float)ky * 8.0f) * src_res + ((float)((vid >> 3) & 7) * src_res + half);
+    const float pz = ((float)kz * 8.0f) * src_res + ((float)(vid >> 6) * src_res + half);
+    const float* M = Tinv.m;
+    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+    const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+    const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+    const float q3 = ((M[12] * px + M[13] * py) + M[14] * pz) + M[15] * 1.0f;
+    const float n0 = NEAREST ? q0 / q3 : q0 / q3 - half, n1 = NEAREST ? q1 / q3 : q1 / q3 - half,
+                n2 = NEAREST ? q2 / q3 : q2 / q3 - half;
+    const int p0 = (int)floorf(n0 / src_res), p1 = (int)floorf(n1 / src_res), p2 = (int)floorf(n2 / src_res);
+    Vox5 r;
+    if (NEAREST) {
+        r = fetch_voxel(S, p0, p1, p2);
+    } else {
+        Vox5 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fetch_voxel(S, p0 + (k & 1), p1 + ((k >> 1) & 1), p2 + ((k >> 2) & 1));
+        // ReadVoxelInterpolate (VoxelCube.cpp:6-50)
+        const float xw = (n0 - (float)p0 * src_res) / src_res, yw = (n1 - (float)p1 * src_res) / src_res,
+                    zw = (n2 - (float)p2 * src_res) / src_res;
+        const Vox5 z1 = interp_stage(interp_stage(v[0], v[1], xw), interp_stage(v[2], v[3], xw), yw);
+        const Vox5 z2 = interp_stage(interp_stage(v[4], v[5], xw), interp_stage(v[6], v[7], xw), yw);
+        r = interp_stage(z1, z2, zw);
+    }
+    float* t = D.pool + (size_t)b * kBlockFloats + vid;
+    t[0] = r.s; t[kVox] = r.w; t[2 * kVox] = r.c0; t[3 * kVox] = r.c1; t[4 * kVox] = r.c2;
+}
+
+// GetPointCloud: voxels with weight != 0 and |sdf| < truncation, in the reference's x,y,z loop order
+// inside a block.  counts == nullptr: emit using offsets; else count only.
+__global__ __launch_bounds__(512) void k_point_cloud(VolView V, float res, float trunc, unsigned* __restrict__ counts,
+                                                     const unsigned* __restrict__ offsets, float* __restrict__ xyz,
+                                                     float* __restrict__ col) {
+    __shared__ unsigned s_w[8];
+    const int b = blockIdx.x, o = threadIdx.x;
+    const int x = o >> 6, y = (o >> 3) & 7, z = o & 7; // loop nest: x outer, y, z inner
+    const int vid = x + y * 8 + z * 64;
+    const float* t = V.pool + (size_t)b * kBlockFloats + vid;
+    const float sdf = t[0], w = t[kVox];
+    const bool ok = w != 0 && fabsf(sdf) < trunc;
+    const unsigned long long m = __ballot(ok);
+    const int lane = o & 63, wave = o >> 6;
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    if (counts) {
+        if (o == 0) { unsigned tot = 0; for (int k = 0; k < 8; ++k) tot += s_w[k]; counts[b] = tot; }
+        return;
+    }
+    if (!ok) return;
+    unsigned rank = __popcll(m & ((1ULL << lane) - 1ULL));
+    for (int k = 0; k < wave; ++k) rank += s_w[k];
+    const size_t pos = (size_t)offsets[b] + rank;
+    const float cube_res = 8.0f * res, half = res / 2; // VoxelCube.h:150, :47
+    const float f = fabsf(sdf) / trunc;
+    xyz[3 * pos] = (float)V.keys[3 * b] * cube_res + ((float)x * res + half);
+    xyz[3 * pos + 1] = (float)V.keys[3 * b + 1] * cube_res + ((float)y * res + half);
+    xyz[3 * pos + 2] = (float)V.keys[3 * b + 2] * cube_res + ((float)z * res + half);
+    col[3 * pos] = f; col[3 * pos + 1] = f; col[3 * pos + 2] = f;
+}
+
 unsigned next_pow2(unsigned long long v) {
     unsigned long long p = 1;
     while (p < v) p <<= 1;
@@ -1275,6 +1412,179 @@ int op_volume_unpack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_uni
     (void)hipFree(d_slots);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "unpack failed: %s", hipGetErrorString(e));
     return vol_check(v);
+}
+
+int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, int nearest, uint64_t max_blocks, op_volume** out) {
+    OP_VOL(src);
+    if (!T || !out) return fail(OP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    unsigned ns = 0;
+    OP_TRY(vol_block_count(src, &ns));
+    // Transform copies c_para into the result (CubeHandler.h:249); TransformNearest does not
+    // (CubeHandler.h:301-305), so its result keeps the default resolution 0.01 (VoxelCube.h:27)
+    const float dst_res = nearest ? 0.01f : src->res;
+    if (max_blocks == 0) max_blocks = std::max<uint64_t>(8ull * ns + 4096ull, 1ull << 14);
+    op_volume* dst = nullptr;
+    OP_TRY(op_volume_create(&src->cam, dst_res, src->trunc, src->far_d, src->near_d, src->device, max_blocks, &dst));
+    Mat4 M, Mi;
+    std::memcpy(M.m, T, sizeof(M.m));
+    if (T_inv) std::memcpy(Mi.m, T_inv, sizeof(Mi.m));
+    else op_host::mat4_inverse(T, Mi.m); // trans.inverse() (CubeHandler.h:265,320)
+    int rc = OP_OK;
+    if (ns) {
+        if (nearest) hipLaunchKernelGGL(k_transform_alloc<true>, dim3(ns), dim3(512), 0, dst->stream, src->view(), dst->view(), dst->state, M, dst_res);
+        else hipLaunchKernelGGL(k_transform_alloc<false>, dim3(ns), dim3(512), 0, dst->stream, src->view(), dst->view(), dst->state, M, dst_res);
+        unsigned nd = 0;
+        rc = vol_block_count(dst, &nd);
+        if (rc == OP_OK && nd) {
+            if (nearest) hipLaunchKernelGGL(k_transform_fill<true>, dim3(nd), dim3(512), 0, dst->stream, src->view(), dst->view(), Mi, src->res);
+            else hipLaunchKernelGGL(k_transform_fill<false>, dim3(nd), dim3(512), 0, dst->stream, src->view(), dst->view(), Mi, src->res);
+            rc = vol_check(dst);
+        }
+    }
+    if (rc != OP_OK) { op_volume_destroy(dst); return rc; }
+    *out = dst;
+    return OP_OK;
+}
+
+int op_volume_resolution(op_volume* v, float* voxel_res) {
+    OP_VOL(v);
+    if (!voxel_res) return fail(OP_ERR_INVALID, "null argument");
+    *voxel_res = v->res;
+    return OP_OK;
+}
+
+int op_volume_point_cloud(op_volume* v, float* xyz, float* colors, size_t cap, size_t* n) {
+    OP_VOL(v);
+    if (!n) return fail(OP_ERR_INVALID, "null n");
+    unsigned nb = 0;
+    OP_TRY(vol_block_count(v, &nb));
+    *n = 0;
+    if (!nb) return OP_OK;
+    unsigned *d_counts = nullptr, *d_offsets = nullptr;
+    float *d_xyz = nullptr, *d_col = nullptr;
+    int rc = OP_OK;
+    hipError_t e = hipMalloc((void**)&d_counts, nb * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_offsets, nb * sizeof(unsigned));
+    std::vector<unsigned> cnt(nb), off(nb);
+    size_t total = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_point_cloud, dim3(nb), dim3(512), 0, v->stream, v->view(), v->res, v->trunc, d_counts, (const unsigned*)nullptr,
+                           (float*)nullptr, (float*)nullptr);
+        e = hipStreamSynchronize(v->stream);
+        if (e == hipSuccess) e = hipMemcpy(cnt.data(), d_counts, nb * sizeof(unsigned), hipMemcpyDeviceToHost);
+        for (unsigned b = 0; b < nb; ++b) { off[b] = (unsigned)total; total += cnt[b]; }
+    }
+    *n = total;
+    if (e == hipSuccess && xyz && colors && total) {
+        if (total > cap) rc = fail(OP_ERR_CAPACITY, "point cloud has %zu points, buffer holds %zu", total, cap);
+        else {
+            e = hipMemcpy(d_offsets, off.data(), nb * sizeof(unsigned), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_xyz, total * 12);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_col, total * 12);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_point_cloud, dim3(nb), dim3(512), 0, v->stream, v->view(), v->res, v->trunc, (unsigned*)nullptr,
+                                   (const unsigned*)d_offsets, d_xyz, d_col);
+                e = hipStreamSynchronize(v->stream);
+            }
+            if (e == hipSuccess) e = hipMemcpy(xyz, d_xyz, total * 12, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(colors, d_col, total * 12, hipMemcpyDeviceToHost);
+        }
+    }
+    void* ptrs[] = {d_counts, d_offsets, d_xyz, d_col};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "point cloud failed: %s", hipGetErrorString(e));
+    return rc;
+}
+
+int op_volume_write_file(op_volume* v, const char* path) {
+    OP_VOL(v);
+    if (!path) return fail(OP_ERR_INVALID, "null path");
+    size_t n = 0;
+    OP_TRY(op_volume_block_count(v, &n));
+    std::vector<int32_t> keys(3 * n);
+    std::vector<float> vox(n * (size_t)kBlockFloats);
+    if (n) OP_TRY(op_volume_download(v, keys.data(), vox.data(), n, &n));
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(OP_ERR_INVALID, "cannot open %s for writing", path);
+    // CubeHandler::WriteToFile (CubeHandler.h:113-128): the block count's raw bits sit in a float slot
+    std::vector<float> buffer;
+    buffer.reserve(n * 64 + 16);
+    buffer.push_back(0.0f);
+    const unsigned int size = (unsigned int)n;
+    std::memcpy(&buffer[0], &size, 4);
+    for (size_t b = 0; b < n; ++b) { // VoxelCube::WriteToBuffer (VoxelCube.h:128-148)
+        for (int c = 0; c < 3; ++c) buffer.push_back((float)keys[3 * b + c]);
+        for (int i = 0; i < kVox; ++i) {
+            const float* t = &vox[(b * kVox + i) * 5];
+            if (std::fabs(t[0]) < 1 && t[1] != 0) {
+                buffer.push_back((float)i);
+                for (int k = 0; k < 5; ++k) buffer.push_back(t[k]);
+            }
+        }
+        buffer.push_back(-2.0f);
+    }
+    const bool ok = std::fwrite(buffer.data(), sizeof(float), buffer.size(), f) == buffer.size();
+    std::fclose(f);
+    return ok ? OP_OK : fail(OP_ERR_INVALID, "short write to %s", path);
+}
+
+int op_volume_read_file(op_volume* v, const char* path, int legacy_float_format) {
+    OP_VOL(v);
+    if (!path) return fail(OP_ERR_INVALID, "null path");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(OP_ERR_INVALID, "cannot open %s", path);
+    std::fseek(f, 0, SEEK_END);
+    const long len = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<float> buffer((size_t)len / sizeof(float) + 1, 0.0f);
+    const size_t nfl = (size_t)len / sizeof(float);
+    const bool ok = std::fread(buffer.data(), sizeof(float), nfl, f) == nfl;
+    std::fclose(f);
+    if (!ok || nfl < 2) return fail(OP_ERR_INVALID, "cannot read %s", path);
+    unsigned int count = 0;
+    size_t ptr = 0;
+    if (legacy_float_format) { count = (unsigned int)buffer[1]; ptr = 2; } // CubeHandler.h:91-94
+    else { std::memcpy(&count, &buffer[0], 4); ptr = 1; }                   // CubeHandler.h:51-53
+    std::vector<int32_t> keys;
+    std::vector<float> vox;
+    keys.reserve(3 * (size_t)count);
+    for (unsigned int c = 0; c < count && ptr + 3 <= nfl; ++c) {
+        keys.push_back((int32_t)buffer[ptr]); keys.push_back((int32_t)buffer[ptr + 1]); keys.push_back((int32_t)buffer[ptr + 2]);
+        ptr += 3;
+        const size_t base = vox.size();
+        vox.resize(base + kBlockFloats);
+        float* blk = &vox[base]; // cube_map[cube_id] = VoxelCube(cube_id): default voxels
+        for (int i = 0; i < kVox; ++i) { blk[5 * i] = 999.0f; blk[5 * i + 1] = 0.0f; blk[5 * i + 2] = blk[5 * i + 3] = blk[5 * i + 4] = -1.0f; }
+        if (!legacy_float_format) { // VoxelCube::ReadFromBuffer (VoxelCube.h:153-166)
+            while (ptr < nfl && buffer[ptr] != -2.0f) {
+                const int i = (int)buffer[ptr++];
+                if (i < 0 || i >= kVox || ptr + 5 > nfl) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
+                for (int k = 0; k < 5; ++k) blk[5 * i + k] = buffer[ptr++];
+            }
+            ptr++;
+        } else { // VoxelCube::ReadFromBufferFloat (VoxelCube.h:168-193)
+            ptr++;
+            while (ptr < nfl && buffer[ptr] != -2.0f) {
+                const int i = (int)buffer[ptr++];
+                if (i < 0 || i >= kVox || ptr + 2 > nfl) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
+                blk[5 * i] = buffer[ptr++]; blk[5 * i + 1] = buffer[ptr++];
+            }
+            ptr++;
+            const size_t cnt = ptr < nfl ? (size_t)buffer[ptr++] : 0;
+            for (size_t k = 0; k < cnt && ptr + 5 <= nfl; ++k) {
+                const int i = (int)buffer[ptr++];
+                if (i < 0 || i >= kVox) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
+                float* t = &blk[5 * i];
+                t[2] = (float)(buffer[ptr++] / 255.0); t[3] = (float)(buffer[ptr++] / 255.0); t[4] = (float)(buffer[ptr++] / 255.0);
+                const float cw = buffer[ptr++];
+                t[2] = t[2] / cw; t[3] = t[3] / cw; t[4] = t[4] / cw;
+            }
+        }
+    }
+    OP_TRY(op_volume_clear(v)); // cube_map.clear() (CubeHandler.h:42)
+    return op_volume_upload(v, keys.data(), vox.data(), keys.size() / 3);
 }
 
 } // extern "C"

@@ -230,6 +230,58 @@ class CubeHandler:
             return
         L.check(rc)
 
+    # -- resampling, point cloud, .map files (CubeHandler.h:40-128,242-338; CubeHandler.cpp:45-69)
+    @classmethod
+    def _wrap(cls, handle, camera, device):
+        out = cls.__new__(cls)
+        out._lib = L.load()
+        out.camera, out.device, out._h = camera, device, handle
+        res = C.c_float(0)
+        L.check(out._lib.op_volume_resolution(handle, C.byref(res)))
+        out._res, out._trunc, out._far, out._near = float(res.value), None, None, None
+        return out
+
+    def _transform(self, trans, nearest, max_blocks):
+        T = _f32(trans).reshape(16)
+        h = C.c_void_p()
+        L.check(self._lib.op_volume_transform(self._h, _fp(T), None, 1 if nearest else 0, max_blocks, C.byref(h)))
+        out = CubeHandler._wrap(h, self.camera, self.device)
+        out._trunc, out._far, out._near = self._trunc, self._far, self._near
+        return out
+
+    def Transform(self, trans, max_blocks=0):
+        """CubeHandler::Transform (CubeHandler.h:242-298): trilinear resampling -> new CubeHandler."""
+        return self._transform(trans, False, max_blocks)
+
+    def TransformNearest(self, trans, max_blocks=0):
+        """CubeHandler::TransformNearest (CubeHandler.h:299-338).  Like the reference, the result keeps
+        the DEFAULT voxel resolution 0.01 (c_para is not copied there)."""
+        return self._transform(trans, True, max_blocks)
+
+    def GetVoxelResolution(self):
+        return self._res
+
+    def GetPointCloud(self):
+        """CubeHandler::GetPointCloud (CubeHandler.cpp:45-69) -> (points [n,3], colors [n,3])."""
+        n = C.c_size_t(0)
+        L.check(self._lib.op_volume_point_cloud(self._h, None, None, 0, C.byref(n)))
+        xyz = np.empty((max(n.value, 1), 3), np.float32)
+        col = np.empty((max(n.value, 1), 3), np.float32)
+        L.check(self._lib.op_volume_point_cloud(self._h, _fp(xyz), _fp(col), n.value, C.byref(n)))
+        return xyz[:n.value], col[:n.value]
+
+    def WriteToFile(self, filename):
+        L.check(self._lib.op_volume_write_file(self._h, str(filename).encode()))
+        return True
+
+    def ReadFromFile(self, filename):
+        L.check(self._lib.op_volume_read_file(self._h, str(filename).encode(), 0))
+        return True
+
+    def ReadFromFileFloat(self, filename):
+        L.check(self._lib.op_volume_read_file(self._h, str(filename).encode(), 1))
+        return True
+
     def GetCubeID(self, point):
         """CubeHandler.h:185-189 / VoxelCube.h:63-74 (float floor, then floor-div by 8)."""
         p = _f32(point)

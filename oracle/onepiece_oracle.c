@@ -480,6 +480,218 @@ int orc_volume_merge(orc_volume *dst, const orc_volume *src) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Volume resampling, point cloud and .map files (CubeHandler.h:40-128,199-338, CubeHandler.cpp:45-69) */
+/* ------------------------------------------------------------------------------------------ */
+static inline int floor_div8(int v) { return (int)floor((v + 0.0) / CUBE); } /* VoxelCube.h:63-67 */
+
+static void set_default_voxel(float *t) { t[0] = 999; t[1] = 0; t[2] = t[3] = t[4] = -1; }
+
+/* voxel of global integer voxel coordinate p in volume v (default voxel when the block is absent):
+ * GetCubeID(Point3i) + GetVoxelID(Point3i) (VoxelCube.h:63-67,81-86) + cube_map.find */
+static void fetch_voxel(const orc_volume *v, const int p[3], float out[5]) {
+    int c[3] = {floor_div8(p[0]), floor_div8(p[1]), floor_div8(p[2])};
+    int64_t b = vol_find(v, c[0], c[1], c[2]);
+    if (b < 0) { set_default_voxel(out); return; }
+    int vid = (p[0] - c[0] * CUBE) + (p[1] - c[1] * CUBE) * CUBE + (p[2] - c[2] * CUBE) * CUBE * CUBE;
+    memcpy(out, v->vox + ((size_t)b * NVOX + vid) * 5, 5 * sizeof(float));
+}
+
+/* TSDFVoxel::operator*(float) (TSDFVoxel.h:56-67) */
+static void voxel_scale(const float *a, float wgt, float *r) {
+    if (wgt == 0 || a[1] == 0) { set_default_voxel(r); return; }
+    r[1] = a[1] * wgt; r[0] = a[0] * wgt; r[2] = a[2] * wgt; r[3] = a[3] * wgt; r[4] = a[4] * wgt;
+}
+/* TSDFVoxel::add (TSDFVoxel.h:40-51) */
+static void voxel_add_direct(const float *a, const float *b, float *r) {
+    if (a[1] == 0) { memcpy(r, b, 5 * sizeof(float)); return; }
+    if (b[1] == 0) { memcpy(r, a, 5 * sizeof(float)); return; }
+    r[1] = a[1] + b[1]; r[0] = a[0] + b[0]; r[2] = a[2] + b[2]; r[3] = a[3] + b[3]; r[4] = a[4] + b[4];
+}
+/* one lerp stage of ReadVoxelInterpolate (VoxelCube.cpp:17-20 etc.):
+ * ((a * (1 - t)).add(b * t)) / ((1 - t) * (a.weight != 0) + t * (b.weight != 0)), default if both empty */
+static void interp_stage(const float *a, const float *b, float t, float *r) {
+    if (!(a[1] != 0 || b[1] != 0)) { set_default_voxel(r); return; }
+    float A[5], B[5], S[5];
+    voxel_scale(a, 1 - t, A);
+    voxel_scale(b, t, B);
+    voxel_add_direct(A, B, S);
+    float d = (1 - t) * (float)(a[1] != 0) + t * (float)(b[1] != 0);
+    voxel_scale(S, 1 / d, r); /* operator/(w) = operator*(1 / w) (TSDFVoxel.h:68-71) */
+}
+/* VoxelCube.cpp:6-50 */
+static void read_voxel_interpolate(const int n0[3], float vox8[8][5], const float pos[3], float res, float *out) {
+    float xw = (pos[0] - n0[0] * res) / res, yw = (pos[1] - n0[1] * res) / res, zw = (pos[2] - n0[2] * res) / res;
+    float r1[5], r2[5], r3[5], r4[5], z1[5], z2[5];
+    interp_stage(vox8[0], vox8[1], xw, r1);
+    interp_stage(vox8[2], vox8[3], xw, r2);
+    interp_stage(r1, r2, yw, z1);
+    interp_stage(vox8[4], vox8[5], xw, r3);
+    interp_stage(vox8[6], vox8[7], xw, r4);
+    interp_stage(r3, r4, yw, z2);
+    interp_stage(z1, z2, zw, out);
+}
+
+/* CubeHandler::TransformNearest (CubeHandler.h:299-338) / Transform (:242-298).
+ * Quirk kept: TransformNearest never copies c_para into the result, so the result volume has the
+ * DEFAULT resolution 0.01 and its allocation pass (AddTransformedCubeNearest, :225-241, executed on
+ * the result object) uses that resolution, while the fill pass uses the source's (this->c_para). */
+orc_volume *orc_volume_transform(const orc_volume *src, const float T[16], int nearest) {
+    float alloc_res = nearest ? 0.01f : src->res;
+    orc_volume *dst = orc_volume_create(&src->cam, alloc_res, src->trunc, src->far_d, src->near_d);
+    float Tinv[16];
+    orc_mat4_inverse(T, Tinv);
+    float half_a = alloc_res / 2;
+    /* pass 1: allocation, with the RESULT's c_para */
+    for (size_t b = 0; b < src->n; ++b) {
+        const int32_t *id = src->keys + 3 * b;
+        float start[3] = {((float)id[0] * (float)CUBE) * alloc_res, ((float)id[1] * (float)CUBE) * alloc_res,
+                          ((float)id[2] * (float)CUBE) * alloc_res};
+        for (int vid = 0; vid < NVOX; ++vid) {
+            const float *o = dst->offset[vid];
+            float q[4], np[3];
+            mat4_mul_p1(T, start[0] + o[0], start[1] + o[1], start[2] + o[2], q);
+            for (int c = 0; c < 3; ++c) np[c] = nearest ? q[c] / q[3] : q[c] / q[3] - half_a;
+            int p0[3] = {(int)floorf(np[0] / alloc_res), (int)floorf(np[1] / alloc_res), (int)floorf(np[2] / alloc_res)};
+            for (int k = 0; k < (nearest ? 1 : 8); ++k) {
+                int p[3] = {p0[0] + (k & 1), p0[1] + ((k >> 1) & 1), p0[2] + ((k >> 2) & 1)};
+                int c[3] = {floor_div8(p[0]), floor_div8(p[1]), floor_div8(p[2])};
+                if (vol_find(dst, c[0], c[1], c[2]) < 0) vol_add(dst, c[0], c[1], c[2]);
+            }
+        }
+    }
+    /* pass 2: fill, with the SOURCE's c_para (this->c_para in the reference) */
+    float half_s = src->res / 2;
+    for (size_t b = 0; b < dst->n; ++b) {
+        const int32_t *id = dst->keys + 3 * b;
+        float start[3] = {((float)id[0] * (float)CUBE) * src->res, ((float)id[1] * (float)CUBE) * src->res,
+                          ((float)id[2] * (float)CUBE) * src->res};
+        for (int vid = 0; vid < NVOX; ++vid) {
+            const float *o = src->offset[vid];
+            float q[4], np[3], r[5];
+            mat4_mul_p1(Tinv, start[0] + o[0], start[1] + o[1], start[2] + o[2], q);
+            for (int c = 0; c < 3; ++c) np[c] = nearest ? q[c] / q[3] : q[c] / q[3] - half_s;
+            int p0[3] = {(int)floorf(np[0] / src->res), (int)floorf(np[1] / src->res), (int)floorf(np[2] / src->res)};
+            if (nearest) {
+                fetch_voxel(src, p0, r);
+            } else {
+                float v8[8][5];
+                for (int k = 0; k < 8; ++k) {
+                    int p[3] = {p0[0] + (k & 1), p0[1] + ((k >> 1) & 1), p0[2] + ((k >> 2) & 1)};
+                    fetch_voxel(src, p, v8[k]);
+                }
+                read_voxel_interpolate(p0, v8, np, src->res, r);
+            }
+            voxel_add(dst->vox + ((size_t)b * NVOX + vid) * 5, r); /* v_cube.voxels[voxel_id] += result */
+        }
+    }
+    return dst;
+}
+
+float orc_volume_resolution(const orc_volume *v) { return v->res; }
+
+/* CubeHandler::GetPointCloud (CubeHandler.cpp:45-69): blocks in insertion order here (the
+ * reference's map order is unspecified), voxels in the reference's x,y,z loop nest order. */
+size_t orc_volume_point_cloud(const orc_volume *v, float *xyz, float *colors, size_t cap) {
+    size_t n = 0;
+    float cube_res = CUBE * v->res; /* VoxelCube.h:150 */
+    for (size_t b = 0; b < v->n; ++b) {
+        const int32_t *id = v->keys + 3 * b;
+        for (int x = 0; x < CUBE; ++x)
+            for (int y = 0; y < CUBE; ++y)
+                for (int z = 0; z < CUBE; ++z) {
+                    int vid = x + y * CUBE + z * CUBE * CUBE;
+                    const float *t = v->vox + ((size_t)b * NVOX + vid) * 5;
+                    if (t[1] != 0 && fabsf(t[0]) < v->trunc) {
+                        if (n < cap) {
+                            float f = fabsf(t[0]) / v->trunc;
+                            for (int c = 0; c < 3; ++c) {
+                                xyz[3 * n + c] = id[c] * cube_res + v->offset[vid][c];
+                                colors[3 * n + c] = f;
+                            }
+                        }
+                        ++n;
+                    }
+                }
+    }
+    return n;
+}
+
+#include <stdio.h>
+/* CubeHandler::WriteToFile (CubeHandler.h:113-128) + VoxelCube::WriteToBuffer (VoxelCube.h:128-148) */
+int orc_volume_write_file(const orc_volume *v, const char *path) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return 1;
+    unsigned int size = (unsigned int)v->n;
+    fwrite(&size, 4, 1, f); /* the count's raw bits live in a float slot */
+    for (size_t b = 0; b < v->n; ++b) {
+        float hdr[3] = {(float)v->keys[3 * b], (float)v->keys[3 * b + 1], (float)v->keys[3 * b + 2]};
+        fwrite(hdr, 4, 3, f);
+        for (int i = 0; i < NVOX; ++i) {
+            const float *t = v->vox + ((size_t)b * NVOX + i) * 5;
+            if (fabsf(t[0]) < 1 && t[1] != 0) {
+                float rec[6] = {(float)i, t[0], t[1], t[2], t[3], t[4]};
+                fwrite(rec, 4, 6, f);
+            }
+        }
+        float end = -2.0f;
+        fwrite(&end, 4, 1, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+/* CubeHandler::ReadFromFile (CubeHandler.h:40-69) / ReadFromFileFloat (:73-109) */
+int orc_volume_read_file(orc_volume *v, const char *path, int legacy_float) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return 1;
+    fseek(f, 0, SEEK_END);
+    long len = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    size_t nf = (size_t)len / 4;
+    float *buf = (float *)malloc((nf + 1) * 4);
+    if (fread(buf, 4, nf, f) != nf) { fclose(f); free(buf); return 1; }
+    fclose(f);
+    orc_volume_clear(v);
+    unsigned int count;
+    size_t ptr;
+    if (legacy_float) { count = (unsigned int)buf[1]; ptr = 2; }
+    else { memcpy(&count, buf, 4); ptr = 1; }
+    for (unsigned int c = 0; c < count; ++c) {
+        int x = (int)buf[ptr], y = (int)buf[ptr + 1], z = (int)buf[ptr + 2];
+        ptr += 3;
+        int64_t b = vol_find(v, x, y, z);
+        if (b < 0) b = vol_add(v, x, y, z);
+        float *vox = v->vox + (size_t)b * NVOX * 5;
+        for (int i = 0; i < NVOX; ++i) set_default_voxel(vox + 5 * i); /* cube_map[id] = VoxelCube(id) */
+        if (!legacy_float) { /* VoxelCube.h:153-166 */
+            while (buf[ptr] != -2.0f) {
+                int i = (int)buf[ptr++];
+                float *t = vox + 5 * i;
+                t[0] = buf[ptr++]; t[1] = buf[ptr++]; t[2] = buf[ptr++]; t[3] = buf[ptr++]; t[4] = buf[ptr++];
+            }
+            ptr++;
+        } else { /* VoxelCube.h:168-193 */
+            ptr++;
+            while (buf[ptr] != -2.0f) {
+                int i = (int)buf[ptr++];
+                vox[5 * i] = buf[ptr++]; vox[5 * i + 1] = buf[ptr++];
+            }
+            ptr++;
+            size_t cnt = (size_t)buf[ptr++];
+            for (size_t k = 0; k < cnt; ++k) {
+                int i = (int)buf[ptr++];
+                float *t = vox + 5 * i;
+                t[2] = (float)(buf[ptr++] / 255.0); t[3] = (float)(buf[ptr++] / 255.0); t[4] = (float)(buf[ptr++] / 255.0);
+                float cw = buf[ptr++];
+                t[2] = t[2] / cw; t[3] = t[3] / cw; t[4] = t[4] / cw;
+            }
+        }
+    }
+    free(buf);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Registration                                                                                */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -75,6 +75,16 @@ void orc_volume_import(orc_volume *v, const int32_t *keys, const float *voxels, 
 /* Integration/CubeHandler.h:145-167 */
 int orc_volume_merge(orc_volume *dst, const orc_volume *src);
 
+/* Integration/CubeHandler.h:242-338 (nearest != 0: TransformNearest incl. its default-resolution
+ * quirk, else Transform with trilinear ReadVoxelInterpolate, VoxelCube.cpp:6-50).  New volume. */
+orc_volume *orc_volume_transform(const orc_volume *src, const float T[16], int nearest);
+float orc_volume_resolution(const orc_volume *v);
+/* Integration/CubeHandler.cpp:45-69: points + colours (n x 3 each); returns the full count. */
+size_t orc_volume_point_cloud(const orc_volume *v, float *xyz, float *colors, size_t cap);
+/* Integration/CubeHandler.h:40-128 (.map stream format; legacy_float = ReadFromFileFloat). */
+int orc_volume_write_file(const orc_volume *v, const char *path);
+int orc_volume_read_file(orc_volume *v, const char *path, int legacy_float);
+
 /* ---- Registration ---- */
 /* Geometry/PointCloud.cpp:72-100.  Returns count; xyz has room for w*h*3 floats. */
 size_t orc_load_from_depth(const orc_camera *cam, const void *depth, int is_u16, float *xyz);

@@ -70,6 +70,16 @@ def lib():
         L.orc_volume_import.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.orc_volume_merge.restype = C.c_int
         L.orc_volume_merge.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_volume_transform.restype = C.c_void_p
+        L.orc_volume_transform.argtypes = [C.c_void_p, _fp, C.c_int]
+        L.orc_volume_resolution.restype = C.c_float
+        L.orc_volume_resolution.argtypes = [C.c_void_p]
+        L.orc_volume_point_cloud.restype = C.c_size_t
+        L.orc_volume_point_cloud.argtypes = [C.c_void_p, _fp, _fp, C.c_size_t]
+        L.orc_volume_write_file.restype = C.c_int
+        L.orc_volume_write_file.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_volume_read_file.restype = C.c_int
+        L.orc_volume_read_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.orc_load_from_depth.restype = C.c_size_t
         L.orc_load_from_depth.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, _fp]
         L.orc_se3_exp.argtypes = [_fp, _fp]
@@ -215,6 +225,30 @@ class Volume:
 
     def merge(self, other):
         return int(lib().orc_volume_merge(self._h, other._h))
+
+    def transform(self, T, nearest=False):
+        """CubeHandler::Transform / TransformNearest -> new Volume."""
+        T = _f32(T).reshape(16)
+        out = Volume.__new__(Volume)
+        out.cam = self.cam
+        out._h = lib().orc_volume_transform(self._h, _p(T), 1 if nearest else 0)
+        return out
+
+    def resolution(self):
+        return float(lib().orc_volume_resolution(self._h))
+
+    def point_cloud(self):
+        n = lib().orc_volume_point_cloud(self._h, None, None, 0)
+        xyz = np.empty((max(n, 1), 3), np.float32)
+        col = np.empty((max(n, 1), 3), np.float32)
+        lib().orc_volume_point_cloud(self._h, _p(xyz), _p(col), n)
+        return xyz[:n], col[:n]
+
+    def write_file(self, path):
+        return int(lib().orc_volume_write_file(self._h, str(path).encode()))
+
+    def read_file(self, path, legacy_float=False):
+        return int(lib().orc_volume_read_file(self._h, str(path).encode(), 1 if legacy_float else 0))
 
 
 def icp(src, tgt, tgt_normals=None, init_T=None, max_iter=30, threshold=0.2, point_to_plane=True):
