@@ -203,6 +203,14 @@ int op_icp_register(int mode, const float *src_xyz, size_t n, const float *tgt_x
 int op_points_from_depth(const op_camera *cam, const void *depth, int depth_fmt, int mem, int device,
                          float *xyz_out, size_t *n);
 
+/* PointCloud::EstimateNormals(radius, knn) (Geometry/PointCloud.cpp:102-144) on the device: exact
+ * knn nearest neighbours (knn <= 32), the prefix whose SQUARED distance is <= radius (the
+ * reference's KnnRadiusSearch, KDTree.h:230-255), PCA plane fit (geometry::FitPlane,
+ * Geometry.cpp:172-218).  normals_out: n x 3 floats in `mem`; the sign of each normal is
+ * undetermined (as in the reference, whose disambiguation is #if 0'd out); < 3 neighbours -> 0. */
+int op_estimate_normals(const float *xyz, size_t n, float radius, int knn, int mem, int device,
+                        float *normals_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@
 // this accumulation is 2*27*N flops -- not a dense contraction, so no MFMA.
 #include <cfloat>
 #include <climits>
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -299,6 +300,124 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double* __restrict__
         for (int gI = 0; gI < 8; ++gI) t += s[gI][threadIdx.x];
         out[threadIdx.x] = t;
     }
+}
+
+// ---- EstimateNormals: exact k-NN over the cell grid + PCA plane fit ----------------------------
+// PointCloud::EstimateNormals (PointCloud.cpp:102-144): knn nearest points (nanoflann order:
+// ascending squared distance), the prefix with SQUARED distance <= radius (KDTree.h:245-251),
+// geometry::FitPlane (Geometry.cpp:172-218).  One thread per (cell-sorted) point; the k best are
+// kept sorted in LDS (one column per thread); cells are scanned in growing Chebyshev rings until
+// the k-th distance is provably final: every unscanned point is farther than ring * cell.
+constexpr int kNrmThreads = 128;
+constexpr int kNrmMaxK = 32;
+
+__device__ __forceinline__ void sym3_smallest_eigvec(double a00, double a01, double a02, double a11, double a12, double a22, double v[3]) {
+    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double kp = A[k][p], kq = A[k][q]; A[k][p] = c * kp - sn * kq; A[k][q] = sn * kp + c * kq; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double pk = A[p][k], qk = A[q][k]; A[p][k] = c * pk - sn * qk; A[q][k] = sn * pk + c * qk; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double kp = V[k][p], kq = V[k][q]; V[k][p] = c * kp - sn * kq; V[k][q] = sn * kp + c * kq; }
+            }
+    }
+    int m = 0;
+    if (A[1][1] < A[m][m]) m = 1;
+    if (A[2][2] < A[m][m]) m = 2;
+    v[0] = V[0][m]; v[1] = V[1][m]; v[2] = V[2][m];
+}
+
+__global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const unsigned* __restrict__ cell_start,
+                                                                  const unsigned* __restrict__ cell_count, const float4* __restrict__ pts,
+                                                                  size_t m, int knn, float radius, float cell, float* __restrict__ normals) {
+    __shared__ float s_d[kNrmMaxK][kNrmThreads];
+    __shared__ int s_p[kNrmMaxK][kNrmThreads]; // sorted position of the neighbour (its record is pts[pos])
+    const int tid = threadIdx.x;
+    const size_t q = blockIdx.x * (size_t)blockDim.x + tid;
+    if (q >= m) return;
+    const float4 me = pts[q];
+    const int cx = cell_coord(me.x, g.ox, g.inv_cell, g.gx), cy = cell_coord(me.y, g.oy, g.inv_cell, g.gy),
+              cz = cell_coord(me.z, g.oz, g.inv_cell, g.gz);
+    int cnt = 0;
+    const int max_ring = max(g.gx, max(g.gy, g.gz));
+    for (int ring = 0; ring <= max_ring; ++ring) {
+        for (int z = cz - ring; z <= cz + ring; ++z) {
+            if (z < 0 || z >= g.gz) continue;
+            for (int y = cy - ring; y <= cy + ring; ++y) {
+                if (y < 0 || y >= g.gy) continue;
+                const bool shell_row = (z == cz - ring || z == cz + ring || y == cy - ring || y == cy + ring);
+                // on a shell row scan the whole x run, otherwise only the two x end cells of the ring
+                for (int part = 0; part < (shell_row ? 1 : 2); ++part) {
+                    int x_lo, x_hi;
+                    if (shell_row) { x_lo = cx - ring; x_hi = cx + ring; }
+                    else { x_lo = x_hi = part == 0 ? cx - ring : cx + ring; if (ring == 0 && part == 1) continue; }
+                    x_lo = max(x_lo, 0); x_hi = min(x_hi, g.gx - 1);
+                    if (x_lo > x_hi) continue;
+                    const size_t row = ((size_t)z * g.gy + y) * g.gx;
+                    const unsigned beg = cell_start[row + x_lo], end = cell_start[row + x_hi] + cell_count[row + x_hi];
+                    for (unsigned p = beg; p < end; ++p) {
+                        const float4 c = pts[p];
+                        const float dx = me.x - c.x, dy = me.y - c.y, dz = me.z - c.z;
+                        const float d = dx * dx + dy * dy + dz * dz;
+                        const int ci = __float_as_int(c.w);
+                        if (cnt == knn) {
+                            const float wd = s_d[cnt - 1][tid];
+                            if (!(d < wd || (d == wd && ci < __float_as_int(pts[s_p[cnt - 1][tid]].w)))) continue;
+                        }
+                        int pos = cnt < knn ? cnt++ : cnt - 1;
+                        while (pos > 0) {
+                            const float pd = s_d[pos - 1][tid];
+                            if (!(d < pd || (d == pd && ci < __float_as_int(pts[s_p[pos - 1][tid]].w)))) break;
+                            s_d[pos][tid] = pd; s_p[pos][tid] = s_p[pos - 1][tid];
+                            --pos;
+                        }
+                        s_d[pos][tid] = d; s_p[pos][tid] = (int)p;
+                    }
+                }
+            }
+        }
+        // every point outside the scanned cube is farther than ring * cell from the query
+        const float reach = (float)ring * cell;
+        if (cnt == knn && s_d[cnt - 1][tid] <= reach * reach) break;
+        if (cnt == (int)min((size_t)knn, m) && ring >= max_ring) break;
+    }
+    int used = 0;
+    while (used < cnt && !(s_d[used][tid] > radius)) ++used; // squared distance vs radius, as the reference does
+    float nx = 0, ny = 0, nz = 0;
+    if (used >= 3) {
+        float s0 = 0, s1 = 0, s2 = 0;
+        for (int k = 0; k < used; ++k) { const float4 c = pts[s_p[k][tid]]; s0 += c.x; s1 += c.y; s2 += c.z; }
+        const float m0 = s0 / (float)used, m1 = s1 / (float)used, m2 = s2 / (float)used;
+        float w00 = 0, w01 = 0, w02 = 0, w11 = 0, w12 = 0, w22 = 0, w10 = 0, w20 = 0, w21 = 0;
+        for (int k = 0; k < used; ++k) {
+            const float4 c = pts[s_p[k][tid]];
+            const float d0 = c.x - m0, d1 = c.y - m1, d2 = c.z - m2;
+            w00 += d0 * d0; w01 += d0 * d1; w02 += d0 * d2; w10 += d1 * d0; w11 += d1 * d1; w12 += d1 * d2;
+            w20 += d2 * d0; w21 += d2 * d1; w22 += d2 * d2;
+        }
+        const float fn = (float)used;
+        double v[3];
+        sym3_smallest_eigvec((double)(w00 / fn), 0.5 * ((double)(w01 / fn) + (double)(w10 / fn)), 0.5 * ((double)(w02 / fn) + (double)(w20 / fn)),
+                             (double)(w11 / fn), 0.5 * ((double)(w12 / fn) + (double)(w21 / fn)), (double)(w22 / fn), v);
+        nx = (float)v[0]; ny = (float)v[1]; nz = (float)v[2];
+        const float z2 = sum3(nx * nx, ny * ny, nz * nz);
+        if (z2 > 0) { const float l = sqrtf(z2); nx /= l; ny /= l; nz /= l; }
+    }
+    const int orig = __float_as_int(me.w);
+    normals[3 * (size_t)orig] = nx; normals[3 * (size_t)orig + 1] = ny; normals[3 * (size_t)orig + 2] = nz;
 }
 
 // ---- LoadFromDepth with order-preserving compaction --------------------------------------------
@@ -620,6 +739,43 @@ int op_points_from_depth(const op_camera* cam, const void* depth, int depth_fmt,
     if (rc != OP_OK) return rc;
     if (e != hipSuccess) return fail(OP_ERR_HIP, "points_from_depth failed: %s", hipGetErrorString(e));
     *n = total;
+    return OP_OK;
+}
+
+int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int mem, int device, float* normals_out) {
+    if (!xyz || !normals_out) return fail(OP_ERR_INVALID, "null argument");
+    if (knn < 1 || knn > kNrmMaxK) return fail(OP_ERR_INVALID, "knn must be in [1, %d]", kNrmMaxK);
+    if (n == 0) return OP_OK;
+    // grid cell ~ extent / 400: a 640x480 depth cloud (3 m, 4 mm spacing) gets ~7 mm cells and
+    // finds its 30 neighbours within 2 rings; op_icp_create turns the "threshold" into the cell size
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    std::vector<float> host;
+    const float* h = xyz;
+    if (mem == OP_MEM_DEVICE) {
+        OP_TRY(op::use_device(device));
+        host.resize(n * 3);
+        OP_HIP(hipMemcpy(host.data(), xyz, n * 12, hipMemcpyDeviceToHost));
+        h = host.data();
+    }
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) { const float v = h[3 * i + c]; if (v == v) { mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); } }
+    const float ext = std::max(mx[0] - mn[0], std::max(mx[1] - mn[1], mx[2] - mn[2]));
+    const double cell_hint = ext > 0 ? (double)ext / 400.0 : 1.0;
+    op_icp* c = nullptr;
+    OP_TRY(op_icp_create(xyz, nullptr, n, cell_hint / 1.001, mem, device, &c));
+    float* d_nrm = nullptr;
+    hipError_t e = hipMalloc((void**)&d_nrm, n * 12);
+    if (e == hipSuccess) e = hipMemsetAsync(d_nrm, 0, n * 12, c->stream);
+    if (e == hipSuccess) {
+        const float cell = 1.0f / c->grid.inv_cell;
+        hipLaunchKernelGGL(k_estimate_normals, dim3((unsigned)((n + kNrmThreads - 1) / kNrmThreads)), dim3(kNrmThreads), 0, c->stream, c->grid,
+                           (const unsigned*)c->cell_start, (const unsigned*)c->cell_count, (const float4*)c->tgt, n, knn, radius, cell, d_nrm);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(normals_out, d_nrm, n * 12, mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+    if (d_nrm) (void)hipFree(d_nrm);
+    op_icp_destroy(c);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "estimate_normals failed: %s", hipGetErrorString(e));
     return OP_OK;
 }
 

@@ -30,6 +30,13 @@ class PointCloud:
     def HasNormals(self):
         return self.normals is not None and len(self.normals) == len(self.points) and len(self.points) > 0
 
+    def EstimateNormals(self, radius=0.1, knn=30, device=0):
+        """PointCloud::EstimateNormals (Geometry/PointCloud.cpp:102-144) on the GPU; fills self.normals."""
+        out = np.zeros_like(self.points)
+        L.check(L.load().op_estimate_normals(C.c_void_p(self.points.ctypes.data), len(self.points), float(radius), int(knn),
+                                             L.OP_MEM_HOST, device, C.c_void_p(out.ctypes.data)))
+        self.normals = out
+
     @staticmethod
     def LoadFromDepth(depth, camera, device=0):
         """PointCloud::LoadFromDepth (Geometry/PointCloud.cpp:72-100), computed on the GPU."""

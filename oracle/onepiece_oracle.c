@@ -946,6 +946,78 @@ static void kd_query(const kdtree *t, int id, const float *q, float *best_d, int
     if (diff * diff <= *best_d) kd_query(t, second, q, best_d, best_i);
 }
 
+/* k nearest neighbours, sorted ascending by (squared distance, index) -- nanoflann knnSearch */
+typedef struct { float d[64]; int i[64]; int n, k; } knn_set;
+static void knn_push(knn_set *s, float d, int idx) {
+    if (s->n == s->k && !(d < s->d[s->n - 1] || (d == s->d[s->n - 1] && idx < s->i[s->n - 1]))) return;
+    int pos = s->n < s->k ? s->n++ : s->n - 1;
+    while (pos > 0 && (d < s->d[pos - 1] || (d == s->d[pos - 1] && idx < s->i[pos - 1]))) {
+        s->d[pos] = s->d[pos - 1]; s->i[pos] = s->i[pos - 1]; --pos;
+    }
+    s->d[pos] = d; s->i[pos] = idx;
+}
+static void kd_knn(const kdtree *t, int id, const float *q, knn_set *s) {
+    const kdnode *nd = &t->nodes[id];
+    if (nd->axis < 0) {
+        for (int i = nd->lo; i < nd->hi; ++i) {
+            const float *p = t->pts + 3 * t->idx[i];
+            float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+            knn_push(s, dx * dx + dy * dy + dz * dz, t->idx[i]);
+        }
+        return;
+    }
+    float diff = q[nd->axis] - nd->split;
+    int first = diff < 0 ? nd->left : nd->right, second = diff < 0 ? nd->right : nd->left;
+    kd_knn(t, first, q, s);
+    if (s->n < s->k || diff * diff <= s->d[s->n - 1]) kd_knn(t, second, q, s);
+}
+
+/* geometry::FitPlane (Geometry.cpp:172-218): float sums in neighbour order, W / n, normal = the
+ * singular vector of the smallest singular value (JacobiSVD U.col(2); sign is whatever the SVD
+ * yields in the reference -- undetermined here), normalised. */
+static void fit_plane_normal(const float *pts, const int *idx, int n, float normal[3]) {
+    if (n < 3) { normal[0] = normal[1] = normal[2] = 0; return; }
+    float sum[3] = {0, 0, 0}, mean[3], W[9] = {0};
+    for (int i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) sum[c] += pts[3 * idx[i] + c];
+    for (int c = 0; c < 3; ++c) mean[c] = sum[c] / (float)n;
+    for (int i = 0; i < n; ++i) {
+        float d[3];
+        for (int c = 0; c < 3; ++c) d[c] = pts[3 * idx[i] + c] - mean[c];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) W[r * 3 + c] += d[r] * d[c];
+    }
+    double A[9], V[9];
+    for (int k = 0; k < 9; ++k) A[k] = (double)(W[k] / (float)n);
+    for (int r = 0; r < 3; ++r) for (int c = r + 1; c < 3; ++c) A[r * 3 + c] = A[c * 3 + r] = 0.5 * (A[r * 3 + c] + A[c * 3 + r]);
+    jacobi_sym(A, V, 3);
+    int m = 0;
+    if (A[4] < A[m * 4]) m = 1;
+    if (A[8] < A[m * 4]) m = 2;
+    float v[3] = {(float)V[0 * 3 + m], (float)V[1 * 3 + m], (float)V[2 * 3 + m]};
+    float z = sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2]);
+    if (z > 0) { float l = sqrtf(z); v[0] /= l; v[1] /= l; v[2] /= l; }
+    normal[0] = v[0]; normal[1] = v[1]; normal[2] = v[2];
+}
+
+/* PointCloud::EstimateNormals(radius, knn) (PointCloud.cpp:102-144; KnnRadiusSearch KDTree.h:230-255:
+ * k nearest, then the prefix whose SQUARED distance is <= radius). */
+void orc_estimate_normals(const float *pts, size_t n, float radius, int knn, float *normals) {
+    if (knn > 64) knn = 64;
+    kdtree t;
+    t.pts = pts; t.idx = (int *)malloc((n + 1) * sizeof(int));
+    t.nodes = (kdnode *)malloc((2 * n + 2) * sizeof(kdnode)); t.n_nodes = 0;
+    for (size_t i = 0; i < n; ++i) t.idx[i] = (int)i;
+    if (n) kd_build(&t, 0, (int)n);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long i = 0; i < (long)n; ++i) {
+        knn_set s; s.n = 0; s.k = knn;
+        kd_knn(&t, 0, pts + 3 * i, &s);
+        int used = 0;
+        while (used < s.n && !(s.d[used] > radius)) ++used;
+        fit_plane_normal(pts, s.i, used, normals + 3 * i);
+    }
+    free(t.idx); free(t.nodes);
+}
+
 /* ICP.cpp:9-30 */
 static double count_inliers(const float *src, const float *tgt, const int *corr, size_t n,
                             const float T[16], double threshold, int32_t *inliers, size_t *n_inl) {

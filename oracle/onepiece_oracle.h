@@ -98,6 +98,9 @@ void orc_solve6(const float JTJ[36], const float JTr[6], float x[6]);
 void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
                       const int32_t *inliers, size_t n, float T[16], float JTJ[36], float JTr[6]);
 
+/* Geometry/PointCloud.cpp:102-144 (normals up to sign; < 3 neighbours -> (0,0,0)). */
+void orc_estimate_normals(const float *pts, size_t n, float radius, int knn, float *normals);
+
 /* Diagnostic only: 1 = accumulate the normal equations in double (the reference uses float). */
 void orc_set_accumulate_double(int on);
 

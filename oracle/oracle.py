@@ -82,6 +82,7 @@ def lib():
         L.orc_volume_read_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.orc_load_from_depth.restype = C.c_size_t
         L.orc_load_from_depth.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, _fp]
+        L.orc_estimate_normals.argtypes = [_fp, C.c_size_t, C.c_float, C.c_int, _fp]
         L.orc_se3_exp.argtypes = [_fp, _fp]
         L.orc_kabsch.argtypes = [_fp, C.c_size_t, _fp]
         L.orc_solve6.argtypes = [_fp, _fp, _fp]
@@ -166,6 +167,14 @@ def load_from_depth(cam, depth):
     xyz = np.empty((cam.width * cam.height, 3), np.float32)
     n = lib().orc_load_from_depth(C.byref(cam), d.ctypes.data, u16, _p(xyz))
     return xyz[:n].copy()
+
+
+def estimate_normals(points, radius=0.1, knn=30):
+    """PointCloud::EstimateNormals (PointCloud.cpp:102-144); normals are defined up to sign."""
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros_like(pts)
+    lib().orc_estimate_normals(_p(pts), len(pts), radius, knn, _p(out))
+    return out
 
 
 class Volume:

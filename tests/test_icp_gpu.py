@@ -94,3 +94,23 @@ def test_load_from_depth_matches(oracle):
     got = R.PointCloud.LoadFromDepth(d16, hcam).points
     ref = oracle.load_from_depth(oracle.make_camera(*cam), d16)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_estimate_normals_matches_oracle_up_to_sign(oracle):
+    """SURVEY 8a G2: PointCloud::EstimateNormals(0.1, 30).  The reference leaves the sign open."""
+    _, pts, _ = room_cloud(42, scale=2)          # 76 800 points
+    pc = R.PointCloud(pts)
+    pc.EstimateNormals(0.1, 30)
+    ref = oracle.estimate_normals(pts, 0.1, 30)
+    dots = np.abs((pc.normals.astype(np.float64) * ref).sum(1))
+    assert np.allclose(np.linalg.norm(pc.normals, axis=1), 1, atol=1e-5)
+    # same neighbour sets -> same covariance up to float summation -> same plane; allow the few
+    # points whose two smallest singular values nearly tie (corners, sphere silhouettes)
+    assert np.mean(dots > 1 - 1e-4) > 0.995 and np.median(dots) > 1 - 1e-6
+    # tiny / degenerate inputs
+    two = R.PointCloud(pts[:2]); two.EstimateNormals()
+    assert np.array_equal(two.normals, np.zeros((2, 3), np.float32))
+    # a plane: normals are exactly +-z
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(40)), -1).reshape(-1, 2).astype(np.float32) * 0.01
+    plane = R.PointCloud(np.concatenate([g, np.full((len(g), 1), 1.5, np.float32)], 1)); plane.EstimateNormals(0.1, 30)
+    assert np.all(np.abs(np.abs(plane.normals[:, 2]) - 1) < 1e-5)
