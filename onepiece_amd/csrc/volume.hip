@@ -53,6 +53,9 @@ constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 
 constexpr int kSelectGrid = 512;     // KB persistent grid.x (256-thread workgroups) per frame
 constexpr int kIntegrateGrid = 1024; // KC persistent grid (512-thread workgroups)
 constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
+#ifndef KC_SUB
+#define KC_SUB 16 // frames whose gathers are in flight together inside k_integrate (divides kMaxBatch)
+#endif
 #ifndef KC_MIN_WAVES
 #define KC_MIN_WAVES 4 // waves per SIMD the integrate kernel is compiled for (2 workgroups of 8 waves per CU)
 #endif
@@ -457,7 +460,13 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
         (const float __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)B;
     unsigned upd = 0, sel = 0;
-    for (unsigned b = blockIdx.x; b < n; b += gridDim.x) {
+    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): XCD x walks
+    // the x-th contiguous eighth of the list, so list neighbours -- blocks along one viewing ray,
+    // which gather the same pixels -- are processed on one XCD close in time and share its L2.
+    const unsigned per_xcd = (n + 7u) / 8u;
+    for (unsigned i = blockIdx.x; i < per_xcd * 8u; i += gridDim.x) {
+        const unsigned b = (i & 7u) * per_xcd + (i >> 3);
+        if (b >= n) continue;
         const int idx = V.tvals[V.blist[b]];
         if (idx < 0) continue; // pool overflow (reported through st->overflow)
         const unsigned mask = V.bmask[V.blist[b]];
@@ -469,49 +478,58 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
         const float px = ((float)kx * 8.0f) * C.res + ox;
         const float py = ((float)ky * 8.0f) * C.res + oy;
         const float pz = ((float)kz * 8.0f) * C.res + oz;
-        uint2 rec[kMaxBatch];
-        float zc[kMaxBatch];
-#pragma unroll
-        for (int f = 0; f < kMaxBatch; ++f) {
-            rec[f] = make_uint2(0u, 0u);
-            zc[f] = 0.0f;
-            if ((mask >> f) & 1u) { // wave-uniform
-                // pose^-1 of frame f, fetched with scalar loads from the kernarg segment right here:
-                // keeping all 16 matrices (192 SGPRs) live across the block loop makes the compiler
-                // spill SGPRs through v_writelane/v_readlane (15 % of the instruction stream).
-                const float __attribute__((address_space(4)))* M = kargs + f * 12;
-                asm volatile("" : "+s"(M));
-                const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-                const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-                const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
-                const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
-                zc[f] = q2;
-                if (!(v < 0 || v >= C.height || u < 0 || u >= C.width)) rec[f] = pimg[(size_t)f * npix + (size_t)v * C.width + u];
-            }
-        }
         bool changed = false;
+        // frames are applied in order, KC_SUB at a time: all gathers of a sub-batch are issued before
+        // the first dependent use, while the register footprint stays small enough for KC_MIN_WAVES
 #pragma unroll
-        for (int f = 0; f < kMaxBatch; ++f) {
-            if ((mask >> f) & 1u) {
-                const float d = __uint_as_float(rec[f].x); // off-image pixels carry d == 0 -> skipped like `continue`
-                if (d > 0) {
-                    const float new_sdf = d - zc[f];
-                    if (fabsf(new_sdf) < C.trunc) {
-                        ++upd;
-                        changed = true;
-                        const unsigned rgba = rec[f].y;
-                        const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
-                        if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
-                            // TSDFVoxel::operator+ with other = (new_sdf, 1.0, c) (TSDFVoxel.h:24-39)
-                            const float wsum = w + 1.0f;
-                            s = (w * s + 1.0f * new_sdf) / wsum;
-                            c0 = (w * c0 + 1.0f * n0) / wsum;
-                            c1 = (w * c1 + 1.0f * n1) / wsum;
-                            c2 = (w * c2 + 1.0f * n2) / wsum;
-                            w = wsum;
-                        } else {
-                            s = new_sdf; w = 1.0f; c0 = n0; c1 = n1; c2 = n2;
+        for (int h = 0; h < kMaxBatch; h += KC_SUB) {
+            if (((mask >> h) & ((1u << KC_SUB) - 1u)) == 0u) continue; // wave-uniform
+            uint2 rec[KC_SUB];
+            float zc[KC_SUB];
+#pragma unroll
+            for (int g = 0; g < KC_SUB; ++g) {
+                const int f = h + g;
+                rec[g] = make_uint2(0u, 0u);
+                zc[g] = 0.0f;
+                if ((mask >> f) & 1u) { // wave-uniform
+                    // pose^-1 of frame f, fetched with scalar loads from the kernarg segment right here:
+                    // keeping all 16 matrices (192 SGPRs) live across the block loop makes the compiler
+                    // spill SGPRs through v_writelane/v_readlane (15 % of the instruction stream).
+                    const float __attribute__((address_space(4)))* M = kargs + f * 12;
+                    asm volatile("" : "+s"(M));
+                    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+                    const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+                    const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+                    const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
+                    const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
+                    zc[g] = q2;
+                    // uniform 64-bit frame base + 32-bit per-lane pixel offset (saddr addressing, no 64-bit VALU math)
+                    const uint2* __restrict__ fimg = pimg + (size_t)f * npix;
+                    if (!(v < 0 || v >= C.height || u < 0 || u >= C.width)) rec[g] = fimg[(unsigned)(v * C.width + u)];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < KC_SUB; ++g) {
+                if ((mask >> (h + g)) & 1u) {
+                    const float d = __uint_as_float(rec[g].x); // off-image pixels carry d == 0 -> skipped like `continue`
+                    if (d > 0) {
+                        const float new_sdf = d - zc[g];
+                        if (fabsf(new_sdf) < C.trunc) {
+                            ++upd;
+                            changed = true;
+                            const unsigned rgba = rec[g].y;
+                            const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
+                            if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
+                                // TSDFVoxel::operator+ with other = (new_sdf, 1.0, c) (TSDFVoxel.h:24-39)
+                                const float wsum = w + 1.0f;
+                                s = (w * s + 1.0f * new_sdf) / wsum;
+                                c0 = (w * c0 + 1.0f * n0) / wsum;
+                                c1 = (w * c1 + 1.0f * n1) / wsum;
+                                c2 = (w * c2 + 1.0f * n2) / wsum;
+                                w = wsum;
+                            } else {
+                                s = new_sdf; w = 1.0f; c0 = n0; c1 = n1; c2 = n2;
+                            }
                         }
                     }
                 }
@@ -521,8 +539,10 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
     }
     // every wave has read its masks: now the owner workgroup clears them for the next batch
     __syncthreads();
-    for (unsigned b = blockIdx.x; b < n; b += gridDim.x)
-        if (vid == 0) V.bmask[V.blist[b]] = 0u;
+    for (unsigned i = blockIdx.x; i < per_xcd * 8u; i += gridDim.x) {
+        const unsigned b = (i & 7u) * per_xcd + (i >> 3);
+        if (b < n && vid == 0) V.bmask[V.blist[b]] = 0u;
+    }
     // per-workgroup counters (each workgroup owns its slot: no atomics)
     upd = wave_sum(upd);
     if ((vid & 63) == 0) s_upd[vid >> 6] = upd;

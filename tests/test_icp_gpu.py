@@ -114,3 +114,25 @@ def test_estimate_normals_matches_oracle_up_to_sign(oracle):
     g = np.stack(np.meshgrid(np.arange(40), np.arange(40)), -1).reshape(-1, 2).astype(np.float32) * 0.01
     plane = R.PointCloud(np.concatenate([g, np.full((len(g), 1), 1.5, np.float32)], 1)); plane.EstimateNormals(0.1, 30)
     assert np.all(np.abs(np.abs(plane.normals[:, 2]) - 1) < 1e-5)
+
+
+def test_returned_T_is_the_exact_kabsch_of_the_returned_pairs(oracle):
+    """RegistrationResult::T = Kabsch over the final inlier pairs (ICP.cpp:221).  The reference sums
+    it sequentially in float32 (Geometry.cpp:117-133); with 3e5 near-planar pairs that float noise
+    reaches 1e-3 (measured in bench.py).  The HIP path reduces in fp64: its T must agree with a
+    float64 Kabsch of its own pairs to 1e-6, and the accumulated pose must agree with the oracle."""
+    _, src, _ = room_cloud(1, scale=1)
+    _, tgt, nrm = room_cloud(0, scale=1)
+    got = R.PointToPlane(R.PointCloud(src), R.PointCloud(tgt, nrm), None, R.ICPParameter(10, 0.01))
+    ref = oracle.icp(src, tgt, nrm, None, 10, 0.01, point_to_plane=True)
+    assert rel_err(got.last_T, ref["last_T"]) <= POSE_TOL
+    p = got.correspondence_set_index
+    s, t = src[p[:, 0]].astype(np.float64), tgt[p[:, 1]].astype(np.float64)
+    ms, mt = s.mean(0), t.mean(0)
+    U, _, Vt = np.linalg.svd((s - ms).T @ (t - mt))
+    Rm = Vt.T @ U.T
+    if np.linalg.det(Rm) < 0:
+        Vt[2] *= -1; Rm = Vt.T @ U.T
+    T64 = np.eye(4); T64[:3, :3] = Rm; T64[:3, 3] = mt - Rm @ ms
+    assert rel_err(got.T, T64) <= 1e-6
+    assert abs(len(p) - len(ref["pairs"])) <= 1e-4 * len(src)
