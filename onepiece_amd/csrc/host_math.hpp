@@ -14,6 +14,8 @@
 #include <cstdint>
 #include <cstring>
 
+#include "px_round.hpp" // OP_HD: __host__ __device__ under hipcc (the ICP update step also runs on the device)
+
 namespace op_host {
 
 // ---- Eigen fixed-size evaluation orders (3rdparty/Eigen/Eigen/src/Core/Redux.h,
@@ -121,12 +123,12 @@ inline void frustum_planes(const CameraPOD& cam, const float pose[16], float far
 }
 
 // ---- SE3 exponential, Sophus convention x = (upsilon, omega) (3rdparty/Sophus/sophus/se3.hpp:468-489).
-inline void se3_exp(const float x[6], float T[16]) {
+OP_HD void se3_exp(const float x[6], float T[16]) {
     const double w[3] = {x[3], x[4], x[5]}, u[3] = {x[0], x[1], x[2]};
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
     double a, b, c; // R = I + a W + b W^2, V = I + b W + c W^2
     if (th < 1e-5) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0; }
-    else { a = std::sin(th) / th; b = (1.0 - std::cos(th)) / th2; c = (th - std::sin(th)) / (th2 * th); }
+    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th); }
     const double W[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
     double W2[3][3];
     for (int i = 0; i < 3; ++i)
@@ -145,7 +147,7 @@ inline void se3_exp(const float x[6], float T[16]) {
 
 // ---- symmetric eigen-decomposition (cyclic Jacobi), N <= 6, double.
 template <int N>
-inline void sym_eig(double A[N][N], double V[N][N]) {
+OP_HD void sym_eig(double A[N][N], double V[N][N]) {
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) V[i][j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 64; ++sweep) {
@@ -156,10 +158,10 @@ inline void sym_eig(double A[N][N], double V[N][N]) {
         for (int p = 0; p < N; ++p)
             for (int q = p + 1; q < N; ++q) {
                 const double apq = A[p][q];
-                if (std::fabs(apq) < 1e-300) continue;
+                if (fabs(apq) < 1e-300) continue;
                 const double theta = (A[q][q] - A[p][p]) / (2 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
-                const double cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double cs = 1 / sqrt(t * t + 1), sn = t * cs;
                 for (int k = 0; k < N; ++k) {
                     const double kp = A[k][p], kq = A[k][q];
                     A[k][p] = cs * kp - sn * kq; A[k][q] = sn * kp + cs * kq;
@@ -178,18 +180,18 @@ inline void sym_eig(double A[N][N], double V[N][N]) {
 
 // x = JacobiSVD(JTJ).solve(-JTr) (Registration/ICP.cpp:137-138): minimum-norm least squares with
 // Eigen's default rank threshold (singular values <= eps_float * 6 * max are dropped).
-inline void solve6_psd(const double JTJ[36], const double JTr[6], float x[6]) {
+OP_HD void solve6_psd(const double JTJ[36], const double JTr[6], float x[6]) {
     double A[6][6], V[6][6], y[6];
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (JTJ[i * 6 + j] + JTJ[j * 6 + i]);
     sym_eig<6>(A, V);
     double smax = 0;
-    for (int i = 0; i < 6; ++i) smax = std::fabs(A[i][i]) > smax ? std::fabs(A[i][i]) : smax;
+    for (int i = 0; i < 6; ++i) smax = fabs(A[i][i]) > smax ? fabs(A[i][i]) : smax;
     const double thr = smax * 6.0 * static_cast<double>(FLT_EPSILON);
     for (int k = 0; k < 6; ++k) {
         double s = 0;
         for (int i = 0; i < 6; ++i) s += V[i][k] * (-JTr[i]);
-        y[k] = std::fabs(A[k][k]) > thr ? s / A[k][k] : 0.0;
+        y[k] = fabs(A[k][k]) > thr ? s / A[k][k] : 0.0;
     }
     for (int i = 0; i < 6; ++i) {
         double s = 0;
@@ -200,7 +202,7 @@ inline void solve6_psd(const double JTJ[36], const double JTr[6], float x[6]) {
 
 // Kabsch from sufficient statistics (Geometry/Geometry.cpp:107-151): n, sum s, sum t, sum s t^T.
 // W = sum (s - ms)(t - mt)^T = sum s t^T - n ms mt^T.  R = V U^T (det-fixed), t = mt - R ms.
-inline void kabsch_from_sums(double n, const double ss[3], const double st[3], const double sst[9], float T[16]) {
+OP_HD void kabsch_from_sums(double n, const double ss[3], const double st[3], const double sst[9], float T[16]) {
     double ms[3], mt[3], W[3][3];
     for (int i = 0; i < 3; ++i) { ms[i] = ss[i] / n; mt[i] = st[i] / n; }
     for (int i = 0; i < 3; ++i)
@@ -216,7 +218,7 @@ inline void kabsch_from_sums(double n, const double ss[3], const double st[3], c
     double Vs[3][3], S[3], U[3][3];
     for (int k = 0; k < 3; ++k) {
         const double ev = A[ord[k]][ord[k]];
-        S[k] = std::sqrt(ev > 0 ? ev : 0);
+        S[k] = sqrt(ev > 0 ? ev : 0);
         for (int i = 0; i < 3; ++i) Vs[i][k] = V[i][ord[k]];
     }
     for (int k = 0; k < 3; ++k)
@@ -239,7 +241,7 @@ inline void kabsch_from_sums(double n, const double ss[3], const double st[3], c
         if (det >= 0) break;
         for (int i = 0; i < 3; ++i) Vs[i][2] = -Vs[i][2]; // Geometry.cpp:139-144
     }
-    std::memset(T, 0, 16 * sizeof(float));
+    for (int i = 0; i < 16; ++i) T[i] = 0.0f;
     for (int i = 0; i < 3; ++i) {
         double s = 0;
         for (int j = 0; j < 3; ++j) { T[i * 4 + j] = static_cast<float>(R[i][j]); s += R[i][j] * ms[j]; }
@@ -249,12 +251,12 @@ inline void kabsch_from_sums(double n, const double ss[3], const double st[3], c
 }
 
 // Matrix4f * Matrix4f (start_T = tmp_T * start_T, ICP.cpp:198), column-accumulating product.
-inline void mat4_mul(const float* A, const float* B, float* C) {
+OP_HD void mat4_mul(const float* A, const float* B, float* C) {
     float out[16];
     for (int r = 0; r < 4; ++r)
         for (int c = 0; c < 4; ++c)
             out[r * 4 + c] = ((A[r * 4] * B[c] + A[r * 4 + 1] * B[4 + c]) + A[r * 4 + 2] * B[8 + c]) + A[r * 4 + 3] * B[12 + c];
-    std::memcpy(C, out, sizeof(out));
+    for (int i = 0; i < 16; ++i) C[i] = out[i];
 }
 
 inline uint64_t hash_key(int32_t x, int32_t y, int32_t z) { // Geometry/Geometry.h:101-112
