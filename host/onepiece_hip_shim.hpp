@@ -1,0 +1,144 @@
+// onepiece_hip_shim.hpp -- C++ glue between the reference's own types and the C-ABI of
+// include/onepiece_hip.h.  Header-only templates: they name no Eigen / OpenCV / OnePiece header, so
+// they compile inside the reference tree (where geometry::TransformationMatrix is Eigen::Matrix4f,
+// images are cv::Mat, CubeMap is std::unordered_map<CubeID, VoxelCube, CubeHasher>) and, for the
+// tests of this repository, against small look-alike types (tests/cpp/shim_check.cpp).
+//
+// INTEGRATION.md shows where each helper is called from inside the reference's
+// CubeHandler (src/Integration/CubeHandler.{h,cpp}) and ICP (src/Registration/ICP.cpp).
+//
+// Type requirements (all satisfied by the reference's types):
+//   Mat4    : float operator()(int row, int col)                    geometry::TransformationMatrix
+//   Image   : .data (byte pointer), int depth()                      cv::Mat (CV_32F == 5, CV_16U == 2)
+//   CubeMap : operator[](CubeID) -> VoxelCube&, clear(), size(), iteration over (CubeID, VoxelCube)
+//   CubeID  : CubeID(int,int,int), int operator()(int)               Eigen::Vector3i
+//   VoxelCube : VoxelCube(CubeID), std::vector<TSDFVoxel> voxels (512, index x + 8y + 64z)
+//   TSDFVoxel : TSDFVoxel(float sdf, float weight, Point3 color), .sdf, .weight, .color(k)
+//   Point3  : Point3(float,float,float), float operator()(int), data() -> contiguous floats
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "onepiece_hip.h"
+
+namespace one_piece {
+namespace hip_shim {
+
+constexpr int kCvDepth32F = 5; // CV_32F: the reference compares depth.depth() == CV_32FC1 (Integrator.cpp:26)
+
+template <class Mat4>
+inline void RowMajor(const Mat4& m, float out[16]) {
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[r * 4 + c] = m(r, c);
+}
+
+template <class Mat4>
+inline void FromRowMajor(const float in[16], Mat4& m) {
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) m(r, c) = in[r * 4 + c];
+}
+
+// CubeHandler::IntegrateImage(depth, rgb, pose) (CubeHandler.cpp:197-210).  pose_inv: the caller's
+// own pose.inverse() (Eigen), so block selection sees exactly the matrix the reference would use.
+template <class Image, class Mat4>
+inline int IntegrateImage(op_volume* vol, const Image& depth, const Image& rgb, const Mat4& pose, const Mat4& pose_inv) {
+    float p[16], pi[16];
+    RowMajor(pose, p);
+    RowMajor(pose_inv, pi);
+    const int fmt = depth.depth() == kCvDepth32F ? OP_DEPTH_F32 : OP_DEPTH_U16;
+    return op_volume_integrate(vol, depth.data, fmt, reinterpret_cast<const uint8_t*>(rgb.data), OP_MEM_HOST, p, pi);
+}
+
+// CubeHandler::PrepareCubes (CubeHandler.cpp:147-196): fills cube_id_list in the reference's order.
+template <class CubeID, class Image, class Mat4>
+inline int PrepareCubes(op_volume* vol, const Image& depth, const Mat4& pose, const Mat4& pose_inv, std::vector<CubeID>& cube_id_list) {
+    float p[16], pi[16];
+    RowMajor(pose, p);
+    RowMajor(pose_inv, pi);
+    const int fmt = depth.depth() == kCvDepth32F ? OP_DEPTH_F32 : OP_DEPTH_U16;
+    size_t n = 0;
+    std::vector<int32_t> ids(3 * 65536);
+    int rc = op_volume_prepare_cubes(vol, depth.data, fmt, OP_MEM_HOST, p, pi, ids.data(), ids.size() / 3, &n, nullptr);
+    if (rc == OP_OK && n > ids.size() / 3) { // blocks are already allocated: the second call only re-lists them
+        ids.resize(3 * n);
+        rc = op_volume_prepare_cubes(vol, depth.data, fmt, OP_MEM_HOST, p, pi, ids.data(), n, &n, nullptr);
+    }
+    cube_id_list.clear();
+    if (rc != OP_OK) return rc;
+    for (size_t i = 0; i < n; ++i) cube_id_list.push_back(CubeID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
+    return OP_OK;
+}
+
+// device volume -> host CubeMap (what GetCubeMap / ExtractTriangleMesh / WriteToFile / ... read)
+template <class CubeMap, class CubeID, class VoxelCube, class TSDFVoxel, class Point3>
+inline int DownloadInto(op_volume* vol, CubeMap& cube_map) {
+    size_t n = 0;
+    int rc = op_volume_block_count(vol, &n);
+    if (rc != OP_OK) return rc;
+    std::vector<int32_t> keys(3 * n);
+    std::vector<float> vox(n * 512 * 5);
+    if (n) rc = op_volume_download(vol, keys.data(), vox.data(), n, &n);
+    if (rc != OP_OK) return rc;
+    cube_map.clear();
+    for (size_t b = 0; b < n; ++b) {
+        const CubeID id(keys[3 * b], keys[3 * b + 1], keys[3 * b + 2]);
+        VoxelCube& cube = (cube_map[id] = VoxelCube(id));
+        for (int v = 0; v < 512; ++v) {
+            const float* p = &vox[(b * 512 + v) * 5];
+            cube.voxels[v] = TSDFVoxel(p[0], p[1], Point3(p[2], p[3], p[4]));
+        }
+    }
+    return OP_OK;
+}
+
+// host CubeMap -> device volume (after ReadFromFile / SetCubeMap / host-side edits)
+template <class CubeMap>
+inline int UploadFrom(op_volume* vol, const CubeMap& cube_map) {
+    int rc = op_volume_clear(vol);
+    if (rc != OP_OK) return rc;
+    std::vector<int32_t> keys;
+    std::vector<float> vox;
+    keys.reserve(3 * cube_map.size());
+    vox.reserve(cube_map.size() * 512 * 5);
+    for (auto it = cube_map.begin(); it != cube_map.end(); ++it) {
+        for (int c = 0; c < 3; ++c) keys.push_back(it->first(c));
+        for (int v = 0; v < 512; ++v) {
+            const auto& t = it->second.voxels[v];
+            vox.push_back(t.sdf); vox.push_back(t.weight);
+            vox.push_back(t.color(0)); vox.push_back(t.color(1)); vox.push_back(t.color(2));
+        }
+    }
+    return op_volume_upload(vol, keys.data(), vox.data(), keys.size() / 3);
+}
+
+// registration::PointToPlane / PointToPoint (ICP.cpp:146-224 / :31-107) for clouds whose points are
+// contiguous xyz floats (geometry::Point3List = std::vector<Eigen::Vector3f>).
+// Result must offer: T (Mat4), rmse, correspondence_set_index (vector<pair<int,int>>),
+// correspondence_set (vector<pair<Point3,Point3>>).
+template <class Result, class Point3List, class Mat4>
+inline int RunICP(int mode, const Point3List& source, const Point3List& target, const Point3List* target_normals, const Mat4& init_T,
+                  int max_iteration, double threshold, int device, Result& result) {
+    float T0[16];
+    RowMajor(init_T, T0);
+    op_icp_result r;
+    std::vector<int32_t> pairs(2 * source.size() + 2);
+    const float* nrm = (target_normals && !target_normals->empty()) ? (*target_normals)[0].data() : nullptr;
+    const int rc = op_icp_register(mode, source.empty() ? nullptr : source[0].data(), source.size(), target.empty() ? nullptr : target[0].data(), nrm,
+                                   target.size(), T0, max_iteration, threshold, device, &r, pairs.data(), source.size());
+    if (rc != OP_OK) return rc;
+    FromRowMajor(r.T, result.T);
+    result.rmse = r.rmse;
+    result.correspondence_set_index.clear();
+    result.correspondence_set.clear();
+    for (uint64_t k = 0; k < r.n_inliers; ++k) {
+        result.correspondence_set_index.push_back(std::make_pair((int)pairs[2 * k], (int)pairs[2 * k + 1]));
+        result.correspondence_set.push_back(std::make_pair(source[pairs[2 * k]], target[pairs[2 * k + 1]]));
+    }
+    return OP_OK;
+}
+
+} // namespace hip_shim
+} // namespace one_piece
