@@ -56,11 +56,20 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch N>1 with torch.distributed.run" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback path")
+    # Test hooks (not used by the driver): ONEPIECE_BENCH_SINGLE_DEVICE=1 maps every rank to cuda:0 and
+    # ONEPIECE_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 control flow can be exercised on a
+    # one-GPU box (RCCL refuses two ranks on one device).
+    if os.environ.get("ONEPIECE_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("ONEPIECE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from onepiece_amd import integration as I, synthetic as S, distributed as D
 

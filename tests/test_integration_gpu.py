@@ -231,3 +231,24 @@ def test_prepare_cubes_leaves_no_pending_selection(oracle):
     ov.prepare_cubes(d0, p0); hv.PrepareCubes(d0, p0)
     ov.integrate(d1, c1, p1); hv.IntegrateImage(d1, c1, p1)
     _compare(oracle, ov, hv)
+
+
+def test_bench_multi_rank_flow_on_one_gpu(oracle, tmp_path):
+    """bench.py --gpus 2 end to end (frame sharding, per-rank fusion, key all_gather, union, sum-form
+    pack, ONE reduce, normalise on rank 0, max-over-ranks timing) with both ranks on cuda:0 and gloo
+    standing in for RCCL (RCCL refuses two ranks on one device)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ONEPIECE_BENCH_SINGLE_DEVICE="1", ONEPIECE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames-per-step", "20", "--no-icp"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["merge_union_blocks"] and r["merge_union_blocks"] >= r["per_frame"]["blocks_selected"]
+    # rank 0's volume now holds the union
+    assert r["per_frame"]["final_blocks_rank0"] == r["merge_union_blocks"]
