@@ -106,7 +106,10 @@ int op_volume_prepare_cubes(op_volume *v, const void *depth, int depth_fmt, int 
                             const float pose[16], const float *pose_inv, int32_t *ids_xyz,
                             size_t cap, size_t *n, size_t *n_candidates);
 /* CubeHandler::IntegrateImage(depth, rgb, pose) (CubeHandler.cpp:197-210 -> Integrator.cpp:36-94).
- * Asynchronous on the volume's stream. */
+ * Asynchronous: frames are queued and fused up to 16 at a time (results identical to frame-by-frame
+ * fusion); every accessor / setter / op_volume_sync flushes the queue first.  OP_MEM_HOST images are
+ * copied before the call returns; OP_MEM_DEVICE images must stay valid until the next
+ * synchronising call. */
 int op_volume_integrate(op_volume *v, const void *depth, int depth_fmt, const uint8_t *rgb,
                         int mem, const float pose[16], const float *pose_inv);
 /* Multi-frame form of the same call for frames already resident on the device: frame f uses

@@ -50,7 +50,10 @@ constexpr unsigned long long kEmptyKey = ~0ULL; // table slot never used
 constexpr int kPending = -1;         // slot claimed, pool slot not published yet
 constexpr int kDead = -3;            // slot claimed but the pool was full
 constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 4)
-constexpr int kSelectGrid = 512;     // KB persistent grid.x (256-thread workgroups) per frame
+#ifndef KB_GRID
+#define KB_GRID 512
+#endif
+constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
 constexpr int kIntegrateGrid = 1024; // KC persistent grid (512-thread workgroups)
 constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
 #ifndef KC_SUB
@@ -71,6 +74,7 @@ struct PoseFwd { float pose[16]; float planes[24]; }; // planes: top, left, righ
 struct PoseInv { float m[12]; };                      // rows 0..2 of pose^-1
 struct BatchFwd { PoseFwd f[kMaxBatch]; };
 struct BatchInv { PoseInv f[kMaxBatch]; };
+struct BatchPtrs { const void* depth[kMaxBatch]; const unsigned char* rgb[kMaxBatch]; }; // device images of each frame
 
 struct State {
     unsigned n_batch;   // length of the batch block list
@@ -231,17 +235,16 @@ __global__ void k_finish_select(VolView V, const State* st) {
 // the later gathers are single 8-byte loads.  grid = (ceil(W*H/1024), n_frames).
 // One bounding partial per workgroup (no atomics): [max x,y,z, min x,y,z, inside, pad].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C, const void* __restrict__ depth, size_t depth_stride,
-                                                        const unsigned char* __restrict__ rgb, size_t rgb_stride,
-                                                        uint2* __restrict__ pimg, float* __restrict__ partial, State* st) {
+__global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C, BatchPtrs Q, uint2* __restrict__ pimg,
+                                                        float* __restrict__ partial, State* st) {
     __shared__ float s_red[4][6];
     __shared__ unsigned s_cnt[4];
     const int tid = threadIdx.x, f = blockIdx.y;
     if (blockIdx.x == 0 && f == 0 && tid == 0) { st->n_batch = 0; st->n_rec = 0; } // new batch: empty lists
     const PoseFwd& P = B.f[f];
     const int npix = C.width * C.height;
-    const void* dptr = (const char*)depth + (size_t)f * depth_stride;
-    const unsigned char* cptr = rgb ? rgb + (size_t)f * rgb_stride : nullptr;
+    const void* dptr = Q.depth[f];
+    const unsigned char* cptr = Q.rgb[f];
     uint2* out = pimg + (size_t)f * npix;
     float mx0 = -FLT_MAX, mx1 = -FLT_MAX, mx2 = -FLT_MAX, mn0 = FLT_MAX, mn1 = FLT_MAX, mn2 = FLT_MAX;
     unsigned inside = 0;
@@ -382,13 +385,31 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
             const int bj = j0 + (int)((c / (unsigned long long)nk) % (unsigned long long)nj);
             const int bi = i0 + (int)(c / (unsigned long long)(nk * nj));
             const float bx = (float)bi * cube_res, by = (float)bj * cube_res, bz = (float)bk * cube_res;
-            float min_sdf = FLT_MAX;
+            // Integrator::GetSDF (Integrator.cpp:8-35) for the 8 corner voxels {0,7,56,63,448,455,504,511}:
+            // all 8 projections first, then all 8 gathers in flight together, then the min
+            int pix[8];
+            float zc[8];
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) { // voxel ids {0,7,56,63,448,455,504,511}
+            for (int corner = 0; corner < 8; ++corner) {
                 const float px = bx + ((corner & 1) ? o_hi : o_lo);
                 const float py = by + ((corner & 2) ? o_hi : o_lo);
                 const float pz = bz + ((corner & 4) ? o_hi : o_lo);
-                const float a = fabsf(get_sdf<FAST>(C, M, img, px, py, pz));
+                const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+                const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+                const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+                const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
+                const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
+                zc[corner] = q2;
+                pix[corner] = (v < 0 || v >= C.height || u < 0 || u >= C.width) ? -1 : v * C.width + u;
+            }
+            float dd[8];
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) dd[corner] = pix[corner] >= 0 ? __uint_as_float(img[(unsigned)pix[corner]].x) : 0.0f;
+            float min_sdf = FLT_MAX;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const float sdf = dd[corner] <= 0 ? 999.0f : dd[corner] - zc[corner]; // off-image or d <= 0 -> 999
+                const float a = fabsf(sdf);
                 if (min_sdf > a) min_sdf = a;
             }
             if (min_sdf < C.trunc) {
@@ -838,9 +859,16 @@ struct op_volume {
     uint64_t prof_batch = 0;
     std::vector<hipEvent_t> prof_events; // 4 per sampled batch
     std::vector<int> prof_frames;
-    void* img_depth = nullptr; // staging for host images
+    // staging ring for host images: one slot per frame of a batch
+    void* img_depth = nullptr;
     unsigned char* img_rgb = nullptr;
     size_t img_cap_px = 0;
+    // frames accepted by op_volume_integrate but not launched yet: single-frame calls are queued
+    // and fused in batches of kMaxBatch (every accessor flushes first, so this is unobservable)
+    int pend_n = 0, pend_fmt = 0;
+    BatchFwd pend_F;
+    BatchInv pend_I;
+    BatchPtrs pend_P;
 
     VolView view() const {
         VolView V;
@@ -852,6 +880,8 @@ struct op_volume {
 };
 
 namespace {
+
+int vol_flush(op_volume* v); // launches the frames queued by op_volume_integrate
 
 int vol_reset(op_volume* v) {
     hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, v->tkeys, v->tvals, (size_t)v->table_size);
@@ -866,6 +896,7 @@ int vol_reset(op_volume* v) {
 
 // Raises OP_ERR_CAPACITY if a previous kernel flagged an overflow.  Synchronises.
 int vol_check(op_volume* v) {
+    OP_TRY(vol_flush(v));
     OP_HIP(hipStreamSynchronize(v->stream));
     unsigned of = 0;
     OP_HIP(hipMemcpy(&of, &v->state->overflow, sizeof(of), hipMemcpyDeviceToHost));
@@ -883,21 +914,28 @@ int vol_block_count(op_volume* v, unsigned* n) {
     return OP_OK;
 }
 
-int vol_stage_images(op_volume* v, const void** depth, int depth_fmt, const unsigned char** rgb, int mem) {
+// Host images are copied into slot `slot` of the staging ring (stream-ordered, so a slot is not
+// overwritten before the batch that used it has been prepared); device images are used in place.
+int vol_stage_images(op_volume* v, const void** depth, int depth_fmt, const unsigned char** rgb, int mem, int slot = 0) {
     if (mem == OP_MEM_DEVICE) return OP_OK;
     const size_t npx = (size_t)v->cam.width * v->cam.height;
     if (npx > v->img_cap_px) {
+        OP_TRY(vol_flush(v));
+        OP_HIP(hipStreamSynchronize(v->stream));
         if (v->img_depth) OP_HIP(hipFree(v->img_depth));
         if (v->img_rgb) OP_HIP(hipFree(v->img_rgb));
-        OP_HIP(hipMalloc(&v->img_depth, npx * 4));
-        OP_HIP(hipMalloc((void**)&v->img_rgb, npx * 3));
+        v->img_depth = nullptr; v->img_rgb = nullptr; v->img_cap_px = 0;
+        OP_HIP(hipMalloc(&v->img_depth, (size_t)kMaxBatch * npx * 4));
+        OP_HIP(hipMalloc((void**)&v->img_rgb, (size_t)kMaxBatch * npx * 3));
         v->img_cap_px = npx;
     }
-    OP_HIP(hipMemcpyAsync(v->img_depth, *depth, npx * (depth_fmt == OP_DEPTH_U16 ? 2 : 4), hipMemcpyHostToDevice, v->stream));
-    *depth = v->img_depth;
+    void* d = (char*)v->img_depth + (size_t)slot * npx * 4;
+    OP_HIP(hipMemcpyAsync(d, *depth, npx * (depth_fmt == OP_DEPTH_U16 ? 2 : 4), hipMemcpyHostToDevice, v->stream));
+    *depth = d;
     if (rgb && *rgb) {
-        OP_HIP(hipMemcpyAsync(v->img_rgb, *rgb, npx * 3, hipMemcpyHostToDevice, v->stream));
-        *rgb = v->img_rgb;
+        unsigned char* c = v->img_rgb + (size_t)slot * npx * 3;
+        OP_HIP(hipMemcpyAsync(c, *rgb, npx * 3, hipMemcpyHostToDevice, v->stream));
+        *rgb = c;
     }
     return OP_OK;
 }
@@ -938,8 +976,7 @@ int vol_ensure_frame_buffers(op_volume* v) {
 
 // Enqueue one batch (1..kMaxBatch frames whose images are on the device): KA, KB and, unless
 // select_only, KC.  No host synchronisation.
-int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, int nf, int depth_fmt, const void* d_depth, size_t depth_stride,
-                      const unsigned char* d_rgb, size_t rgb_stride, bool select_only, bool record) {
+int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const BatchPtrs& Q, int nf, int depth_fmt, bool select_only, bool record) {
     OP_TRY(vol_ensure_frame_buffers(v));
     const CamParams C = cam_params(v, depth_fmt);
     const int npix = C.width * C.height;
@@ -952,8 +989,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, int nf
         for (auto& e : ev) OP_HIP(hipEventCreate(&e));
         OP_HIP(hipEventRecord(ev[0], v->stream));
     }
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, d_depth, depth_stride, d_rgb, rgb_stride, v->pimg,
-                       v->partial, v->state);
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state);
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
     if (C.fast_px)
         hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
@@ -977,6 +1013,14 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, int nf
     }
     OP_HIP(hipGetLastError());
     return OP_OK;
+}
+
+// launch the frames queued by op_volume_integrate
+int vol_flush(op_volume* v) {
+    if (v->pend_n == 0) return OP_OK;
+    const int nf = v->pend_n;
+    v->pend_n = 0;
+    return vol_enqueue_batch(v, v->pend_F, v->pend_I, v->pend_P, nf, v->pend_fmt, false, false);
 }
 
 int check_cam(const op_camera* cam) {
@@ -1091,29 +1135,34 @@ int op_volume_destroy(op_volume* v) {
 
 int op_volume_set_resolution(op_volume* v, float voxel_res) {
     OP_VOL(v);
+    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
     if (!(voxel_res > 0)) return fail(OP_ERR_INVALID, "voxel_res must be > 0");
     v->res = voxel_res;
     return OP_OK;
 }
 int op_volume_set_truncation(op_volume* v, float truncation) {
     OP_VOL(v);
+    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
     v->trunc = truncation;
     return OP_OK;
 }
 int op_volume_set_camera(op_volume* v, const op_camera* cam) {
     OP_VOL(v);
+    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
     OP_TRY(check_cam(cam));
     v->cam = *cam;
     return OP_OK;
 }
 int op_volume_set_near_far(op_volume* v, float near_dist, float far_dist) {
     OP_VOL(v);
+    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
     v->near_d = near_dist; v->far_d = far_dist;
     return OP_OK;
 }
 
 int op_volume_clear(op_volume* v) {
     OP_VOL(v);
+    v->pend_n = 0; // queued frames would be wiped anyway
     unsigned n = 0;
     OP_HIP(hipStreamSynchronize(v->stream));
     OP_HIP(hipMemcpy(&n, v->n_blocks, sizeof(n), hipMemcpyDeviceToHost));
@@ -1149,15 +1198,17 @@ int op_volume_compute_bounding(op_volume* v, const void* depth, int depth_fmt, i
                                float min_pos[3], size_t* n_inside) {
     OP_VOL(v);
     if (!depth || !pose) return fail(OP_ERR_INVALID, "null argument");
+    OP_TRY(vol_flush(v));
     OP_TRY(vol_stage_images(v, &depth, depth_fmt, nullptr, mem));
     OP_TRY(vol_ensure_frame_buffers(v));
     BatchFwd F;
     BatchInv I;
+    BatchPtrs Q{};
     frame_params(v, pose, nullptr, &F.f[0], &I.f[0]);
+    Q.depth[0] = depth;
     const CamParams C = cam_params(v, depth_fmt);
     const int npix = C.width * C.height, g1 = (npix + kPixPerWg - 1) / kPixPerWg;
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, depth, (size_t)0, (const unsigned char*)nullptr, (size_t)0,
-                       v->pimg, v->partial, v->state);
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state);
     OP_HIP(hipGetLastError());
     OP_HIP(hipStreamSynchronize(v->stream));
     std::vector<float> part((size_t)g1 * 8);
@@ -1183,11 +1234,14 @@ int op_volume_prepare_cubes(op_volume* v, const void* depth, int depth_fmt, int 
                             int32_t* ids_xyz, size_t cap, size_t* n, size_t* n_candidates) {
     OP_VOL(v);
     if (!depth || !pose) return fail(OP_ERR_INVALID, "null argument");
+    OP_TRY(vol_flush(v));
     OP_TRY(vol_stage_images(v, &depth, depth_fmt, nullptr, mem));
     BatchFwd F;
     BatchInv I;
+    BatchPtrs Q{};
     frame_params(v, pose, pose_inv, &F.f[0], &I.f[0]);
-    OP_TRY(vol_enqueue_batch(v, F, I, 1, depth_fmt, depth, 0, nullptr, 0, /*select_only=*/true, /*record=*/true));
+    Q.depth[0] = depth;
+    OP_TRY(vol_enqueue_batch(v, F, I, Q, 1, depth_fmt, /*select_only=*/true, /*record=*/true));
     OP_TRY(vol_check(v));
     State st;
     OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
@@ -1219,29 +1273,42 @@ int op_volume_integrate(op_volume* v, const void* depth, int depth_fmt, const ui
                         const float* pose_inv) {
     OP_VOL(v);
     if (!depth || !rgb || !pose) return fail(OP_ERR_INVALID, "null argument");
+    // Single frames are queued and fused kMaxBatch at a time (one launch group per batch instead of
+    // per frame); every accessor, setter and synchronising call flushes the queue first, so the
+    // deferral cannot be observed.  Host images are copied to the staging ring right here (the
+    // caller's buffers are only borrowed for the call); device images are used in place at flush.
+    if (v->pend_n > 0 && v->pend_fmt != depth_fmt) OP_TRY(vol_flush(v));
     const unsigned char* c = rgb;
-    OP_TRY(vol_stage_images(v, &depth, depth_fmt, &c, mem));
-    BatchFwd F;
-    BatchInv I;
-    frame_params(v, pose, pose_inv, &F.f[0], &I.f[0]);
-    return vol_enqueue_batch(v, F, I, 1, depth_fmt, depth, 0, c, 0, false, false);
+    const int slot = v->pend_n;
+    OP_TRY(vol_stage_images(v, &depth, depth_fmt, &c, mem, slot));
+    frame_params(v, pose, pose_inv, &v->pend_F.f[slot], &v->pend_I.f[slot]);
+    v->pend_P.depth[slot] = depth;
+    v->pend_P.rgb[slot] = c;
+    v->pend_fmt = depth_fmt;
+    if (++v->pend_n == kMaxBatch) return vol_flush(v);
+    return OP_OK;
 }
 
 int op_volume_integrate_sequence(op_volume* v, const void* depth, size_t depth_stride_bytes, int depth_fmt, const uint8_t* rgb,
                                  size_t rgb_stride_bytes, const float* poses, size_t n_frames) {
     OP_VOL(v);
     if (!depth || !rgb || !poses) return fail(OP_ERR_INVALID, "null argument");
+    OP_TRY(vol_flush(v));
     BatchFwd F;
     BatchInv I;
+    BatchPtrs Q{};
     // balanced batches (sizes differ by at most one): 100 frames -> 7 launches of 14-15 frames
     // rather than 6 x 16 + 4, so no launch group is left with a poorly amortised tail
     const size_t n_batches = (n_frames + kMaxBatch - 1) / kMaxBatch;
     size_t f0 = 0;
     for (size_t b = 0; b < n_batches; ++b) {
         const int nf = (int)(n_frames / n_batches + (b < n_frames % n_batches ? 1 : 0));
-        for (int f = 0; f < nf; ++f) frame_params(v, poses + 16 * (f0 + f), nullptr, &F.f[f], &I.f[f]);
-        OP_TRY(vol_enqueue_batch(v, F, I, nf, depth_fmt, (const char*)depth + f0 * depth_stride_bytes, depth_stride_bytes,
-                                 rgb + f0 * rgb_stride_bytes, rgb_stride_bytes, false, false));
+        for (int f = 0; f < nf; ++f) {
+            frame_params(v, poses + 16 * (f0 + f), nullptr, &F.f[f], &I.f[f]);
+            Q.depth[f] = (const char*)depth + (f0 + f) * depth_stride_bytes;
+            Q.rgb[f] = rgb + (f0 + f) * rgb_stride_bytes;
+        }
+        OP_TRY(vol_enqueue_batch(v, F, I, Q, nf, depth_fmt, false, false));
         f0 += (size_t)nf;
     }
     return OP_OK;
@@ -1266,6 +1333,7 @@ int op_volume_stats(op_volume* v, uint64_t* frames, uint64_t* blocks_selected, u
 
 int op_volume_profile_enable(op_volume* v, int sample_every) {
     OP_VOL(v);
+    OP_TRY(vol_flush(v));
     OP_HIP(hipStreamSynchronize(v->stream));
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     v->prof_events.clear();
@@ -1278,6 +1346,7 @@ int op_volume_profile_enable(op_volume* v, int sample_every) {
 int op_volume_profile_read(op_volume* v, double ms_sum[3], uint64_t* n_launches, uint64_t* n_frames) {
     OP_VOL(v);
     if (!ms_sum || !n_launches || !n_frames) return fail(OP_ERR_INVALID, "null argument");
+    OP_TRY(vol_flush(v));
     OP_HIP(hipStreamSynchronize(v->stream));
     ms_sum[0] = ms_sum[1] = ms_sum[2] = 0.0;
     const size_t n = v->prof_events.size() / 4;

@@ -86,8 +86,17 @@ def merge_volumes(ops, root=0, group=None):
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded, group=group)
     allk = torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
-    # 2. identical sorted union on every rank
-    union = torch.unique(allk, dim=0).contiguous() if allk.shape[0] else allk
+    # 2. identical sorted union on every rank: pack each key into one int64 (3 x 21 bits, the same
+    #    packing the device hash table uses) so that the union is a 1-D radix sort instead of the much
+    #    slower row-wise torch.unique(dim=0); the packed order is the lexicographic (x, y, z) order
+    if allk.shape[0]:
+        off = 1 << 20
+        k64 = allk.to(torch.int64) + off
+        packed_keys = torch.unique((k64[:, 0] << 42) | (k64[:, 1] << 21) | k64[:, 2])
+        union = torch.stack([(packed_keys >> 42) - off, ((packed_keys >> 21) & 0x1FFFFF) - off, (packed_keys & 0x1FFFFF) - off],
+                            dim=1).to(torch.int32).contiguous()
+    else:
+        union = allk
     n_union = int(union.shape[0])
     if n_union == 0:
         return 0

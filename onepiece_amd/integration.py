@@ -78,6 +78,7 @@ class CubeHandler:
         # defaults: VoxelResolution 0.01 (VoxelCube.h:27), truncation 0.1 (Integrator.h:23),
         # far 5.0 / near 0.5 (CubeHandler.h:363-364)
         self._res, self._trunc, self._far, self._near = 0.01, 0.1, 5.0, 0.5
+        self._alive = []
         L.check(self._lib.op_volume_create(C.byref(self.camera), self._res, self._trunc, self._far,
                                            self._near, device, max_blocks, C.byref(self._h)))
 
@@ -144,10 +145,11 @@ class CubeHandler:
             raise ValueError("depth and rgb must both be host arrays or both be device tensors")
         pose = _f32(pose).reshape(16)
         pinv = _f32(pose_inv).reshape(16) if pose_inv is not None else None
+        # host buffers are borrowed for the call only (the library stages them before returning); device
+        # tensors must stay alive until the next synchronising call -- keep a reference until then
         L.check(self._lib.op_volume_integrate(self._h, pd, fmt, pr, mem, _fp(pose), _fp(pinv) if pinv is not None else None))
-        if mem == L.OP_MEM_HOST:
-            # host buffers are borrowed for the call only (SURVEY 8b "Ownership")
-            self.Synchronize()
+        if mem == L.OP_MEM_DEVICE:
+            self._alive.append((_k1, _k2))
 
     def IntegrateSequence(self, depth, rgb, poses):
         """n frames resident on the device (torch tensors [n,h,w] / [n,h,w,3]); identical to n
@@ -164,6 +166,7 @@ class CubeHandler:
 
     def Synchronize(self):
         L.check(self._lib.op_volume_sync(self._h))
+        self._alive = []
 
     def Stream(self):
         s = C.c_void_p()
@@ -236,6 +239,7 @@ class CubeHandler:
         out = cls.__new__(cls)
         out._lib = L.load()
         out.camera, out.device, out._h = camera, device, handle
+        out._alive = []
         res = C.c_float(0)
         L.check(out._lib.op_volume_resolution(handle, C.byref(res)))
         out._res, out._trunc, out._far, out._near = float(res.value), None, None, None
