@@ -158,6 +158,16 @@ int op_volume_point_cloud(op_volume *v, float *xyz, float *colors, size_t cap, s
 int op_volume_write_file(op_volume *v, const char *path);
 int op_volume_read_file(op_volume *v, const char *path, int legacy_float_format);
 
+/* TSDF ray casting (north_star "integrate/raycast").  NO reference counterpart: OnePiece has no
+ * raycast, so the definition is this library's own and is validated against the
+ * analytic synthetic scene.  For every pixel of `cam` (NULL = the volume's camera) at camera-to-world
+ * `pose`: march the viewing ray from the near to the far plane, sample the sdf trilinearly over the
+ * 8 surrounding voxel centres (all observed), step one voxel while samples are valid and one block
+ * otherwise, report the first + -> - zero crossing as z-depth in metres (0 = no hit).  Optional
+ * outputs: world-frame normals (sdf gradient) and trilinear colours, W*H*3 floats each. */
+int op_volume_raycast(op_volume *v, const op_camera *cam, const float pose[16], float *depth_out,
+                      float *normals_out, float *colors_out, int mem);
+
 /* Frame-sharded multi-GPU merge (the distributed form of CubeHandler::Merge; DESIGN.md "Multi-GPU").
  * All pointers are DEVICE pointers on the volume's device.
  *   keys_device : copy this volume's block keys (n x 3 int32) into d_keys.

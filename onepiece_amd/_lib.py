@@ -82,6 +82,7 @@ SIGNATURES = {
     "op_volume_point_cloud": (C.c_int, [_vp, _fp, _fp, C.c_size_t, _szp]),
     "op_volume_write_file": (C.c_int, [_vp, C.c_char_p]),
     "op_volume_read_file": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "op_volume_raycast": (C.c_int, [_vp, C.POINTER(Camera), _fp, _fp, _fp, _fp, C.c_int]),
     "op_volume_keys_device": (C.c_int, [_vp, _vp, C.c_size_t, _szp]),
     "op_volume_pack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "op_volume_unpack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),

@@ -274,6 +274,17 @@ class CubeHandler:
         L.check(self._lib.op_volume_point_cloud(self._h, _fp(xyz), _fp(col), n.value, C.byref(n)))
         return xyz[:n.value], col[:n.value]
 
+    def Raycast(self, pose, camera=None):
+        """Ray casting (north_star; no reference counterpart) -> (depth [h,w], normals [h,w,3],
+        colors [h,w,3]); depth 0 = no hit."""
+        cam = camera if camera is not None else self.camera
+        pose = _f32(pose).reshape(16)
+        d = np.zeros((cam.height, cam.width), np.float32)
+        n = np.zeros((cam.height, cam.width, 3), np.float32)
+        c = np.zeros((cam.height, cam.width, 3), np.float32)
+        L.check(self._lib.op_volume_raycast(self._h, C.byref(cam), _fp(pose), _fp(d), _fp(n), _fp(c), L.OP_MEM_HOST))
+        return d, n, c
+
     def WriteToFile(self, filename):
         L.check(self._lib.op_volume_write_file(self._h, str(filename).encode()))
         return True

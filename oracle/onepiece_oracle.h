@@ -85,6 +85,10 @@ size_t orc_volume_point_cloud(const orc_volume *v, float *xyz, float *colors, si
 int orc_volume_write_file(const orc_volume *v, const char *path);
 int orc_volume_read_file(orc_volume *v, const char *path, int legacy_float);
 
+/* Ray casting -- NO reference counterpart; restates the definition of op_volume_raycast. */
+void orc_volume_raycast(const orc_volume *v, const orc_camera *cam, const float pose[16], float *depth_out,
+                        float *normals_out, float *colors_out);
+
 /* ---- Registration ---- */
 /* Geometry/PointCloud.cpp:72-100.  Returns count; xyz has room for w*h*3 floats. */
 size_t orc_load_from_depth(const orc_camera *cam, const void *depth, int is_u16, float *xyz);

@@ -80,6 +80,7 @@ def lib():
         L.orc_volume_write_file.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_volume_read_file.restype = C.c_int
         L.orc_volume_read_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.orc_volume_raycast.argtypes = [C.c_void_p, C.POINTER(Camera), _fp, _fp, _fp, _fp]
         L.orc_load_from_depth.restype = C.c_size_t
         L.orc_load_from_depth.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, _fp]
         L.orc_estimate_normals.argtypes = [_fp, C.c_size_t, C.c_float, C.c_int, _fp]
@@ -252,6 +253,16 @@ class Volume:
         col = np.empty((max(n, 1), 3), np.float32)
         lib().orc_volume_point_cloud(self._h, _p(xyz), _p(col), n)
         return xyz[:n], col[:n]
+
+    def raycast(self, pose, cam=None):
+        """No reference counterpart: CPU restatement of op_volume_raycast's definition."""
+        cam = cam or self.cam
+        pose = _f32(pose).reshape(16)
+        d = np.zeros((cam.height, cam.width), np.float32)
+        n = np.zeros((cam.height, cam.width, 3), np.float32)
+        c = np.zeros((cam.height, cam.width, 3), np.float32)
+        lib().orc_volume_raycast(self._h, C.byref(cam), _p(pose), _p(d), _p(n), _p(c))
+        return d, n, c
 
     def write_file(self, path):
         return int(lib().orc_volume_write_file(self._h, str(path).encode()))

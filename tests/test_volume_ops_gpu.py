@@ -109,3 +109,23 @@ def test_legacy_float_map_format(oracle, tmp_path):
     ok, ox = _same(ov, hv)
     assert ok.tolist() == [[-4, 0, 9], [1, -2, 3]]
     assert np.allclose(ox[1, 5], [0.25, 3.0, 1.0, 0.5, 0.25]) and np.allclose(ox[1, 77, :2], [-0.5, 1.0])
+
+
+def test_raycast_matches_its_cpu_restatement_and_the_analytic_scene(oracle):
+    """north_star names a raycast; the reference has none.  The HIP raycaster must agree
+    with the CPU restatement of its own definition, and both with the analytic room it was fused from."""
+    frames = tuple(range(0, 60, 6))
+    ov, hv = _pair(oracle, 0.02, frames=frames)
+    cam = small_camera(4)
+    pose = S.room_pose(30)
+    truth, _c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+    hd, hn, hc = hv.Raycast(pose)
+    od, on, oc = ov.raycast(pose)
+    assert np.array_equal(hd > 0, od > 0)
+    hit = od > 0
+    assert hit.mean() > 0.4
+    assert np.abs(hd - od)[hit].max() <= 1e-5 and np.abs(hn - on)[hit].max() <= 1e-3 and np.abs(hc - oc)[hit].max() <= 1e-5
+    err = np.abs(hd - truth)[hit]
+    assert np.median(err) < 0.001 and np.percentile(err, 95) < 0.005          # 2 cm voxels, sub-voxel surface
+    nn = np.linalg.norm(hn[hit], axis=1)
+    assert np.all((np.abs(nn - 1) < 1e-4) | (nn == 0))
