@@ -3,29 +3,34 @@
 //
 // What it replaces (file:line under /root/reference/src):
 //   integration::CubeHandler::IntegrateImage      Integration/CubeHandler.cpp:197-210
-//   CubeHandler::ComputeBounding  (kernel K1)     Integration/CubeHandler.cpp:116-145
-//   CubeHandler::PrepareCubes     (kernel K2)     Integration/CubeHandler.cpp:147-196
+//   CubeHandler::ComputeBounding  (kernel KA)     Integration/CubeHandler.cpp:116-145
+//   CubeHandler::PrepareCubes     (kernel KB)     Integration/CubeHandler.cpp:147-196
 //   Integrator::GetSDF                            Integration/Integrator.cpp:8-35
-//   Integrator::IntegrateImage    (kernel K3)     Integration/Integrator.cpp:36-94
+//   Integrator::IntegrateImage    (kernel KC)     Integration/Integrator.cpp:36-94
 //   TSDFVoxel::operator+                          Integration/TSDFVoxel.h:24-39
-//   CubeHandler::Merge            (kernel K4*)    Integration/CubeHandler.h:145-167
+//   CubeHandler::Merge            (k_merge_blocks, K4 k_pack_sum/k_unpack_sum)  Integration/CubeHandler.h:145-167
+//   CubeHandler::Transform / TransformNearest / GetPointCloud                   Integration/CubeHandler.h:199-338, CubeHandler.cpp:45-69
+//   CubeHandler::WriteToFile / ReadFromFile / ReadFromFileFloat                 Integration/CubeHandler.h:40-128
+// plus a raycaster that north_star asks for and the reference does not have (k_raycast).
 //
-// Data layout in HBM (DESIGN.md "Data layout"):
+// Data layout in HBM:
 //   pool   : max_blocks x [5 planes x 512 floats]; plane order sdf, weight, c0, c1, c2; in-plane
 //            index = the reference's voxel id x + 8y + 64z.  A wave64 therefore owns one z-slice
 //            and reads/writes 256 contiguous bytes per plane -- fully coalesced, unlike the
 //            reference's 20-byte AoS TSDFVoxel.
 //   keys   : max_blocks x int32[3] (block id), indexed by pool slot.
-//   table  : open-addressing hash table of int4 {x, y, z, pool slot}; the probe start is the low
-//            bits of the reference's 64-bit VoxelGridHasher value (Geometry/Geometry.h:101-112).
-//   frame lists (sel_list / sel_cand) : pool slots + candidate ranks of the blocks PrepareCubes
-//            selected for the current frame.
-// The whole per-frame path (K1 -> K2 -> K3) is enqueued without any host synchronisation: every
-// kernel is launched with a fixed grid and reads its trip counts from device memory.
+//   tkeys / tvals : open-addressing hash table (packed 64-bit block id -> pool slot); the probe start
+//            is the low bits of the reference's 64-bit VoxelGridHasher value (Geometry/Geometry.h:101-112).
+//   bmask / blist : per table slot, the frames of the current batch that selected the block; the
+//            list of slots the batch touched.
+//   pimg   : the batch's frames packed as {depth, rgba} per pixel.
+// Frames are fused in batches of up to kMaxBatch: KA (prepare + bounding) -> KB (select) -> KC
+// (integrate), enqueued without any host synchronisation: every kernel is launched with a fixed
+// grid and reads its trip counts from device memory.
 //
 // Floating point: compiled with -ffp-contract=off; every expression keeps the reference's operand
-// order and intermediate types (see oracle/onepiece_oracle.c, which this must match bit for bit on
-// block selection and to rounding on voxel values -- in practice also bit for bit).
+// order and intermediate types (the CPU restatement in oracle/ is what the tests compare against --
+// bit for bit on block selection and, in practice, on every voxel value).
 #include <cfloat>
 #include <climits>
 #include <algorithm>
@@ -124,21 +129,6 @@ template <bool FAST>
 __device__ __forceinline__ int project_px(float f, float X, float Z, float c, const PxSplit& sp) {
     const float a = (f * X) / Z;
     return FAST ? px_round_sp(a, sp) : px_round_dp(a, c);
-}
-
-// Integrator::GetSDF with pose_inv precomputed (Integrator.cpp:8-35); depth comes from the packed
-// per-frame image {depth bits, rgba}.
-template <bool FAST>
-__device__ __forceinline__ float get_sdf(const CamParams& C, const float* M, const uint2* __restrict__ img, float px, float py, float pz) {
-    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-    const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-    const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-    const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
-    const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
-    if (v < 0 || v >= C.height || u < 0 || u >= C.width) return 999.0f;
-    const float d = __uint_as_float(img[(size_t)v * C.width + u].x);
-    if (d <= 0) return 999.0f;
-    return d - q2;
 }
 
 __device__ __forceinline__ float wave_max(float v) {

@@ -252,3 +252,68 @@ def test_bench_multi_rank_flow_on_one_gpu(oracle, tmp_path):
     assert r["merge_union_blocks"] and r["merge_union_blocks"] >= r["per_frame"]["blocks_selected"]
     # rank 0's volume now holds the union
     assert r["per_frame"]["final_blocks_rank0"] == r["merge_union_blocks"]
+
+
+def test_survey_reference_run_anchor_on_the_gpu():
+    """The HIP path against committed data only (no live oracle): the statistics the survey recorded from
+    the REFERENCE ITSELF on the 5-frame wall scene (tests/golden/survey_wall_anchor.json)."""
+    import json, os
+    a = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_wall_anchor.json")))
+    hv = I.CubeHandler(); hv.SetVoxelResolution(a["voxel_res"])
+    d = S.wall_depth(); rgb = np.full((S.H, S.W, 3), 128, np.uint8)
+    for i in range(a["frames"]):
+        pose = np.eye(4, dtype=np.float32); pose[0, 3] = np.float32(0.01 * i)
+        hv.IntegrateImage(d, rgb, pose)
+    keys, vox = hv.GetCubeMap()
+    w = vox[:, :, 1]
+    x = 0
+    for k in keys:
+        x ^= I.hash_key(*k)
+    assert len(keys) == a["blocks"] and int((w > 0).sum()) == a["voxels_with_weight"]
+    assert int(w.sum(dtype=np.float64)) == a["weight_sum"] and x == int(a["xor_of_key_hashes"], 16)
+    for kx, ky, kz, h in a["hash_known_answers"]:
+        assert I.hash_key(kx, ky, kz) == h
+
+
+def test_far_from_origin_negative_block_ids_and_tum_camera(oracle):
+    """Block ids around (-1250, 625, -375) exercise sign extension in the 64-bit hash and the 21-bit key
+    packing; the TUM preset exercises cy = 255.3 / depth_scale 5000 (Camera.h:78-92) with uint16 depth."""
+    cam = (517.3, 516.5, 318.6, 255.3, 640, 480, 5000.0)
+    ov, hv = _mk(oracle, 0.01, cam=cam)
+    shift = np.eye(4, dtype=np.float32); shift[:3, 3] = (-100.0, 50.0, -30.0)
+    for i in (3, 9):
+        d, rgb, pose = S.room_frame(i)
+        d16 = np.round(d * 5000.0).astype(np.uint16)
+        pose = (shift @ pose).astype(np.float32)
+        ov.integrate(d16, rgb, pose); hv.IntegrateImage(d16, rgb, pose)
+    ok, _ = _compare(oracle, ov, hv)
+    assert ok[:, 0].max() < -1200 and ok[:, 1].min() > 600
+
+
+def test_large_image_mi_dataset_camera(oracle):
+    """1440x1080 MI_DATASET intrinsics (Camera.h:106-120): more pixels than one KA workgroup row, cx = 756.2."""
+    cam = (2209.84366, 2210.23057, 756.24762, 530.00418, 1440, 1080, 1000.0)
+    ov, hv = _mk(oracle, 0.02, cam=cam)
+    pose = S.room_pose(50)
+    d, rgb = S.room_render(pose, width=1440, height=1080, fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+    ov.integrate(d, rgb, pose); hv.IntegrateImage(d, rgb, pose)
+    _compare(oracle, ov, hv)
+    omx, omn, oin = oracle.compute_bounding(ov.cam, d, pose)
+    hmx, hmn, hin = hv.ComputeBounding(d, pose)
+    assert oin == hin and np.array_equal(omx, hmx) and np.array_equal(omn, hmn)
+
+
+def test_queued_frames_survive_setters_and_mixed_formats(oracle):
+    """Single-frame calls are queued; a setter, a format change or an accessor must flush with the OLD
+    settings first -- so the sequence below equals the oracle's strictly sequential semantics."""
+    ov, hv = _mk(oracle, 0.01)
+    d0, c0, p0 = S.room_frame(0); d1, c1, p1 = S.room_frame(8); d2, c2, p2 = S.room_frame(16)
+    hv.IntegrateImage(d0, c0, p0); ov.integrate(d0, c0, p0)
+    hv.SetTruncation(0.05)                                  # flushes frame 0 under trunc 0.1
+    ov2 = oracle.Volume(ov.cam, voxel_res=0.01, trunc=0.05)
+    k, v = ov.export(); ov2.load(k, v)
+    d1u = np.round(d1 * 1000).astype(np.uint16)
+    hv.IntegrateImage(d1u, c1, p1); ov2.integrate(d1u, c1, p1)   # u16 after f32: separate batch
+    hv.IntegrateImage(d2, c2, p2); ov2.integrate(d2, c2, p2)
+    assert hv.Stats()["frames"] == 3
+    _compare(oracle, ov2, hv)
