@@ -220,12 +220,20 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                             // cells x_lo..x_hi own one contiguous run of the sorted target
                             const unsigned beg = cell_start[row + x_lo];
                             const unsigned end = cell_start[row + x_hi] + cell_count[row + x_hi];
-                            for (unsigned p = beg; p < end; ++p) {
-                                const float4 c = tgt[p];
-                                const float dx = tp0 - c.x, dyy = tp1 - c.y, dzz = tp2 - c.z;
-                                const float d = dx * dx + dyy * dyy + dzz * dzz;
-                                const int ci = __float_as_int(c.w);
-                                if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)p; }
+                            // 4 candidates per trip: the loads are independent, so 4 L2 round trips overlap
+                            // (the scan is a latency chain otherwise: ~56 dependent 16-byte loads per query)
+                            for (unsigned p = beg; p < end; p += 4) {
+                                float4 c[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) c[k] = tgt[min(p + k, end - 1)];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    if (p + k >= end) break;
+                                    const float dx = tp0 - c[k].x, dyy = tp1 - c[k].y, dzz = tp2 - c[k].z;
+                                    const float d = dx * dx + dyy * dyy + dzz * dzz;
+                                    const int ci = __float_as_int(c[k].w);
+                                    if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)(p + k); }
+                                }
                             }
                         }
                     }
@@ -288,6 +296,27 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         if (!(MODE != 1 && threadIdx.x >= 15 && threadIdx.x < 27))
             for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
         partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
+    }
+}
+
+// Second pass, stage 1: kStage1 workgroups each fold a contiguous slice of the per-workgroup
+// partials (deterministic order), so the final single-workgroup kernel only sees kStage1 rows.
+constexpr int kStage1 = 32;
+__global__ __launch_bounds__(256) void k_reduce_stage1(const double* __restrict__ partials, int n_partials, double* __restrict__ stage) {
+    __shared__ double s[8][kNSums];
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5; // 8 groups x 32 sums
+    const int per = (n_partials + kStage1 - 1) / kStage1;
+    const int lo = blockIdx.x * per, hi = min(lo + per, n_partials);
+    double v0 = 0, v1 = 0;
+    int p = lo + grp;
+    for (; p + 8 < hi; p += 16) { v0 += partials[(size_t)p * kNSums + k]; v1 += partials[(size_t)(p + 8) * kNSums + k]; }
+    for (; p < hi; p += 8) v0 += partials[(size_t)p * kNSums + k];
+    s[grp][k] = v0 + v1;
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double t = 0;
+        for (int g = 0; g < 8; ++g) t += s[g][threadIdx.x];
+        stage[(size_t)blockIdx.x * kNSums + threadIdx.x] = t;
     }
 }
 
@@ -516,7 +545,7 @@ struct op_icp {
     float* src = nullptr;
     size_t src_cap = 0;
     int *nn = nullptr, *inl = nullptr;
-    double *partials = nullptr, *result = nullptr;
+    double *partials = nullptr, *result = nullptr, *stage = nullptr;
     float* T_dev = nullptr;        // start_T (16 floats)
     int* it_inl_dev = nullptr;     // per-iteration inlier counts
     float* it_T_dev = nullptr;     // per-iteration start_T
@@ -533,7 +562,13 @@ void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace) {
     hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, (const float*)c->T_dev, (const float*)c->src, c->n,
                        c->grid, (const unsigned*)c->cell_start, (const unsigned*)c->cell_count, (const float4*)c->tgt, (const float4*)c->tgt_n,
                        (const float*)c->tgt_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials);
-    hipLaunchKernelGGL(k_reduce_update, dim3(1), dim3(1024), 0, c->stream, (const double*)c->partials, c->n_wg, c->result, update, c->T_dev, it,
+    const double* rows = c->partials;
+    int n_rows = c->n_wg;
+    if (c->n_wg > 4 * kStage1) { // two-stage second pass: 1200 rows -> 32 rows -> 1
+        hipLaunchKernelGGL(k_reduce_stage1, dim3(kStage1), dim3(256), 0, c->stream, (const double*)c->partials, c->n_wg, c->stage);
+        rows = c->stage; n_rows = kStage1;
+    }
+    hipLaunchKernelGGL(k_reduce_update, dim3(1), dim3(1024), 0, c->stream, rows, n_rows, c->result, update, c->T_dev, it,
                        trace ? c->it_inl_dev : nullptr, trace ? c->it_T_dev : nullptr);
 }
 
@@ -633,6 +668,7 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     if (e != hipSuccess) return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e)));
     OP_HIP_C(hipMalloc((void**)&c->result, kNSums * sizeof(double)));
     OP_HIP_C(hipMalloc((void**)&c->T_dev, 16 * sizeof(float)));
+    OP_HIP_C(hipMalloc((void**)&c->stage, (size_t)kStage1 * kNSums * sizeof(double)));
 #undef OP_HIP_C
     *out = c;
     return OP_OK;
@@ -643,7 +679,7 @@ int op_icp_destroy(op_icp* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->tgt_orig, c->tgt, c->tgt_n, c->cell_start, c->cell_count, c->src, c->nn, c->inl, c->partials, c->result,
-                    c->T_dev, c->it_inl_dev, c->it_T_dev};
+                    c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -714,13 +750,14 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     }
     if (max_iteration <= 0 && c->n) OP_HIP(hipMemsetAsync(c->nn, 0xff, c->n * sizeof(int), c->stream)); // corresponding_index stays -1
     OP_HIP(hipMemcpyAsync(c->T_dev, init_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    // ICP.cpp:177-199.  The 29 reduced sums come back to the host, which does the 6x6 solve / Kabsch
-    // and the SE3 exp exactly as north_star prescribes.  (Measured: running that step on the device
-    // in k_reduce_update -- update = 1 -- costs 400 us of single-thread fp64 Jacobi per iteration,
-    // while the host round trip costs nothing measurable; the device path is kept for point-to-point,
-    // whose 3x3 step is cheap, so that loop needs no host round trip at all.)
+    // ICP.cpp:177-199.  Point-to-point: the Kabsch step is cheap enough for one GPU thread, so the
+    // whole loop is enqueued back to back with the update in k_reduce_update (no host round trip).
+    // Point-to-plane: the 29 reduced sums come back to the host, which does the 6x6 solve and the SE3
+    // exp as north_star prescribes -- measured alternatives on the device (single-thread fp64 Jacobi:
+    // +400 us/iteration; single-thread LDL^T + exp: +45 us) are slower than the 256-byte round trip.
     const int pass_mode = mode == OP_ICP_POINT_TO_PLANE ? 1 : 0;
-    if (pass_mode == 0) {
+    const bool host_path = pass_mode == 1;
+    if (!host_path) {
         for (int it = 0; it < max_iteration; ++it) OP_TRY(enqueue_pass(c, 0, false, 2, it, true));
     } else {
         float cur[16], tmp_T[16];
@@ -746,9 +783,9 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     OP_HIP(hipMemcpyAsync(r, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     OP_HIP(hipMemcpyAsync(start_T, c->T_dev, sizeof(start_T), hipMemcpyDeviceToHost, c->stream));
     OP_HIP(hipStreamSynchronize(c->stream));
-    if (pass_mode == 0 && per_iter_inliers && max_iteration > 0)
+    if (!host_path && per_iter_inliers && max_iteration > 0)
         OP_HIP(hipMemcpy(per_iter_inliers, c->it_inl_dev, (size_t)max_iteration * sizeof(int), hipMemcpyDeviceToHost));
-    if (pass_mode == 0 && per_iter_T && max_iteration > 0)
+    if (!host_path && per_iter_T && max_iteration > 0)
         OP_HIP(hipMemcpy(per_iter_T, c->it_T_dev, (size_t)max_iteration * 16 * sizeof(float), hipMemcpyDeviceToHost));
     const double n_inl = r[28];
     result->n_inliers = (uint64_t)(n_inl + 0.5);
