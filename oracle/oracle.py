@@ -186,8 +186,8 @@ class Volume:
         self._h = lib().orc_volume_create(C.byref(self.cam), voxel_res, trunc, far, near)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_volume_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # _lib may already be gone at interpreter exit
+            _lib.orc_volume_destroy(self._h)
             self._h = None
 
     def clear(self):

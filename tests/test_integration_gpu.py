@@ -317,3 +317,19 @@ def test_queued_frames_survive_setters_and_mixed_formats(oracle):
     hv.IntegrateImage(d2, c2, p2); ov2.integrate(d2, c2, p2)
     assert hv.Stats()["frames"] == 3
     _compare(oracle, ov2, hv)
+
+
+def test_host_buffers_are_only_borrowed_for_the_call(oracle):
+    """SURVEY 8b "Ownership": IntegrateImage borrows the cv::Mat buffers for the call only.  Frames are
+    queued inside the library, so the caller scribbling over its buffers right after the call returns
+    must not change the result."""
+    ov, hv = _mk(oracle, 0.01)
+    buf_d = np.empty((S.H, S.W), np.float32)
+    buf_c = np.empty((S.H, S.W, 3), np.uint8)
+    for i in (0, 12, 24, 36, 48):
+        d, c, p = S.room_frame(i)
+        ov.integrate(d, c, p)
+        buf_d[:] = d; buf_c[:] = c
+        hv.IntegrateImage(buf_d, buf_c, p)
+        buf_d[:] = -7.0; buf_c[:] = 255          # the caller reuses its buffers immediately
+    _compare(oracle, ov, hv)
