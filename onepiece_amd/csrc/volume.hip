@@ -895,6 +895,8 @@ __global__ __launch_bounds__(256) void k_raycast(VolView V, op_camera cam, Mat4 
     if (colors_out) { colors_out[3 * pix] = c[0]; colors_out[3 * pix + 1] = c[1]; colors_out[3 * pix + 2] = c[2]; }
 }
 
+__global__ void k_has_cube(VolView V, int x, int y, int z, int* out) { *out = table_find(V, x, y, z) >= 0 ? 1 : 0; }
+
 unsigned next_pow2(unsigned long long v) {
     unsigned long long p = 1;
     while (p < v) p <<= 1;
@@ -1443,13 +1445,14 @@ int op_volume_profile_read(op_volume* v, double ms_sum[3], uint64_t* n_launches,
 int op_volume_has_cube(op_volume* v, int32_t x, int32_t y, int32_t z, int* present) {
     OP_VOL(v);
     if (!present) return fail(OP_ERR_INVALID, "null present");
-    unsigned nb = 0;
-    OP_TRY(vol_block_count(v, &nb));
-    std::vector<int> keys((size_t)nb * 3);
-    if (nb) OP_HIP(hipMemcpy(keys.data(), v->keys, keys.size() * sizeof(int), hipMemcpyDeviceToHost));
-    *present = 0;
-    for (unsigned i = 0; i < nb; ++i)
-        if (keys[3 * i] == x && keys[3 * i + 1] == y && keys[3 * i + 2] == z) { *present = 1; break; }
+    OP_TRY(vol_check(v));
+    int* d_out = nullptr;
+    OP_HIP(hipMalloc((void**)&d_out, sizeof(int)));
+    hipLaunchKernelGGL(k_has_cube, dim3(1), dim3(1), 0, v->stream, v->view(), x, y, z, d_out); // cube_map.find (CubeHandler.h:129-132)
+    hipError_t e = hipMemcpyAsync(present, d_out, sizeof(int), hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "has_cube failed: %s", hipGetErrorString(e));
     return OP_OK;
 }
 
