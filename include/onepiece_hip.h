@@ -44,6 +44,7 @@ typedef enum {
 enum { OP_DEPTH_F32 = 0, OP_DEPTH_U16 = 1 };
 enum { OP_MEM_HOST = 0, OP_MEM_DEVICE = 1 };
 enum { OP_ICP_POINT_TO_POINT = 0, OP_ICP_POINT_TO_PLANE = 1 };
+enum { OP_TRACK_HYBRID = 0, OP_TRACK_PHOTO = 1, OP_TRACK_DEPTH = 2 }; /* DenseTracking term_type (Odometry.cpp:546-553) */
 
 /* camera::PinholeCamera (Camera/Camera.h:13-131) as a POD. */
 typedef struct {
@@ -54,6 +55,7 @@ typedef struct {
 
 typedef struct op_volume op_volume; /* device-resident integration::CubeHandler state */
 typedef struct op_icp op_icp;       /* device-resident target cloud + search grid */
+typedef struct op_tracker op_tracker; /* dense RGB-D tracker workspace (stream, device state) */
 
 /* ---- library ----------------------------------------------------------------------------- */
 int op_abi_version(void);
@@ -223,6 +225,60 @@ int op_points_from_depth(const op_camera *cam, const void *depth, int depth_fmt,
  * undetermined (as in the reference, whose disambiguation is #if 0'd out); < 3 neighbours -> 0. */
 int op_estimate_normals(const float *xyz, size_t n, float radius, int knn, int mem, int device,
                         float *normals_out);
+
+/* ---- dense RGB-D tracker (Odometry/Odometry.h:38-175) ------------------------
+ * Boundary = the inputs of Odometry::MultiScaleComputing (Odometry.cpp:621-636): image pyramids
+ * already built (cv::pyrDown / cv::Sobel / cv::GaussianBlur stay where they are in the reference,
+ * Odometry.cpp:436-449,609-620).  All images are dense row-major float32 of width x height
+ * (CV_32FC1); invalid depth is NaN (ConvertDepthTo32FNaN, DenseOdometryFunction.cpp:28-56); the
+ * *_dx/_dy images are the raw cv::Sobel outputs (SOBEL_SCALE is applied inside).  The image-XYZ
+ * pyramids of the reference are recomputed from the depth pyramids with TransformToMatXYZ's own
+ * arithmetic (Geometry.cpp:72-106).  levels[0] is full resolution (camera_pyramid[0]). */
+typedef struct {
+    int32_t width, height;          /* camera_pyramid[l].GetWidth()/GetHeight() */
+    float fx, fy, cx, cy;           /* Camera.h:38-42: halved per level */
+    const float *source_color, *source_depth, *target_color, *target_depth;
+    const float *target_color_dx, *target_color_dy, *target_depth_dx, *target_depth_dy;
+} op_track_level;
+
+typedef struct {
+    float T[16];                 /* DenseTrackingResult::T (Odometry.h:32) */
+    double rmse;                 /* ComputeReprojectionError3D(correspondence_set, T), Odometry.cpp:606 */
+    uint64_t n_correspondences;  /* pixel_correspondence_set.size(): pairs of the LAST executed iteration */
+    int32_t tracking_success;    /* ratio >= MIN_INLIER_RATIO_DENSE over the FULL-resolution pixel count */
+    int32_t iterations;          /* iterations executed (early-out at ratio > MAX_INLIER_RATIO_DENSE) */
+} op_track_result;
+
+int op_tracker_create(int device, op_tracker **out);
+int op_tracker_destroy(op_tracker *t);
+/* Odometry::MultiScaleComputing + the result assembly of DenseTracking (Odometry.cpp:621-687,
+ * :600-607).  iters_per_level[l] = iter_count_per_level[l] (Odometry.h:170, default {4,8,16});
+ * levels are visited n_levels-1 .. 0.  full_width/full_height = camera.GetWidth()/GetHeight(), the
+ * denominator of both inlier ratios at EVERY level (Odometry.cpp:635,669,686).
+ * Optional outputs (may be NULL): pixel_corr (corr_cap x 4 int32 {v_s,u_s,v_t,u_t}, raster order of
+ * the source pixel = the reference's push_back order), point_corr (corr_cap x 6 float: source xyz,
+ * target xyz, both read at the SOURCE pixel of level 0 as Odometry.cpp:676-683 does),
+ * per_iter_count (sum(iters) int32) and per_iter_T (sum(iters) x 16): the correspondence count used
+ * by, and the pose after, each executed iteration. */
+int op_tracker_track(op_tracker *t, const op_track_level *levels, int n_levels,
+                     const int32_t *iters_per_level, int full_width, int full_height, int term_type,
+                     const float init_T[16], int mem, op_track_result *result, int32_t *pixel_corr,
+                     float *point_corr, size_t corr_cap, int32_t *per_iter_count, float *per_iter_T);
+/* ComputeCorrespondencePixelWise (DenseOdometryFunction.cpp:72-128) alone, incl. its source-indexed
+ * "z-buffer" (:9-27): what DenseTracking runs with the identity pose before NormalizeIntensity
+ * (Odometry.cpp:543-544). */
+int op_tracker_correspondences(op_tracker *t, const op_track_level *level, const float T[16], int mem,
+                               int32_t *pixel_corr, size_t corr_cap, size_t *n);
+/* Convenience: create + track + destroy. */
+int op_dense_track(const op_track_level *levels, int n_levels, const int32_t *iters_per_level,
+                   int full_width, int full_height, int term_type, const float init_T[16], int mem,
+                   int device, op_track_result *result, int32_t *pixel_corr, float *point_corr,
+                   size_t corr_cap);
+/* Host-side arithmetic of that path, exported so it can be checked without a GPU:
+ * K*R*K.inverse() and K*t as Eigen 3.3.7 evaluates them (DenseOdometryFunction.cpp:82-87; cam4 =
+ * {fx,fy,cx,cy}, row-major 3x3 out) and JTJ.ldlt().solve(-JTr) (:404; JTJ row-major 6x6). */
+int op_track_projection(const float cam4[4], const float T[16], float KRK_inv[9], float Kt[3]);
+int op_ldlt_solve6(const double JTJ[36], const double JTr[6], float x[6]);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,20 @@ class IcpResult(C.Structure):
                 ("n_inliers", C.c_uint64), ("iterations", C.c_int32)]
 
 
+class TrackLevel(C.Structure):
+    """op_track_level: one pyramid level of Odometry::MultiScaleComputing's inputs."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float)] + [
+        (k, C.c_void_p) for k in ("source_color", "source_depth", "target_color", "target_depth",
+                                  "target_color_dx", "target_color_dy", "target_depth_dx", "target_depth_dy")]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("rmse", C.c_double), ("n_correspondences", C.c_uint64),
+                ("tracking_success", C.c_int32), ("iterations", C.c_int32)]
+
+
+OP_TRACK_HYBRID, OP_TRACK_PHOTO, OP_TRACK_DEPTH = 0, 1, 2
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
@@ -97,6 +111,15 @@ SIGNATURES = {
                                   C.c_double, C.c_int, C.POINTER(IcpResult), _ip, C.c_size_t]),
     "op_estimate_normals": (C.c_int, [_vp, C.c_size_t, C.c_float, C.c_int, C.c_int, C.c_int, _vp]),
     "op_points_from_depth": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, C.c_int, C.c_int, _vp, _szp]),
+    "op_tracker_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "op_tracker_destroy": (C.c_int, [_vp]),
+    "op_tracker_track": (C.c_int, [_vp, C.POINTER(TrackLevel), C.c_int, _ip, C.c_int, C.c_int, C.c_int, _fp,
+                                   C.c_int, C.POINTER(TrackResult), _vp, _vp, C.c_size_t, _vp, _vp]),
+    "op_tracker_correspondences": (C.c_int, [_vp, C.POINTER(TrackLevel), _fp, C.c_int, _vp, C.c_size_t, _szp]),
+    "op_dense_track": (C.c_int, [C.POINTER(TrackLevel), C.c_int, _ip, C.c_int, C.c_int, C.c_int, _fp, C.c_int,
+                                 C.c_int, C.POINTER(TrackResult), _vp, _vp, C.c_size_t]),
+    "op_track_projection": (C.c_int, [_fp, _fp, _fp, _fp]),
+    "op_ldlt_solve6": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), _fp]),
 }
 
 _lib = None

@@ -259,6 +259,74 @@ OP_HD void mat4_mul(const float* A, const float* B, float* C) {
     for (int i = 0; i < 16; ++i) C[i] = out[i];
 }
 
+// ---- dense tracker helpers (Odometry/DenseOdometryFunction.cpp) -------------------------------
+OP_HD float hm_sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); } // Eigen 3-term redux order
+
+// Matrix3f::inverse() as Eigen 3.3.7 evaluates it (LU/InverseImpl.h:126-170): cofactors of column 0,
+// det = c0*m00 + (c1*m10 + c2*m20), every entry = cofactor * (1/det).  Row-major.
+OP_HD void mat3_inverse(const float m[9], float out[9]) {
+#define OPM3(i, j) m[(((i)) % 3) * 3 + (((j)) % 3)]
+#define OPCOF(i, j) (OPM3((i) + 1, (j) + 1) * OPM3((i) + 2, (j) + 2) - OPM3((i) + 1, (j) + 2) * OPM3((i) + 2, (j) + 1))
+    const float c0 = OPCOF(0, 0), c1 = OPCOF(1, 0), c2 = OPCOF(2, 0);
+    const float det = hm_sum3(c0 * m[0], c1 * m[3], c2 * m[6]);
+    const float invdet = 1.0f / det;
+    out[0] = c0 * invdet; out[1] = c1 * invdet; out[2] = c2 * invdet;
+    out[3] = OPCOF(0, 1) * invdet; out[4] = OPCOF(1, 1) * invdet; out[5] = OPCOF(2, 1) * invdet;
+    out[6] = OPCOF(0, 2) * invdet; out[7] = OPCOF(1, 2) * invdet; out[8] = OPCOF(2, 2) * invdet;
+#undef OPCOF
+#undef OPM3
+}
+
+OP_HD void mat3_mul(const float* A, const float* B, float* C) {
+    float o[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) o[r * 3 + c] = hm_sum3(A[r * 3] * B[c], A[r * 3 + 1] * B[3 + c], A[r * 3 + 2] * B[6 + c]);
+    for (int i = 0; i < 9; ++i) C[i] = o[i];
+}
+
+// DenseOdometryFunction.cpp:82-87: Kt = K*t, KRK_inv = K*R*K.inverse() (float, Eigen order).
+OP_HD void track_projection(float fx, float fy, float cx, float cy, const float T[16], float KRK_inv[9], float Kt[3]) {
+    const float K[9] = {fx, 0.0f, cx, 0.0f, fy, cy, 0.0f, 0.0f, 1.0f};
+    const float R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    float K_inv[9], KR[9];
+    for (int r = 0; r < 3; ++r) Kt[r] = hm_sum3(K[r * 3] * T[3], K[r * 3 + 1] * T[7], K[r * 3 + 2] * T[11]);
+    mat3_inverse(K, K_inv);
+    mat3_mul(K, R, KR);
+    mat3_mul(KR, K_inv, KRK_inv);
+}
+
+// x = JTJ.ldlt().solve(-JTr) (DenseOdometryFunction.cpp:404): symmetric-pivoted LDL^T in double;
+// zero pivots give zero components (Eigen's pseudo-inverse of D).
+OP_HD void ldlt_solve6(const double JTJ[36], const double JTr[6], float x[6]) {
+    double A[6][6], b[6], y[6];
+    int perm[6];
+    for (int i = 0; i < 6; ++i) {
+        perm[i] = i; b[i] = -JTr[i];
+        for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (JTJ[i * 6 + j] + JTJ[j * 6 + i]);
+    }
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 6; ++i) if (fabs(A[i][i]) > fabs(A[p][p])) p = i;
+        if (p != k) {
+            for (int j = 0; j < 6; ++j) { const double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
+            for (int j = 0; j < 6; ++j) { const double t = A[j][k]; A[j][k] = A[j][p]; A[j][p] = t; }
+            const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+            const double tb = b[k]; b[k] = b[p]; b[p] = tb;
+        }
+        const double d = A[k][k];
+        if (d == 0) continue;
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = A[i][k] / d;
+            for (int j = k + 1; j < 6; ++j) A[i][j] -= l * A[k][j];
+            A[i][k] = l;
+        }
+    }
+    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int j = 0; j < i; ++j) s -= A[i][j] * y[j]; y[i] = s; }
+    for (int i = 0; i < 6; ++i) y[i] = A[i][i] != 0 ? y[i] / A[i][i] : 0.0;
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 6; ++j) s -= A[j][i] * y[j]; y[i] = s; }
+    for (int i = 0; i < 6; ++i) x[perm[i]] = static_cast<float>(y[i]);
+}
+
 inline uint64_t hash_key(int32_t x, int32_t y, int32_t z) { // Geometry/Geometry.h:101-112
     return (static_cast<uint64_t>(static_cast<int64_t>(x)) * 73856093ULL) ^
            (static_cast<uint64_t>(static_cast<int64_t>(y)) * 19349663ULL) ^

@@ -1,0 +1,544 @@
+// odometry.hip -- dense RGB-D frame-to-frame tracker on gfx950.
+//
+// Replaces odometry::Odometry::MultiScaleComputing (Odometry/Odometry.cpp:621-687) and what it calls
+// (Odometry/DenseOdometryFunction.cpp): per iteration
+//     ComputeCorrespondencePixelWise (:72-128)   -> k_track_assoc + the chain walk in k_track_accum
+//     ComputeJTJandJTr{Hybrid,Photo,Depth}Term   -> k_track_accum (fp64 wave-shuffle + LDS reduction)
+//     JTJ.ldlt().solve(-JTr), Se3ToSE3, T update -> k_track_solve (one workgroup, thread 0 solves)
+// and afterwards the correspondence_set / rmse of DenseTracking (Odometry.cpp:676-683, :606) in the
+// k_emit_* kernels.  The whole coarse-to-fine loop is enqueued without a host round trip: the pose,
+// the per-level image descriptors and the early-out flag (ratio > MAX_INLIER_RATIO_DENSE) live in a
+// device-side TrackState.
+//
+// The reference's "z-buffer" (AddElementToCorrespondenceMap, :9-27) reads wraping_depth at the TARGET
+// pixel but writes it at the SOURCE pixel, in raster order.  With p(s) the target cell of source
+// pixel s, td(s) its transformed depth and ok(s) the geometric gate, that sequential loop is
+//     acc(s) = ok(s) && ( p(s) >= s  ||  !acc(p(s))  ||  td(p(s)) > td(s) )
+// which only ever refers to a SMALLER raster index, so every thread resolves it independently by
+// walking p(.) until a link is decided without recursion; acc(s) is the parity of the walk length.
+#include <cstddef>
+
+#include "common.hpp"
+#include "host_math.hpp"
+
+using namespace op;
+
+namespace {
+
+constexpr int kMaxLevels = 8;
+constexpr int kMaxIters = 256;      // total iterations over all levels
+constexpr int kThreads = 256;
+constexpr int kNSums = 32;          // [0..20] JTJ upper triangle, [21..26] JTr, [27] sum r^2, [28] count
+
+struct LevelDev {
+    int w, h;
+    float fx, fy, cx, cy;
+    const float *sc, *sd, *tc, *td, *tcdx, *tcdy, *tddx, *tddy;
+};
+
+struct TrackState {
+    float T[16];
+    LevelDev lv[kMaxLevels];
+    int full_w, full_h, term;
+    int stop_level;                  // level whose remaining iterations are skipped (-1: none)
+    int iters_done;
+    int last_level;                  // level of the last executed iteration (-1: none)
+    unsigned long long n_last;       // its correspondence count
+    unsigned long long n_emit;
+    double rmse;
+    int success;
+    int per_iter_count[kMaxIters];
+    float per_iter_T[kMaxIters * 16];
+};
+
+__device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- association: p(s), td(s) for every source pixel (DenseOdometryFunction.cpp:89-114) --------
+__global__ __launch_bounds__(kThreads) void k_track_assoc(const TrackState* __restrict__ st, int l, int2* __restrict__ cand) {
+    if (st->stop_level == l) return;
+    __shared__ float s_krk[9], s_kt[3];
+    const LevelDev L = st->lv[l];
+    if (threadIdx.x == 0) op_host::track_projection(L.fx, L.fy, L.cx, L.cy, st->T, s_krk, s_kt);
+    __syncthreads();
+    const int npix = L.w * L.h, s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= npix) return;
+    const int i = s / L.w, j = s - i * L.w;
+    const float d_s = L.sd[s];
+    int p = -1;
+    float td = 0.0f;
+    if (!isnan(d_s)) {
+        const float fj = (float)j, fi = (float)i;
+        // d_s * KRK_inv * Point3(j,i,1.0) + Kt: Eigen evaluates (d_s*KRK_inv) first, rows as a0+(a1+a2)
+        const float uv0 = sum3((d_s * s_krk[0]) * fj, (d_s * s_krk[1]) * fi, (d_s * s_krk[2]) * 1.0f) + s_kt[0];
+        const float uv1 = sum3((d_s * s_krk[3]) * fj, (d_s * s_krk[4]) * fi, (d_s * s_krk[5]) * 1.0f) + s_kt[1];
+        td = sum3((d_s * s_krk[6]) * fj, (d_s * s_krk[7]) * fi, (d_s * s_krk[8]) * 1.0f) + s_kt[2];
+        // (int)(x / z + 0.5): float quotient, double sum, truncation toward zero (so (-1,0) -> 0)
+        const double ax = (double)(uv0 / td) + 0.5, ay = (double)(uv1 / td) + 0.5;
+        if (ax > -1.0 && ax < (double)L.w && ay > -1.0 && ay < (double)L.h) { // NaN fails
+            const int u_t = (int)ax, v_t = (int)ay;
+            const float d_t = L.td[v_t * L.w + u_t];
+            // |d_t - td| < MAX_DIFF_DEPTH (double 0.05): for floats that is < 0.05f exactly.  A stored
+            // depth of exactly -1 is indistinguishable from "unset" in the reference -> never a pair.
+            if (!isnan(d_t) && fabsf(d_t - td) < 0.05f && td != -1.0f) p = v_t * L.w + u_t;
+        }
+    }
+    cand[s] = make_int2(p, __float_as_int(td));
+}
+
+// ---- acceptance + Jacobian rows + normal-equation partials ------------------------------------
+template <int TERM>
+__global__ __launch_bounds__(kThreads) void k_track_accum(const TrackState* __restrict__ st, int l, const int2* __restrict__ cand,
+                                                          unsigned char* __restrict__ accf, double* __restrict__ partials) {
+    if (st->stop_level == l) return;
+    __shared__ double s_red[kThreads / 64][kNSums];
+    __shared__ float s_T[12];
+    const LevelDev L = st->lv[l];
+    if (threadIdx.x < 12) s_T[threadIdx.x] = st->T[threadIdx.x];
+    __syncthreads();
+    const int npix = L.w * L.h, s = blockIdx.x * kThreads + threadIdx.x;
+    double acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+    bool accepted = false;
+    int2 c = make_int2(-1, 0);
+    if (s < npix) c = cand[s];
+    if (c.x >= 0) {
+        // walk the chain of undecided links; acc(s) = (number of undecided links is even)
+        int cur = s, p = c.x, parity = 0;
+        float tdc = __int_as_float(c.y);
+        while (p < cur) {
+            const int2 c2 = cand[p];
+            if (c2.x < 0) break;                              // p holds no depth ("-1") -> accept
+            const float tdp = __int_as_float(c2.y);
+            if (tdp > tdc) break;                             // existing_depth > transformed_d_s -> accept
+            parity ^= 1;                                      // depends on acc(p): acc(cur) = !acc(p)
+            cur = p; p = c2.x; tdc = tdp;
+        }
+        accepted = parity == 0;
+    }
+    if (s < npix) accf[s] = accepted ? 1 : 0;
+    if (accepted) {
+        const int i = s / L.w, j = s - i * L.w, t = c.x;
+        // source_XYZ[v_s][u_s] (Geometry.cpp:84-100)
+        const float z = L.sd[s];
+        float p0 = -1.0f, p1 = -1.0f, p2 = -1.0f;
+        if (z > 0) { p0 = ((float)j - L.cx) * z / L.fx; p1 = ((float)i - L.cy) * z / L.fy; p2 = z; }
+        const float q0 = sum3(s_T[0] * p0, s_T[1] * p1, s_T[2] * p2) + s_T[3];
+        const float q1 = sum3(s_T[4] * p0, s_T[5] * p1, s_T[6] * p2) + s_T[7];
+        const float q2 = sum3(s_T[8] * p0, s_T[9] * p1, s_T[10] * p2) + s_T[11];
+        const float invz = (float)(1.0 / (double)q2);
+        const float sq_img = (float)0.70710678118654757, sq_dep = (float)0.70710678118654757; // sqrt(1-0.5), sqrt(0.5)
+        float J[2][6], r[2];
+        int rows = 0;
+        if (TERM != 2) { // photometric row (:146-193 / :262-283)
+            const float diff = L.tc[t] - L.sc[s];
+            const float dIdx = 0.125f * L.tcdx[t], dIdy = 0.125f * L.tcdy[t]; // SOBEL_SCALE
+            const float c0 = dIdx * L.fx * invz, c1 = dIdy * L.fy * invz;
+            const float c2 = -(c0 * q0 + c1 * q1) * invz;
+            const float jr[6] = {c0, c1, c2, -q2 * c1 + q1 * c2, q2 * c0 - q0 * c2, -q1 * c0 + q0 * c1};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_img * jr[k] : jr[k];
+            r[rows] = TERM == 0 ? sq_img * diff : diff;
+            ++rows;
+        }
+        if (TERM != 1) { // geometric row (:194-241 / :284-294)
+            float dDdx = 0.125f * L.tddx[t], dDdy = 0.125f * L.tddy[t];
+            if (isnan(dDdx)) dDdx = 0.0f;
+            if (isnan(dDdy)) dDdy = 0.0f;
+            const float diff = L.td[t] - q2;
+            const float d0 = dDdx * L.fx * invz, d1 = dDdy * L.fy * invz;
+            const float d2 = -(d0 * q0 + d1 * q1) * invz;
+            const float jr[6] = {d0, d1, d2 - 1.0f, (-q2 * d1 + q1 * d2) - q1, (q2 * d0 - q0 * d2) + q0, -q1 * d0 + q0 * d1};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_dep * jr[k] : jr[k];
+            r[rows] = TERM == 0 ? sq_dep * diff : diff;
+            ++rows;
+        }
+        // float products as the reference forms them, summed in double
+#pragma unroll
+        for (int m = 0; m < (TERM == 0 ? 2 : 1); ++m) {
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[k++] += (double)(J[m][a] * J[m][b]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(J[m][a] * r[m]);
+            acc[27] += (double)(r[m] * r[m]);
+        }
+        acc[28] = 1.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 29; ++k) {
+        const double v = wave_sum_d(acc[k]);
+        if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double v = 0;
+        if (threadIdx.x < 29)
+            for (int w = 0; w < kThreads / 64; ++w) v += s_red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
+    }
+}
+
+// ---- second reduction pass + solve + pose update (DenseOdometryFunction.cpp:404-413) ------------
+__global__ __launch_bounds__(1024) void k_track_solve(TrackState* __restrict__ st, int l, int it, const double* __restrict__ partials) {
+    if (st->stop_level == l) return;
+    __shared__ double s[32][kNSums];
+    __shared__ double tot[kNSums];
+    const LevelDev& L = st->lv[l];
+    const int n_partials = (L.w * L.h + kThreads - 1) / kThreads;
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    int p = grp;
+    for (; p + 96 < n_partials; p += 128) {
+        v0 += partials[(size_t)p * kNSums + k];
+        v1 += partials[(size_t)(p + 32) * kNSums + k];
+        v2 += partials[(size_t)(p + 64) * kNSums + k];
+        v3 += partials[(size_t)(p + 96) * kNSums + k];
+    }
+    for (; p < n_partials; p += 32) v0 += partials[(size_t)p * kNSums + k];
+    s[grp][k] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double t = 0;
+        for (int g = 0; g < 32; ++g) t += s[g][threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double JTJ[36], JTr[6];
+        float x[6], D[16], cur[16];
+        int q = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { JTJ[a * 6 + b] = tot[q]; JTJ[b * 6 + a] = tot[q]; ++q; }
+        for (int a = 0; a < 6; ++a) JTr[a] = tot[21 + a];
+        op_host::ldlt_solve6(JTJ, JTr, x);
+        op_host::se3_exp(x, D);
+        for (int i = 0; i < 16; ++i) cur[i] = st->T[i];
+        op_host::mat4_mul(D, cur, cur);               // relative_pose = delta_matrix * relative_pose
+        for (int i = 0; i < 16; ++i) st->T[i] = cur[i];
+        const unsigned long long n = (unsigned long long)(tot[28] + 0.5);
+        st->n_last = n;
+        st->last_level = l;
+        st->iters_done = st->iters_done + 1;
+        st->per_iter_count[it] = (int)n;
+        for (int i = 0; i < 16; ++i) st->per_iter_T[16 * it + i] = cur[i];
+        // Odometry.cpp:669: (float)size / (height*width) > MAX_INLIER_RATIO_DENSE, FULL-resolution h*w
+        if ((double)((float)n / (float)(st->full_h * st->full_w)) > 0.9) st->stop_level = l;
+    }
+}
+
+// ---- correspondence_set / pixel_correspondence_set / rmse (Odometry.cpp:676-687, :606) ---------
+// Ordered (raster) compaction of the last executed iteration's accepted pixels.
+__global__ __launch_bounds__(kThreads) void k_emit_count(const TrackState* __restrict__ st, const unsigned char* __restrict__ accf,
+                                                         unsigned* __restrict__ wg_count) {
+    __shared__ unsigned s_c[kThreads / 64];
+    const int ll = st->last_level;
+    const int npix = ll < 0 ? 0 : st->lv[ll].w * st->lv[ll].h;
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    const bool a = s < npix && accf[s];
+    const unsigned long long m = __ballot(a);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+__global__ __launch_bounds__(1024) void k_emit_scan(TrackState* __restrict__ st, unsigned* __restrict__ wg_count, int n_wg) {
+    // exclusive scan of n_wg counts by one workgroup (n_wg <= a few thousand), in place
+    __shared__ unsigned s_part[1024];
+    const int per = (n_wg + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, n_wg);
+    unsigned sum = 0;
+    for (int i = lo; i < hi; ++i) sum += wg_count[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) { const unsigned c = wg_count[i]; wg_count[i] = run; run += c; }
+    if (threadIdx.x == 1023) st->n_emit = s_part[1023];
+}
+
+__global__ __launch_bounds__(kThreads) void k_emit_scatter(const TrackState* __restrict__ st, const int2* __restrict__ cand,
+                                                           const unsigned char* __restrict__ accf, const unsigned* __restrict__ wg_off,
+                                                           int4* __restrict__ pix_out, float* __restrict__ pts_out,
+                                                           double* __restrict__ partials) {
+    __shared__ unsigned s_c[kThreads / 64];
+    __shared__ double s_e[kThreads / 64];
+    const int ll = st->last_level;
+    const int npix = ll < 0 ? 0 : st->lv[ll].w * st->lv[ll].h;
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    const bool a = s < npix && accf[s];
+    const unsigned long long m = __ballot(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_c[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    double e = 0.0;
+    if (a) {
+        unsigned idx = wg_off[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) idx += s_c[w];
+        const int W = st->lv[ll].w;
+        const int v_s = s / W, u_s = s - v_s * W, t = cand[s].x;
+        pix_out[idx] = make_int4(v_s, u_s, t / W, t - (t / W) * W);
+        // source / target image_xyz of LEVEL 0, both at the SOURCE pixel (Odometry.cpp:676-683)
+        const LevelDev& L0 = st->lv[0];
+        const size_t o = (size_t)v_s * L0.w + u_s;
+        const float zs = L0.sd[o], zt = L0.td[o];
+        float p[3] = {-1.0f, -1.0f, -1.0f}, q[3] = {-1.0f, -1.0f, -1.0f};
+        if (zs > 0) { p[0] = ((float)u_s - L0.cx) * zs / L0.fx; p[1] = ((float)v_s - L0.cy) * zs / L0.fy; p[2] = zs; }
+        if (zt > 0) { q[0] = ((float)u_s - L0.cx) * zt / L0.fx; q[1] = ((float)v_s - L0.cy) * zt / L0.fy; q[2] = zt; }
+        if (pts_out) {
+            float* o6 = pts_out + (size_t)idx * 6;
+            o6[0] = p[0]; o6[1] = p[1]; o6[2] = p[2]; o6[3] = q[0]; o6[4] = q[1]; o6[5] = q[2];
+        }
+        // ComputeReprojectionError3D (Geometry.cpp:48-61): (T*(p,1)).head<3>()/w - q, squaredNorm
+        const float* T = st->T;
+        float h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = ((T[r * 4] * p[0] + T[r * 4 + 1] * p[1]) + T[r * 4 + 2] * p[2]) + T[r * 4 + 3] * 1.0f;
+        const float e0 = h[0] / h[3] - q[0], e1 = h[1] / h[3] - q[1], e2 = h[2] / h[3] - q[2];
+        e = (double)sum3(e0 * e0, e1 * e1, e2 * e2);
+    }
+    e = wave_sum_d(e);
+    if (lane == 0) s_e[wave] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
+}
+
+__global__ __launch_bounds__(1024) void k_emit_finish(TrackState* __restrict__ st, const double* __restrict__ partials, int n_wg) {
+    __shared__ double s_w[16];
+    double v = 0;
+    for (int i = threadIdx.x; i < n_wg; i += 1024) v += partials[i];
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < 16; ++w) t += s_w[w];
+        const unsigned long long n = st->last_level < 0 ? 0ull : st->n_last;
+        st->rmse = sqrt(t / (double)n);                      // n == 0 -> NaN, as the reference's 0/0
+        st->success = (double)((float)n / (float)(st->full_h * st->full_w)) >= 0.3 ? 1 : 0; // MIN_INLIER_RATIO_DENSE
+    }
+}
+
+} // namespace
+
+struct op_tracker {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    TrackState* st = nullptr;        // device
+    TrackState* st_host = nullptr;   // pinned
+    size_t pix_cap = 0;              // workspace capacity in pixels
+    int2* cand = nullptr;
+    unsigned char* accf = nullptr;
+    double* partials = nullptr;
+    unsigned* wg_count = nullptr;
+    int4* pix_out = nullptr;
+    float* pts_out = nullptr;
+    float* images = nullptr;         // device copies of OP_MEM_HOST pyramids
+    size_t images_cap = 0;           // floats
+};
+
+namespace {
+
+int tracker_reserve(op_tracker* t, size_t npix, size_t image_floats) {
+    if (npix > t->pix_cap) {
+        (void)hipFree(t->cand); (void)hipFree(t->accf); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
+        t->cand = nullptr; t->accf = nullptr; t->partials = nullptr; t->wg_count = nullptr; t->pix_out = nullptr; t->pts_out = nullptr;
+        t->pix_cap = 0;
+        const size_t n_wg = (npix + kThreads - 1) / kThreads;
+        OP_HIP(hipMalloc(&t->cand, npix * sizeof(int2)));
+        OP_HIP(hipMalloc(&t->accf, npix));
+        OP_HIP(hipMalloc(&t->partials, n_wg * kNSums * sizeof(double)));
+        OP_HIP(hipMalloc(&t->wg_count, n_wg * sizeof(unsigned)));
+        OP_HIP(hipMalloc(&t->pix_out, npix * sizeof(int4)));
+        OP_HIP(hipMalloc(&t->pts_out, npix * 6 * sizeof(float)));
+        t->pix_cap = npix;
+    }
+    if (image_floats > t->images_cap) {
+        (void)hipFree(t->images);
+        t->images = nullptr; t->images_cap = 0;
+        OP_HIP(hipMalloc(&t->images, image_floats * sizeof(float)));
+        t->images_cap = image_floats;
+    }
+    return OP_OK;
+}
+
+template <int TERM>
+void launch_accum(op_tracker* t, int l, int n_wg) {
+    hipLaunchKernelGGL(k_track_accum<TERM>, dim3(n_wg), dim3(kThreads), 0, t->stream, t->st, l, t->cand, t->accf, t->partials);
+}
+
+} // namespace
+
+extern "C" {
+
+int op_tracker_create(int device, op_tracker** out) {
+    if (!out) return fail(OP_ERR_INVALID, "op_tracker_create: out is NULL");
+    OP_TRY(use_device(device));
+    op_tracker* t = new op_tracker();
+    t->device = device;
+    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&t->st, sizeof(TrackState)) != hipSuccess ||
+        hipHostMalloc(&t->st_host, sizeof(TrackState)) != hipSuccess) {
+        op_tracker_destroy(t);
+        return fail(OP_ERR_HIP, "op_tracker_create: allocating tracker state failed");
+    }
+    *out = t;
+    return OP_OK;
+}
+
+int op_tracker_destroy(op_tracker* t) {
+    if (!t) return OP_OK;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    (void)hipFree(t->cand); (void)hipFree(t->accf); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
+    (void)hipFree(t->images); (void)hipFree(t->st);
+    if (t->st_host) (void)hipHostFree(t->st_host);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    return OP_OK;
+}
+
+int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, const int32_t* iters_per_level, int full_width,
+                     int full_height, int term_type, const float init_T[16], int mem, op_track_result* result, int32_t* pixel_corr,
+                     float* point_corr, size_t corr_cap, int32_t* per_iter_count, float* per_iter_T) {
+    if (!t || !levels || !iters_per_level || !init_T || !result) return fail(OP_ERR_INVALID, "op_tracker_track: NULL argument");
+    if (n_levels < 1 || n_levels > kMaxLevels) return fail(OP_ERR_INVALID, "op_tracker_track: n_levels %d not in [1,%d]", n_levels, kMaxLevels);
+    if (term_type < 0 || term_type > 2) return fail(OP_ERR_INVALID, "op_tracker_track: term_type %d not in {0,1,2}", term_type);
+    if (full_width <= 0 || full_height <= 0) return fail(OP_ERR_INVALID, "op_tracker_track: full resolution %dx%d", full_width, full_height);
+    if (mem != OP_MEM_HOST && mem != OP_MEM_DEVICE) return fail(OP_ERR_INVALID, "op_tracker_track: bad mem %d", mem);
+    size_t max_pix = 0, image_floats = 0;
+    int total_iters = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const op_track_level& L = levels[l];
+        if (L.width <= 0 || L.height <= 0 || (size_t)L.width * L.height > (1u << 28))
+            return fail(OP_ERR_INVALID, "op_tracker_track: level %d size %dx%d", l, L.width, L.height);
+        if (!L.source_color || !L.source_depth || !L.target_color || !L.target_depth || !L.target_color_dx || !L.target_color_dy ||
+            !L.target_depth_dx || !L.target_depth_dy)
+            return fail(OP_ERR_INVALID, "op_tracker_track: level %d has a NULL image", l);
+        if (iters_per_level[l] < 0) return fail(OP_ERR_INVALID, "op_tracker_track: negative iteration count at level %d", l);
+        const size_t np = (size_t)L.width * L.height;
+        max_pix = np > max_pix ? np : max_pix;
+        image_floats += 8 * np;
+        total_iters += iters_per_level[l];
+    }
+    if (total_iters > kMaxIters) return fail(OP_ERR_INVALID, "op_tracker_track: %d iterations exceed the limit %d", total_iters, kMaxIters);
+    OP_TRY(use_device(t->device));
+    OP_TRY(tracker_reserve(t, max_pix, mem == OP_MEM_HOST ? image_floats : 0));
+
+    TrackState* h = t->st_host;
+    std::memcpy(h->T, init_T, sizeof(h->T));
+    h->full_w = full_width; h->full_h = full_height; h->term = term_type;
+    h->stop_level = -1; h->iters_done = 0; h->last_level = -1; h->n_last = 0; h->n_emit = 0; h->rmse = 0; h->success = 0;
+    float* dst = t->images;
+    for (int l = 0; l < n_levels; ++l) {
+        const op_track_level& L = levels[l];
+        LevelDev& D = h->lv[l];
+        D.w = L.width; D.h = L.height; D.fx = L.fx; D.fy = L.fy; D.cx = L.cx; D.cy = L.cy;
+        const float* src[8] = {L.source_color, L.source_depth, L.target_color, L.target_depth,
+                               L.target_color_dx, L.target_color_dy, L.target_depth_dx, L.target_depth_dy};
+        const float** out[8] = {&D.sc, &D.sd, &D.tc, &D.td, &D.tcdx, &D.tcdy, &D.tddx, &D.tddy};
+        const size_t np = (size_t)L.width * L.height;
+        for (int k = 0; k < 8; ++k) {
+            if (mem == OP_MEM_HOST) {
+                OP_HIP(hipMemcpyAsync(dst, src[k], np * sizeof(float), hipMemcpyHostToDevice, t->stream));
+                *out[k] = dst;
+                dst += np;
+            } else {
+                *out[k] = src[k];
+            }
+        }
+    }
+    // header of the state only (the per-iteration logs are outputs)
+    OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
+
+    int it = 0;
+    for (int l = n_levels - 1; l >= 0; --l) {
+        const int n_wg = (int)(((size_t)levels[l].width * levels[l].height + kThreads - 1) / kThreads);
+        for (int j = 0; j < iters_per_level[l]; ++j, ++it) {
+            hipLaunchKernelGGL(k_track_assoc, dim3(n_wg), dim3(kThreads), 0, t->stream, t->st, l, t->cand);
+            if (term_type == 0) launch_accum<0>(t, l, n_wg);
+            else if (term_type == 1) launch_accum<1>(t, l, n_wg);
+            else launch_accum<2>(t, l, n_wg);
+            hipLaunchKernelGGL(k_track_solve, dim3(1), dim3(1024), 0, t->stream, t->st, l, it, t->partials);
+        }
+    }
+    const int n_wg_max = (int)((max_pix + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_emit_count, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->accf, t->wg_count);
+    hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg_max);
+    hipLaunchKernelGGL(k_emit_scatter, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->cand, t->accf, t->wg_count, t->pix_out,
+                       point_corr ? t->pts_out : nullptr, t->partials);
+    hipLaunchKernelGGL(k_emit_finish, dim3(1), dim3(1024), 0, t->stream, t->st, t->partials, n_wg_max);
+    OP_HIP(hipGetLastError());
+    const bool want_logs = per_iter_count || per_iter_T;
+    OP_HIP(hipMemcpyAsync(h, t->st, want_logs ? sizeof(TrackState) : offsetof(TrackState, per_iter_count), hipMemcpyDeviceToHost, t->stream));
+    OP_HIP(hipStreamSynchronize(t->stream));
+
+    std::memcpy(result->T, h->T, sizeof(result->T));
+    result->rmse = h->rmse;
+    result->n_correspondences = h->last_level < 0 ? 0 : h->n_last;
+    result->tracking_success = h->success;
+    result->iterations = h->iters_done;
+    if (h->last_level >= 0 && h->n_emit != h->n_last)
+        return fail(OP_ERR_HIP, "op_tracker_track: emitted %llu correspondences, counted %llu", h->n_emit, h->n_last);
+    if (per_iter_count) std::memcpy(per_iter_count, h->per_iter_count, sizeof(int) * h->iters_done);
+    if (per_iter_T) std::memcpy(per_iter_T, h->per_iter_T, sizeof(float) * 16 * h->iters_done);
+    const size_t n = (size_t)result->n_correspondences;
+    if ((pixel_corr || point_corr) && n) {
+        if (n > corr_cap) return fail(OP_ERR_CAPACITY, "op_tracker_track: %zu correspondences exceed corr_cap %zu", n, corr_cap);
+        if (pixel_corr) OP_HIP(hipMemcpyAsync(pixel_corr, t->pix_out, n * sizeof(int4), hipMemcpyDeviceToHost, t->stream));
+        if (point_corr) OP_HIP(hipMemcpyAsync(point_corr, t->pts_out, n * 6 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+        OP_HIP(hipStreamSynchronize(t->stream));
+    }
+    return OP_OK;
+}
+
+int op_tracker_correspondences(op_tracker* t, const op_track_level* level, const float T[16], int mem, int32_t* pixel_corr,
+                               size_t corr_cap, size_t* n) {
+    if (!t || !level || !T || !n) return fail(OP_ERR_INVALID, "op_tracker_correspondences: NULL argument");
+    // ComputeCorrespondencePixelWise alone == one level with zero iterations... the acceptance pass
+    // lives in k_track_accum, so run exactly one iteration on a scratch pose and emit its pairs.
+    op_track_result res;
+    const int32_t iters[1] = {1};
+    OP_TRY(op_tracker_track(t, level, 1, iters, level->width, level->height, OP_TRACK_DEPTH, T, mem, &res, pixel_corr, nullptr,
+                            corr_cap, nullptr, nullptr));
+    *n = (size_t)res.n_correspondences;
+    return OP_OK;
+}
+
+int op_track_projection(const float cam4[4], const float T[16], float KRK_inv[9], float Kt[3]) {
+    if (!cam4 || !T || !KRK_inv || !Kt) return fail(OP_ERR_INVALID, "op_track_projection: NULL argument");
+    op_host::track_projection(cam4[0], cam4[1], cam4[2], cam4[3], T, KRK_inv, Kt);
+    return OP_OK;
+}
+
+int op_ldlt_solve6(const double JTJ[36], const double JTr[6], float x[6]) {
+    if (!JTJ || !JTr || !x) return fail(OP_ERR_INVALID, "op_ldlt_solve6: NULL argument");
+    op_host::ldlt_solve6(JTJ, JTr, x);
+    return OP_OK;
+}
+
+int op_dense_track(const op_track_level* levels, int n_levels, const int32_t* iters_per_level, int full_width, int full_height,
+                   int term_type, const float init_T[16], int mem, int device, op_track_result* result, int32_t* pixel_corr,
+                   float* point_corr, size_t corr_cap) {
+    op_tracker* t = nullptr;
+    OP_TRY(op_tracker_create(device, &t));
+    const int rc = op_tracker_track(t, levels, n_levels, iters_per_level, full_width, full_height, term_type, init_T, mem, result,
+                                    pixel_corr, point_corr, corr_cap, nullptr, nullptr);
+    op_tracker_destroy(t);
+    return rc;
+}
+
+} // extern "C"

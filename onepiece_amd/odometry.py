@@ -1,0 +1,294 @@
+"""Host-side mirror of one_piece::odometry::Odometry's DENSE tracker over the C-ABI.
+
+Same names, argument meaning and result fields as /root/reference/src/Odometry/Odometry.h:29-37
+(DenseTrackingResult) and :82-88,100-120,168-170 (DenseTracking, SetMultiScale,
+CreatePyramidCameras, multi_scale_level, iter_count_per_level).  The coarse-to-fine Gauss-Newton
+loop -- projective association with the reference's source-indexed "z-buffer", the hybrid / photo /
+depth Jacobians, the 6x6 LDL^T solve and the pose update -- runs inside libonepiece_hip.so
+(csrc/odometry.hip); nothing of it is computed here.
+
+What IS computed here, in numpy, is the image preparation the reference delegates to OpenCV
+(cvtColor, GaussianBlur 3x3, pyrDown, Sobel 3x3; Odometry.cpp:436-449,609-620).  OpenCV is not
+vendored by the reference, so that stage is outside the pinned boundary: the
+functions below follow OpenCV's published definitions (BORDER_REFLECT_101, the [1 4 6 4 1]/16
+pyrDown kernel, the [1 2 1]x[-1 0 1] Sobel) but are not claimed bit-identical to it.  A caller that
+already has OpenCV pyramids (the reference's RGBDFrame) passes them straight to
+`MultiScaleComputing`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .integration import PinholeCamera
+
+TRACK_IMAGES = ("source_color", "source_depth", "target_color", "target_depth", "target_color_dx",
+                "target_color_dy", "target_depth_dx", "target_depth_dy")
+
+MAX_DEPTH, MIN_DEPTH = 4.0, 0.5  # OdometryPredefined.h:10-11
+
+
+class DenseTrackingResult:
+    """odometry::DenseTrackingResult (Odometry.h:29-37)."""
+
+    def __init__(self):
+        self.T = np.eye(4, dtype=np.float32)
+        self.pixel_correspondence_set = np.zeros((0, 4), np.int32)   # {v_s, u_s, v_t, u_t}
+        self.correspondence_set = np.zeros((0, 2, 3), np.float32)    # (source xyz, target xyz)
+        self.rmse = 1e6
+        self.tracking_success = False
+        self.iterations = 0
+        self.per_iter_count = None
+        self.per_iter_T = None
+
+
+# ---- image preparation (numpy; see the module docstring) ---------------------------------------
+def _reflect101(a, r, axis):
+    idx = np.arange(-r, a.shape[axis] + r)
+    n = a.shape[axis]
+    idx = np.abs(idx)
+    idx = np.where(idx >= n, 2 * (n - 1) - idx, idx)
+    return np.take(a, idx, axis=axis)
+
+
+def _sep_filter(img, kx, ky):
+    img = np.asarray(img, np.float32)
+    rx, ry = len(kx) // 2, len(ky) // 2
+    p = _reflect101(img, rx, 1)
+    out = np.zeros_like(img)
+    for k, w in enumerate(kx):
+        out = out + np.float32(w) * p[:, k:k + img.shape[1]]
+    p = _reflect101(out, ry, 0)
+    out2 = np.zeros_like(img)
+    for k, w in enumerate(ky):
+        out2 = out2 + np.float32(w) * p[k:k + img.shape[0], :]
+    return out2.astype(np.float32)
+
+
+def ConvertColorToIntensity32F(color, scale=255.0):
+    """DenseOdometryFunction.cpp:58-71: cvtColor(RGB2GRAY) on 8-bit, then / scale."""
+    color = np.asarray(color)
+    if color.ndim == 2:
+        gray = color.astype(np.uint8)
+    else:
+        c = color.astype(np.int64)
+        # OpenCV 8-bit RGB2GRAY: (R*4899 + G*9617 + B*1868 + 8192) >> 14 with R = channel 0
+        gray = ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+    return (gray.astype(np.float32) / np.float32(scale)).astype(np.float32)
+
+
+def ConvertDepthTo32FNaN(depth, depth_scale=1000.0):
+    """DenseOdometryFunction.cpp:28-56: metres, NaN outside (MIN_DEPTH, MAX_DEPTH)."""
+    depth = np.asarray(depth)
+    if depth.dtype == np.uint16:
+        ok = (depth > MIN_DEPTH * depth_scale) & (depth < MAX_DEPTH * depth_scale)
+        out = depth.astype(np.float32) / np.float32(depth_scale)
+    else:
+        depth = depth.astype(np.float32)
+        ok = (depth > MIN_DEPTH) & (depth < MAX_DEPTH)
+        out = depth.copy()
+    out[~ok] = np.nan
+    return out
+
+
+def GaussianFiltering(img, k_size=3):
+    """tool::GaussianFiltering (ImageProcessing.cpp:43-46): GaussianBlur(k, sigma=0); k = 3 -> [1 2 1]/4."""
+    if k_size != 3:
+        raise ValueError("only the 3x3 kernel the tracker uses is provided")
+    k = (0.25, 0.5, 0.25)
+    return _sep_filter(img, k, k)
+
+
+def PyrDown(img):
+    """cv::pyrDown to (cols/2, rows/2): [1 4 6 4 1]/16 separable, even samples."""
+    k = tuple(v / 16.0 for v in (1, 4, 6, 4, 1))
+    f = _sep_filter(img, k, k)
+    h, w = img.shape
+    return np.ascontiguousarray(f[0:2 * (h // 2):2, 0:2 * (w // 2):2])
+
+
+def CreatePyramid(img, levels):
+    out = [np.ascontiguousarray(img, np.float32)]
+    for _ in range(1, levels):
+        out.append(PyrDown(out[-1]))
+    return out
+
+
+def SobelFiltering(img, axis):
+    """cv::Sobel(src, CV_32F, dx, dy) with the default 3x3 kernel (ImageProcessing.cpp:25-34)."""
+    d, s = (-1.0, 0.0, 1.0), (1.0, 2.0, 1.0)
+    return _sep_filter(img, d, s) if axis == "x" else _sep_filter(img, s, d)
+
+
+def NormalizeIntensity(source_gray, target_gray, correspondences):
+    """DenseOdometryFunction.cpp:129-145: float sequential means over the identity-pose pairs."""
+    c = np.asarray(correspondences, np.int64).reshape(-1, 4)
+    ms = np.float32(0.0)
+    mt = np.float32(0.0)
+    sv = source_gray[c[:, 0], c[:, 1]].astype(np.float32)
+    tv = target_gray[c[:, 2], c[:, 3]].astype(np.float32)
+    # sequential float32 accumulation (np.cumsum keeps the running sum in float32)
+    if len(c):
+        ms = np.cumsum(sv, dtype=np.float32)[-1]
+        mt = np.cumsum(tv, dtype=np.float32)[-1]
+    ms = np.float32(ms / np.float32(len(c))) if len(c) else np.float32(np.nan)
+    mt = np.float32(mt / np.float32(len(c))) if len(c) else np.float32(np.nan)
+    # LinearTransform(img, 0.5 / mean, 0.0): the scale is a double converted to float at the call
+    return (source_gray * np.float32(0.5 / float(ms)) + np.float32(0.0)).astype(np.float32), \
+           (target_gray * np.float32(0.5 / float(mt)) + np.float32(0.0)).astype(np.float32)
+
+
+def make_level(cam, source_color, source_depth, target_color, target_depth, target_color_dx, target_color_dy,
+               target_depth_dx, target_depth_dy):
+    lv = {"width": int(cam.width), "height": int(cam.height), "fx": float(cam.fx), "fy": float(cam.fy),
+          "cx": float(cam.cx), "cy": float(cam.cy)}
+    for k, v in zip(TRACK_IMAGES, (source_color, source_depth, target_color, target_depth, target_color_dx,
+                                   target_color_dy, target_depth_dx, target_depth_dy)):
+        lv[k] = v
+    return lv
+
+
+def _image_ptr(a, h, w, keep):
+    """numpy float32 (h,w) -> host pointer; torch CUDA float32 tensor -> device pointer."""
+    if isinstance(a, np.ndarray) or not hasattr(a, "data_ptr"):
+        a = np.ascontiguousarray(a, np.float32)
+        if a.shape != (h, w):
+            raise ValueError("image shape %s != (%d, %d)" % (a.shape, h, w))
+        keep.append(a)
+        return a.ctypes.data, L.OP_MEM_HOST
+    import torch
+    if a.dtype != torch.float32 or not a.is_contiguous() or tuple(a.shape) != (h, w):
+        raise ValueError("device images must be contiguous float32 (h, w) tensors")
+    keep.append(a)
+    return a.data_ptr(), (L.OP_MEM_DEVICE if a.is_cuda else L.OP_MEM_HOST)
+
+
+def _levels_arg(levels):
+    arr = (L.TrackLevel * len(levels))()
+    keep, mems = [], set()
+    for k, lv in enumerate(levels):
+        arr[k].width, arr[k].height = int(lv["width"]), int(lv["height"])
+        arr[k].fx, arr[k].fy, arr[k].cx, arr[k].cy = (float(lv[c]) for c in ("fx", "fy", "cx", "cy"))
+        for name in TRACK_IMAGES:
+            ptr, mem = _image_ptr(lv[name], arr[k].height, arr[k].width, keep)
+            setattr(arr[k], name, ptr)
+            mems.add(mem)
+    if len(mems) != 1:
+        raise ValueError("all pyramid images must live in the same memory space")
+    return arr, mems.pop(), keep
+
+
+class Odometry:
+    """odometry::Odometry, dense part (Odometry.h:38-175)."""
+
+    def __init__(self, camera=None, device=0):
+        self.camera = camera if camera is not None else PinholeCamera()
+        self.multi_scale_level = 3                     # Odometry.h:168
+        self.iter_count_per_level = [4, 8, 16]         # Odometry.h:170
+        self.device = device
+        self._h = C.c_void_p()
+        L.check(L.load().op_tracker_create(device, C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and L is not None and getattr(L, "_lib", None) is not None:
+            L._lib.op_tracker_destroy(h)
+            self._h = None
+
+    def SetCamera(self, camera):
+        self.camera = camera
+
+    def SetMultiScale(self, layer_count):
+        """Odometry.h:100-104: resize(layer_count, 4) keeps existing entries, pads with 4."""
+        self.multi_scale_level = int(layer_count)
+        cur = list(self.iter_count_per_level)[:layer_count]
+        self.iter_count_per_level = cur + [4] * (layer_count - len(cur))
+
+    def CreatePyramidCameras(self):
+        """Odometry.h:110-120 / Camera.h:38-42: fx,fy,cx,cy halved (float), width/height halved (int)."""
+        cams = []
+        for i in range(self.multi_scale_level):
+            if i == 0:
+                c = self.camera
+                cams.append(L.Camera(c.fx, c.fy, c.cx, c.cy, c.width, c.height, c.depth_scale))
+            else:
+                p = cams[-1]
+                cams.append(L.Camera(p.fx / 2.0, p.fy / 2.0, p.cx / 2.0, p.cy / 2.0,   # halving is exact in float
+                                     p.width // 2, p.height // 2, p.depth_scale))
+        return cams
+
+    # -- image preparation (numpy stage, see module docstring) --
+    def InitializeRGBDDenseTracking(self, color, depth):
+        """Odometry.cpp:609-620: intensity / NaN-depth conversion, 3x3 Gaussian on both."""
+        gray = GaussianFiltering(ConvertColorToIntensity32F(color, 255.0))
+        refined = GaussianFiltering(ConvertDepthTo32FNaN(depth, self.camera.depth_scale))
+        return gray, refined
+
+    def CreateImagePyramid(self, gray, depth):
+        """Odometry.cpp:436-449 -> (color, depth, color_dx, color_dy, depth_dx, depth_dy) pyramids."""
+        cp, dp = CreatePyramid(gray, self.multi_scale_level), CreatePyramid(depth, self.multi_scale_level)
+        return (cp, dp, [SobelFiltering(c, "x") for c in cp], [SobelFiltering(c, "y") for c in cp],
+                [SobelFiltering(d, "x") for d in dp], [SobelFiltering(d, "y") for d in dp])
+
+    def BuildLevels(self, source_gray, source_depth, target_gray, target_depth):
+        cams = self.CreatePyramidCameras()
+        scp, sdp, _, _, _, _ = self.CreateImagePyramid(source_gray, source_depth)
+        tcp, tdp, tcdx, tcdy, tddx, tddy = self.CreateImagePyramid(target_gray, target_depth)
+        return [make_level(cams[i], scp[i], sdp[i], tcp[i], tdp[i], tcdx[i], tcdy[i], tddx[i], tddy[i])
+                for i in range(self.multi_scale_level)]
+
+    # -- the GPU path --
+    def ComputeCorrespondencePixelWise(self, level, T=None):
+        """DenseOdometryFunction.cpp:72-128 on the GPU: (n,4) int32 {v_s,u_s,v_t,u_t}, raster order."""
+        arr, mem, keep = _levels_arg([level])
+        T = np.ascontiguousarray(np.eye(4) if T is None else T, np.float32).reshape(16)
+        cap = arr[0].width * arr[0].height
+        out = np.empty((cap, 4), np.int32)
+        n = C.c_size_t(0)
+        L.check(L.load().op_tracker_correspondences(self._h, arr, T.ctypes.data_as(L._fp), mem, C.c_void_p(out.ctypes.data),
+                                                    cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def MultiScaleComputing(self, levels, T=None, term_type=0, want_correspondences=True, want_log=False):
+        """Odometry::MultiScaleComputing + result assembly (Odometry.cpp:621-687, :600-607)."""
+        arr, mem, keep = _levels_arg(levels)
+        if len(levels) != len(self.iter_count_per_level):
+            raise ValueError("levels and iter_count_per_level differ in length")
+        T0 = np.ascontiguousarray(np.eye(4) if T is None else T, np.float32).reshape(16)
+        iters = np.asarray(self.iter_count_per_level, np.int32)
+        total = int(iters.sum())
+        res = L.TrackResult()
+        cap = max(int(lv["width"]) * int(lv["height"]) for lv in levels) if want_correspondences else 0
+        pix = np.empty((cap, 4), np.int32) if want_correspondences else None
+        pts = np.empty((cap, 6), np.float32) if want_correspondences else None
+        per_n = np.zeros(max(total, 1), np.int32) if want_log else None
+        per_T = np.zeros((max(total, 1), 16), np.float32) if want_log else None
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
+        L.check(L.load().op_tracker_track(self._h, arr, len(levels), iters.ctypes.data_as(L._ip), int(self.camera.width),
+                                          int(self.camera.height), int(term_type), T0.ctypes.data_as(L._fp), mem, C.byref(res),
+                                          vp(pix), vp(pts), cap, vp(per_n), vp(per_T)))
+        out = DenseTrackingResult()
+        out.T = np.array(res.T, np.float32).reshape(4, 4)
+        out.rmse = float(res.rmse)
+        out.tracking_success = bool(res.tracking_success)
+        out.iterations = int(res.iterations)
+        out.n_correspondences = int(res.n_correspondences)
+        if want_correspondences:
+            n = out.n_correspondences
+            out.pixel_correspondence_set = pix[:n].copy()
+            out.correspondence_set = pts[:n].reshape(-1, 2, 3).copy()
+        if want_log:
+            out.per_iter_count = per_n[:out.iterations].copy()
+            out.per_iter_T = per_T[:out.iterations].reshape(-1, 4, 4).copy()
+        return out
+
+    def DenseTracking(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0, **kw):
+        """Odometry::DenseTracking (Odometry.cpp:463-524): prepare, normalise intensity over the
+        identity-pose correspondences, build pyramids, MultiScaleComputing."""
+        sg, sd = self.InitializeRGBDDenseTracking(source_color, source_depth)
+        tg, td = self.InitializeRGBDDenseTracking(target_color, target_depth)
+        z = np.zeros_like(sg)
+        cam = self.CreatePyramidCameras()[0]
+        corr = self.ComputeCorrespondencePixelWise(make_level(cam, z, sd, z, td, z, z, z, z), np.eye(4))
+        sg, tg = NormalizeIntensity(sg, tg, corr)
+        return self.MultiScaleComputing(self.BuildLevels(sg, sd, tg, td), initial_T, term_type, **kw)

@@ -1179,3 +1179,259 @@ int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt
     free(corr); free(tp); free(inl); free(pairs); free(t.idx); free(t.nodes);
     return 0;
 }
+
+/* ======================= dense RGB-D tracker (Odometry/) ================================== */
+
+/* Eigen 3.3.7 LU/InverseImpl.h:126-170 (compute_inverse<Matrix3f>): cofactors of column 0,
+ * det = 3-term redux a0+(a1+a2), every entry = cofactor * (1/det).  Row-major in/out. */
+void orc_mat3_inverse(const float m[9], float out[9]) {
+#define M3(i, j) m[((i) % 3) * 3 + ((j) % 3)]
+#define COF(i, j) (M3((i) + 1, (j) + 1) * M3((i) + 2, (j) + 2) - M3((i) + 1, (j) + 2) * M3((i) + 2, (j) + 1))
+    float c0 = COF(0, 0), c1 = COF(1, 0), c2 = COF(2, 0);
+    float det = sum3(c0 * m[0], c1 * m[3], c2 * m[6]);
+    float invdet = 1.0f / det;
+    out[0] = c0 * invdet; out[1] = c1 * invdet; out[2] = c2 * invdet;
+    out[3] = COF(0, 1) * invdet; out[4] = COF(1, 1) * invdet; out[5] = COF(2, 1) * invdet;
+    out[6] = COF(0, 2) * invdet; out[7] = COF(1, 2) * invdet; out[8] = COF(2, 2) * invdet;
+#undef COF
+#undef M3
+}
+
+static void mat3_mul(const float *A, const float *B, float *C) { /* Matrix3f * Matrix3f, 3-term redux */
+    float o[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) o[r * 3 + c] = sum3(A[r * 3] * B[c], A[r * 3 + 1] * B[3 + c], A[r * 3 + 2] * B[6 + c]);
+    memcpy(C, o, sizeof(o));
+}
+
+/* DenseOdometryFunction.cpp:82-87: K, Kt = K*t, K_inv = K.inverse(), KRK_inv = K*R*K_inv. */
+void orc_track_projection(const float cam[4], const float T[16], float K_inv[9], float KRK_inv[9], float Kt[3]) {
+    float K[9] = {cam[0], 0, cam[2], 0, cam[1], cam[3], 0, 0, 1};
+    float R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, t[3] = {T[3], T[7], T[11]};
+    float KR[9];
+    for (int r = 0; r < 3; ++r) Kt[r] = sum3(K[r * 3] * t[0], K[r * 3 + 1] * t[1], K[r * 3 + 2] * t[2]);
+    orc_mat3_inverse(K, K_inv);
+    mat3_mul(K, R, KR);
+    mat3_mul(KR, K_inv, KRK_inv);
+}
+
+/* DenseOdometryFunction.cpp:95-101: uv = d_s * KRK_inv * Point3(j,i,1.0) + Kt (the scalar*matrix
+ * is evaluated first), u_t = (int)(uv0/uv2 + 0.5) with the division in float and the +0.5 in
+ * double.  A non-finite quotient (x86 cvttsd2si -> INT_MIN) is reported as INT32_MIN. */
+void orc_track_project_pixel(const float KRK_inv[9], const float Kt[3], float d_s, int j, int i, float uv[3], int ut[2]) {
+    float fj = (float)j, fi = (float)i;
+    for (int r = 0; r < 3; ++r)
+        uv[r] = sum3((d_s * KRK_inv[r * 3]) * fj, (d_s * KRK_inv[r * 3 + 1]) * fi, (d_s * KRK_inv[r * 3 + 2]) * 1.0f) + Kt[r];
+    for (int c = 0; c < 2; ++c) {
+        double q = (double)(uv[c] / uv[2]) + 0.5;
+        ut[c] = (q > -2147483649.0 && q < 2147483648.0) ? (int)q : INT32_MIN; /* NaN fails both */
+    }
+}
+
+/* DenseOdometryFunction.cpp:72-128 incl. AddElementToCorrespondenceMap (:9-27): the "z-buffer"
+ * READS wraping_depth at the TARGET pixel but WRITES at the SOURCE pixel; restated as written.
+ * corr: 4 int32 per correspondence {v_s, u_s, v_t, u_t} in raster order; returns the count. */
+size_t orc_pixel_correspondences(const orc_track_level *L, const float T[16], int32_t *corr) {
+    int W = L->width, H = L->height;
+    float cam[4] = {L->fx, L->fy, L->cx, L->cy}, K_inv[9], KRK[9], Kt[3];
+    orc_track_projection(cam, T, K_inv, KRK, Kt);
+    float *wd = (float *)malloc((size_t)W * H * sizeof(float));
+    int32_t *wm = (int32_t *)malloc((size_t)W * H * 2 * sizeof(int32_t));
+    for (size_t k = 0; k < (size_t)W * H; ++k) { wd[k] = -1.0f; wm[2 * k] = wm[2 * k + 1] = -1; }
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            float d_s = L->source_depth[(size_t)i * W + j];
+            if (isnan(d_s)) continue;
+            float uv[3]; int ut[2];
+            orc_track_project_pixel(KRK, Kt, d_s, j, i, uv, ut);
+            float td = uv[2];
+            int u_t = ut[0], v_t = ut[1];
+            if (!(u_t >= 0 && u_t < W && v_t >= 0 && v_t < H)) continue;
+            float d_t = L->target_depth[(size_t)v_t * W + u_t];
+            if (isnan(d_t) || !((double)fabsf(d_t - td) < 0.05)) continue; /* MAX_DIFF_DEPTH */
+            float existing = wd[(size_t)v_t * W + u_t];
+            if (existing == -1.0f || existing > td) {
+                wm[2 * ((size_t)i * W + j)] = v_t; wm[2 * ((size_t)i * W + j) + 1] = u_t;
+                wd[(size_t)i * W + j] = td;
+            }
+        }
+    size_t n = 0;
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j)
+            if (wd[(size_t)i * W + j] != -1.0f) {
+                if (corr) { corr[4 * n] = i; corr[4 * n + 1] = j; corr[4 * n + 2] = wm[2 * ((size_t)i * W + j)]; corr[4 * n + 3] = wm[2 * ((size_t)i * W + j) + 1]; }
+                ++n;
+            }
+    free(wd); free(wm);
+    return n;
+}
+
+/* Geometry/Geometry.cpp:72-106 (TransformToMatXYZ) for one pixel. */
+static void pixel_xyz(const orc_track_level *L, const float *depth, int v, int u, float p[3]) {
+    float z = depth[(size_t)v * L->width + u];
+    if (z > 0) { p[0] = (u - L->cx) * z / L->fx; p[1] = (v - L->cy) * z / L->fy; p[2] = z; }
+    else p[0] = p[1] = p[2] = -1.0f;
+}
+
+/* DenseOdometryFunction.cpp:146-296: Jacobian rows + residuals of one correspondence.
+ * term: 0 hybrid (2 rows), 1 photo, 2 depth.  Returns the row count. */
+static int track_rows(const orc_track_level *L, const float T[16], const int32_t *c, int term, float J[2][6], float r[2]) {
+    const float sqrt_dep = (float)sqrt(0.5), sqrt_img = (float)sqrt(1.0 - 0.5); /* LAMBDA_HYBRID_DEPTH */
+    int W = L->width, v_s = c[0], u_s = c[1], v_t = c[2], u_t = c[3];
+    size_t is = (size_t)v_s * W + u_s, it = (size_t)v_t * W + u_t;
+    float p[3], q[3];
+    pixel_xyz(L, L->source_depth, v_s, u_s, p);
+    for (int k = 0; k < 3; ++k) q[k] = sum3(T[k * 4] * p[0], T[k * 4 + 1] * p[1], T[k * 4 + 2] * p[2]) + T[k * 4 + 3];
+    float invz = (float)(1. / (double)q[2]);
+    float c0 = 0, c1 = 0, c2 = 0, d0 = 0, d1 = 0, d2 = 0, diff_photo = 0, diff_geo = 0;
+    if (term != 2) {
+        diff_photo = L->target_color[it] - L->source_color[is];
+        float dIdx = (float)(0.125 * (double)L->target_color_dx[it]), dIdy = (float)(0.125 * (double)L->target_color_dy[it]);
+        c0 = dIdx * L->fx * invz; c1 = dIdy * L->fy * invz;
+        c2 = -(c0 * q[0] + c1 * q[1]) * invz;
+    }
+    if (term != 1) {
+        float dDdx = (float)(0.125 * (double)L->target_depth_dx[it]), dDdy = (float)(0.125 * (double)L->target_depth_dy[it]);
+        if (isnan(dDdx)) dDdx = 0;
+        if (isnan(dDdy)) dDdy = 0;
+        diff_geo = L->target_depth[it] - q[2];
+        d0 = dDdx * L->fx * invz; d1 = dDdy * L->fy * invz;
+        d2 = -(d0 * q[0] + d1 * q[1]) * invz;
+    }
+    float jp[6] = {c0, c1, c2, -q[2] * c1 + q[1] * c2, q[2] * c0 - q[0] * c2, -q[1] * c0 + q[0] * c1};
+    float jd[6] = {d0, d1, d2 - 1.0f, (-q[2] * d1 + q[1] * d2) - q[1], (q[2] * d0 - q[0] * d2) + q[0], (-q[1] * d0 + q[0] * d1)};
+    if (term == 0) {
+        for (int k = 0; k < 6; ++k) { J[0][k] = sqrt_img * jp[k]; J[1][k] = sqrt_dep * jd[k]; }
+        r[0] = sqrt_img * diff_photo; r[1] = sqrt_dep * diff_geo;
+        return 2;
+    }
+    memcpy(J[0], term == 1 ? jp : jd, sizeof(jp));
+    r[0] = term == 1 ? diff_photo : diff_geo;
+    return 1;
+}
+
+/* DenseOdometryFunction.cpp:297-381: float, sequential, `JTJ.noalias() += J*J^T; JTr += J*r;
+ * r2 += r*r` per Jacobian row. */
+typedef struct { float jtj[36], jtr[6], rs; double djtj[36], djtr[6], drs; } gn_acc;
+static inline void gn_add_row(gn_acc *s, const float J[6], float r) {
+    for (int a = 0; a < 6; ++a) {
+        for (int b = 0; b < 6; ++b) { s->jtj[a * 6 + b] += J[a] * J[b]; s->djtj[a * 6 + b] += (double)(J[a] * J[b]); }
+        s->jtr[a] += J[a] * r;
+        s->djtr[a] += (double)(J[a] * r);
+    }
+    s->rs += r * r; s->drs += (double)(r * r);
+}
+static void gn_finish(const gn_acc *s, float JTJ[36], float JTr[6], float *r2) {
+    if (g_accumulate_double) {
+        for (int a = 0; a < 36; ++a) JTJ[a] = (float)s->djtj[a];
+        for (int a = 0; a < 6; ++a) JTr[a] = (float)s->djtr[a];
+        if (r2) *r2 = (float)s->drs;
+    } else {
+        memcpy(JTJ, s->jtj, sizeof(s->jtj)); memcpy(JTr, s->jtr, sizeof(s->jtr));
+        if (r2) *r2 = s->rs;
+    }
+}
+/* The accumulation alone, over caller-supplied rows (pins the order against Eigen's, tests/golden). */
+void orc_track_accumulate_rows(const float *J, const float *r, size_t n, float JTJ[36], float JTr[6], float *r2) {
+    gn_acc s; memset(&s, 0, sizeof(s));
+    for (size_t i = 0; i < n; ++i) gn_add_row(&s, J + 6 * i, r[i]);
+    gn_finish(&s, JTJ, JTr, r2);
+}
+void orc_track_normal_equations(const orc_track_level *L, const float T[16], const int32_t *corr, size_t n, int term,
+                                float JTJ[36], float JTr[6], float *r2) {
+    gn_acc s; memset(&s, 0, sizeof(s));
+    for (size_t i = 0; i < n; ++i) {
+        float J[2][6], r[2];
+        int rows = track_rows(L, T, corr + 4 * i, term, J, r);
+        for (int k = 0; k < rows; ++k) gn_add_row(&s, J[k], r[k]);
+    }
+    gn_finish(&s, JTJ, JTr, r2);
+}
+
+/* x = JTJ.ldlt().solve(-JTr) (DenseOdometryFunction.cpp:404).  Restated as a symmetric-pivoted
+ * LDL^T in double from the float inputs (Eigen factorises in float; agreement is float rounding
+ * times the condition number, pinned at 1e-4 in tests/test_oracle_golden.py).  Zero pivots give
+ * zero components, as Eigen's pseudo-inverse of D does. */
+void orc_ldlt_solve6(const float JTJ[36], const float JTr[6], float x[6]) {
+    double A[36], b[6], y[6];
+    int perm[6];
+    for (int i = 0; i < 6; ++i) { perm[i] = i; b[i] = -(double)JTr[i]; for (int j = 0; j < 6; ++j) A[i * 6 + j] = 0.5 * ((double)JTJ[i * 6 + j] + (double)JTJ[j * 6 + i]); }
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 6; ++i) if (fabs(A[i * 7]) > fabs(A[p * 7])) p = i;
+        if (p != k) {
+            for (int j = 0; j < 6; ++j) { double t = A[k * 6 + j]; A[k * 6 + j] = A[p * 6 + j]; A[p * 6 + j] = t; }
+            for (int j = 0; j < 6; ++j) { double t = A[j * 6 + k]; A[j * 6 + k] = A[j * 6 + p]; A[j * 6 + p] = t; }
+            int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+            double tb = b[k]; b[k] = b[p]; b[p] = tb;
+        }
+        double d = A[k * 7];
+        if (d == 0) continue;
+        for (int i = k + 1; i < 6; ++i) {
+            double l = A[i * 6 + k] / d;
+            for (int j = k + 1; j < 6; ++j) A[i * 6 + j] -= l * A[k * 6 + j];
+            A[i * 6 + k] = l;
+        }
+    }
+    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int j = 0; j < i; ++j) s -= A[i * 6 + j] * y[j]; y[i] = s; }
+    for (int i = 0; i < 6; ++i) y[i] = A[i * 7] != 0 ? y[i] / A[i * 7] : 0.0;
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 6; ++j) s -= A[j * 6 + i] * y[j]; y[i] = s; }
+    for (int i = 0; i < 6; ++i) x[perm[i]] = (float)y[i];
+}
+
+/* DoSingleIteration* (DenseOdometryFunction.cpp:382-475): correspondences at T, normal equations,
+ * delta, T <- Se3ToSE3(delta) * T.  Returns the correspondence count. */
+size_t orc_track_iteration(const orc_track_level *L, int term, float T[16], int32_t *corr) {
+    size_t n = orc_pixel_correspondences(L, T, corr);
+    float JTJ[36], JTr[6], x[6], D[16];
+    orc_track_normal_equations(L, T, corr, n, term, JTJ, JTr, NULL);
+    orc_ldlt_solve6(JTJ, JTr, x);
+    orc_se3_exp(x, D);
+    mat4_mul(D, T, T);
+    return n;
+}
+
+/* Odometry::MultiScaleComputing (Odometry.cpp:621-687) + the rmse line of DenseTracking (:606,
+ * Geometry.cpp:48-61).  levels[0] is full resolution; iters[i] = iter_count_per_level[i]
+ * (Odometry.h:170).  The inlier ratios divide by the FULL-resolution width*height at every level,
+ * as the reference does.  pixel_corr: room for 4*w0*h0 int32; per_iter_count / per_iter_T: room for
+ * sum(iters) entries / x16 floats; may be NULL. */
+int orc_dense_track(const orc_track_level *levels, int n_levels, const int *iters, int full_w, int full_h, int term,
+                    const float init_T[16], orc_track_result *res, int32_t *pixel_corr, int32_t *per_iter_count,
+                    float *per_iter_T) {
+    float T[16];
+    memcpy(T, init_T, sizeof(T));
+    size_t cap = 0;
+    for (int l = 0; l < n_levels; ++l) { size_t s = (size_t)levels[l].width * levels[l].height; if (s > cap) cap = s; }
+    int32_t *corr = (int32_t *)malloc((cap ? cap : 1) * 4 * sizeof(int32_t));
+    size_t n = 0;
+    int total = 0;
+    for (int l = n_levels - 1; l >= 0; --l)
+        for (int j = 0; j != iters[l]; ++j) {
+            n = orc_track_iteration(&levels[l], term, T, corr);
+            if (per_iter_count) per_iter_count[total] = (int32_t)n;
+            if (per_iter_T) memcpy(per_iter_T + 16 * total, T, sizeof(T));
+            ++total;
+            if ((float)n / (full_h * full_w) > 0.9) break; /* MAX_INLIER_RATIO_DENSE (double compare) */
+        }
+    /* correspondence_set: source xyz and TARGET xyz both read at the SOURCE pixel of LEVEL 0
+     * (Odometry.cpp:676-683) whatever level `correspondences` came from. */
+    double sum_error = 0.0;
+    const orc_track_level *L0 = &levels[0];
+    for (size_t i = 0; i < n; ++i) {
+        float p[3], q[3], tp[4];
+        pixel_xyz(L0, L0->source_depth, corr[4 * i], corr[4 * i + 1], p);
+        pixel_xyz(L0, L0->target_depth, corr[4 * i], corr[4 * i + 1], q);
+        mat4_mul_p1(T, p[0], p[1], p[2], tp);
+        float e[3] = {tp[0] / tp[3] - q[0], tp[1] / tp[3] - q[1], tp[2] / tp[3] - q[2]};
+        sum_error += (double)sum3(e[0] * e[0], e[1] * e[1], e[2] * e[2]);
+    }
+    memcpy(res->T, T, sizeof(T));
+    res->n_correspondences = n;
+    res->rmse = sqrt(sum_error / (double)n);
+    res->tracking_success = (float)n / (full_h * full_w) >= 0.3; /* MIN_INLIER_RATIO_DENSE */
+    res->iterations = total;
+    if (pixel_corr) memcpy(pixel_corr, corr, n * 4 * sizeof(int32_t));
+    free(corr);
+    return 0;
+}

@@ -124,6 +124,49 @@ int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt
             orc_icp_result *res, int32_t *inlier_pairs, int32_t *per_iter_inliers,
             float *per_iter_T);
 
+/* ---- Dense RGB-D tracker (Odometry/) ----
+ * Boundary = the inputs of Odometry::MultiScaleComputing (Odometry.cpp:621-636): the image pyramids
+ * are GIVEN (they come out of cv::pyrDown / cv::Sobel / cv::GaussianBlur, un-vendored OpenCV, so
+ * nothing below that boundary can be pinned here).  Image-XYZ pyramids are recomputed from the
+ * depth pyramids with TransformToMatXYZ's own arithmetic (Geometry.cpp:72-106). */
+typedef struct {
+    int width, height;              /* camera_pyramid[l].GetWidth()/GetHeight() == image size */
+    float fx, fy, cx, cy;           /* Camera.h:38-42 (GenerateNextPyramid halves all four) */
+    const float *source_color, *source_depth; /* CV_32FC1, depth NaN = invalid (DenseOdometryFunction.cpp:28-56) */
+    const float *target_color, *target_depth;
+    const float *target_color_dx, *target_color_dy, *target_depth_dx, *target_depth_dy; /* raw Sobel (x SOBEL_SCALE inside) */
+} orc_track_level;
+
+typedef struct {
+    float T[16];
+    double rmse;                    /* ComputeReprojectionError3D over correspondence_set */
+    size_t n_correspondences;       /* of the last executed iteration */
+    int tracking_success;
+    int iterations;                 /* iterations actually executed */
+} orc_track_result;
+
+/* Eigen 3.3.7 LU/InverseImpl.h:126-170 (Matrix3f::inverse()), row-major. */
+void orc_mat3_inverse(const float m[9], float out[9]);
+/* DenseOdometryFunction.cpp:82-87; cam = {fx,fy,cx,cy}. */
+void orc_track_projection(const float cam[4], const float T[16], float K_inv[9], float KRK_inv[9], float Kt[3]);
+/* DenseOdometryFunction.cpp:95-101; ut = {u_t, v_t}. */
+void orc_track_project_pixel(const float KRK_inv[9], const float Kt[3], float d_s, int j, int i, float uv[3], int ut[2]);
+/* DenseOdometryFunction.cpp:72-128 (+ :9-27).  corr: 4 int32 each {v_s,u_s,v_t,u_t}; may be NULL. */
+size_t orc_pixel_correspondences(const orc_track_level *L, const float T[16], int32_t *corr);
+/* DenseOdometryFunction.cpp:146-381; term 0 hybrid, 1 photo, 2 depth. */
+void orc_track_normal_equations(const orc_track_level *L, const float T[16], const int32_t *corr, size_t n, int term,
+                                float JTJ[36], float JTr[6], float *r2);
+/* The accumulation statement of :297-381 alone, over given rows J (n x 6) and residuals r (n). */
+void orc_track_accumulate_rows(const float *J, const float *r, size_t n, float JTJ[36], float JTr[6], float *r2);
+/* JTJ.ldlt().solve(-JTr), DenseOdometryFunction.cpp:404 (restated in double). */
+void orc_ldlt_solve6(const float JTJ[36], const float JTr[6], float x[6]);
+/* DenseOdometryFunction.cpp:382-475 */
+size_t orc_track_iteration(const orc_track_level *L, int term, float T[16], int32_t *corr);
+/* Odometry.cpp:621-687 + :606. */
+int orc_dense_track(const orc_track_level *levels, int n_levels, const int *iters, int full_w, int full_h, int term,
+                    const float init_T[16], orc_track_result *res, int32_t *pixel_corr, int32_t *per_iter_count,
+                    float *per_iter_T);
+
 #ifdef __cplusplus
 }
 #endif

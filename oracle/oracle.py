@@ -33,6 +33,19 @@ class IcpResult(C.Structure):
                 ("n_inliers", C.c_size_t), ("iterations", C.c_int)]
 
 
+class TrackLevel(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float)] + [
+        (k, C.POINTER(C.c_float)) for k in ("source_color", "source_depth", "target_color", "target_depth",
+                                            "target_color_dx", "target_color_dy", "target_depth_dx",
+                                            "target_depth_dy")]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("rmse", C.c_double), ("n_correspondences", C.c_size_t),
+                ("tracking_success", C.c_int), ("iterations", C.c_int)]
+
+
 _lib = None
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -91,6 +104,19 @@ def lib():
         L.orc_icp.restype = C.c_int
         L.orc_icp.argtypes = [C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp, C.c_int,
                               C.c_double, C.POINTER(IcpResult), _ip, _ip, _fp]
+        L.orc_mat3_inverse.argtypes = [_fp, _fp]
+        L.orc_track_projection.argtypes = [_fp, _fp, _fp, _fp, _fp]
+        L.orc_track_project_pixel.argtypes = [_fp, _fp, C.c_float, C.c_int, C.c_int, _fp, C.POINTER(C.c_int)]
+        L.orc_pixel_correspondences.restype = C.c_size_t
+        L.orc_pixel_correspondences.argtypes = [C.POINTER(TrackLevel), _fp, _ip]
+        L.orc_track_normal_equations.argtypes = [C.POINTER(TrackLevel), _fp, _ip, C.c_size_t, C.c_int, _fp, _fp, _fp]
+        L.orc_track_accumulate_rows.argtypes = [_fp, _fp, C.c_size_t, _fp, _fp, _fp]
+        L.orc_ldlt_solve6.argtypes = [_fp, _fp, _fp]
+        L.orc_track_iteration.restype = C.c_size_t
+        L.orc_track_iteration.argtypes = [C.POINTER(TrackLevel), C.c_int, _fp, _ip]
+        L.orc_dense_track.restype = C.c_int
+        L.orc_dense_track.argtypes = [C.POINTER(TrackLevel), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                      _fp, C.POINTER(TrackResult), _ip, _ip, _fp]
         _lib = L
     return _lib
 
@@ -291,3 +317,100 @@ def icp(src, tgt, tgt_normals=None, init_T=None, max_iter=30, threshold=0.2, poi
             "rmse": float(res.rmse), "pairs": pairs[:n].copy(),
             "per_iter_inliers": per_n[:max_iter].copy(),
             "per_iter_T": per_T[:max_iter].reshape(-1, 4, 4).copy()}
+
+
+# ---- dense RGB-D tracker (Odometry/) ---------------------------------------------------------
+TRACK_IMAGES = ("source_color", "source_depth", "target_color", "target_depth", "target_color_dx",
+                "target_color_dy", "target_depth_dx", "target_depth_dy")
+
+
+def _track_levels(levels):
+    """levels: list of dicts {width,height,fx,fy,cx,cy + the 8 TRACK_IMAGES as (h,w) float32}."""
+    arr = (TrackLevel * len(levels))()
+    keep = []
+    for k, lv in enumerate(levels):
+        arr[k].width, arr[k].height = int(lv["width"]), int(lv["height"])
+        arr[k].fx, arr[k].fy, arr[k].cx, arr[k].cy = (float(lv[c]) for c in ("fx", "fy", "cx", "cy"))
+        for name in TRACK_IMAGES:
+            a = _f32(lv[name])
+            assert a.shape == (arr[k].height, arr[k].width), (name, a.shape)
+            keep.append(a)
+            setattr(arr[k], name, _p(a))
+    return arr, keep
+
+
+def mat3_inverse(m):
+    m = _f32(m).reshape(9)
+    out = np.empty(9, np.float32)
+    lib().orc_mat3_inverse(_p(m), _p(out))
+    return out.reshape(3, 3)
+
+
+def track_projection(cam4, T):
+    cam4, T = _f32(cam4).reshape(4), _f32(T).reshape(16)
+    ki, krk, kt = np.empty(9, np.float32), np.empty(9, np.float32), np.empty(3, np.float32)
+    lib().orc_track_projection(_p(cam4), _p(T), _p(ki), _p(krk), _p(kt))
+    return ki.reshape(3, 3), krk.reshape(3, 3), kt
+
+
+def track_project_pixel(krk, kt, d, j, i):
+    krk, kt = _f32(krk).reshape(9), _f32(kt).reshape(3)
+    uv = np.empty(3, np.float32)
+    ut = (C.c_int * 2)()
+    lib().orc_track_project_pixel(_p(krk), _p(kt), float(d), int(j), int(i), _p(uv), ut)
+    return uv, (int(ut[0]), int(ut[1]))
+
+
+def pixel_correspondences(level, T):
+    """ComputeCorrespondencePixelWise (DenseOdometryFunction.cpp:72-128): (n,4) {v_s,u_s,v_t,u_t}."""
+    arr, keep = _track_levels([level])
+    T = _f32(T).reshape(16)
+    corr = np.empty((arr[0].width * arr[0].height, 4), np.int32)
+    n = lib().orc_pixel_correspondences(arr, _p(T), _p(corr, _ip))
+    return corr[:n].copy()
+
+
+def track_normal_equations(level, T, corr, term=0):
+    arr, keep = _track_levels([level])
+    T = _f32(T).reshape(16)
+    corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 4)
+    JTJ, JTr, r2 = np.empty(36, np.float32), np.empty(6, np.float32), np.empty(1, np.float32)
+    lib().orc_track_normal_equations(arr, _p(T), _p(corr, _ip), len(corr), int(term), _p(JTJ), _p(JTr), _p(r2))
+    return JTJ.reshape(6, 6), JTr, float(r2[0])
+
+
+def track_accumulate_rows(J, r):
+    J, r = _f32(J).reshape(-1, 6), _f32(r).reshape(-1)
+    JTJ, JTr, r2 = np.empty(36, np.float32), np.empty(6, np.float32), np.empty(1, np.float32)
+    lib().orc_track_accumulate_rows(_p(J), _p(r), len(r), _p(JTJ), _p(JTr), _p(r2))
+    return JTJ.reshape(6, 6), JTr, r2[0]
+
+
+def ldlt_solve6(JTJ, JTr):
+    JTJ, JTr = _f32(JTJ).reshape(36), _f32(JTr).reshape(6)
+    x = np.empty(6, np.float32)
+    lib().orc_ldlt_solve6(_p(JTJ), _p(JTr), _p(x))
+    return x
+
+
+def dense_track(levels, iters=(4, 8, 16), full_w=None, full_h=None, term=0, init_T=None):
+    """Odometry::MultiScaleComputing (Odometry.cpp:621-687); levels[0] = full resolution."""
+    arr, keep = _track_levels(levels)
+    full_w = int(levels[0]["width"] if full_w is None else full_w)
+    full_h = int(levels[0]["height"] if full_h is None else full_h)
+    T0 = _f32(np.eye(4) if init_T is None else init_T).reshape(16)
+    it = (C.c_int * len(levels))(*[int(v) for v in iters])
+    total = int(sum(iters))
+    res = TrackResult()
+    cap = max(int(lv["width"]) * int(lv["height"]) for lv in levels)
+    corr = np.empty((cap, 4), np.int32)
+    per_n = np.zeros(max(total, 1), np.int32)
+    per_T = np.zeros((max(total, 1), 16), np.float32)
+    lib().orc_dense_track(arr, len(levels), it, full_w, full_h, int(term), _p(T0), C.byref(res),
+                          _p(corr, _ip), _p(per_n, _ip), _p(per_T))
+    n = int(res.n_correspondences)
+    return {"T": np.array(res.T, np.float32).reshape(4, 4), "rmse": float(res.rmse),
+            "tracking_success": bool(res.tracking_success), "iterations": int(res.iterations),
+            "pixel_correspondences": corr[:n].copy(),
+            "per_iter_count": per_n[:res.iterations].copy(),
+            "per_iter_T": per_T[:res.iterations].reshape(-1, 4, 4).copy()}

@@ -8,3 +8,6 @@ mkdir -p "$HERE/../_ref"
 g++ -std=c++11 -O3 -msse4.2 -fopenmp -w -I$R/Eigen -I$R/Sophus "$HERE/gen_eigen_golden.cpp" -o "$HERE/../_ref/gen_eigen_golden"
 "$HERE/../_ref/gen_eigen_golden" "$HERE/../../tests/golden/eigen_golden.json"
 echo "wrote tests/golden/eigen_golden.json"
+g++ -std=c++11 -O3 -msse4.2 -w -I$R/Eigen -I$R/Sophus "$HERE/gen_odometry_golden.cpp" -o "$HERE/../_ref/gen_odometry_golden"
+"$HERE/../_ref/gen_odometry_golden" "$HERE/../../tests/golden/odometry_golden.json"
+echo "wrote tests/golden/odometry_golden.json"
