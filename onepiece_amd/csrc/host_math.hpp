@@ -296,35 +296,118 @@ OP_HD void track_projection(float fx, float fy, float cx, float cy, const float 
 }
 
 // x = JTJ.ldlt().solve(-JTr) (DenseOdometryFunction.cpp:404): symmetric-pivoted LDL^T in double;
-// zero pivots give zero components (Eigen's pseudo-inverse of D).
+// zero pivots give zero components (Eigen's pseudo-inverse of D).  Every index below is a
+// compile-time constant after unrolling (the pivot swap is a chain of predicated exchanges), so on
+// the device the 6x6 system lives in registers instead of scratch memory.
+OP_HD void ldlt_swap(double& a, double& b, bool c) { const double t = a; a = c ? b : a; b = c ? t : b; }
+// Fast path for the usual case: JTJ is symmetric positive definite, where LDL^T needs no pivoting to
+// be backward stable (it is Cholesky); ~200 dependent flops in registers.  Returns false -- and the
+// caller takes the pivoted route below -- as soon as a pivot is not safely positive.
+OP_HD bool ldlt_solve6_spd(const double JTJ[36], const double JTr[6], float x[6]) {
+    double A[6][6], y[6];
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (JTJ[i * 6 + j] + JTJ[j * 6 + i]);
+        dmax = A[i][i] > dmax ? A[i][i] : dmax;
+    }
+    const double floor_ = dmax * 1e-9;
+    bool ok = dmax > 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double d = A[k][k];
+        ok = ok && d > floor_;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = A[i][k] * inv;
+#pragma unroll
+            for (int j = k + 1; j <= i; ++j) A[i][j] -= l * A[j][k];   // lower triangle only; A[j][k] still holds d*L(j,k)
+        }
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) A[i][k] *= inv;
+    }
+    if (!ok) return false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = -JTr[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s -= A[i][j] * y[j];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = y[i] / A[i][i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= A[j][i] * y[j];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = static_cast<float>(y[i]);
+    return true;
+}
+
 OP_HD void ldlt_solve6(const double JTJ[36], const double JTr[6], float x[6]) {
+    if (ldlt_solve6_spd(JTJ, JTr, x)) return;
     double A[6][6], b[6], y[6];
     int perm[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         perm[i] = i; b[i] = -JTr[i];
+#pragma unroll
         for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (JTJ[i * 6 + j] + JTJ[j * 6 + i]);
     }
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         int p = k;
-        for (int i = k + 1; i < 6; ++i) if (fabs(A[i][i]) > fabs(A[p][p])) p = i;
-        if (p != k) {
-            for (int j = 0; j < 6; ++j) { const double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
-            for (int j = 0; j < 6; ++j) { const double t = A[j][k]; A[j][k] = A[j][p]; A[j][p] = t; }
-            const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
-            const double tb = b[k]; b[k] = b[p]; b[p] = tb;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) { const double v = fabs(A[i][i]); if (v > best) { best = v; p = i; } }
+#pragma unroll
+        for (int q = k + 1; q < 6; ++q) { // exchange rows/columns k <-> q iff q is the pivot
+            const bool c = q == p;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ldlt_swap(A[k][j], A[q][j], c);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ldlt_swap(A[j][k], A[j][q], c);
+            ldlt_swap(b[k], b[q], c);
+            const int t = perm[k]; perm[k] = c ? perm[q] : perm[k]; perm[q] = c ? t : perm[q];
         }
         const double d = A[k][k];
-        if (d == 0) continue;
-        for (int i = k + 1; i < 6; ++i) {
-            const double l = A[i][k] / d;
-            for (int j = k + 1; j < 6; ++j) A[i][j] -= l * A[k][j];
-            A[i][k] = l;
+        if (d != 0) {
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) {
+                const double l = A[i][k] / d;
+#pragma unroll
+                for (int j = k + 1; j < 6; ++j) A[i][j] -= l * A[k][j];
+                A[i][k] = l;
+            }
         }
     }
-    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int j = 0; j < i; ++j) s -= A[i][j] * y[j]; y[i] = s; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s -= A[i][j] * y[j];
+        y[i] = s;
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] = A[i][i] != 0 ? y[i] / A[i][i] : 0.0;
-    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 6; ++j) s -= A[j][i] * y[j]; y[i] = s; }
-    for (int i = 0; i < 6; ++i) x[perm[i]] = static_cast<float>(y[i]);
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= A[j][i] * y[j];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (perm[i] == j) x[j] = static_cast<float>(y[i]);
 }
 
 inline uint64_t hash_key(int32_t x, int32_t y, int32_t z) { // Geometry/Geometry.h:101-112

@@ -2,8 +2,8 @@
 //
 // Replaces odometry::Odometry::MultiScaleComputing (Odometry/Odometry.cpp:621-687) and what it calls
 // (Odometry/DenseOdometryFunction.cpp): per iteration
-//     ComputeCorrespondencePixelWise (:72-128)   -> k_track_assoc + the chain walk in k_track_accum
-//     ComputeJTJandJTr{Hybrid,Photo,Depth}Term   -> k_track_accum (fp64 wave-shuffle + LDS reduction)
+//     ComputeCorrespondencePixelWise (:72-128)   -> k_track_assoc + the chain walk in k_track_iter
+//     ComputeJTJandJTr{Hybrid,Photo,Depth}Term   -> k_track_iter (fp64 wave reduce-scatter + LDS)
 //     JTJ.ldlt().solve(-JTr), Se3ToSE3, T update -> k_track_solve (one workgroup, thread 0 solves)
 // and afterwards the correspondence_set / rmse of DenseTracking (Odometry.cpp:676-683, :606) in the
 // k_emit_* kernels.  The whole coarse-to-fine loop is enqueued without a host round trip: the pose,
@@ -57,15 +57,44 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// ---- association: p(s), td(s) for every source pixel (DenseOdometryFunction.cpp:89-114) --------
-__global__ __launch_bounds__(kThreads) void k_track_assoc(const TrackState* __restrict__ st, int l, int2* __restrict__ cand) {
-    if (st->stop_level == l) return;
-    __shared__ float s_krk[9], s_kt[3];
-    const LevelDev L = st->lv[l];
-    if (threadIdx.x == 0) op_host::track_projection(L.fx, L.fy, L.cx, L.cy, st->T, s_krk, s_kt);
-    __syncthreads();
-    const int npix = L.w * L.h, s = blockIdx.x * kThreads + threadIdx.x;
-    if (s >= npix) return;
+// Wave-wide sums of 32 doubles per lane by recursive halving ("reduce-scatter"): at the step with
+// lane mask m a lane keeps one half of its values and receives the partner's copy of that half, so
+// the work halves every step (16+8+4+2+1+1 = 32 fp64 adds per lane instead of 32 x 6).  On return
+// lane L holds in v[0] the wave total of element (L >> 1) & 31.
+template <int H, int M>
+__device__ __forceinline__ void wave_halve(double (&v)[32], int lane) {
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const double keep = up ? v[i + H] : v[i];
+        const double give = up ? v[i] : v[i + H];
+        v[i] = keep + __shfl_xor(give, M, 64);
+    }
+}
+__device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+    wave_halve<16, 32>(v, lane);
+    wave_halve<8, 16>(v, lane);
+    wave_halve<4, 8>(v, lane);
+    wave_halve<2, 4>(v, lane);
+    wave_halve<1, 2>(v, lane);
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
+
+// ---- association (DenseOdometryFunction.cpp:89-114) + the acceptance link of every pixel ---------
+// ok(s), p(s), td(s) as the reference computes them; then, because acc(s) only needs acc(p(s)) when
+// p(s) < s, ok(p(s)) and td(p(s)) <= td(s), the thread ALSO evaluates the association of pixel p(s)
+// itself (no inter-thread dependency) and stores a 16-bit link code:
+//   kInvalid   not ok(s)                     (never the target of a link)
+//   kTerminal  accepted without recursion
+//   kFar       depends on p(s) but s - p(s) does not fit 16 bits (consult pair_p)
+//   d + 3      depends on pixel s - d        (acc(s) = !acc(s - d))
+constexpr unsigned short kInvalid = 0, kTerminal = 1, kFar = 2;
+constexpr int kLinkBias = 3;
+
+struct Proj { float krk[9], kt[3]; };
+
+__device__ __forceinline__ int2 associate(const LevelDev& L, const Proj& P, int s) {
     const int i = s / L.w, j = s - i * L.w;
     const float d_s = L.sd[s];
     int p = -1;
@@ -73,9 +102,9 @@ __global__ __launch_bounds__(kThreads) void k_track_assoc(const TrackState* __re
     if (!isnan(d_s)) {
         const float fj = (float)j, fi = (float)i;
         // d_s * KRK_inv * Point3(j,i,1.0) + Kt: Eigen evaluates (d_s*KRK_inv) first, rows as a0+(a1+a2)
-        const float uv0 = sum3((d_s * s_krk[0]) * fj, (d_s * s_krk[1]) * fi, (d_s * s_krk[2]) * 1.0f) + s_kt[0];
-        const float uv1 = sum3((d_s * s_krk[3]) * fj, (d_s * s_krk[4]) * fi, (d_s * s_krk[5]) * 1.0f) + s_kt[1];
-        td = sum3((d_s * s_krk[6]) * fj, (d_s * s_krk[7]) * fi, (d_s * s_krk[8]) * 1.0f) + s_kt[2];
+        const float uv0 = sum3((d_s * P.krk[0]) * fj, (d_s * P.krk[1]) * fi, (d_s * P.krk[2]) * 1.0f) + P.kt[0];
+        const float uv1 = sum3((d_s * P.krk[3]) * fj, (d_s * P.krk[4]) * fi, (d_s * P.krk[5]) * 1.0f) + P.kt[1];
+        td = sum3((d_s * P.krk[6]) * fj, (d_s * P.krk[7]) * fi, (d_s * P.krk[8]) * 1.0f) + P.kt[2];
         // (int)(x / z + 0.5): float quotient, double sum, truncation toward zero (so (-1,0) -> 0)
         const double ax = (double)(uv0 / td) + 0.5, ay = (double)(uv1 / td) + 0.5;
         if (ax > -1.0 && ax < (double)L.w && ay > -1.0 && ay < (double)L.h) { // NaN fails
@@ -86,43 +115,107 @@ __global__ __launch_bounds__(kThreads) void k_track_assoc(const TrackState* __re
             if (!isnan(d_t) && fabsf(d_t - td) < 0.05f && td != -1.0f) p = v_t * L.w + u_t;
         }
     }
-    cand[s] = make_int2(p, __float_as_int(td));
+    return make_int2(p, __float_as_int(td));
 }
 
-// ---- acceptance + Jacobian rows + normal-equation partials ------------------------------------
-template <int TERM>
-__global__ __launch_bounds__(kThreads) void k_track_accum(const TrackState* __restrict__ st, int l, const int2* __restrict__ cand,
-                                                          unsigned char* __restrict__ accf, double* __restrict__ partials) {
+__global__ __launch_bounds__(kThreads) void k_track_assoc(const TrackState* __restrict__ st, int l, int* __restrict__ pair_p,
+                                                          unsigned short* __restrict__ code) {
     if (st->stop_level == l) return;
-    __shared__ double s_red[kThreads / 64][kNSums];
+    __shared__ Proj s_P;
+    const LevelDev L = st->lv[l];
+    if (threadIdx.x == 0) op_host::track_projection(L.fx, L.fy, L.cx, L.cy, st->T, s_P.krk, s_P.kt);
+    __syncthreads();
+    const Proj P = s_P;
+    const int npix = L.w * L.h, s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= npix) return;
+    const int2 c = associate(L, P, s);
+    unsigned short cd = kInvalid;
+    if (c.x >= 0) {
+        cd = kTerminal;
+        if (c.x < s) {
+            const int2 c2 = associate(L, P, c.x);
+            // wraping_depth(p) is set (!= -1) iff p was accepted; if it is, accept s only when it is nearer
+            if (c2.x >= 0 && !(__int_as_float(c2.y) > __int_as_float(c.y)))
+                cd = (s - c.x) + kLinkBias <= 0xffff ? (unsigned short)((s - c.x) + kLinkBias) : kFar;
+        }
+    }
+    pair_p[s] = c.x;
+    code[s] = cd;
+}
+
+// ---- acceptance (parity of the link chain) + Jacobian rows + normal-equation partials ----------
+// Chains are 40-150 links long on real motion and run backwards in raster order, so each workgroup
+// first stages the link codes of a window ending at its last own pixel in LDS (the whole level when
+// it fits: 2 bytes per pixel, up to ~150 KB of the 160 KB LDS) and walks there (~50 ns per link
+// instead of ~1 us per dependent L2/HBM gather).  Links that leave the window fall back to global.
+constexpr int kIterThreads = 1024;
+
+template <int TERM>
+__global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* __restrict__ st, int l, int win_cap,
+                                                             const int* __restrict__ pair_p, const unsigned short* __restrict__ code,
+                                                             int* __restrict__ pair_t, double* __restrict__ partials) {
+    if (st->stop_level == l) return;
+    extern __shared__ unsigned short s_code[];
+    __shared__ double s_red[kIterThreads / 64][kNSums];
     __shared__ float s_T[12];
     const LevelDev L = st->lv[l];
     if (threadIdx.x < 12) s_T[threadIdx.x] = st->T[threadIdx.x];
-    __syncthreads();
-    const int npix = L.w * L.h, s = blockIdx.x * kThreads + threadIdx.x;
-    double acc[29];
+    const int npix = L.w * L.h;
+    const int own0 = blockIdx.x * kIterThreads, own1 = min(own0 + kIterThreads, npix); // one own pixel per thread
+    const int win0 = max(0, own1 - win_cap) & ~7;              // 16-byte aligned window start
+    {   // stage the window, 8 codes (16 B) per load; links that point before the window become kFar
+        const int n8 = (own1 - win0 + 7) >> 3;
+        const uint4* src = reinterpret_cast<const uint4*>(code + win0);
+        uint4* dst = reinterpret_cast<uint4*>(s_code);
+        for (int k = threadIdx.x; k < n8; k += kIterThreads) {
+            uint4 v = src[k];
+            if (win0 > 0 && k < 8192) {                        // only the first 65535 entries can point outside
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 29; ++k) acc[k] = 0.0;
-    bool accepted = false;
-    int2 c = make_int2(-1, 0);
-    if (s < npix) c = cand[s];
-    if (c.x >= 0) {
-        // walk the chain of undecided links; acc(s) = (number of undecided links is even)
-        int cur = s, p = c.x, parity = 0;
-        float tdc = __int_as_float(c.y);
-        while (p < cur) {
-            const int2 c2 = cand[p];
-            if (c2.x < 0) break;                              // p holds no depth ("-1") -> accept
-            const float tdp = __int_as_float(c2.y);
-            if (tdp > tdc) break;                             // existing_depth > transformed_d_s -> accept
-            parity ^= 1;                                      // depends on acc(p): acc(cur) = !acc(p)
-            cur = p; p = c2.x; tdc = tdp;
+                for (int q = 0; q < 4; ++q) {
+                    unsigned lo = w[q] & 0xffffu, hi = w[q] >> 16;
+                    const int e = k * 8 + q * 2;
+                    if ((int)lo - kLinkBias > e) lo = kFar;
+                    if ((int)hi - kLinkBias > e + 1) hi = kFar;
+                    w[q] = lo | (hi << 16);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            dst[k] = v;
         }
-        accepted = parity == 0;
     }
-    if (s < npix) accf[s] = accepted ? 1 : 0;
+    __syncthreads();
+
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    const int s = own0 + threadIdx.x;
+    bool accepted = false;
+    if (s < own1) {
+        int cur = s - win0, parity = 0;
+        unsigned cd = s_code[cur];
+        if (cd != kInvalid) {
+            while (cd > kFar) {                                // acc(cur) = !acc(cur - d): LDS-only loop
+                cur -= (int)cd - kLinkBias;
+                parity ^= 1;
+                cd = s_code[cur];
+            }
+            if (cd == kFar) {                                  // the chain leaves the window: finish in global memory
+                int g = cur + win0;
+                unsigned c = kFar;
+                while (c != kTerminal) {
+                    g = c == kFar ? pair_p[g] : g - ((int)c - kLinkBias);
+                    parity ^= 1;
+                    c = code[g];
+                }
+            }
+            accepted = parity == 0;
+        }
+        pair_t[s] = accepted ? pair_p[s] : -1;
+    }
     if (accepted) {
-        const int i = s / L.w, j = s - i * L.w, t = c.x;
+        const int t = pair_p[s];
+        const int i = s / L.w, j = s - i * L.w;
         // source_XYZ[v_s][u_s] (Geometry.cpp:84-100)
         const float z = L.sd[s];
         float p0 = -1.0f, p1 = -1.0f, p2 = -1.0f;
@@ -173,27 +266,22 @@ __global__ __launch_bounds__(kThreads) void k_track_accum(const TrackState* __re
         acc[28] = 1.0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 29; ++k) {
-        const double v = wave_sum_d(acc[k]);
-        if (lane == 0) s_red[wave][k] = v;
-    }
+    wave_reduce_scatter32(acc);
+    if ((lane & 1) == 0) s_red[wave][lane >> 1] = acc[0];
     __syncthreads();
     if (threadIdx.x < kNSums) {
         double v = 0;
-        if (threadIdx.x < 29)
-            for (int w = 0; w < kThreads / 64; ++w) v += s_red[w][threadIdx.x];
+        for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
         partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
     }
 }
 
 // ---- second reduction pass + solve + pose update (DenseOdometryFunction.cpp:404-413) ------------
-__global__ __launch_bounds__(1024) void k_track_solve(TrackState* __restrict__ st, int l, int it, const double* __restrict__ partials) {
+__global__ __launch_bounds__(1024) void k_track_solve(TrackState* __restrict__ st, int l, int it, const double* __restrict__ partials,
+                                                      int n_partials) {
     if (st->stop_level == l) return;
     __shared__ double s[32][kNSums];
     __shared__ double tot[kNSums];
-    const LevelDev& L = st->lv[l];
-    const int n_partials = (L.w * L.h + kThreads - 1) / kThreads;
     const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     int p = grp;
@@ -237,13 +325,13 @@ __global__ __launch_bounds__(1024) void k_track_solve(TrackState* __restrict__ s
 
 // ---- correspondence_set / pixel_correspondence_set / rmse (Odometry.cpp:676-687, :606) ---------
 // Ordered (raster) compaction of the last executed iteration's accepted pixels.
-__global__ __launch_bounds__(kThreads) void k_emit_count(const TrackState* __restrict__ st, const unsigned char* __restrict__ accf,
+__global__ __launch_bounds__(kThreads) void k_emit_count(const TrackState* __restrict__ st, const int* __restrict__ pair_t,
                                                          unsigned* __restrict__ wg_count) {
     __shared__ unsigned s_c[kThreads / 64];
     const int ll = st->last_level;
     const int npix = ll < 0 ? 0 : st->lv[ll].w * st->lv[ll].h;
     const int s = blockIdx.x * kThreads + threadIdx.x;
-    const bool a = s < npix && accf[s];
+    const bool a = s < npix && pair_t[s] >= 0;
     const unsigned long long m = __ballot(a);
     if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = (unsigned)__popcll(m);
     __syncthreads();
@@ -270,8 +358,8 @@ __global__ __launch_bounds__(1024) void k_emit_scan(TrackState* __restrict__ st,
     if (threadIdx.x == 1023) st->n_emit = s_part[1023];
 }
 
-__global__ __launch_bounds__(kThreads) void k_emit_scatter(const TrackState* __restrict__ st, const int2* __restrict__ cand,
-                                                           const unsigned char* __restrict__ accf, const unsigned* __restrict__ wg_off,
+__global__ __launch_bounds__(kThreads) void k_emit_scatter(const TrackState* __restrict__ st, const int* __restrict__ pair_t,
+                                                           const unsigned* __restrict__ wg_off,
                                                            int4* __restrict__ pix_out, float* __restrict__ pts_out,
                                                            double* __restrict__ partials) {
     __shared__ unsigned s_c[kThreads / 64];
@@ -279,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_scatter(const TrackState* __r
     const int ll = st->last_level;
     const int npix = ll < 0 ? 0 : st->lv[ll].w * st->lv[ll].h;
     const int s = blockIdx.x * kThreads + threadIdx.x;
-    const bool a = s < npix && accf[s];
+    const bool a = s < npix && pair_t[s] >= 0;
     const unsigned long long m = __ballot(a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) s_c[wave] = (unsigned)__popcll(m);
@@ -289,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_scatter(const TrackState* __r
         unsigned idx = wg_off[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; ++w) idx += s_c[w];
         const int W = st->lv[ll].w;
-        const int v_s = s / W, u_s = s - v_s * W, t = cand[s].x;
+        const int v_s = s / W, u_s = s - v_s * W, t = pair_t[s];
         pix_out[idx] = make_int4(v_s, u_s, t / W, t - (t / W) * W);
         // source / target image_xyz of LEVEL 0, both at the SOURCE pixel (Odometry.cpp:676-683)
         const LevelDev& L0 = st->lv[0];
@@ -340,8 +428,11 @@ struct op_tracker {
     TrackState* st = nullptr;        // device
     TrackState* st_host = nullptr;   // pinned
     size_t pix_cap = 0;              // workspace capacity in pixels
-    int2* cand = nullptr;
-    unsigned char* accf = nullptr;
+    int* pair_p = nullptr;           // per source pixel: candidate target pixel index p(s) or -1
+    int* pair_t = nullptr;           // per source pixel: accepted target pixel index or -1
+    unsigned short* code = nullptr;  // per source pixel: acceptance link code
+    int lds_cap = 0;                 // dynamic LDS bytes available to one k_track_iter workgroup
+    int lds_total = 0, lds_static = 0, n_cu = 256;
     double* partials = nullptr;
     unsigned* wg_count = nullptr;
     int4* pix_out = nullptr;
@@ -354,12 +445,13 @@ namespace {
 
 int tracker_reserve(op_tracker* t, size_t npix, size_t image_floats) {
     if (npix > t->pix_cap) {
-        (void)hipFree(t->cand); (void)hipFree(t->accf); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
-        t->cand = nullptr; t->accf = nullptr; t->partials = nullptr; t->wg_count = nullptr; t->pix_out = nullptr; t->pts_out = nullptr;
+        (void)hipFree(t->pair_t); (void)hipFree(t->pair_p); (void)hipFree(t->code); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
+        t->pair_t = nullptr; t->pair_p = nullptr; t->code = nullptr; t->partials = nullptr; t->wg_count = nullptr; t->pix_out = nullptr; t->pts_out = nullptr;
         t->pix_cap = 0;
         const size_t n_wg = (npix + kThreads - 1) / kThreads;
-        OP_HIP(hipMalloc(&t->cand, npix * sizeof(int2)));
-        OP_HIP(hipMalloc(&t->accf, npix));
+        OP_HIP(hipMalloc(&t->pair_t, npix * sizeof(int)));
+        OP_HIP(hipMalloc(&t->pair_p, npix * sizeof(int)));
+        OP_HIP(hipMalloc(&t->code, (npix + 16) * sizeof(unsigned short))); // window staging reads whole 16 B groups
         OP_HIP(hipMalloc(&t->partials, n_wg * kNSums * sizeof(double)));
         OP_HIP(hipMalloc(&t->wg_count, n_wg * sizeof(unsigned)));
         OP_HIP(hipMalloc(&t->pix_out, npix * sizeof(int4)));
@@ -375,9 +467,26 @@ int tracker_reserve(op_tracker* t, size_t npix, size_t image_floats) {
     return OP_OK;
 }
 
+// Per-level launch geometry of k_track_iter: one own pixel per thread; the LDS window is the whole
+// level when that fits, and at most half of the LDS when there are more workgroups than CUs (so two
+// workgroups share a CU and every workgroup of the level is resident at once).
+struct IterGeom { int n_wg, win_cap; size_t lds_bytes; };
+IterGeom iter_geom(const op_tracker* t, size_t npix) {
+    IterGeom g;
+    g.n_wg = (int)((npix + kIterThreads - 1) / kIterThreads);
+    const size_t want = (npix + 8) * sizeof(unsigned short);  // the whole level (+ alignment slack)
+    size_t cap = (size_t)t->lds_cap;
+    if (g.n_wg > t->n_cu) cap = ((size_t)t->lds_total / 2 - (size_t)t->lds_static) & ~(size_t)255;
+    g.lds_bytes = (((want < cap ? want : cap)) + 15) & ~(size_t)15;
+    if (g.lds_bytes > cap) g.lds_bytes = cap & ~(size_t)15;
+    g.win_cap = (int)(g.lds_bytes / sizeof(unsigned short)) - 8; // the window start is rounded down to 8 entries
+    return g;
+}
+
 template <int TERM>
-void launch_accum(op_tracker* t, int l, int n_wg) {
-    hipLaunchKernelGGL(k_track_accum<TERM>, dim3(n_wg), dim3(kThreads), 0, t->stream, t->st, l, t->cand, t->accf, t->partials);
+void launch_iter(op_tracker* t, int l, const IterGeom& g) {
+    hipLaunchKernelGGL(k_track_iter<TERM>, dim3(g.n_wg), dim3(kIterThreads), g.lds_bytes, t->stream, t->st, l, g.win_cap,
+                       t->pair_p, t->code, t->pair_t, t->partials);
 }
 
 } // namespace
@@ -395,6 +504,17 @@ int op_tracker_create(int device, op_tracker** out) {
         op_tracker_destroy(t);
         return fail(OP_ERR_HIP, "op_tracker_create: allocating tracker state failed");
     }
+    // k_track_iter stages link codes in as much LDS as a workgroup may have (160 KB on gfx950)
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds_max < 32768) lds_max = 65536;
+    const int lds_static = (int)(sizeof(double) * (kIterThreads / 64) * kNSums + 64) + 256;
+    t->lds_total = lds_max; t->lds_static = lds_static;
+    t->lds_cap = lds_max - lds_static;
+    if (hipDeviceGetAttribute(&t->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || t->n_cu <= 0) t->n_cu = 256;
+    bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<1>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<2>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess;
+    if (!attr_ok) { (void)hipGetLastError(); t->lds_total = 65536; t->lds_cap = 65536 - lds_static; }
     *out = t;
     return OP_OK;
 }
@@ -403,7 +523,7 @@ int op_tracker_destroy(op_tracker* t) {
     if (!t) return OP_OK;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
-    (void)hipFree(t->cand); (void)hipFree(t->accf); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
+    (void)hipFree(t->pair_t); (void)hipFree(t->pair_p); (void)hipFree(t->code); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
     (void)hipFree(t->images); (void)hipFree(t->st);
     if (t->st_host) (void)hipHostFree(t->st_host);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -466,19 +586,21 @@ int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, 
 
     int it = 0;
     for (int l = n_levels - 1; l >= 0; --l) {
-        const int n_wg = (int)(((size_t)levels[l].width * levels[l].height + kThreads - 1) / kThreads);
+        const size_t np = (size_t)levels[l].width * levels[l].height;
+        const int n_wg_a = (int)((np + kThreads - 1) / kThreads);
+        const IterGeom g = iter_geom(t, np);
         for (int j = 0; j < iters_per_level[l]; ++j, ++it) {
-            hipLaunchKernelGGL(k_track_assoc, dim3(n_wg), dim3(kThreads), 0, t->stream, t->st, l, t->cand);
-            if (term_type == 0) launch_accum<0>(t, l, n_wg);
-            else if (term_type == 1) launch_accum<1>(t, l, n_wg);
-            else launch_accum<2>(t, l, n_wg);
-            hipLaunchKernelGGL(k_track_solve, dim3(1), dim3(1024), 0, t->stream, t->st, l, it, t->partials);
+            hipLaunchKernelGGL(k_track_assoc, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, t->pair_p, t->code);
+            if (term_type == 0) launch_iter<0>(t, l, g);
+            else if (term_type == 1) launch_iter<1>(t, l, g);
+            else launch_iter<2>(t, l, g);
+            hipLaunchKernelGGL(k_track_solve, dim3(1), dim3(1024), 0, t->stream, t->st, l, it, t->partials, g.n_wg);
         }
     }
     const int n_wg_max = (int)((max_pix + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(k_emit_count, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->accf, t->wg_count);
+    hipLaunchKernelGGL(k_emit_count, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->pair_t, t->wg_count);
     hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg_max);
-    hipLaunchKernelGGL(k_emit_scatter, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->cand, t->accf, t->wg_count, t->pix_out,
+    hipLaunchKernelGGL(k_emit_scatter, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->pair_t, t->wg_count, t->pix_out,
                        point_corr ? t->pts_out : nullptr, t->partials);
     hipLaunchKernelGGL(k_emit_finish, dim3(1), dim3(1024), 0, t->stream, t->st, t->partials, n_wg_max);
     OP_HIP(hipGetLastError());
@@ -508,8 +630,8 @@ int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, 
 int op_tracker_correspondences(op_tracker* t, const op_track_level* level, const float T[16], int mem, int32_t* pixel_corr,
                                size_t corr_cap, size_t* n) {
     if (!t || !level || !T || !n) return fail(OP_ERR_INVALID, "op_tracker_correspondences: NULL argument");
-    // ComputeCorrespondencePixelWise alone == one level with zero iterations... the acceptance pass
-    // lives in k_track_accum, so run exactly one iteration on a scratch pose and emit its pairs.
+    // The acceptance pass lives in k_track_iter, so run exactly one iteration of one level (its pose
+    // update is discarded) and emit that iteration's pairs.
     op_track_result res;
     const int32_t iters[1] = {1};
     OP_TRY(op_tracker_track(t, level, 1, iters, level->width, level->height, OP_TRACK_DEPTH, T, mem, &res, pixel_corr, nullptr,

@@ -154,3 +154,36 @@ def test_pixel_rounding_fast_path_equals_double_formula(hip):
         assert np.array_equal(got, ref[:4000])
     assert lib.op_debug_project_px(float("nan"), 318.771, 1) == -2**31 == lib.op_debug_project_px(float("nan"), 318.771, 0)
     assert lib.op_debug_project_px(-0.6, 0.0, 1) == 0 == lib.op_debug_project_px(-0.6, 0.0, 0)   # (-1,0) truncates to 0
+
+
+def test_tracker_host_math_matches_eigen_golden(hip):
+    """op_track_projection (K*R*K^-1, K*t) bit-exact and op_ldlt_solve6 within float rounding of Eigen's
+    ldlt().solve() -- the host/device-shared arithmetic of csrc/odometry.hip, checked without a GPU."""
+    lib = hip.load()
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "odometry_golden.json")))
+    f = lambda b: np.array(b, np.uint32).view(np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for c in g["projective"]:
+        cam, T = f(c["cam"]).copy(), f(c["T"]).copy()
+        krk, kt = np.empty(9, np.float32), np.empty(3, np.float32)
+        assert lib.op_track_projection(fp(cam), fp(T), fp(krk), fp(kt)) == 0
+        assert np.array_equal(krk.view(np.uint32), np.array(c["KRK_inv"], np.uint32))
+        assert np.array_equal(kt.view(np.uint32), np.array(c["Kt"], np.uint32))
+    for c in g["gauss_newton"]:
+        JTJ, JTr = f(c["JTJ"]).astype(np.float64), f(c["JTr"]).astype(np.float64)
+        x, xr = np.empty(6, np.float32), f(c["delta"])
+        assert lib.op_ldlt_solve6(dp(JTJ), dp(JTr), fp(x)) == 0
+        assert np.linalg.norm(x - xr) <= 1e-5 * np.linalg.norm(xr) + 1e-7
+    # singular system: zero pivots -> zero components (Eigen's pseudo-inverse of D)
+    x = np.ones(6, np.float32)
+    assert lib.op_ldlt_solve6(dp(np.zeros(36)), dp(np.zeros(6)), fp(x)) == 0 and not x.any()
+
+
+def test_tracker_refuses_without_gpu(hip):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert hip.load().op_tracker_create(0, C.byref(h)) == hip.OP_ERR_NO_DEVICE  # no CPU fallback
+    assert b"no CPU fallback" in hip.load().op_last_error()

@@ -1,0 +1,46 @@
+"""Dense-tracker timing: tracks/s at 640x480, 3 levels {4,8,16}, hybrid term, pyramids resident in HBM.
+Also used under rocprofv3 --kernel-trace --stats (tools/profile_track.sh)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import ctypes as C
+import numpy as np
+import torch
+from onepiece_amd import odometry as O, integration as I, _lib as L
+from helpers import track_levels
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+lib = L.load()
+odo = O.Odometry(I.PinholeCamera("OPEN3D_DATASET"))
+for (i, j, term, name) in [(300, 301, 0, "hybrid 300->301"), (100, 102, 0, "hybrid 100->102"), (300, 301, 2, "depth 300->301")]:
+    levels, T_true = track_levels(i, j, holes=True, scale=1)
+    dev = []
+    for lv in levels:
+        d = dict(lv)
+        for k in O.TRACK_IMAGES:
+            d[k] = torch.from_numpy(np.ascontiguousarray(lv[k])).cuda()
+        dev.append(d)
+    arr, mem, keep = O._levels_arg(dev)
+    iters = np.array([4, 8, 16], np.int32)
+    T0 = np.eye(4, dtype=np.float32).reshape(16)
+    res = L.TrackResult()
+    call = lambda: L.check(lib.op_tracker_track(odo._h, arr, 3, iters.ctypes.data_as(L._ip), 640, 480, term, T0.ctypes.data_as(L._fp),
+                                                mem, C.byref(res), None, None, 0, None, None))
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        call()
+    dt = time.perf_counter() - t
+    print("%-18s device pyramids: %.1f tracks/s  %.3f ms/track  iterations %d  n %d" % (name, reps / dt, dt / reps * 1e3, res.iterations, res.n_correspondences))
+    # host pyramids (PCIe-inclusive)
+    arr_h, mem_h, keep_h = O._levels_arg(levels)
+    call_h = lambda: L.check(lib.op_tracker_track(odo._h, arr_h, 3, iters.ctypes.data_as(L._ip), 640, 480, term, T0.ctypes.data_as(L._fp),
+                                                  mem_h, C.byref(res), None, None, 0, None, None))
+    call_h()
+    t = time.perf_counter()
+    for _ in range(max(reps // 10, 5)):
+        call_h()
+    dt = time.perf_counter() - t
+    print("%-18s host pyramids  : %.1f tracks/s  %.3f ms/track" % (name, max(reps // 10, 5) / dt, dt / max(reps // 10, 5) * 1e3))
