@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=40, help="frames of the workload the CPU baseline fuses (~0.25 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-icp", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--profile-every", type=int, default=1, help="HIP-event sample rate for the roofline (every k-th launch group)")
     args = ap.parse_args()
 
@@ -263,6 +264,58 @@ def main():
                 "note": "RegistrationResult::T is a Kabsch fit whose sums the reference accumulates sequentially in float32 over ~3e5 "
                         "near-planar pairs (Geometry.cpp:117-133); that rounding noise, not the GPU, is what returned_T_rel_err_vs_cpu shows"}
             out["icp"]["note"] = "cpu oracle (kd-tree NN, OpenMP over %d threads) timed on the same clouds" % os.cpu_count()
+
+    # ---- dense RGB-D tracking (Odometry::DenseTracking's coarse-to-fine loop); rank 0 reports
+    if rank == 0 and not args.no_tracking:
+        import ctypes as C
+        from onepiece_amd import odometry as OD, _lib as L
+        lib = L.load()
+        odo = OD.Odometry(hv.camera, device=local_rank)
+        # frame 1 -> frame 0 of this rank's shard; image preparation (numpy stand-in for the reference's
+        # OpenCV stage) is outside the timed region: the tracker's boundary is MultiScaleComputing's inputs
+        sg, sd = odo.InitializeRGBDDenseTracking(rgb[1].cpu().numpy(), depth[1].cpu().numpy())
+        tg, td = odo.InitializeRGBDDenseTracking(rgb[0].cpu().numpy(), depth[0].cpu().numpy())
+        levels = odo.BuildLevels(sg, sd, tg, td)
+        dev_levels = []
+        for lv in levels:
+            d = dict(lv)
+            for k in OD.TRACK_IMAGES:
+                d[k] = torch.from_numpy(np.ascontiguousarray(lv[k])).to(dev)
+            dev_levels.append(d)
+        arr, mem, _keep = OD._levels_arg(dev_levels)
+        it3 = np.array(odo.iter_count_per_level, np.int32)
+        T0 = np.eye(4, dtype=np.float32).reshape(16)
+        tres = L.TrackResult()
+        run = lambda: L.check(lib.op_tracker_track(odo._h, arr, 3, it3.ctypes.data_as(L._ip), W, H, 0, T0.ctypes.data_as(L._fp), mem,
+                                                   C.byref(tres), None, None, 0, None, None))
+        for _ in range(5):
+            run()
+        n_tr = 100
+        t = time.perf_counter()
+        for _ in range(n_tr):
+            run()
+        tr_s = n_tr / (time.perf_counter() - t)
+        out["tracking"] = {"tracks_per_s": tr_s, "ms_per_track": 1e3 / tr_s, "levels": 3, "iters_per_level": [4, 8, 16],
+                           "iterations_executed": int(tres.iterations), "term": "hybrid", "resolution": [W, H],
+                           "correspondences": int(tres.n_correspondences), "tracking_success": bool(tres.tracking_success),
+                           "input": "pyramids resident in HBM (boundary = Odometry::MultiScaleComputing inputs)"}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            O.dense_track(levels, (4, 8, 16), term=0)
+            t = time.perf_counter()
+            for _ in range(5):
+                ref = O.dense_track(levels, (4, 8, 16), term=0)
+            out["cpu_baseline"]["tracks_per_s"] = 5 / (time.perf_counter() - t)
+            O.lib().orc_set_accumulate_double(1)
+            ref_d = O.dense_track(levels, (4, 8, 16), term=0)
+            O.lib().orc_set_accumulate_double(0)
+            rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+            g = np.array(tres.T, np.float64).reshape(4, 4)
+            out["tracking"]["parity"] = {"pose_rel_err_vs_cpu": rel(g, ref["T"]), "pose_rel_err_vs_cpu_double_sums": rel(g, ref_d["T"]),
+                                         "cpu_float_vs_double_sums": rel(ref["T"], ref_d["T"]),
+                                         "iterations": {"gpu": int(tres.iterations), "cpu": int(ref["iterations"])},
+                                         "correspondences": {"gpu": int(tres.n_correspondences), "cpu": int(len(ref["pixel_correspondences"]))}}
+        del odo
 
     if rank == 0:
         print(json.dumps(out))
