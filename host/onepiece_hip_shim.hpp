@@ -5,7 +5,8 @@
 // tests of this repository, against small look-alike types (tests/cpp/shim_check.cpp).
 //
 // INTEGRATION.md shows where each helper is called from inside the reference's
-// CubeHandler (src/Integration/CubeHandler.{h,cpp}) and ICP (src/Registration/ICP.cpp).
+// CubeHandler (src/Integration/CubeHandler.{h,cpp}), ICP (src/Registration/ICP.cpp) and the dense
+// tracker (src/Odometry/Odometry.cpp).
 //
 // Type requirements (all satisfied by the reference's types):
 //   Mat4    : float operator()(int row, int col)                    geometry::TransformationMatrix
@@ -137,6 +138,54 @@ inline int RunICP(int mode, const Point3List& source, const Point3List& target, 
         result.correspondence_set_index.push_back(std::make_pair((int)pairs[2 * k], (int)pairs[2 * k + 1]));
         result.correspondence_set.push_back(std::make_pair(source[pairs[2 * k]], target[pairs[2 * k + 1]]));
     }
+    return OP_OK;
+}
+
+// Odometry::MultiScaleComputing (Odometry.cpp:621-687): the eight pyramids + the camera pyramid in,
+// pose / pixel pairs / point pairs out.  FloatImage: .ptr<float>() (cv::Mat CV_32FC1, continuous);
+// Camera: GetWidth/GetHeight/GetFx/GetFy/GetCx/GetCy (camera::PinholeCamera).  PixelPairs:
+// vector<pair<Point2ui,Point2ui>> with Point2ui(unsigned,unsigned); PointPairs:
+// vector<pair<Point3,Point3>>.  Returns the status; *success = the reference's return value.
+template <class Point2ui, class Point3, class FloatImage, class Camera, class Mat4, class PixelPairs, class PointPairs>
+inline int MultiScaleComputing(op_tracker* tracker, const std::vector<FloatImage>& source_color, const std::vector<FloatImage>& target_color,
+                               const std::vector<FloatImage>& source_depth, const std::vector<FloatImage>& target_depth,
+                               const std::vector<FloatImage>& target_depth_dx, const std::vector<FloatImage>& target_depth_dy,
+                               const std::vector<FloatImage>& target_color_dx, const std::vector<FloatImage>& target_color_dy,
+                               const std::vector<Camera>& camera_pyramid, const std::vector<int>& iter_count_per_level, int term_type, Mat4& T,
+                               PointPairs& correspondence_set, PixelPairs& pixel_correspondence_set, bool* success, double* rmse = nullptr) {
+    const int n = (int)camera_pyramid.size();
+    std::vector<op_track_level> lv(n);
+    for (int i = 0; i < n; ++i) {
+        const Camera& c = camera_pyramid[i];
+        lv[i].width = (int32_t)c.GetWidth(); lv[i].height = (int32_t)c.GetHeight();
+        lv[i].fx = c.GetFx(); lv[i].fy = c.GetFy(); lv[i].cx = c.GetCx(); lv[i].cy = c.GetCy();
+        lv[i].source_color = source_color[i].template ptr<float>(); lv[i].source_depth = source_depth[i].template ptr<float>();
+        lv[i].target_color = target_color[i].template ptr<float>(); lv[i].target_depth = target_depth[i].template ptr<float>();
+        lv[i].target_color_dx = target_color_dx[i].template ptr<float>(); lv[i].target_color_dy = target_color_dy[i].template ptr<float>();
+        lv[i].target_depth_dx = target_depth_dx[i].template ptr<float>(); lv[i].target_depth_dy = target_depth_dy[i].template ptr<float>();
+    }
+    const int W = n ? lv[0].width : 0, H = n ? lv[0].height : 0;
+    float T0[16];
+    RowMajor(T, T0);
+    std::vector<int32_t> iters(iter_count_per_level.begin(), iter_count_per_level.end());
+    iters.resize(n, 4); // SetMultiScale pads with 4 (Odometry.h:100-104)
+    std::vector<int32_t> pix(4 * (size_t)W * H + 4);
+    std::vector<float> pts(6 * (size_t)W * H + 6);
+    op_track_result r;
+    const int rc = op_tracker_track(tracker, lv.data(), n, iters.data(), W, H, term_type, T0, OP_MEM_HOST, &r, pix.data(), pts.data(),
+                                    (size_t)W * H, nullptr, nullptr);
+    if (rc != OP_OK) return rc;
+    FromRowMajor(r.T, T);
+    correspondence_set.clear();
+    pixel_correspondence_set.clear();
+    for (uint64_t k = 0; k < r.n_correspondences; ++k) {
+        pixel_correspondence_set.push_back(std::make_pair(Point2ui((unsigned)pix[4 * k], (unsigned)pix[4 * k + 1]),
+                                                          Point2ui((unsigned)pix[4 * k + 2], (unsigned)pix[4 * k + 3])));
+        correspondence_set.push_back(std::make_pair(Point3(pts[6 * k], pts[6 * k + 1], pts[6 * k + 2]),
+                                                    Point3(pts[6 * k + 3], pts[6 * k + 4], pts[6 * k + 5])));
+    }
+    if (success) *success = r.tracking_success != 0;
+    if (rmse) *rmse = r.rmse;
     return OP_OK;
 }
 

@@ -51,6 +51,16 @@ struct Cube {
     explicit Cube(const Vec3i& id) : voxels(512), cube_id(id) {}
 };
 typedef std::unordered_map<Vec3i, Cube, Hasher> Map;
+struct FloatMat { // cv::Mat CV_32FC1 look-alike
+    std::vector<float> buf;
+    template <class T> const T* ptr() const { return reinterpret_cast<const T*>(buf.data()); }
+};
+struct Cam { // camera::PinholeCamera getters (GetWidth/GetHeight return float in the reference, Camera.h:61-62)
+    float fx, fy, cx, cy; int w, h;
+    float GetWidth() const { return (float)w; } float GetHeight() const { return (float)h; }
+    float GetFx() const { return fx; } float GetFy() const { return fy; } float GetCx() const { return cx; } float GetCy() const { return cy; }
+};
+struct Pt2u { unsigned v[2]; Pt2u() : v{0, 0} {} Pt2u(unsigned a, unsigned b) : v{a, b} {} unsigned operator()(int i) const { return v[i]; } };
 struct Result {
     Mat4 T;
     double rmse = 0;
@@ -108,9 +118,28 @@ int main(int argc, char** argv) {
     }
     Result res; res.T = Mat4::Identity();
     const int rc = sh::RunICP(OP_ICP_POINT_TO_POINT, src, tgt, (const std::vector<Vec3f>*)nullptr, Mat4::Identity(), 10, 0.05, 0, res);
+    // dense tracker through the shim: the wall scene against itself, one level, identity expected
+    op_tracker* trk = nullptr;
+    int trc = op_tracker_create(0, &trk);
+    std::vector<FloatMat> sc(1), sdp(1), zero(1);
+    sc[0].buf.resize(640 * 480); sdp[0].buf = d; zero[0].buf.assign(640 * 480, 0.0f);
+    for (int k = 0; k < 640 * 480; ++k) sc[0].buf[k] = 0.5f + 0.25f * sinf((float)(k % 640) / 17.0f);
+    std::vector<Cam> cams(1); cams[0] = Cam{cam.fx, cam.fy, cam.cx, cam.cy, 640, 480};
+    std::vector<int> it(1, 2);
+    Mat4 Tt = Mat4::Identity();
+    std::vector<std::pair<Vec3f, Vec3f>> pt_pairs;
+    std::vector<std::pair<Pt2u, Pt2u>> px_pairs;
+    bool ok = false;
+    double rmse = -1;
+    if (trc == OP_OK)
+        trc = sh::MultiScaleComputing<Pt2u, Vec3f>(trk, sc, sc, sdp, sdp, zero, zero, zero, zero, cams, it, OP_TRACK_HYBRID, Tt, pt_pairs, px_pairs, &ok, &rmse);
+    op_tracker_destroy(trk);
     std::printf("{\"blocks\": %zu, \"observed\": %llu, \"weight_sum\": %.0f, \"xor\": \"0x%llx\", \"first_list\": %zu, \"reupload_blocks\": %zu, "
-                "\"icp_rc\": %d, \"icp_pairs\": %zu, \"icp_tx\": %.6f}\n",
-                map.size(), observed, wsum, x, first_list, n2, rc, res.correspondence_set_index.size(), res.T(0, 3));
+                "\"icp_rc\": %d, \"icp_pairs\": %zu, \"icp_tx\": %.6f, \"track_rc\": %d, \"track_pairs\": %zu, \"track_ok\": %d, "
+                "\"track_tx\": %.6f, \"track_rmse\": %.6g, \"track_first_pair\": [%u, %u, %u, %u]}\n",
+                map.size(), observed, wsum, x, first_list, n2, rc, res.correspondence_set_index.size(), res.T(0, 3), trc, px_pairs.size(), (int)ok,
+                Tt(0, 3), rmse, px_pairs.empty() ? 0u : px_pairs[0].first(0), px_pairs.empty() ? 0u : px_pairs[0].first(1),
+                px_pairs.empty() ? 0u : px_pairs[0].second(0), px_pairs.empty() ? 0u : px_pairs[0].second(1));
     op_volume_destroy(vol); op_volume_destroy(vol2);
     return 0;
 }

@@ -35,6 +35,9 @@ def test_shim_end_to_end_reproduces_reference_run_statistics(hip):
     assert int(r["weight_sum"]) == anchor["weight_sum"] and int(r["xor"], 16) == int(anchor["xor_of_key_hashes"], 16)
     assert r["first_list"] == 21146 and r["reupload_blocks"] == anchor["blocks"]
     assert r["icp_rc"] == 0 and r["icp_pairs"] == 4800 and abs(r["icp_tx"] + 0.002) < 2e-4
+    # dense tracker through the shim: a frame against itself -> every pixel pairs with itself, pose stays put
+    assert r["track_rc"] == 0 and r["track_pairs"] == 640 * 480 and r["track_ok"] == 1
+    assert abs(r["track_tx"]) < 1e-5 and r["track_rmse"] < 1e-5 and r["track_first_pair"] == [0, 0, 0, 0]
 
 
 def test_shim_instantiates_with_real_eigen_types(hip):
