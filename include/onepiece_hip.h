@@ -269,6 +269,24 @@ int op_tracker_track(op_tracker *t, const op_track_level *levels, int n_levels,
  * (Odometry.cpp:543-544). */
 int op_tracker_correspondences(op_tracker *t, const op_track_level *level, const float T[16], int mem,
                                int32_t *pixel_corr, size_t corr_cap, size_t *n);
+/* Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524), end to end on the device:
+ * InitializeRGBDDenseTracking (:609-620) for both frames, ComputeCorrespondencePixelWise at the
+ * identity + NormalizeIntensity (:543-544, DenseOdometryFunction.cpp:129-145), CreatePyramidCameras,
+ * CreateImagePyramid (:436-449), MultiScaleComputing.  rgb: 3 bytes / pixel in stored order; depth:
+ * OP_DEPTH_F32 metres or OP_DEPTH_U16 raw (divided by cam->depth_scale).  n_levels = multi_scale_level.
+ * PARITY NOTE: the reference's cvtColor / GaussianBlur / pyrDown / Sobel are OpenCV calls (not vendored);
+ * this entry point implements their published definitions (BORDER_REFLECT_101, float) and is checked
+ * against a restatement of those definitions, not against OpenCV.  A caller who needs the reference's
+ * exact OpenCV pyramids builds them on the host and calls op_tracker_track. */
+int op_tracker_dense_tracking(op_tracker *t, const op_camera *cam, int n_levels,
+                              const int32_t *iters_per_level, const uint8_t *source_rgb,
+                              const uint8_t *target_rgb, const void *source_depth,
+                              const void *target_depth, int depth_fmt, const float init_T[16],
+                              int term_type, int mem, op_track_result *result, int32_t *pixel_corr,
+                              float *point_corr, size_t corr_cap);
+/* Reads back an image prepared by the last op_tracker_dense_tracking call: frame 0 source / 1 target;
+ * kind 0 colour, 1 depth, 2 colour_dx, 3 colour_dy, 4 depth_dx, 5 depth_dy (derivatives: target only). */
+int op_tracker_read_pyramid(op_tracker *t, int frame, int kind, int level, float *out, size_t cap);
 /* Convenience: create + track + destroy. */
 int op_dense_track(const op_track_level *levels, int n_levels, const int32_t *iters_per_level,
                    int full_width, int full_height, int term_type, const float init_T[16], int mem,

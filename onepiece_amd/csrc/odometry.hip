@@ -213,7 +213,11 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
         }
         pair_t[s] = accepted ? pair_p[s] : -1;
     }
-    if (accepted) {
+    if (accepted && TERM == 3) { // NormalizeIntensity sums (DenseOdometryFunction.cpp:129-139)
+        acc[0] = (double)L.sc[s];
+        acc[1] = (double)L.tc[pair_p[s]];
+        acc[28] = 1.0;
+    } else if (accepted) {
         const int t = pair_p[s];
         const int i = s / L.w, j = s - i * L.w;
         // source_XYZ[v_s][u_s] (Geometry.cpp:84-100)
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
         const float sq_img = (float)0.70710678118654757, sq_dep = (float)0.70710678118654757; // sqrt(1-0.5), sqrt(0.5)
         float J[2][6], r[2];
         int rows = 0;
-        if (TERM != 2) { // photometric row (:146-193 / :262-283)
+        if (TERM == 0 || TERM == 1) { // photometric row (:146-193 / :262-283)
             const float diff = L.tc[t] - L.sc[s];
             const float dIdx = 0.125f * L.tcdx[t], dIdy = 0.125f * L.tcdy[t]; // SOBEL_SCALE
             const float c0 = dIdx * L.fx * invz, c1 = dIdy * L.fy * invz;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
             r[rows] = TERM == 0 ? sq_img * diff : diff;
             ++rows;
         }
-        if (TERM != 1) { // geometric row (:194-241 / :284-294)
+        if (TERM == 0 || TERM == 2) { // geometric row (:194-241 / :284-294)
             float dDdx = 0.125f * L.tddx[t], dDdy = 0.125f * L.tddy[t];
             if (isnan(dDdx)) dDdx = 0.0f;
             if (isnan(dDdy)) dDdy = 0.0f;
@@ -321,6 +325,128 @@ __global__ __launch_bounds__(1024) void k_track_solve(TrackState* __restrict__ s
         // Odometry.cpp:669: (float)size / (height*width) > MAX_INLIER_RATIO_DENSE, FULL-resolution h*w
         if ((double)((float)n / (float)(st->full_h * st->full_w)) > 0.9) st->stop_level = l;
     }
+}
+
+// ---- image preparation of Odometry::DenseTracking (Odometry.cpp:436-449,609-620) -----------------
+// The reference delegates this stage to OpenCV (cvtColor, GaussianBlur 3x3, pyrDown, Sobel 3x3), which it
+// does not vendor: the kernels below implement OpenCV's published kernels / BORDER_REFLECT_101 in float
+// (horizontal pass, then vertical, taps accumulated in order) and are checked against the restatement
+// of the same definitions in oracle/ -- not against OpenCV.  ConvertDepthTo32FNaN, the /255 intensity
+// scale and NormalizeIntensity are reference code (DenseOdometryFunction.cpp:28-71,129-145).
+struct PrepFrames {
+    const unsigned char* rgb[2];
+    const void* depth[2];
+    int is_u16;
+    float depth_scale;
+    int w, h;
+    float* out[4];      // src gray, tgt gray, src depth, tgt depth (level 0)
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return i < 0 ? 0 : i;
+}
+
+__device__ __forceinline__ float prep_raw(const PrepFrames& P, int z, int y, int x) {
+    const size_t k = (size_t)y * P.w + x;
+    if (z < 2) {
+        const unsigned char* c = P.rgb[z] + 3 * k;
+        const int g = (c[0] * 4899 + c[1] * 9617 + c[2] * 1868 + 8192) >> 14; // cvtColor RGB2GRAY, 8-bit
+        return (float)(g & 255) / 255.0f;
+    }
+    if (P.is_u16) {
+        const unsigned short d = static_cast<const unsigned short*>(P.depth[z - 2])[k];
+        return ((double)d > 0.5 * (double)P.depth_scale && (float)d < 4.0f * P.depth_scale) ? (float)d / P.depth_scale : __builtin_nanf("");
+    }
+    const float d = static_cast<const float*>(P.depth[z - 2])[k];
+    return ((double)d > 0.5 && d < 4.0f) ? d : __builtin_nanf("");
+}
+
+// conversion + GaussianBlur(3x3, sigma 0) = [1 2 1]/4 separable, for the four level-0 images at once
+__global__ __launch_bounds__(kThreads) void k_prep_convert_blur(PrepFrames P) {
+    const int z = blockIdx.y, s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= P.w * P.h) return;
+    const int y = s / P.w, x = s - y * P.w;
+    const int xs[3] = {reflect101(x - 1, P.w), x, reflect101(x + 1, P.w)};
+    float hrow[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = reflect101(y - 1 + r, P.h);
+        hrow[r] = (0.25f * prep_raw(P, z, yy, xs[0]) + 0.5f * prep_raw(P, z, yy, xs[1])) + 0.25f * prep_raw(P, z, yy, xs[2]);
+    }
+    P.out[z][s] = (0.25f * hrow[0] + 0.5f * hrow[1]) + 0.25f * hrow[2];
+}
+
+struct PrepImages { const float* in[4]; float* out[4]; int w, h; }; // w, h of the INPUT images
+
+// pyrDown to (w/2, h/2): [1 4 6 4 1]/16 separable at the even samples, four images at once
+__global__ __launch_bounds__(kThreads) void k_prep_pyrdown(PrepImages P) {
+    const int z = blockIdx.y, w2 = P.w / 2, h2 = P.h / 2, s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= w2 * h2) return;
+    const int y = s / w2, x = s - y * w2;
+    const float k[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    const float* in = P.in[z];
+    int xs[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) xs[c] = reflect101(2 * x - 2 + c, P.w);
+    float v = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const float* row = in + (size_t)reflect101(2 * y - 2 + r, P.h) * P.w;
+        float hsum = k[0] * row[xs[0]];
+#pragma unroll
+        for (int c = 1; c < 5; ++c) hsum = hsum + k[c] * row[xs[c]];
+        v = r == 0 ? k[0] * hsum : v + k[r] * hsum;
+    }
+    P.out[z][s] = v;
+}
+
+// Sobel 3x3: z = 0/1 -> d/dx, d/dy of in[0] into out[0], out[1]; z = 2/3 -> of in[1] into out[2], out[3]
+__global__ __launch_bounds__(kThreads) void k_prep_sobel(PrepImages P) {
+    const int z = blockIdx.y, s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= P.w * P.h) return;
+    const int y = s / P.w, x = s - y * P.w;
+    const float* in = P.in[z >> 1];
+    const float dk[3] = {-1.0f, 0.0f, 1.0f}, sk[3] = {1.0f, 2.0f, 1.0f};
+    const bool dx = (z & 1) == 0;
+    const int xs[3] = {reflect101(x - 1, P.w), x, reflect101(x + 1, P.w)};
+    float v = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float* row = in + (size_t)reflect101(y - 1 + r, P.h) * P.w;
+        const float kx0 = dx ? dk[0] : sk[0], kx1 = dx ? dk[1] : sk[1], kx2 = dx ? dk[2] : sk[2];
+        const float hsum = (kx0 * row[xs[0]] + kx1 * row[xs[1]]) + kx2 * row[xs[2]];
+        const float ky = dx ? sk[r] : dk[r];
+        v = r == 0 ? ky * hsum : v + ky * hsum;
+    }
+    P.out[z][s] = v;
+}
+
+// NormalizeIntensity (DenseOdometryFunction.cpp:129-145): means over the identity-pose pairs (summed in
+// double here, sequentially in float there), scale = float(0.5 / mean), img = img * scale + 0.
+__global__ __launch_bounds__(1024) void k_norm_scales(const double* __restrict__ partials, int n_partials, float* __restrict__ scales) {
+    __shared__ double s_w[3][16];
+    double a = 0, b = 0, n = 0;
+    for (int i = threadIdx.x; i < n_partials; i += 1024) {
+        a += partials[(size_t)i * kNSums + 0]; b += partials[(size_t)i * kNSums + 1]; n += partials[(size_t)i * kNSums + 28];
+    }
+    a = wave_sum_d(a); b = wave_sum_d(b); n = wave_sum_d(n);
+    if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = a; s_w[1][threadIdx.x >> 6] = b; s_w[2][threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0, tb = 0, tn = 0;
+        for (int w = 0; w < 16; ++w) { ta += s_w[0][w]; tb += s_w[1][w]; tn += s_w[2][w]; }
+        const float ms = (float)ta / (float)tn, mt = (float)tb / (float)tn;
+        scales[0] = (float)(0.5 / (double)ms);
+        scales[1] = (float)(0.5 / (double)mt);
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_norm_apply(float* __restrict__ gs, float* __restrict__ gt, int npix, const float* __restrict__ scales) {
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= npix) return;
+    float* img = blockIdx.y ? gt : gs;
+    img[s] = img[s] * scales[blockIdx.y] + 0.0f;
 }
 
 // ---- correspondence_set / pixel_correspondence_set / rmse (Odometry.cpp:676-687, :606) ---------
@@ -439,6 +565,14 @@ struct op_tracker {
     float* pts_out = nullptr;
     float* images = nullptr;         // device copies of OP_MEM_HOST pyramids
     size_t images_cap = 0;           // floats
+    // op_tracker_dense_tracking: raw frames and the pyramids it builds
+    unsigned char* raw_rgb = nullptr;
+    unsigned char* raw_depth = nullptr;
+    size_t raw_cap = 0;              // pixels
+    float* pyr = nullptr;            // [frame 2][kind 6][levels] images, see pyr_image()
+    size_t pyr_cap = 0;              // floats
+    float* norm_scales = nullptr;    // 2 floats
+    int pyr_w = 0, pyr_h = 0, pyr_levels = 0;
 };
 
 namespace {
@@ -513,7 +647,8 @@ int op_tracker_create(int device, op_tracker** out) {
     if (hipDeviceGetAttribute(&t->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || t->n_cu <= 0) t->n_cu = 256;
     bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<1>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<2>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess;
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<2>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<3>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess;
     if (!attr_ok) { (void)hipGetLastError(); t->lds_total = 65536; t->lds_cap = 65536 - lds_static; }
     *out = t;
     return OP_OK;
@@ -524,69 +659,29 @@ int op_tracker_destroy(op_tracker* t) {
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->pair_t); (void)hipFree(t->pair_p); (void)hipFree(t->code); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
-    (void)hipFree(t->images); (void)hipFree(t->st);
+    (void)hipFree(t->images); (void)hipFree(t->st); (void)hipFree(t->raw_rgb); (void)hipFree(t->raw_depth); (void)hipFree(t->pyr); (void)hipFree(t->norm_scales);
     if (t->st_host) (void)hipHostFree(t->st_host);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     return OP_OK;
 }
 
-int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, const int32_t* iters_per_level, int full_width,
-                     int full_height, int term_type, const float init_T[16], int mem, op_track_result* result, int32_t* pixel_corr,
-                     float* point_corr, size_t corr_cap, int32_t* per_iter_count, float* per_iter_T) {
-    if (!t || !levels || !iters_per_level || !init_T || !result) return fail(OP_ERR_INVALID, "op_tracker_track: NULL argument");
-    if (n_levels < 1 || n_levels > kMaxLevels) return fail(OP_ERR_INVALID, "op_tracker_track: n_levels %d not in [1,%d]", n_levels, kMaxLevels);
-    if (term_type < 0 || term_type > 2) return fail(OP_ERR_INVALID, "op_tracker_track: term_type %d not in {0,1,2}", term_type);
-    if (full_width <= 0 || full_height <= 0) return fail(OP_ERR_INVALID, "op_tracker_track: full resolution %dx%d", full_width, full_height);
-    if (mem != OP_MEM_HOST && mem != OP_MEM_DEVICE) return fail(OP_ERR_INVALID, "op_tracker_track: bad mem %d", mem);
-    size_t max_pix = 0, image_floats = 0;
-    int total_iters = 0;
-    for (int l = 0; l < n_levels; ++l) {
-        const op_track_level& L = levels[l];
-        if (L.width <= 0 || L.height <= 0 || (size_t)L.width * L.height > (1u << 28))
-            return fail(OP_ERR_INVALID, "op_tracker_track: level %d size %dx%d", l, L.width, L.height);
-        if (!L.source_color || !L.source_depth || !L.target_color || !L.target_depth || !L.target_color_dx || !L.target_color_dy ||
-            !L.target_depth_dx || !L.target_depth_dy)
-            return fail(OP_ERR_INVALID, "op_tracker_track: level %d has a NULL image", l);
-        if (iters_per_level[l] < 0) return fail(OP_ERR_INVALID, "op_tracker_track: negative iteration count at level %d", l);
-        const size_t np = (size_t)L.width * L.height;
-        max_pix = np > max_pix ? np : max_pix;
-        image_floats += 8 * np;
-        total_iters += iters_per_level[l];
-    }
-    if (total_iters > kMaxIters) return fail(OP_ERR_INVALID, "op_tracker_track: %d iterations exceed the limit %d", total_iters, kMaxIters);
-    OP_TRY(use_device(t->device));
-    OP_TRY(tracker_reserve(t, max_pix, mem == OP_MEM_HOST ? image_floats : 0));
-
+// The coarse-to-fine loop + result assembly over the level descriptors already stored in t->st_host->lv
+// (device pointers).  Everything is enqueued on t->stream; one synchronisation at the end.
+static int track_run(op_tracker* t, int n_levels, const int32_t* iters_per_level, int full_width, int full_height, int term_type,
+                     const float init_T[16], op_track_result* result, int32_t* pixel_corr, float* point_corr, size_t corr_cap,
+                     int32_t* per_iter_count, float* per_iter_T) {
     TrackState* h = t->st_host;
     std::memcpy(h->T, init_T, sizeof(h->T));
     h->full_w = full_width; h->full_h = full_height; h->term = term_type;
     h->stop_level = -1; h->iters_done = 0; h->last_level = -1; h->n_last = 0; h->n_emit = 0; h->rmse = 0; h->success = 0;
-    float* dst = t->images;
-    for (int l = 0; l < n_levels; ++l) {
-        const op_track_level& L = levels[l];
-        LevelDev& D = h->lv[l];
-        D.w = L.width; D.h = L.height; D.fx = L.fx; D.fy = L.fy; D.cx = L.cx; D.cy = L.cy;
-        const float* src[8] = {L.source_color, L.source_depth, L.target_color, L.target_depth,
-                               L.target_color_dx, L.target_color_dy, L.target_depth_dx, L.target_depth_dy};
-        const float** out[8] = {&D.sc, &D.sd, &D.tc, &D.td, &D.tcdx, &D.tcdy, &D.tddx, &D.tddy};
-        const size_t np = (size_t)L.width * L.height;
-        for (int k = 0; k < 8; ++k) {
-            if (mem == OP_MEM_HOST) {
-                OP_HIP(hipMemcpyAsync(dst, src[k], np * sizeof(float), hipMemcpyHostToDevice, t->stream));
-                *out[k] = dst;
-                dst += np;
-            } else {
-                *out[k] = src[k];
-            }
-        }
-    }
     // header of the state only (the per-iteration logs are outputs)
     OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
-
+    size_t max_pix = 0;
     int it = 0;
     for (int l = n_levels - 1; l >= 0; --l) {
-        const size_t np = (size_t)levels[l].width * levels[l].height;
+        const size_t np = (size_t)h->lv[l].w * h->lv[l].h;
+        max_pix = np > max_pix ? np : max_pix;
         const int n_wg_a = (int)((np + kThreads - 1) / kThreads);
         const IterGeom g = iter_geom(t, np);
         for (int j = 0; j < iters_per_level[l]; ++j, ++it) {
@@ -614,16 +709,184 @@ int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, 
     result->tracking_success = h->success;
     result->iterations = h->iters_done;
     if (h->last_level >= 0 && h->n_emit != h->n_last)
-        return fail(OP_ERR_HIP, "op_tracker_track: emitted %llu correspondences, counted %llu", h->n_emit, h->n_last);
+        return fail(OP_ERR_HIP, "tracker: emitted %llu correspondences, counted %llu", h->n_emit, h->n_last);
     if (per_iter_count) std::memcpy(per_iter_count, h->per_iter_count, sizeof(int) * h->iters_done);
     if (per_iter_T) std::memcpy(per_iter_T, h->per_iter_T, sizeof(float) * 16 * h->iters_done);
     const size_t n = (size_t)result->n_correspondences;
     if ((pixel_corr || point_corr) && n) {
-        if (n > corr_cap) return fail(OP_ERR_CAPACITY, "op_tracker_track: %zu correspondences exceed corr_cap %zu", n, corr_cap);
+        if (n > corr_cap) return fail(OP_ERR_CAPACITY, "tracker: %zu correspondences exceed corr_cap %zu", n, corr_cap);
         if (pixel_corr) OP_HIP(hipMemcpyAsync(pixel_corr, t->pix_out, n * sizeof(int4), hipMemcpyDeviceToHost, t->stream));
         if (point_corr) OP_HIP(hipMemcpyAsync(point_corr, t->pts_out, n * 6 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
         OP_HIP(hipStreamSynchronize(t->stream));
     }
+    return OP_OK;
+}
+
+static int check_iters(const char* who, int n_levels, const int32_t* iters_per_level, int term_type) {
+    if (n_levels < 1 || n_levels > kMaxLevels) return fail(OP_ERR_INVALID, "%s: n_levels %d not in [1,%d]", who, n_levels, kMaxLevels);
+    if (term_type < 0 || term_type > 2) return fail(OP_ERR_INVALID, "%s: term_type %d not in {0,1,2}", who, term_type);
+    int total = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (iters_per_level[l] < 0) return fail(OP_ERR_INVALID, "%s: negative iteration count at level %d", who, l);
+        total += iters_per_level[l];
+    }
+    if (total > kMaxIters) return fail(OP_ERR_INVALID, "%s: %d iterations exceed the limit %d", who, total, kMaxIters);
+    return OP_OK;
+}
+
+int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, const int32_t* iters_per_level, int full_width,
+                     int full_height, int term_type, const float init_T[16], int mem, op_track_result* result, int32_t* pixel_corr,
+                     float* point_corr, size_t corr_cap, int32_t* per_iter_count, float* per_iter_T) {
+    if (!t || !levels || !iters_per_level || !init_T || !result) return fail(OP_ERR_INVALID, "op_tracker_track: NULL argument");
+    OP_TRY(check_iters("op_tracker_track", n_levels, iters_per_level, term_type));
+    if (full_width <= 0 || full_height <= 0) return fail(OP_ERR_INVALID, "op_tracker_track: full resolution %dx%d", full_width, full_height);
+    if (mem != OP_MEM_HOST && mem != OP_MEM_DEVICE) return fail(OP_ERR_INVALID, "op_tracker_track: bad mem %d", mem);
+    size_t max_pix = 0, image_floats = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const op_track_level& L = levels[l];
+        if (L.width <= 0 || L.height <= 0 || (size_t)L.width * L.height > (1u << 28))
+            return fail(OP_ERR_INVALID, "op_tracker_track: level %d size %dx%d", l, L.width, L.height);
+        if (!L.source_color || !L.source_depth || !L.target_color || !L.target_depth || !L.target_color_dx || !L.target_color_dy ||
+            !L.target_depth_dx || !L.target_depth_dy)
+            return fail(OP_ERR_INVALID, "op_tracker_track: level %d has a NULL image", l);
+        const size_t np = (size_t)L.width * L.height;
+        max_pix = np > max_pix ? np : max_pix;
+        image_floats += 8 * np;
+    }
+    OP_TRY(use_device(t->device));
+    OP_TRY(tracker_reserve(t, max_pix, mem == OP_MEM_HOST ? image_floats : 0));
+    TrackState* h = t->st_host;
+    float* dst = t->images;
+    for (int l = 0; l < n_levels; ++l) {
+        const op_track_level& L = levels[l];
+        LevelDev& D = h->lv[l];
+        D.w = L.width; D.h = L.height; D.fx = L.fx; D.fy = L.fy; D.cx = L.cx; D.cy = L.cy;
+        const float* src[8] = {L.source_color, L.source_depth, L.target_color, L.target_depth,
+                               L.target_color_dx, L.target_color_dy, L.target_depth_dx, L.target_depth_dy};
+        const float** out[8] = {&D.sc, &D.sd, &D.tc, &D.td, &D.tcdx, &D.tcdy, &D.tddx, &D.tddy};
+        const size_t np = (size_t)L.width * L.height;
+        for (int k = 0; k < 8; ++k) {
+            if (mem == OP_MEM_HOST) {
+                OP_HIP(hipMemcpyAsync(dst, src[k], np * sizeof(float), hipMemcpyHostToDevice, t->stream));
+                *out[k] = dst;
+                dst += np;
+            } else {
+                *out[k] = src[k];
+            }
+        }
+    }
+    return track_run(t, n_levels, iters_per_level, full_width, full_height, term_type, init_T, result, pixel_corr, point_corr, corr_cap,
+                     per_iter_count, per_iter_T);
+}
+
+// image (frame f: 0 source / 1 target, kind k: 0 colour 1 depth 2 colour_dx 3 colour_dy 4 depth_dx 5 depth_dy, level l)
+static float* pyr_image(const op_tracker* t, int f, int k, int l) {
+    size_t off = 0;
+    for (int q = 0; q < l; ++q) off += (size_t)(t->pyr_w >> q) * (t->pyr_h >> q);
+    size_t per_set = 0;
+    for (int q = 0; q < t->pyr_levels; ++q) per_set += (size_t)(t->pyr_w >> q) * (t->pyr_h >> q);
+    return t->pyr + (size_t)(f * 6 + k) * per_set + off;
+}
+
+int op_tracker_dense_tracking(op_tracker* t, const op_camera* cam, int n_levels, const int32_t* iters_per_level, const uint8_t* source_rgb,
+                              const uint8_t* target_rgb, const void* source_depth, const void* target_depth, int depth_fmt,
+                              const float init_T[16], int term_type, int mem, op_track_result* result, int32_t* pixel_corr,
+                              float* point_corr, size_t corr_cap) {
+    if (!t || !cam || !iters_per_level || !source_rgb || !target_rgb || !source_depth || !target_depth || !init_T || !result)
+        return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: NULL argument");
+    OP_TRY(check_iters("op_tracker_dense_tracking", n_levels, iters_per_level, term_type));
+    if (depth_fmt != OP_DEPTH_F32 && depth_fmt != OP_DEPTH_U16) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: bad depth_fmt %d", depth_fmt);
+    if (mem != OP_MEM_HOST && mem != OP_MEM_DEVICE) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: bad mem %d", mem);
+    const int W = cam->width, H = cam->height;
+    if (W < 4 || H < 4 || (size_t)W * H > (1u << 28) || (W >> (n_levels - 1)) < 3 || (H >> (n_levels - 1)) < 3)
+        return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: %dx%d with %d levels", W, H, n_levels);
+    OP_TRY(use_device(t->device));
+    const size_t np = (size_t)W * H;
+    OP_TRY(tracker_reserve(t, np, 0));
+    size_t per_set = 0;
+    for (int q = 0; q < n_levels; ++q) per_set += (size_t)(W >> q) * (H >> q);
+    if (12 * per_set > t->pyr_cap) {
+        (void)hipFree(t->pyr); t->pyr = nullptr; t->pyr_cap = 0;
+        OP_HIP(hipMalloc(&t->pyr, 12 * per_set * sizeof(float)));
+        t->pyr_cap = 12 * per_set;
+    }
+    if (!t->norm_scales) OP_HIP(hipMalloc(&t->norm_scales, 2 * sizeof(float)));
+    t->pyr_w = W; t->pyr_h = H; t->pyr_levels = n_levels;
+    const size_t dbytes = depth_fmt == OP_DEPTH_U16 ? 2 : 4;
+    PrepFrames P;
+    if (mem == OP_MEM_HOST) {
+        if (np > t->raw_cap) {
+            (void)hipFree(t->raw_rgb); (void)hipFree(t->raw_depth); t->raw_rgb = nullptr; t->raw_depth = nullptr; t->raw_cap = 0;
+            OP_HIP(hipMalloc(&t->raw_rgb, 2 * np * 3));
+            OP_HIP(hipMalloc(&t->raw_depth, 2 * np * 4));
+            t->raw_cap = np;
+        }
+        OP_HIP(hipMemcpyAsync(t->raw_rgb, source_rgb, np * 3, hipMemcpyHostToDevice, t->stream));
+        OP_HIP(hipMemcpyAsync(t->raw_rgb + np * 3, target_rgb, np * 3, hipMemcpyHostToDevice, t->stream));
+        OP_HIP(hipMemcpyAsync(t->raw_depth, source_depth, np * dbytes, hipMemcpyHostToDevice, t->stream));
+        OP_HIP(hipMemcpyAsync(t->raw_depth + np * 4, target_depth, np * dbytes, hipMemcpyHostToDevice, t->stream));
+        P.rgb[0] = t->raw_rgb; P.rgb[1] = t->raw_rgb + np * 3; P.depth[0] = t->raw_depth; P.depth[1] = t->raw_depth + np * 4;
+    } else {
+        P.rgb[0] = source_rgb; P.rgb[1] = target_rgb; P.depth[0] = source_depth; P.depth[1] = target_depth;
+    }
+    P.is_u16 = depth_fmt == OP_DEPTH_U16; P.depth_scale = cam->depth_scale; P.w = W; P.h = H;
+    P.out[0] = pyr_image(t, 0, 0, 0); P.out[1] = pyr_image(t, 1, 0, 0); P.out[2] = pyr_image(t, 0, 1, 0); P.out[3] = pyr_image(t, 1, 1, 0);
+    const int n_wg0 = (int)((np + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_prep_convert_blur, dim3(n_wg0, 4), dim3(kThreads), 0, t->stream, P);
+
+    // level descriptors (Camera.h:38-42: intrinsics halved per level)
+    TrackState* h = t->st_host;
+    float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
+    for (int l = 0; l < n_levels; ++l) {
+        LevelDev& D = h->lv[l];
+        D.w = W >> l; D.h = H >> l; D.fx = fx; D.fy = fy; D.cx = cx; D.cy = cy;
+        D.sc = pyr_image(t, 0, 0, l); D.sd = pyr_image(t, 0, 1, l); D.tc = pyr_image(t, 1, 0, l); D.td = pyr_image(t, 1, 1, l);
+        D.tcdx = pyr_image(t, 1, 2, l); D.tcdy = pyr_image(t, 1, 3, l); D.tddx = pyr_image(t, 1, 4, l); D.tddy = pyr_image(t, 1, 5, l);
+        fx /= 2; fy /= 2; cx /= 2; cy /= 2;
+    }
+    // NormalizeIntensity over the identity-pose correspondences of level 0 (Odometry.cpp:543-544)
+    {
+        const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        std::memcpy(h->T, I4, sizeof(I4));
+        h->full_w = W; h->full_h = H; h->term = 3; h->stop_level = -1;
+        OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
+        const IterGeom g = iter_geom(t, np);
+        hipLaunchKernelGGL(k_track_assoc, dim3(n_wg0), dim3(kThreads), 0, t->stream, t->st, 0, t->pair_p, t->code);
+        launch_iter<3>(t, 0, g);
+        hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(1024), 0, t->stream, t->partials, g.n_wg, t->norm_scales);
+        hipLaunchKernelGGL(k_norm_apply, dim3(n_wg0, 2), dim3(kThreads), 0, t->stream, pyr_image(t, 0, 0, 0), pyr_image(t, 1, 0, 0), (int)np,
+                           t->norm_scales);
+        // the state header is re-sent by track_run; the host copy must not be modified while this one is
+        // in flight (pinned memory is read asynchronously)
+        OP_HIP(hipStreamSynchronize(t->stream));
+    }
+    for (int l = 0; l < n_levels; ++l) {
+        const int w = W >> l, hh = H >> l;
+        if (l > 0) {
+            PrepImages D;
+            for (int f = 0; f < 2; ++f)
+                for (int k = 0; k < 2; ++k) { D.in[f * 2 + k] = pyr_image(t, f, k, l - 1); D.out[f * 2 + k] = pyr_image(t, f, k, l); }
+            D.w = W >> (l - 1); D.h = H >> (l - 1);
+            hipLaunchKernelGGL(k_prep_pyrdown, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, D);
+        }
+        PrepImages S;
+        S.in[0] = pyr_image(t, 1, 0, l); S.in[1] = pyr_image(t, 1, 1, l); S.in[2] = S.in[3] = nullptr;
+        S.out[0] = pyr_image(t, 1, 2, l); S.out[1] = pyr_image(t, 1, 3, l); S.out[2] = pyr_image(t, 1, 4, l); S.out[3] = pyr_image(t, 1, 5, l);
+        S.w = w; S.h = hh;
+        hipLaunchKernelGGL(k_prep_sobel, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, S);
+    }
+    return track_run(t, n_levels, iters_per_level, W, H, term_type, init_T, result, pixel_corr, point_corr, corr_cap, nullptr, nullptr);
+}
+
+int op_tracker_read_pyramid(op_tracker* t, int frame, int kind, int level, float* out, size_t cap) {
+    if (!t || !out) return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: NULL argument");
+    if (!t->pyr || frame < 0 || frame > 1 || kind < 0 || kind > 5 || level < 0 || level >= t->pyr_levels || (frame == 0 && kind > 1))
+        return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: no such image (frame %d kind %d level %d)", frame, kind, level);
+    const size_t n = (size_t)(t->pyr_w >> level) * (t->pyr_h >> level);
+    if (cap < n) return fail(OP_ERR_CAPACITY, "op_tracker_read_pyramid: cap %zu < %zu", cap, n);
+    OP_TRY(use_device(t->device));
+    OP_HIP(hipMemcpyAsync(out, pyr_image(t, frame, kind, level), n * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+    OP_HIP(hipStreamSynchronize(t->stream));
     return OP_OK;
 }
 

@@ -282,9 +282,52 @@ class Odometry:
             out.per_iter_T = per_T[:out.iterations].reshape(-1, 4, 4).copy()
         return out
 
-    def DenseTracking(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0, **kw):
-        """Odometry::DenseTracking (Odometry.cpp:463-524): prepare, normalise intensity over the
-        identity-pose correspondences, build pyramids, MultiScaleComputing."""
+    def DenseTracking(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0,
+                      want_correspondences=True):
+        """Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524), end to end on the GPU
+        (op_tracker_dense_tracking): image preparation, NormalizeIntensity, pyramids, MultiScaleComputing.
+        colour: (h,w,3) uint8; depth: (h,w) float32 metres or uint16 raw; numpy or CUDA torch tensors."""
+        from .integration import _image_arg
+        ps, fs, ms, k0 = _image_arg(source_depth, "depth")
+        pt, ft, mt, k1 = _image_arg(target_depth, "depth")
+        cs, _, mcs, k2 = _image_arg(source_color, "rgb")
+        ct, _, mct, k3 = _image_arg(target_color, "rgb")
+        if len({ms, mt, mcs, mct}) != 1 or fs != ft:
+            raise ValueError("all four images must share memory space and depth format")
+        T0 = np.ascontiguousarray(np.eye(4) if initial_T is None else initial_T, np.float32).reshape(16)
+        iters = np.asarray(self.iter_count_per_level, np.int32)
+        if len(iters) != self.multi_scale_level:
+            raise ValueError("iter_count_per_level must have multi_scale_level entries")
+        res = L.TrackResult()
+        cap = int(self.camera.width) * int(self.camera.height) if want_correspondences else 0
+        pix = np.empty((cap, 4), np.int32) if want_correspondences else None
+        pts = np.empty((cap, 6), np.float32) if want_correspondences else None
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
+        L.check(L.load().op_tracker_dense_tracking(self._h, C.byref(self.camera), self.multi_scale_level, iters.ctypes.data_as(L._ip),
+                                                   cs, ct, ps, pt, fs, T0.ctypes.data_as(L._fp), int(term_type), ms, C.byref(res),
+                                                   vp(pix), vp(pts), cap))
+        out = DenseTrackingResult()
+        out.T = np.array(res.T, np.float32).reshape(4, 4)
+        out.rmse = float(res.rmse)
+        out.tracking_success = bool(res.tracking_success)
+        out.iterations = int(res.iterations)
+        out.n_correspondences = int(res.n_correspondences)
+        if want_correspondences:
+            out.pixel_correspondence_set = pix[:out.n_correspondences].copy()
+            out.correspondence_set = pts[:out.n_correspondences].reshape(-1, 2, 3).copy()
+        return out
+
+    def ReadPyramid(self, frame, kind, level):
+        """Image prepared by the last DenseTracking call (frame 0 source / 1 target; kind index into
+        (colour, depth, colour_dx, colour_dy, depth_dx, depth_dy))."""
+        w, h = int(self.camera.width) >> level, int(self.camera.height) >> level
+        out = np.empty((h, w), np.float32)
+        L.check(L.load().op_tracker_read_pyramid(self._h, int(frame), int(kind), int(level), out.ctypes.data_as(L._fp), out.size))
+        return out
+
+    def DenseTrackingHostPrepared(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0, **kw):
+        """The same flow with the numpy image preparation of this module feeding MultiScaleComputing
+        (what a caller with its own -- e.g. OpenCV -- pyramids does)."""
         sg, sd = self.InitializeRGBDDenseTracking(source_color, source_depth)
         tg, td = self.InitializeRGBDDenseTracking(target_color, target_depth)
         z = np.zeros_like(sg)

@@ -1435,3 +1435,157 @@ int orc_dense_track(const orc_track_level *levels, int n_levels, const int *iter
     free(corr);
     return 0;
 }
+
+/* ======================= tracker image preparation ========================================== */
+/* Odometry::InitializeRGBDDenseTracking / CreateImagePyramid (Odometry.cpp:436-449,609-620) delegate to
+ * OpenCV (cvtColor, GaussianBlur, pyrDown, Sobel), which the reference does not vendor: NOTHING in
+ * this block is pinned to OpenCV's arithmetic.  It restates the DEFINITIONS the product uses for that
+ * stage (op_tracker_dense_tracking): OpenCV's published kernels and border rule (BORDER_REFLECT_101),
+ * evaluated in float, horizontal pass then vertical pass, taps accumulated left to right / top to
+ * bottom.  Only ConvertDepthTo32FNaN, the /255 intensity scaling and NormalizeIntensity are reference
+ * code (DenseOdometryFunction.cpp:28-71,129-145). */
+static inline int reflect101(int i, int n) { /* n >= 2 for radius-2 kernels on >= 3 px images */
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    if (i < 0) i = 0; /* degenerate tiny images */
+    return i;
+}
+
+/* cvtColor(CV_RGB2GRAY) on 8-bit data (channel 0 weighted as R, as the reference's call does on
+ * imread's BGR data), then / 255.0 (DenseOdometryFunction.cpp:58-71). */
+void orc_prep_intensity(const uint8_t *rgb, int w, int h, float *out) {
+    for (size_t k = 0; k < (size_t)w * h; ++k) {
+        int g = (rgb[3 * k] * 4899 + rgb[3 * k + 1] * 9617 + rgb[3 * k + 2] * 1868 + 8192) >> 14;
+        out[k] = (float)(unsigned char)g / 255.0f; /* gray.at<uchar>(i,j)/scale with float scale = 255 */
+    }
+}
+
+/* DenseOdometryFunction.cpp:28-56 */
+void orc_prep_depth_nan(const void *depth, int is_u16, float depth_scale, int w, int h, float *out) {
+    for (size_t k = 0; k < (size_t)w * h; ++k) {
+        if (is_u16) {
+            unsigned short d = ((const unsigned short *)depth)[k];
+            out[k] = ((double)d > 0.5 * (double)depth_scale && (double)d < 4 * (double)depth_scale) ? (float)d / depth_scale : NAN;
+        } else {
+            float d = ((const float *)depth)[k];
+            out[k] = ((double)d > 0.5 && d < 4) ? d : NAN;
+        }
+    }
+}
+
+static void sep_filter(const float *in, int w, int h, const float *kx, int nx, const float *ky, int ny, float *out) {
+    float *tmp = (float *)malloc((size_t)w * h * sizeof(float));
+    int rx = nx / 2, ry = ny / 2;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s = kx[0] * in[(size_t)y * w + reflect101(x - rx, w)];
+            for (int k = 1; k < nx; ++k) s = s + kx[k] * in[(size_t)y * w + reflect101(x - rx + k, w)];
+            tmp[(size_t)y * w + x] = s;
+        }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s = ky[0] * tmp[(size_t)reflect101(y - ry, h) * w + x];
+            for (int k = 1; k < ny; ++k) s = s + ky[k] * tmp[(size_t)reflect101(y - ry + k, h) * w + x];
+            out[(size_t)y * w + x] = s;
+        }
+    free(tmp);
+}
+
+/* GaussianBlur(3x3, sigma 0) -> [1 2 1]/4 (ImageProcessing.cpp:43-46) */
+void orc_prep_blur3(const float *in, int w, int h, float *out) {
+    const float k[3] = {0.25f, 0.5f, 0.25f};
+    sep_filter(in, w, h, k, 3, k, 3, out);
+}
+/* pyrDown to (w/2, h/2): [1 4 6 4 1]/16 then even samples (ImageProcessing.cpp:6-20) */
+void orc_prep_pyrdown(const float *in, int w, int h, float *out) {
+    const float k[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    float *full = (float *)malloc((size_t)w * h * sizeof(float));
+    sep_filter(in, w, h, k, 5, k, 5, full);
+    int w2 = w / 2, h2 = h / 2;
+    for (int y = 0; y < h2; ++y)
+        for (int x = 0; x < w2; ++x) out[(size_t)y * w2 + x] = full[(size_t)(2 * y) * w + 2 * x];
+    free(full);
+}
+/* Sobel 3x3 (ImageProcessing.cpp:25-34): axis 0 = d/dx, 1 = d/dy */
+void orc_prep_sobel(const float *in, int w, int h, int axis, float *out) {
+    const float d[3] = {-1.0f, 0.0f, 1.0f}, s[3] = {1.0f, 2.0f, 1.0f};
+    if (axis == 0) sep_filter(in, w, h, d, 3, s, 3, out);
+    else sep_filter(in, w, h, s, 3, d, 3, out);
+}
+
+/* DenseOdometryFunction.cpp:129-145 (float sequential means, LinearTransform with a float scale). */
+void orc_normalize_intensity(float *source, float *target, int w, int h, const int32_t *corr, size_t n) {
+    float mean_s = 0.0f, mean_t = 0.0f;
+    for (size_t r = 0; r < n; ++r) {
+        mean_s += source[(size_t)corr[4 * r] * w + corr[4 * r + 1]];
+        mean_t += target[(size_t)corr[4 * r + 2] * w + corr[4 * r + 3]];
+    }
+    mean_s /= (float)n; mean_t /= (float)n;
+    const float ss = (float)(0.5 / (double)mean_s), st = (float)(0.5 / (double)mean_t);
+    for (size_t k = 0; k < (size_t)w * h; ++k) { source[k] = source[k] * ss + 0.0f; target[k] = target[k] * st + 0.0f; }
+}
+
+/* Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524), with the preparation above.
+ * pyr_out (optional): receives, for frame f (0 source, 1 target), kind k (0 colour, 1 depth, 2 colour_dx,
+ * 3 colour_dy, 4 depth_dx, 5 depth_dy) and level l, a malloc'ed image at pyr_out[(f*6+k)*n_levels+l]
+ * (caller frees). */
+int orc_dense_tracking(const orc_camera *cam, int n_levels, const int *iters, const uint8_t *src_rgb, const uint8_t *tgt_rgb,
+                       const void *src_depth, const void *tgt_depth, int is_u16, int term, const float init_T[16],
+                       orc_track_result *res, int32_t *pixel_corr, float **pyr_out) {
+    int w = cam->width, h = cam->height;
+    size_t np = (size_t)w * h;
+    float *img[2][6][8];
+    memset(img, 0, sizeof(img));
+    const uint8_t *rgb[2] = {src_rgb, tgt_rgb};
+    const void *dep[2] = {src_depth, tgt_depth};
+    float *raw = (float *)malloc(np * sizeof(float));
+    for (int f = 0; f < 2; ++f) {
+        img[f][0][0] = (float *)malloc(np * sizeof(float)); img[f][1][0] = (float *)malloc(np * sizeof(float));
+        orc_prep_intensity(rgb[f], w, h, raw); orc_prep_blur3(raw, w, h, img[f][0][0]);
+        orc_prep_depth_nan(dep[f], is_u16, cam->depth_scale, w, h, raw); orc_prep_blur3(raw, w, h, img[f][1][0]);
+    }
+    free(raw);
+    /* identity-pose correspondences on the full-resolution depth, then NormalizeIntensity (:543-544) */
+    orc_track_level L0;
+    memset(&L0, 0, sizeof(L0));
+    L0.width = w; L0.height = h; L0.fx = cam->fx; L0.fy = cam->fy; L0.cx = cam->cx; L0.cy = cam->cy;
+    L0.source_depth = img[0][1][0]; L0.target_depth = img[1][1][0];
+    const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int32_t *corr = (int32_t *)malloc(np * 4 * sizeof(int32_t));
+    size_t nc = orc_pixel_correspondences(&L0, I4, corr);
+    orc_normalize_intensity(img[0][0][0], img[1][0][0], w, h, corr, nc);
+    free(corr);
+    orc_track_level lv[8];
+    int lw = w, lh = h;
+    float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
+    for (int l = 0; l < n_levels; ++l) {
+        if (l > 0) {
+            for (int f = 0; f < 2; ++f)
+                for (int k = 0; k < 2; ++k) {
+                    img[f][k][l] = (float *)malloc((size_t)(lw / 2) * (lh / 2) * sizeof(float));
+                    orc_prep_pyrdown(img[f][k][l - 1], lw, lh, img[f][k][l]);
+                }
+            lw /= 2; lh /= 2; fx /= 2; fy /= 2; cx /= 2; cy /= 2; /* Camera.h:38-42 */
+        }
+        for (int f = 0; f < 2; ++f)
+            for (int k = 0; k < 2; ++k)
+                for (int a = 0; a < 2; ++a) {
+                    img[f][2 + 2 * k + a][l] = (float *)malloc((size_t)lw * lh * sizeof(float));
+                    orc_prep_sobel(img[f][k][l], lw, lh, a, img[f][2 + 2 * k + a][l]);
+                }
+        lv[l].width = lw; lv[l].height = lh; lv[l].fx = fx; lv[l].fy = fy; lv[l].cx = cx; lv[l].cy = cy;
+        lv[l].source_color = img[0][0][l]; lv[l].source_depth = img[0][1][l];
+        lv[l].target_color = img[1][0][l]; lv[l].target_depth = img[1][1][l];
+        lv[l].target_color_dx = img[1][2][l]; lv[l].target_color_dy = img[1][3][l];
+        lv[l].target_depth_dx = img[1][4][l]; lv[l].target_depth_dy = img[1][5][l];
+    }
+    int rc = orc_dense_track(lv, n_levels, iters, w, h, term, init_T, res, pixel_corr, NULL, NULL);
+    for (int f = 0; f < 2; ++f)
+        for (int k = 0; k < 6; ++k)
+            for (int l = 0; l < n_levels; ++l) {
+                if (pyr_out) pyr_out[(f * 6 + k) * n_levels + l] = img[f][k][l];
+                else free(img[f][k][l]);
+            }
+    return rc;
+}
+void orc_free(void *p) { free(p); }

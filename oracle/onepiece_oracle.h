@@ -167,6 +167,23 @@ int orc_dense_track(const orc_track_level *levels, int n_levels, const int *iter
                     const float init_T[16], orc_track_result *res, int32_t *pixel_corr, int32_t *per_iter_count,
                     float *per_iter_T);
 
+/* ---- tracker image preparation.  NOT pinned to OpenCV (un-vendored): restates the definitions the
+ * product uses for cvtColor / GaussianBlur 3x3 / pyrDown / Sobel 3x3 (BORDER_REFLECT_101, float,
+ * horizontal then vertical, taps accumulated in order).  Reference code here: ConvertDepthTo32FNaN,
+ * the /255 scaling and NormalizeIntensity (DenseOdometryFunction.cpp:28-71,129-145). */
+void orc_prep_intensity(const uint8_t *rgb, int w, int h, float *out);
+void orc_prep_depth_nan(const void *depth, int is_u16, float depth_scale, int w, int h, float *out);
+void orc_prep_blur3(const float *in, int w, int h, float *out);
+void orc_prep_pyrdown(const float *in, int w, int h, float *out);   /* out: (w/2) x (h/2) */
+void orc_prep_sobel(const float *in, int w, int h, int axis, float *out);
+void orc_normalize_intensity(float *source, float *target, int w, int h, const int32_t *corr, size_t n);
+/* Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524).  pyr_out: optional array of
+ * 2*6*n_levels image pointers [(frame*6+kind)*n_levels+level], each released with orc_free. */
+int orc_dense_tracking(const orc_camera *cam, int n_levels, const int *iters, const uint8_t *src_rgb, const uint8_t *tgt_rgb,
+                       const void *src_depth, const void *tgt_depth, int is_u16, int term, const float init_T[16],
+                       orc_track_result *res, int32_t *pixel_corr, float **pyr_out);
+void orc_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

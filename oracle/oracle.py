@@ -117,6 +117,17 @@ def lib():
         L.orc_dense_track.restype = C.c_int
         L.orc_dense_track.argtypes = [C.POINTER(TrackLevel), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                       _fp, C.POINTER(TrackResult), _ip, _ip, _fp]
+        L.orc_prep_intensity.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp]
+        L.orc_prep_depth_nan.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, _fp]
+        L.orc_prep_blur3.argtypes = [_fp, C.c_int, C.c_int, _fp]
+        L.orc_prep_pyrdown.argtypes = [_fp, C.c_int, C.c_int, _fp]
+        L.orc_prep_sobel.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp]
+        L.orc_normalize_intensity.argtypes = [_fp, _fp, C.c_int, C.c_int, _ip, C.c_size_t]
+        L.orc_dense_tracking.restype = C.c_int
+        L.orc_dense_tracking.argtypes = [C.POINTER(Camera), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_int, _fp, C.POINTER(TrackResult), _ip,
+                                         C.POINTER(C.POINTER(C.c_float))]
+        L.orc_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -414,3 +425,74 @@ def dense_track(levels, iters=(4, 8, 16), full_w=None, full_h=None, term=0, init
             "pixel_correspondences": corr[:n].copy(),
             "per_iter_count": per_n[:res.iterations].copy(),
             "per_iter_T": per_T[:res.iterations].reshape(-1, 4, 4).copy()}
+
+
+# ---- tracker image preparation (own definitions, NOT pinned to OpenCV; see onepiece_oracle.h) ----
+PYRAMID_KINDS = ("color", "depth", "color_dx", "color_dy", "depth_dx", "depth_dy")
+
+
+def prep_intensity(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.empty((h, w), np.float32)
+    lib().orc_prep_intensity(C.c_void_p(rgb.ctypes.data), w, h, _p(out))
+    return out
+
+
+def prep_depth_nan(depth, depth_scale=1000.0):
+    d, is16 = _depth_arg(depth)
+    h, w = d.shape
+    out = np.empty((h, w), np.float32)
+    lib().orc_prep_depth_nan(C.c_void_p(d.ctypes.data), is16, float(depth_scale), w, h, _p(out))
+    return out
+
+
+def _img_op(fn, img, *extra, half=False):
+    img = _f32(img)
+    h, w = img.shape
+    out = np.empty((h // 2, w // 2) if half else (h, w), np.float32)
+    fn(_p(img), w, h, *extra, _p(out))
+    return out
+
+
+def prep_blur3(img):
+    return _img_op(lib().orc_prep_blur3, img)
+
+
+def prep_pyrdown(img):
+    return _img_op(lib().orc_prep_pyrdown, img, half=True)
+
+
+def prep_sobel(img, axis):
+    return _img_op(lib().orc_prep_sobel, img, int(axis))
+
+
+def dense_tracking(cam, src_rgb, tgt_rgb, src_depth, tgt_depth, iters=(4, 8, 16), term=0, init_T=None, want_pyramids=False):
+    """Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524), incl. the image preparation."""
+    sr, tr = np.ascontiguousarray(src_rgb, np.uint8), np.ascontiguousarray(tgt_rgb, np.uint8)
+    sd, is16 = _depth_arg(src_depth)
+    td, is16b = _depth_arg(tgt_depth)
+    assert is16 == is16b
+    n = len(iters)
+    it = (C.c_int * n)(*[int(v) for v in iters])
+    T0 = _f32(np.eye(4) if init_T is None else init_T).reshape(16)
+    res = TrackResult()
+    corr = np.empty((cam.width * cam.height, 4), np.int32)
+    pyr = (C.POINTER(C.c_float) * (12 * n))() if want_pyramids else None
+    lib().orc_dense_tracking(C.byref(cam), n, it, C.c_void_p(sr.ctypes.data), C.c_void_p(tr.ctypes.data),
+                             C.c_void_p(sd.ctypes.data), C.c_void_p(td.ctypes.data), is16, int(term), _p(T0),
+                             C.byref(res), _p(corr, _ip), pyr)
+    out = {"T": np.array(res.T, np.float32).reshape(4, 4), "rmse": float(res.rmse),
+           "tracking_success": bool(res.tracking_success), "iterations": int(res.iterations),
+           "pixel_correspondences": corr[:int(res.n_correspondences)].copy()}
+    if want_pyramids:
+        P = {}
+        for f, fname in enumerate(("source", "target")):
+            for k, kname in enumerate(PYRAMID_KINDS):
+                for l in range(n):
+                    w, h = cam.width >> l, cam.height >> l
+                    ptr = pyr[(f * 6 + k) * n + l]
+                    P[(fname, kname, l)] = np.ctypeslib.as_array(ptr, shape=(h, w)).copy()
+                    lib().orc_free(ptr)
+        out["pyramids"] = P
+    return out

@@ -208,16 +208,74 @@ def test_device_resident_pyramids(odo):
     odo.SetCamera(I.PinholeCamera("OPEN3D_DATASET"))
 
 
-def test_dense_tracking_end_to_end(odo):
-    """DenseTracking from raw colour/depth (numpy image preparation + the GPU loop) recovers the motion."""
+def _room_pair(i, j, u16=False, holes=True):
     from onepiece_amd import synthetic as S
-    d0, c0, p0 = S.room_frame(300)
-    d1, c1, p1 = S.room_frame(301)
+    out = []
+    for k in (i, j):
+        d, c, p = S.room_frame(k)
+        d = d.copy()
+        if holes:
+            d[100:140, 200:300] = 0.0
+            d[300:340, 80:140] = 7.5
+            d[::37, ::29] = 0.2
+        if u16:
+            d = np.round(d * 1000.0).astype(np.uint16)
+        out.append((d, c, p))
+    return out
+
+
+@pytest.mark.parametrize("u16", [False, True])
+def test_dense_tracking_image_preparation(oracle, odo, u16):
+    """op_tracker_dense_tracking's image preparation (conversion, 3x3 Gaussian, NormalizeIntensity,
+    pyrDown, Sobel) against the oracle's restatement of the same definitions (NOT against OpenCV, which
+    the reference does not vendor): depth pyramids bit-exact incl. NaN placement, colour within the
+    float-vs-double summation difference of the NormalizeIntensity means."""
+    (d1, c1, _), (d0, c0, _) = _room_pair(301, 300, u16=u16)
+    odo.SetCamera(I.PinholeCamera("OPEN3D_DATASET")); odo.SetMultiScale(3); odo.iter_count_per_level = [4, 8, 16]
+    got = odo.DenseTracking(c1, c0, d1, d0, None, 0)
+    ref = oracle.dense_tracking(oracle.make_camera(), c1, c0, d1, d0, (4, 8, 16), 0, want_pyramids=True)
+    P = ref["pyramids"]
+    for level in range(3):
+        for f, fname in ((0, "source"), (1, "target")):
+            g = odo.ReadPyramid(f, 1, level)
+            r = P[(fname, "depth", level)]
+            assert np.array_equal(np.isnan(g), np.isnan(r))
+            assert np.array_equal(g.view(np.uint32)[~np.isnan(r)], r.view(np.uint32)[~np.isnan(r)])
+            # colour: identical up to ONE global factor per frame -- the NormalizeIntensity mean, which the
+            # reference accumulates sequentially in float over ~3e5 pixels (off by ~6e-5 from the exact mean)
+            gc, rc = odo.ReadPyramid(f, 0, level), P[(fname, "color", level)]
+            ratio = np.median(gc / np.maximum(rc, 1e-6))
+            assert abs(ratio - 1.0) <= 2e-4
+            assert np.abs(gc - ratio * rc).max() <= 2e-6
+        for kind, kname in ((4, "depth_dx"), (5, "depth_dy")):
+            g, r = odo.ReadPyramid(1, kind, level), P[("target", kname, level)]
+            assert np.array_equal(np.isnan(g), np.isnan(r))
+            assert np.array_equal(g.view(np.uint32)[~np.isnan(r)], r.view(np.uint32)[~np.isnan(r)])
+        for kind, kname in ((2, "color_dx"), (3, "color_dy")):
+            g, r = odo.ReadPyramid(1, kind, level), P[("target", kname, level)]
+            assert np.abs(g - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-3) + 1e-6
+    # and the tracking result itself
+    assert got.iterations == ref["iterations"] and got.tracking_success == ref["tracking_success"]
+    assert rel_err(got.T, ref["T"]) <= POSE_TOL
+
+
+def test_dense_tracking_end_to_end(oracle, odo):
+    """DenseTracking from raw colour/depth entirely on the GPU recovers the motion; device-resident raw
+    frames give the same answer as host frames."""
+    import torch
+    (d1, c1, p1), (d0, c0, p0) = _room_pair(301, 300, holes=False)
     odo.SetCamera(I.PinholeCamera("OPEN3D_DATASET")); odo.SetMultiScale(3); odo.iter_count_per_level = [4, 8, 16]
     res = odo.DenseTracking(c1, c0, d1, d0, None, 0)
     T_true = np.linalg.inv(p0.astype(np.float64)) @ p1.astype(np.float64)
     assert res.tracking_success and np.abs(res.T - T_true).max() < 5e-3
     assert len(res.pixel_correspondence_set) == res.n_correspondences > 0.3 * 640 * 480
+    tc = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dev = odo.DenseTracking(tc(c1), tc(c0), tc(d1), tc(d0), None, 0)
+    assert np.array_equal(dev.T, res.T) and np.array_equal(dev.pixel_correspondence_set, res.pixel_correspondence_set)
+    # the numpy-prepared route (host pyramids -> MultiScaleComputing) lands on the same pose up to the
+    # tracker's sensitivity to the 6e-5 difference in the NormalizeIntensity scale (float vs double mean)
+    hp = odo.DenseTrackingHostPrepared(c1, c0, d1, d0, None, 0)
+    assert rel_err(hp.T, res.T) <= 2e-3 and np.abs(hp.T - T_true).max() < 5e-3
 
 
 def test_argument_errors(odo):
