@@ -310,3 +310,37 @@ def test_dense_slam_pose_chain(oracle):
         assert rel_err(slam.global_poses[i], ref_poses[i]) <= 1e-3      # per-pair agreement is 1e-4..1e-3 (see TRACK_CASES)
         assert np.abs(np.asarray(slam.global_poses[i], np.float64) - g0 @ frames[i][2].astype(np.float64))[:3, 3].max() < 0.05  # odometry drift of the reference algorithm itself
     assert slam.last_tracking_frame_id == n - 1 and all(slam.tracking_success)
+
+
+def test_degenerate_inputs(oracle, odo):
+    """Edge cases the reference's loop meets: no valid depth at all (zero pairs -> singular normal
+    equations -> pose untouched, rmse = 0/0 = NaN, failure), a single valid pixel, and zero iterations."""
+    W, H = 64, 48
+    lv = {"width": W, "height": H, "fx": 60.0, "fy": 60.0, "cx": 31.5, "cy": 23.5}
+    z = np.zeros((H, W), np.float32)
+    for k in O.TRACK_IMAGES:
+        lv[k] = z
+    lv["source_depth"] = np.full((H, W), np.nan, np.float32)
+    lv["target_depth"] = np.full((H, W), 1.5, np.float32)
+    cam = I.PinholeCamera("OPEN3D_DATASET"); cam.width, cam.height = W, H
+    odo.SetCamera(cam); odo.SetMultiScale(1); odo.iter_count_per_level = [3]
+    init = _perturb(np.eye(4, dtype=np.float32), 1.0)
+    got = odo.MultiScaleComputing([lv], init, 0, want_log=True)
+    ref = oracle.dense_track([lv], (3,), term=0, init_T=init)
+    assert got.n_correspondences == 0 == len(ref["pixel_correspondences"]) and got.iterations == ref["iterations"] == 3
+    assert np.array_equal(got.T, init) and np.array_equal(ref["T"], init)
+    assert np.isnan(got.rmse) and np.isnan(ref["rmse"]) and not got.tracking_success and not ref["tracking_success"]
+    # exactly one valid source pixel
+    sd = lv["source_depth"].copy(); sd[20, 30] = 1.5
+    lv["source_depth"] = sd
+    got = odo.MultiScaleComputing([lv], None, 2)
+    ref = oracle.dense_track([lv], (3,), term=2)
+    assert got.pixel_correspondence_set.tolist() == ref["pixel_correspondences"].tolist() == [[20, 30, 20, 30]]
+    assert rel_err(got.T, ref["T"]) <= POSE_TOL
+    # zero iterations everywhere: nothing executed, empty result, pose = init
+    odo.iter_count_per_level = [0]
+    got = odo.MultiScaleComputing([lv], init, 0)
+    ref = oracle.dense_track([lv], (0,), term=0, init_T=init)
+    assert got.iterations == 0 == ref["iterations"] and got.n_correspondences == 0 and np.array_equal(got.T, init)
+    assert not got.tracking_success and not ref["tracking_success"]
+    odo.SetCamera(I.PinholeCamera("OPEN3D_DATASET"))
