@@ -61,6 +61,30 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Wave-wide sums of 32 doubles per lane by recursive halving ("reduce-scatter"): at the step with lane
+// mask M a lane keeps one half of its values and receives the partner's copy of that half, so the work
+// halves every step (16+8+4+2+1+1 = 32 fp64 adds per lane instead of 29 x 6).  On return lane L holds in
+// v[0] the wave total of element (L >> 1) & 31.
+template <int H, int M>
+__device__ __forceinline__ void wave_halve(double (&v)[32], int lane) {
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const double keep = up ? v[i + H] : v[i];
+        const double give = up ? v[i] : v[i + H];
+        v[i] = keep + __shfl_xor(give, M, 64);
+    }
+}
+__device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+    wave_halve<16, 32>(v, lane);
+    wave_halve<8, 16>(v, lane);
+    wave_halve<4, 8>(v, lane);
+    wave_halve<2, 4>(v, lane);
+    wave_halve<1, 2>(v, lane);
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
+
 __device__ __forceinline__ int cell_coord(float p, float o, float inv, int g) {
     int c = (int)floorf((p - o) * inv);
     return c < 0 ? 0 : (c >= g ? g - 1 : c);
@@ -176,22 +200,26 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, const float* __res
 // MODE 0 (point): sums[0..2] = sum s', [3..5] = sum t, [6..14] = sum s' t^T.
 // MODE 2 (final): like MODE 0 but over the ORIGINAL source points and the stored nn[] (no search).
 template <int MODE>
-__global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restrict__ T, const float* __restrict__ src, size_t n, Grid g,
+__global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restrict__ T, Mat4 T_arg, const float* __restrict__ src, size_t n, Grid g,
                                                            const unsigned* __restrict__ cell_start, const unsigned* __restrict__ cell_count,
                                                            const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
                                                            const float* __restrict__ tgt_orig, double thr2, int* __restrict__ nn,
                                                            int* __restrict__ inl, double* __restrict__ partials) {
     __shared__ double s_red[kIterThreads / 64][kNSums];
-    double acc[29];
+    double acc[32];
 #pragma unroll
-    for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 
     // exactly one source point per thread (grid = ceil(n / 256)): the 29 fp64 accumulators are then
     // not live across the neighbour search, which keeps the kernel at ~80 VGPRs instead of 150
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) {
         const float s0 = src[3 * i], s1 = src[3 * i + 1], s2 = src[3 * i + 2];
-        const float* M = T; // start_T lives in device memory: the update step runs on the device too
+        // start_T: device memory when the update step runs on the device (T != nullptr), a by-value kernel
+        // argument when the host does the solve (saves the per-iteration host-to-device copy)
+        float M[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) M[k] = T ? T[k] : T_arg.m[k];
         float tp0 = 0, tp1 = 0, tp2 = 0;
         int best = -1;
         float t0 = 0, t1 = 0, t2 = 0, n0 = 0, n1 = 0, n2 = 0;
@@ -209,31 +237,40 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                 const int cx = (int)floorf((tp0 - g.ox) * g.inv_cell), cy = (int)floorf((tp1 - g.oy) * g.inv_cell),
                           cz = (int)floorf((tp2 - g.oz) * g.inv_cell);
                 const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, g.gx - 1);
+                // distance from the query to the near face of the neighbouring rows of cells: every point of
+                // row (cy+dy, cz+dz) is at least sqrt(gy[dy]^2 + gz[dz]^2) away, so once a candidate nearer
+                // than that bound (with 1 % slack for the rounding of the cell assignment) is known the row
+                // cannot contain the nearest neighbour.  The centre row is scanned first.
+                const float cell = 1.0f / g.inv_cell;
+                const float fy = (tp1 - g.oy) - (float)cy * cell, fz = (tp2 - g.oz) - (float)cz * cell;
+                const float gy[3] = {fmaxf(fy, 0.0f), 0.0f, fmaxf(cell - fy, 0.0f)};
+                const float gz[3] = {fmaxf(fz, 0.0f), 0.0f, fmaxf(cell - fz, 0.0f)};
                 if (x_lo <= x_hi)
-                    for (int dz = -1; dz <= 1; ++dz) {
-                        const int z = cz + dz;
-                        if (z < 0 || z >= g.gz) continue;
-                        for (int dy = -1; dy <= 1; ++dy) {
-                            const int y = cy + dy;
-                            if (y < 0 || y >= g.gy) continue;
-                            const size_t row = ((size_t)z * g.gy + y) * g.gx;
-                            // cells x_lo..x_hi own one contiguous run of the sorted target
-                            const unsigned beg = cell_start[row + x_lo];
-                            const unsigned end = cell_start[row + x_hi] + cell_count[row + x_hi];
-                            // 4 candidates per trip: the loads are independent, so 4 L2 round trips overlap
-                            // (the scan is a latency chain otherwise: ~56 dependent 16-byte loads per query)
-                            for (unsigned p = beg; p < end; p += 4) {
-                                float4 c[4];
+                    for (int r = 0; r < 9; ++r) {
+                        // r = 0: (dy,dz) = (0,0); then the remaining 8 rows
+                        const int q = r == 0 ? 4 : (r <= 4 ? r - 1 : r);
+                        const int dy = q % 3 - 1, dz = q / 3 - 1;
+                        const int z = cz + dz, y = cy + dy;
+                        if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
+                        const float bound = gy[dy + 1] * gy[dy + 1] + gz[dz + 1] * gz[dz + 1];
+                        if (0.99f * bound > best_d) continue;
+                        const size_t row = ((size_t)z * g.gy + y) * g.gx;
+                        // cells x_lo..x_hi own one contiguous run of the sorted target
+                        const unsigned beg = cell_start[row + x_lo];
+                        const unsigned end = cell_start[row + x_hi] + cell_count[row + x_hi];
+                        // 4 candidates per trip: the loads are independent, so 4 L2 round trips overlap
+                        // (the scan is a latency chain otherwise)
+                        for (unsigned p = beg; p < end; p += 4) {
+                            float4 c[4];
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) c[k] = tgt[min(p + k, end - 1)];
+                            for (int k = 0; k < 4; ++k) c[k] = tgt[min(p + k, end - 1)];
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    if (p + k >= end) break;
-                                    const float dx = tp0 - c[k].x, dyy = tp1 - c[k].y, dzz = tp2 - c[k].z;
-                                    const float d = dx * dx + dyy * dyy + dzz * dzz;
-                                    const int ci = __float_as_int(c[k].w);
-                                    if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)(p + k); }
-                                }
+                            for (int k = 0; k < 4; ++k) {
+                                if (p + k >= end) break;
+                                const float dx = tp0 - c[k].x, dyy = tp1 - c[k].y, dzz = tp2 - c[k].z;
+                                const float d = dx * dx + dyy * dyy + dzz * dzz;
+                                const int ci = __float_as_int(c[k].w);
+                                if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)(p + k); }
                             }
                         }
                     }
@@ -282,19 +319,14 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         }
         if (inl) inl[i] = inlier ? best : -1;
     }
-    // wave64 shuffle reduction, then LDS across the workgroup's waves, one partial per workgroup
+    // wave64 reduce-scatter, then LDS across the workgroup's waves, one partial per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 29; ++k) {
-        if (MODE != 1 && k >= 15 && k < 27) continue;
-        const double v = wave_sum_d(acc[k]);
-        if (lane == 0) s_red[wave][k] = v;
-    }
+    wave_reduce_scatter32(acc);
+    if ((lane & 1) == 0) s_red[wave][lane >> 1] = acc[0];
     __syncthreads();
-    if (threadIdx.x < 29) {
+    if (threadIdx.x < kNSums) {
         double v = 0;
-        if (!(MODE != 1 && threadIdx.x >= 15 && threadIdx.x < 27))
-            for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
+        for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
         partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
     }
 }
@@ -326,7 +358,7 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(const double* __restrict_
 // update: 0 = reduce only, 1 = point-to-plane step, 2 = point-to-point (Kabsch) step.
 __global__ __launch_bounds__(1024) void k_reduce_update(const double* __restrict__ partials, int n_partials, double* __restrict__ out,
                                                         int update, float* __restrict__ T, int it, int* __restrict__ per_iter_inliers,
-                                                        float* __restrict__ per_iter_T) {
+                                                        float* __restrict__ per_iter_T, double* __restrict__ host_out, double seq) {
     __shared__ double s[32][kNSums];
     __shared__ double tot[kNSums];
     const int k = threadIdx.x & 31, grp = threadIdx.x >> 5; // 32 groups x 32 sums
@@ -346,8 +378,13 @@ __global__ __launch_bounds__(1024) void k_reduce_update(const double* __restrict
         for (int g = 0; g < 32; ++g) t += s[g][threadIdx.x];
         out[threadIdx.x] = t;
         tot[threadIdx.x] = t;
+        if (host_out && threadIdx.x < kNSums - 1) host_out[threadIdx.x] = t; // host-mapped pinned memory
     }
+    if (host_out) __threadfence_system();
     __syncthreads();
+    if (host_out && threadIdx.x == 0) { // publish: the host spins on this sequence number
+        __hip_atomic_store(&host_out[kNSums - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (threadIdx.x == 0 && update) {
         float tmp_T[16], cur[16];
         if (update == 1) {
@@ -546,6 +583,9 @@ struct op_icp {
     size_t src_cap = 0;
     int *nn = nullptr, *inl = nullptr;
     double *partials = nullptr, *result = nullptr, *stage = nullptr;
+    double* result_host = nullptr;      // pinned + mapped: k_reduce_update publishes the sums here (host-solve path)
+    double* result_host_dev = nullptr;  // its device-side address
+    double seq = 0.0;                   // publication sequence number
     float* T_dev = nullptr;        // start_T (16 floats)
     int* it_inl_dev = nullptr;     // per-iteration inlier counts
     float* it_T_dev = nullptr;     // per-iteration start_T
@@ -558,8 +598,11 @@ namespace {
 // one fused pass (transform + NN + inliers + sums) followed by the reduce/update kernel; start_T is
 // read from c->T_dev.  update: see k_reduce_update.
 template <int MODE>
-void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace) {
-    hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, (const float*)c->T_dev, (const float*)c->src, c->n,
+void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace, const float* host_T = nullptr, double seq = 0.0) {
+    Mat4 Tv;
+    if (host_T) std::memcpy(Tv.m, host_T, sizeof(Tv.m)); else std::memset(Tv.m, 0, sizeof(Tv.m));
+    hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
+                       (const float*)c->src, c->n,
                        c->grid, (const unsigned*)c->cell_start, (const unsigned*)c->cell_count, (const float4*)c->tgt, (const float4*)c->tgt_n,
                        (const float*)c->tgt_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials);
     const double* rows = c->partials;
@@ -569,7 +612,7 @@ void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace) {
         rows = c->stage; n_rows = kStage1;
     }
     hipLaunchKernelGGL(k_reduce_update, dim3(1), dim3(1024), 0, c->stream, rows, n_rows, c->result, update, c->T_dev, it,
-                       trace ? c->it_inl_dev : nullptr, trace ? c->it_T_dev : nullptr);
+                       trace ? c->it_inl_dev : nullptr, trace ? c->it_T_dev : nullptr, host_T ? c->result_host_dev : nullptr, seq);
 }
 
 int enqueue_pass(op_icp* c, int mode, bool write_inl, int update, int it, bool trace) {
@@ -669,6 +712,9 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     OP_HIP_C(hipMalloc((void**)&c->result, kNSums * sizeof(double)));
     OP_HIP_C(hipMalloc((void**)&c->T_dev, 16 * sizeof(float)));
     OP_HIP_C(hipMalloc((void**)&c->stage, (size_t)kStage1 * kNSums * sizeof(double)));
+    OP_HIP_C(hipHostMalloc((void**)&c->result_host, kNSums * sizeof(double), hipHostMallocMapped));
+    OP_HIP_C(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0));
+    std::memset(c->result_host, 0, kNSums * sizeof(double));
 #undef OP_HIP_C
     *out = c;
     return OP_OK;
@@ -682,6 +728,7 @@ int op_icp_destroy(op_icp* c) {
                     c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->result_host) (void)hipHostFree(c->result_host);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return OP_OK;
@@ -752,9 +799,11 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     OP_HIP(hipMemcpyAsync(c->T_dev, init_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     // ICP.cpp:177-199.  Point-to-point: the Kabsch step is cheap enough for one GPU thread, so the
     // whole loop is enqueued back to back with the update in k_reduce_update (no host round trip).
-    // Point-to-plane: the 29 reduced sums come back to the host, which does the 6x6 solve and the SE3
-    // exp as north_star prescribes -- measured alternatives on the device (single-thread fp64 Jacobi:
-    // +400 us/iteration; single-thread LDL^T + exp: +45 us) are slower than the 256-byte round trip.
+    // Point-to-plane: the 29 reduced sums come back to the host, which does the 6x6 solve (JacobiSVD
+    // semantics incl. its rank threshold -- the synthetic room's JTJ has cond 1.5e8, so the threshold
+    // matters) and the SE3 exp as north_star prescribes.  The round trip is kept short: the pose goes
+    // down as a by-value kernel argument and the sums come up through host-mapped pinned memory that
+    // k_reduce_update publishes with a sequence number the host spins on (no memcpy, no stream sync).
     const int pass_mode = mode == OP_ICP_POINT_TO_PLANE ? 1 : 0;
     const bool host_path = pass_mode == 1;
     if (!host_path) {
@@ -762,20 +811,31 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     } else {
         float cur[16], tmp_T[16];
         std::memcpy(cur, init_T, sizeof(cur));
+        volatile double* pub = c->result_host;
         for (int it = 0; it < max_iteration; ++it) {
-            OP_TRY(enqueue_pass(c, 1, false, 0, it, false));
-            OP_HIP(hipMemcpyAsync(r, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            OP_HIP(hipStreamSynchronize(c->stream));
+            c->seq += 1.0;
+            launch_pass<1>(c, false, 0, it, false, cur, c->seq);
+            OP_HIP(hipGetLastError());
+            for (unsigned spin = 0; pub[kNSums - 1] != c->seq; ++spin) {
+                if ((spin & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) { // finished or failed
+                    OP_HIP(hipStreamSynchronize(c->stream));
+                    if (pub[kNSums - 1] != c->seq) return fail(OP_ERR_HIP, "icp: the reduce kernel did not publish its result");
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            for (int k = 0; k < kNSums - 1; ++k) r[k] = pub[k];
             double JTJ[36], JTr[6];
             float x[6];
             expand_plane_sums(r, JTJ, JTr);
             op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
             op_host::se3_exp(x, tmp_T);        // ICP.cpp:143
             op_host::mat4_mul(tmp_T, cur, cur); // ICP.cpp:198
-            OP_HIP(hipMemcpyAsync(c->T_dev, cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
             if (per_iter_inliers) per_iter_inliers[it] = (int32_t)(r[28] + 0.5);
             if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
         }
+        OP_HIP(hipMemcpyAsync(c->T_dev, cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
+        OP_HIP(hipStreamSynchronize(c->stream)); // `cur` is a stack buffer
     }
     // ICP.cpp:206-221: CountInliers with the final start_T over the last NN set, then Kabsch over
     // (original source, target) pairs
