@@ -148,33 +148,49 @@ OP_HD void se3_exp(const float x[6], float T[16]) {
 // ---- symmetric eigen-decomposition (cyclic Jacobi), N <= 6, double.
 template <int N>
 OP_HD void sym_eig(double A[N][N], double V[N][N]) {
-    for (int i = 0; i < N; ++i)
+    // every inner loop is fully unrolled so that, on the device, A and V are indexed with compile-time
+    // constants and stay in registers (dynamic indexing would put them in scratch memory)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
         for (int j = 0; j < N; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    }
     for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0;
-        for (int i = 0; i < N; ++i)
+        double off = 0, diag = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diag += A[i][i] * A[i][i];
+#pragma unroll
             for (int j = i + 1; j < N; ++j) off += A[i][j] * A[i][j];
-        if (off < 1e-300) break;
-        for (int p = 0; p < N; ++p)
+        }
+        // converged: off-diagonal mass below 1e-17 of the diagonal's (the limit of double) or exactly zero
+        if (off < 1e-300 || off <= 1e-34 * diag) break;
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+#pragma unroll
             for (int q = p + 1; q < N; ++q) {
                 const double apq = A[p][q];
                 if (fabs(apq) < 1e-300) continue;
                 const double theta = (A[q][q] - A[p][p]) / (2 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
                 const double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+#pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const double kp = A[k][p], kq = A[k][q];
                     A[k][p] = cs * kp - sn * kq; A[k][q] = sn * kp + cs * kq;
                 }
+#pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const double pk = A[p][k], qk = A[q][k];
                     A[p][k] = cs * pk - sn * qk; A[q][k] = sn * pk + cs * qk;
                 }
+#pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const double kp = V[k][p], kq = V[k][q];
                     V[k][p] = cs * kp - sn * kq; V[k][q] = sn * kp + cs * kq;
                 }
             }
+        }
     }
 }
 
@@ -211,16 +227,27 @@ OP_HD void kabsch_from_sums(double n, const double ss[3], const double st[3], co
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) A[i][j] = W[0][i] * W[0][j] + W[1][i] * W[1][j] + W[2][i] * W[2][j];
     sym_eig<3>(A, V);
-    int ord[3] = {0, 1, 2};
-    for (int i = 0; i < 3; ++i)
-        for (int j = i + 1; j < 3; ++j)
-            if (A[ord[j]][ord[j]] > A[ord[i]][ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    // eigenvalues in descending order with their eigenvectors (columns): three predicated exchanges, all
+    // indices static
+    double ev[3] = {A[0][0], A[1][1], A[2][2]};
     double Vs[3][3], S[3], U[3][3];
-    for (int k = 0; k < 3; ++k) {
-        const double ev = A[ord[k]][ord[k]];
-        S[k] = sqrt(ev > 0 ? ev : 0);
-        for (int i = 0; i < 3; ++i) Vs[i][k] = V[i][ord[k]];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Vs[i][j] = V[i][j];
     }
+#define OP_KSWAP(a, b)                                                                               \
+    {                                                                                                \
+        const bool sw = ev[b] > ev[a];                                                               \
+        const double te = ev[a]; ev[a] = sw ? ev[b] : ev[a]; ev[b] = sw ? te : ev[b];                \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                              \
+            const double tv = Vs[i][a]; Vs[i][a] = sw ? Vs[i][b] : Vs[i][a]; Vs[i][b] = sw ? tv : Vs[i][b]; \
+        }                                                                                            \
+    }
+    OP_KSWAP(0, 1) OP_KSWAP(0, 2) OP_KSWAP(1, 2)
+#undef OP_KSWAP
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S[k] = sqrt(ev[k] > 0 ? ev[k] : 0);
     for (int k = 0; k < 3; ++k)
         for (int i = 0; i < 3; ++i) {
             const double s = W[i][0] * Vs[0][k] + W[i][1] * Vs[1][k] + W[i][2] * Vs[2][k];

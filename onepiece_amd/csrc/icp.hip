@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(const double* __restrict_
 // Second pass of the reduction + the per-iteration update (ICP.cpp:195-198), so that a whole ICP
 // run is enqueued without a single host round trip: thread 0 solves the 6x6 system (or the Kabsch
 // fit), exponentiates, and left-multiplies start_T in device memory.
-// update: 0 = reduce only, 1 = point-to-plane step, 2 = point-to-point (Kabsch) step.
+// update: 0 = reduce only, 2 = point-to-point (Kabsch) step.
 __global__ __launch_bounds__(1024) void k_reduce_update(const double* __restrict__ partials, int n_partials, double* __restrict__ out,
                                                         int update, float* __restrict__ T, int it, int* __restrict__ per_iter_inliers,
                                                         float* __restrict__ per_iter_T, double* __restrict__ host_out, double seq) {
@@ -387,18 +387,8 @@ __global__ __launch_bounds__(1024) void k_reduce_update(const double* __restrict
     }
     if (threadIdx.x == 0 && update) {
         float tmp_T[16], cur[16];
-        if (update == 1) {
-            double JTJ[36], JTr[6];
-            float x[6];
-            int q = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int b = a; b < 6; ++b) { JTJ[a * 6 + b] = tot[q]; JTJ[b * 6 + a] = tot[q]; ++q; }
-            for (int a = 0; a < 6; ++a) JTr[a] = tot[21 + a];
-            op_host::solve6_psd(JTJ, JTr, x); // ICP.cpp:137-138
-            op_host::se3_exp(x, tmp_T);       // ICP.cpp:143
-        } else {
-            op_host::kabsch_from_sums(tot[28], tot, tot + 3, tot + 6, tmp_T); // ICP.cpp:79
-        }
+        // point-to-point step (the point-to-plane 6x6 solve stays on the host, see op_icp_run)
+        op_host::kabsch_from_sums(tot[28], tot, tot + 3, tot + 6, tmp_T); // ICP.cpp:79
         for (int i = 0; i < 16; ++i) cur[i] = T[i];
         op_host::mat4_mul(tmp_T, cur, cur);   // ICP.cpp:198: start_T = tmp_T * start_T
         for (int i = 0; i < 16; ++i) T[i] = cur[i];
