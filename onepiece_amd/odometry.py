@@ -2,18 +2,18 @@
 
 Same names, argument meaning and result fields as /root/reference/src/Odometry/Odometry.h:29-37
 (DenseTrackingResult) and :82-88,100-120,168-170 (DenseTracking, SetMultiScale,
-CreatePyramidCameras, multi_scale_level, iter_count_per_level).  The coarse-to-fine Gauss-Newton
-loop -- projective association with the reference's source-indexed "z-buffer", the hybrid / photo /
-depth Jacobians, the 6x6 LDL^T solve and the pose update -- runs inside libonepiece_hip.so
-(csrc/odometry.hip); nothing of it is computed here.
+CreatePyramidCameras, multi_scale_level, iter_count_per_level).  Nothing is computed here: the image
+preparation, the coarse-to-fine Gauss-Newton loop -- projective association with the reference's
+source-indexed "z-buffer", the hybrid / photo / depth Jacobians, the 6x6 LDL^T solve and the pose
+update -- all run inside libonepiece_hip.so (csrc/odometry.hip).
 
-What IS computed here, in numpy, is the image preparation the reference delegates to OpenCV
-(cvtColor, GaussianBlur 3x3, pyrDown, Sobel 3x3; Odometry.cpp:436-449,609-620).  OpenCV is not
-vendored by the reference, so that stage is outside the pinned boundary: the
-functions below follow OpenCV's published definitions (BORDER_REFLECT_101, the [1 4 6 4 1]/16
-pyrDown kernel, the [1 2 1]x[-1 0 1] Sobel) but are not claimed bit-identical to it.  A caller that
-already has OpenCV pyramids (the reference's RGBDFrame) passes them straight to
-`MultiScaleComputing`.
+Two entry points, as in the reference:
+  * `DenseTracking(source_color, target_color, source_depth, target_depth, T0, term)`: from raw frames,
+    end to end on the GPU.  The preparation stage (cvtColor / GaussianBlur / pyrDown / Sobel) is OpenCV
+    in the reference and not vendored by it, so the library implements OpenCV's published definitions;
+    that stage is outside the pinned parity boundary.
+  * `MultiScaleComputing(levels, T0, term)`: pyramids supplied by the caller (e.g. the reference's own
+    OpenCV pyramids from an RGBDFrame) -- the pinned boundary.
 """
 import ctypes as C
 
@@ -24,9 +24,6 @@ from .integration import PinholeCamera
 
 TRACK_IMAGES = ("source_color", "source_depth", "target_color", "target_depth", "target_color_dx",
                 "target_color_dy", "target_depth_dx", "target_depth_dy")
-
-MAX_DEPTH, MIN_DEPTH = 4.0, 0.5  # OdometryPredefined.h:10-11
-
 
 class DenseTrackingResult:
     """odometry::DenseTrackingResult (Odometry.h:29-37)."""
@@ -40,102 +37,6 @@ class DenseTrackingResult:
         self.iterations = 0
         self.per_iter_count = None
         self.per_iter_T = None
-
-
-# ---- image preparation (numpy; see the module docstring) ---------------------------------------
-def _reflect101(a, r, axis):
-    idx = np.arange(-r, a.shape[axis] + r)
-    n = a.shape[axis]
-    idx = np.abs(idx)
-    idx = np.where(idx >= n, 2 * (n - 1) - idx, idx)
-    return np.take(a, idx, axis=axis)
-
-
-def _sep_filter(img, kx, ky):
-    img = np.asarray(img, np.float32)
-    rx, ry = len(kx) // 2, len(ky) // 2
-    p = _reflect101(img, rx, 1)
-    out = np.zeros_like(img)
-    for k, w in enumerate(kx):
-        out = out + np.float32(w) * p[:, k:k + img.shape[1]]
-    p = _reflect101(out, ry, 0)
-    out2 = np.zeros_like(img)
-    for k, w in enumerate(ky):
-        out2 = out2 + np.float32(w) * p[k:k + img.shape[0], :]
-    return out2.astype(np.float32)
-
-
-def ConvertColorToIntensity32F(color, scale=255.0):
-    """DenseOdometryFunction.cpp:58-71: cvtColor(RGB2GRAY) on 8-bit, then / scale."""
-    color = np.asarray(color)
-    if color.ndim == 2:
-        gray = color.astype(np.uint8)
-    else:
-        c = color.astype(np.int64)
-        # OpenCV 8-bit RGB2GRAY: (R*4899 + G*9617 + B*1868 + 8192) >> 14 with R = channel 0
-        gray = ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
-    return (gray.astype(np.float32) / np.float32(scale)).astype(np.float32)
-
-
-def ConvertDepthTo32FNaN(depth, depth_scale=1000.0):
-    """DenseOdometryFunction.cpp:28-56: metres, NaN outside (MIN_DEPTH, MAX_DEPTH)."""
-    depth = np.asarray(depth)
-    if depth.dtype == np.uint16:
-        ok = (depth > MIN_DEPTH * depth_scale) & (depth < MAX_DEPTH * depth_scale)
-        out = depth.astype(np.float32) / np.float32(depth_scale)
-    else:
-        depth = depth.astype(np.float32)
-        ok = (depth > MIN_DEPTH) & (depth < MAX_DEPTH)
-        out = depth.copy()
-    out[~ok] = np.nan
-    return out
-
-
-def GaussianFiltering(img, k_size=3):
-    """tool::GaussianFiltering (ImageProcessing.cpp:43-46): GaussianBlur(k, sigma=0); k = 3 -> [1 2 1]/4."""
-    if k_size != 3:
-        raise ValueError("only the 3x3 kernel the tracker uses is provided")
-    k = (0.25, 0.5, 0.25)
-    return _sep_filter(img, k, k)
-
-
-def PyrDown(img):
-    """cv::pyrDown to (cols/2, rows/2): [1 4 6 4 1]/16 separable, even samples."""
-    k = tuple(v / 16.0 for v in (1, 4, 6, 4, 1))
-    f = _sep_filter(img, k, k)
-    h, w = img.shape
-    return np.ascontiguousarray(f[0:2 * (h // 2):2, 0:2 * (w // 2):2])
-
-
-def CreatePyramid(img, levels):
-    out = [np.ascontiguousarray(img, np.float32)]
-    for _ in range(1, levels):
-        out.append(PyrDown(out[-1]))
-    return out
-
-
-def SobelFiltering(img, axis):
-    """cv::Sobel(src, CV_32F, dx, dy) with the default 3x3 kernel (ImageProcessing.cpp:25-34)."""
-    d, s = (-1.0, 0.0, 1.0), (1.0, 2.0, 1.0)
-    return _sep_filter(img, d, s) if axis == "x" else _sep_filter(img, s, d)
-
-
-def NormalizeIntensity(source_gray, target_gray, correspondences):
-    """DenseOdometryFunction.cpp:129-145: float sequential means over the identity-pose pairs."""
-    c = np.asarray(correspondences, np.int64).reshape(-1, 4)
-    ms = np.float32(0.0)
-    mt = np.float32(0.0)
-    sv = source_gray[c[:, 0], c[:, 1]].astype(np.float32)
-    tv = target_gray[c[:, 2], c[:, 3]].astype(np.float32)
-    # sequential float32 accumulation (np.cumsum keeps the running sum in float32)
-    if len(c):
-        ms = np.cumsum(sv, dtype=np.float32)[-1]
-        mt = np.cumsum(tv, dtype=np.float32)[-1]
-    ms = np.float32(ms / np.float32(len(c))) if len(c) else np.float32(np.nan)
-    mt = np.float32(mt / np.float32(len(c))) if len(c) else np.float32(np.nan)
-    # LinearTransform(img, 0.5 / mean, 0.0): the scale is a double converted to float at the call
-    return (source_gray * np.float32(0.5 / float(ms)) + np.float32(0.0)).astype(np.float32), \
-           (target_gray * np.float32(0.5 / float(mt)) + np.float32(0.0)).astype(np.float32)
 
 
 def make_level(cam, source_color, source_depth, target_color, target_depth, target_color_dx, target_color_dy,
@@ -216,26 +117,6 @@ class Odometry:
                 cams.append(L.Camera(p.fx / 2.0, p.fy / 2.0, p.cx / 2.0, p.cy / 2.0,   # halving is exact in float
                                      p.width // 2, p.height // 2, p.depth_scale))
         return cams
-
-    # -- image preparation (numpy stage, see module docstring) --
-    def InitializeRGBDDenseTracking(self, color, depth):
-        """Odometry.cpp:609-620: intensity / NaN-depth conversion, 3x3 Gaussian on both."""
-        gray = GaussianFiltering(ConvertColorToIntensity32F(color, 255.0))
-        refined = GaussianFiltering(ConvertDepthTo32FNaN(depth, self.camera.depth_scale))
-        return gray, refined
-
-    def CreateImagePyramid(self, gray, depth):
-        """Odometry.cpp:436-449 -> (color, depth, color_dx, color_dy, depth_dx, depth_dy) pyramids."""
-        cp, dp = CreatePyramid(gray, self.multi_scale_level), CreatePyramid(depth, self.multi_scale_level)
-        return (cp, dp, [SobelFiltering(c, "x") for c in cp], [SobelFiltering(c, "y") for c in cp],
-                [SobelFiltering(d, "x") for d in dp], [SobelFiltering(d, "y") for d in dp])
-
-    def BuildLevels(self, source_gray, source_depth, target_gray, target_depth):
-        cams = self.CreatePyramidCameras()
-        scp, sdp, _, _, _, _ = self.CreateImagePyramid(source_gray, source_depth)
-        tcp, tdp, tcdx, tcdy, tddx, tddy = self.CreateImagePyramid(target_gray, target_depth)
-        return [make_level(cams[i], scp[i], sdp[i], tcp[i], tdp[i], tcdx[i], tcdy[i], tddx[i], tddy[i])
-                for i in range(self.multi_scale_level)]
 
     # -- the GPU path --
     def ComputeCorrespondencePixelWise(self, level, T=None):
@@ -325,13 +206,13 @@ class Odometry:
         L.check(L.load().op_tracker_read_pyramid(self._h, int(frame), int(kind), int(level), out.ctypes.data_as(L._fp), out.size))
         return out
 
-    def DenseTrackingHostPrepared(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0, **kw):
-        """The same flow with the numpy image preparation of this module feeding MultiScaleComputing
-        (what a caller with its own -- e.g. OpenCV -- pyramids does)."""
-        sg, sd = self.InitializeRGBDDenseTracking(source_color, source_depth)
-        tg, td = self.InitializeRGBDDenseTracking(target_color, target_depth)
-        z = np.zeros_like(sg)
-        cam = self.CreatePyramidCameras()[0]
-        corr = self.ComputeCorrespondencePixelWise(make_level(cam, z, sd, z, td, z, z, z, z), np.eye(4))
-        sg, tg = NormalizeIntensity(sg, tg, corr)
-        return self.MultiScaleComputing(self.BuildLevels(sg, sd, tg, td), initial_T, term_type, **kw)
+    def PreparedLevels(self):
+        """The pyramids the last DenseTracking call built on the GPU, as `levels` for MultiScaleComputing
+        (downloaded copies)."""
+        cams = self.CreatePyramidCameras()
+        levels = []
+        for l in range(self.multi_scale_level):
+            levels.append(make_level(cams[l], self.ReadPyramid(0, 0, l), self.ReadPyramid(0, 1, l), self.ReadPyramid(1, 0, l),
+                                     self.ReadPyramid(1, 1, l), self.ReadPyramid(1, 2, l), self.ReadPyramid(1, 3, l),
+                                     self.ReadPyramid(1, 4, l), self.ReadPyramid(1, 5, l)))
+        return levels

@@ -30,10 +30,10 @@ def rel_err(a, b):
 
 def track_levels(i, j, n_levels=3, holes=True, scale=1):
     """Pyramid inputs of Odometry::MultiScaleComputing for synthetic room frames i (source) -> j (target),
-    built with the numpy image preparation of onepiece_amd.odometry (test INPUT; the tracker's parity
+    prepared on the CPU with the oracle's image preparation (test INPUT; the tracker's pinned parity
     boundary starts at these arrays).  holes: punch NaN regions / out-of-range depth into both frames.
     Returns (levels, T_true) with T_true = pose_j^-1 * pose_i (source camera -> target camera)."""
-    from onepiece_amd import odometry as O
+    from oracle import oracle as ORC
     fx, fy, cx, cy, w, h, _ = small_camera(scale)
 
     def prep(k):
@@ -44,20 +44,25 @@ def track_levels(i, j, n_levels=3, holes=True, scale=1):
             d[h // 5:h // 5 + h // 12, w // 3:w // 3 + w // 6] = 0.0          # sensor dropout
             d[(3 * h) // 5:(3 * h) // 5 + h // 10, w // 8:w // 8 + w // 10] = 7.5  # beyond MAX_DEPTH
             d[::37, ::29] = 0.2                                                # below MIN_DEPTH speckle
-        g = O.GaussianFiltering(O.ConvertColorToIntensity32F(rgb))
-        dd = O.GaussianFiltering(O.ConvertDepthTo32FNaN(d))
+        g = ORC.prep_blur3(ORC.prep_intensity(rgb))
+        dd = ORC.prep_blur3(ORC.prep_depth_nan(d))
         return g, dd, pose
+
+    def pyramid(img):
+        out = [img]
+        for _ in range(1, n_levels):
+            out.append(ORC.prep_pyrdown(out[-1]))
+        return out
 
     sg, sd, ps = prep(i)
     tg, td, pt = prep(j)
-    scp, sdp = O.CreatePyramid(sg, n_levels), O.CreatePyramid(sd, n_levels)
-    tcp, tdp = O.CreatePyramid(tg, n_levels), O.CreatePyramid(td, n_levels)
+    scp, sdp, tcp, tdp = pyramid(sg), pyramid(sd), pyramid(tg), pyramid(td)
     levels = []
     for l in range(n_levels):
         levels.append({"width": w, "height": h, "fx": fx, "fy": fy, "cx": cx, "cy": cy,
                        "source_color": scp[l], "source_depth": sdp[l], "target_color": tcp[l], "target_depth": tdp[l],
-                       "target_color_dx": O.SobelFiltering(tcp[l], "x"), "target_color_dy": O.SobelFiltering(tcp[l], "y"),
-                       "target_depth_dx": O.SobelFiltering(tdp[l], "x"), "target_depth_dy": O.SobelFiltering(tdp[l], "y")})
+                       "target_color_dx": ORC.prep_sobel(tcp[l], 0), "target_color_dy": ORC.prep_sobel(tcp[l], 1),
+                       "target_depth_dx": ORC.prep_sobel(tdp[l], 0), "target_depth_dy": ORC.prep_sobel(tdp[l], 1)})
         fx, fy, cx, cy, w, h = fx / 2, fy / 2, cx / 2, cy / 2, w // 2, h // 2
     T_true = np.linalg.inv(pt.astype(np.float64)) @ ps.astype(np.float64)
     return levels, T_true.astype(np.float32)
