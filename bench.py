@@ -33,6 +33,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 W, H = 640, 480
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +196,8 @@ def main():
         cpu_dt = time.perf_counter() - t
         out["cpu_baseline"] = {"value": ns / cpu_dt, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "first %d frames of the same sequence fused by oracle/onepiece_oracle.c "
-                                         "(the reference's integrate path is serial), host has %d cores" % (ns, os.cpu_count())}
+                                         "(the reference's integrate path is serial), host has %d cores" % (ns, os.cpu_count()),
+                               "host_cores": os.cpu_count(), "cpu_model": _cpu_model()}
         # parity at the benchmark's own sizes: same sample through the HIP path, compared bit for bit
         hv2 = I.CubeHandler(device=local_rank, max_blocks=1 << 17)
         hv2.SetVoxelResolution(args.voxel)
@@ -226,7 +237,10 @@ def main():
         gpu_it_s = iters / (time.perf_counter() - t)
         lib.op_icp_destroy(h)
         out["icp"] = {"iters_per_s": gpu_it_s, "points": int(len(src)), "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31)",
-                      "final_inliers": int(res.n_inliers), "estimate_normals_s": normals_s}
+                      "final_inliers": int(res.n_inliers), "estimate_normals_s": normals_s,
+                      # 36 B per source point per iteration (source + matched target + normal); the kernel is
+                      # a latency-bound gather (27-cell scan), so this is far from the HBM roof by construction
+                      "algorithmic_gbs": 36.0 * len(src) * gpu_it_s / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             t = time.perf_counter()

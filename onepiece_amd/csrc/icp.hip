@@ -411,7 +411,8 @@ __device__ __forceinline__ void sym3_smallest_eigvec(double a00, double a01, dou
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 32; ++sweep) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off < 1e-300) break;
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off < 1e-300 || off <= 1e-34 * diag) break; // converged to the limit of double
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -429,10 +430,12 @@ __device__ __forceinline__ void sym3_smallest_eigvec(double a00, double a01, dou
                 for (int k = 0; k < 3; ++k) { const double kp = V[k][p], kq = V[k][q]; V[k][p] = c * kp - sn * kq; V[k][q] = sn * kp + c * kq; }
             }
     }
-    int m = 0;
-    if (A[1][1] < A[m][m]) m = 1;
-    if (A[2][2] < A[m][m]) m = 2;
-    v[0] = V[0][m]; v[1] = V[1][m]; v[2] = V[2][m];
+    // column of the smallest eigenvalue, selected without dynamic indexing (keeps A, V in registers)
+    const bool m1 = A[1][1] < A[0][0];
+    const double e01 = m1 ? A[1][1] : A[0][0];
+    const bool m2 = A[2][2] < e01;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = m2 ? V[k][2] : (m1 ? V[k][1] : V[k][0]);
 }
 
 __global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const unsigned* __restrict__ cell_start,
