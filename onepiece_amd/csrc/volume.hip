@@ -821,17 +821,21 @@ __global__ __launch_bounds__(512) void k_point_cloud(VolView V, float res, float
 // ---------------------------------------------------------------------------------------------
 struct BlockCache { int cx, cy, cz, idx; };
 
+template <bool COL>
 __device__ __forceinline__ bool rc_fetch(const VolView& V, BlockCache& bc, int px, int py, int pz, Vox5* out) {
     const int cx = px >> 3, cy = py >> 3, cz = pz >> 3;
     if (!(cx == bc.cx && cy == bc.cy && cz == bc.cz)) { bc.cx = cx; bc.cy = cy; bc.cz = cz; bc.idx = table_find(V, cx, cy, cz); }
     if (bc.idx < 0) return false;
     const int vid = (px - cx * 8) + (py - cy * 8) * 8 + (pz - cz * 8) * 64;
     const float* t = V.pool + (size_t)bc.idx * kBlockFloats + vid;
-    out->s = t[0]; out->w = t[kVox]; out->c0 = t[2 * kVox]; out->c1 = t[3 * kVox]; out->c2 = t[4 * kVox];
+    out->s = t[0]; out->w = t[kVox];
+    if (COL) { out->c0 = t[2 * kVox]; out->c1 = t[3 * kVox]; out->c2 = t[4 * kVox]; } // colour planes only at the hit
+    else { out->c0 = out->c1 = out->c2 = 0.0f; }
     return out->w > 0;
 }
 
-__device__ bool rc_sample(const VolView& V, BlockCache& bc, float res, float x, float y, float z, float* sdf, float* col) {
+template <bool COL>
+__device__ bool rc_sample_t(const VolView& V, BlockCache& bc, float res, float x, float y, float z, float* sdf, float* col) {
     const float gx = x / res - 0.5f, gy = y / res - 0.5f, gz = z / res - 0.5f;
     const float fx0 = floorf(gx), fy0 = floorf(gy), fz0 = floorf(gz);
     const int ix = (int)fx0, iy = (int)fy0, iz = (int)fz0;
@@ -840,14 +844,18 @@ __device__ bool rc_sample(const VolView& V, BlockCache& bc, float res, float x, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         Vox5 t;
-        if (!rc_fetch(V, bc, ix + (k & 1), iy + ((k >> 1) & 1), iz + ((k >> 2) & 1), &t)) return false;
+        if (!rc_fetch<COL>(V, bc, ix + (k & 1), iy + ((k >> 1) & 1), iz + ((k >> 2) & 1), &t)) return false;
         const float wx = (k & 1) ? fx : 1.0f - fx, wy = (k & 2) ? fy : 1.0f - fy, wz = (k & 4) ? fz : 1.0f - fz;
         const float w = (wx * wy) * wz;
         acc += w * t.s; a0 += w * t.c0; a1 += w * t.c1; a2 += w * t.c2;
     }
     *sdf = acc;
-    if (col) { col[0] = a0; col[1] = a1; col[2] = a2; }
+    if (COL) { col[0] = a0; col[1] = a1; col[2] = a2; }
     return true;
+}
+// marching and normal samples read only the sdf and weight planes (2 of the 5)
+__device__ __forceinline__ bool rc_sample(const VolView& V, BlockCache& bc, float res, float x, float y, float z, float* sdf, float* col) {
+    return col ? rc_sample_t<true>(V, bc, res, x, y, z, sdf, col) : rc_sample_t<false>(V, bc, res, x, y, z, sdf, nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_raycast(VolView V, op_camera cam, Mat4 P, float res, float near_d, float far_d,
