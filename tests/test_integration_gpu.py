@@ -333,3 +333,45 @@ def test_host_buffers_are_only_borrowed_for_the_call(oracle):
         hv.IntegrateImage(buf_d, buf_c, p)
         buf_d[:] = -7.0; buf_c[:] = 255          # the caller reuses its buffers immediately
     _compare(oracle, ov, hv)
+
+
+def test_full_size_invariants_without_the_oracle():
+    """BASELINE sizes (640x480, 5 mm, 160 frames resident in HBM): properties that hold at any size and
+    need no CPU run -- weight checksum, allocated-set = union of the per-frame selections,
+    shard-and-merge against sequential fusion, upload/download idempotence."""
+    import torch
+    n = 160
+    dev = torch.device("cuda", 0)
+    depth, rgb, poses = S.room_sequence_torch(40, n, dev)
+    hv = I.CubeHandler(max_blocks=1 << 18); hv.SetVoxelResolution(0.005)
+    hv.IntegrateSequence(depth, rgb, poses)
+    st = hv.Stats()
+    keys, vox = hv.GetCubeMap()
+    assert st["frames"] == n and st["voxels_visited"] == 512 * st["blocks_selected"]
+    # every update adds weight 1 (TSDFVoxel::operator+, w + 1): the weight plane is a checksum of the updates
+    assert int(vox[:, :, 1].astype(np.float64).sum()) == st["voxels_updated"]
+    assert np.all(vox[:, :, 1] == np.round(vox[:, :, 1])) and vox[:, :, 1].max() <= n
+    observed = vox[:, :, 1] > 0
+    assert np.all(np.abs(vox[:, :, 0][observed]) < 0.1 + 1e-6) and np.all(vox[:, :, 0][~observed] == 999)
+    assert np.all((vox[:, :, 2:][observed] >= 0) & (vox[:, :, 2:][observed] <= 1))
+    # allocated block set == union over frames of PrepareCubes' lists (CubeHandler.cpp:181-190), sampled frames
+    probe = I.CubeHandler(max_blocks=1 << 18); probe.SetVoxelResolution(0.005)
+    keyset = set(map(tuple, keys.tolist()))
+    for i in (0, 57, n - 1):
+        ids = probe.PrepareCubes(depth[i], poses[i])
+        assert set(map(tuple, np.asarray(ids).tolist())) <= keyset
+    # shard-and-merge (two contiguous halves, CubeHandler::Merge) vs sequential: same keys, same weights exactly,
+    # sdf / colour within 1e-4 (mean of means vs running mean)
+    a = I.CubeHandler(max_blocks=1 << 18); a.SetVoxelResolution(0.005)
+    b = I.CubeHandler(max_blocks=1 << 18); b.SetVoxelResolution(0.005)
+    a.IntegrateSequence(depth[:n // 2], rgb[:n // 2], poses[:n // 2])
+    b.IntegrateSequence(depth[n // 2:], rgb[n // 2:], poses[n // 2:])
+    a.Merge(b)
+    mk, mv = a.GetCubeMap()
+    assert np.array_equal(mk, keys) and np.array_equal(mv[:, :, 1], vox[:, :, 1])
+    assert np.abs(mv[:, :, 0] - vox[:, :, 0])[observed].max() <= TOL * 0.1
+    assert np.abs(mv[:, :, 2:] - vox[:, :, 2:])[observed].max() <= TOL
+    # upload/download idempotence
+    c = I.CubeHandler(max_blocks=1 << 18); c.SetVoxelResolution(0.005); c.SetCubeMap(keys, vox)
+    ck, cv = c.GetCubeMap()
+    assert np.array_equal(ck, keys) and np.array_equal(cv.view(np.uint32), vox.view(np.uint32))
