@@ -25,5 +25,7 @@ def oracle():
 def hip():
     """The product library through its host mirror; fails loudly when it is not built."""
     from onepiece_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):   # fresh checkout: compile in-tree (hipcc cross-compiles without a GPU)
+        _lib.build()
     _lib.load()
     return _lib
