@@ -84,3 +84,47 @@ def ConvertDepthTo32F(depth, depth_scale):
     out = d.astype(np.float32) / np.float32(depth_scale)
     out[out < 0] = 0
     return out
+
+
+class FramePrefetcher:
+    """Decodes the PNG pairs of a sequence ahead of the consumer on a pool of host threads (PIL releases
+    the GIL while inflating), so that file IO does not cap the fusion rate (1000 frames/s
+    x 2.1 MB = 2.1 GB/s of decoded pixels).  Iterating yields (index, rgb_bgr_u8, depth_u16) in order.
+
+        for i, rgb, depth in FramePrefetcher(rgb_files, depth_files, indices=range(0, n, 10)):
+            ...
+    """
+
+    def __init__(self, rgb_files, depth_files, indices=None, workers=16, ahead=64):
+        from concurrent.futures import ThreadPoolExecutor
+        self.rgb_files, self.depth_files = rgb_files, depth_files
+        self.indices = list(range(len(rgb_files)) if indices is None else indices)
+        self.ahead = max(1, int(ahead))
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+
+    def _load(self, i):
+        return i, imread(self.rgb_files[i]), imread(self.depth_files[i], unchanged=True)
+
+    def __iter__(self):
+        from collections import deque
+        pending = deque()
+        it = iter(self.indices)
+        try:
+            for i in it:
+                pending.append(self._pool.submit(self._load, i))
+                if len(pending) >= self.ahead:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+        finally:
+            for f in pending:
+                f.cancel()
+
+    def close(self):
+        self._pool.shutdown(wait=False)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -125,3 +125,22 @@ def test_two_rank_gloo_merge_equals_reference_merge(oracle, tmp_path):
     # both shards really contributed and really overlapped
     k0 = {tuple(r) for r in s0["k"].tolist()}; k1 = {tuple(r) for r in s1["k"].tolist()}
     assert k0 - k1 and k1 - k0 and k0 & k1
+
+
+def test_frame_prefetcher_yields_in_order(tmp_path):
+    """Harness code: threaded PNG prefetch returns exactly what sequential imread returns."""
+    import numpy as np
+    from onepiece_amd import sequence as Q
+    rng = np.random.default_rng(3)
+    n, h, w = 12, 24, 32
+    depths = [rng.uniform(0.5, 4.0, (h, w)).astype(np.float32) for _ in range(n)]
+    rgbs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(n)]
+    poses = [np.eye(4, dtype=np.float32) for _ in range(n)]
+    Q.WriteImageSequence(str(tmp_path), depths, rgbs, poses)
+    rgb_files, depth_files = Q.ReadImageSequence(str(tmp_path))
+    got = list(Q.FramePrefetcher(rgb_files, depth_files, indices=range(0, n, 2), workers=4, ahead=3))
+    assert [g[0] for g in got] == list(range(0, n, 2))
+    for i, rgb, depth in got:
+        assert np.array_equal(rgb, Q.imread(rgb_files[i])) and np.array_equal(rgb, rgbs[i])
+        assert np.array_equal(depth, Q.imread(depth_files[i], unchanged=True))
+        assert depth.dtype == np.uint16 and np.array_equal(depth, np.round(depths[i].astype(np.float64) * 1000).astype(np.uint16))
