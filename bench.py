@@ -342,28 +342,33 @@ def main():
         from onepiece_amd import dense_slam as DS
         n_df = min(100, n_local)
 
-        def dense_fusion_pass():
-            slam = DS.DenseSlam(hv.camera, device=local_rank)
+        def dense_fusion_pass(pipe):
             vol = I.CubeHandler(hv.camera, device=local_rank)
             vol.SetVoxelResolution(0.005)
+            slam = DS.DenseSlam(hv.camera, device=local_rank, pipeline=pipe,
+                                on_tracked=lambda fid, c, d, T: vol.IntegrateImage(d, c, T))
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for i in range(n_df):
-                if slam.UpdateFrame(rgb[i], depth[i]):
-                    vol.IntegrateImage(depth[i], rgb[i], slam.global_poses[i])
+                slam.UpdateFrame(rgb[i], depth[i])
+            slam.Finish()
             nb = vol.BlockCount()           # flushes the pending batch and synchronises
             return slam, nb, time.perf_counter() - t0
 
-        dense_fusion_pass()                 # warm-up
-        slam, nb, dt = dense_fusion_pass()
+        dense_fusion_pass(4)                # warm-up
+        _s1, _nb1, dt_seq = dense_fusion_pass(1)
+        slam, nb, dt = dense_fusion_pass(4)
         g0 = np.linalg.inv(poses[0].astype(np.float64))
         drift = max(float(np.abs(np.asarray(slam.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max())
                     for i in range(n_df))
-        out["dense_fusion"] = {"frames_per_s": n_df / dt, "frames": n_df, "tracked": int(sum(slam.tracking_success)),
+        out["dense_fusion"] = {"frames_per_s": n_df / dt, "one_pair_at_a_time_frames_per_s": n_df / dt_seq, "pairs_in_flight": 4,
+                               "frames": n_df, "tracked": int(sum(slam.tracking_success)),
                                "blocks": int(nb), "voxel_m": 0.005, "max_translation_drift_m": drift,
                                "pipeline": "per frame: Odometry::DenseTracking(prev, cur, I) on the GPU (image preparation, 3 levels x "
                                            "{4,8,16}), pose chaining on the host, CubeHandler::IntegrateImage with the TRACKED pose; "
-                                           "no submap registration / BA (out of scope)"}
+                                           "no submap registration / BA (out of scope).  pairs_in_flight independent frame pairs are tracked "
+                                           "concurrently on separate HIP streams (speculating on the success flag, resolved in order): "
+                                           "identical poses, the latency-bound tracker no longer leaves the chip idle"}
 
     if rank == 0:
         print(json.dumps(out))

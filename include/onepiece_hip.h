@@ -284,6 +284,18 @@ int op_tracker_dense_tracking(op_tracker *t, const op_camera *cam, int n_levels,
                               const void *target_depth, int depth_fmt, const float init_T[16],
                               int term_type, int mem, op_track_result *result, int32_t *pixel_corr,
                               float *point_corr, size_t corr_cap);
+/* The same call split in two so that several trackers (each owns a HIP stream) can work on independent
+ * frame pairs concurrently -- a single 640x480 track is 28 strictly sequential small problems that leave
+ * most of the 256 CUs idle.  _enqueue returns as soon as everything is on the tracker's stream (device
+ * frames are used in place and must stay valid until the wait); op_tracker_wait synchronises that stream
+ * and fills the result.  One enqueue may be outstanding per tracker. */
+int op_tracker_dense_tracking_enqueue(op_tracker *t, const op_camera *cam, int n_levels,
+                                      const int32_t *iters_per_level, const uint8_t *source_rgb,
+                                      const uint8_t *target_rgb, const void *source_depth,
+                                      const void *target_depth, int depth_fmt, const float init_T[16],
+                                      int term_type, int mem, int want_point_corr);
+int op_tracker_wait(op_tracker *t, op_track_result *result, int32_t *pixel_corr, float *point_corr,
+                    size_t corr_cap);
 /* Reads back an image prepared by the last op_tracker_dense_tracking call: frame 0 source / 1 target;
  * kind 0 colour, 1 depth, 2 colour_dx, 3 colour_dy, 4 depth_dx, 5 depth_dy (derivatives: target only). */
 int op_tracker_read_pyramid(op_tracker *t, int frame, int kind, int level, float *out, size_t cap);

@@ -118,6 +118,9 @@ SIGNATURES = {
     "op_tracker_correspondences": (C.c_int, [_vp, C.POINTER(TrackLevel), _fp, C.c_int, _vp, C.c_size_t, _szp]),
     "op_tracker_dense_tracking": (C.c_int, [_vp, C.POINTER(Camera), C.c_int, _ip, _vp, _vp, _vp, _vp, C.c_int, _fp, C.c_int,
                                             C.c_int, C.POINTER(TrackResult), _vp, _vp, C.c_size_t]),
+    "op_tracker_dense_tracking_enqueue": (C.c_int, [_vp, C.POINTER(Camera), C.c_int, _ip, _vp, _vp, _vp, _vp, C.c_int, _fp, C.c_int,
+                                                    C.c_int, C.c_int]),
+    "op_tracker_wait": (C.c_int, [_vp, C.POINTER(TrackResult), _vp, _vp, C.c_size_t]),
     "op_tracker_read_pyramid": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t]),
     "op_dense_track": (C.c_int, [C.POINTER(TrackLevel), C.c_int, _ip, C.c_int, C.c_int, C.c_int, _fp, C.c_int,
                                  C.c_int, C.POINTER(TrackResult), _vp, _vp, C.c_size_t]),

@@ -552,7 +552,11 @@ struct op_tracker {
     int device = 0;
     hipStream_t stream = nullptr;
     TrackState* st = nullptr;        // device
-    TrackState* st_host = nullptr;   // pinned
+    TrackState* st_host = nullptr;   // pinned: header uploaded for the loop
+    TrackState* st_host_norm = nullptr; // pinned: header uploaded for the NormalizeIntensity pass
+    TrackState* st_back = nullptr;   // pinned: state downloaded after the run
+    bool pending = false;            // a run has been enqueued and not yet waited for
+    bool pending_logs = false, pending_points = false;
     size_t pix_cap = 0;              // workspace capacity in pixels
     int* pair_p = nullptr;           // per source pixel: candidate target pixel index p(s) or -1
     int* pair_t = nullptr;           // per source pixel: accepted target pixel index or -1
@@ -634,7 +638,9 @@ int op_tracker_create(int device, op_tracker** out) {
     t->device = device;
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&t->st, sizeof(TrackState)) != hipSuccess ||
-        hipHostMalloc(&t->st_host, sizeof(TrackState)) != hipSuccess) {
+        hipHostMalloc(&t->st_host, sizeof(TrackState)) != hipSuccess ||
+        hipHostMalloc(&t->st_host_norm, sizeof(TrackState)) != hipSuccess ||
+        hipHostMalloc(&t->st_back, sizeof(TrackState)) != hipSuccess) {
         op_tracker_destroy(t);
         return fail(OP_ERR_HIP, "op_tracker_create: allocating tracker state failed");
     }
@@ -661,16 +667,18 @@ int op_tracker_destroy(op_tracker* t) {
     (void)hipFree(t->pair_t); (void)hipFree(t->pair_p); (void)hipFree(t->code); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
     (void)hipFree(t->images); (void)hipFree(t->st); (void)hipFree(t->raw_rgb); (void)hipFree(t->raw_depth); (void)hipFree(t->pyr); (void)hipFree(t->norm_scales);
     if (t->st_host) (void)hipHostFree(t->st_host);
+    if (t->st_host_norm) (void)hipHostFree(t->st_host_norm);
+    if (t->st_back) (void)hipHostFree(t->st_back);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     return OP_OK;
 }
 
-// The coarse-to-fine loop + result assembly over the level descriptors already stored in t->st_host->lv
-// (device pointers).  Everything is enqueued on t->stream; one synchronisation at the end.
-static int track_run(op_tracker* t, int n_levels, const int32_t* iters_per_level, int full_width, int full_height, int term_type,
-                     const float init_T[16], op_track_result* result, int32_t* pixel_corr, float* point_corr, size_t corr_cap,
-                     int32_t* per_iter_count, float* per_iter_T) {
+// Enqueues the coarse-to-fine loop + result assembly over the level descriptors already stored in
+// t->st_host->lv (device pointers) on t->stream and returns; track_finish() synchronises and reads the
+// result.  The pinned buffers are only touched between a finish and the next enqueue.
+static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_level, int full_width, int full_height, int term_type,
+                         const float init_T[16], bool want_points, bool want_logs) {
     TrackState* h = t->st_host;
     std::memcpy(h->T, init_T, sizeof(h->T));
     h->full_w = full_width; h->full_h = full_height; h->term = term_type;
@@ -696,13 +704,21 @@ static int track_run(op_tracker* t, int n_levels, const int32_t* iters_per_level
     hipLaunchKernelGGL(k_emit_count, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->pair_t, t->wg_count);
     hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg_max);
     hipLaunchKernelGGL(k_emit_scatter, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->pair_t, t->wg_count, t->pix_out,
-                       point_corr ? t->pts_out : nullptr, t->partials);
+                       want_points ? t->pts_out : nullptr, t->partials);
     hipLaunchKernelGGL(k_emit_finish, dim3(1), dim3(1024), 0, t->stream, t->st, t->partials, n_wg_max);
     OP_HIP(hipGetLastError());
-    const bool want_logs = per_iter_count || per_iter_T;
-    OP_HIP(hipMemcpyAsync(h, t->st, want_logs ? sizeof(TrackState) : offsetof(TrackState, per_iter_count), hipMemcpyDeviceToHost, t->stream));
-    OP_HIP(hipStreamSynchronize(t->stream));
+    OP_HIP(hipMemcpyAsync(t->st_back, t->st, want_logs ? sizeof(TrackState) : offsetof(TrackState, per_iter_count), hipMemcpyDeviceToHost,
+                          t->stream));
+    t->pending = true; t->pending_logs = want_logs; t->pending_points = want_points;
+    return OP_OK;
+}
 
+static int track_finish(op_tracker* t, op_track_result* result, int32_t* pixel_corr, float* point_corr, size_t corr_cap,
+                        int32_t* per_iter_count, float* per_iter_T) {
+    if (!t->pending) return fail(OP_ERR_INVALID, "tracker: nothing has been enqueued");
+    t->pending = false;
+    OP_HIP(hipStreamSynchronize(t->stream));
+    const TrackState* h = t->st_back;
     std::memcpy(result->T, h->T, sizeof(result->T));
     result->rmse = h->rmse;
     result->n_correspondences = h->last_level < 0 ? 0 : h->n_last;
@@ -710,16 +726,26 @@ static int track_run(op_tracker* t, int n_levels, const int32_t* iters_per_level
     result->iterations = h->iters_done;
     if (h->last_level >= 0 && h->n_emit != h->n_last)
         return fail(OP_ERR_HIP, "tracker: emitted %llu correspondences, counted %llu", h->n_emit, h->n_last);
+    if ((per_iter_count || per_iter_T) && !t->pending_logs) return fail(OP_ERR_INVALID, "tracker: per-iteration logs were not requested at enqueue");
     if (per_iter_count) std::memcpy(per_iter_count, h->per_iter_count, sizeof(int) * h->iters_done);
     if (per_iter_T) std::memcpy(per_iter_T, h->per_iter_T, sizeof(float) * 16 * h->iters_done);
     const size_t n = (size_t)result->n_correspondences;
     if ((pixel_corr || point_corr) && n) {
         if (n > corr_cap) return fail(OP_ERR_CAPACITY, "tracker: %zu correspondences exceed corr_cap %zu", n, corr_cap);
+        if (point_corr && !t->pending_points) return fail(OP_ERR_INVALID, "tracker: point correspondences were not requested at enqueue");
         if (pixel_corr) OP_HIP(hipMemcpyAsync(pixel_corr, t->pix_out, n * sizeof(int4), hipMemcpyDeviceToHost, t->stream));
         if (point_corr) OP_HIP(hipMemcpyAsync(point_corr, t->pts_out, n * 6 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
         OP_HIP(hipStreamSynchronize(t->stream));
     }
     return OP_OK;
+}
+
+static int track_run(op_tracker* t, int n_levels, const int32_t* iters_per_level, int full_width, int full_height, int term_type,
+                     const float init_T[16], op_track_result* result, int32_t* pixel_corr, float* point_corr, size_t corr_cap,
+                     int32_t* per_iter_count, float* per_iter_T) {
+    OP_TRY(track_enqueue(t, n_levels, iters_per_level, full_width, full_height, term_type, init_T, point_corr != nullptr,
+                         per_iter_count || per_iter_T));
+    return track_finish(t, result, pixel_corr, point_corr, corr_cap, per_iter_count, per_iter_T);
 }
 
 static int check_iters(const char* who, int n_levels, const int32_t* iters_per_level, int term_type) {
@@ -753,6 +779,7 @@ int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, 
         max_pix = np > max_pix ? np : max_pix;
         image_floats += 8 * np;
     }
+    if (t->pending) return fail(OP_ERR_INVALID, "op_tracker_track: an enqueued run has not been waited for");
     OP_TRY(use_device(t->device));
     OP_TRY(tracker_reserve(t, max_pix, mem == OP_MEM_HOST ? image_floats : 0));
     TrackState* h = t->st_host;
@@ -788,12 +815,12 @@ static float* pyr_image(const op_tracker* t, int f, int k, int l) {
     return t->pyr + (size_t)(f * 6 + k) * per_set + off;
 }
 
-int op_tracker_dense_tracking(op_tracker* t, const op_camera* cam, int n_levels, const int32_t* iters_per_level, const uint8_t* source_rgb,
-                              const uint8_t* target_rgb, const void* source_depth, const void* target_depth, int depth_fmt,
-                              const float init_T[16], int term_type, int mem, op_track_result* result, int32_t* pixel_corr,
-                              float* point_corr, size_t corr_cap) {
-    if (!t || !cam || !iters_per_level || !source_rgb || !target_rgb || !source_depth || !target_depth || !init_T || !result)
+int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n_levels, const int32_t* iters_per_level,
+                                      const uint8_t* source_rgb, const uint8_t* target_rgb, const void* source_depth, const void* target_depth,
+                                      int depth_fmt, const float init_T[16], int term_type, int mem, int want_point_corr) {
+    if (!t || !cam || !iters_per_level || !source_rgb || !target_rgb || !source_depth || !target_depth || !init_T)
         return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: NULL argument");
+    if (t->pending) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: an enqueued run has not been waited for");
     OP_TRY(check_iters("op_tracker_dense_tracking", n_levels, iters_per_level, term_type));
     if (depth_fmt != OP_DEPTH_F32 && depth_fmt != OP_DEPTH_U16) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: bad depth_fmt %d", depth_fmt);
     if (mem != OP_MEM_HOST && mem != OP_MEM_DEVICE) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: bad mem %d", mem);
@@ -835,7 +862,7 @@ int op_tracker_dense_tracking(op_tracker* t, const op_camera* cam, int n_levels,
     hipLaunchKernelGGL(k_prep_convert_blur, dim3(n_wg0, 4), dim3(kThreads), 0, t->stream, P);
 
     // level descriptors (Camera.h:38-42: intrinsics halved per level)
-    TrackState* h = t->st_host;
+    TrackState* h = t->st_host_norm;
     float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
     for (int l = 0; l < n_levels; ++l) {
         LevelDev& D = h->lv[l];
@@ -844,21 +871,22 @@ int op_tracker_dense_tracking(op_tracker* t, const op_camera* cam, int n_levels,
         D.tcdx = pyr_image(t, 1, 2, l); D.tcdy = pyr_image(t, 1, 3, l); D.tddx = pyr_image(t, 1, 4, l); D.tddy = pyr_image(t, 1, 5, l);
         fx /= 2; fy /= 2; cx /= 2; cy /= 2;
     }
-    // NormalizeIntensity over the identity-pose correspondences of level 0 (Odometry.cpp:543-544)
+    // NormalizeIntensity over the identity-pose correspondences of level 0 (Odometry.cpp:543-544).  Its state
+    // header is uploaded from its own pinned buffer, so the loop's header (st_host) can be prepared while this
+    // copy is still in flight: the whole call is enqueued without a host-side wait.
     {
         const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         std::memcpy(h->T, I4, sizeof(I4));
         h->full_w = W; h->full_h = H; h->term = 3; h->stop_level = -1;
+        h->iters_done = 0; h->last_level = -1; h->n_last = 0; h->n_emit = 0; h->rmse = 0; h->success = 0;
         OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
+        std::memcpy(t->st_host->lv, h->lv, sizeof(h->lv));
         const IterGeom g = iter_geom(t, np);
         hipLaunchKernelGGL(k_track_assoc, dim3(n_wg0), dim3(kThreads), 0, t->stream, t->st, 0, t->pair_p, t->code);
         launch_iter<3>(t, 0, g);
         hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(1024), 0, t->stream, t->partials, g.n_wg, t->norm_scales);
         hipLaunchKernelGGL(k_norm_apply, dim3(n_wg0, 2), dim3(kThreads), 0, t->stream, pyr_image(t, 0, 0, 0), pyr_image(t, 1, 0, 0), (int)np,
                            t->norm_scales);
-        // the state header is re-sent by track_run; the host copy must not be modified while this one is
-        // in flight (pinned memory is read asynchronously)
-        OP_HIP(hipStreamSynchronize(t->stream));
     }
     for (int l = 0; l < n_levels; ++l) {
         const int w = W >> l, hh = H >> l;
@@ -875,11 +903,28 @@ int op_tracker_dense_tracking(op_tracker* t, const op_camera* cam, int n_levels,
         S.w = w; S.h = hh;
         hipLaunchKernelGGL(k_prep_sobel, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, S);
     }
-    return track_run(t, n_levels, iters_per_level, W, H, term_type, init_T, result, pixel_corr, point_corr, corr_cap, nullptr, nullptr);
+    return track_enqueue(t, n_levels, iters_per_level, W, H, term_type, init_T, want_point_corr != 0, false);
+}
+
+int op_tracker_wait(op_tracker* t, op_track_result* result, int32_t* pixel_corr, float* point_corr, size_t corr_cap) {
+    if (!t || !result) return fail(OP_ERR_INVALID, "op_tracker_wait: NULL argument");
+    OP_TRY(use_device(t->device));
+    return track_finish(t, result, pixel_corr, point_corr, corr_cap, nullptr, nullptr);
+}
+
+int op_tracker_dense_tracking(op_tracker* t, const op_camera* cam, int n_levels, const int32_t* iters_per_level, const uint8_t* source_rgb,
+                              const uint8_t* target_rgb, const void* source_depth, const void* target_depth, int depth_fmt,
+                              const float init_T[16], int term_type, int mem, op_track_result* result, int32_t* pixel_corr,
+                              float* point_corr, size_t corr_cap) {
+    if (!result) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: NULL argument");
+    OP_TRY(op_tracker_dense_tracking_enqueue(t, cam, n_levels, iters_per_level, source_rgb, target_rgb, source_depth, target_depth, depth_fmt,
+                                             init_T, term_type, mem, point_corr != nullptr));
+    return op_tracker_wait(t, result, pixel_corr, point_corr, corr_cap);
 }
 
 int op_tracker_read_pyramid(op_tracker* t, int frame, int kind, int level, float* out, size_t cap) {
     if (!t || !out) return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: NULL argument");
+    if (t->pending) return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: an enqueued run has not been waited for");
     if (!t->pyr || frame < 0 || frame > 1 || kind < 0 || kind > 5 || level < 0 || level >= t->pyr_levels || (frame == 0 && kind > 1))
         return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: no such image (frame %d kind %d level %d)", frame, kind, level);
     const size_t n = (size_t)(t->pyr_w >> level) * (t->pyr_h >> level);

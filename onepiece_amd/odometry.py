@@ -163,11 +163,11 @@ class Odometry:
             out.per_iter_T = per_T[:out.iterations].reshape(-1, 4, 4).copy()
         return out
 
-    def DenseTracking(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0,
-                      want_correspondences=True):
-        """Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524), end to end on the GPU
-        (op_tracker_dense_tracking): image preparation, NormalizeIntensity, pyramids, MultiScaleComputing.
-        colour: (h,w,3) uint8; depth: (h,w) float32 metres or uint16 raw; numpy or CUDA torch tensors."""
+    def DenseTrackingEnqueue(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0,
+                             want_point_correspondences=False):
+        """First half of DenseTracking: puts the whole computation on this tracker's stream and returns.
+        Several Odometry objects can thus work on independent frame pairs at once; `Wait()` returns the result.
+        Device-resident images must stay alive until then (a reference is kept here)."""
         from .integration import _image_arg
         ps, fs, ms, k0 = _image_arg(source_depth, "depth")
         pt, ft, mt, k1 = _image_arg(target_depth, "depth")
@@ -179,14 +179,20 @@ class Odometry:
         iters = np.asarray(self.iter_count_per_level, np.int32)
         if len(iters) != self.multi_scale_level:
             raise ValueError("iter_count_per_level must have multi_scale_level entries")
+        self._inflight = (k0, k1, k2, k3)
+        L.check(L.load().op_tracker_dense_tracking_enqueue(self._h, C.byref(self.camera), self.multi_scale_level,
+                                                           iters.ctypes.data_as(L._ip), cs, ct, ps, pt, fs, T0.ctypes.data_as(L._fp),
+                                                           int(term_type), ms, 1 if want_point_correspondences else 0))
+
+    def Wait(self, want_correspondences=False):
+        """Second half: synchronise this tracker's stream and return the DenseTrackingResult."""
         res = L.TrackResult()
         cap = int(self.camera.width) * int(self.camera.height) if want_correspondences else 0
         pix = np.empty((cap, 4), np.int32) if want_correspondences else None
         pts = np.empty((cap, 6), np.float32) if want_correspondences else None
         vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
-        L.check(L.load().op_tracker_dense_tracking(self._h, C.byref(self.camera), self.multi_scale_level, iters.ctypes.data_as(L._ip),
-                                                   cs, ct, ps, pt, fs, T0.ctypes.data_as(L._fp), int(term_type), ms, C.byref(res),
-                                                   vp(pix), vp(pts), cap))
+        L.check(L.load().op_tracker_wait(self._h, C.byref(res), vp(pix), vp(pts), cap))
+        self._inflight = None
         out = DenseTrackingResult()
         out.T = np.array(res.T, np.float32).reshape(4, 4)
         out.rmse = float(res.rmse)
@@ -197,6 +203,15 @@ class Odometry:
             out.pixel_correspondence_set = pix[:out.n_correspondences].copy()
             out.correspondence_set = pts[:out.n_correspondences].reshape(-1, 2, 3).copy()
         return out
+
+    def DenseTracking(self, source_color, target_color, source_depth, target_depth, initial_T=None, term_type=0,
+                      want_correspondences=True):
+        """Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524), end to end on the GPU
+        (op_tracker_dense_tracking): image preparation, NormalizeIntensity, pyramids, MultiScaleComputing.
+        colour: (h,w,3) uint8; depth: (h,w) float32 metres or uint16 raw; numpy or CUDA torch tensors."""
+        self.DenseTrackingEnqueue(source_color, target_color, source_depth, target_depth, initial_T, term_type,
+                                  want_point_correspondences=want_correspondences)
+        return self.Wait(want_correspondences)
 
     def ReadPyramid(self, frame, kind, level):
         """Image prepared by the last DenseTracking call (frame 0 source / 1 target; kind index into

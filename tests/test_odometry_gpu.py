@@ -344,3 +344,32 @@ def test_degenerate_inputs(oracle, odo):
     assert got.iterations == 0 == ref["iterations"] and got.n_correspondences == 0 and np.array_equal(got.T, init)
     assert not got.tracking_success and not ref["tracking_success"]
     odo.SetCamera(I.PinholeCamera("OPEN3D_DATASET"))
+
+
+def test_pipelined_dense_slam_equals_sequential():
+    """DenseSlam(pipeline=4): several frame pairs in flight on separate trackers/streams, resolved in order.
+    Poses, flags and the order of the on_tracked callbacks are identical to the sequential loop -- also when a
+    frame fails to track (a blank depth image), which invalidates the pairs speculatively enqueued after it."""
+    import torch
+    from onepiece_amd import dense_slam as DS, synthetic as S
+    n = 14
+    dev = torch.device("cuda", 0)
+    depth, rgb, _poses = S.room_sequence_torch(200, n, dev)
+    depth = depth.clone()
+    depth[6] = 0.0                                     # frame 6 cannot be tracked; 7 must be tracked against 5
+    cam = I.PinholeCamera("OPEN3D_DATASET")
+    seen = {1: [], 4: []}
+    runs = {}
+    for p in (1, 4):
+        slam = DS.DenseSlam(cam, pipeline=p, on_tracked=lambda fid, c, d, T, p=p: seen[p].append((fid, T.copy())))
+        for i in range(n):
+            slam.UpdateFrame(rgb[i], depth[i])
+        slam.Finish()
+        runs[p] = slam
+    a, b = runs[1], runs[4]
+    assert a.tracking_success == b.tracking_success and a.tracking_success[6] is False and all(a.tracking_success[:6]) and all(a.tracking_success[7:])
+    assert a.last_tracking_frame_id == b.last_tracking_frame_id == n - 1
+    for i in range(n):
+        assert np.array_equal(a.global_poses[i], b.global_poses[i]), i
+    assert [f for f, _ in seen[1]] == [f for f, _ in seen[4]] == [i for i in range(n) if i != 6]
+    assert all(np.array_equal(x[1], y[1]) for x, y in zip(seen[1], seen[4]))

@@ -14,27 +14,36 @@ depth, rgb, poses = S.room_sequence_torch(0, n, dev)
 cam = I.PinholeCamera("OPEN3D_DATASET")
 
 
-def run(fuse):
-    slam = DS.DenseSlam(cam)
+pipeline = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+
+
+def run(fuse, pipe):
     vol = I.CubeHandler(cam)
     vol.SetVoxelResolution(0.005)
+
+    def on_tracked(fid, c, d, T):
+        if fuse and fid % every == 0:
+            vol.IntegrateImage(d, c, T)
+
+    slam = DS.DenseSlam(cam, pipeline=pipe, on_tracked=on_tracked)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for i in range(n):
-        ok = slam.UpdateFrame(rgb[i], depth[i])
-        if fuse and ok and i % every == 0:
-            vol.IntegrateImage(depth[i], rgb[i], slam.global_poses[i])
+        slam.UpdateFrame(rgb[i], depth[i])
+    slam.Finish()
     blocks = vol.BlockCount() if fuse else 0   # flushes + synchronises
     dt = time.perf_counter() - t
     return slam, blocks, dt
 
 
-run(True)  # warm-up (allocations, first-touch)
-slam, _, dt_track = run(False)
-slam, blocks, dt = run(True)
+run(True, pipeline)  # warm-up (allocations, first-touch)
+_, _, dt_seq = run(True, 1)
+slam, _, dt_track = run(False, pipeline)
+slam, blocks, dt = run(True, pipeline)
 g0 = np.linalg.inv(poses[0].astype(np.float64))
 drift = [np.abs(np.asarray(slam.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max() for i in range(n)]
-print(json.dumps({"frames": n, "fuse_every": every, "tracked": int(sum(slam.tracking_success)),
+print(json.dumps({"frames": n, "fuse_every": every, "pipeline": pipeline, "tracked": int(sum(slam.tracking_success)),
                   "tracking_plus_fusion_frames_per_s": n / dt, "tracking_only_frames_per_s": n / dt_track,
+                  "sequential_tracking_plus_fusion_frames_per_s": n / dt_seq,
                   "blocks": int(blocks), "max_translation_drift_m": float(max(drift)), "final_translation_drift_m": float(drift[-1]),
                   "mean_rmse": float(np.mean(slam.rmse[1:]))}))
