@@ -17,6 +17,7 @@
 // which only ever refers to a SMALLER raster index, so every thread resolves it independently by
 // walking p(.) until a link is decided without recursion; acc(s) is the parity of the walk length.
 #include <cstddef>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "host_math.hpp"
@@ -364,7 +365,8 @@ __device__ __forceinline__ float prep_raw(const PrepFrames& P, int z, int y, int
 }
 
 // conversion + GaussianBlur(3x3, sigma 0) = [1 2 1]/4 separable, for the four level-0 images at once
-__global__ __launch_bounds__(kThreads) void k_prep_convert_blur(PrepFrames P) {
+__global__ __launch_bounds__(kThreads) void k_prep_convert_blur(const PrepFrames* __restrict__ Pp) {
+    const PrepFrames P = *Pp;   // per-call frame pointers live in device memory so that a captured graph can be replayed
     const int z = blockIdx.y, s = blockIdx.x * kThreads + threadIdx.x;
     if (s >= P.w * P.h) return;
     const int y = s / P.w, x = s - y * P.w;
@@ -577,6 +579,13 @@ struct op_tracker {
     size_t pyr_cap = 0;              // floats
     float* norm_scales = nullptr;    // 2 floats
     int pyr_w = 0, pyr_h = 0, pyr_levels = 0;
+    PrepFrames* prep_host = nullptr; // pinned: this call's frame pointers
+    PrepFrames* prep_dev = nullptr;
+    // hipGraph of one whole dense-tracking call (device frames, no point pairs): the ~100 launches of a call
+    // cost ~0.3 ms of host time when issued one by one, which caps several trackers working concurrently
+    hipGraphExec_t graph_exec = nullptr;
+    unsigned long long graph_key[4] = {0, 0, 0, 0};
+    int graph_ok = 1;                // cleared when capture/instantiate fails (then launches are issued directly)
 };
 
 namespace {
@@ -640,7 +649,8 @@ int op_tracker_create(int device, op_tracker** out) {
         hipMalloc(&t->st, sizeof(TrackState)) != hipSuccess ||
         hipHostMalloc(&t->st_host, sizeof(TrackState)) != hipSuccess ||
         hipHostMalloc(&t->st_host_norm, sizeof(TrackState)) != hipSuccess ||
-        hipHostMalloc(&t->st_back, sizeof(TrackState)) != hipSuccess) {
+        hipHostMalloc(&t->st_back, sizeof(TrackState)) != hipSuccess ||
+        hipHostMalloc(&t->prep_host, sizeof(PrepFrames)) != hipSuccess || hipMalloc(&t->prep_dev, sizeof(PrepFrames)) != hipSuccess) {
         op_tracker_destroy(t);
         return fail(OP_ERR_HIP, "op_tracker_create: allocating tracker state failed");
     }
@@ -656,6 +666,7 @@ int op_tracker_create(int device, op_tracker** out) {
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<2>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<3>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess;
     if (!attr_ok) { (void)hipGetLastError(); t->lds_total = 65536; t->lds_cap = 65536 - lds_static; }
+    if (const char* e = std::getenv("ONEPIECE_TRACKER_GRAPH")) t->graph_ok = std::atoi(e) != 0;
     *out = t;
     return OP_OK;
 }
@@ -665,7 +676,9 @@ int op_tracker_destroy(op_tracker* t) {
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->pair_t); (void)hipFree(t->pair_p); (void)hipFree(t->code); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
-    (void)hipFree(t->images); (void)hipFree(t->st); (void)hipFree(t->raw_rgb); (void)hipFree(t->raw_depth); (void)hipFree(t->pyr); (void)hipFree(t->norm_scales);
+    (void)hipFree(t->images); (void)hipFree(t->st); (void)hipFree(t->raw_rgb); (void)hipFree(t->raw_depth); (void)hipFree(t->pyr); (void)hipFree(t->norm_scales); (void)hipFree(t->prep_dev);
+    if (t->prep_host) (void)hipHostFree(t->prep_host);
+    if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
     if (t->st_host) (void)hipHostFree(t->st_host);
     if (t->st_host_norm) (void)hipHostFree(t->st_host_norm);
     if (t->st_back) (void)hipHostFree(t->st_back);
@@ -677,12 +690,17 @@ int op_tracker_destroy(op_tracker* t) {
 // Enqueues the coarse-to-fine loop + result assembly over the level descriptors already stored in
 // t->st_host->lv (device pointers) on t->stream and returns; track_finish() synchronises and reads the
 // result.  The pinned buffers are only touched between a finish and the next enqueue.
-static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_level, int full_width, int full_height, int term_type,
-                         const float init_T[16], bool want_points, bool want_logs) {
+static void fill_loop_header(op_tracker* t, int full_width, int full_height, int term_type, const float init_T[16]) {
     TrackState* h = t->st_host;
     std::memcpy(h->T, init_T, sizeof(h->T));
     h->full_w = full_width; h->full_h = full_height; h->term = term_type;
     h->stop_level = -1; h->iters_done = 0; h->last_level = -1; h->n_last = 0; h->n_emit = 0; h->rmse = 0; h->success = 0;
+}
+
+static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_level, int full_width, int full_height, int term_type,
+                         const float init_T[16], bool want_points, bool want_logs) {
+    TrackState* h = t->st_host;
+    fill_loop_header(t, full_width, full_height, term_type, init_T);
     // header of the state only (the per-iteration logs are outputs)
     OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
     size_t max_pix = 0;
@@ -840,7 +858,7 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
     if (!t->norm_scales) OP_HIP(hipMalloc(&t->norm_scales, 2 * sizeof(float)));
     t->pyr_w = W; t->pyr_h = H; t->pyr_levels = n_levels;
     const size_t dbytes = depth_fmt == OP_DEPTH_U16 ? 2 : 4;
-    PrepFrames P;
+    PrepFrames& P = *t->prep_host;
     if (mem == OP_MEM_HOST) {
         if (np > t->raw_cap) {
             (void)hipFree(t->raw_rgb); (void)hipFree(t->raw_depth); t->raw_rgb = nullptr; t->raw_depth = nullptr; t->raw_cap = 0;
@@ -858,10 +876,8 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
     }
     P.is_u16 = depth_fmt == OP_DEPTH_U16; P.depth_scale = cam->depth_scale; P.w = W; P.h = H;
     P.out[0] = pyr_image(t, 0, 0, 0); P.out[1] = pyr_image(t, 1, 0, 0); P.out[2] = pyr_image(t, 0, 1, 0); P.out[3] = pyr_image(t, 1, 1, 0);
-    const int n_wg0 = (int)((np + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(k_prep_convert_blur, dim3(n_wg0, 4), dim3(kThreads), 0, t->stream, P);
 
-    // level descriptors (Camera.h:38-42: intrinsics halved per level)
+    // level descriptors (Camera.h:38-42: intrinsics halved per level) + the NormalizeIntensity pass header
     TrackState* h = t->st_host_norm;
     float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
     for (int l = 0; l < n_levels; ++l) {
@@ -871,39 +887,84 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
         D.tcdx = pyr_image(t, 1, 2, l); D.tcdy = pyr_image(t, 1, 3, l); D.tddx = pyr_image(t, 1, 4, l); D.tddy = pyr_image(t, 1, 5, l);
         fx /= 2; fy /= 2; cx /= 2; cy /= 2;
     }
-    // NormalizeIntensity over the identity-pose correspondences of level 0 (Odometry.cpp:543-544).  Its state
-    // header is uploaded from its own pinned buffer, so the loop's header (st_host) can be prepared while this
-    // copy is still in flight: the whole call is enqueued without a host-side wait.
     {
         const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         std::memcpy(h->T, I4, sizeof(I4));
         h->full_w = W; h->full_h = H; h->term = 3; h->stop_level = -1;
         h->iters_done = 0; h->last_level = -1; h->n_last = 0; h->n_emit = 0; h->rmse = 0; h->success = 0;
-        OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
         std::memcpy(t->st_host->lv, h->lv, sizeof(h->lv));
+    }
+    fill_loop_header(t, W, H, term_type, init_T);
+
+    // One call = ~100 small launches.  With device-resident frames the sequence depends on the call only through
+    // the three pinned buffers filled above, so it is captured once into a hipGraph and replayed afterwards.
+    unsigned long long key[4] = {((unsigned long long)(unsigned)W << 32) | (unsigned)H,
+                                 ((unsigned long long)(unsigned)n_levels << 40) | ((unsigned long long)(unsigned)term_type << 32) |
+                                     ((unsigned long long)(unsigned)depth_fmt << 16) | (unsigned)t->lds_cap,
+                                 0ull, (unsigned long long)(uintptr_t)t->pyr ^ ((unsigned long long)(uintptr_t)t->pair_p << 1)};
+    for (int l = 0; l < n_levels; ++l) key[2] = key[2] * 1000003ull + (unsigned long long)(unsigned)iters_per_level[l] + 1ull;
+    const bool graph_path = t->graph_ok && mem == OP_MEM_DEVICE && !want_point_corr;
+    if (graph_path && t->graph_exec && std::memcmp(key, t->graph_key, sizeof(key)) == 0) {
+        OP_HIP(hipGraphLaunch(t->graph_exec, t->stream));
+        t->pending = true; t->pending_logs = false; t->pending_points = false;
+        return OP_OK;
+    }
+    bool capturing = false;
+    if (graph_path) {
+        if (t->graph_exec) { (void)hipGraphExecDestroy(t->graph_exec); t->graph_exec = nullptr; }
+        if (hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
+        else { (void)hipGetLastError(); t->graph_ok = 0; }
+    }
+    auto enqueue_all = [&]() -> int {
+        const int n_wg0 = (int)((np + kThreads - 1) / kThreads);
+        OP_HIP(hipMemcpyAsync(t->prep_dev, t->prep_host, sizeof(PrepFrames), hipMemcpyHostToDevice, t->stream));
+        hipLaunchKernelGGL(k_prep_convert_blur, dim3(n_wg0, 4), dim3(kThreads), 0, t->stream, (const PrepFrames*)t->prep_dev);
+        // NormalizeIntensity over the identity-pose correspondences of level 0 (Odometry.cpp:543-544).  Its state header
+        // is uploaded from its own pinned buffer (st_host_norm), the loop's from st_host: no host-side wait in between.
+        OP_HIP(hipMemcpyAsync(t->st, t->st_host_norm, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
         const IterGeom g = iter_geom(t, np);
         hipLaunchKernelGGL(k_track_assoc, dim3(n_wg0), dim3(kThreads), 0, t->stream, t->st, 0, t->pair_p, t->code);
         launch_iter<3>(t, 0, g);
         hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(1024), 0, t->stream, t->partials, g.n_wg, t->norm_scales);
         hipLaunchKernelGGL(k_norm_apply, dim3(n_wg0, 2), dim3(kThreads), 0, t->stream, pyr_image(t, 0, 0, 0), pyr_image(t, 1, 0, 0), (int)np,
                            t->norm_scales);
-    }
-    for (int l = 0; l < n_levels; ++l) {
-        const int w = W >> l, hh = H >> l;
-        if (l > 0) {
-            PrepImages D;
-            for (int f = 0; f < 2; ++f)
-                for (int k = 0; k < 2; ++k) { D.in[f * 2 + k] = pyr_image(t, f, k, l - 1); D.out[f * 2 + k] = pyr_image(t, f, k, l); }
-            D.w = W >> (l - 1); D.h = H >> (l - 1);
-            hipLaunchKernelGGL(k_prep_pyrdown, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, D);
+        for (int l = 0; l < n_levels; ++l) {
+            const int w = W >> l, hh = H >> l;
+            if (l > 0) {
+                PrepImages D;
+                for (int f = 0; f < 2; ++f)
+                    for (int k = 0; k < 2; ++k) { D.in[f * 2 + k] = pyr_image(t, f, k, l - 1); D.out[f * 2 + k] = pyr_image(t, f, k, l); }
+                D.w = W >> (l - 1); D.h = H >> (l - 1);
+                hipLaunchKernelGGL(k_prep_pyrdown, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, D);
+            }
+            PrepImages S;
+            S.in[0] = pyr_image(t, 1, 0, l); S.in[1] = pyr_image(t, 1, 1, l); S.in[2] = S.in[3] = nullptr;
+            S.out[0] = pyr_image(t, 1, 2, l); S.out[1] = pyr_image(t, 1, 3, l); S.out[2] = pyr_image(t, 1, 4, l); S.out[3] = pyr_image(t, 1, 5, l);
+            S.w = w; S.h = hh;
+            hipLaunchKernelGGL(k_prep_sobel, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, S);
         }
-        PrepImages S;
-        S.in[0] = pyr_image(t, 1, 0, l); S.in[1] = pyr_image(t, 1, 1, l); S.in[2] = S.in[3] = nullptr;
-        S.out[0] = pyr_image(t, 1, 2, l); S.out[1] = pyr_image(t, 1, 3, l); S.out[2] = pyr_image(t, 1, 4, l); S.out[3] = pyr_image(t, 1, 5, l);
-        S.w = w; S.h = hh;
-        hipLaunchKernelGGL(k_prep_sobel, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, S);
+        return track_enqueue(t, n_levels, iters_per_level, W, H, term_type, init_T, want_point_corr != 0, false);
+    };
+    const int rc = enqueue_all();
+    if (capturing) {
+        hipGraph_t graph = nullptr;
+        const hipError_t ec = hipStreamEndCapture(t->stream, &graph);
+        t->pending = false;
+        bool ok = rc == OP_OK && ec == hipSuccess && graph != nullptr;
+        if (ok) ok = hipGraphInstantiate(&t->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) {
+            std::memcpy(t->graph_key, key, sizeof(key));
+            OP_HIP(hipGraphLaunch(t->graph_exec, t->stream));
+            t->pending = true; t->pending_logs = false; t->pending_points = false;
+            return OP_OK;
+        }
+        // capture is not usable here: issue the launches directly from now on
+        (void)hipGetLastError();
+        t->graph_exec = nullptr; t->graph_ok = 0;
+        return enqueue_all();
     }
-    return track_enqueue(t, n_levels, iters_per_level, W, H, term_type, init_T, want_point_corr != 0, false);
+    return rc;
 }
 
 int op_tracker_wait(op_tracker* t, op_track_result* result, int32_t* pixel_corr, float* point_corr, size_t corr_cap) {
