@@ -358,6 +358,23 @@ def main():
         dense_fusion_pass(4)                # warm-up
         _s1, _nb1, dt_seq = dense_fusion_pass(1)
         slam, nb, dt = dense_fusion_pass(4)
+        if world == 1 and not args.no_cpu_baseline:
+            # the same pipeline on one host core (the reference's tracker and integrator are serial): 4 frames
+            from oracle import oracle as O
+            ocam = O.make_camera()
+            ovol = O.Volume(ocam, voxel_res=0.005)
+            hd, hc = depth[:4].cpu().numpy(), rgb[:4].cpu().numpy()
+            t0 = time.perf_counter()
+            gp = np.eye(4, dtype=np.float32)
+            ovol.integrate(hd[0], hc[0], gp)
+            for i in range(1, 4):
+                r = O.dense_tracking(ocam, hc[i - 1], hc[i], hd[i - 1], hd[i], (4, 8, 16), 0)
+                gp = DS._mat4_mul_f32(gp, O.mat4_inverse(r["T"]))
+                ovol.integrate(hd[i], hc[i], gp)
+            out["cpu_baseline"]["dense_fusion_frames_per_s"] = 4 / (time.perf_counter() - t0)
+            # pose chain parity on those frames (per-pair bar as in tests/test_odometry_gpu.py)
+            out["dense_fusion_parity_pose3_rel_err_vs_cpu"] = float(np.linalg.norm(np.asarray(slam.global_poses[3], np.float64) - gp) /
+                                                                    np.linalg.norm(gp.astype(np.float64)))
         g0 = np.linalg.inv(poses[0].astype(np.float64))
         drift = max(float(np.abs(np.asarray(slam.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max())
                     for i in range(n_df))
