@@ -61,30 +61,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// Wave-wide sums of 32 doubles per lane by recursive halving ("reduce-scatter"): at the step with lane
-// mask M a lane keeps one half of its values and receives the partner's copy of that half, so the work
-// halves every step (16+8+4+2+1+1 = 32 fp64 adds per lane instead of 29 x 6).  On return lane L holds in
-// v[0] the wave total of element (L >> 1) & 31.
-template <int H, int M>
-__device__ __forceinline__ void wave_halve(double (&v)[32], int lane) {
-    const bool up = (lane & M) != 0;
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const double keep = up ? v[i + H] : v[i];
-        const double give = up ? v[i] : v[i + H];
-        v[i] = keep + __shfl_xor(give, M, 64);
-    }
-}
-__device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
-    const int lane = threadIdx.x & 63;
-    wave_halve<16, 32>(v, lane);
-    wave_halve<8, 16>(v, lane);
-    wave_halve<4, 8>(v, lane);
-    wave_halve<2, 4>(v, lane);
-    wave_halve<1, 2>(v, lane);
-    v[0] += __shfl_xor(v[0], 1, 64);
-}
-
 __device__ __forceinline__ int cell_coord(float p, float o, float inv, int g) {
     int c = (int)floorf((p - o) * inv);
     return c < 0 ? 0 : (c >= g ? g - 1 : c);
@@ -321,7 +297,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     }
     // wave64 reduce-scatter, then LDS across the workgroup's waves, one partial per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    wave_reduce_scatter32(acc);
+    op::wave_reduce_scatter32(acc);
     if ((lane & 1) == 0) s_red[wave][lane >> 1] = acc[0];
     __syncthreads();
     if (threadIdx.x < kNSums) {

@@ -16,6 +16,11 @@
 //     acc(s) = ok(s) && ( p(s) >= s  ||  !acc(p(s))  ||  td(p(s)) > td(s) )
 // which only ever refers to a SMALLER raster index, so every thread resolves it independently by
 // walking p(.) until a link is decided without recursion; acc(s) is the parity of the walk length.
+//
+// op_tracker_dense_tracking additionally runs Odometry::DenseTracking's image preparation (k_prep_*,
+// NormalizeIntensity) on the device, and splits into _enqueue / op_tracker_wait so that several trackers
+// (one HIP stream each) keep independent frame pairs in flight; one call's ~100 launches are captured
+// into a hipGraph on first use and replayed afterwards.
 #include <cstddef>
 #include <cstdlib>
 
@@ -56,30 +61,6 @@ __device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 
 __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-
-// Wave-wide sums of 32 doubles per lane by recursive halving ("reduce-scatter"): at the step with
-// lane mask m a lane keeps one half of its values and receives the partner's copy of that half, so
-// the work halves every step (16+8+4+2+1+1 = 32 fp64 adds per lane instead of 32 x 6).  On return
-// lane L holds in v[0] the wave total of element (L >> 1) & 31.
-template <int H, int M>
-__device__ __forceinline__ void wave_halve(double (&v)[32], int lane) {
-    const bool up = (lane & M) != 0;
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const double keep = up ? v[i + H] : v[i];
-        const double give = up ? v[i] : v[i + H];
-        v[i] = keep + __shfl_xor(give, M, 64);
-    }
-}
-__device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
-    const int lane = threadIdx.x & 63;
-    wave_halve<16, 32>(v, lane);
-    wave_halve<8, 16>(v, lane);
-    wave_halve<4, 8>(v, lane);
-    wave_halve<2, 4>(v, lane);
-    wave_halve<1, 2>(v, lane);
-    v[0] += __shfl_xor(v[0], 1, 64);
 }
 
 // ---- association (DenseOdometryFunction.cpp:89-114) + the acceptance link of every pixel ---------
