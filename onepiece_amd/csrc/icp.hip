@@ -79,10 +79,19 @@ __global__ void k_bbox(const float* __restrict__ xyz, size_t m, unsigned* __rest
             mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o, 64));
             mn[c] = fminf(mn[c], __shfl_xor(mn[c], o, 64));
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMax(&box[c], enc_f(mx[c]));
-            atomicMin(&box[3 + c], enc_f(mn[c]));
-        }
+    }
+    // one atomic pair per workgroup and component (six hot addresses: per-wave atomics serialise badly)
+    __shared__ float s_mx[4][3], s_mn[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 3; ++c) { s_mx[wave][c] = mx[c]; s_mn[wave][c] = mn[c]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        float a = s_mx[0][c], b = s_mn[0][c];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { a = fmaxf(a, s_mx[w][c]); b = fminf(b, s_mn[w][c]); }
+        atomicMax(&box[c], enc_f(a));
+        atomicMin(&box[3 + c], enc_f(b));
     }
 }
 
@@ -640,7 +649,7 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     OP_HIP_C(hipMalloc((void**)&d_box, 6 * sizeof(unsigned)));
     unsigned init[6] = {0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     OP_HIP_C(hipMemcpy(d_box, init, sizeof(init), hipMemcpyHostToDevice));
-    if (m) hipLaunchKernelGGL(k_bbox, dim3(512), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, d_box);
+    if (m) hipLaunchKernelGGL(k_bbox, dim3(128), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, d_box);
     OP_HIP_C(hipStreamSynchronize(c->stream));
     unsigned box[6];
     OP_HIP_C(hipMemcpy(box, d_box, sizeof(box), hipMemcpyDeviceToHost));
