@@ -213,6 +213,18 @@ int op_icp_register(int mode, const float *src_xyz, size_t n, const float *tgt_x
                     const float *tgt_normals, size_t m, const float init_T[16], int max_iteration,
                     double threshold, int device, op_icp_result *result, int32_t *pairs,
                     size_t pairs_cap);
+/* registration::EstimateRigidTransformationPointToPlane (ICP.h:24-26, ICP.cpp:108-144): one Gauss-Newton
+ * step over caller-supplied inliers (n x 2 int32: source id, target id); source = the ALREADY transformed
+ * points, as the reference's loop passes them.  Sums on the device (fp64), JacobiSVD-semantics solve +
+ * SE3 exp on the host. */
+int op_estimate_rigid_point_to_plane(const float *source_xyz, size_t n_source, const float *target_xyz,
+                                     const float *target_normals, size_t n_target,
+                                     const int32_t *inliers, size_t n_inliers, int mem, int device,
+                                     float T[16]);
+/* geometry::EstimateRigidTransformation (Geometry/Geometry.cpp:107-151): Kabsch fit of a correspondence set
+ * given as n x 6 floats (source xyz, target xyz). */
+int op_estimate_rigid_transformation(const float *pairs_xyz6, size_t n_pairs, int mem, int device,
+                                     float T[16]);
 /* PointCloud::LoadFromDepth (Geometry/PointCloud.cpp:72-100) on the device: xyz_out (mem) gets the
  * compacted row-major-ordered points; *n the count. */
 int op_points_from_depth(const op_camera *cam, const void *depth, int depth_fmt, int mem, int device,

@@ -316,6 +316,54 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     }
 }
 
+
+// Sums over an EXPLICIT correspondence list -- registration::EstimateRigidTransformationPointToPlane
+// (ICP.cpp:108-144; MODE 1: rows [n ; s x n], r = n.s - n.t over inliers (source id, target id)) and
+// geometry::EstimateRigidTransformation (Geometry.cpp:107-151; MODE 0: sum s, sum t, sum s t^T over point
+// pairs given as 6 floats each).  Same accumulation and reduction as k_icp_iter.
+template <int MODE>
+__global__ __launch_bounds__(kIterThreads) void k_pair_sums(const float* __restrict__ src, const float* __restrict__ tgt, const float* __restrict__ nrm,
+                                                            const int* __restrict__ inliers, size_t n, double* __restrict__ partials) {
+    __shared__ double s_red[kIterThreads / 64][kNSums];
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (MODE == 1) {
+            const size_t a = (size_t)inliers[2 * i], b = (size_t)inliers[2 * i + 1];
+            const float s0 = src[3 * a], s1 = src[3 * a + 1], s2 = src[3 * a + 2];
+            const float t0 = tgt[3 * b], t1 = tgt[3 * b + 1], t2 = tgt[3 * b + 2];
+            const float n0 = nrm[3 * b], n1 = nrm[3 * b + 1], n2 = nrm[3 * b + 2];
+            const float r = sum3(n0 * s0, n1 * s1, n2 * s2) - sum3(n0 * t0, n1 * t1, n2 * t2);
+            const float row[6] = {n0, n1, n2, s1 * n2 - s2 * n1, s2 * n0 - s0 * n2, s0 * n1 - s1 * n0};
+            int k = 0;
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int q = p; q < 6; ++q) acc[k++] += (double)(row[p] * row[q]);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) acc[21 + p] += (double)(r * row[p]);
+        } else {
+            const float a0 = src[6 * i], a1 = src[6 * i + 1], a2 = src[6 * i + 2], t0 = src[6 * i + 3], t1 = src[6 * i + 4], t2 = src[6 * i + 5];
+            acc[0] += a0; acc[1] += a1; acc[2] += a2;
+            acc[3] += t0; acc[4] += t1; acc[5] += t2;
+            acc[6] += (double)a0 * t0; acc[7] += (double)a0 * t1; acc[8] += (double)a0 * t2;
+            acc[9] += (double)a1 * t0; acc[10] += (double)a1 * t1; acc[11] += (double)a1 * t2;
+            acc[12] += (double)a2 * t0; acc[13] += (double)a2 * t1; acc[14] += (double)a2 * t2;
+        }
+        acc[28] += 1.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    op::wave_reduce_scatter32(acc);
+    if ((lane & 1) == 0) s_red[wave][lane >> 1] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double v = 0;
+        for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
+    }
+}
+
 // Second pass, stage 1: kStage1 workgroups each fold a contiguous slice of the per-workgroup
 // partials (deterministic order), so the final single-workgroup kernel only sees kStage1 rows.
 constexpr int kStage1 = 32;
@@ -851,6 +899,59 @@ int op_icp_register(int mode, const float* src_xyz, size_t n, const float* tgt_x
     if (rc == OP_OK) rc = op_icp_run(c, mode, init_T, max_iteration, result, pairs, pairs_cap, nullptr, nullptr);
     op_icp_destroy(c);
     return rc;
+}
+
+
+// The two estimators of the registration module as stand-alone calls over caller-supplied correspondences.
+static int pair_sums_run(int mode, const float* a, size_t na_floats, const float* b, size_t nb_floats, const float* nrm, const int32_t* inliers,
+                         size_t n, int mem, int device, double out[kNSums]) {
+    OP_TRY(op::use_device(device));
+    const int n_wg = 256;
+    float *d_a = nullptr, *d_b = nullptr, *d_n = nullptr;
+    int* d_i = nullptr;
+    double *d_part = nullptr, *d_out = nullptr;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void* src, size_t bytes, void** dst) {
+        if (e != hipSuccess || !src || !bytes) return;
+        if (mem == OP_MEM_DEVICE) { *dst = const_cast<void*>(src); return; }
+        e = hipMalloc(dst, bytes);
+        if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    up(a, na_floats * 4, (void**)&d_a); up(b, nb_floats * 4, (void**)&d_b); up(nrm, nb_floats * 4, (void**)&d_n); up(inliers, n * 8, (void**)&d_i);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_part, (size_t)n_wg * kNSums * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, kNSums * sizeof(double));
+    if (e == hipSuccess) {
+        if (mode == 1) hipLaunchKernelGGL(k_pair_sums<1>, dim3(n_wg), dim3(kIterThreads), 0, nullptr, (const float*)d_a, (const float*)d_b, (const float*)d_n, (const int*)d_i, n, d_part);
+        else hipLaunchKernelGGL(k_pair_sums<0>, dim3(n_wg), dim3(kIterThreads), 0, nullptr, (const float*)d_a, (const float*)nullptr, (const float*)nullptr, (const int*)nullptr, n, d_part);
+        hipLaunchKernelGGL(k_reduce_update, dim3(1), dim3(1024), 0, nullptr, (const double*)d_part, n_wg, d_out, 0, (float*)nullptr, 0, (int*)nullptr,
+                           (float*)nullptr, (double*)nullptr, 0.0);
+        e = hipMemcpy(out, d_out, kNSums * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    if (mem != OP_MEM_DEVICE) { (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_n); (void)hipFree(d_i); }
+    (void)hipFree(d_part); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "pair sums failed: %s", hipGetErrorString(e));
+    return OP_OK;
+}
+
+int op_estimate_rigid_point_to_plane(const float* source_xyz, size_t n_source, const float* target_xyz, const float* target_normals, size_t n_target,
+                                     const int32_t* inliers, size_t n_inliers, int mem, int device, float T[16]) {
+    if (!T || (n_inliers && (!source_xyz || !target_xyz || !target_normals || !inliers))) return fail(OP_ERR_INVALID, "null argument");
+    double r[kNSums] = {0};
+    if (n_inliers) OP_TRY(pair_sums_run(1, source_xyz, n_source * 3, target_xyz, n_target * 3, target_normals, inliers, n_inliers, mem, device, r));
+    double JTJ[36], JTr[6];
+    float x[6];
+    expand_plane_sums(r, JTJ, JTr);
+    op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
+    op_host::se3_exp(x, T);            // ICP.cpp:143
+    return OP_OK;
+}
+
+int op_estimate_rigid_transformation(const float* pairs_xyz6, size_t n_pairs, int mem, int device, float T[16]) {
+    if (!T || (n_pairs && !pairs_xyz6)) return fail(OP_ERR_INVALID, "null argument");
+    double r[kNSums] = {0};
+    if (n_pairs) OP_TRY(pair_sums_run(0, pairs_xyz6, n_pairs * 6, nullptr, 0, nullptr, nullptr, n_pairs, mem, device, r));
+    op_host::kabsch_from_sums(r[28], r, r + 3, r + 6, T); // Geometry.cpp:107-151
+    return OP_OK;
 }
 
 int op_points_from_depth(const op_camera* cam, const void* depth, int depth_fmt, int mem, int device, float* xyz_out, size_t* n) {

@@ -225,8 +225,22 @@ class CubeHandler:
         voxels = _f32(voxels).reshape(-1, 512, 5)
         L.check(self._lib.op_volume_upload(self._h, _ip(keys), _fp(voxels), keys.shape[0]))
 
-    def Merge(self, another):
-        """CubeHandler.h:145-167: mismatching resolution -> warning line, no change."""
+    def AddCube(self, cube_id):
+        """CubeHandler::AddCube (CubeHandler.h:191-197): a default block (sdf 999, weight 0, colour -1) unless present."""
+        if self.HasCube(cube_id):
+            return
+        vox = np.empty((1, 512, 5), np.float32)
+        vox[..., 0], vox[..., 1], vox[..., 2:] = 999.0, 0.0, -1.0
+        self.AddCubes(np.asarray(cube_id, np.int32).reshape(1, 3), vox)
+
+    def Merge(self, another, trans=None):
+        """CubeHandler::Merge (CubeHandler.h:145-177): mismatching resolution -> warning line, no change.
+        With `trans`: Merge(*another.Transform(trans)) (:168-177)."""
+        if trans is not None:
+            if another.GetVoxelResolution() != self.GetVoxelResolution():
+                print("[Warning]::[MergeVoxelHash]::Voxel resolution is not identical.")
+                return
+            another = another.Transform(trans)
         rc = self._lib.op_volume_merge(self._h, another._h)
         if rc == L.OP_ERR_MISMATCH:
             print(self._lib.op_last_error().decode())

@@ -127,3 +127,24 @@ def Se3ToSE3(x):
     T = np.empty(16, np.float32)
     L.check(L.load().op_se3_exp(_fp(x), _fp(T)))
     return T.reshape(4, 4)
+
+
+def EstimateRigidTransformationPointToPlane(source, target, target_normal, inliers, device=0):
+    """registration::EstimateRigidTransformationPointToPlane (ICP.h:24-26): one point-to-plane step over the
+    given inliers (n x 2: source id, target id); `source` = the already transformed points."""
+    src = np.ascontiguousarray(source, np.float32).reshape(-1, 3)
+    tgt = np.ascontiguousarray(target, np.float32).reshape(-1, 3)
+    nrm = np.ascontiguousarray(target_normal, np.float32).reshape(-1, 3)
+    inl = np.ascontiguousarray(inliers, np.int32).reshape(-1, 2)
+    T = np.empty(16, np.float32)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    L.check(L.load().op_estimate_rigid_point_to_plane(vp(src), len(src), vp(tgt), vp(nrm), len(tgt), vp(inl), len(inl), L.OP_MEM_HOST, device, _fp(T)))
+    return T.reshape(4, 4)
+
+
+def EstimateRigidTransformation(correspondence_set, device=0):
+    """geometry::EstimateRigidTransformation (Geometry.cpp:107-151): Kabsch over (n, 2, 3) point pairs."""
+    pairs = np.ascontiguousarray(correspondence_set, np.float32).reshape(-1, 6)
+    T = np.empty(16, np.float32)
+    L.check(L.load().op_estimate_rigid_transformation(C.c_void_p(pairs.ctypes.data), len(pairs), L.OP_MEM_HOST, device, _fp(T)))
+    return T.reshape(4, 4)

@@ -136,3 +136,29 @@ def test_returned_T_is_the_exact_kabsch_of_the_returned_pairs(oracle):
     T64 = np.eye(4); T64[:3, :3] = Rm; T64[:3, 3] = mt - Rm @ ms
     assert rel_err(got.T, T64) <= 1e-6
     assert abs(len(p) - len(ref["pairs"])) <= 1e-4 * len(src)
+
+
+def test_standalone_estimators_match_oracle(oracle):
+    """registration::EstimateRigidTransformationPointToPlane (ICP.cpp:108-144) and
+    geometry::EstimateRigidTransformation (Geometry.cpp:107-151) over caller-supplied correspondences."""
+    import ctypes as C
+    from oracle import oracle as O
+    _, tgt, nrm = room_cloud(100, scale=4)
+    x = np.array([0.003, -0.002, 0.0015, 0.002, -0.001, 0.0015], np.float32)
+    Tx = oracle.se3_exp(x).astype(np.float64)
+    src = (tgt @ Tx[:3, :3].T + Tx[:3, 3]).astype(np.float32)
+    rng = np.random.default_rng(5)
+    ids = rng.permutation(len(src))[: len(src) // 2].astype(np.int32)
+    inl = np.stack([ids, ids], 1).astype(np.int32)
+    got = R.EstimateRigidTransformationPointToPlane(src, tgt, nrm, inl)
+    T = np.empty(16, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    O.lib().orc_p2plane_step(fp(src), fp(tgt), fp(nrm), inl.ctypes.data_as(C.POINTER(C.c_int32)), len(inl), fp(T), None, None)
+    assert rel_err(got, T.reshape(4, 4)) <= POSE_TOL
+    pairs = np.concatenate([src[ids], tgt[ids]], 1).astype(np.float32)
+    gotk = R.EstimateRigidTransformation(pairs.reshape(-1, 2, 3))
+    refk = oracle.kabsch(src[ids], tgt[ids])
+    assert rel_err(gotk, refk) <= POSE_TOL
+    assert rel_err(gotk, np.linalg.inv(Tx)) <= 1e-5      # exact correspondences -> the inverse motion
+    # empty sets: zero normal equations -> identity step (JacobiSVD solve of 0 is 0)
+    assert np.array_equal(R.EstimateRigidTransformationPointToPlane(src, tgt, nrm, np.zeros((0, 2), np.int32)), np.eye(4, dtype=np.float32))
