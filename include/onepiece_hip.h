@@ -230,6 +230,11 @@ int op_estimate_rigid_transformation(const float *pairs_xyz6, size_t n_pairs, in
 int op_points_from_depth(const op_camera *cam, const void *depth, int depth_fmt, int mem, int device,
                          float *xyz_out, size_t *n);
 
+/* PointCloud::LoadFromRGBD (Geometry/PointCloud.cpp:17-48): the same compaction plus colours =
+ * (b0,b1,b2)/255 in stored channel order (n x 3 floats). */
+int op_points_from_rgbd(const op_camera *cam, const void *depth, int depth_fmt, const uint8_t *rgb,
+                        int mem, int device, float *xyz_out, float *colors_out, size_t *n);
+
 /* PointCloud::EstimateNormals(radius, knn) (Geometry/PointCloud.cpp:102-144) on the device: exact
  * knn nearest neighbours (knn <= 32), the prefix whose SQUARED distance is <= radius (the
  * reference's KnnRadiusSearch, KDTree.h:230-255), PCA plane fit (geometry::FitPlane,

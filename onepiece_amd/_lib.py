@@ -112,6 +112,7 @@ SIGNATURES = {
     "op_estimate_normals": (C.c_int, [_vp, C.c_size_t, C.c_float, C.c_int, C.c_int, C.c_int, _vp]),
     "op_estimate_rigid_point_to_plane": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, _fp]),
     "op_estimate_rigid_transformation": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_int, _fp]),
+    "op_points_from_rgbd": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _szp]),
     "op_points_from_depth": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, C.c_int, C.c_int, _vp, _szp]),
     "op_tracker_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "op_tracker_destroy": (C.c_int, [_vp]),

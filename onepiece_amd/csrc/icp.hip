@@ -560,7 +560,8 @@ __global__ __launch_bounds__(256) void k_depth_count(const void* __restrict__ de
     count[i] = z > 0 ? 1u : 0u;
 }
 __global__ __launch_bounds__(256) void k_depth_scatter(const void* __restrict__ depth, int is_u16, op_camera cam, size_t npix,
-                                                       const unsigned* __restrict__ start, float* __restrict__ xyz) {
+                                                       const unsigned* __restrict__ start, float* __restrict__ xyz,
+                                                       const unsigned char* __restrict__ rgb, float* __restrict__ colors) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const float z = is_u16 ? (float)((const unsigned short*)depth)[i] / cam.depth_scale : ((const float*)depth)[i];
@@ -570,6 +571,11 @@ __global__ __launch_bounds__(256) void k_depth_scatter(const void* __restrict__ 
     xyz[3 * p] = ((float)c - cam.cx) * z / cam.fx; // PointCloud.cpp:90-93
     xyz[3 * p + 1] = ((float)r - cam.cy) * z / cam.fy;
     xyz[3 * p + 2] = z;
+    if (colors) { // LoadFromRGBD (PointCloud.cpp:40-42): Point3(b0,b1,b2) / 255.0f in stored channel order
+        colors[3 * p] = (float)rgb[3 * i] / 255.0f;
+        colors[3 * p + 1] = (float)rgb[3 * i + 1] / 255.0f;
+        colors[3 * p + 2] = (float)rgb[3 * i + 2] / 255.0f;
+    }
 }
 
 int device_exclusive_scan(const unsigned* d_count, size_t n, unsigned* d_start, hipStream_t stream, unsigned* total_out) {
@@ -954,15 +960,18 @@ int op_estimate_rigid_transformation(const float* pairs_xyz6, size_t n_pairs, in
     return OP_OK;
 }
 
-int op_points_from_depth(const op_camera* cam, const void* depth, int depth_fmt, int mem, int device, float* xyz_out, size_t* n) {
-    if (!cam || !depth || !xyz_out || !n) return fail(OP_ERR_INVALID, "null argument");
+static int points_from_images(const op_camera* cam, const void* depth, int depth_fmt, const uint8_t* rgb, int mem, int device, float* xyz_out,
+                              float* colors_out, size_t* n) {
+    if (!cam || !depth || !xyz_out || !n || ((rgb == nullptr) != (colors_out == nullptr))) return fail(OP_ERR_INVALID, "null argument");
     if (cam->width <= 0 || cam->height <= 0) return fail(OP_ERR_INVALID, "invalid camera");
     OP_TRY(op::use_device(device));
     const size_t npix = (size_t)cam->width * cam->height;
     const size_t dbytes = npix * (depth_fmt == OP_DEPTH_U16 ? 2 : 4);
     void* d_depth = nullptr;
     unsigned *d_count = nullptr, *d_start = nullptr;
-    float* d_xyz = nullptr;
+    float *d_xyz = nullptr, *d_col = nullptr;
+    unsigned char* d_rgb = nullptr;
+    const unsigned char* rsrc = rgb;
     int rc = OP_OK;
     hipError_t e = hipSuccess;
     const void* dsrc = depth;
@@ -974,6 +983,12 @@ int op_points_from_depth(const op_camera* cam, const void* depth, int depth_fmt,
     if (e == hipSuccess) e = hipMalloc((void**)&d_count, npix * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&d_start, npix * 4);
     if (e == hipSuccess && mem == OP_MEM_HOST) e = hipMalloc((void**)&d_xyz, npix * 12);
+    if (e == hipSuccess && mem == OP_MEM_HOST && rgb) {
+        e = hipMalloc((void**)&d_col, npix * 12);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_rgb, npix * 3);
+        if (e == hipSuccess) e = hipMemcpy(d_rgb, rgb, npix * 3, hipMemcpyHostToDevice);
+        rsrc = d_rgb;
+    }
     unsigned total = 0;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_depth_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, nullptr, dsrc, depth_fmt == OP_DEPTH_U16,
@@ -981,20 +996,34 @@ int op_points_from_depth(const op_camera* cam, const void* depth, int depth_fmt,
         rc = device_exclusive_scan(d_count, npix, d_start, nullptr, &total);
         if (rc == OP_OK) {
             float* dst = mem == OP_MEM_HOST ? d_xyz : xyz_out;
+            float* cdst = rgb ? (mem == OP_MEM_HOST ? d_col : colors_out) : nullptr;
             hipLaunchKernelGGL(k_depth_scatter, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, nullptr, dsrc, depth_fmt == OP_DEPTH_U16, *cam,
-                               npix, (const unsigned*)d_start, dst);
+                               npix, (const unsigned*)d_start, dst, rsrc, cdst);
             e = hipDeviceSynchronize();
             if (e == hipSuccess && mem == OP_MEM_HOST && total) e = hipMemcpy(xyz_out, d_xyz, (size_t)total * 12, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && mem == OP_MEM_HOST && total && rgb) e = hipMemcpy(colors_out, d_col, (size_t)total * 12, hipMemcpyDeviceToHost);
         }
     }
     if (d_depth) (void)hipFree(d_depth);
     if (d_count) (void)hipFree(d_count);
     if (d_start) (void)hipFree(d_start);
     if (d_xyz) (void)hipFree(d_xyz);
+    if (d_col) (void)hipFree(d_col);
+    if (d_rgb) (void)hipFree(d_rgb);
     if (rc != OP_OK) return rc;
     if (e != hipSuccess) return fail(OP_ERR_HIP, "points_from_depth failed: %s", hipGetErrorString(e));
     *n = total;
     return OP_OK;
+}
+
+int op_points_from_depth(const op_camera* cam, const void* depth, int depth_fmt, int mem, int device, float* xyz_out, size_t* n) {
+    return points_from_images(cam, depth, depth_fmt, nullptr, mem, device, xyz_out, nullptr, n);
+}
+
+int op_points_from_rgbd(const op_camera* cam, const void* depth, int depth_fmt, const uint8_t* rgb, int mem, int device, float* xyz_out,
+                        float* colors_out, size_t* n) {
+    if (!rgb || !colors_out) return fail(OP_ERR_INVALID, "null argument");
+    return points_from_images(cam, depth, depth_fmt, rgb, mem, device, xyz_out, colors_out, n);
 }
 
 int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int mem, int device, float* normals_out) {

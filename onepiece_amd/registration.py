@@ -50,6 +50,20 @@ class PointCloud:
         return PointCloud(xyz[:n.value].copy())
 
 
+def LoadFromRGBD(rgb, depth, camera, device=0):
+    """PointCloud::LoadFromRGBD (Geometry/PointCloud.cpp:17-48) on the GPU -> (PointCloud, colors [n,3])."""
+    from .integration import _image_arg
+    p, fmt, mem, _k0 = _image_arg(depth, "depth")
+    c, _, memc, _k1 = _image_arg(rgb, "rgb")
+    if mem != L.OP_MEM_HOST or memc != L.OP_MEM_HOST:
+        raise ValueError("LoadFromRGBD mirror takes host images")
+    npix = camera.width * camera.height
+    xyz, col = np.empty((npix, 3), np.float32), np.empty((npix, 3), np.float32)
+    n = C.c_size_t(0)
+    L.check(L.load().op_points_from_rgbd(C.byref(camera), p, fmt, c, mem, device, C.c_void_p(xyz.ctypes.data), C.c_void_p(col.ctypes.data), C.byref(n)))
+    return PointCloud(xyz[:n.value].copy()), col[:n.value].copy()
+
+
 class RegistrationResult:
     """registration::RegistrationResult (RegistrationResult.h:9-16)."""
 

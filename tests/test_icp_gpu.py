@@ -162,3 +162,20 @@ def test_standalone_estimators_match_oracle(oracle):
     assert rel_err(gotk, np.linalg.inv(Tx)) <= 1e-5      # exact correspondences -> the inverse motion
     # empty sets: zero normal equations -> identity step (JacobiSVD solve of 0 is 0)
     assert np.array_equal(R.EstimateRigidTransformationPointToPlane(src, tgt, nrm, np.zeros((0, 2), np.int32)), np.eye(4, dtype=np.float32))
+
+
+def test_load_from_rgbd_matches(oracle):
+    """PointCloud::LoadFromRGBD (PointCloud.cpp:17-48): the points of LoadFromDepth plus colours = stored bytes / 255
+    (float division) for exactly the kept pixels, in raster order."""
+    cam = small_camera(2)
+    from onepiece_amd import synthetic as SY
+    depth, rgb = SY.room_render(SY.room_pose(23), width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+    depth = depth.copy(); depth[20:50, 30:120] = 0; depth[::7, ::5] = -2
+    hcam = I.PinholeCamera()
+    hcam.fx, hcam.fy, hcam.cx, hcam.cy, hcam.width, hcam.height, hcam.depth_scale = cam
+    pc, col = R.LoadFromRGBD(rgb, depth, hcam)
+    ref = oracle.load_from_depth(oracle.make_camera(*cam), depth)
+    assert np.array_equal(pc.points.view(np.uint32), ref.view(np.uint32))
+    keep = depth.reshape(-1) > 0
+    exp = (rgb.reshape(-1, 3)[keep].astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    assert col.shape == exp.shape and np.array_equal(col.view(np.uint32), exp.view(np.uint32))
