@@ -53,6 +53,12 @@ inline int IntegrateImage(op_volume* vol, const Image& depth, const Image& rgb, 
     return op_volume_integrate(vol, depth.data, fmt, reinterpret_cast<const uint8_t*>(rgb.data), OP_MEM_HOST, p, pi);
 }
 
+// CubeHandler::IntegrateImage(const geometry::RGBDFrame&, pose) (CubeHandler.cpp:211-214): rgbd.depth / rgbd.rgb.
+template <class Frame, class Mat4>
+inline int IntegrateFrame(op_volume* vol, const Frame& rgbd, const Mat4& pose, const Mat4& pose_inv) {
+    return IntegrateImage(vol, rgbd.depth, rgbd.rgb, pose, pose_inv);
+}
+
 // CubeHandler::PrepareCubes (CubeHandler.cpp:147-196): fills cube_id_list in the reference's order.
 template <class CubeID, class Image, class Mat4>
 inline int PrepareCubes(op_volume* vol, const Image& depth, const Mat4& pose, const Mat4& pose_inv, std::vector<CubeID>& cube_id_list) {

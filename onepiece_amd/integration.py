@@ -151,6 +151,10 @@ class CubeHandler:
         if mem == L.OP_MEM_DEVICE:
             self._alive.append((_k1, _k2))
 
+    def IntegrateFrame(self, rgbd, pose, pose_inv=None):
+        """CubeHandler::IntegrateImage(const geometry::RGBDFrame&, pose) (CubeHandler.cpp:211-214)."""
+        return self.IntegrateImage(rgbd.depth, rgbd.rgb, pose, pose_inv)
+
     def IntegrateSequence(self, depth, rgb, poses):
         """n frames resident on the device (torch tensors [n,h,w] / [n,h,w,3]); identical to n
         IntegrateImage calls in order (example/ImageSequenceIntegration.cpp:27-42)."""
