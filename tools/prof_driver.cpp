@@ -2,11 +2,14 @@
 // when the profiled process is python+torch).  Reads a frame dump written by tools/dump_frames.py:
 //   int32 n, w, h;  then n x { float pose[16]; float depth[w*h]; uint8 rgb[w*h*3] }
 // uploads the frames to HBM once, then fuses them `reps` times into a fresh 5 mm volume.
+// With a 5th argument "track": instead tracks every consecutive frame pair (op_tracker_dense_tracking, device
+// frames) and fuses each frame with its TRACKED pose -- the config-4 pipeline, one pair at a time.
 // Build: hipcc -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o gpurun_out/prof_driver
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "onepiece_hip.h"
 
@@ -37,6 +40,37 @@ int main(int argc, char** argv) {
     op_camera cam; CK(op_camera_preset(1, &cam));
     cam.width = w; cam.height = h;
     op_volume* v; CK(op_volume_create(&cam, voxel, 0.1f, 5.0f, 0.5f, 0, 1u << 18, &v));
+    const bool track = argc > 4 && std::string(argv[4]) == "track";
+    if (track) {
+        op_tracker* trk; CK(op_tracker_create(0, &trk));
+        const int32_t iters[3] = {4, 8, 16};
+        const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int r = 0; r < reps; ++r) {
+            CK(op_volume_clear(v));
+            float g[16]; for (int k = 0; k < 16; ++k) g[k] = I4[k];
+            auto t0 = std::chrono::steady_clock::now();
+            CK(op_volume_integrate(v, d_depth, OP_DEPTH_F32, d_rgb, OP_MEM_DEVICE, g, nullptr));
+            int ok = 1;
+            for (int i = 1; i < n; ++i) {
+                op_track_result res;
+                CK(op_tracker_dense_tracking(trk, &cam, 3, iters, d_rgb + npx * 3 * (i - 1), d_rgb + npx * 3 * i, d_depth + npx * (i - 1), d_depth + npx * i,
+                                             OP_DEPTH_F32, I4, OP_TRACK_HYBRID, OP_MEM_DEVICE, &res, nullptr, nullptr, 0));
+                ok += res.tracking_success;
+                float inv[16], ng[16];                      // global = global_last * T^-1 (DenseSlam.cpp:31)
+                CK(op_mat4_inverse(res.T, inv));
+                for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) ng[a * 4 + b] = ((g[a * 4] * inv[b] + g[a * 4 + 1] * inv[4 + b]) + g[a * 4 + 2] * inv[8 + b]) + g[a * 4 + 3] * inv[12 + b];
+                for (int k = 0; k < 16; ++k) g[k] = ng[k];
+                CK(op_volume_integrate(v, d_depth + npx * i, OP_DEPTH_F32, d_rgb + npx * 3 * i, OP_MEM_DEVICE, g, nullptr));
+            }
+            CK(op_volume_sync(v));
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            size_t nb; CK(op_volume_block_count(v, &nb));
+            printf("rep %d: tracked %d/%d frames, %.3f ms/frame (tracking + fusion), blocks %zu, final t = (%.4f %.4f %.4f)\n", r, ok, n, dt / n * 1e3, nb, g[3], g[7], g[11]);
+        }
+        op_tracker_destroy(trk);
+        op_volume_destroy(v);
+        return 0;
+    }
     for (int r = 0; r < reps; ++r) {
         CK(op_volume_clear(v));
         auto t0 = std::chrono::steady_clock::now();
