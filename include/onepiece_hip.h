@@ -155,6 +155,18 @@ int op_volume_resolution(op_volume *v, float *voxel_res);
 /* CubeHandler::GetPointCloud (CubeHandler.cpp:45-69): points and grey colours |sdf|/truncation
  * (n x 3 floats each, host).  *n is the full count; xyz/colors may be NULL to query it. */
 int op_volume_point_cloud(op_volume *v, float *xyz, float *colors, size_t cap, size_t *n);
+/* CubeHandler::ExtractTriangleMesh (Integration/CubeHandler.cpp:9-44) = GenerateMeshByCube (:70-114) over
+ * every block + MarchingCube (MarchingCube.cpp:8-74), on the device.  tri_table (256 x 16 int32, rows of edge
+ * ids terminated by -1) and edge_pairs (12 x 2 corner ids) are the CALLER'S tables -- in the reference they are
+ * `MCLookTable` / `EdgeIndexPairs` of MarchingCubePredefined.h, which its shim passes straight through (the
+ * library neither contains nor assumes a particular table).  Output: three unshared vertices per triangle
+ * (triangle k = vertices 3k..3k+2), points and colours as n x 3 floats, exactly as MarchingCube() pushes them;
+ * blocks in pool order (the reference's order is its unordered_map's), voxels in the x, y, z loop order.
+ * only_block: NULL, or the one CubeID to mesh (= GenerateMeshByCube).  points/colors may be NULL to query
+ * *n_vertices. */
+int op_volume_extract_mesh(op_volume *v, const int32_t *tri_table, const int32_t *edge_pairs,
+                           const int32_t *only_block, float *points, float *colors,
+                           size_t cap_vertices, size_t *n_vertices);
 /* CubeHandler::WriteToFile / ReadFromFile / ReadFromFileFloat (CubeHandler.h:40-128): the .map
  * float-stream format (VoxelCube.h:128-193).  Blocks are written in pool order. */
 int op_volume_write_file(op_volume *v, const char *path);

@@ -94,6 +94,7 @@ SIGNATURES = {
     "op_volume_transform": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_uint64, C.POINTER(_vp)]),
     "op_volume_resolution": (C.c_int, [_vp, _fp]),
     "op_volume_point_cloud": (C.c_int, [_vp, _fp, _fp, C.c_size_t, _szp]),
+    "op_volume_extract_mesh": (C.c_int, [_vp, _ip, _ip, _ip, _fp, _fp, C.c_size_t, _szp]),
     "op_volume_write_file": (C.c_int, [_vp, C.c_char_p]),
     "op_volume_read_file": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "op_volume_raycast": (C.c_int, [_vp, C.POINTER(Camera), _fp, _fp, _fp, _fp, C.c_int]),

@@ -809,6 +809,92 @@ __global__ __launch_bounds__(512) void k_point_cloud(VolView V, float res, float
     col[3 * pos] = f; col[3 * pos + 1] = f; col[3 * pos + 2] = f;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Mesh extraction: CubeHandler::ExtractTriangleMesh / GenerateMeshByCube (CubeHandler.cpp:9-114) +
+// MarchingCube (MarchingCube.cpp:8-74).  One workgroup per block, one thread per voxel in the reference's
+// x, y, z loop order; the 7 neighbour blocks a voxel on the +x/+y/+z faces needs are looked up once per
+// workgroup.  The 256 x 16 triangle table and the 12 x 2 edge table are the CALLER'S data (the reference
+// keeps them in MarchingCubePredefined.h; its shim passes them through the C-ABI), staged in LDS.
+// Two passes with the same kernel: counts (triangles per block) and, after a scan, the ordered emit of
+// three unshared vertices per triangle, exactly as MarchingCube() pushes them.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const int* __restrict__ tri_table, const int* __restrict__ edge_pairs,
+                                              const unsigned* __restrict__ blocks, unsigned* __restrict__ counts,
+                                              const unsigned* __restrict__ offsets, float* __restrict__ pts, float* __restrict__ col) {
+    __shared__ int s_tri[256 * 16];
+    __shared__ int s_edge[24];
+    __shared__ int s_nb[8];
+    __shared__ unsigned s_w[8];
+    const int b = (int)blocks[blockIdx.x], o = threadIdx.x;
+    for (int k = o; k < 256 * 16; k += 512) s_tri[k] = tri_table[k];
+    if (o < 24) s_edge[o] = edge_pairs[o];
+    const int kx = V.keys[3 * b], ky = V.keys[3 * b + 1], kz = V.keys[3 * b + 2];
+    if (o < 8) s_nb[o] = o == 0 ? b : table_find(V, kx + (o & 1), ky + ((o >> 1) & 1), kz + ((o >> 2) & 1)); // HasCube(neighbor_cube_id)
+    __syncthreads();
+    const int x = o >> 6, y = (o >> 3) & 7, z = o & 7;    // loop nest: x outer, y, z inner
+    const int ox = x == 7, oy = y == 7, oz = z == 7;      // NeighborCubeIDOffset[index]
+    const float cube_res = 8.0f * res, half = res / 2;    // VoxelCube.h:149-153, :48-61
+    float cp[8][3], cs[8], cc[8][3];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int xo = (i == 1 || i == 2 || i == 5 || i == 6), yo = (i == 2 || i == 3 || i == 6 || i == 7), zo = i >= 4; // CornerXYZOffset, VoxelCube.h:45-47
+        const int sel = (xo & ox) | ((yo & oy) << 1) | ((zo & oz) << 2);
+        const int nb = s_nb[sel];
+        const int vx = (x + xo) & 7, vy = (y + yo) & 7, vz = (z + zo) & 7;
+        if (ok && nb < 0) ok = false;
+        if (ok) {
+            const float* t = V.pool + (size_t)nb * kBlockFloats + (vx + vy * 8 + vz * 64);
+            const float sdf = t[0], w = t[kVox];
+            cs[i] = sdf; cc[i][0] = t[2 * kVox]; cc[i][1] = t[3 * kVox]; cc[i][2] = t[4 * kVox];
+            cp[i][0] = (float)(kx + (xo & ox)) * cube_res + ((float)vx * res + half);
+            cp[i][1] = (float)(ky + (yo & oy)) * cube_res + ((float)vy * res + half);
+            cp[i][2] = (float)(kz + (zo & oz)) * cube_res + ((float)vz * res + half);
+            if (sdf >= 1 || w <= 0) ok = false;            // !IsValid (TSDFVoxel.h:75-78)
+        }
+    }
+    int ci = 0;
+    unsigned ntri = 0;
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ci |= cs[i] > 0 ? 1 << i : 0;  // DetermineCase
+        for (int i = 0; i < 16 && s_tri[16 * ci + i] != -1; i += 3) ++ntri;
+    }
+    // exclusive scan of ntri over the workgroup in thread (= reference loop) order
+    unsigned incl = ntri;
+    const int lane = o & 63, wave = o >> 6;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    if (counts) {
+        if (o == 0) { unsigned tot = 0; for (int k = 0; k < 8; ++k) tot += s_w[k]; counts[blockIdx.x] = tot; }
+        return;
+    }
+    if (!ntri) return;
+    unsigned first = incl - ntri;
+    for (int k = 0; k < wave; ++k) first += s_w[k];
+    size_t vtx = ((size_t)offsets[blockIdx.x] + first) * 3;
+    for (int i = 0; i < 16 && s_tri[16 * ci + i] != -1; i += 3)
+        for (int j = 0; j < 3; ++j, ++vtx) {
+            const int e = s_tri[16 * ci + i + j], a = s_edge[2 * e], c = s_edge[2 * e + 1];
+            // InterpolateEdgeVetex (MarchingCube.cpp:8-16); corners picked by dynamic index -> select chains
+            float pa[3] = {0, 0, 0}, pc[3] = {0, 0, 0}, ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0}, sa = 0, sc = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q == a) { sa = cs[q]; pa[0] = cp[q][0]; pa[1] = cp[q][1]; pa[2] = cp[q][2]; ca[0] = cc[q][0]; ca[1] = cc[q][1]; ca[2] = cc[q][2]; }
+                if (q == c) { sc = cs[q]; pc[0] = cp[q][0]; pc[1] = cp[q][1]; pc[2] = cp[q][2]; cb[0] = cc[q][0]; cb[1] = cc[q][1]; cb[2] = cc[q][2]; }
+            }
+            const float sdf_diff = sc - sa;
+            const float t = sa / sdf_diff;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pts[3 * vtx + k] = pa[k] - t * (pc[k] - pa[k]);
+                col[3 * vtx + k] = (ca[k] + cb[k]) / 2.0f;  // (c1 + c2) / 2
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Ray casting (north_star "integrate/raycast").  The reference has NO raycast; the
 // definition is this implementation's own and is validated against the analytic synthetic scene:
@@ -1671,6 +1757,82 @@ int op_volume_point_cloud(op_volume* v, float* xyz, float* colors, size_t cap, s
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "point cloud failed: %s", hipGetErrorString(e));
+    return rc;
+}
+
+
+int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t* edge_pairs, const int32_t* only_block, float* points,
+                           float* colors, size_t cap_vertices, size_t* n_vertices) {
+    OP_VOL(v);
+    if (!tri_table || !edge_pairs || !n_vertices) return fail(OP_ERR_INVALID, "null argument");
+    for (int c = 0; c < 256; ++c)
+        for (int i = 0; i < 16; ++i) {
+            const int e = tri_table[16 * c + i];
+            if (e < -1 || e > 11) return fail(OP_ERR_INVALID, "tri_table[%d][%d] = %d is not an edge id or -1", c, i, e);
+            if (i == 15 && e != -1) return fail(OP_ERR_INVALID, "tri_table row %d is not -1 terminated", c);
+        }
+    for (int i = 0; i < 24; ++i)
+        if (edge_pairs[i] < 0 || edge_pairs[i] > 7) return fail(OP_ERR_INVALID, "edge_pairs[%d] = %d is not a corner id", i, edge_pairs[i]);
+    unsigned nb = 0;
+    OP_TRY(vol_block_count(v, &nb));
+    *n_vertices = 0;
+    if (!nb) return OP_OK;
+    // block list: every block in pool order, or the one requested (GenerateMeshByCube)
+    std::vector<unsigned> list;
+    if (only_block) {
+        std::vector<int> keys((size_t)nb * 3);
+        OP_HIP(hipMemcpy(keys.data(), v->keys, keys.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (unsigned b = 0; b < nb; ++b)
+            if (keys[3 * b] == only_block[0] && keys[3 * b + 1] == only_block[1] && keys[3 * b + 2] == only_block[2]) list.push_back(b);
+        if (list.empty()) return OP_OK;
+    } else {
+        list.resize(nb);
+        for (unsigned b = 0; b < nb; ++b) list[b] = b;
+    }
+    const unsigned nl = (unsigned)list.size();
+    unsigned *d_list = nullptr, *d_counts = nullptr, *d_offsets = nullptr;
+    int *d_tri = nullptr, *d_edge = nullptr;
+    float *d_pts = nullptr, *d_col = nullptr;
+    int rc = OP_OK;
+    hipError_t e = hipMalloc((void**)&d_list, nl * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_counts, nl * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_offsets, nl * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_tri, 256 * 16 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_edge, 24 * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_list, list.data(), nl * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_tri, tri_table, 256 * 16 * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_edge, edge_pairs, 24 * sizeof(int), hipMemcpyHostToDevice);
+    std::vector<unsigned> cnt(nl), off(nl);
+    size_t total_tri = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const int*)d_tri, (const int*)d_edge, (const unsigned*)d_list,
+                           d_counts, (const unsigned*)nullptr, (float*)nullptr, (float*)nullptr);
+        e = hipStreamSynchronize(v->stream);
+        if (e == hipSuccess) e = hipMemcpy(cnt.data(), d_counts, nl * sizeof(unsigned), hipMemcpyDeviceToHost);
+        for (unsigned b = 0; b < nl; ++b) { off[b] = (unsigned)total_tri; total_tri += cnt[b]; }
+    }
+    const size_t total = total_tri * 3;
+    *n_vertices = total;
+    if (e == hipSuccess && points && colors && total) {
+        if (total > cap_vertices) rc = fail(OP_ERR_CAPACITY, "mesh has %zu vertices, buffer holds %zu", total, cap_vertices);
+        else if (total_tri > 0xffffffffull / 3) rc = fail(OP_ERR_CAPACITY, "mesh too large");
+        else {
+            e = hipMemcpy(d_offsets, off.data(), nl * sizeof(unsigned), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_pts, total * 12);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_col, total * 12);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const int*)d_tri, (const int*)d_edge,
+                                   (const unsigned*)d_list, (unsigned*)nullptr, (const unsigned*)d_offsets, d_pts, d_col);
+                e = hipStreamSynchronize(v->stream);
+            }
+            if (e == hipSuccess) e = hipMemcpy(points, d_pts, total * 12, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(colors, d_col, total * 12, hipMemcpyDeviceToHost);
+        }
+    }
+    void* ptrs[] = {d_list, d_counts, d_offsets, d_tri, d_edge, d_pts, d_col};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "mesh extraction failed: %s", hipGetErrorString(e));
     return rc;
 }
 

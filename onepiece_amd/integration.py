@@ -292,6 +292,25 @@ class CubeHandler:
         L.check(self._lib.op_volume_point_cloud(self._h, _fp(xyz), _fp(col), n.value, C.byref(n)))
         return xyz[:n.value], col[:n.value]
 
+    def ExtractTriangleMesh(self, tri_table, edge_pairs, only_block=None):
+        """CubeHandler::ExtractTriangleMesh (CubeHandler.cpp:9-44) on the GPU -> (points [n,3], colors [n,3]); triangle k
+        is vertices 3k..3k+2 (MarchingCube() pushes unshared vertices).  tri_table (256 x 16) / edge_pairs (12 x 2) are
+        the caller's marching-cubes tables (the reference's MCLookTable / EdgeIndexPairs)."""
+        tt = np.ascontiguousarray(tri_table, np.int32).reshape(256 * 16)
+        ep = np.ascontiguousarray(edge_pairs, np.int32).reshape(24)
+        ob = None if only_block is None else np.ascontiguousarray(only_block, np.int32).reshape(3)
+        obp = None if ob is None else _ip(ob)
+        n = C.c_size_t(0)
+        L.check(self._lib.op_volume_extract_mesh(self._h, _ip(tt), _ip(ep), obp, None, None, 0, C.byref(n)))
+        pts, col = np.empty((max(n.value, 1), 3), np.float32), np.empty((max(n.value, 1), 3), np.float32)
+        if n.value:
+            L.check(self._lib.op_volume_extract_mesh(self._h, _ip(tt), _ip(ep), obp, _fp(pts), _fp(col), n.value, C.byref(n)))
+        return pts[:n.value].copy(), col[:n.value].copy()
+
+    def GenerateMeshByCube(self, cube_id, tri_table, edge_pairs):
+        """CubeHandler::GenerateMeshByCube (CubeHandler.cpp:70-114) for one block."""
+        return self.ExtractTriangleMesh(tri_table, edge_pairs, only_block=cube_id)
+
     def Raycast(self, pose, camera=None):
         """Ray casting (north_star; no reference counterpart) -> (depth [h,w], normals [h,w,3],
         colors [h,w,3]); depth 0 = no hit."""

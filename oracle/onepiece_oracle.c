@@ -1589,3 +1589,62 @@ int orc_dense_tracking(const orc_camera *cam, int n_levels, const int *iters, co
     return rc;
 }
 void orc_free(void *p) { free(p); }
+
+/* ======================= mesh extraction (Integration/MarchingCube.cpp, CubeHandler.cpp:9-114) == */
+/* CubeHandler::ExtractTriangleMesh = GenerateMeshByCube (CubeHandler.cpp:70-114) for every block +
+ * MarchingCube (MarchingCube.cpp:31-74).  The 256x16 triangle table (MarchingCubePredefined.h:17-274) and
+ * the 12x2 edge table (:275-289) are INPUTS: they are data of the reference's header, supplied by whoever
+ * calls (the reference-side shim passes its own arrays); nothing here depends on their content beyond
+ * "rows are -1 terminated edge triples".  Vertices are emitted three per triangle, unshared, in the order
+ * MarchingCube() pushes them; blocks in insertion order, voxels in the reference's x, y, z loop order.
+ * only_block: NULL or the one CubeID to mesh (GenerateMeshByCube alone).  Returns the vertex count. */
+size_t orc_volume_extract_mesh(const orc_volume *v, const int32_t *tri_table, const int32_t *edge_pairs, const int32_t *only_block,
+                               float *points, float *colors, size_t cap_vertices) {
+    static const int cxo[8] = {0, 1, 1, 0, 0, 1, 1, 0}, cyo[8] = {0, 0, 1, 1, 0, 0, 1, 1}, czo[8] = {0, 0, 0, 0, 1, 1, 1, 1}; /* VoxelCube.h:45-47 */
+    size_t n = 0;
+    float cube_res = CUBE * v->res; /* VoxelCube.h:149-153 */
+    for (size_t b = 0; b < v->n; ++b) {
+        const int32_t *id = v->keys + 3 * b;
+        if (only_block && (id[0] != only_block[0] || id[1] != only_block[1] || id[2] != only_block[2])) continue;
+        for (int x = 0; x < CUBE; ++x)
+            for (int y = 0; y < CUBE; ++y)
+                for (int z = 0; z < CUBE; ++z) {
+                    int ox = x == CUBE - 1, oy = y == CUBE - 1, oz = z == CUBE - 1; /* NeighborCubeIDOffset[index] */
+                    float corner[8][3], csdf[8], ccol[8][3];
+                    int ok = 1;
+                    for (int i = 0; i < 8 && ok; ++i) {
+                        int nx = id[0] + (cxo[i] & ox), ny = id[1] + (cyo[i] & oy), nz = id[2] + (czo[i] & oz);
+                        int vx = (x + cxo[i]) % CUBE, vy = (y + cyo[i]) % CUBE, vz = (z + czo[i]) % CUBE;
+                        int vid = vx + vy * CUBE + vz * CUBE * CUBE;
+                        int64_t nb = vol_find(v, nx, ny, nz);
+                        if (nb < 0) { ok = 0; break; }
+                        const float *t = v->vox + ((size_t)nb * NVOX + vid) * 5;
+                        corner[i][0] = nx * cube_res + v->offset[vid][0];
+                        corner[i][1] = ny * cube_res + v->offset[vid][1];
+                        corner[i][2] = nz * cube_res + v->offset[vid][2];
+                        csdf[i] = t[0]; ccol[i][0] = t[2]; ccol[i][1] = t[3]; ccol[i][2] = t[4];
+                        if (t[0] >= 1 || t[1] <= 0) ok = 0; /* !IsValid (TSDFVoxel.h:75-78) */
+                    }
+                    if (!ok) continue;
+                    int ci = 0;
+                    for (int i = 0; i < 8; ++i) ci |= (csdf[i] > 0 ? 1 << i : 0); /* DetermineCase */
+                    const int32_t *E = tri_table + 16 * ci;
+                    for (int i = 0; i < 16; i += 3) {
+                        if (E[i] == -1) break;
+                        for (int j = 0; j < 3; ++j) {
+                            int e = E[i + j], a = edge_pairs[2 * e], c = edge_pairs[2 * e + 1];
+                            if (n < cap_vertices) {
+                                float sdf_diff = csdf[c] - csdf[a];            /* InterpolateEdgeVetex */
+                                float t = csdf[a] / sdf_diff;
+                                for (int k = 0; k < 3; ++k) {
+                                    points[3 * n + k] = corner[a][k] - t * (corner[c][k] - corner[a][k]);
+                                    colors[3 * n + k] = (ccol[a][k] + ccol[c][k]) / 2;
+                                }
+                            }
+                            ++n;
+                        }
+                    }
+                }
+    }
+    return n;
+}

@@ -85,6 +85,13 @@ size_t orc_volume_point_cloud(const orc_volume *v, float *xyz, float *colors, si
 int orc_volume_write_file(const orc_volume *v, const char *path);
 int orc_volume_read_file(orc_volume *v, const char *path, int legacy_float);
 
+/* CubeHandler::ExtractTriangleMesh / GenerateMeshByCube (CubeHandler.cpp:9-114) + MarchingCube
+ * (MarchingCube.cpp:8-74).  tri_table (256 x 16, -1 terminated rows) and edge_pairs (12 x 2) are the
+ * CALLER'S data (the reference keeps them in MarchingCubePredefined.h).  3 unshared vertices per triangle;
+ * returns the vertex count (may exceed cap_vertices; only cap written).  only_block: NULL or one CubeID. */
+size_t orc_volume_extract_mesh(const orc_volume *v, const int32_t *tri_table, const int32_t *edge_pairs,
+                               const int32_t *only_block, float *points, float *colors, size_t cap_vertices);
+
 /* Ray casting -- NO reference counterpart; restates the definition of op_volume_raycast. */
 void orc_volume_raycast(const orc_volume *v, const orc_camera *cam, const float pose[16], float *depth_out,
                         float *normals_out, float *colors_out);

@@ -93,6 +93,8 @@ def lib():
         L.orc_volume_write_file.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_volume_read_file.restype = C.c_int
         L.orc_volume_read_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.orc_volume_extract_mesh.restype = C.c_size_t
+        L.orc_volume_extract_mesh.argtypes = [C.c_void_p, _ip, _ip, _ip, _fp, _fp, C.c_size_t]
         L.orc_volume_raycast.argtypes = [C.c_void_p, C.POINTER(Camera), _fp, _fp, _fp, _fp]
         L.orc_load_from_depth.restype = C.c_size_t
         L.orc_load_from_depth.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, _fp]
@@ -290,6 +292,18 @@ class Volume:
         col = np.empty((max(n, 1), 3), np.float32)
         lib().orc_volume_point_cloud(self._h, _p(xyz), _p(col), n)
         return xyz[:n], col[:n]
+
+    def extract_mesh(self, tri_table, edge_pairs, only_block=None):
+        """ExtractTriangleMesh / GenerateMeshByCube with caller-supplied tables -> (points [n,3], colors [n,3]);
+        triangle k = vertices 3k..3k+2."""
+        tt = np.ascontiguousarray(tri_table, np.int32).reshape(256 * 16)
+        ep = np.ascontiguousarray(edge_pairs, np.int32).reshape(24)
+        ob = None if only_block is None else np.ascontiguousarray(only_block, np.int32).reshape(3)
+        obp = None if ob is None else _p(ob, _ip)
+        n = lib().orc_volume_extract_mesh(self._h, _p(tt, _ip), _p(ep, _ip), obp, None, None, 0)
+        pts, col = np.empty((max(n, 1), 3), np.float32), np.empty((max(n, 1), 3), np.float32)
+        lib().orc_volume_extract_mesh(self._h, _p(tt, _ip), _p(ep, _ip), obp, _p(pts), _p(col), n)
+        return pts[:n].copy(), col[:n].copy()
 
     def raycast(self, pose, cam=None):
         """No reference counterpart: CPU restatement of op_volume_raycast's definition."""

@@ -66,3 +66,28 @@ def track_levels(i, j, n_levels=3, holes=True, scale=1):
         fx, fy, cx, cy, w, h = fx / 2, fy / 2, cx / 2, cy / 2, w // 2, h // 2
     T_true = np.linalg.inv(pt.astype(np.float64)) @ ps.astype(np.float64)
     return levels, T_true.astype(np.float32)
+
+
+# canonical cube edges for the corner numbering of VoxelCube.h:45-47 (bottom ring, top ring, verticals)
+MC_EDGE_PAIRS = np.array([[0, 1], [1, 2], [2, 3], [3, 0], [4, 5], [5, 6], [6, 7], [7, 4], [0, 4], [1, 5], [2, 6], [3, 7]], np.int32)
+
+
+def procedural_mc_table():
+    """A 256 x 16 marching-cubes style table for TESTS: for every sign configuration, a triangle fan over the
+    edges whose end points differ in sign (so every interpolation has a non-zero denominator), at most five
+    triangles, rows terminated by -1.  It is NOT the reference's table (that one is data of the reference's
+    header and is passed in by the caller in a real build); the extraction code is table-agnostic, so any
+    well-formed table exercises the same path on both sides."""
+    tab = np.full((256, 16), -1, np.int32)
+    for case in range(256):
+        active = [e for e, (a, b) in enumerate(MC_EDGE_PAIRS) if ((case >> a) & 1) != ((case >> b) & 1)]
+        tris = [(active[0], active[k], active[k + 1]) for k in range(1, len(active) - 1)][:5] if len(active) >= 3 else []
+        flat = [e for t in tris for e in t]
+        tab[case, :len(flat)] = flat
+    return tab
+
+
+def triangle_soup(points, colors):
+    """Order-independent form of an unshared-vertex mesh: rows = triangles (18 floats), sorted lexicographically."""
+    t = np.concatenate([points.reshape(-1, 9), colors.reshape(-1, 9)], 1)
+    return t[np.lexsort(t.T[::-1])]

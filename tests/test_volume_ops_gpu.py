@@ -153,3 +153,36 @@ def test_merge_with_transform_and_add_cube(oracle):
     hv.AddCube(key0)                                   # existing block is left untouched
     k2, v2 = hv.GetCubeMap()
     assert np.array_equal(v2[np.where((k2 == key0).all(1))[0][0]].view(np.uint32), hvx[0].view(np.uint32))
+
+
+def test_extract_triangle_mesh(oracle):
+    """CubeHandler::ExtractTriangleMesh / GenerateMeshByCube (CubeHandler.cpp:9-114, MarchingCube.cpp:8-74) with
+    caller-supplied tables: per block the vertex stream is identical (order included); over the whole volume the
+    triangle soups are identical (block order is the hash map's in the reference, pool order here)."""
+    from helpers import procedural_mc_table, MC_EDGE_PAIRS, triangle_soup
+    tab = procedural_mc_table()
+    ov, hv = _pair(oracle, 0.02, (0, 10, 20))
+    keys, _ = hv.GetCubeMap()
+    rp, rc = ov.extract_mesh(tab, MC_EDGE_PAIRS)
+    gp, gc = hv.ExtractTriangleMesh(tab, MC_EDGE_PAIRS)
+    assert len(rp) == len(gp) > 3000 and len(gp) % 3 == 0
+    a, b = triangle_soup(rp, rc), triangle_soup(gp, gc)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # vertices lie between voxel centres: inside the volume's bounding box
+    lo, hi = keys.min(0) * 0.16, (keys.max(0) + 1) * 0.16 + 0.02
+    assert np.all(gp >= lo - 1e-4) and np.all(gp <= hi + 1e-4) and np.all((gc >= 0) & (gc <= 1))
+    checked = 0
+    for k in keys[:: max(1, len(keys) // 25)]:
+        r1, c1 = ov.extract_mesh(tab, MC_EDGE_PAIRS, only_block=k)
+        g1, d1 = hv.GenerateMeshByCube(k, tab, MC_EDGE_PAIRS)
+        assert np.array_equal(r1.view(np.uint32), g1.view(np.uint32)) and np.array_equal(c1.view(np.uint32), d1.view(np.uint32))
+        checked += len(g1)
+    assert checked > 0
+    # a block that does not exist, an empty volume, and a malformed table
+    assert len(hv.GenerateMeshByCube((9999, 9999, 9999), tab, MC_EDGE_PAIRS)[0]) == 0
+    empty = I.CubeHandler(); empty.SetVoxelResolution(0.02)
+    assert len(empty.ExtractTriangleMesh(tab, MC_EDGE_PAIRS)[0]) == 0
+    bad = tab.copy(); bad[3, 0] = 12
+    from onepiece_amd import _lib as L
+    with pytest.raises(L.OnePieceHipError):
+        hv.ExtractTriangleMesh(bad, MC_EDGE_PAIRS)
