@@ -195,5 +195,25 @@ inline int MultiScaleComputing(op_tracker* tracker, const std::vector<FloatImage
     return OP_OK;
 }
 
+// CubeHandler::ExtractTriangleMesh (CubeHandler.cpp:9-44) / GenerateMeshByCube (:70-114).  tri_table / edge_pairs:
+// the reference's own `&MCLookTable[0][0]` / `&EdgeIndexPairs[0][0]` (MarchingCubePredefined.h).  Mesh must offer
+// points, colors (vectors of Point3) and triangles (vector of Point3ui); only_block: nullptr or int[3].
+template <class Point3, class Point3ui, class Mesh>
+inline int ExtractTriangleMesh(op_volume* vol, const int* tri_table, const int* edge_pairs, const int* only_block, Mesh& mesh) {
+    size_t n = 0;
+    int rc = op_volume_extract_mesh(vol, tri_table, edge_pairs, only_block, nullptr, nullptr, 0, &n);
+    if (rc != OP_OK || n == 0) return rc;
+    std::vector<float> p(3 * n), c(3 * n);
+    rc = op_volume_extract_mesh(vol, tri_table, edge_pairs, only_block, p.data(), c.data(), n, &n);
+    if (rc != OP_OK) return rc;
+    unsigned index = (unsigned)mesh.points.size();   // MarchingCube.cpp:39: triangles index the running vertex list
+    for (size_t k = 0; k < n; ++k) {
+        mesh.points.push_back(Point3(p[3 * k], p[3 * k + 1], p[3 * k + 2]));
+        mesh.colors.push_back(Point3(c[3 * k], c[3 * k + 1], c[3 * k + 2]));
+        if (k % 3 == 2) { mesh.triangles.push_back(Point3ui(index, index + 1, index + 2)); index += 3; }
+    }
+    return OP_OK;
+}
+
 } // namespace hip_shim
 } // namespace one_piece

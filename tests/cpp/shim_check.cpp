@@ -61,6 +61,8 @@ struct Cam { // camera::PinholeCamera getters (GetWidth/GetHeight return float i
     float GetFx() const { return fx; } float GetFy() const { return fy; } float GetCx() const { return cx; } float GetCy() const { return cy; }
 };
 struct Pt2u { unsigned v[2]; Pt2u() : v{0, 0} {} Pt2u(unsigned a, unsigned b) : v{a, b} {} unsigned operator()(int i) const { return v[i]; } };
+struct Tri3 { unsigned v[3]; Tri3() : v{0, 0, 0} {} Tri3(unsigned a, unsigned b, unsigned c) : v{a, b, c} {} };
+struct Mesh { std::vector<Vec3f> points, colors; std::vector<Tri3> triangles; };
 struct Result {
     Mat4 T;
     double rmse = 0;
@@ -118,6 +120,17 @@ int main(int argc, char** argv) {
     }
     Result res; res.T = Mat4::Identity();
     const int rc = sh::RunICP(OP_ICP_POINT_TO_POINT, src, tgt, (const std::vector<Vec3f>*)nullptr, Mat4::Identity(), 10, 0.05, 0, res);
+    // mesh extraction through the shim with a procedural table (a fan over the sign-changing edges)
+    static const int EP[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    static int TT[256][16];
+    for (int cs = 0; cs < 256; ++cs) {
+        int act[12], na = 0, k = 0;
+        for (int e2 = 0; e2 < 12; ++e2) if (((cs >> EP[e2][0]) & 1) != ((cs >> EP[e2][1]) & 1)) act[na++] = e2;
+        for (int i = 0; i < 16; ++i) TT[cs][i] = -1;
+        for (int q = 1; q + 1 < na && k < 15; ++q) { TT[cs][k++] = act[0]; TT[cs][k++] = act[q]; TT[cs][k++] = act[q + 1]; }
+    }
+    Mesh mesh;
+    const int mrc = (sh::ExtractTriangleMesh<Vec3f, Tri3>(vol, &TT[0][0], &EP[0][0], (const int*)nullptr, mesh));
     // dense tracker through the shim: the wall scene against itself, one level, identity expected
     op_tracker* trk = nullptr;
     int trc = op_tracker_create(0, &trk);
@@ -136,10 +149,10 @@ int main(int argc, char** argv) {
     op_tracker_destroy(trk);
     std::printf("{\"blocks\": %zu, \"observed\": %llu, \"weight_sum\": %.0f, \"xor\": \"0x%llx\", \"first_list\": %zu, \"reupload_blocks\": %zu, "
                 "\"icp_rc\": %d, \"icp_pairs\": %zu, \"icp_tx\": %.6f, \"track_rc\": %d, \"track_pairs\": %zu, \"track_ok\": %d, "
-                "\"track_tx\": %.6f, \"track_rmse\": %.6g, \"track_first_pair\": [%u, %u, %u, %u]}\n",
+                "\"track_tx\": %.6f, \"track_rmse\": %.6g, \"track_first_pair\": [%u, %u, %u, %u], \"mesh_rc\": %d, \"mesh_triangles\": %zu, \"mesh_vertices\": %zu}\n",
                 map.size(), observed, wsum, x, first_list, n2, rc, res.correspondence_set_index.size(), res.T(0, 3), trc, px_pairs.size(), (int)ok,
                 Tt(0, 3), rmse, px_pairs.empty() ? 0u : px_pairs[0].first(0), px_pairs.empty() ? 0u : px_pairs[0].first(1),
-                px_pairs.empty() ? 0u : px_pairs[0].second(0), px_pairs.empty() ? 0u : px_pairs[0].second(1));
+                px_pairs.empty() ? 0u : px_pairs[0].second(0), px_pairs.empty() ? 0u : px_pairs[0].second(1), mrc, mesh.triangles.size(), mesh.points.size());
     op_volume_destroy(vol); op_volume_destroy(vol2);
     return 0;
 }

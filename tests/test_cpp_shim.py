@@ -38,6 +38,8 @@ def test_shim_end_to_end_reproduces_reference_run_statistics(hip):
     # dense tracker through the shim: a frame against itself -> every pixel pairs with itself, pose stays put
     assert r["track_rc"] == 0 and r["track_pairs"] == 640 * 480 and r["track_ok"] == 1
     assert abs(r["track_tx"]) < 1e-5 and r["track_rmse"] < 1e-5 and r["track_first_pair"] == [0, 0, 0, 0]
+    # mesh extraction through the shim: the wall is one surface -> hundreds of thousands of triangles, 3 vertices each
+    assert r["mesh_rc"] == 0 and r["mesh_triangles"] > 100000 and r["mesh_vertices"] == 3 * r["mesh_triangles"]
 
 
 def test_shim_instantiates_with_real_eigen_types(hip):
