@@ -100,7 +100,10 @@ def merge_volumes(ops, root=0, group=None):
     n_union = int(union.shape[0])
     if n_union == 0:
         return 0
-    # 3.-4. sum-form pack, one reduce to the root
+    # 3.-4. sum-form pack, one reduce to the root.  `union` was produced by torch ops queued on torch's stream,
+    # k_pack_sum runs on the volume's own stream: make the keys final before the kernel reads them.
+    if union.is_cuda:
+        torch.cuda.current_stream(union.device).synchronize()
     packed = ops.pack_sum(union).contiguous()
     dist.reduce(packed, dst=root, op=dist.ReduceOp.SUM, group=group)
     if packed.is_cuda:
