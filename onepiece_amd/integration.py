@@ -37,7 +37,12 @@ def _ip(a):
 
 
 def _image_arg(img, kind):
-    """-> (pointer, fmt, mem, keepalive).  kind: 'depth' | 'rgb'."""
+    """-> (pointer, fmt, mem, keepalive).  kind: 'depth' | 'rgb'.
+
+    CUDA torch tensors are used in place by kernels on the LIBRARY's streams (each volume / tracker / ICP object
+    owns one), not on torch's: the tensor's contents must be final when the call is made -- synchronise the torch
+    stream that produced it (`torch.cuda.current_stream().synchronize()`) if it was written by an asynchronous
+    torch op just before."""
     if hasattr(img, "data_ptr"):  # torch tensor
         if not img.is_cuda or not img.is_contiguous():
             raise ValueError("torch images must be contiguous CUDA tensors")
