@@ -34,6 +34,7 @@ using op::fail;
 
 constexpr int kNSums = 32;      // doubles per partial: sums[0..26], [27] = sum_sq_err, [28] = inlier count
 constexpr int kIterThreads = 256;
+constexpr int kScan = 8;          // candidates fetched per trip of the neighbour scan
 constexpr unsigned long long kMaxCells = 1ull << 26;
 
 struct Grid {
@@ -230,27 +231,39 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                 const float fy = (tp1 - g.oy) - (float)cy * cell, fz = (tp2 - g.oz) - (float)cz * cell;
                 const float gy[3] = {fmaxf(fy, 0.0f), 0.0f, fmaxf(cell - fy, 0.0f)};
                 const float gz[3] = {fmaxf(fz, 0.0f), 0.0f, fmaxf(cell - fz, 0.0f)};
-                if (x_lo <= x_hi)
+                if (x_lo <= x_hi) {
+                    // the [begin, end) runs of all nine rows are fetched first (independent loads, one round trip)
+                    // instead of one dependent round trip per visited row
+                    unsigned rb[9], re[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        const int dy = q % 3 - 1, dz = q / 3 - 1;
+                        const int z = cz + dz, y = cy + dy;
+                        rb[q] = 0u; re[q] = 0u;
+                        if (!(z < 0 || z >= g.gz || y < 0 || y >= g.gy)) {
+                            const size_t row = ((size_t)z * g.gy + y) * g.gx;
+                            // cells x_lo..x_hi own one contiguous run of the sorted target
+                            rb[q] = cell_start[row + x_lo];
+                            re[q] = cell_start[row + x_hi] + cell_count[row + x_hi];
+                        }
+                    }
+#pragma unroll
                     for (int r = 0; r < 9; ++r) {
                         // r = 0: (dy,dz) = (0,0); then the remaining 8 rows
                         const int q = r == 0 ? 4 : (r <= 4 ? r - 1 : r);
                         const int dy = q % 3 - 1, dz = q / 3 - 1;
-                        const int z = cz + dz, y = cy + dy;
-                        if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
+                        const unsigned beg = rb[q], end = re[q];
+                        if (beg >= end) continue;
                         const float bound = gy[dy + 1] * gy[dy + 1] + gz[dz + 1] * gz[dz + 1];
                         if (0.99f * bound > best_d) continue;
-                        const size_t row = ((size_t)z * g.gy + y) * g.gx;
-                        // cells x_lo..x_hi own one contiguous run of the sorted target
-                        const unsigned beg = cell_start[row + x_lo];
-                        const unsigned end = cell_start[row + x_hi] + cell_count[row + x_hi];
-                        // 4 candidates per trip: the loads are independent, so 4 L2 round trips overlap
+                        // kScan candidates per trip: the loads are independent, so their L2 round trips overlap
                         // (the scan is a latency chain otherwise)
-                        for (unsigned p = beg; p < end; p += 4) {
-                            float4 c[4];
+                        for (unsigned p = beg; p < end; p += kScan) {
+                            float4 c[kScan];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) c[k] = tgt[min(p + k, end - 1)];
+                            for (int k = 0; k < kScan; ++k) c[k] = tgt[min(p + k, end - 1)];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
+                            for (int k = 0; k < kScan; ++k) {
                                 if (p + k >= end) break;
                                 const float dx = tp0 - c[k].x, dyy = tp1 - c[k].y, dzz = tp2 - c[k].z;
                                 const float d = dx * dx + dyy * dyy + dzz * dzz;
@@ -259,6 +272,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                             }
                         }
                     }
+                }
             }
             nn[i] = best;
             if (best >= 0) {
