@@ -187,3 +187,14 @@ def test_tracker_refuses_without_gpu(hip):
     h = C.c_void_p()
     assert hip.load().op_tracker_create(0, C.byref(h)) == hip.OP_ERR_NO_DEVICE  # no CPU fallback
     assert b"no CPU fallback" in hip.load().op_last_error()
+
+
+def test_only_test_infrastructure_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/: the developer
+    tools under tools/ and the examples stay oracle-free (validation scripts that need it live in tests/tools/)."""
+    for sub in ("tools", "examples", "host", "include"):
+        for dirpath, _dirs, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".cpp", ".hpp", ".h")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert not re.search(r"\b(from|import)\s+oracle\b|oracle/|onepiece_oracle|from helpers import track_levels", text), os.path.join(dirpath, f)

@@ -1,7 +1,7 @@
 """Diagnostic: GPU tracker vs oracle (float sums) vs oracle (double sums) on the multi-scale loop."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from onepiece_amd import odometry as O, integration as I
 from oracle import oracle

@@ -1,7 +1,7 @@
 """Mesh-extraction timing: ExtractTriangleMesh over a 5 mm volume fused from N room frames (GPU vs CPU oracle)."""
 import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np, torch
 from onepiece_amd import integration as I, synthetic as S
 from helpers import procedural_mc_table, MC_EDGE_PAIRS

@@ -1,7 +1,7 @@
 """One-off full-size parity run (too slow for the test suite): N frames of the bench workload at
 640x480 / 5 mm through the HIP sequence path and through the CPU oracle, compared bit for bit."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from onepiece_amd import integration as I, synthetic as S
 from oracle import oracle as O

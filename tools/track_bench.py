@@ -2,18 +2,22 @@
 Also used under rocprofv3 --kernel-trace --stats (tools/profile_track.sh)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import ctypes as C
 import numpy as np
 import torch
 from onepiece_amd import odometry as O, integration as I, _lib as L
-from helpers import track_levels
+from onepiece_amd import synthetic as S
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 lib = L.load()
 odo = O.Odometry(I.PinholeCamera("OPEN3D_DATASET"))
 for (i, j, term, name) in [(300, 301, 0, "hybrid 300->301"), (100, 102, 0, "hybrid 100->102"), (300, 301, 2, "depth 300->301")]:
-    levels, T_true = track_levels(i, j, holes=True, scale=1)
+    # pyramids built by the library itself from the two raw frames (DenseTracking), then read back
+    di, ci, _ = S.room_frame(i)
+    dj, cj, _ = S.room_frame(j)
+    odo.SetMultiScale(3); odo.iter_count_per_level = [4, 8, 16]
+    odo.DenseTracking(ci, cj, di, dj, None, 0, want_correspondences=False)
+    levels = odo.PreparedLevels()
     dev = []
     for lv in levels:
         d = dict(lv)
