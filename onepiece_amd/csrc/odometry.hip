@@ -345,20 +345,29 @@ __device__ __forceinline__ float prep_raw(const PrepFrames& P, int z, int y, int
     return ((double)d > 0.5 && d < 4.0f) ? d : __builtin_nanf("");
 }
 
-// conversion + GaussianBlur(3x3, sigma 0) = [1 2 1]/4 separable, for the four level-0 images at once
-__global__ __launch_bounds__(kThreads) void k_prep_convert_blur(const PrepFrames* __restrict__ Pp) {
+// conversion + GaussianBlur(3x3, sigma 0) = [1 2 1]/4 separable, for the four level-0 images at once.
+// 32 x 8 output tile per workgroup: the (32+2) x (8+2) converted input values are staged in LDS once (the grey
+// conversion alone is three byte loads + integer math per tap otherwise), the nine taps then come from LDS.
+constexpr int kBlurTx = 32, kBlurTy = 8;
+__global__ __launch_bounds__(kBlurTx * kBlurTy) void k_prep_convert_blur(const PrepFrames* __restrict__ Pp) {
     const PrepFrames P = *Pp;   // per-call frame pointers live in device memory so that a captured graph can be replayed
-    const int z = blockIdx.y, s = blockIdx.x * kThreads + threadIdx.x;
-    if (s >= P.w * P.h) return;
-    const int y = s / P.w, x = s - y * P.w;
-    const int xs[3] = {reflect101(x - 1, P.w), x, reflect101(x + 1, P.w)};
+    __shared__ float s_in[kBlurTy + 2][kBlurTx + 2];
+    const int z = blockIdx.z;
+    const int x0 = blockIdx.x * kBlurTx, y0 = blockIdx.y * kBlurTy;
+    for (int k = threadIdx.x; k < (kBlurTy + 2) * (kBlurTx + 2); k += kBlurTx * kBlurTy) {
+        const int ly = k / (kBlurTx + 2), lx = k - ly * (kBlurTx + 2);
+        // BORDER_REFLECT_101 on the image, clamped for the part of the tile that hangs over the image
+        const int yy = reflect101(min(y0 + ly - 1, P.h), P.h), xx = reflect101(min(x0 + lx - 1, P.w), P.w);
+        s_in[ly][lx] = prep_raw(P, z, yy, xx);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % kBlurTx, ly = threadIdx.x / kBlurTx;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= P.w || y >= P.h) return;
     float hrow[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int yy = reflect101(y - 1 + r, P.h);
-        hrow[r] = (0.25f * prep_raw(P, z, yy, xs[0]) + 0.5f * prep_raw(P, z, yy, xs[1])) + 0.25f * prep_raw(P, z, yy, xs[2]);
-    }
-    P.out[z][s] = (0.25f * hrow[0] + 0.5f * hrow[1]) + 0.25f * hrow[2];
+    for (int r = 0; r < 3; ++r) hrow[r] = (0.25f * s_in[ly + r][lx] + 0.5f * s_in[ly + r][lx + 1]) + 0.25f * s_in[ly + r][lx + 2];
+    P.out[z][(size_t)y * P.w + x] = (0.25f * hrow[0] + 0.5f * hrow[1]) + 0.25f * hrow[2];
 }
 
 struct PrepImages { const float* in[4]; float* out[4]; int w, h; }; // w, h of the INPUT images
@@ -899,7 +908,8 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
     auto enqueue_all = [&]() -> int {
         const int n_wg0 = (int)((np + kThreads - 1) / kThreads);
         OP_HIP(hipMemcpyAsync(t->prep_dev, t->prep_host, sizeof(PrepFrames), hipMemcpyHostToDevice, t->stream));
-        hipLaunchKernelGGL(k_prep_convert_blur, dim3(n_wg0, 4), dim3(kThreads), 0, t->stream, (const PrepFrames*)t->prep_dev);
+        hipLaunchKernelGGL(k_prep_convert_blur, dim3((W + kBlurTx - 1) / kBlurTx, (H + kBlurTy - 1) / kBlurTy, 4), dim3(kBlurTx * kBlurTy), 0, t->stream,
+                           (const PrepFrames*)t->prep_dev);
         // NormalizeIntensity over the identity-pose correspondences of level 0 (Odometry.cpp:543-544).  Its state header
         // is uploaded from its own pinned buffer (st_host_norm), the loop's from st_host: no host-side wait in between.
         OP_HIP(hipMemcpyAsync(t->st, t->st_host_norm, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
