@@ -373,3 +373,32 @@ def test_pipelined_dense_slam_equals_sequential():
         assert np.array_equal(a.global_poses[i], b.global_poses[i]), i
     assert [f for f, _ in seen[1]] == [f for f, _ in seen[4]] == [i for i in range(n) if i != 6]
     assert all(np.array_equal(x[1], y[1]) for x, y in zip(seen[1], seen[4]))
+
+
+def test_dense_tracking_odd_image_size(oracle, odo):
+    """Odd width/height: pyrDown targets (cols/2, rows/2), so 161x121 -> 80x60 -> 40x30; preparation and tracking
+    agree with the oracle there too."""
+    from onepiece_amd import synthetic as S
+    w, h = 161, 121
+    fx, fy, cx, cy = S.FX / 4, S.FY / 4, S.CX / 4, S.CY / 4
+    frames = []
+    for k in (300, 301):
+        d, c = S.room_render(S.room_pose(k), width=w, height=h, fx=fx, fy=fy, cx=cx, cy=cy)
+        d = d.copy(); d[30:45, 50:90] = 0.0
+        frames.append((d, c))
+    cam = I.PinholeCamera("OPEN3D_DATASET")
+    cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height = fx, fy, cx, cy, w, h
+    odo.SetCamera(cam); odo.SetMultiScale(3); odo.iter_count_per_level = [4, 8, 16]
+    got = odo.DenseTracking(frames[1][1], frames[0][1], frames[1][0], frames[0][0], None, 0)
+    ocam = oracle.make_camera(fx, fy, cx, cy, w, h)
+    ref = oracle.dense_tracking(ocam, frames[1][1], frames[0][1], frames[1][0], frames[0][0], (4, 8, 16), 0, want_pyramids=True)
+    for level, (lw, lh) in enumerate(((161, 121), (80, 60), (40, 30))):
+        g, r = odo.ReadPyramid(1, 1, level), ref["pyramids"][("target", "depth", level)]
+        assert g.shape == r.shape == (lh, lw)
+        assert np.array_equal(np.isnan(g), np.isnan(r)) and np.array_equal(g.view(np.uint32)[~np.isnan(r)], r.view(np.uint32)[~np.isnan(r)])
+        g, r = odo.ReadPyramid(1, 5, level), ref["pyramids"][("target", "depth_dy", level)]
+        assert np.array_equal(np.isnan(g), np.isnan(r)) and np.array_equal(g.view(np.uint32)[~np.isnan(r)], r.view(np.uint32)[~np.isnan(r)])
+    # the loop itself is covered elsewhere; at 40x30 pixels on the coarsest level a free run is in the regime where the
+    # reference does not reproduce itself (see TRACK_CASES) -- here only that both land on the same motion
+    assert got.iterations == ref["iterations"] and rel_err(got.T, ref["T"]) <= 1e-2
+    odo.SetCamera(I.PinholeCamera("OPEN3D_DATASET"))
