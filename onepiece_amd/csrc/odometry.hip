@@ -330,18 +330,21 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i < 0 ? 0 : i;
 }
 
+// z: 0/1 = grey of frame 0/1, 2/3 = depth of frame 0/1.  The frame pointers are picked with selects (indexing the
+// by-value struct with a run-time z would move it to scratch memory).
 __device__ __forceinline__ float prep_raw(const PrepFrames& P, int z, int y, int x) {
     const size_t k = (size_t)y * P.w + x;
     if (z < 2) {
-        const unsigned char* c = P.rgb[z] + 3 * k;
+        const unsigned char* c = (z == 0 ? P.rgb[0] : P.rgb[1]) + 3 * k;
         const int g = (c[0] * 4899 + c[1] * 9617 + c[2] * 1868 + 8192) >> 14; // cvtColor RGB2GRAY, 8-bit
         return (float)(g & 255) / 255.0f;
     }
+    const void* dp = z == 2 ? P.depth[0] : P.depth[1];
     if (P.is_u16) {
-        const unsigned short d = static_cast<const unsigned short*>(P.depth[z - 2])[k];
+        const unsigned short d = static_cast<const unsigned short*>(dp)[k];
         return ((double)d > 0.5 * (double)P.depth_scale && (float)d < 4.0f * P.depth_scale) ? (float)d / P.depth_scale : __builtin_nanf("");
     }
-    const float d = static_cast<const float*>(P.depth[z - 2])[k];
+    const float d = static_cast<const float*>(dp)[k];
     return ((double)d > 0.5 && d < 4.0f) ? d : __builtin_nanf("");
 }
 
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(kBlurTx * kBlurTy) void k_prep_convert_blur(const P
     float hrow[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) hrow[r] = (0.25f * s_in[ly + r][lx] + 0.5f * s_in[ly + r][lx + 1]) + 0.25f * s_in[ly + r][lx + 2];
-    P.out[z][(size_t)y * P.w + x] = (0.25f * hrow[0] + 0.5f * hrow[1]) + 0.25f * hrow[2];
+    float* out = z == 0 ? P.out[0] : (z == 1 ? P.out[1] : (z == 2 ? P.out[2] : P.out[3]));
+    out[(size_t)y * P.w + x] = (0.25f * hrow[0] + 0.5f * hrow[1]) + 0.25f * hrow[2];
 }
 
 struct PrepImages { const float* in[4]; float* out[4]; int w, h; }; // w, h of the INPUT images
