@@ -375,3 +375,28 @@ def test_full_size_invariants_without_the_oracle():
     c = I.CubeHandler(max_blocks=1 << 18); c.SetVoxelResolution(0.005); c.SetCubeMap(keys, vox)
     ck, cv = c.GetCubeMap()
     assert np.array_equal(ck, keys) and np.array_equal(cv.view(np.uint32), vox.view(np.uint32))
+
+
+def test_random_frames_fuzz(oracle):
+    """Unstructured inputs: random depth (incl. zeros, negatives, NaN, huge values), random colours, random rigid poses
+    (large rotations, camera inside/outside the volume) -- bit-identical to the oracle frame after frame."""
+    rng = np.random.default_rng(20260928)
+    cam = (120.0, 118.0, 79.3, 60.7, 160, 120, 1000.0)
+    ov, hv = _mk(oracle, 0.02, cam, max_blocks=1 << 16)
+    for k in range(12):
+        d = rng.uniform(0.3, 4.5, (120, 160)).astype(np.float32)
+        d[rng.random((120, 160)) < 0.1] = 0.0
+        d[rng.random((120, 160)) < 0.02] = -1.0
+        d[rng.random((120, 160)) < 0.01] = np.nan
+        d[rng.random((120, 160)) < 0.01] = 1e6
+        if k % 3 == 0:                                   # smooth surface so that many voxels actually update
+            u, v = np.meshgrid(np.arange(160), np.arange(120))
+            d = (1.5 + 0.5 * np.sin(u / 17.0 + k) * np.cos(v / 13.0)).astype(np.float32)
+        c = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+        x = np.concatenate([rng.uniform(-0.3, 0.3, 3), rng.uniform(-1.0, 1.0, 3)]).astype(np.float32)
+        pose = oracle.se3_exp(x)
+        ov.integrate(d, c, pose)
+        hv.IntegrateImage(d, c, pose)
+        if k % 4 == 3:
+            _compare(oracle, ov, hv)
+    _compare(oracle, ov, hv)
