@@ -179,3 +179,25 @@ def test_load_from_rgbd_matches(oracle):
     keep = depth.reshape(-1) > 0
     exp = (rgb.reshape(-1, 3)[keep].astype(np.float32) / np.float32(255.0)).astype(np.float32)
     assert col.shape == exp.shape and np.array_equal(col.view(np.uint32), exp.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed,thr", [(1, 0.03), (2, 0.08), (3, 0.015)])
+def test_unstructured_clouds_fuzz(oracle, seed, thr):
+    """Random (non-image) clouds of different sizes, duplicated target points, source points far outside the target's
+    bounding box: the grid search and the oracle's kd-tree agree on every inlier pair and on the pose."""
+    rng = np.random.default_rng(seed)
+    m, n = 6000, 4500
+    tgt = rng.uniform(-1.0, 1.0, (m, 3)).astype(np.float32) * np.array([1.0, 0.6, 0.3], np.float32)
+    tgt[100:130] = tgt[200:230]                                  # exact duplicates: ties resolved by the lower index
+    nrm = rng.normal(size=(m, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    x = np.array([0.004, -0.003, 0.002, 0.01, -0.008, 0.006], np.float32)
+    Tx = oracle.se3_exp(x).astype(np.float64)
+    src = (tgt[rng.permutation(m)[:n]] @ Tx[:3, :3].T + Tx[:3, 3] + rng.normal(scale=0.002, size=(n, 3))).astype(np.float32)
+    src[:40] += 25.0                                             # far away: never matched
+    for plane in (True, False):
+        ref = oracle.icp(src, tgt, nrm if plane else None, None, 6, thr, point_to_plane=plane)
+        fn = R.PointToPlane if plane else R.PointToPoint
+        got = fn(R.PointCloud(src), R.PointCloud(tgt, nrm if plane else None), None, R.ICPParameter(6, thr))
+        assert got.per_iter_inliers[0] == ref["per_iter_inliers"][0]
+        assert np.array_equal(got.correspondence_set_index, ref["pairs"])
+        assert rel_err(got.last_T, ref["last_T"]) <= POSE_TOL
