@@ -402,3 +402,28 @@ def test_dense_tracking_odd_image_size(oracle, odo):
     # reference does not reproduce itself (see TRACK_CASES) -- here only that both land on the same motion
     assert got.iterations == ref["iterations"] and rel_err(got.T, ref["T"]) <= 1e-2
     odo.SetCamera(I.PinholeCamera("OPEN3D_DATASET"))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_pixel_correspondences_fuzz(oracle, odo, seed):
+    """Unstructured depth (noise, NaN speckle, steps) and random small motions: the acceptance chains become
+    irregular (they jump between rows and stop at NaNs) -- pairs stay bit-identical to the oracle's raster-order loop."""
+    rng = np.random.default_rng(seed)
+    W, H = 213, 97
+    lv = {"width": W, "height": H, "fx": 180.0 + seed, "fy": 175.0, "cx": 105.3, "cy": 47.9}
+    z = np.zeros((H, W), np.float32)
+    for k in O.TRACK_IMAGES:
+        lv[k] = z
+    base = (1.2 + 0.8 * rng.random((H, W))).astype(np.float32)
+    base[:, W // 2:] += 0.5                                       # a depth step
+    src = base + rng.normal(scale=0.01, size=(H, W)).astype(np.float32)
+    tgt = base + rng.normal(scale=0.01, size=(H, W)).astype(np.float32)
+    src[rng.random((H, W)) < 0.05] = np.nan
+    tgt[rng.random((H, W)) < 0.05] = np.nan
+    lv["source_depth"], lv["target_depth"] = src, tgt
+    for trial in range(4):
+        x = np.concatenate([rng.uniform(-0.03, 0.03, 3), rng.uniform(-0.02, 0.02, 3)]).astype(np.float32)
+        T = oracle.se3_exp(x)
+        ref = oracle.pixel_correspondences(lv, T)
+        got = odo.ComputeCorrespondencePixelWise(lv, T)
+        assert np.array_equal(got, ref) and len(ref) > 100
