@@ -427,3 +427,25 @@ def test_pixel_correspondences_fuzz(oracle, odo, seed):
         ref = oracle.pixel_correspondences(lv, T)
         got = odo.ComputeCorrespondencePixelWise(lv, T)
         assert np.array_equal(got, ref) and len(ref) > 100
+
+
+def test_chains_longer_than_the_lds_window(oracle, odo):
+    """A fronto-parallel plane shifted by exactly one pixel UP at 640x480: every acceptance chain runs along its column
+    (one link per row, up to 479 links), far beyond the rows a workgroup stages in LDS -- the global fallback of the walk."""
+    W, H = 640, 480
+    lv = {"width": W, "height": H, "fx": 500.0, "fy": 500.0, "cx": 320.0, "cy": 240.0}
+    z = np.zeros((H, W), np.float32)
+    for k in O.TRACK_IMAGES:
+        lv[k] = z
+    lv["source_depth"] = np.full((H, W), 2.0, np.float32)
+    lv["target_depth"] = np.full((H, W), 2.0, np.float32)
+    T = np.eye(4, dtype=np.float32); T[1, 3] = -2.0 / 500.0
+    ref = oracle.pixel_correspondences(lv, T)
+    got = odo.ComputeCorrespondencePixelWise(lv, T)
+    assert np.array_equal(got, ref)
+    assert 0.4 * W * H < len(ref) < 0.6 * W * H      # alternating accept / reject down every column
+    # and a link that does not fit the 16-bit code: 110 rows up in one step (depth step makes the gate pass)
+    T2 = np.eye(4, dtype=np.float32); T2[1, 3] = -110 * 2.0 / 500.0
+    ref = oracle.pixel_correspondences(lv, T2)
+    got = odo.ComputeCorrespondencePixelWise(lv, T2)
+    assert np.array_equal(got, ref) and len(ref) > 0
