@@ -2,10 +2,11 @@
 then TSDF fusion of every `--every`-th tracked frame with the tracked poses, trajectory.txt out.
 
     python examples/dense_fusion.py <basepath> <voxel_resolution> [--every 8]     # a TUM-format folder
-    python examples/dense_fusion.py --synthetic 200 0.01                           # the analytic room
+    python examples/dense_fusion.py - 0.01 --synthetic 200                         # the analytic room
 
 Differences from the reference example, stated: no submap registration / FastBA (out
-of scope) so poses are pure odometry; no bilateral depth filter (OpenCV); no mesh extraction (N2).
+of scope) so poses are pure odometry; the bilateral depth filter (DenseFusion.cpp:92-93) follows
+cv::bilateralFilter's documented definition (OpenCV is unpinned); no mesh written.
 """
 import argparse
 import os
@@ -15,7 +16,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from onepiece_amd import integration as I, dense_slam as DS, synthetic as S, sequence as Q  # noqa: E402
+from onepiece_amd import integration as I, dense_slam as DS, synthetic as S, sequence as Q, tool  # noqa: E402
 
 
 def main():
@@ -46,8 +47,8 @@ def main():
     for i, (rgb, depth) in enumerate(zip(rgbs, depths)):
         if not slam.tracking_success[i] or i % args.every:
             continue
-        d32 = Q.ConvertDepthTo32F(depth, cam.depth_scale) if depth.dtype == np.uint16 else depth
-        vol.IntegrateImage(d32, rgb, slam.global_poses[i])
+        filtered_depth = tool.BilateralFilter(depth, depth_scale=cam.depth_scale)   # ConvertDepthTo32F + BilateralFilter (:92-93)
+        vol.IntegrateImage(filtered_depth, rgb, slam.global_poses[i])
         fused += 1
     n_blocks = vol.BlockCount()
     t2 = time.perf_counter()

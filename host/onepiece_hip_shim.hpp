@@ -53,6 +53,16 @@ inline int IntegrateImage(op_volume* vol, const Image& depth, const Image& rgb, 
     return op_volume_integrate(vol, depth.data, fmt, reinterpret_cast<const uint8_t*>(rgb.data), OP_MEM_HOST, p, pi);
 }
 
+// tool::ConvertDepthTo32F(depth, refined, depth_scale) + tool::BilateralFilter(refined, target, range)
+// (Tool/ImageProcessing.cpp:68-91, 64-67): `source` is the raw CV_16UC1 image or an already converted CV_32FC1
+// one; `target_data` is target.data after target.create(source.rows, source.cols, CV_32FC1).
+template <class Image>
+inline int BilateralFilter(const Image& source, float depth_scale, float* target_data, int range = 7, int device = 0) {
+    const int fmt = source.depth() == kCvDepth32F ? OP_DEPTH_F32 : OP_DEPTH_U16;
+    return op_bilateral_filter_depth(source.data, fmt, depth_scale, source.cols, source.rows, 1, range, 0.03f, 4.5f, OP_MEM_HOST, device,
+                                     nullptr, target_data);
+}
+
 // CubeHandler::IntegrateImage(const geometry::RGBDFrame&, pose) (CubeHandler.cpp:211-214): rgbd.depth / rgbd.rgb.
 template <class Frame, class Mat4>
 inline int IntegrateFrame(op_volume* vol, const Frame& rgbd, const Mat4& pose, const Mat4& pose_inv) {

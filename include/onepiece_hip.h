@@ -237,6 +237,24 @@ int op_estimate_rigid_point_to_plane(const float *source_xyz, size_t n_source, c
  * given as n x 6 floats (source xyz, target xyz). */
 int op_estimate_rigid_transformation(const float *pairs_xyz6, size_t n_pairs, int mem, int device,
                                      float T[16]);
+/* tool::ConvertDepthTo32F + tool::BilateralFilter (Tool/ImageProcessing.cpp:68-91, 64-67; header default
+ * range = 7, Tool/ImageProcessing.h:19), the depth preprocessing every fusion driver runs right before
+ * IntegrateImage (example/ImageSequenceIntegration.cpp:36-38, DenseFusion/DenseFusion.cpp:92-94,
+ * ImageIntegration.cpp:24-27): cv::bilateralFilter(src, dst, d, sigma_color = 0.03, sigma_space = 4.5) on
+ * n_images row-major width x height depth images (OP_DEPTH_U16 input is first divided by depth_scale).
+ * PARITY NOTE: OpenCV is not vendored by the reference; this is cv::bilateralFilter's documented CV_32FC1
+ * definition, unpinned:  radius = d / 2 (d <= 0: round(1.5 sigma_space); at least 1), sigma <= 0 -> 1,
+ *     out(p) = sum_q w(q) src(q) / sum_q w(q),  q = p + (i, j) with i*i + j*j <= radius^2, BORDER_REFLECT_101,
+ *     w(q) = exp(-(i*i + j*j) / (2 sigma_space^2)) * exp(-(src(q) - src(p))^2 / (2 sigma_color^2)),
+ * in float32, taps summed row by row.  (OpenCV evaluates the second factor through a 4096-bin linearly
+ * interpolated table over the image's value range; this evaluates it directly.)
+ * stream: NULL -> the call runs on the library's stream and returns when `out` is final; a hipStream_t
+ * (OP_MEM_DEVICE only) -> only enqueued on that stream, e.g. op_volume_stream() so that the filtered depth
+ * feeds op_volume_integrate without a host synchronisation. */
+int op_bilateral_filter_depth(const void *depth, int depth_format, float depth_scale, int width, int height,
+                              int n_images, int d, float sigma_color, float sigma_space, int mem, int device,
+                              void *stream, float *out);
+
 /* PointCloud::LoadFromDepth (Geometry/PointCloud.cpp:72-100) on the device: xyz_out (mem) gets the
  * compacted row-major-ordered points; *n the count. */
 int op_points_from_depth(const op_camera *cam, const void *depth, int depth_fmt, int mem, int device,

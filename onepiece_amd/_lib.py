@@ -48,6 +48,7 @@ OP_TRACK_HYBRID, OP_TRACK_PHOTO, OP_TRACK_DEPTH = 0, 1, 2
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
+OP_OK, OP_ERR_INVALID = 0, 1
 OP_ERR_NO_DEVICE, OP_ERR_CAPACITY, OP_ERR_MISMATCH, OP_ERR_NO_NORMALS = 2, 3, 4, 5
 
 _fp = C.POINTER(C.c_float)
@@ -114,6 +115,7 @@ SIGNATURES = {
     "op_estimate_rigid_point_to_plane": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, _fp]),
     "op_estimate_rigid_transformation": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_int, _fp]),
     "op_points_from_rgbd": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _szp]),
+    "op_bilateral_filter_depth": (C.c_int, [_vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "op_points_from_depth": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, C.c_int, C.c_int, _vp, _szp]),
     "op_tracker_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "op_tracker_destroy": (C.c_int, [_vp]),

@@ -1513,6 +1513,41 @@ void orc_prep_sobel(const float *in, int w, int h, int axis, float *out) {
     else sep_filter(in, w, h, s, 3, d, 3, out);
 }
 
+/* tool::ConvertDepthTo32F + tool::BilateralFilter (Tool/ImageProcessing.cpp:68-91, 64-67) =
+ * cv::bilateralFilter(src, dst, d, sigma_color, sigma_space) on CV_32FC1.  OpenCV is not vendored: this restates the
+ * DOCUMENTED definition (the one include/onepiece_hip.h gives for op_bilateral_filter_depth), parity unpinned. */
+static int reflect101_any(int i, int n) { /* cv::borderInterpolate(BORDER_REFLECT_101) for any offset */
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+void orc_bilateral_filter(const void *depth, int is_u16, float depth_scale, int w, int h, int d, float sigma_color,
+                          float sigma_space, float *out) {
+    if (!(sigma_color > 0)) sigma_color = 1.0f;
+    if (!(sigma_space > 0)) sigma_space = 1.0f;
+    int radius = d <= 0 ? (int)lrint((double)sigma_space * 1.5) : d / 2;
+    if (radius < 1) radius = 1;
+    const float gc = (float)(-0.5 / ((double)sigma_color * sigma_color)), gs = (float)(-0.5 / ((double)sigma_space * sigma_space));
+    float *src = (float *)malloc((size_t)w * h * sizeof(float));
+    for (size_t k = 0; k < (size_t)w * h; ++k) /* ImageProcessing.cpp:76-88 */
+        src[k] = is_u16 ? (float)((const uint16_t *)depth)[k] / depth_scale : ((const float *)depth)[k];
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float v0 = src[(size_t)y * w + x];
+            float sum = 0.0f, wsum = 0.0f;
+            for (int i = -radius; i <= radius; ++i)
+                for (int j = -radius; j <= radius; ++j) {
+                    if (i * i + j * j > radius * radius) continue;
+                    const float v = src[(size_t)reflect101_any(y + i, h) * w + reflect101_any(x + j, w)];
+                    const float wgt = expf((float)(i * i + j * j) * gs) * expf((v - v0) * (v - v0) * gc);
+                    sum += v * wgt;
+                    wsum += wgt;
+                }
+            out[(size_t)y * w + x] = sum / wsum;
+        }
+    free(src);
+}
+
 /* DenseOdometryFunction.cpp:129-145 (float sequential means, LinearTransform with a float scale). */
 void orc_normalize_intensity(float *source, float *target, int w, int h, const int32_t *corr, size_t n) {
     float mean_s = 0.0f, mean_t = 0.0f;

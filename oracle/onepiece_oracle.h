@@ -183,6 +183,8 @@ void orc_prep_depth_nan(const void *depth, int is_u16, float depth_scale, int w,
 void orc_prep_blur3(const float *in, int w, int h, float *out);
 void orc_prep_pyrdown(const float *in, int w, int h, float *out);   /* out: (w/2) x (h/2) */
 void orc_prep_sobel(const float *in, int w, int h, int axis, float *out);
+void orc_bilateral_filter(const void *depth, int is_u16, float depth_scale, int w, int h, int d, float sigma_color,
+                          float sigma_space, float *out);
 void orc_normalize_intensity(float *source, float *target, int w, int h, const int32_t *corr, size_t n);
 /* Odometry::DenseTracking, cv::Mat overload (Odometry.cpp:463-524).  pyr_out: optional array of
  * 2*6*n_levels image pointers [(frame*6+kind)*n_levels+level], each released with orc_free. */

@@ -124,6 +124,7 @@ def lib():
         L.orc_prep_blur3.argtypes = [_fp, C.c_int, C.c_int, _fp]
         L.orc_prep_pyrdown.argtypes = [_fp, C.c_int, C.c_int, _fp]
         L.orc_prep_sobel.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp]
+        L.orc_bilateral_filter.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp]
         L.orc_normalize_intensity.argtypes = [_fp, _fp, C.c_int, C.c_int, _ip, C.c_size_t]
         L.orc_dense_tracking.restype = C.c_int
         L.orc_dense_tracking.argtypes = [C.POINTER(Camera), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -466,6 +467,16 @@ def _img_op(fn, img, *extra, half=False):
     h, w = img.shape
     out = np.empty((h // 2, w // 2) if half else (h, w), np.float32)
     fn(_p(img), w, h, *extra, _p(out))
+    return out
+
+
+def bilateral_filter(depth, d=7, sigma_color=0.03, sigma_space=4.5, depth_scale=1000.0):
+    """tool::BilateralFilter after tool::ConvertDepthTo32F (float32 metres or uint16 / depth_scale in)."""
+    a = np.ascontiguousarray(depth)
+    assert a.dtype in (np.float32, np.uint16) and a.ndim == 2
+    out = np.empty(a.shape, np.float32)
+    lib().orc_bilateral_filter(C.c_void_p(a.ctypes.data), int(a.dtype == np.uint16), float(depth_scale), a.shape[1], a.shape[0],
+                               int(d), float(sigma_color), float(sigma_space), out.ctypes.data_as(_fp))
     return out
 
 

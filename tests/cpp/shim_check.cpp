@@ -98,6 +98,11 @@ int main(int argc, char** argv) {
         if (i == 0) { if (sh::PrepareCubes(vol, depth, pose, inv, list) != OP_OK) return 1; first_list = list.size(); }
         if (sh::IntegrateImage(vol, depth, rgb, pose, inv) != OP_OK) { std::printf("{\"error\": \"%s\"}\n", op_last_error()); return 1; }
     }
+    // the drivers' depth front end through the shim: a smooth surface stays within a millimetre, the image stays valid
+    std::vector<float> filtered(640 * 480);
+    const int frc = sh::BilateralFilter(depth, 1000.0f, filtered.data());
+    double fmax = 0;
+    for (size_t k = 0; k < filtered.size(); ++k) fmax = std::fmax(fmax, std::fabs((double)filtered[k] - d[k]));
     Map map;
     if ((sh::DownloadInto<Map, Vec3i, Cube, Voxel, Vec3f>(vol, map)) != OP_OK) return 1;
     unsigned long long observed = 0, x = 0;
@@ -149,10 +154,10 @@ int main(int argc, char** argv) {
     op_tracker_destroy(trk);
     std::printf("{\"blocks\": %zu, \"observed\": %llu, \"weight_sum\": %.0f, \"xor\": \"0x%llx\", \"first_list\": %zu, \"reupload_blocks\": %zu, "
                 "\"icp_rc\": %d, \"icp_pairs\": %zu, \"icp_tx\": %.6f, \"track_rc\": %d, \"track_pairs\": %zu, \"track_ok\": %d, "
-                "\"track_tx\": %.6f, \"track_rmse\": %.6g, \"track_first_pair\": [%u, %u, %u, %u], \"mesh_rc\": %d, \"mesh_triangles\": %zu, \"mesh_vertices\": %zu}\n",
+                "\"track_tx\": %.6f, \"track_rmse\": %.6g, \"track_first_pair\": [%u, %u, %u, %u], \"mesh_rc\": %d, \"mesh_triangles\": %zu, \"mesh_vertices\": %zu, \"filter_rc\": %d, \"filter_max_change\": %.6g}\n",
                 map.size(), observed, wsum, x, first_list, n2, rc, res.correspondence_set_index.size(), res.T(0, 3), trc, px_pairs.size(), (int)ok,
                 Tt(0, 3), rmse, px_pairs.empty() ? 0u : px_pairs[0].first(0), px_pairs.empty() ? 0u : px_pairs[0].first(1),
-                px_pairs.empty() ? 0u : px_pairs[0].second(0), px_pairs.empty() ? 0u : px_pairs[0].second(1), mrc, mesh.triangles.size(), mesh.points.size());
+                px_pairs.empty() ? 0u : px_pairs[0].second(0), px_pairs.empty() ? 0u : px_pairs[0].second(1), mrc, mesh.triangles.size(), mesh.points.size(), frc, fmax);
     op_volume_destroy(vol); op_volume_destroy(vol2);
     return 0;
 }

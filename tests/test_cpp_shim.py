@@ -40,6 +40,9 @@ def test_shim_end_to_end_reproduces_reference_run_statistics(hip):
     assert abs(r["track_tx"]) < 1e-5 and r["track_rmse"] < 1e-5 and r["track_first_pair"] == [0, 0, 0, 0]
     # mesh extraction through the shim: the wall is one surface -> hundreds of thousands of triangles, 3 vertices each
     assert r["mesh_rc"] == 0 and r["mesh_triangles"] > 100000 and r["mesh_vertices"] == 3 * r["mesh_triangles"]
+    # tool::BilateralFilter through the shim: the smooth wall moves (most at the reflected borders, where the slope of up to
+    # 7.5 mm / pixel turns into a kink), but by millimetres
+    assert r["filter_rc"] == 0 and 1e-5 < r["filter_max_change"] < 0.02, r
 
 
 def test_shim_instantiates_with_real_eigen_types(hip):
