@@ -48,6 +48,15 @@ inline int use_device(int device) {
 
 constexpr int kWave = 64; // gfx950 wavefront width
 
+// XCD-aware workgroup order.  Workgroup p of a 1-D grid is dispatched to XCD p % 8 and every XCD has its own 4 MiB
+// L2 (MI355X_MICROARCH.md), so with the plain order eight neighbouring workgroups -- which gather neighbouring data --
+// land on eight different L2s and each L2 sees the whole working set.  This bijection of [0, n) hands XCD x the
+// contiguous slab of logical indices [start_x, start_x + q + (x < r)), q = n / 8, r = n % 8.
+__device__ __forceinline__ unsigned xcd_slab_index(unsigned p, unsigned n) {
+    const unsigned x = p & 7u, slot = p >> 3, q = n >> 3, r = n & 7u;
+    return x * q + (x < r ? x : r) + slot;
+}
+
 // Wave-wide sums of 32 doubles per lane by recursive halving ("reduce-scatter"): at the step with lane
 // mask M a lane keeps one half of its values and receives the partner's copy of that half, so the work
 // halves every step (16+8+4+2+1+1 = 32 fp64 adds per lane instead of 32 x 6 for a butterfly per value).

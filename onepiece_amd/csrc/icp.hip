@@ -192,13 +192,18 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                                                            const float* __restrict__ tgt_orig, double thr2, int* __restrict__ nn,
                                                            int* __restrict__ inl, double* __restrict__ partials) {
     __shared__ double s_red[kIterThreads / 64][kNSums];
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    __shared__ uint2 s_runs[8][kIterThreads]; // per lane: the [begin, end) runs of the rows it still has to scan
+    // what the point contributes to the sums; the 29 fp64 accumulators themselves are only formed after the search
+    bool inlier = false;
+    double e = 0.0;
+    float a0 = 0, a1 = 0, a2 = 0, t0 = 0, t1 = 0, t2 = 0, n0 = 0, n1 = 0, n2 = 0;
 
     // exactly one source point per thread (grid = ceil(n / 256)): the 29 fp64 accumulators are then
     // not live across the neighbour search, which keeps the kernel at ~80 VGPRs instead of 150
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    // XCD-aware: the source is in image order, so a contiguous slab of it meets a contiguous part of the cell-sorted
+    // target; with the plain order every XCD's L2 would see all of target + normals + cell tables (> 4 MiB)
+    const unsigned wg = op::xcd_slab_index(blockIdx.x, gridDim.x);
+    const size_t i = wg * (size_t)blockDim.x + threadIdx.x;
     if (i < n) {
         const float s0 = src[3 * i], s1 = src[3 * i + 1], s2 = src[3 * i + 2];
         // start_T: device memory when the update step runs on the device (T != nullptr), a by-value kernel
@@ -208,7 +213,6 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         for (int k = 0; k < 16; ++k) M[k] = T ? T[k] : T_arg.m[k];
         float tp0 = 0, tp1 = 0, tp2 = 0;
         int best = -1;
-        float t0 = 0, t1 = 0, t2 = 0, n0 = 0, n1 = 0, n2 = 0;
         if (MODE != 2) {
             // TransformPoints (Geometry.cpp:19-27): 4x4 * (s,1), then divide by w
             const float q0 = ((M[0] * s0 + M[1] * s1) + M[2] * s2) + M[3] * 1.0f;
@@ -232,44 +236,74 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                 const float gy[3] = {fmaxf(fy, 0.0f), 0.0f, fmaxf(cell - fy, 0.0f)};
                 const float gz[3] = {fmaxf(fz, 0.0f), 0.0f, fmaxf(cell - fz, 0.0f)};
                 if (x_lo <= x_hi) {
-                    // the [begin, end) runs of all nine rows are fetched first (independent loads, one round trip)
-                    // instead of one dependent round trip per visited row
-                    unsigned rb[9], re[9];
+                    // the [begin, end) runs of all nine rows are fetched first (independent loads, one round trip) instead of
+                    // one dependent round trip per visited row; the centre row's stays in registers, the other eight are
+                    // parked in the lane's LDS column (slot = q, skipping the centre) until the centre row has been scanned
+                    unsigned cb = 0u, ce = 0u;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
                         const int dy = q % 3 - 1, dz = q / 3 - 1;
                         const int z = cz + dz, y = cy + dy;
-                        rb[q] = 0u; re[q] = 0u;
+                        unsigned rb = 0u, re = 0u;
                         if (!(z < 0 || z >= g.gz || y < 0 || y >= g.gy)) {
                             const size_t row = ((size_t)z * g.gy + y) * g.gx;
                             // cells x_lo..x_hi own one contiguous run of the sorted target
-                            rb[q] = cell_start[row + x_lo];
-                            re[q] = cell_start[row + x_hi] + cell_count[row + x_hi];
+                            rb = cell_start[row + x_lo];
+                            re = cell_start[row + x_hi] + cell_count[row + x_hi];
+                        }
+                        if (q == 4) { cb = rb; ce = re; }
+                        else s_runs[q < 4 ? q : q - 1][threadIdx.x] = make_uint2(rb, re);
+                    }
+                    // one candidate: min by (distance, original index), so the visiting order does not matter
+                    auto visit = [&](const float4& c, unsigned pos) {
+                        const float dx = tp0 - c.x, dyy = tp1 - c.y, dzz = tp2 - c.z;
+                        const float d = dx * dx + dyy * dyy + dzz * dzz;
+                        const int ci = __float_as_int(c.w);
+                        if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)pos; }
+                    };
+                    // 1. the centre row (dy,dz) = (0,0), kScan candidates per trip: the loads are independent, so their
+                    //    L2 round trips overlap (the scan is a latency chain otherwise)
+                    for (unsigned p = cb; p < ce; p += kScan) {
+                        float4 c[kScan];
+#pragma unroll
+                        for (int k = 0; k < kScan; ++k) c[k] = tgt[min(p + k, ce - 1)];
+#pragma unroll
+                        for (int k = 0; k < kScan; ++k) {
+                            if (p + k >= ce) break;
+                            visit(c[k], p + k);
                         }
                     }
+                    // 2. the other 8 rows: those that can still hold the nearest neighbour are decided NOW, with the centre
+                    //    row's best distance, and their runs are walked as ONE flattened candidate stream.  A wave then
+                    //    makes max-over-lanes ceil(candidates / kScan) trips instead of one or two trips for every row that
+                    //    ANY of its lanes still needs (the union over 64 lanes is almost always all 8 rows).  The runs of a
+                    //    lane sit in its private LDS column, which a dynamic index reaches without scratch memory; the
+                    //    survivors are compacted in place (nr never overtakes the slot being read).
+                    int nr = 0;
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) {
-                        // r = 0: (dy,dz) = (0,0); then the remaining 8 rows
-                        const int q = r == 0 ? 4 : (r <= 4 ? r - 1 : r);
+                    for (int q = 0; q < 9; ++q) {
+                        if (q == 4) continue;
                         const int dy = q % 3 - 1, dz = q / 3 - 1;
-                        const unsigned beg = rb[q], end = re[q];
-                        if (beg >= end) continue;
                         const float bound = gy[dy + 1] * gy[dy + 1] + gz[dz + 1] * gz[dz + 1];
-                        if (0.99f * bound > best_d) continue;
-                        // kScan candidates per trip: the loads are independent, so their L2 round trips overlap
-                        // (the scan is a latency chain otherwise)
-                        for (unsigned p = beg; p < end; p += kScan) {
-                            float4 c[kScan];
+                        const uint2 run = s_runs[q < 4 ? q : q - 1][threadIdx.x];
+                        if (run.x < run.y && !(0.99f * bound > best_d)) { s_runs[nr][threadIdx.x] = run; ++nr; }
+                    }
+                    unsigned p = 0, e = 0;
+                    int ri = 0;
+                    while (p < e || ri < nr) {
+                        unsigned idx[kScan];
 #pragma unroll
-                            for (int k = 0; k < kScan; ++k) c[k] = tgt[min(p + k, end - 1)];
+                        for (int k = 0; k < kScan; ++k) {
+                            if (p == e && ri < nr) { const uint2 run = s_runs[ri][threadIdx.x]; p = run.x; e = run.y; ++ri; } // runs are non-empty
+                            idx[k] = p < e ? p++ : 0xffffffffu;
+                        }
+                        float4 c[kScan];
 #pragma unroll
-                            for (int k = 0; k < kScan; ++k) {
-                                if (p + k >= end) break;
-                                const float dx = tp0 - c[k].x, dyy = tp1 - c[k].y, dzz = tp2 - c[k].z;
-                                const float d = dx * dx + dyy * dyy + dzz * dzz;
-                                const int ci = __float_as_int(c[k].w);
-                                if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)(p + k); }
-                            }
+                        for (int k = 0; k < kScan; ++k) c[k] = tgt[idx[k] != 0xffffffffu ? idx[k] : idx[0]];
+#pragma unroll
+                        for (int k = 0; k < kScan; ++k) {
+                            if (idx[k] == 0xffffffffu) break;
+                            visit(c[k], idx[k]);
                         }
                     }
                 }
@@ -284,39 +318,42 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             best = nn[i];
             if (best >= 0) { t0 = tgt_orig[3 * best]; t1 = tgt_orig[3 * best + 1]; t2 = tgt_orig[3 * best + 2]; }
         }
-        bool inlier = false;
         if (best >= 0) {
             // CountInliers (ICP.cpp:15-23): ||(R s + t) - target||^2 in float, compared in double
             const float d0 = (sum3(M[0] * s0, M[1] * s1, M[2] * s2) + M[3]) - t0;
             const float d1 = (sum3(M[4] * s0, M[5] * s1, M[6] * s2) + M[7]) - t1;
             const float d2 = (sum3(M[8] * s0, M[9] * s1, M[10] * s2) + M[11]) - t2;
-            const double e = (double)sum3(d0 * d0, d1 * d1, d2 * d2);
-            if (e < thr2) {
-                inlier = true;
-                acc[27] += e;
-                acc[28] += 1.0;
-                if (MODE == 1) {
-                    // ICP.cpp:121-136: row = [n ; s' x n], r = n.s' - n.t
-                    const float r = sum3(n0 * tp0, n1 * tp1, n2 * tp2) - sum3(n0 * t0, n1 * t1, n2 * t2);
-                    const float row[6] = {n0, n1, n2, tp1 * n2 - tp2 * n1, tp2 * n0 - tp0 * n2, tp0 * n1 - tp1 * n0};
-                    int k = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a)
-#pragma unroll
-                        for (int b = a; b < 6; ++b) acc[k++] += (double)(row[a] * row[b]);
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(r * row[a]);
-                } else {
-                    const float a0 = MODE == 0 ? tp0 : s0, a1 = MODE == 0 ? tp1 : s1, a2 = MODE == 0 ? tp2 : s2;
-                    acc[0] += a0; acc[1] += a1; acc[2] += a2;
-                    acc[3] += t0; acc[4] += t1; acc[5] += t2;
-                    acc[6] += (double)a0 * t0; acc[7] += (double)a0 * t1; acc[8] += (double)a0 * t2;
-                    acc[9] += (double)a1 * t0; acc[10] += (double)a1 * t1; acc[11] += (double)a1 * t2;
-                    acc[12] += (double)a2 * t0; acc[13] += (double)a2 * t1; acc[14] += (double)a2 * t2;
-                }
-            }
+            e = (double)sum3(d0 * d0, d1 * d1, d2 * d2);
+            inlier = e < thr2;
         }
+        // the point the sums are taken over: the transformed point, except for the final pass of PointToPoint (MODE 2)
+        a0 = MODE == 2 ? s0 : tp0; a1 = MODE == 2 ? s1 : tp1; a2 = MODE == 2 ? s2 : tp2;
         if (inl) inl[i] = inlier ? best : -1;
+    }
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if (inlier) {
+        acc[27] = e;
+        acc[28] = 1.0;
+        if (MODE == 1) {
+            // ICP.cpp:121-136: row = [n ; s' x n], r = n.s' - n.t
+            const float r = sum3(n0 * a0, n1 * a1, n2 * a2) - sum3(n0 * t0, n1 * t1, n2 * t2);
+            const float row[6] = {n0, n1, n2, a1 * n2 - a2 * n1, a2 * n0 - a0 * n2, a0 * n1 - a1 * n0};
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[k++] = (double)(row[a] * row[b]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[21 + a] = (double)(r * row[a]);
+        } else {
+            acc[0] = a0; acc[1] = a1; acc[2] = a2;
+            acc[3] = t0; acc[4] = t1; acc[5] = t2;
+            acc[6] = (double)a0 * t0; acc[7] = (double)a0 * t1; acc[8] = (double)a0 * t2;
+            acc[9] = (double)a1 * t0; acc[10] = (double)a1 * t1; acc[11] = (double)a1 * t2;
+            acc[12] = (double)a2 * t0; acc[13] = (double)a2 * t1; acc[14] = (double)a2 * t2;
+        }
     }
     // wave64 reduce-scatter, then LDS across the workgroup's waves, one partial per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -326,7 +363,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     if (threadIdx.x < kNSums) {
         double v = 0;
         for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
+        partials[(size_t)wg * kNSums + threadIdx.x] = v; // logical order: the second pass sums in source order as before
     }
 }
 

@@ -4,6 +4,8 @@
 // uploads the frames to HBM once, then fuses them `reps` times into a fresh 5 mm volume.
 // With a 5th argument "track": instead tracks every consecutive frame pair (op_tracker_dense_tracking, device
 // frames) and fuses each frame with its TRACKED pose -- the config-4 pipeline, one pair at a time.
+// With "icp": registration::PointToPlane of frame 1's cloud onto frame 0's (LoadFromDepth, EstimateNormals, 30 iterations,
+// threshold 0.01 -- ICPTest.cpp's configuration), `reps` times.
 // Build: hipcc -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o gpurun_out/prof_driver
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -68,6 +70,29 @@ int main(int argc, char** argv) {
             printf("rep %d: tracked %d/%d frames, %.3f ms/frame (tracking + fusion), blocks %zu, final t = (%.4f %.4f %.4f)\n", r, ok, n, dt / n * 1e3, nb, g[3], g[7], g[11]);
         }
         op_tracker_destroy(trk);
+        op_volume_destroy(v);
+        return 0;
+    }
+    if (argc > 4 && std::string(argv[4]) == "icp") {
+        if (n < 2) return 1;
+        std::vector<float> tgt(npx * 3), src(npx * 3), nrm(npx * 3);
+        size_t nt = 0, ns = 0;
+        CK(op_points_from_depth(&cam, depth.data(), OP_DEPTH_F32, OP_MEM_HOST, 0, tgt.data(), &nt));
+        CK(op_points_from_depth(&cam, depth.data() + npx, OP_DEPTH_F32, OP_MEM_HOST, 0, src.data(), &ns));
+        CK(op_estimate_normals(tgt.data(), nt, 0.1f, 30, OP_MEM_HOST, 0, nrm.data()));
+        op_icp* icp; CK(op_icp_create(tgt.data(), nrm.data(), nt, 0.01, OP_MEM_HOST, 0, &icp));
+        CK(op_icp_set_source(icp, src.data(), ns, OP_MEM_HOST));
+        const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int r = 0; r < reps; ++r)
+            for (int mode = 1; mode >= 0; --mode) {
+                op_icp_result res;
+                auto t0 = std::chrono::steady_clock::now();
+                CK(op_icp_run(icp, mode, I4, 30, &res, nullptr, 0, nullptr, nullptr));
+                double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                printf("rep %d %s: %zu x %zu points, 30 iterations in %.3f ms (%.0f it/s), inliers %llu, rmse %.6g\n", r, mode ? "point-to-plane" : "point-to-point",
+                       ns, nt, dt * 1e3, 30 / dt, (unsigned long long)res.n_inliers, res.rmse);
+            }
+        op_icp_destroy(icp);
         op_volume_destroy(v);
         return 0;
     }
