@@ -108,7 +108,8 @@ __global__ __launch_bounds__(kThreads) void k_track_assoc(const TrackState* __re
     if (threadIdx.x == 0) op_host::track_projection(L.fx, L.fy, L.cx, L.cy, st->T, s_P.krk, s_P.kt);
     __syncthreads();
     const Proj P = s_P;
-    const int npix = L.w * L.h, s = blockIdx.x * kThreads + threadIdx.x;
+    // XCD-aware order (common.hpp): an XCD works on one band of the image, so its L2 holds one band of the target images
+    const int npix = L.w * L.h, s = (int)op::xcd_slab_index(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
     if (s >= npix) return;
     const int2 c = associate(L, P, s);
     unsigned short cd = kInvalid;
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
     const LevelDev L = st->lv[l];
     if (threadIdx.x < 12) s_T[threadIdx.x] = st->T[threadIdx.x];
     const int npix = L.w * L.h;
-    const int own0 = blockIdx.x * kIterThreads, own1 = min(own0 + kIterThreads, npix); // one own pixel per thread
+    const int wg = (int)op::xcd_slab_index(blockIdx.x, gridDim.x);  // XCD-aware order, as in k_track_assoc
+    const int own0 = wg * kIterThreads, own1 = min(own0 + kIterThreads, npix); // one own pixel per thread
     const int win0 = max(0, own1 - win_cap) & ~7;              // 16-byte aligned window start
     {   // stage the window, 8 codes (16 B) per load; links that point before the window become kFar
         const int n8 = (own1 - win0 + 7) >> 3;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
     if (threadIdx.x < kNSums) {
         double v = 0;
         for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
+        partials[(size_t)wg * kNSums + threadIdx.x] = v;
     }
 }
 
