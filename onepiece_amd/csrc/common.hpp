@@ -61,8 +61,8 @@ __device__ __forceinline__ unsigned xcd_slab_index(unsigned p, unsigned n) {
 // mask M a lane keeps one half of its values and receives the partner's copy of that half, so the work
 // halves every step (16+8+4+2+1+1 = 32 fp64 adds per lane instead of 32 x 6 for a butterfly per value).
 // On return lane L holds in v[0] the wave total of element (L >> 1) & 31.
-template <int H, int M>
-__device__ __forceinline__ void wave_halve(double (&v)[32], int lane) {
+template <int H, int M, int N>
+__device__ __forceinline__ void wave_halve(double (&v)[N], int lane) {
     const bool up = (lane & M) != 0;
 #pragma unroll
     for (int i = 0; i < H; ++i) {
@@ -79,6 +79,31 @@ __device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
     wave_halve<2, 4>(v, lane);
     wave_halve<1, 2>(v, lane);
     v[0] += __shfl_xor(v[0], 1, 64);
+}
+// The same reduction when the 32 per-lane values are cheap to (re)compute: `val(k)` (k a compile-time constant after
+// unrolling) is evaluated inside the first halving step, so only 16 doubles are ever live (32 VGPRs instead of 64).
+// Returns what wave_reduce_scatter32 leaves in v[0]; bit-identical to it.
+template <int K> struct index_c { static constexpr int value = K; };
+template <int I, class F>
+__device__ __forceinline__ void lazy_first_step(F& val, bool up, double (&v)[16]) {
+    if constexpr (I < 16) {
+        const double lo = val(index_c<I>{}), hi = val(index_c<I + 16>{});
+        v[I] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 32, 64);
+        lazy_first_step<I + 1>(val, up, v);
+    }
+}
+// val is called as val(index_c<k>{}) so that k is a constant expression inside it
+template <class F>
+__device__ __forceinline__ double wave_reduce_scatter32_lazy(F val) {
+    const int lane = threadIdx.x & 63;
+    const bool up = (lane & 32) != 0;
+    double v[16];
+    lazy_first_step<0>(val, up, v);
+    wave_halve<8, 16>(v, lane);
+    wave_halve<4, 8>(v, lane);
+    wave_halve<2, 4>(v, lane);
+    wave_halve<1, 2>(v, lane);
+    return v[0] + __shfl_xor(v[0], 1, 64);
 }
 
 } // namespace op

@@ -170,9 +170,6 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
     }
     __syncthreads();
 
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
     const int s = own0 + threadIdx.x;
     bool accepted = false;
     if (s < own1) {
@@ -197,65 +194,94 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
         }
         pair_t[s] = accepted ? pair_p[s] : -1;
     }
-    if (accepted && TERM == 3) { // NormalizeIntensity sums (DenseOdometryFunction.cpp:129-139)
-        acc[0] = (double)L.sc[s];
-        acc[1] = (double)L.tc[pair_p[s]];
-        acc[28] = 1.0;
-    } else if (accepted) {
-        const int t = pair_p[s];
-        const int i = s / L.w, j = s - i * L.w;
-        // source_XYZ[v_s][u_s] (Geometry.cpp:84-100)
-        const float z = L.sd[s];
-        float p0 = -1.0f, p1 = -1.0f, p2 = -1.0f;
-        if (z > 0) { p0 = ((float)j - L.cx) * z / L.fx; p1 = ((float)i - L.cy) * z / L.fy; p2 = z; }
-        const float q0 = sum3(s_T[0] * p0, s_T[1] * p1, s_T[2] * p2) + s_T[3];
-        const float q1 = sum3(s_T[4] * p0, s_T[5] * p1, s_T[6] * p2) + s_T[7];
-        const float q2 = sum3(s_T[8] * p0, s_T[9] * p1, s_T[10] * p2) + s_T[11];
-        const float invz = (float)(1.0 / (double)q2);
-        const float sq_img = (float)0.70710678118654757, sq_dep = (float)0.70710678118654757; // sqrt(1-0.5), sqrt(0.5)
-        float J[2][6], r[2];
-        int rows = 0;
-        if (TERM == 0 || TERM == 1) { // photometric row (:146-193 / :262-283)
-            const float diff = L.tc[t] - L.sc[s];
-            const float dIdx = 0.125f * L.tcdx[t], dIdy = 0.125f * L.tcdy[t]; // SOBEL_SCALE
-            const float c0 = dIdx * L.fx * invz, c1 = dIdy * L.fy * invz;
-            const float c2 = -(c0 * q0 + c1 * q1) * invz;
-            const float jr[6] = {c0, c1, c2, -q2 * c1 + q1 * c2, q2 * c0 - q0 * c2, -q1 * c0 + q0 * c1};
-#pragma unroll
-            for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_img * jr[k] : jr[k];
-            r[rows] = TERM == 0 ? sq_img * diff : diff;
-            ++rows;
-        }
-        if (TERM == 0 || TERM == 2) { // geometric row (:194-241 / :284-294)
-            float dDdx = 0.125f * L.tddx[t], dDdy = 0.125f * L.tddy[t];
-            if (isnan(dDdx)) dDdx = 0.0f;
-            if (isnan(dDdy)) dDdy = 0.0f;
-            const float diff = L.td[t] - q2;
-            const float d0 = dDdx * L.fx * invz, d1 = dDdy * L.fy * invz;
-            const float d2 = -(d0 * q0 + d1 * q1) * invz;
-            const float jr[6] = {d0, d1, d2 - 1.0f, (-q2 * d1 + q1 * d2) - q1, (q2 * d0 - q0 * d2) + q0, -q1 * d0 + q0 * d1};
-#pragma unroll
-            for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_dep * jr[k] : jr[k];
-            r[rows] = TERM == 0 ? sq_dep * diff : diff;
-            ++rows;
-        }
-        // float products as the reference forms them, summed in double
-#pragma unroll
-        for (int m = 0; m < (TERM == 0 ? 2 : 1); ++m) {
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[k++] += (double)(J[m][a] * J[m][b]);
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] += (double)(J[m][a] * r[m]);
-            acc[27] += (double)(r[m] * r[m]);
-        }
-        acc[28] = 1.0;
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    wave_reduce_scatter32(acc);
-    if ((lane & 1) == 0) s_red[wave][lane >> 1] = acc[0];
+    double total;
+    if (TERM == 3) { // NormalizeIntensity sums (DenseOdometryFunction.cpp:129-139)
+        double acc[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+        if (accepted) {
+            acc[0] = (double)L.sc[s];
+            acc[1] = (double)L.tc[pair_p[s]];
+            acc[28] = 1.0;
+        }
+        wave_reduce_scatter32(acc);
+        total = acc[0];
+    } else {
+        // the pixel's Jacobian rows (zero when it is not accepted); the 29 sums are formed from them inside the wave
+        // reduction, so that 16 instead of 32 fp64 values are live: <= 64 VGPRs, i.e. two 1024-thread workgroups per CU,
+        // which is what lets the 300 workgroups of a 640x480 level run in ONE round on 256 CUs
+        float J[2][6], r[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            r[m] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) J[m][k] = 0.0f;
+        }
+        if (accepted) {
+            const int t = pair_p[s];
+            const int i = s / L.w, j = s - i * L.w;
+            // source_XYZ[v_s][u_s] (Geometry.cpp:84-100)
+            const float z = L.sd[s];
+            float p0 = -1.0f, p1 = -1.0f, p2 = -1.0f;
+            if (z > 0) { p0 = ((float)j - L.cx) * z / L.fx; p1 = ((float)i - L.cy) * z / L.fy; p2 = z; }
+            const float q0 = sum3(s_T[0] * p0, s_T[1] * p1, s_T[2] * p2) + s_T[3];
+            const float q1 = sum3(s_T[4] * p0, s_T[5] * p1, s_T[6] * p2) + s_T[7];
+            const float q2 = sum3(s_T[8] * p0, s_T[9] * p1, s_T[10] * p2) + s_T[11];
+            const float invz = (float)(1.0 / (double)q2);
+            const float sq_img = (float)0.70710678118654757, sq_dep = (float)0.70710678118654757; // sqrt(1-0.5), sqrt(0.5)
+            int rows = 0;
+            if (TERM == 0 || TERM == 1) { // photometric row (:146-193 / :262-283)
+                const float diff = L.tc[t] - L.sc[s];
+                const float dIdx = 0.125f * L.tcdx[t], dIdy = 0.125f * L.tcdy[t]; // SOBEL_SCALE
+                const float c0 = dIdx * L.fx * invz, c1 = dIdy * L.fy * invz;
+                const float c2 = -(c0 * q0 + c1 * q1) * invz;
+                const float jr[6] = {c0, c1, c2, -q2 * c1 + q1 * c2, q2 * c0 - q0 * c2, -q1 * c0 + q0 * c1};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_img * jr[k] : jr[k];
+                r[rows] = TERM == 0 ? sq_img * diff : diff;
+                ++rows;
+            }
+            if (TERM == 0 || TERM == 2) { // geometric row (:194-241 / :284-294)
+                float dDdx = 0.125f * L.tddx[t], dDdy = 0.125f * L.tddy[t];
+                if (isnan(dDdx)) dDdx = 0.0f;
+                if (isnan(dDdy)) dDdy = 0.0f;
+                const float diff = L.td[t] - q2;
+                const float d0 = dDdx * L.fx * invz, d1 = dDdy * L.fy * invz;
+                const float d2 = -(d0 * q0 + d1 * q1) * invz;
+                const float jr[6] = {d0, d1, d2 - 1.0f, (-q2 * d1 + q1 * d2) - q1, (q2 * d0 - q0 * d2) + q0, -q1 * d0 + q0 * d1};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_dep * jr[k] : jr[k];
+                r[rows] = TERM == 0 ? sq_dep * diff : diff;
+                ++rows;
+            }
+        }
+        // sum k of the pixel: float products as the reference forms them, summed in double ([0..20] upper triangle of
+        // J^T J row by row, [21..26] J^T r, [27] r^2, [28] count).  A row that does not exist is all zero.
+        auto val = [&](auto kc) -> double {
+            constexpr int k = decltype(kc)::value;
+            constexpr int NR = TERM == 0 ? 2 : 1;
+            double v = 0.0;
+            if constexpr (k < 21) {
+                constexpr int a = k < 6 ? 0 : k < 11 ? 1 : k < 15 ? 2 : k < 18 ? 3 : k < 20 ? 4 : 5;
+                constexpr int first = a == 0 ? 0 : a == 1 ? 6 : a == 2 ? 11 : a == 3 ? 15 : a == 4 ? 18 : 20;
+                constexpr int b = a + (k - first);
+#pragma unroll
+                for (int m = 0; m < NR; ++m) v += (double)(J[m][a] * J[m][b]);
+            } else if constexpr (k < 27) {
+#pragma unroll
+                for (int m = 0; m < NR; ++m) v += (double)(J[m][k - 21] * r[m]);
+            } else if constexpr (k == 27) {
+#pragma unroll
+                for (int m = 0; m < NR; ++m) v += (double)(r[m] * r[m]);
+            } else if constexpr (k == 28) {
+                v = accepted ? 1.0 : 0.0;
+            }
+            return v;
+        };
+        total = wave_reduce_scatter32_lazy(val);
+    }
+    if ((lane & 1) == 0) s_red[wave][lane >> 1] = total;
     __syncthreads();
     if (threadIdx.x < kNSums) {
         double v = 0;
