@@ -37,6 +37,10 @@
 #include <numeric>
 #include <vector>
 
+#include <atomic>
+#include <memory>
+#include <thread>
+
 #include "common.hpp"
 #include "host_math.hpp"
 #include "px_round.hpp"
@@ -1201,6 +1205,22 @@ int check_cam(const op_camera* cam) {
     return OP_OK;
 }
 
+// Host-side helper of the .map stream code: f(block_begin, block_end) on up to 16 host threads (the formatting loops are
+// per-block independent once the per-block offsets are known; one thread formats ~0.1 GB/s of this stream).
+template <class F>
+void for_block_ranges(size_t n, F f) {
+    size_t nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    if (n < 1024 || nt == 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t) {
+        const size_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back([=] { f(lo, hi); });
+    }
+    for (auto& x : th) x.join();
+}
+
 } // namespace
 
 extern "C" {
@@ -1842,28 +1862,47 @@ int op_volume_write_file(op_volume* v, const char* path) {
     size_t n = 0;
     OP_TRY(op_volume_block_count(v, &n));
     std::vector<int32_t> keys(3 * n);
-    std::vector<float> vox(n * (size_t)kBlockFloats);
-    if (n) OP_TRY(op_volume_download(v, keys.data(), vox.data(), n, &n));
+    std::unique_ptr<float[]> vox(new float[std::max<size_t>(n, 1) * (size_t)kBlockFloats]);
+    if (n) OP_TRY(op_volume_download(v, keys.data(), vox.get(), n, &n));
     FILE* f = std::fopen(path, "wb");
     if (!f) return fail(OP_ERR_INVALID, "cannot open %s for writing", path);
-    // CubeHandler::WriteToFile (CubeHandler.h:113-128): the block count's raw bits sit in a float slot
-    std::vector<float> buffer;
-    buffer.reserve(n * 64 + 16);
-    buffer.push_back(0.0f);
+    // CubeHandler::WriteToFile (CubeHandler.h:113-128): the block count's raw bits sit in a float slot; then per block
+    // VoxelCube::WriteToBuffer (VoxelCube.h:128-148): id, {i, sdf, w, c0, c1, c2} of every voxel with |sdf| < 1 and
+    // w != 0, terminator -2.  Two passes: per-block record counts -> offsets, then the blocks are formatted in parallel.
+    const float* vx = vox.get();
+    std::vector<size_t> off(n + 1, 0);
+    for_block_ranges(n, [&](size_t lo, size_t hi) {
+        for (size_t b = lo; b < hi; ++b) {
+            size_t c = 0;
+            for (int i = 0; i < kVox; ++i) {
+                const float* t = &vx[(b * kVox + i) * 5];
+                c += (std::fabs(t[0]) < 1 && t[1] != 0) ? 1 : 0;
+            }
+            off[b + 1] = 4 + 6 * c;
+        }
+    });
+    off[0] = 1;
+    for (size_t b = 0; b < n; ++b) off[b + 1] += off[b];
+    const size_t total = off[n];
+    std::unique_ptr<float[]> buffer(new float[total]);
     const unsigned int size = (unsigned int)n;
     std::memcpy(&buffer[0], &size, 4);
-    for (size_t b = 0; b < n; ++b) { // VoxelCube::WriteToBuffer (VoxelCube.h:128-148)
-        for (int c = 0; c < 3; ++c) buffer.push_back((float)keys[3 * b + c]);
-        for (int i = 0; i < kVox; ++i) {
-            const float* t = &vox[(b * kVox + i) * 5];
-            if (std::fabs(t[0]) < 1 && t[1] != 0) {
-                buffer.push_back((float)i);
-                for (int k = 0; k < 5; ++k) buffer.push_back(t[k]);
+    float* out = buffer.get();
+    for_block_ranges(n, [&](size_t lo, size_t hi) {
+        for (size_t b = lo; b < hi; ++b) {
+            float* o = out + off[b];
+            for (int c = 0; c < 3; ++c) *o++ = (float)keys[3 * b + c];
+            for (int i = 0; i < kVox; ++i) {
+                const float* t = &vx[(b * kVox + i) * 5];
+                if (std::fabs(t[0]) < 1 && t[1] != 0) {
+                    *o++ = (float)i;
+                    for (int k = 0; k < 5; ++k) *o++ = t[k];
+                }
             }
+            *o++ = -2.0f;
         }
-        buffer.push_back(-2.0f);
-    }
-    const bool ok = std::fwrite(buffer.data(), sizeof(float), buffer.size(), f) == buffer.size();
+    });
+    const bool ok = std::fwrite(buffer.get(), sizeof(float), total, f) == total;
     std::fclose(f);
     return ok ? OP_OK : fail(OP_ERR_INVALID, "short write to %s", path);
 }
@@ -1876,53 +1915,79 @@ int op_volume_read_file(op_volume* v, const char* path, int legacy_float_format)
     std::fseek(f, 0, SEEK_END);
     const long len = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
-    std::vector<float> buffer((size_t)len / sizeof(float) + 1, 0.0f);
     const size_t nfl = (size_t)len / sizeof(float);
-    const bool ok = std::fread(buffer.data(), sizeof(float), nfl, f) == nfl;
+    std::unique_ptr<float[]> buffer_mem(new float[nfl + 1]);
+    float* buffer = buffer_mem.get();
+    buffer[nfl] = 0.0f;
+    const bool ok = std::fread(buffer, sizeof(float), nfl, f) == nfl;
     std::fclose(f);
     if (!ok || nfl < 2) return fail(OP_ERR_INVALID, "cannot read %s", path);
     unsigned int count = 0;
     size_t ptr = 0;
     if (legacy_float_format) { count = (unsigned int)buffer[1]; ptr = 2; } // CubeHandler.h:91-94
     else { std::memcpy(&count, &buffer[0], 4); ptr = 1; }                   // CubeHandler.h:51-53
-    std::vector<int32_t> keys;
-    std::vector<float> vox;
-    keys.reserve(3 * (size_t)count);
+    // pass 1 (sequential, cheap): where every block's record starts -- the stream is only delimited by its terminators
+    std::vector<size_t> start;
+    start.reserve((size_t)count + 1);
     for (unsigned int c = 0; c < count && ptr + 3 <= nfl; ++c) {
-        keys.push_back((int32_t)buffer[ptr]); keys.push_back((int32_t)buffer[ptr + 1]); keys.push_back((int32_t)buffer[ptr + 2]);
+        start.push_back(ptr);
         ptr += 3;
-        const size_t base = vox.size();
-        vox.resize(base + kBlockFloats);
-        float* blk = &vox[base]; // cube_map[cube_id] = VoxelCube(cube_id): default voxels
-        for (int i = 0; i < kVox; ++i) { blk[5 * i] = 999.0f; blk[5 * i + 1] = 0.0f; blk[5 * i + 2] = blk[5 * i + 3] = blk[5 * i + 4] = -1.0f; }
-        if (!legacy_float_format) { // VoxelCube::ReadFromBuffer (VoxelCube.h:153-166)
-            while (ptr < nfl && buffer[ptr] != -2.0f) {
-                const int i = (int)buffer[ptr++];
-                if (i < 0 || i >= kVox || ptr + 5 > nfl) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
-                for (int k = 0; k < 5; ++k) blk[5 * i + k] = buffer[ptr++];
-            }
+        if (!legacy_float_format) {                  // VoxelCube::ReadFromBuffer (VoxelCube.h:153-166): {i, 5 floats}* -2
+            while (ptr < nfl && buffer[ptr] != -2.0f) ptr += 6;
             ptr++;
-        } else { // VoxelCube::ReadFromBufferFloat (VoxelCube.h:168-193)
+        } else {                                     // VoxelCube::ReadFromBufferFloat (VoxelCube.h:168-193)
             ptr++;
-            while (ptr < nfl && buffer[ptr] != -2.0f) {
-                const int i = (int)buffer[ptr++];
-                if (i < 0 || i >= kVox || ptr + 2 > nfl) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
-                blk[5 * i] = buffer[ptr++]; blk[5 * i + 1] = buffer[ptr++];
-            }
+            while (ptr < nfl && buffer[ptr] != -2.0f) ptr += 3;
             ptr++;
             const size_t cnt = ptr < nfl ? (size_t)buffer[ptr++] : 0;
-            for (size_t k = 0; k < cnt && ptr + 5 <= nfl; ++k) {
-                const int i = (int)buffer[ptr++];
-                if (i < 0 || i >= kVox) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
-                float* t = &blk[5 * i];
-                t[2] = (float)(buffer[ptr++] / 255.0); t[3] = (float)(buffer[ptr++] / 255.0); t[4] = (float)(buffer[ptr++] / 255.0);
-                const float cw = buffer[ptr++];
-                t[2] = t[2] / cw; t[3] = t[3] / cw; t[4] = t[4] / cw;
+            ptr += 5 * cnt;
+        }
+        if (ptr > nfl + 1) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
+    }
+    const size_t nb = start.size();
+    start.push_back(ptr < nfl ? ptr : nfl);
+    // pass 2 (parallel over blocks): cube_map[cube_id] = VoxelCube(cube_id) (default voxels), then the stored voxels
+    std::vector<int32_t> keys(3 * nb);
+    std::unique_ptr<float[]> vox_mem(new float[std::max<size_t>(nb, 1) * (size_t)kBlockFloats]);
+    float* vox = vox_mem.get();
+    std::atomic<int> bad{0};
+    for_block_ranges(nb, [&](size_t lo, size_t hi) {
+        for (size_t b = lo; b < hi; ++b) {
+            size_t q = start[b];
+            const size_t end = start[b + 1];
+            for (int c = 0; c < 3; ++c) keys[3 * b + c] = (int32_t)buffer[q + c];
+            q += 3;
+            float* blk = vox + b * (size_t)kBlockFloats;
+            for (int i = 0; i < kVox; ++i) { blk[5 * i] = 999.0f; blk[5 * i + 1] = 0.0f; blk[5 * i + 2] = blk[5 * i + 3] = blk[5 * i + 4] = -1.0f; }
+            if (!legacy_float_format) {
+                while (q < end && buffer[q] != -2.0f) {
+                    const int i = (int)buffer[q++];
+                    if (i < 0 || i >= kVox || q + 5 > nfl) { bad = 1; break; }
+                    for (int k = 0; k < 5; ++k) blk[5 * i + k] = buffer[q++];
+                }
+            } else {
+                q++;
+                while (q < end && buffer[q] != -2.0f) {
+                    const int i = (int)buffer[q++];
+                    if (i < 0 || i >= kVox || q + 2 > nfl) { bad = 1; break; }
+                    blk[5 * i] = buffer[q++]; blk[5 * i + 1] = buffer[q++];
+                }
+                q++;
+                const size_t cnt = q < nfl ? (size_t)buffer[q++] : 0;
+                for (size_t k = 0; k < cnt && q + 5 <= nfl; ++k) {
+                    const int i = (int)buffer[q++];
+                    if (i < 0 || i >= kVox) { bad = 1; break; }
+                    float* t = &blk[5 * i];
+                    t[2] = (float)(buffer[q++] / 255.0); t[3] = (float)(buffer[q++] / 255.0); t[4] = (float)(buffer[q++] / 255.0);
+                    const float cw = buffer[q++];
+                    t[2] = t[2] / cw; t[3] = t[3] / cw; t[4] = t[4] / cw;
+                }
             }
         }
-    }
+    });
+    if (bad) return fail(OP_ERR_INVALID, "corrupt .map file %s", path);
     OP_TRY(op_volume_clear(v)); // cube_map.clear() (CubeHandler.h:42)
-    return op_volume_upload(v, keys.data(), vox.data(), keys.size() / 3);
+    return op_volume_upload(v, keys.data(), vox, nb);
 }
 
 int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], float* depth_out, float* normals_out, float* colors_out, int mem) {
