@@ -63,7 +63,14 @@ constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 
 #define KB_GRID 512
 #endif
 constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
-constexpr int kIntegrateGrid = 1024; // KC persistent grid (512-thread workgroups)
+// KC grid (512-thread workgroups walking the batch's block list with a grid stride).  Blocks differ in work (1..16
+// frames touch them), so more, shorter-lived workgroups balance the tail better: 1024 -> 691 us, 1536 -> 654,
+// 2048 -> 641 per 14-frame launch.  Beyond 2^20 work-items per dispatch (grid > 2048) the kernel itself keeps getting
+// faster (3072 -> 626, 12288 -> 613) but every launch then costs ~85 us extra outside the kernel: stay at 2^20.
+#ifndef KC_GRID
+#define KC_GRID 2048
+#endif
+constexpr int kIntegrateGrid = KC_GRID;
 constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
 #ifndef KC_SUB
 #define KC_SUB 16 // frames whose gathers are in flight together inside k_integrate (divides kMaxBatch)
