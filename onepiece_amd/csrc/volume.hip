@@ -63,13 +63,12 @@ constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 
 #define KB_GRID 512
 #endif
 constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
-// KC grid (512-thread workgroups walking the batch's block list with a grid stride).  Blocks differ in work (1..16
-// frames touch them), so more, shorter-lived workgroups balance the tail better: 1024 -> 691 us, 1536 -> 654,
-// 2048 -> 641 per 14-frame launch.  Beyond 2^20 work-items per dispatch (grid > 2048) the kernel itself keeps getting
-// faster (3072 -> 626, 12288 -> 613) but every launch then costs ~85 us extra outside the kernel: stay at 2^20.
+// KC grid: 512-thread workgroups that draw blocks of the batch's list from per-XCD counters (see k_integrate); 768 is
+// what is resident at the kernel's 76 VGPRs (3 workgroups of 8 waves per CU).  Must be a multiple of 8 (XCDs).
 #ifndef KC_GRID
-#define KC_GRID 2048
+#define KC_GRID 768
 #endif
+static_assert(KC_GRID % 8 == 0 && KC_GRID >= 8, "one drawing workgroup per XCD slab at least");
 constexpr int kIntegrateGrid = KC_GRID;
 constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
 #ifndef KC_SUB
@@ -101,6 +100,7 @@ struct State {
     unsigned long long n_cand[kMaxBatch];
     float bbox[kMaxBatch][6]; // max xyz, min xyz
     unsigned n_inside[kMaxBatch];
+    unsigned kc_next[8 * 16]; // KC dynamic scheduling: next list position of each XCD's slab (one cache line each)
 };
 
 struct VolView {
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C,
     __shared__ unsigned s_cnt[4];
     const int tid = threadIdx.x, f = blockIdx.y;
     if (blockIdx.x == 0 && f == 0 && tid == 0) { st->n_batch = 0; st->n_rec = 0; } // new batch: empty lists
+    if (blockIdx.x == 0 && f == 0 && tid < 8) st->kc_next[tid * 16] = 0u;
     const PoseFwd& P = B.f[f];
     const int npix = C.width * C.height;
     const void* dptr = Q.depth[f];
@@ -486,11 +487,21 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
     // the x-th contiguous eighth of the list, so list neighbours -- blocks along one viewing ray,
     // which gather the same pixels -- are processed on one XCD close in time and share its L2.
     const unsigned per_xcd = (n + 7u) / 8u;
-    for (unsigned i = blockIdx.x; i < per_xcd * 8u; i += gridDim.x) {
-        const unsigned b = (i & 7u) * per_xcd + (i >> 3);
-        if (b >= n) continue;
-        const int idx = V.tvals[V.blist[b]];
-        if (idx < 0) continue; // pool overflow (reported through st->overflow)
+    // Dynamic scheduling: blocks differ in work (1..16 frames touch them), so the workgroups of XCD x DRAW list positions
+    // of slab x from one counter instead of owning a fixed stride (static grids: 1024 workgroups 691 us per 14-frame
+    // launch, 2048 -> 648; drawn: 623, the grid being exactly what is resident).  The next position is requested before
+    // the current block is processed, so the atomic's round trip is hidden.
+    __shared__ unsigned s_next[2];
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned* ctr = &st->kc_next[xcd * 16u];
+    if (vid == 0) s_next[0] = atomicAdd(ctr, 1u);
+    __syncthreads();
+    unsigned slot = 0u;
+    for (unsigned j = s_next[0]; j < per_xcd;) {
+        if (vid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
+        const unsigned b = xcd * per_xcd + j;
+        const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
+        if (idx >= 0) {
         const unsigned mask = V.bmask[V.blist[b]];
         sel += __popc(mask);
         const int kx = V.keys[3 * idx], ky = V.keys[3 * idx + 1], kz = V.keys[3 * idx + 2];
@@ -558,12 +569,11 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
             }
         }
         if (changed) { vox[0] = s; vox[kVox] = w; vox[2 * kVox] = c0; vox[3 * kVox] = c1; vox[4 * kVox] = c2; }
-    }
-    // every wave has read its masks: now the owner workgroup clears them for the next batch
-    __syncthreads();
-    for (unsigned i = blockIdx.x; i < per_xcd * 8u; i += gridDim.x) {
-        const unsigned b = (i & 7u) * per_xcd + (i >> 3);
-        if (b < n && vid == 0) V.bmask[V.blist[b]] = 0u;
+        }
+        __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
+        if (b < n && vid == 0) V.bmask[V.blist[b]] = 0u;   // the owner clears it for the next batch
+        slot ^= 1u;
+        j = s_next[slot];
     }
     // per-workgroup counters (each workgroup owns its slot: no atomics)
     upd = wave_sum(upd);
