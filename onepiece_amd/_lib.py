@@ -68,6 +68,7 @@ SIGNATURES = {
     "op_frustum_planes": (C.c_int, [C.POINTER(Camera), _fp, C.c_float, C.c_float, _fp]),
     "op_se3_exp": (C.c_int, [_fp, _fp]),
     "op_debug_project_px": (C.c_int, [C.c_float, C.c_float, C.c_int]),
+    "op_debug_project_uv": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
     "op_volume_create": (C.c_int, [C.POINTER(Camera), C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_uint64, C.POINTER(_vp)]),
     "op_volume_destroy": (C.c_int, [_vp]),

@@ -75,7 +75,7 @@ constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_int
 #define KC_SUB 16 // frames whose gathers are in flight together inside k_integrate (divides kMaxBatch)
 #endif
 #ifndef KC_MIN_WAVES
-#define KC_MIN_WAVES 4 // waves per SIMD the integrate kernel is compiled for (2 workgroups of 8 waves per CU)
+#define KC_MIN_WAVES 6 // waves per SIMD the integrate kernel is compiled for: 3 workgroups of 8 waves per CU = KC_GRID
 #endif
 constexpr int kCoordLimit = 1 << 20; // |block coordinate| < 2^20 (40 km at 4 cm blocks)
 
@@ -140,6 +140,57 @@ template <bool FAST>
 __device__ __forceinline__ int project_px(float f, float X, float Z, float c, const PxSplit& sp) {
     const float a = (f * X) / Z;
     return FAST ? px_round_sp(a, sp) : px_round_dp(a, c);
+}
+
+// The two quotients (fx*X)/Z and (fy*Y)/Z of one projection with ONE reciprocal.  An IEEE float division is, on this
+// hardware, v_div_scale x2, v_rcp, two FMAs refining the reciprocal, mul + three FMAs for the quotient, v_div_fmas,
+// v_div_fixup (11 instructions; the six divisions of a voxel update were 37 % of KC's VALU work).  When v_div_scale does
+// not rescale, the result IS fma(r1, y, q1) of the sequence below, so both quotients can share y: 13 instead of 22
+// instructions, bit-identical.  The hardware rescales only when the divisor or the quotient leaves the range where these
+// plain FMAs are exact (|Z| or |q| beyond ~2^+-96, denormals); outside the window tested here -- 2^-60 <= |Z| < 2^60 --
+// the three operands are first rescaled by 2^+-96 (exact; an operand that over- or underflows in that belongs to a
+// quotient beyond 2^+-90), and inside it a quotient that differs can only be one of magnitude < 2^-36 (which every pixel
+// rounding maps to the same pixel: the thresholds of px_round are >= 2^-23 away from 0) or > 2^36 (which no image
+// contains: both forms are rejected by the caller's bounds test).  Z = 0, inf, NaN give NaN here and +-inf / 0 / NaN
+// there: rejected, or a pixel whose sdf = d - Z cannot pass the truncation test.  tests/test_integration_gpu.py compares this function
+// with the plain division on the device over dense random and boundary operands (op_debug_project_uv).
+__device__ __forceinline__ float div_shared_rcp(float n, float z, float y) {
+    float q = n * y;
+    float r = __builtin_fmaf(-z, q, n);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-z, q, n);
+    return __builtin_fmaf(r, y, q);
+}
+template <bool FAST>
+__device__ __forceinline__ void project_uv(float fx, float fy, float X, float Y, float Z, float cx, float cy, const PxSplit& sx,
+                                           const PxSplit& sy, int& u, int& v) {
+    float nx = fx * X, ny = fy * Y, z = Z;
+    const unsigned ez = (__float_as_uint(Z) >> 23) & 0xffu;    // biased exponent of Z
+    if (!(ez - 67u < 120u)) {                                  // outside 2^-60 <= |Z| < 2^60 (never, for a camera):
+        const float s = ez < 67u ? 0x1p96f : 0x1p-96f;         // rescale all three by an exact power of two, which is
+        z *= s; nx *= s; ny *= s;                              // what v_div_scale does; the quotients are unchanged
+    }
+    float y = __builtin_amdgcn_rcpf(z);
+    const float e = __builtin_fmaf(-z, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    const float ax = div_shared_rcp(nx, z, y), ay = div_shared_rcp(ny, z, y);
+    u = FAST ? px_round_sp(ax, sx) : px_round_dp(ax, cx);
+    v = FAST ? px_round_sp(ay, sy) : px_round_dp(ay, cy);
+}
+
+// test hook: both forms of the projection for n operand triples (see op_debug_project_uv)
+__global__ void k_debug_project_uv(float fx, float fy, float cx, float cy, const float* __restrict__ X, const float* __restrict__ Y,
+                                   const float* __restrict__ Z, size_t n, int* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PxSplit sx = px_split(cx), sy = px_split(cy);
+    int u, v;
+    if (sx.exact && sy.exact) project_uv<true>(fx, fy, X[i], Y[i], Z[i], cx, cy, sx, sy, u, v);
+    else project_uv<false>(fx, fy, X[i], Y[i], Z[i], cx, cy, sx, sy, u, v);
+    out[4 * i] = u;
+    out[4 * i + 1] = v;
+    out[4 * i + 2] = px_round_dp((fx * X[i]) / Z[i], cx);   // the reference's formula with the plain division
+    out[4 * i + 3] = px_round_dp((fy * Y[i]) / Z[i], cy);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -399,8 +450,8 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
                 const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
                 const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
                 const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
-                const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
+                int u, v;
+                project_uv<FAST>(C.fx, C.fy, q0, q1, q2, C.cx, C.cy, C.sx, C.sy, u, v);
                 zc[corner] = q2;
                 pix[corner] = (v < 0 || v >= C.height || u < 0 || u >= C.width) ? -1 : v * C.width + u;
             }
@@ -533,8 +584,8 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                     const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
                     const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
                     const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                    const int u = project_px<FAST>(C.fx, q0, q2, C.cx, C.sx);
-                    const int v = project_px<FAST>(C.fy, q1, q2, C.cy, C.sy);
+                    int u, v;
+                    project_uv<FAST>(C.fx, C.fy, q0, q1, q2, C.cx, C.cy, C.sx, C.sy, u, v);
                     zc[g] = q2;
                     // uniform 64-bit frame base + 32-bit per-lane pixel offset (saddr addressing, no 64-bit VALU math)
                     const uint2* __restrict__ fimg = pimg + (size_t)f * npix;
@@ -1279,6 +1330,28 @@ int op_frustum_planes(const op_camera* cam, const float pose[16], float far_dist
 
 int op_debug_project_px(float a, float c, int fast) {
     return fast ? px_round_sp(a, px_split(c)) : px_round_dp(a, c);
+}
+
+int op_debug_project_uv(float fx, float fy, float cx, float cy, const float* X, const float* Y, const float* Z, size_t n, int device, int32_t* out) {
+    if (!X || !Y || !Z || !out) return fail(OP_ERR_INVALID, "null argument");
+    OP_TRY(op::use_device(device));
+    if (n == 0) return OP_OK;
+    float* d_in = nullptr;
+    int* d_out = nullptr;
+    OP_HIP(hipMalloc((void**)&d_in, 3 * n * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_out, 4 * n * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_in, X, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in + n, Y, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in + 2 * n, Z, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_project_uv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fx, fy, cx, cy, (const float*)d_in,
+                           (const float*)(d_in + n), (const float*)(d_in + 2 * n), n, d_out);
+        e = hipMemcpy(out, d_out, 4 * n * sizeof(int), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "op_debug_project_uv failed: %s", hipGetErrorString(e));
+    return OP_OK;
 }
 
 int op_se3_exp(const float x[6], float T[16]) {

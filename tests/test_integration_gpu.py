@@ -400,3 +400,64 @@ def test_random_frames_fuzz(oracle):
         if k % 4 == 3:
             _compare(oracle, ov, hv)
     _compare(oracle, ov, hv)
+
+
+def test_projection_with_shared_reciprocal_equals_plain_division():
+    """The kernels evaluate (fx*X)/Z and (fy*Y)/Z with one refined reciprocal (csrc/volume.hip: project_uv).  On the device,
+    over dense random operands, operands a few ulp around every kind of rounding boundary, and specials (0, inf, NaN,
+    denormals, |Z| outside the fast window), the resulting pixel equals the reference formula with the plain IEEE division
+    whenever either of them is a pixel an image could contain (except for Z = +-inf, where no sdf can be finite)."""
+    import ctypes as C
+    from onepiece_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(7)
+    fx, fy, cx, cy = np.float32(514.817), np.float32(515.375), np.float32(318.771), np.float32(238.447)
+
+    def run(X, Y, Z, fx=fx, fy=fy, cx=cx, cy=cy):
+        X, Y, Z = (np.ascontiguousarray(a, np.float32) for a in (X, Y, Z))
+        out = np.empty((len(X), 4), np.int32)
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        L.check(lib.op_debug_project_uv(float(fx), float(fy), float(cx), float(cy), vp(X), vp(Y), vp(Z), len(X), 0, vp(out)))
+        return out
+
+    def agree(out, limit=1 << 16):
+        inside = lambda a: (a >= 0) & (a < limit)
+        for k in (0, 1):
+            f, r = out[:, k], out[:, 2 + k]
+            bad = (f != r) & (inside(f) | inside(r))
+            assert not bad.any(), (k, np.flatnonzero(bad)[:5], f[bad][:5], r[bad][:5])
+        return inside(out[:, 2]).mean()
+
+    n = 1 << 21
+    sign = lambda m: np.where(rng.random(m) < 0.5, -1.0, 1.0)
+    # 1. camera-like operands: Z in [0.05, 20] m, X / Y within a few field-of-views
+    Z = rng.uniform(0.05, 20.0, n) * np.where(rng.random(n) < 0.1, -1.0, 1.0)
+    frac = agree(run(rng.uniform(-2, 2, n) * np.abs(Z), rng.uniform(-2, 2, n) * np.abs(Z), Z))
+    assert frac > 0.2
+    # 2. log-uniform magnitudes across and beyond the fast window, every sign
+    Z = sign(n) * np.exp2(rng.uniform(-80, 80, n))
+    agree(run(sign(n) * np.exp2(rng.uniform(-149, 120, n)), sign(n) * np.exp2(rng.uniform(-149, 120, n)), Z))
+    q = np.exp2(rng.uniform(-60, 20, n))                         # quotients from far below a pixel to far beyond an image
+    agree(run(sign(n) * q * np.abs(Z) / fx, sign(n) * q * np.abs(Z) / fy, Z))
+    # 3. a few ulp around the rounding boundaries: (fx*X)/Z = k + 0.5 - frac(cx) etc.
+    for c, f, col in ((cx, fx, 0), (cy, fy, 1)):
+        k = rng.integers(-700, 700, n).astype(np.float64)
+        tgt = (k + rng.choice([-0.5, 0.5, 1.5], n) - (np.float64(c) - np.floor(np.float64(c)))).astype(np.float32)
+        Z = (sign(n) * rng.uniform(0.3, 6.0, n)).astype(np.float32)
+        X = (tgt.astype(np.float64) * Z.astype(np.float64) / np.float64(f)).astype(np.float32)
+        X = (X.view(np.int32) + rng.integers(-3, 4, n).astype(np.int32)).view(np.float32)
+        other = rng.uniform(-1, 1, n).astype(np.float32)
+        agree(run(X, other, Z) if col == 0 else run(other, X, Z))
+    # 4. specials in every position
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3e38, -3e38, 1.0, -1.0, 2.0 ** -60, 2.0 ** 60,
+                   2.0 ** -61, 2.0 ** 59, 0.5, 1234.5], np.float32)
+    g = np.stack(np.meshgrid(sp, sp, sp, indexing="ij"), -1).reshape(-1, 3)
+    with np.errstate(all="ignore"):
+        out = run(g[:, 0], g[:, 1], g[:, 2])
+    fin = ~np.isinf(g[:, 2])
+    agree(out[fin])
+    # Z = +-inf is the one operand where the two differ: the plain quotient is +-0 (the principal point), the shared
+    # reciprocal gives NaN (no pixel).  Neither can matter: the voxel's sdf is d - Z = -+inf, never inside the truncation.
+    assert np.all(out[~fin][:, :2] == np.iinfo(np.int32).min)
+    # 5. an intrinsic whose fractional part is 0.5 takes the double-precision rounding path
+    agree(run(rng.uniform(-2, 2, 4096), rng.uniform(-2, 2, 4096), rng.uniform(0.2, 5, 4096), cx=np.float32(320.5), cy=np.float32(240.5)))
