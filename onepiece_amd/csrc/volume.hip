@@ -506,8 +506,8 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
 
 // ---------------------------------------------------------------------------------------------
 // KC: Integrator::IntegrateImage (Integrator.cpp:36-94) for all frames of the batch.  One
-// 512-thread workgroup per block of the batch list (thread = voxel, wave = z-slice), persistent
-// grid.  The voxel is read ONCE, every frame that selected the block is applied to it in frame
+// 512-thread workgroup per block of the batch list (thread = voxel, wave = z-slice); the resident
+// workgroups draw blocks from per-XCD counters.  The voxel is read ONCE, every frame that selected the block is applied to it in frame
 // order in registers (bit-identical to the reference's frame-by-frame running mean), and it is
 // written once -- HBM traffic per voxel drops from 40 B per frame to 40 B per batch.
 // All per-frame gathers ({depth, rgba} records) are issued before the first dependent use.
