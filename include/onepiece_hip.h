@@ -213,6 +213,24 @@ typedef struct {
 int op_icp_create(const float *tgt_xyz, const float *tgt_normals, size_t m, double threshold,
                   int mem, int device, op_icp **out);
 int op_icp_destroy(op_icp *icp);
+/* How the two sequential float32 accumulations of the reference are reproduced.
+ *   OP_ICP_OPT_FINISH: the Kabsch fit that becomes RegistrationResult::T (ICP.cpp:215-221 -> Geometry.cpp:117-133).
+ *     OP_ICP_FINISH_REFERENCE (default): the final inlier pairs are compacted on the device in ascending source
+ *       index and summed by one host thread in float32, pair by pair, exactly like the reference's two loops --
+ *       over 3e5 near-planar pairs their rounding is ~1e-3 of T, i.e. it is part of the reference's result.
+ *     OP_ICP_FINISH_FP64: order-free fp64 reduction on the device (closer to the exact Kabsch of the pairs).
+ *   OP_ICP_OPT_SUMS: the per-iteration sums (JTJ/JTr, ICP.cpp:121-136; the point-to-point Kabsch, :76-79).
+ *     OP_ICP_SUMS_FP64 (default): fp64 reduction on the device, no host round trip in the point-to-point loop.
+ *     OP_ICP_SUMS_REFERENCE_F32: VALIDATION mode -- every iteration's inlier rows are brought to the host in
+ *       inlier order and summed sequentially in float32 as the reference does (slow: one PCIe transfer and one
+ *       host pass per iteration); with it the per-iteration inlier counts equal the CPU path's at any size. */
+#define OP_ICP_OPT_FINISH 0
+#define OP_ICP_OPT_SUMS 1
+#define OP_ICP_FINISH_REFERENCE 0
+#define OP_ICP_FINISH_FP64 1
+#define OP_ICP_SUMS_FP64 0
+#define OP_ICP_SUMS_REFERENCE_F32 1
+int op_icp_set_option(op_icp *icp, int option, int value);
 int op_icp_set_source(op_icp *icp, const float *src_xyz, size_t n, int mem);
 /* One loop body of ICP.cpp:177-199 without the solve: transform by T, 1-NN, CountInliers and the
  * normal-equation sums.  mode PLANE: sums[0..35] = JTJ (row-major 6x6), sums[36..41] = JTr.
@@ -238,10 +256,19 @@ int op_estimate_rigid_point_to_plane(const float *source_xyz, size_t n_source, c
                                      const float *target_normals, size_t n_target,
                                      const int32_t *inliers, size_t n_inliers, int mem, int device,
                                      float T[16]);
+/* The same with the accumulation chosen: sums = OP_ICP_SUMS_FP64 (what the plain entry does) or
+ * OP_ICP_SUMS_REFERENCE_F32 (JTJ/JTr summed sequentially in float32 on one host thread, ICP.cpp:121-136). */
+int op_estimate_rigid_point_to_plane_ex(const float *source_xyz, size_t n_source, const float *target_xyz,
+                                        const float *target_normals, size_t n_target,
+                                        const int32_t *inliers, size_t n_inliers, int mem, int device,
+                                        int sums, float T[16]);
 /* geometry::EstimateRigidTransformation (Geometry/Geometry.cpp:107-151): Kabsch fit of a correspondence set
- * given as n x 6 floats (source xyz, target xyz). */
+ * given as n x 6 floats (source xyz, target xyz).  The plain entry sums as the reference does (sequential
+ * float32 in pair order, OP_ICP_FINISH_REFERENCE); _ex selects OP_ICP_FINISH_FP64 (order-free device reduction). */
 int op_estimate_rigid_transformation(const float *pairs_xyz6, size_t n_pairs, int mem, int device,
                                      float T[16]);
+int op_estimate_rigid_transformation_ex(const float *pairs_xyz6, size_t n_pairs, int mem, int device,
+                                        int finish, float T[16]);
 /* tool::ConvertDepthTo32F + tool::BilateralFilter (Tool/ImageProcessing.cpp:68-91, 64-67; header default
  * range = 7, Tool/ImageProcessing.h:19), the depth preprocessing every fusion driver runs right before
  * IntegrateImage (example/ImageSequenceIntegration.cpp:36-38, DenseFusion/DenseFusion.cpp:92-94,

@@ -48,6 +48,9 @@ OP_TRACK_HYBRID, OP_TRACK_PHOTO, OP_TRACK_DEPTH = 0, 1, 2
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
+OP_ICP_OPT_FINISH, OP_ICP_OPT_SUMS = 0, 1
+OP_ICP_FINISH_REFERENCE, OP_ICP_FINISH_FP64 = 0, 1
+OP_ICP_SUMS_FP64, OP_ICP_SUMS_REFERENCE_F32 = 0, 1
 OP_OK, OP_ERR_INVALID = 0, 1
 OP_ERR_NO_DEVICE, OP_ERR_CAPACITY, OP_ERR_MISMATCH, OP_ERR_NO_NORMALS = 2, 3, 4, 5
 
@@ -105,6 +108,7 @@ SIGNATURES = {
     "op_volume_unpack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "op_icp_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]),
     "op_icp_destroy": (C.c_int, [_vp]),
+    "op_icp_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "op_icp_set_source": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "op_icp_iterate": (C.c_int, [_vp, _fp, C.c_int, C.POINTER(C.c_double), _u64p,
                                  C.POINTER(C.c_double)]),
@@ -115,6 +119,8 @@ SIGNATURES = {
     "op_estimate_normals": (C.c_int, [_vp, C.c_size_t, C.c_float, C.c_int, C.c_int, C.c_int, _vp]),
     "op_estimate_rigid_point_to_plane": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, _fp]),
     "op_estimate_rigid_transformation": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_int, _fp]),
+    "op_estimate_rigid_point_to_plane_ex": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp]),
+    "op_estimate_rigid_transformation_ex": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp]),
     "op_points_from_rgbd": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _szp]),
     "op_bilateral_filter_depth": (C.c_int, [_vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "op_points_from_depth": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, C.c_int, C.c_int, _vp, _szp]),

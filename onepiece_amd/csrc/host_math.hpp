@@ -146,7 +146,9 @@ OP_HD void se3_exp(const float x[6], float T[16]) {
 }
 
 // ---- symmetric eigen-decomposition (cyclic Jacobi), N <= 6, double.
-template <int N>
+// FULL = true sweeps until the off-diagonal mass underflows (the textbook stopping rule the CPU restatement uses;
+// validation mode of the ICP path) instead of stopping at the limit of double.
+template <int N, bool FULL = false>
 OP_HD void sym_eig(double A[N][N], double V[N][N]) {
     // every inner loop is fully unrolled so that, on the device, A and V are indexed with compile-time
     // constants and stay in registers (dynamic indexing would put them in scratch memory)
@@ -164,7 +166,7 @@ OP_HD void sym_eig(double A[N][N], double V[N][N]) {
             for (int j = i + 1; j < N; ++j) off += A[i][j] * A[i][j];
         }
         // converged: off-diagonal mass below 1e-17 of the diagonal's (the limit of double) or exactly zero
-        if (off < 1e-300 || off <= 1e-34 * diag) break;
+        if (off < 1e-300 || (!FULL && off <= 1e-34 * diag)) break;
 #pragma unroll
         for (int p = 0; p < N; ++p) {
 #pragma unroll
@@ -196,11 +198,12 @@ OP_HD void sym_eig(double A[N][N], double V[N][N]) {
 
 // x = JacobiSVD(JTJ).solve(-JTr) (Registration/ICP.cpp:137-138): minimum-norm least squares with
 // Eigen's default rank threshold (singular values <= eps_float * 6 * max are dropped).
+template <bool FULL = false>
 OP_HD void solve6_psd(const double JTJ[36], const double JTr[6], float x[6]) {
     double A[6][6], V[6][6], y[6];
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (JTJ[i * 6 + j] + JTJ[j * 6 + i]);
-    sym_eig<6>(A, V);
+    sym_eig<6, FULL>(A, V);
     double smax = 0;
     for (int i = 0; i < 6; ++i) smax = fabs(A[i][i]) > smax ? fabs(A[i][i]) : smax;
     const double thr = smax * 6.0 * static_cast<double>(FLT_EPSILON);
@@ -216,17 +219,14 @@ OP_HD void solve6_psd(const double JTJ[36], const double JTr[6], float x[6]) {
     }
 }
 
-// Kabsch from sufficient statistics (Geometry/Geometry.cpp:107-151): n, sum s, sum t, sum s t^T.
-// W = sum (s - ms)(t - mt)^T = sum s t^T - n ms mt^T.  R = V U^T (det-fixed), t = mt - R ms.
-OP_HD void kabsch_from_sums(double n, const double ss[3], const double st[3], const double sst[9], float T[16]) {
-    double ms[3], mt[3], W[3][3];
-    for (int i = 0; i < 3; ++i) { ms[i] = ss[i] / n; mt[i] = st[i] / n; }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) W[i][j] = sst[i * 3 + j] - n * ms[i] * mt[j];
+// Kabsch, the part after the sums (Geometry/Geometry.cpp:134-150): W = U S V^T (from the eigen-decomposition of
+// W^T W), R = V U^T (det-fixed), t = mt - R ms.
+template <bool FULL = false>
+OP_HD void kabsch_finish(const double ms[3], const double mt[3], const double W[3][3], float T[16]) {
     double A[3][3], V[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) A[i][j] = W[0][i] * W[0][j] + W[1][i] * W[1][j] + W[2][i] * W[2][j];
-    sym_eig<3>(A, V);
+    sym_eig<3, FULL>(A, V);
     // eigenvalues in descending order with their eigenvectors (columns): three predicated exchanges, all
     // indices static
     double ev[3] = {A[0][0], A[1][1], A[2][2]};
@@ -275,6 +275,63 @@ OP_HD void kabsch_from_sums(double n, const double ss[3], const double st[3], co
         T[i * 4 + 3] = static_cast<float>(mt[i] - s);
     }
     T[15] = 1.0f;
+}
+
+// Kabsch from sufficient statistics reduced in fp64 (the order-free variant): n, sum s, sum t, sum s t^T.
+// W = sum (s - ms)(t - mt)^T = sum s t^T - n ms mt^T.
+OP_HD void kabsch_from_sums(double n, const double ss[3], const double st[3], const double sst[9], float T[16]) {
+    double ms[3], mt[3], W[3][3];
+    for (int i = 0; i < 3; ++i) { ms[i] = ss[i] / n; mt[i] = st[i] / n; }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W[i][j] = sst[i * 3 + j] - n * ms[i] * mt[j];
+    kabsch_finish(ms, mt, W, T);
+}
+
+// geometry::EstimateRigidTransformation in the REFERENCE'S ORDER (Geometry/Geometry.cpp:117-133): the two means and
+// then the 3x3 sum of centred outer products are accumulated pair by pair in float32, exactly as the reference's
+// loops do (Eigen evaluates `mean += p` and `W += a * b^T` component-wise: one rounded product, one rounded add per
+// entry; no FMA in its -msse4.2 build).  Over 3e5 near-planar pairs that rounding noise is ~1e-3 of the result, and it
+// is part of what RegistrationResult::T is -- so this is what op_icp_run returns by default.  pairs: n x 6 floats
+// (source xyz, target xyz) in correspondence_set order (ascending source index).
+template <bool FULL = false>
+inline void kabsch_reference_order(const float* pairs, size_t n, float T[16]) {
+    float ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0}, W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) { ms[c] += pairs[6 * i + c]; mt[c] += pairs[6 * i + 3 + c]; } // :122-127
+    for (int c = 0; c < 3; ++c) { ms[c] /= static_cast<float>(n); mt[c] /= static_cast<float>(n); } // :128-129
+    for (size_t i = 0; i < n; ++i) { // :130-133
+        float a[3], b[3];
+        for (int c = 0; c < 3; ++c) { a[c] = pairs[6 * i + c] - ms[c]; b[c] = pairs[6 * i + 3 + c] - mt[c]; }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) W[r * 3 + c] += a[r] * b[c];
+    }
+    double dms[3], dmt[3], dW[3][3];
+    for (int i = 0; i < 3; ++i) {
+        dms[i] = ms[i]; dmt[i] = mt[i];
+        for (int j = 0; j < 3; ++j) dW[i][j] = W[i * 3 + j];
+    }
+    kabsch_finish<FULL>(dms, dmt, dW, T);
+}
+
+// registration::EstimateRigidTransformationPointToPlane's accumulation in the REFERENCE'S ORDER (ICP.cpp:121-136):
+// JTJ (all 36 entries) and JTr summed row by row in float32; tmp_r is the float difference of two float dots, widened
+// to double and narrowed again by Eigen's scalar promotion before it multiplies the row.  rows: n x 9 floats
+// (transformed source point, target point, target normal) in inlier order.  Validation mode of op_icp_run.
+inline void plane_sums_reference_order(const float* rows, size_t n, double JTJ[36], double JTr[6]) {
+    float jtj[36], jtr[6];
+    for (int k = 0; k < 36; ++k) jtj[k] = 0.0f;
+    for (int k = 0; k < 6; ++k) jtr[k] = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float *s = rows + 9 * i, *t = s + 3, *nn = s + 6;
+        const double r = static_cast<double>(dot3(nn, s) - dot3(nn, t));
+        const float row[6] = {nn[0], nn[1], nn[2], s[1] * nn[2] - s[2] * nn[1], s[2] * nn[0] - s[0] * nn[2], s[0] * nn[1] - s[1] * nn[0]};
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) jtj[a * 6 + b] += row[a] * row[b];
+            jtr[a] += static_cast<float>(r) * row[a];
+        }
+    }
+    for (int k = 0; k < 36; ++k) JTJ[k] = jtj[k];
+    for (int k = 0; k < 6; ++k) JTr[k] = jtr[k];
 }
 
 // Matrix4f * Matrix4f (start_T = tmp_T * start_T, ICP.cpp:198), column-accumulating product.

@@ -73,7 +73,7 @@ __global__ void k_bbox(const float* __restrict__ xyz, size_t m, unsigned* __rest
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x)
         for (int c = 0; c < 3; ++c) {
             const float v = xyz[3 * i + c];
-            if (v == v) { mx[c] = fmaxf(mx[c], v); mn[c] = fminf(mn[c], v); }
+            if (fabsf(v) <= FLT_MAX) { mx[c] = fmaxf(mx[c], v); mn[c] = fminf(mn[c], v); } // NaN and +-inf never enter the grid
         }
     for (int c = 0; c < 3; ++c) {
         for (int o = 32; o > 0; o >>= 1) {
@@ -100,7 +100,7 @@ __global__ void k_cell_count(const float* __restrict__ xyz, size_t m, Grid g, un
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= m) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    if (!(x == x && y == y && z == z)) return;
+    if (!(fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX)) return;
     const int cx = cell_coord(x, g.ox, g.inv_cell, g.gx), cy = cell_coord(y, g.oy, g.inv_cell, g.gy),
               cz = cell_coord(z, g.oz, g.inv_cell, g.gz);
     atomicAdd(&count[((size_t)cz * g.gy + cy) * g.gx + cx], 1u);
@@ -172,7 +172,7 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, const float* __res
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= m) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    if (!(x == x && y == y && z == z)) return;
+    if (!(fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX)) return;
     const int cx = cell_coord(x, g.ox, g.inv_cell, g.gx), cy = cell_coord(y, g.oy, g.inv_cell, g.gy),
               cz = cell_coord(z, g.oz, g.inv_cell, g.gz);
     const size_t c = ((size_t)cz * g.gy + cy) * g.gx + cx;
@@ -223,9 +223,12 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             // exact 1-NN restricted to the 27 cells around the query (see header comment)
             float best_d = FLT_MAX;
             int best_pos = -1;
-            if (tp0 == tp0 && tp1 == tp1 && tp2 == tp2) {
-                const int cx = (int)floorf((tp0 - g.ox) * g.inv_cell), cy = (int)floorf((tp1 - g.oy) * g.inv_cell),
-                          cz = (int)floorf((tp2 - g.oz) * g.inv_cell);
+            if (fabsf(tp0) <= FLT_MAX && fabsf(tp1) <= FLT_MAX && fabsf(tp2) <= FLT_MAX) { // NaN / inf queries match nothing
+                // cell of the query, clamped to two cells outside the grid (beyond that nothing can be within a cell of it;
+                // keeps the int conversion and the +-1 neighbourhood arithmetic in range for far-away points)
+                const int cx = (int)fminf(fmaxf(floorf((tp0 - g.ox) * g.inv_cell), -2.0f), (float)g.gx + 1.0f),
+                          cy = (int)fminf(fmaxf(floorf((tp1 - g.oy) * g.inv_cell), -2.0f), (float)g.gy + 1.0f),
+                          cz = (int)fminf(fmaxf(floorf((tp2 - g.oz) * g.inv_cell), -2.0f), (float)g.gz + 1.0f);
                 const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, g.gx - 1);
                 // distance from the query to the near face of the neighbouring rows of cells: every point of
                 // row (cy+dy, cz+dz) is at least sqrt(gy[dy]^2 + gz[dz]^2) away, so once a candidate nearer
@@ -413,6 +416,43 @@ __global__ __launch_bounds__(kIterThreads) void k_pair_sums(const float* __restr
         for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
         partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = v;
     }
+}
+
+// ---- ordered emission of the inlier rows ----------------------------------------------------------
+// The reference's own accumulations are sequential float32 loops over the inliers in ascending source index
+// (Geometry.cpp:117-133 for the returned T, ICP.cpp:121-136 for JTJ/JTr).  To reproduce their rounding the
+// inlier rows are compacted in that order on the device (flag -> scan -> scatter) and summed by ONE host thread.
+// KIND 0: original source point, target point (6 floats; the correspondence_set of ICP.cpp:215-221)
+// KIND 1: transformed source point, target point, target normal (9 floats; ICP.cpp:195-196)
+// KIND 2: transformed source point, target point (6 floats; ICP.cpp:76-79)
+__global__ __launch_bounds__(256) void k_inl_flag(const int* __restrict__ inl, size_t n, unsigned* __restrict__ count) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) count[i] = inl[i] >= 0 ? 1u : 0u;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void k_emit_rows(const float* __restrict__ T, const float* __restrict__ src, const float* __restrict__ tgt_orig,
+                                                   const float* __restrict__ nrm_orig, const int* __restrict__ inl,
+                                                   const unsigned* __restrict__ start, size_t n, float* __restrict__ rows) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = inl[i];
+    if (b < 0) return;
+    float s0 = src[3 * i], s1 = src[3 * i + 1], s2 = src[3 * i + 2];
+    if (KIND != 0) { // TransformPoints (Geometry.cpp:19-27), the same operations as k_icp_iter
+        float M[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) M[k] = T[k];
+        const float q0 = ((M[0] * s0 + M[1] * s1) + M[2] * s2) + M[3] * 1.0f;
+        const float q1 = ((M[4] * s0 + M[5] * s1) + M[6] * s2) + M[7] * 1.0f;
+        const float q2 = ((M[8] * s0 + M[9] * s1) + M[10] * s2) + M[11] * 1.0f;
+        const float q3 = ((M[12] * s0 + M[13] * s1) + M[14] * s2) + M[15] * 1.0f;
+        s0 = q0 / q3; s1 = q1 / q3; s2 = q2 / q3;
+    }
+    constexpr int W = KIND == 1 ? 9 : 6;
+    float* o = rows + (size_t)start[i] * W;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+    o[3] = tgt_orig[3 * (size_t)b]; o[4] = tgt_orig[3 * (size_t)b + 1]; o[5] = tgt_orig[3 * (size_t)b + 2];
+    if (KIND == 1) { o[6] = nrm_orig[3 * (size_t)b]; o[7] = nrm_orig[3 * (size_t)b + 1]; o[8] = nrm_orig[3 * (size_t)b + 2]; }
 }
 
 // Second pass, stage 1: kStage1 workgroups each fold a contiguous slice of the per-workgroup
@@ -674,6 +714,12 @@ struct op_icp {
     float* it_T_dev = nullptr;     // per-iteration start_T
     int it_cap = 0;
     int n_wg = 0, partials_cap = 0;
+    // reference-order finish / strict sums (OP_ICP_OPT_*): ordered inlier rows
+    int finish = OP_ICP_FINISH_REFERENCE, sums = OP_ICP_SUMS_FP64;
+    float* nrm_orig = nullptr;          // m x 3 target normals in original order (rows of KIND 1)
+    unsigned *flag = nullptr, *start = nullptr, *scan_tot = nullptr;
+    float *rows_dev = nullptr, *rows_host = nullptr; // src_cap x 9 floats each; rows_host is pinned
+    size_t rows_cap = 0;
 };
 
 namespace {
@@ -722,6 +768,43 @@ void expand_plane_sums(const double in[kNSums], double JTJ[36], double JTr[6]) {
     for (int a = 0; a < 6; ++a) JTr[a] = in[21 + a];
 }
 
+// Compacts the rows of the current inlier set (c->inl, written by a pass with write_inl) in ascending source
+// index, copies the first n_rows of them to pinned host memory and waits.  The transform is read from c->T_dev.
+int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
+    *rows = nullptr;
+    if (!c->n || !n_rows) return OP_OK;
+    if (c->rows_cap < c->n) {
+        void* old[] = {c->flag, c->start, c->scan_tot, c->rows_dev};
+        for (void* p : old)
+            if (p) OP_HIP(hipFree(p));
+        if (c->rows_host) OP_HIP(hipHostFree(c->rows_host));
+        c->flag = c->start = c->scan_tot = nullptr; c->rows_dev = c->rows_host = nullptr; c->rows_cap = 0;
+        const size_t cap = c->src_cap;
+        OP_HIP(hipMalloc((void**)&c->flag, cap * sizeof(unsigned)));
+        OP_HIP(hipMalloc((void**)&c->start, cap * sizeof(unsigned)));
+        OP_HIP(hipMalloc((void**)&c->scan_tot, ((cap + kScanWg - 1) / kScanWg + 1) * sizeof(unsigned)));
+        OP_HIP(hipMalloc((void**)&c->rows_dev, cap * 9 * sizeof(float)));
+        OP_HIP(hipHostMalloc((void**)&c->rows_host, cap * 9 * sizeof(float), hipHostMallocDefault));
+        c->rows_cap = cap;
+    }
+    const size_t n = c->n, nwg = (n + kScanWg - 1) / kScanWg;
+    const unsigned g256 = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_inl_flag, dim3(g256), dim3(256), 0, c->stream, (const int*)c->inl, n, c->flag);
+    hipLaunchKernelGGL(k_scan_totals, dim3((unsigned)nwg), dim3(256), 0, c->stream, (const unsigned*)c->flag, n, c->scan_tot);
+    hipLaunchKernelGGL(k_scan_of_totals, dim3(1), dim3(1024), 0, c->stream, c->scan_tot, nwg);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nwg), dim3(256), 0, c->stream, (const unsigned*)c->flag, n, (const unsigned*)c->scan_tot, c->start);
+#define OP_EMIT(K) hipLaunchKernelGGL(k_emit_rows<K>, dim3(g256), dim3(256), 0, c->stream, (const float*)c->T_dev, (const float*)c->src, \
+                                      (const float*)c->tgt_orig, (const float*)c->nrm_orig, (const int*)c->inl, (const unsigned*)c->start, n, c->rows_dev)
+    if (kind == 1) OP_EMIT(1); else if (kind == 2) OP_EMIT(2); else OP_EMIT(0);
+#undef OP_EMIT
+    OP_HIP(hipGetLastError());
+    const size_t w = kind == 1 ? 9 : 6;
+    OP_HIP(hipMemcpyAsync(c->rows_host, c->rows_dev, n_rows * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OP_HIP(hipStreamSynchronize(c->stream));
+    *rows = c->rows_host;
+    return OP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -747,6 +830,7 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     if (c->has_normals) {
         OP_HIP_C(hipMalloc((void**)&c->tgt_n, m1 * sizeof(float4)));
         OP_HIP_C(hipMalloc((void**)&d_nrm, m1 * 3 * sizeof(float)));
+        c->nrm_orig = d_nrm; // owned by the context from here on (freed by op_icp_destroy)
         if (m) OP_HIP_C(hipMemcpy(d_nrm, tgt_normals, m * 3 * sizeof(float), kind));
     }
     // bounding box -> grid
@@ -765,10 +849,14 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     // cell >= threshold (slightly larger so that float rounding of the cell index cannot hide a
     // neighbour closer than threshold); grow it if the grid would exceed kMaxCells
     double cell = threshold * 1.001;
-    for (;;) {
-        unsigned long long tot = 1;
-        for (int k = 0; k < 3; ++k) tot *= (unsigned long long)std::floor((mx[k] - mn[k]) / cell) + 2ull;
-        if (tot <= kMaxCells) break;
+    for (int k = 0; k < 3; ++k)
+        if (!std::isfinite(mx[k]) || !std::isfinite(mn[k]) || !std::isfinite((double)mx[k] - (double)mn[k]))
+            return bail(fail(OP_ERR_INVALID, "target bounding box is not finite"));
+    for (int grow = 0;; ++grow) { // bounded: the extent is finite, so cell *= 1.26 reaches it within ~400 steps of doubles
+        double tot = 1;
+        for (int k = 0; k < 3; ++k) tot *= std::floor(((double)mx[k] - (double)mn[k]) / cell) + 2.0;
+        if (tot <= (double)kMaxCells) break;
+        if (grow > 4096 || !std::isfinite(cell)) return bail(fail(OP_ERR_INVALID, "cannot size the search grid (threshold %g)", threshold));
         cell *= 1.26;
     }
     c->grid.ox = mn[0]; c->grid.oy = mn[1]; c->grid.oz = mn[2];
@@ -785,12 +873,11 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     OP_HIP_C(hipMemsetAsync(d_fill, 0, c->ncell * sizeof(unsigned), c->stream));
     if (m) hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, c->grid, c->cell_count);
     int rc = device_exclusive_scan(c->cell_count, c->ncell, c->cell_start, c->stream, nullptr);
-    if (rc != OP_OK) { (void)hipFree(d_fill); if (d_nrm) (void)hipFree(d_nrm); return bail(rc); }
+    if (rc != OP_OK) { (void)hipFree(d_fill); return bail(rc); }
     if (m) hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, (const float*)d_nrm, m,
                               c->grid, (const unsigned*)c->cell_start, d_fill, c->tgt, c->tgt_n);
     hipError_t e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_fill);
-    if (d_nrm) (void)hipFree(d_nrm);
     if (e != hipSuccess) return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e)));
     OP_HIP_C(hipMalloc((void**)&c->result, kNSums * sizeof(double)));
     OP_HIP_C(hipMalloc((void**)&c->T_dev, 16 * sizeof(float)));
@@ -808,13 +895,21 @@ int op_icp_destroy(op_icp* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->tgt_orig, c->tgt, c->tgt_n, c->cell_start, c->cell_count, c->src, c->nn, c->inl, c->partials, c->result,
-                    c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage};
+                    c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage, c->nrm_orig, c->flag, c->start, c->scan_tot, c->rows_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->result_host) (void)hipHostFree(c->result_host);
+    if (c->rows_host) (void)hipHostFree(c->rows_host);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return OP_OK;
+}
+
+int op_icp_set_option(op_icp* c, int option, int value) {
+    if (!c) return fail(OP_ERR_INVALID, "null icp");
+    if (option == OP_ICP_OPT_FINISH && (value == OP_ICP_FINISH_REFERENCE || value == OP_ICP_FINISH_FP64)) { c->finish = value; return OP_OK; }
+    if (option == OP_ICP_OPT_SUMS && (value == OP_ICP_SUMS_FP64 || value == OP_ICP_SUMS_REFERENCE_F32)) { c->sums = value; return OP_OK; }
+    return fail(OP_ERR_INVALID, "op_icp_set_option: unknown option %d / value %d", option, value);
 }
 
 int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
@@ -888,8 +983,35 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     // down as a by-value kernel argument and the sums come up through host-mapped pinned memory that
     // k_reduce_update publishes with a sequence number the host spins on (no memcpy, no stream sync).
     const int pass_mode = mode == OP_ICP_POINT_TO_PLANE ? 1 : 0;
-    const bool host_path = pass_mode == 1;
-    if (!host_path) {
+    const bool strict = c->sums == OP_ICP_SUMS_REFERENCE_F32;
+    const bool host_path = pass_mode == 1 || strict;
+    if (strict) {
+        // Validation mode: every iteration's inlier rows come to the host in inlier order and are summed there
+        // sequentially in float32, as the reference's loops do (ICP.cpp:121-136 / Geometry.cpp:117-133 via :76-79);
+        // the search, the inlier test and the rows themselves still come from the kernels.
+        float cur[16], tmp_T[16];
+        std::memcpy(cur, init_T, sizeof(cur));
+        for (int it = 0; it < max_iteration; ++it) {
+            OP_TRY(run_pass(c, pass_mode, cur, true, r)); // leaves `cur` in c->T_dev
+            const size_t n_it = (size_t)(r[28] + 0.5);
+            const float* rows = nullptr;
+            OP_TRY(emit_rows(c, pass_mode == 1 ? 1 : 2, n_it, &rows));
+            if (pass_mode == 1) {
+                double JTJ[36], JTr[6];
+                float x[6];
+                op_host::plane_sums_reference_order(rows, n_it, JTJ, JTr);
+                op_host::solve6_psd<true>(JTJ, JTr, x);
+                op_host::se3_exp(x, tmp_T);
+            } else {
+                op_host::kabsch_reference_order<true>(rows, n_it, tmp_T);
+            }
+            op_host::mat4_mul(tmp_T, cur, cur);
+            if (per_iter_inliers) per_iter_inliers[it] = (int32_t)n_it;
+            if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
+        }
+        OP_HIP(hipMemcpyAsync(c->T_dev, cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
+        OP_HIP(hipStreamSynchronize(c->stream));
+    } else if (!host_path) {
         for (int it = 0; it < max_iteration; ++it) OP_TRY(enqueue_pass(c, 0, false, 2, it, true));
     } else {
         float cur[16], tmp_T[16];
@@ -935,7 +1057,16 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     result->rmse = std::sqrt(r[27] / n_inl);
     result->iterations = max_iteration;
     std::memcpy(result->last_T, start_T, sizeof(start_T));
-    op_host::kabsch_from_sums(n_inl, r, r + 3, r + 6, result->T);
+    if (c->finish == OP_ICP_FINISH_REFERENCE) {
+        // RegistrationResult::T as the reference forms it (ICP.cpp:215-221 -> Geometry.cpp:117-133): sequential
+        // float32 sums over the correspondence_set in ascending source index
+        const float* rows = nullptr;
+        OP_TRY(emit_rows(c, 0, (size_t)result->n_inliers, &rows));
+        if (strict) op_host::kabsch_reference_order<true>(rows, (size_t)result->n_inliers, result->T);
+        else op_host::kabsch_reference_order(rows, (size_t)result->n_inliers, result->T);
+    } else {
+        op_host::kabsch_from_sums(n_inl, r, r + 3, r + 6, result->T); // order-free fp64 reduction
+    }
     if (pairs && c->n) {
         std::vector<int> inl(c->n);
         OP_HIP(hipMemcpy(inl.data(), c->inl, c->n * sizeof(int), hipMemcpyDeviceToHost));
@@ -990,25 +1121,71 @@ static int pair_sums_run(int mode, const float* a, size_t na_floats, const float
     return OP_OK;
 }
 
-int op_estimate_rigid_point_to_plane(const float* source_xyz, size_t n_source, const float* target_xyz, const float* target_normals, size_t n_target,
-                                     const int32_t* inliers, size_t n_inliers, int mem, int device, float T[16]) {
+// host copy of a caller array (the reference-order sums run on one host thread)
+static int host_view(const void* p, size_t bytes, int mem, std::vector<unsigned char>& keep, const void** out) {
+    *out = p;
+    if (mem != OP_MEM_DEVICE || !bytes) return OP_OK;
+    keep.resize(bytes);
+    OP_HIP(hipMemcpy(keep.data(), p, bytes, hipMemcpyDeviceToHost));
+    *out = keep.data();
+    return OP_OK;
+}
+
+int op_estimate_rigid_point_to_plane_ex(const float* source_xyz, size_t n_source, const float* target_xyz, const float* target_normals,
+                                        size_t n_target, const int32_t* inliers, size_t n_inliers, int mem, int device, int sums, float T[16]) {
     if (!T || (n_inliers && (!source_xyz || !target_xyz || !target_normals || !inliers))) return fail(OP_ERR_INVALID, "null argument");
-    double r[kNSums] = {0};
-    if (n_inliers) OP_TRY(pair_sums_run(1, source_xyz, n_source * 3, target_xyz, n_target * 3, target_normals, inliers, n_inliers, mem, device, r));
     double JTJ[36], JTr[6];
     float x[6];
-    expand_plane_sums(r, JTJ, JTr);
-    op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
+    if (sums == OP_ICP_SUMS_REFERENCE_F32) { // ICP.cpp:121-136 as written: one thread, float32, inlier order
+        OP_TRY(op::use_device(device));
+        std::vector<unsigned char> k0, k1, k2, k3;
+        const void *hs, *ht, *hn, *hi;
+        OP_TRY(host_view(source_xyz, n_source * 12, mem, k0, &hs)); OP_TRY(host_view(target_xyz, n_target * 12, mem, k1, &ht));
+        OP_TRY(host_view(target_normals, n_target * 12, mem, k2, &hn)); OP_TRY(host_view(inliers, n_inliers * 8, mem, k3, &hi));
+        std::vector<float> rows(n_inliers * 9);
+        const float *S = (const float*)hs, *Tg = (const float*)ht, *N = (const float*)hn;
+        const int32_t* I = (const int32_t*)hi;
+        for (size_t i = 0; i < n_inliers; ++i) {
+            const size_t a = (size_t)I[2 * i], b = (size_t)I[2 * i + 1];
+            if (a >= n_source || b >= n_target) return fail(OP_ERR_INVALID, "inlier %zu out of range", i);
+            for (int k = 0; k < 3; ++k) { rows[9 * i + k] = S[3 * a + k]; rows[9 * i + 3 + k] = Tg[3 * b + k]; rows[9 * i + 6 + k] = N[3 * b + k]; }
+        }
+        op_host::plane_sums_reference_order(rows.data(), n_inliers, JTJ, JTr);
+        op_host::solve6_psd<true>(JTJ, JTr, x);
+    } else {
+        double r[kNSums] = {0};
+        if (n_inliers) OP_TRY(pair_sums_run(1, source_xyz, n_source * 3, target_xyz, n_target * 3, target_normals, inliers, n_inliers, mem, device, r));
+        expand_plane_sums(r, JTJ, JTr);
+        op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
+    }
     op_host::se3_exp(x, T);            // ICP.cpp:143
     return OP_OK;
 }
 
-int op_estimate_rigid_transformation(const float* pairs_xyz6, size_t n_pairs, int mem, int device, float T[16]) {
+int op_estimate_rigid_point_to_plane(const float* source_xyz, size_t n_source, const float* target_xyz, const float* target_normals, size_t n_target,
+                                     const int32_t* inliers, size_t n_inliers, int mem, int device, float T[16]) {
+    return op_estimate_rigid_point_to_plane_ex(source_xyz, n_source, target_xyz, target_normals, n_target, inliers, n_inliers, mem, device,
+                                               OP_ICP_SUMS_FP64, T);
+}
+
+int op_estimate_rigid_transformation_ex(const float* pairs_xyz6, size_t n_pairs, int mem, int device, int finish, float T[16]) {
     if (!T || (n_pairs && !pairs_xyz6)) return fail(OP_ERR_INVALID, "null argument");
+    if (finish == OP_ICP_FINISH_REFERENCE) { // Geometry.cpp:117-133 as written: one thread, float32, pair order
+        OP_TRY(op::use_device(device));
+        std::vector<unsigned char> keep;
+        const void* hp;
+        OP_TRY(host_view(pairs_xyz6, n_pairs * 24, mem, keep, &hp));
+        op_host::kabsch_reference_order((const float*)hp, n_pairs, T);
+        return OP_OK;
+    }
     double r[kNSums] = {0};
     if (n_pairs) OP_TRY(pair_sums_run(0, pairs_xyz6, n_pairs * 6, nullptr, 0, nullptr, nullptr, n_pairs, mem, device, r));
     op_host::kabsch_from_sums(r[28], r, r + 3, r + 6, T); // Geometry.cpp:107-151
     return OP_OK;
+}
+
+int op_estimate_rigid_transformation(const float* pairs_xyz6, size_t n_pairs, int mem, int device, float T[16]) {
+    return op_estimate_rigid_transformation_ex(pairs_xyz6, n_pairs, mem, device, OP_ICP_FINISH_REFERENCE, T);
 }
 
 static int points_from_images(const op_camera* cam, const void* depth, int depth_fmt, const uint8_t* rgb, int mem, int device, float* xyz_out,

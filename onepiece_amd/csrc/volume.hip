@@ -972,7 +972,9 @@ __global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const int* _
 // definition is this implementation's own and is validated against the analytic synthetic scene:
 // march every pixel ray from near to far through the voxel-block hash, sample the sdf
 // trilinearly over the 8 surrounding voxel centres (all 8 must be observed, weight > 0), step one
-// voxel while samples are valid and one block (8 voxels) while they are not, and report the first
+// voxel inside allocated blocks (valid sample or not: IntegrateImage only writes |sdf| < truncation, so the
+// free space in front of a surface is unobserved voxels INSIDE allocated blocks and must not be leapt over), jump
+// to the exit face of a block that is absent from the hash, and report the first
 // + -> - crossing by linear interpolation as z-depth.  Normal = normalised central difference of the
 // trilinear sdf (+-res/2), colour = trilinear colour at the hit.  16x16 pixel tiles per workgroup
 // keep neighbouring rays -- which walk the same blocks -- on one CU.
@@ -1037,7 +1039,22 @@ __global__ __launch_bounds__(256) void k_raycast(VolView V, op_camera cam, Mat4 
             t += fine;
         } else {
             have_prev = false;
-            t += coarse;
+            // an invalid sample inside an allocated block is an unobserved voxel: step one voxel.  Only a block that
+            // is absent from the hash is skipped, up to its exit face (no valid sample can lie in it: all 8 voxel
+            // centres around a point of an absent block cannot be observed)
+            const float p0 = o0 + t * d0, p1 = o1 + t * d1, p2 = o2 + t * d2;
+            const float b0 = floorf(p0 / coarse), b1 = floorf(p1 / coarse), b2 = floorf(p2 / coarse);
+            const int bx = (int)b0, by = (int)b1, bz = (int)b2;
+            if (!(bx == bc.cx && by == bc.cy && bz == bc.cz)) { bc.cx = bx; bc.cy = by; bc.cz = bz; bc.idx = table_find(V, bx, by, bz); }
+            float step = fine;
+            if (bc.idx < 0) {
+                float t_exit = FLT_MAX;
+                if (d0 > 0) t_exit = fminf(t_exit, ((b0 + 1.0f) * coarse - p0) / d0); else if (d0 < 0) t_exit = fminf(t_exit, (b0 * coarse - p0) / d0);
+                if (d1 > 0) t_exit = fminf(t_exit, ((b1 + 1.0f) * coarse - p1) / d1); else if (d1 < 0) t_exit = fminf(t_exit, (b1 * coarse - p1) / d1);
+                if (d2 > 0) t_exit = fminf(t_exit, ((b2 + 1.0f) * coarse - p2) / d2); else if (d2 < 0) t_exit = fminf(t_exit, (b2 * coarse - p2) / d2);
+                if (t_exit < FLT_MAX) step = fmaxf(fine, t_exit + 0.01f * res);
+            }
+            t += step;
         }
     }
     depth_out[pix] = hit;
@@ -1688,6 +1705,7 @@ int op_volume_upload(op_volume* v, const int32_t* keys_xyz, const float* voxels_
     OP_VOL(v);
     if (n == 0) return OP_OK;
     if (!keys_xyz || !voxels_aos) return fail(OP_ERR_INVALID, "null argument");
+    OP_TRY(vol_flush(v)); // frames queued by op_volume_integrate come BEFORE the upload, as the caller issued them
     // later duplicates override earlier ones, like repeated map assignment; the device insert needs distinct keys
     std::vector<size_t> order(n);
     std::iota(order.begin(), order.end(), (size_t)0);
@@ -1772,10 +1790,11 @@ int op_volume_pack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_union
 
 int op_volume_unpack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_union, const float* d_sum) {
     OP_VOL(v);
+    // validate BEFORE the volume's own content is dropped: a refused unpack must leave the locally fused volume intact
+    if (n_union && (!d_union_keys || !d_sum)) return fail(OP_ERR_INVALID, "null argument");
+    if (n_union > v->max_blocks) return fail(OP_ERR_CAPACITY, "union of %zu blocks exceeds max_blocks %u", n_union, v->max_blocks);
     OP_TRY(op_volume_clear(v));
     if (n_union == 0) return OP_OK;
-    if (!d_union_keys || !d_sum) return fail(OP_ERR_INVALID, "null argument");
-    if (n_union > v->max_blocks) return fail(OP_ERR_CAPACITY, "union of %zu blocks exceeds max_blocks %u", n_union, v->max_blocks);
     int* d_slots = nullptr;
     OP_HIP(hipMalloc((void**)&d_slots, n_union * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, d_slots, v->state);

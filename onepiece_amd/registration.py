@@ -82,7 +82,7 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def _run(mode, source, target, init_T, icp_para, device):
+def _run(mode, source, target, init_T, icp_para, device, finish="reference", sums="fp64"):
     lib = L.load()
     res = RegistrationResult()
     # ICP.cpp:150-163: scaling != 1 or missing normals -> error line, default result
@@ -100,6 +100,8 @@ def _run(mode, source, target, init_T, icp_para, device):
     L.check(lib.op_icp_create(C.c_void_p(tgt.ctypes.data), C.c_void_p(nrm.ctypes.data) if nrm is not None else None,
                               len(tgt), float(icp_para.threshold), L.OP_MEM_HOST, device, C.byref(h)))
     try:
+        L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_FINISH, {"reference": L.OP_ICP_FINISH_REFERENCE, "fp64": L.OP_ICP_FINISH_FP64}[finish]))
+        L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_SUMS, {"fp64": L.OP_ICP_SUMS_FP64, "reference_f32": L.OP_ICP_SUMS_REFERENCE_F32}[sums]))
         L.check(lib.op_icp_set_source(h, C.c_void_p(src.ctypes.data), len(src), L.OP_MEM_HOST))
         out = L.IcpResult()
         iters = max(int(icp_para.max_iteration), 0)
@@ -125,14 +127,16 @@ def _run(mode, source, target, init_T, icp_para, device):
     return res
 
 
-def PointToPlane(source, target, init_T=None, icp_para=None, device=0):
-    """registration::PointToPlane (ICP.cpp:146-224)."""
-    return _run(L.OP_ICP_POINT_TO_PLANE, source, target, init_T, icp_para or ICPParameter(), device)
+def PointToPlane(source, target, init_T=None, icp_para=None, device=0, finish="reference", sums="fp64"):
+    """registration::PointToPlane (ICP.cpp:146-224).  finish / sums: op_icp_set_option (include/onepiece_hip.h) --
+    "reference" finish (default) forms RegistrationResult::T with the reference's sequential float32 sums;
+    sums="reference_f32" is the validation mode that also sums every iteration's JTJ/JTr that way."""
+    return _run(L.OP_ICP_POINT_TO_PLANE, source, target, init_T, icp_para or ICPParameter(), device, finish, sums)
 
 
-def PointToPoint(source, target, init_T=None, icp_para=None, device=0):
+def PointToPoint(source, target, init_T=None, icp_para=None, device=0, finish="reference", sums="fp64"):
     """registration::PointToPoint (ICP.cpp:31-107)."""
-    return _run(L.OP_ICP_POINT_TO_POINT, source, target, init_T, icp_para or ICPParameter(), device)
+    return _run(L.OP_ICP_POINT_TO_POINT, source, target, init_T, icp_para or ICPParameter(), device, finish, sums)
 
 
 def Se3ToSE3(x):
@@ -143,7 +147,7 @@ def Se3ToSE3(x):
     return T.reshape(4, 4)
 
 
-def EstimateRigidTransformationPointToPlane(source, target, target_normal, inliers, device=0):
+def EstimateRigidTransformationPointToPlane(source, target, target_normal, inliers, device=0, sums="fp64"):
     """registration::EstimateRigidTransformationPointToPlane (ICP.h:24-26): one point-to-plane step over the
     given inliers (n x 2: source id, target id); `source` = the already transformed points."""
     src = np.ascontiguousarray(source, np.float32).reshape(-1, 3)
@@ -152,13 +156,15 @@ def EstimateRigidTransformationPointToPlane(source, target, target_normal, inlie
     inl = np.ascontiguousarray(inliers, np.int32).reshape(-1, 2)
     T = np.empty(16, np.float32)
     vp = lambda a: C.c_void_p(a.ctypes.data)
-    L.check(L.load().op_estimate_rigid_point_to_plane(vp(src), len(src), vp(tgt), vp(nrm), len(tgt), vp(inl), len(inl), L.OP_MEM_HOST, device, _fp(T)))
+    L.check(L.load().op_estimate_rigid_point_to_plane_ex(vp(src), len(src), vp(tgt), vp(nrm), len(tgt), vp(inl), len(inl), L.OP_MEM_HOST, device,
+                                                         {"fp64": L.OP_ICP_SUMS_FP64, "reference_f32": L.OP_ICP_SUMS_REFERENCE_F32}[sums], _fp(T)))
     return T.reshape(4, 4)
 
 
-def EstimateRigidTransformation(correspondence_set, device=0):
+def EstimateRigidTransformation(correspondence_set, device=0, finish="reference"):
     """geometry::EstimateRigidTransformation (Geometry.cpp:107-151): Kabsch over (n, 2, 3) point pairs."""
     pairs = np.ascontiguousarray(correspondence_set, np.float32).reshape(-1, 6)
     T = np.empty(16, np.float32)
-    L.check(L.load().op_estimate_rigid_transformation(C.c_void_p(pairs.ctypes.data), len(pairs), L.OP_MEM_HOST, device, _fp(T)))
+    L.check(L.load().op_estimate_rigid_transformation_ex(C.c_void_p(pairs.ctypes.data), len(pairs), L.OP_MEM_HOST, device,
+                                                         {"reference": L.OP_ICP_FINISH_REFERENCE, "fp64": L.OP_ICP_FINISH_FP64}[finish], _fp(T)))
     return T.reshape(4, 4)

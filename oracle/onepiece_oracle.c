@@ -740,8 +740,19 @@ void orc_volume_raycast(const orc_volume *v, const orc_camera *cam, const float 
                     have_prev = 1; s_prev = sdf; t_prev = t;
                     t += fine;
                 } else {
+                    /* unobserved voxel inside an allocated block: one voxel; absent block: jump to its exit face */
                     have_prev = 0;
-                    t += coarse;
+                    float bf[3], step = fine;
+                    for (int c = 0; c < 3; ++c) bf[c] = floorf(p[c] / coarse);
+                    if (vol_find(v, (int)bf[0], (int)bf[1], (int)bf[2]) < 0) {
+                        float t_exit = FLT_MAX;
+                        for (int c = 0; c < 3; ++c) {
+                            if (dir[c] > 0) t_exit = fminf(t_exit, ((bf[c] + 1.0f) * coarse - p[c]) / dir[c]);
+                            else if (dir[c] < 0) t_exit = fminf(t_exit, (bf[c] * coarse - p[c]) / dir[c]);
+                        }
+                        if (t_exit < FLT_MAX) step = fmaxf(fine, t_exit + 0.01f * v->res);
+                    }
+                    t += step;
                 }
             }
             depth_out[pix] = hit;
