@@ -19,6 +19,14 @@
 #define CUBE 8
 #define NVOX 512
 
+/* Threads for the fusion path.  The reference integrates serially (CubeHandler.cpp:205-208), so the default is 1
+ * and that is what bench.py's cpu_baseline times.  Every unit the loops below hand to a thread is independent in
+ * the reference too (a pixel of ComputeBounding, a candidate block of PrepareCubes, a selected block of
+ * IntegrateImage -- blocks are exclusively owned), and min/max/integer sums do not depend on the order, so the
+ * results are bit-identical for any thread count; tests raise it so that full-size sequences finish in seconds. */
+static int g_fusion_threads = 1;
+void orc_set_fusion_threads(int n) { g_fusion_threads = n < 1 ? 1 : n; }
+
 /* ------------------------------------------------------------------------------------------ */
 /* Eigen 3.3.7 fixed-size semantics used all over the reference                                */
 /* ------------------------------------------------------------------------------------------ */
@@ -193,6 +201,8 @@ size_t orc_compute_bounding(const orc_camera *cam, const void *depth, int is_u16
     for (int i = 0; i < 3; ++i) { max_pos[i] = -FLT_MAX; min_pos[i] = FLT_MAX; }
     float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
     size_t inside = 0;
+    float mx0 = -FLT_MAX, mx1 = -FLT_MAX, mx2 = -FLT_MAX, mn0 = FLT_MAX, mn1 = FLT_MAX, mn2 = FLT_MAX;
+#pragma omp parallel for num_threads(g_fusion_threads) schedule(static) reduction(+ : inside) reduction(max : mx0, mx1, mx2) reduction(min : mn0, mn1, mn2)
     for (int i = 0; i < cam->height; ++i)
         for (int j = 0; j < cam->width; ++j) {
             float z = depth_at(depth, is_u16, cam->depth_scale, (size_t)i * cam->width + j);
@@ -206,12 +216,13 @@ size_t orc_compute_bounding(const orc_camera *cam, const void *depth, int is_u16
             p[0] = q[0] / q[3]; p[1] = q[1] / q[3]; p[2] = q[2] / q[3];
             if (frustum_contains(planes, p)) {
                 ++inside;
-                for (int c = 0; c < 3; ++c) {
-                    max_pos[c] = p[c] > max_pos[c] ? p[c] : max_pos[c]; /* std::max(p, max) */
-                    min_pos[c] = p[c] < min_pos[c] ? p[c] : min_pos[c];
-                }
+                /* std::max(p, max) / std::min: NaN never replaces the running value */
+                mx0 = p[0] > mx0 ? p[0] : mx0; mx1 = p[1] > mx1 ? p[1] : mx1; mx2 = p[2] > mx2 ? p[2] : mx2;
+                mn0 = p[0] < mn0 ? p[0] : mn0; mn1 = p[1] < mn1 ? p[1] : mn1; mn2 = p[2] < mn2 ? p[2] : mn2;
             }
         }
+    max_pos[0] = mx0; max_pos[1] = mx1; max_pos[2] = mx2;
+    min_pos[0] = mn0; min_pos[1] = mn1; min_pos[2] = mn2;
     return inside;
 }
 
@@ -342,25 +353,34 @@ size_t orc_volume_prepare_cubes(orc_volume *v, const void *depth, int is_u16, co
     orc_cube_id(v->res, minp, minid);
     orc_mat4_inverse(pose, pose_inv); /* Integrator.cpp:18 (recomputed per call there) */
     float cube_res = v->res * CUBE;   /* CubeHandler.cpp:164 */
-    size_t n = 0, ncand = 0;
-    for (int i = minid[0] - 1; i <= maxid[0] + 1; ++i)
-        for (int j = minid[1] - 1; j <= maxid[1] + 1; ++j)
-            for (int k = minid[2] - 1; k <= maxid[2] + 1; ++k) {
-                ++ncand;
-                float min_sdf = FLT_MAX;
-                for (int c = 0; c < 8; ++c) {
-                    const float *o = v->offset[kCornerVoxel[c]];
-                    float p[3] = {i * cube_res + o[0], j * cube_res + o[1], k * cube_res + o[2]};
-                    float sdf = orc_get_sdf(&v->cam, p, pose_inv, depth, is_u16);
-                    if (min_sdf > fabsf(sdf)) min_sdf = fabsf(sdf);
-                }
-                if (min_sdf < v->trunc) {
-                    if (vol_find(v, i, j, k) < 0) vol_add(v, i, j, k);
-                    if (ids && n < cap) { ids[3 * n] = i; ids[3 * n + 1] = j; ids[3 * n + 2] = k; }
-                    ++n;
-                }
-            }
-    if (n_candidates) *n_candidates = ncand;
+    size_t n = 0;
+    /* the 8-corner test of every candidate is independent (CubeHandler.cpp:166-180): evaluated first, possibly on
+     * several threads; allocation and the id list then follow in the reference's i, j, k loop order (:181-190) */
+    const long long ni = (long long)maxid[0] - minid[0] + 3, nj = (long long)maxid[1] - minid[1] + 3,
+                    nk = (long long)maxid[2] - minid[2] + 3;
+    const long long ncand = ni * nj * nk;
+    unsigned char *sel = (unsigned char *)malloc((size_t)(ncand > 0 ? ncand : 1));
+#pragma omp parallel for num_threads(g_fusion_threads) schedule(static)
+    for (long long q = 0; q < ncand; ++q) {
+        const int i = minid[0] - 1 + (int)(q / (nj * nk)), j = minid[1] - 1 + (int)((q / nk) % nj), k = minid[2] - 1 + (int)(q % nk);
+        float min_sdf = FLT_MAX;
+        for (int c = 0; c < 8; ++c) {
+            const float *o = v->offset[kCornerVoxel[c]];
+            float p[3] = {i * cube_res + o[0], j * cube_res + o[1], k * cube_res + o[2]};
+            float sdf = orc_get_sdf(&v->cam, p, pose_inv, depth, is_u16);
+            if (min_sdf > fabsf(sdf)) min_sdf = fabsf(sdf);
+        }
+        sel[q] = min_sdf < v->trunc;
+    }
+    for (long long q = 0; q < ncand; ++q) {
+        if (!sel[q]) continue;
+        const int i = minid[0] - 1 + (int)(q / (nj * nk)), j = minid[1] - 1 + (int)((q / nk) % nj), k = minid[2] - 1 + (int)(q % nk);
+        if (vol_find(v, i, j, k) < 0) vol_add(v, i, j, k);
+        if (ids && n < cap) { ids[3 * n] = i; ids[3 * n + 1] = j; ids[3 * n + 2] = k; }
+        ++n;
+    }
+    free(sel);
+    if (n_candidates) *n_candidates = (size_t)(ncand > 0 ? ncand : 0);
     return n;
 }
 
@@ -422,6 +442,8 @@ size_t orc_volume_integrate(orc_volume *v, const void *depth, int is_u16, const 
     float pose_inv[16];
     orc_mat4_inverse(pose, pose_inv); /* Integrator.cpp:48 */
     uint64_t upd = 0;
+    /* CubeHandler.cpp:205-208: serial in the reference; every selected block is owned by exactly one iteration */
+#pragma omp parallel for num_threads(g_fusion_threads) schedule(dynamic, 32) reduction(+ : upd)
     for (size_t i = 0; i < n; ++i) {
         int64_t b = vol_find(v, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
         upd += integrate_block(v, b, depth, is_u16, rgb, pose_inv);

@@ -44,6 +44,9 @@ uint64_t orc_hash(int x, int y, int z);
 /* Integration/Frustum.cpp:7-46, Geometry.cpp:165-171. planes: top,left,right,bottom,near,far. */
 void orc_frustum_planes(const orc_camera *cam, const float pose[16], float far_d, float near_d,
                         float planes[24]);
+/* Threads used by orc_compute_bounding / orc_volume_prepare_cubes / orc_volume_integrate (default 1 = the
+ * reference's serial path, which is what cpu_baseline times); results do not depend on it. */
+void orc_set_fusion_threads(int n);
 /* Integration/CubeHandler.cpp:116-145; returns number of points inside the frustum. */
 size_t orc_compute_bounding(const orc_camera *cam, const void *depth, int is_u16,
                             const float pose[16], float far_d, float near_d, float max_pos[3],

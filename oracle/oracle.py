@@ -143,6 +143,18 @@ def _p(a, t=_fp):
     return a.ctypes.data_as(t)
 
 
+def set_fusion_threads(n=None):
+    """Threads for compute_bounding / prepare_cubes / integrate (None = min(32, host cores): measured best on the
+    256-core GPU box, tests/tools/oracle_thread_scaling.py -- 73 ms/frame with 1 thread, 6.6 with 32, 31 with 128;
+    1 = the reference's serial path and the default).  Results are bit-identical for any value; tests use it to run
+    full-size sequences."""
+    import os
+    L = lib()
+    L.orc_set_fusion_threads.restype = None
+    L.orc_set_fusion_threads.argtypes = [C.c_int]
+    L.orc_set_fusion_threads(int(n if n is not None else min(32, os.cpu_count() or 1)))
+
+
 def make_camera(fx=514.817, fy=515.375, cx=318.771, cy=238.447, width=640, height=480,
                 depth_scale=1000.0):
     """Default = OPEN3D_DATASET preset (Camera/Camera.h:94-104)."""
