@@ -1,0 +1,102 @@
+// Integration/CubeHandler.h -- one_piece::integration::CubeHandler on an MI355X.
+//
+// Same class name, namespace, public signatures, default arguments and value semantics as the reference's
+// src/Integration/CubeHandler.h:24-366, so that code written against it (example/ImageSequenceIntegration.cpp,
+// example/DenseFusion) compiles and links against this library instead.  What differs is where the block hash lives:
+// the reference holds a std::unordered_map<CubeID, VoxelCube> on the host; here the object owns a device-resident
+// volume (op_volume, include/onepiece_hip.h) and every member forwards to the C-ABI:
+//
+//   IntegrateImage      -> op_volume_integrate   (enqueues; frames are fused in batches of up to 16 per launch)
+//   every reader        -> flushes + synchronises first (GetCubeMap, HasCube, ExtractTriangleMesh, WriteToFile, ...),
+//                          so the deferral cannot be observed (SURVEY 8b "Threading")
+//   GetCubeMap()        -> downloads into a fresh CubeMap and returns it BY VALUE, as the reference does
+//   copy construction / assignment -> deep copy on the device (a CubeHandler owns its volume; no sharing)
+//   Transform* / GetPointCloud     -> std::shared_ptr to freshly made objects
+//   errors              -> a coloured line on std::cout and an early return; nothing throws (reference behaviour)
+//
+// The `cube_map` member of the reference is kept only as the return type of GetCubeMap / argument of SetCubeMap: there is
+// no host copy of the volume to go stale.  Device selection: environment variable ONEPIECE_HIP_DEVICE (default 0).
+#pragma once
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "Camera/Camera.h"
+#include "Geometry/Geometry.h"
+#include "Geometry/RGBDFrame.h"
+#include "Geometry/TriangleMesh.h"
+#include "Integration/Integrator.h"
+#include "Integration/MarchingCube.h"
+#include "Integration/VoxelCube.h"
+
+#define TRUNCATED_DISTANCES 1.0
+
+struct op_volume;
+
+namespace one_piece {
+namespace integration {
+
+typedef std::unordered_map<CubeID, VoxelCube, CubeHasher> CubeMap;
+
+class CubeHandler {
+  public:
+    CubeHandler();
+    CubeHandler(const camera::PinholeCamera& _camera);
+    CubeHandler(const CubeHandler& other);
+    CubeHandler& operator=(const CubeHandler& other);
+    ~CubeHandler();
+
+    void SetVoxelResolution(float resolution);
+    bool ReadFromFile(const std::string& filename);
+    bool ReadFromFileFloat(const std::string& filename);
+    bool WriteToFile(const std::string& filename);
+    bool HasCube(const CubeID& cube_id) const;
+    void Clear();
+    void SetCamera(const camera::PinholeCamera& _camera);
+    void SetTruncation(float trunc);
+    void Merge(const CubeHandler& another);
+    void Merge(const CubeHandler& another, const geometry::TransformationMatrix& trans);
+    void ComputeBounding(const cv::Mat& depth, const geometry::TransformationMatrix& pose, geometry::Point3& max_pos, geometry::Point3& min_pos);
+    void PrepareCubes(const cv::Mat& depth, const geometry::TransformationMatrix& pose, std::vector<CubeID>& cube_id_list);
+    void IntegrateImage(const cv::Mat& depth, const cv::Mat& rgb, const geometry::TransformationMatrix& pose);
+    void IntegrateImage(const geometry::RGBDFrame& rgbd, const geometry::TransformationMatrix& pose);
+    CubeID GetCubeID(const geometry::Point3& point) const { return c_para.GetCubeID(point); }
+    void AddCube(const CubeID& cube_id);
+    void ExtractTriangleMesh(geometry::TriangleMesh& mesh);
+    void GenerateMeshByCube(const CubeID& cube_id, geometry::TriangleMesh& mesh);
+    std::shared_ptr<geometry::PointCloud> GetPointCloud() const;
+    std::shared_ptr<CubeHandler> Transform(const geometry::TransformationMatrix& trans) const;
+    std::shared_ptr<CubeHandler> TransformNearest(const geometry::TransformationMatrix& trans);
+    CubeMap GetCubeMap();
+    void SetCubeMap(const CubeMap& _cube_map);
+    void SetFarPlane(float _far);
+    void SetNearPlane(float _near);
+
+    // ---- beyond the reference's surface -------------------------------------------------------------------
+    // blocks currently allocated (cube_map.size() in the reference); flushes
+    size_t GetCubeCount() const;
+    // waits until every queued frame has been fused
+    void Synchronize() const;
+    // frame-sharded fusion: merges the volumes of all ranks of an RCCL communicator into `root`'s with one
+    // reduce; see op_volume_merge_rccl.  comm is an ncclComm_t.
+    bool MergeAcrossRanks(void* nccl_comm, int root);
+    // the C-ABI handle (created on first use), for callers that mix in direct op_volume_* calls
+    op_volume* Handle() const;
+
+  protected:
+    camera::PinholeCamera camera;
+    Integrator integrator;
+    CubePara c_para;
+    float far = 5.0;
+    float near = 0.5;
+
+  private:
+    bool Ensure() const;                 // creates the device volume on first use; false (after a message) without a GPU
+    static void Report(const char* where);
+    mutable op_volume* vol = nullptr;
+    explicit CubeHandler(op_volume* adopted, const CubeHandler& like, float resolution);
+};
+
+} // namespace integration
+} // namespace one_piece

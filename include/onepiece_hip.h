@@ -198,6 +198,13 @@ int op_volume_keys_device(op_volume *v, int32_t *d_keys, size_t cap, size_t *n);
 int op_volume_pack_sum(op_volume *v, const int32_t *d_union_keys, size_t n_union, float *d_out);
 int op_volume_unpack_sum(op_volume *v, const int32_t *d_union_keys, size_t n_union,
                          const float *d_sum);
+/* The whole merge as ONE call for a C/C++ host: all-gather of the per-rank block keys over RCCL, the
+ * identical sorted union on every rank, sum-form pack, ONE ncclReduce(float32, sum) to `root`, normalisation on the
+ * root -- i.e. CubeHandler::Merge (CubeHandler.h:145-167) across the ranks of a communicator.  nccl_comm is an
+ * ncclComm_t whose rank owns the volume's device; call from one host thread (or process) per rank.  Non-root volumes
+ * are left untouched.  *n_union (may be NULL) = number of blocks in the merged volume.  RCCL is bound at run time
+ * (dlopen), so the library does not need it until this entry point is used. */
+int op_volume_merge_rccl(op_volume *v, void *nccl_comm, int root, size_t *n_union);
 
 /* ---- registration (Registration/ICP.h:13-26, RegistrationResult.h:9-16) ------------------- */
 typedef struct {
