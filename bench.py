@@ -91,8 +91,7 @@ def main():
     depth, rgb, poses = S.room_sequence_torch(first, n_local, dev)
     torch.cuda.synchronize()
 
-    max_blocks = 1 << 19  # 5 GiB pool; the 1000-frame room needs ~1e5 blocks
-    hv = I.CubeHandler(device=local_rank, max_blocks=max_blocks)
+    hv = I.CubeHandler(device=local_rank)  # default pool (2^18 blocks, 2.7 GB); it grows on demand like the reference's map
     hv.SetVoxelResolution(args.voxel)
     ops = D.HipVolumeOps(hv, dev)
 
@@ -227,7 +226,7 @@ def main():
                                          "(the reference's integrate path is serial), host has %d cores" % (ns, os.cpu_count()),
                                "host_cores": os.cpu_count(), "cpu_model": _cpu_model()}
         # parity at the benchmark's own sizes: same sample through the HIP path, compared bit for bit
-        hv2 = I.CubeHandler(device=local_rank, max_blocks=1 << 17)
+        hv2 = I.CubeHandler(device=local_rank)
         hv2.SetVoxelResolution(args.voxel)
         hv2.IntegrateSequence(depth[:ns], rgb[:ns], poses[:ns])
         hk, hvx = hv2.GetCubeMap()

@@ -38,7 +38,10 @@
 #include <vector>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "common.hpp"
@@ -95,7 +98,9 @@ struct State {
     unsigned n_batch;   // length of the batch block list
     unsigned overflow;  // bit0 pool full, bit1 table full, bit2 bbox too large, bit3 coordinate range
     unsigned n_rec;     // PrepareCubes record mode: entries in sel_list / sel_cand
-    unsigned pad;
+    unsigned fail_seq;  // sequence number of the batch that first ran out of pool / table space (valid while overflow & 3)
+    unsigned cur_seq;   // sequence number of the batch whose kernels are running (written by KA)
+    unsigned pad[3];
     unsigned long long stat_frames;
     unsigned long long n_cand[kMaxBatch];
     float bbox[kMaxBatch][6]; // max xyz, min xyz
@@ -224,7 +229,7 @@ __device__ int table_claim(const VolView& V, State* st, int x, int y, int z, boo
             if (k == kEmptyKey) { // slot is ours: allocate a pool block
                 const unsigned idx = atomicAdd(V.n_blocks, 1u);
                 if (idx >= V.max_blocks) {
-                    atomicOr(&st->overflow, 1u);
+                    if ((atomicOr(&st->overflow, 1u) & 3u) == 0u) st->fail_seq = st->cur_seq;
                     V.tvals[s] = kDead;
                 } else {
                     V.keys[3 * idx] = x; V.keys[3 * idx + 1] = y; V.keys[3 * idx + 2] = z;
@@ -236,7 +241,7 @@ __device__ int table_claim(const VolView& V, State* st, int x, int y, int z, boo
         }
         if (k == key) return (int)s;
     }
-    atomicOr(&st->overflow, 2u);
+    if ((atomicOr(&st->overflow, 2u) & 3u) == 0u) st->fail_seq = st->cur_seq;
     return -1;
 }
 
@@ -272,6 +277,16 @@ __global__ void k_clear_table(unsigned long long* tkeys, int* tvals, size_t n) {
     }
 }
 
+// Growth: the n allocated blocks (distinct keys, pool slot = index) re-enter a freshly cleared, larger table.
+__global__ void k_rehash(unsigned long long* __restrict__ tkeys, int* __restrict__ tvals, unsigned mask, const int* __restrict__ keys, unsigned n) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = keys[3 * i], y = keys[3 * i + 1], z = keys[3 * i + 2];
+    const unsigned long long key = pack_key(x, y, z);
+    for (unsigned s = (unsigned)hash_key_dev(x, y, z) & mask;; s = (s + 1) & mask)
+        if (atomicCAS(&tkeys[s], kEmptyKey, key) == kEmptyKey) { tvals[s] = (int)i; return; }
+}
+
 // After a select-only launch (PrepareCubes API): clear the batch masks again and translate the
 // recorded table slots into pool slots.
 __global__ void k_finish_select(VolView V, const State* st) {
@@ -288,11 +303,23 @@ __global__ void k_finish_select(VolView V, const State* st) {
 // One bounding partial per workgroup (no atomics): [max x,y,z, min x,y,z, inside, pad].
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C, BatchPtrs Q, uint2* __restrict__ pimg,
-                                                        float* __restrict__ partial, State* st) {
+                                                        float* __restrict__ partial, State* st, unsigned seq,
+                                                        const unsigned* __restrict__ n_blocks, unsigned* __restrict__ hstat) {
     __shared__ float s_red[4][6];
     __shared__ unsigned s_cnt[4];
     const int tid = threadIdx.x, f = blockIdx.y;
-    if (blockIdx.x == 0 && f == 0 && tid == 0) { st->n_batch = 0; st->n_rec = 0; } // new batch: empty lists
+    if (blockIdx.x == 0 && f == 0 && tid == 0) {
+        st->n_batch = 0; st->n_rec = 0; // new batch: empty lists
+        st->cur_seq = seq;
+        // Progress report for the host (host-mapped pinned memory, read without any synchronisation): this kernel starting
+        // means every earlier batch has finished; unless the stream is poisoned by an overflow they all completed.  The host
+        // uses it to retire its replay log / staging slots and to grow the pool BEFORE it runs full.
+        if (hstat && (st->overflow & 3u) == 0u) {
+            hstat[1] = *n_blocks;
+            __threadfence_system();
+            __hip_atomic_store(&hstat[0], seq - 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (blockIdx.x == 0 && f == 0 && tid < 8) st->kc_next[tid * 16] = 0u;
     const PoseFwd& P = B.f[f];
     const int npix = C.width * C.height;
@@ -424,6 +451,10 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
     }
     if (blockIdx.x == 0 && tid == 0) st->n_cand[f] = ncand;
 
+    // A batch that ran out of pool / table space poisons the stream: its KC and every later batch do nothing, so that the
+    // host can grow the volume and REPLAY from the failing batch on -- no frame is ever partially fused (see vol_recover).
+    if (st->overflow & 3u) ncand = 0;
+
     const float cube_res = C.res * 8.0f; // CubeHandler.cpp:164
     const float half = C.res / 2;        // VoxelCube.h:47
     const float o_lo = 0.0f * C.res + half, o_hi = 7.0f * C.res + half; // VoxelCentroidOffSet of x = 0 / 7
@@ -519,6 +550,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                                                    unsigned long long* __restrict__ sel_partial) {
     __shared__ unsigned s_upd[8];
     __shared__ float s_c255[256]; // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
+    if (st->overflow & 3u) return; // pool / table exhausted in this or an earlier batch: nothing is fused, the host replays
     const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
     const int vid = threadIdx.x;
     if (vid < 256) s_c255[vid] = (float)vid / 255.0f;
@@ -1120,10 +1152,37 @@ struct op_volume {
     uint64_t prof_batch = 0;
     std::vector<hipEvent_t> prof_events; // 4 per sampled batch
     std::vector<int> prof_frames;
-    // staging ring for host images: one slot per frame of a batch
+    // scratch for the single-frame synchronous calls that take host images (ComputeBounding / PrepareCubes)
     void* img_depth = nullptr;
     unsigned char* img_rgb = nullptr;
     size_t img_cap_px = 0;
+    // Staging ring for host images handed to op_volume_integrate: kRing batch slots, each with pinned host buffers and
+    // device buffers for kMaxBatch frames.  A frame is copied into the pinned slot by the caller's thread (+ helper
+    // threads), DMA'd on `copy_stream` while the caller fills the next frame, and the batch's kernels wait for the
+    // slot's `copied` event -- so the H2D of batch b+1 overlaps the kernels of batch b.  A slot is reused only after the
+    // batch that used it is CONFIRMED complete (its device images are what a replay after pool growth reads).
+    struct RingSlot {
+        void* d_depth = nullptr; unsigned char* d_rgb = nullptr;
+        void* h_depth = nullptr; unsigned char* h_rgb = nullptr;
+        hipEvent_t copied = nullptr;
+        uint64_t busy_seq = 0; // sequence number of the batch staged here, 0 = free
+    };
+    static constexpr int kRing = 3;
+    RingSlot ring[kRing];
+    size_t ring_px = 0;
+    int ring_cur = -1;          // slot of the batch being assembled (-1: none acquired yet)
+    unsigned ring_next = 0;
+    hipStream_t copy_stream = nullptr;
+    // Growth / replay.  Every launched batch is logged until it is confirmed complete; if a batch exhausts the pool or the
+    // hash table the stream is poisoned on the device (nothing is fused from that batch on), and the host -- at its next
+    // look -- grows the volume and replays the log from the failing batch.  No frame is lost or partially applied.
+    struct BatchRec { uint64_t seq; BatchFwd F; BatchInv I; BatchPtrs P; int nf, fmt, ring_slot; };
+    std::deque<BatchRec> log;
+    uint64_t seq = 0;            // sequence number of the last launched batch
+    unsigned* hstat = nullptr;   // pinned + mapped: [0] = last batch known complete, [1] = n_blocks at that time
+    unsigned* hstat_dev = nullptr;
+    bool recovering = false;     // vol_recover is replaying: no nested growth checks
+    bool grow_refused = false;   // an early growth could not get memory: stop asking before every batch (a real overflow still tries)
     // frames accepted by op_volume_integrate but not launched yet: single-frame calls are queued
     // and fused in batches of kMaxBatch (every accessor flushes first, so this is unobservable)
     int pend_n = 0, pend_fmt = 0;
@@ -1155,14 +1214,138 @@ int vol_reset(op_volume* v) {
     return OP_OK;
 }
 
-// Raises OP_ERR_CAPACITY if a previous kernel flagged an overflow.  Synchronises.
+constexpr unsigned kHardMaxBlocks = 1u << 24; // 172 GB of pool: what one 288 GB MI355X can hold next to its inputs
+
+int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const BatchPtrs& Q, int nf, int depth_fmt, bool select_only, bool record);
+
+// Grows the pool to new_max blocks (and the hash table to twice that), keeping the first n_valid blocks.  The stream
+// must be idle.  The new buffers are allocated before the old ones are released, so a failed allocation leaves the
+// volume intact (OP_ERR_CAPACITY).  CubeMap growth in the reference is std::unordered_map's (CubeHandler.h:22).
+int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
+    if (want > kHardMaxBlocks) want = kHardMaxBlocks;
+    if (want <= v->max_blocks) return fail(OP_ERR_CAPACITY, "volume cannot grow beyond %u blocks", v->max_blocks);
+    const unsigned new_max = (unsigned)want, new_table = next_pow2(2ull * new_max);
+    float* pool = nullptr;
+    int *keys = nullptr, *blist = nullptr, *sel_list = nullptr, *tvals = nullptr;
+    unsigned long long *sel_cand = nullptr, *tkeys = nullptr;
+    unsigned* bmask = nullptr;
+    hipError_t e = hipMalloc((void**)&pool, sizeof(float) * kBlockFloats * (size_t)new_max);
+    if (e == hipSuccess) e = hipMalloc((void**)&keys, sizeof(int) * 3 * (size_t)new_max);
+    if (e == hipSuccess) e = hipMalloc((void**)&blist, sizeof(int) * (size_t)new_max);
+    if (e == hipSuccess) e = hipMalloc((void**)&sel_list, sizeof(int) * (size_t)new_max);
+    if (e == hipSuccess) e = hipMalloc((void**)&sel_cand, sizeof(unsigned long long) * (size_t)new_max);
+    if (e == hipSuccess) e = hipMalloc((void**)&tkeys, sizeof(unsigned long long) * (size_t)new_table);
+    if (e == hipSuccess) e = hipMalloc((void**)&tvals, sizeof(int) * (size_t)new_table);
+    if (e == hipSuccess) e = hipMalloc((void**)&bmask, sizeof(unsigned) * (size_t)new_table);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        void* got[] = {pool, keys, blist, sel_list, sel_cand, tkeys, tvals, bmask};
+        for (void* q : got)
+            if (q) (void)hipFree(q);
+        return fail(OP_ERR_CAPACITY, "cannot grow the volume to %u blocks: %s", new_max, hipGetErrorString(e));
+    }
+    if (n_valid) {
+        OP_HIP(hipMemcpyAsync(pool, v->pool, sizeof(float) * kBlockFloats * (size_t)n_valid, hipMemcpyDeviceToDevice, v->stream));
+        OP_HIP(hipMemcpyAsync(keys, v->keys, sizeof(int) * 3 * (size_t)n_valid, hipMemcpyDeviceToDevice, v->stream));
+    }
+    hipLaunchKernelGGL(k_fill_pool, dim3(4096), dim3(256), 0, v->stream, pool, (size_t)n_valid, (size_t)(new_max - n_valid));
+    hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, tkeys, tvals, (size_t)new_table);
+    OP_HIP(hipMemsetAsync(bmask, 0, sizeof(unsigned) * (size_t)new_table, v->stream));
+    if (n_valid) hipLaunchKernelGGL(k_rehash, dim3((n_valid + 255) / 256), dim3(256), 0, v->stream, tkeys, tvals, new_table - 1, (const int*)keys, n_valid);
+    OP_HIP(hipMemcpyAsync(v->n_blocks, &n_valid, sizeof(unsigned), hipMemcpyHostToDevice, v->stream));
+    OP_HIP(hipGetLastError());
+    OP_HIP(hipStreamSynchronize(v->stream)); // n_valid is a stack variable; the old buffers are released next
+    void* old[] = {v->pool, v->keys, v->blist, v->sel_list, v->sel_cand, v->tkeys, v->tvals, v->bmask};
+    for (void* q : old)
+        if (q) (void)hipFree(q);
+    v->pool = pool; v->keys = keys; v->blist = blist; v->sel_list = sel_list; v->sel_cand = sel_cand;
+    v->tkeys = tkeys; v->tvals = tvals; v->bmask = bmask;
+    v->max_blocks = new_max; v->table_size = new_table;
+    return OP_OK;
+}
+
+// Makes room for `need` blocks in total (upload / merge / unpack know their demand up front).  Synchronises when it grows.
+int vol_reserve(op_volume* v, unsigned long long need) {
+    if (need <= v->max_blocks) return OP_OK;
+    if (need > kHardMaxBlocks) return fail(OP_ERR_CAPACITY, "%llu blocks exceed the limit of %u blocks per volume", need, kHardMaxBlocks);
+    OP_HIP(hipStreamSynchronize(v->stream));
+    unsigned n = 0;
+    OP_HIP(hipMemcpy(&n, v->n_blocks, sizeof(n), hipMemcpyDeviceToHost));
+    if (n > v->max_blocks) n = v->max_blocks;
+    return vol_grow(v, std::max<unsigned long long>(next_pow2(need), 2ull * v->max_blocks), n);
+}
+
+// Retires log entries (and their staging slots) of batches the device has reported complete.  Never blocks.
+void vol_retire(op_volume* v) {
+    if (!v->hstat) return;
+    const unsigned lo = __atomic_load_n(&v->hstat[0], __ATOMIC_ACQUIRE);
+    // widen the 32-bit report: it can only lie at or behind the last launched batch, and less than 2^31 behind
+    uint64_t done = (v->seq & ~0xffffffffull) | lo;
+    if (done > v->seq) done -= 1ull << 32;
+    while (!v->log.empty() && v->log.front().seq <= done) {
+        const int rs = v->log.front().ring_slot;
+        if (rs >= 0 && v->ring[rs].busy_seq == v->log.front().seq) v->ring[rs].busy_seq = 0;
+        v->log.pop_front();
+    }
+}
+
+// The stream is idle.  If a batch exhausted the pool or the table: grow, then replay everything from that batch on (the
+// failing batch's KC and all later batches did nothing).  Loops until the log has gone through.  Other overflow bits
+// (bad frames) are left for the caller to report.
+int vol_recover(op_volume* v, unsigned* flags_out) {
+    for (;;) {
+        State st;
+        OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
+        if (flags_out) *flags_out = st.overflow;
+        if ((st.overflow & 3u) == 0u) {
+            for (auto& r : v->log)
+                if (r.ring_slot >= 0 && v->ring[r.ring_slot].busy_seq == r.seq) v->ring[r.ring_slot].busy_seq = 0;
+            v->log.clear();
+            return OP_OK;
+        }
+        unsigned n = 0;
+        OP_HIP(hipMemcpy(&n, v->n_blocks, sizeof(n), hipMemcpyDeviceToHost));
+        if (n > v->max_blocks) n = v->max_blocks; // claims beyond the pool were marked dead; the blocks below it are real
+        // first failing batch: widen the device's 32-bit sequence number like vol_retire does
+        uint64_t fail_seq = (v->seq & ~0xffffffffull) | st.fail_seq;
+        if (fail_seq > v->seq) fail_seq -= 1ull << 32;
+        int rc = vol_grow(v, 2ull * v->max_blocks, n);
+        if (rc != OP_OK) { // cannot grow: report, drop the frames that cannot be fused
+            v->log.clear();
+            for (auto& r : v->ring) r.busy_seq = 0;
+            const unsigned keep = st.overflow & ~3u;
+            OP_HIP(hipMemcpy(&v->state->overflow, &keep, sizeof(keep), hipMemcpyHostToDevice));
+            return rc;
+        }
+        const unsigned keep = st.overflow & ~3u;
+        OP_HIP(hipMemcpy(&v->state->overflow, &keep, sizeof(keep), hipMemcpyHostToDevice));
+        std::deque<op_volume::BatchRec> replay;
+        replay.swap(v->log);
+        while (!replay.empty() && replay.front().seq < fail_seq) replay.pop_front(); // those completed
+        v->recovering = true;
+        int rrc = OP_OK;
+        for (auto& r : replay) {
+            rrc = vol_enqueue_batch(v, r.F, r.I, r.P, r.nf, r.fmt, false, false); // assigns a new sequence number
+            if (rrc != OP_OK) break;
+            if (r.ring_slot >= 0) v->ring[r.ring_slot].busy_seq = v->seq;
+            v->log.back().ring_slot = r.ring_slot;
+        }
+        v->recovering = false;
+        OP_TRY(rrc);
+        OP_HIP(hipStreamSynchronize(v->stream));
+    }
+}
+
+// Flushes, synchronises, grows + replays if needed, and reports frames that cannot be fused at all.
 int vol_check(op_volume* v) {
     OP_TRY(vol_flush(v));
     OP_HIP(hipStreamSynchronize(v->stream));
     unsigned of = 0;
-    OP_HIP(hipMemcpy(&of, &v->state->overflow, sizeof(of), hipMemcpyDeviceToHost));
-    if (of & 1u) return fail(OP_ERR_CAPACITY, "block pool exhausted (max_blocks = %u); create the volume with a larger max_blocks", v->max_blocks);
-    if (of & 2u) return fail(OP_ERR_CAPACITY, "hash table exhausted (size %u)", v->table_size);
+    OP_TRY(vol_recover(v, &of));
+    if (of & 12u) { // report once, then clear: the offending frames selected nothing, everything else was fused
+        const unsigned zero = 0;
+        OP_HIP(hipMemcpy(&v->state->overflow, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    }
     if (of & 4u) return fail(OP_ERR_INVALID, "frame bounding box spans more than 4096 blocks on an axis");
     if (of & 8u) return fail(OP_ERR_INVALID, "block coordinate outside +-2^20 (not representable in the device hash key)");
     return OP_OK;
@@ -1175,8 +1358,8 @@ int vol_block_count(op_volume* v, unsigned* n) {
     return OP_OK;
 }
 
-// Host images are copied into slot `slot` of the staging ring (stream-ordered, so a slot is not
-// overwritten before the batch that used it has been prepared); device images are used in place.
+// Single-frame scratch of the synchronous calls (ComputeBounding / PrepareCubes): host images are copied to the device
+// stream-ordered; device images are used in place.  (op_volume_integrate stages through the pinned ring below.)
 int vol_stage_images(op_volume* v, const void** depth, int depth_fmt, const unsigned char** rgb, int mem, int slot = 0) {
     if (mem == OP_MEM_DEVICE) return OP_OK;
     const size_t npx = (size_t)v->cam.width * v->cam.height;
@@ -1186,8 +1369,8 @@ int vol_stage_images(op_volume* v, const void** depth, int depth_fmt, const unsi
         if (v->img_depth) OP_HIP(hipFree(v->img_depth));
         if (v->img_rgb) OP_HIP(hipFree(v->img_rgb));
         v->img_depth = nullptr; v->img_rgb = nullptr; v->img_cap_px = 0;
-        OP_HIP(hipMalloc(&v->img_depth, (size_t)kMaxBatch * npx * 4));
-        OP_HIP(hipMalloc((void**)&v->img_rgb, (size_t)kMaxBatch * npx * 3));
+        OP_HIP(hipMalloc(&v->img_depth, npx * 4));
+        OP_HIP(hipMalloc((void**)&v->img_rgb, npx * 3));
         v->img_cap_px = npx;
     }
     void* d = (char*)v->img_depth + (size_t)slot * npx * 4;
@@ -1239,6 +1422,24 @@ int vol_ensure_frame_buffers(op_volume* v) {
 // select_only, KC.  No host synchronisation.
 int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const BatchPtrs& Q, int nf, int depth_fmt, bool select_only, bool record) {
     OP_TRY(vol_ensure_frame_buffers(v));
+    // Look at the device's lagging progress report (no synchronisation): retire confirmed batches and, when the pool is
+    // about to run full, grow it NOW -- between batches -- instead of paying for a replay later.
+    vol_retire(v);
+    if (v->hstat && !v->recovering && !v->grow_refused && (unsigned long long)v->hstat[1] + v->max_blocks / 8u > v->max_blocks && v->max_blocks < kHardMaxBlocks) {
+        OP_HIP(hipStreamSynchronize(v->stream));
+        unsigned of = 0;
+        OP_TRY(vol_recover(v, &of)); // also handles an overflow that has already happened
+        unsigned n = 0;
+        OP_HIP(hipMemcpy(&n, v->n_blocks, sizeof(n), hipMemcpyDeviceToHost));
+        if ((unsigned long long)n + v->max_blocks / 8u > v->max_blocks) {
+            const int rc = vol_grow(v, 2ull * v->max_blocks, n < v->max_blocks ? n : v->max_blocks);
+            if (rc != OP_OK && rc != OP_ERR_CAPACITY) return rc; // out of memory is not fatal yet: the pool may still suffice
+            if (rc == OP_ERR_CAPACITY) v->grow_refused = true;
+        }
+        v->hstat[1] = n;
+    }
+    const unsigned seq = (unsigned)(++v->seq);
+    if (!select_only) v->log.push_back(op_volume::BatchRec{v->seq, F, I, Q, nf, depth_fmt, -1});
     const CamParams C = cam_params(v, depth_fmt);
     const int npix = C.width * C.height;
     const int g1 = (npix + kPixPerWg - 1) / kPixPerWg;
@@ -1250,7 +1451,8 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         for (auto& e : ev) OP_HIP(hipEventCreate(&e));
         OP_HIP(hipEventRecord(ev[0], v->stream));
     }
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state);
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state, seq,
+                       (const unsigned*)v->n_blocks, v->hstat_dev);
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
     if (C.fast_px)
         hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
@@ -1279,9 +1481,137 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
 // launch the frames queued by op_volume_integrate
 int vol_flush(op_volume* v) {
     if (v->pend_n == 0) return OP_OK;
-    const int nf = v->pend_n;
+    const int nf = v->pend_n, rs = v->ring_cur;
     v->pend_n = 0;
-    return vol_enqueue_batch(v, v->pend_F, v->pend_I, v->pend_P, nf, v->pend_fmt, false, false);
+    v->ring_cur = -1;
+    if (rs >= 0) { // the batch's kernels start when its host images have arrived
+        OP_HIP(hipEventRecord(v->ring[rs].copied, v->copy_stream));
+        OP_HIP(hipStreamWaitEvent(v->stream, v->ring[rs].copied, 0));
+    }
+    OP_TRY(vol_enqueue_batch(v, v->pend_F, v->pend_I, v->pend_P, nf, v->pend_fmt, false, false));
+    if (rs >= 0) { v->ring[rs].busy_seq = v->seq; v->log.back().ring_slot = rs; }
+    return OP_OK;
+}
+
+// ---- host-image staging ring (op_volume_integrate with OP_MEM_HOST) ------------------------------------------------
+// Helper threads for the pageable -> pinned copy: one host core moves ~10-15 GB/s, i.e. 2.1 MB frames at 5-7 k frames/s;
+// the caller's thread plus two helpers share the chunks of a frame.  The helpers spin briefly after work (calls arrive
+// every < 100 us while a sequence is being fused) and sleep on a condition variable when idle.
+class CopyPool {
+  public:
+    static CopyPool& get() { static CopyPool p; return p; }
+    void copy2(void* d0, const void* s0, size_t n0, void* d1, const void* s1, size_t n1) {
+        if (helpers_.empty() || n0 + n1 < (1u << 18)) { std::memcpy(d0, s0, n0); if (n1) std::memcpy(d1, s1, n1); return; }
+        std::lock_guard<std::mutex> call(call_mutex_); // one copy at a time (volumes on several threads share the pool)
+        job_[0] = {(char*)d0, (const char*)s0, n0}; job_[1] = {(char*)d1, (const char*)s1, n1};
+        const size_t chunks = (n0 + kChunk - 1) / kChunk + (n1 + kChunk - 1) / kChunk;
+        done_.store(0, std::memory_order_relaxed);
+        next_.store(0, std::memory_order_relaxed);
+        total_ = chunks;
+        { std::lock_guard<std::mutex> lk(m_); ++epoch_; }
+        cv_.notify_all();
+        work();
+        while (done_.load(std::memory_order_acquire) < chunks) __builtin_ia32_pause();
+    }
+  private:
+    static constexpr size_t kChunk = 1u << 17;
+    struct Job { char* d; const char* s; size_t n; };
+    CopyPool() {
+        int n = 2;
+        if (const char* e = std::getenv("ONEPIECE_HIP_COPY_THREADS")) n = std::atoi(e);
+        if ((int)std::thread::hardware_concurrency() <= 2) n = 0;
+        for (int i = 0; i < n && i < 8; ++i) helpers_.emplace_back([this] { loop(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
+        cv_.notify_all();
+        for (auto& t : helpers_) t.join();
+    }
+    void work() {
+        const size_t c0 = (job_[0].n + kChunk - 1) / kChunk;
+        for (;;) {
+            const size_t c = next_.fetch_add(1, std::memory_order_acq_rel);
+            if (c >= total_) return;
+            const Job& j = c < c0 ? job_[0] : job_[1];
+            const size_t off = (c < c0 ? c : c - c0) * kChunk;
+            std::memcpy(j.d + off, j.s + off, std::min(kChunk, j.n - off));
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            // spin for a while (a frame arrives every < 100 us during a sequence), then sleep
+            bool have = false;
+            for (int spin = 0; spin < 20000 && !have; ++spin) {
+                { std::lock_guard<std::mutex> lk(m_); have = epoch_ != seen; }
+                if (!have) __builtin_ia32_pause();
+            }
+            if (!have) { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return epoch_ != seen; }); }
+            { std::lock_guard<std::mutex> lk(m_); seen = epoch_; if (stop_) return; }
+            work();
+        }
+    }
+    std::vector<std::thread> helpers_;
+    std::mutex m_, call_mutex_;
+    std::condition_variable cv_;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+    Job job_[2];
+    size_t total_ = 0;
+    std::atomic<size_t> next_{0}, done_{0};
+};
+
+int vol_ring_alloc(op_volume* v) {
+    const size_t npx = (size_t)v->cam.width * v->cam.height;
+    if (v->ring_px >= npx && v->copy_stream) return OP_OK;
+    OP_TRY(vol_check(v)); // nothing in flight may still read the old slots
+    if (!v->copy_stream) OP_HIP(hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking));
+    for (auto& r : v->ring) {
+        if (r.d_depth) OP_HIP(hipFree(r.d_depth));
+        if (r.d_rgb) OP_HIP(hipFree(r.d_rgb));
+        if (r.h_depth) OP_HIP(hipHostFree(r.h_depth));
+        if (r.h_rgb) OP_HIP(hipHostFree(r.h_rgb));
+        r.d_depth = r.h_depth = nullptr; r.d_rgb = r.h_rgb = nullptr; r.busy_seq = 0;
+        OP_HIP(hipMalloc(&r.d_depth, (size_t)kMaxBatch * npx * 4));
+        OP_HIP(hipMalloc((void**)&r.d_rgb, (size_t)kMaxBatch * npx * 3));
+        OP_HIP(hipHostMalloc(&r.h_depth, (size_t)kMaxBatch * npx * 4, hipHostMallocDefault));
+        OP_HIP(hipHostMalloc((void**)&r.h_rgb, (size_t)kMaxBatch * npx * 3, hipHostMallocDefault));
+        if (!r.copied) OP_HIP(hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
+    }
+    v->ring_px = npx;
+    v->ring_cur = -1;
+    return OP_OK;
+}
+
+// Stages one host frame into position `pos` of the batch being assembled: pageable -> pinned on the host (parallel),
+// then an asynchronous DMA on the copy stream.  The caller's buffers are free again when this returns.
+int vol_ring_stage(op_volume* v, const void** depth, int depth_fmt, const unsigned char** rgb, int pos) {
+    OP_TRY(vol_ring_alloc(v));
+    if (v->ring_cur < 0) { // first host frame of this batch: take the next slot
+        const int rs = (int)(v->ring_next++ % (unsigned)op_volume::kRing);
+        vol_retire(v);
+        if (v->ring[rs].busy_seq != 0) { // its batch is not confirmed yet (only when the GPU is the bottleneck)
+            const int keep_n = v->pend_n;
+            v->pend_n = 0;                 // vol_check must not flush the half-assembled batch
+            const int rc = vol_check(v);
+            v->pend_n = keep_n;
+            OP_TRY(rc);
+        }
+        v->ring_cur = rs;
+    }
+    op_volume::RingSlot& r = v->ring[v->ring_cur];
+    const size_t npx = (size_t)v->cam.width * v->cam.height, dbytes = npx * (depth_fmt == OP_DEPTH_U16 ? 2 : 4), cbytes = npx * 3;
+    char* hd = (char*)r.h_depth + (size_t)pos * npx * 4;
+    unsigned char* hc = r.h_rgb + (size_t)pos * npx * 3;
+    CopyPool::get().copy2(hd, *depth, dbytes, hc, *rgb, cbytes);
+    char* dd = (char*)r.d_depth + (size_t)pos * npx * 4;
+    unsigned char* dc = r.d_rgb + (size_t)pos * npx * 3;
+    OP_HIP(hipMemcpyAsync(dd, hd, dbytes, hipMemcpyHostToDevice, v->copy_stream));
+    OP_HIP(hipMemcpyAsync(dc, hc, cbytes, hipMemcpyHostToDevice, v->copy_stream));
+    *depth = dd;
+    *rgb = dc;
+    return OP_OK;
 }
 
 int check_cam(const op_camera* cam) {
@@ -1384,8 +1714,8 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     OP_TRY(check_cam(cam));
     if (!(voxel_res > 0) || !(truncation > 0)) return fail(OP_ERR_INVALID, "voxel_res and truncation must be > 0");
     OP_TRY(op::use_device(device));
-    if (max_blocks == 0) max_blocks = 1u << 18;
-    if (max_blocks > (1ull << 27)) return fail(OP_ERR_INVALID, "max_blocks too large");
+    if (max_blocks == 0) max_blocks = 1u << 18; // initial capacity; the pool and the table grow on demand (vol_grow)
+    if (max_blocks > kHardMaxBlocks) return fail(OP_ERR_INVALID, "max_blocks too large (limit %u)", kHardMaxBlocks);
     op_volume* v = new op_volume();
     v->device = device; v->cam = *cam; v->res = voxel_res; v->trunc = truncation; v->far_d = far_dist; v->near_d = near_dist;
     v->max_blocks = (unsigned)max_blocks;
@@ -1405,6 +1735,9 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     OP_HIP_C(hipMalloc((void**)&v->sel_cand, sizeof(unsigned long long) * (size_t)v->max_blocks));
     OP_HIP_C(hipMalloc((void**)&v->state, sizeof(State)));
     OP_HIP_C(hipMalloc((void**)&v->upd_partial, sizeof(unsigned long long) * kIntegrateGrid));
+    OP_HIP_C(hipHostMalloc((void**)&v->hstat, 2 * sizeof(unsigned), hipHostMallocMapped));
+    v->hstat[0] = 0; v->hstat[1] = 0;
+    OP_HIP_C(hipHostGetDevicePointer((void**)&v->hstat_dev, v->hstat, 0));
 #undef OP_HIP_C
     hipLaunchKernelGGL(k_fill_pool, dim3(4096), dim3(256), 0, v->stream, v->pool, (size_t)0, (size_t)v->max_blocks);
     int rc = vol_reset(v);
@@ -1423,6 +1756,16 @@ int op_volume_destroy(op_volume* v) {
                     v->partial, v->pimg, v->upd_partial, v->sel_partial, v->img_depth, v->img_rgb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
+    for (auto& r : v->ring) {
+        if (r.d_depth) (void)hipFree(r.d_depth);
+        if (r.d_rgb) (void)hipFree(r.d_rgb);
+        if (r.h_depth) (void)hipHostFree(r.h_depth);
+        if (r.h_rgb) (void)hipHostFree(r.h_rgb);
+        if (r.copied) (void)hipEventDestroy(r.copied);
+    }
+    if (v->hstat) (void)hipHostFree(v->hstat);
+    if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
     if (v->stream) (void)hipStreamDestroy(v->stream);
     delete v;
     return OP_OK;
@@ -1462,8 +1805,13 @@ int op_volume_set_near_far(op_volume* v, float near_dist, float far_dist) {
 int op_volume_clear(op_volume* v) {
     OP_VOL(v);
     v->pend_n = 0; // queued frames would be wiped anyway
+    v->ring_cur = -1;
     unsigned n = 0;
+    if (v->copy_stream) OP_HIP(hipStreamSynchronize(v->copy_stream));
     OP_HIP(hipStreamSynchronize(v->stream));
+    v->log.clear(); // whatever was in flight (fused or poisoned) is wiped with the volume
+    for (auto& r : v->ring) r.busy_seq = 0;
+    if (v->hstat) v->hstat[1] = 0;
     OP_HIP(hipMemcpy(&n, v->n_blocks, sizeof(n), hipMemcpyDeviceToHost));
     if (n > v->max_blocks) n = v->max_blocks;
     if (n) hipLaunchKernelGGL(k_fill_pool, dim3(4096), dim3(256), 0, v->stream, v->pool, (size_t)0, (size_t)n);
@@ -1507,7 +1855,8 @@ int op_volume_compute_bounding(op_volume* v, const void* depth, int depth_fmt, i
     Q.depth[0] = depth;
     const CamParams C = cam_params(v, depth_fmt);
     const int npix = C.width * C.height, g1 = (npix + kPixPerWg - 1) / kPixPerWg;
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state);
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state, (unsigned)(++v->seq),
+                       (const unsigned*)v->n_blocks, v->hstat_dev);
     OP_HIP(hipGetLastError());
     OP_HIP(hipStreamSynchronize(v->stream));
     std::vector<float> part((size_t)g1 * 8);
@@ -1540,8 +1889,12 @@ int op_volume_prepare_cubes(op_volume* v, const void* depth, int depth_fmt, int 
     BatchPtrs Q{};
     frame_params(v, pose, pose_inv, &F.f[0], &I.f[0]);
     Q.depth[0] = depth;
-    OP_TRY(vol_enqueue_batch(v, F, I, Q, 1, depth_fmt, /*select_only=*/true, /*record=*/true));
-    OP_TRY(vol_check(v));
+    for (;;) { // a selection that outgrows the pool grows it (vol_check) and is then simply run again
+        const unsigned cap_before = v->max_blocks;
+        OP_TRY(vol_enqueue_batch(v, F, I, Q, 1, depth_fmt, /*select_only=*/true, /*record=*/true));
+        OP_TRY(vol_check(v));
+        if (v->max_blocks == cap_before) break;
+    }
     State st;
     OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
     const size_t ns = std::min((size_t)st.n_rec, (size_t)v->max_blocks);
@@ -1579,7 +1932,7 @@ int op_volume_integrate(op_volume* v, const void* depth, int depth_fmt, const ui
     if (v->pend_n > 0 && v->pend_fmt != depth_fmt) OP_TRY(vol_flush(v));
     const unsigned char* c = rgb;
     const int slot = v->pend_n;
-    OP_TRY(vol_stage_images(v, &depth, depth_fmt, &c, mem, slot));
+    if (mem == OP_MEM_HOST) OP_TRY(vol_ring_stage(v, &depth, depth_fmt, &c, slot));
     frame_params(v, pose, pose_inv, &v->pend_F.f[slot], &v->pend_I.f[slot]);
     v->pend_P.depth[slot] = depth;
     v->pend_P.rgb[slot] = c;
@@ -1717,6 +2070,11 @@ int op_volume_upload(op_volume* v, const int32_t* keys_xyz, const float* voxels_
         const bool last = i + 1 == n || !std::equal(keys_xyz + 3 * order[i], keys_xyz + 3 * order[i] + 3, keys_xyz + 3 * order[i + 1]);
         if (last) uniq.push_back(order[i]);
     }
+    {   // room for every new block up front (the pool grows; nothing can overflow below)
+        unsigned nb = 0;
+        OP_TRY(vol_block_count(v, &nb));
+        OP_TRY(vol_reserve(v, (unsigned long long)nb + uniq.size()));
+    }
     const size_t chunk = 8192;
     int *d_keys = nullptr, *d_slots = nullptr;
     float* d_vox = nullptr;
@@ -1755,8 +2113,10 @@ int op_volume_merge(op_volume* dst, op_volume* src) {
     if (dst == src) return fail(OP_ERR_INVALID, "cannot merge a volume into itself");
     unsigned ns = 0;
     OP_TRY(vol_block_count(src, &ns));
-    OP_TRY(vol_check(dst));
+    unsigned nd = 0;
+    OP_TRY(vol_block_count(dst, &nd));
     if (!ns) return OP_OK;
+    OP_TRY(vol_reserve(dst, (unsigned long long)nd + ns)); // worst case: no block in common
     int* d_slots = nullptr;
     OP_HIP(hipMalloc((void**)&d_slots, (size_t)ns * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((ns + 255) / 256), dim3(256), 0, dst->stream, dst->view(), (const int*)src->keys, (size_t)ns, d_slots, dst->state);
@@ -1792,7 +2152,8 @@ int op_volume_unpack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_uni
     OP_VOL(v);
     // validate BEFORE the volume's own content is dropped: a refused unpack must leave the locally fused volume intact
     if (n_union && (!d_union_keys || !d_sum)) return fail(OP_ERR_INVALID, "null argument");
-    if (n_union > v->max_blocks) return fail(OP_ERR_CAPACITY, "union of %zu blocks exceeds max_blocks %u", n_union, v->max_blocks);
+    OP_TRY(vol_check(v));
+    OP_TRY(vol_reserve(v, n_union)); // grows the root's pool if the union needs it; a refusal leaves the volume as it was
     OP_TRY(op_volume_clear(v));
     if (n_union == 0) return OP_OK;
     int* d_slots = nullptr;
@@ -1823,10 +2184,14 @@ int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, i
     else op_host::mat4_inverse(T, Mi.m); // trans.inverse() (CubeHandler.h:265,320)
     int rc = OP_OK;
     if (ns) {
-        if (nearest) hipLaunchKernelGGL(k_transform_alloc<true>, dim3(ns), dim3(512), 0, dst->stream, src->view(), dst->view(), dst->state, M, dst_res);
-        else hipLaunchKernelGGL(k_transform_alloc<false>, dim3(ns), dim3(512), 0, dst->stream, src->view(), dst->view(), dst->state, M, dst_res);
         unsigned nd = 0;
-        rc = vol_block_count(dst, &nd);
+        for (;;) { // if the result outgrows its pool, vol_block_count grows it and the (idempotent) allocation pass runs again
+            const unsigned cap_before = dst->max_blocks;
+            if (nearest) hipLaunchKernelGGL(k_transform_alloc<true>, dim3(ns), dim3(512), 0, dst->stream, src->view(), dst->view(), dst->state, M, dst_res);
+            else hipLaunchKernelGGL(k_transform_alloc<false>, dim3(ns), dim3(512), 0, dst->stream, src->view(), dst->view(), dst->state, M, dst_res);
+            rc = vol_block_count(dst, &nd);
+            if (rc != OP_OK || dst->max_blocks == cap_before) break;
+        }
         if (rc == OP_OK && nd) {
             if (nearest) hipLaunchKernelGGL(k_transform_fill<true>, dim3(nd), dim3(512), 0, dst->stream, src->view(), dst->view(), Mi, src->res);
             else hipLaunchKernelGGL(k_transform_fill<false>, dim3(nd), dim3(512), 0, dst->stream, src->view(), dst->view(), Mi, src->res);

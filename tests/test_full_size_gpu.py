@@ -28,7 +28,7 @@ def test_config3_1000_frames_bit_equal(oracle, torch_dev):
     n = 1000
     depth, rgb, poses = S.room_sequence_torch(0, n, torch_dev)
     torch.cuda.synchronize()
-    hv = I.CubeHandler(max_blocks=1 << 18)
+    hv = I.CubeHandler()
     hv.SetVoxelResolution(0.005)
     hv.IntegrateSequence(depth, rgb, poses)
     hv.Synchronize()
@@ -109,7 +109,7 @@ def test_config4_2000_frames_tracking_and_fusion_properties(torch_dev):
     import torch
     from onepiece_amd import dense_slam as DS
     n, chunk = 2000, 250
-    vol = I.CubeHandler(max_blocks=1 << 19)
+    vol = I.CubeHandler()                                  # default pool; grows as the trajectory covers the room
     vol.SetVoxelResolution(0.005)
     fused = []
     slam = DS.DenseSlam(I.PinholeCamera("OPEN3D_DATASET"), pipeline=4,

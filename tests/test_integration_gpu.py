@@ -4,6 +4,9 @@ Bar (BASELINE.json north_star): bit-exact voxel-block keys + 64-bit hashes; TSDF
 relative.  In practice the kernels keep the reference's operation order, so voxel values are
 compared for exact equality first and the tolerance is only the documented fallback.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -141,15 +144,50 @@ def test_merge_upload_download(oracle):
     assert hv1.BlockCount() == before
 
 
-def test_pool_capacity_is_reported(oracle):
+def test_volume_grows_like_the_reference_map(oracle):
+    """CubeMap is a std::unordered_map that grows with the scene (CubeHandler.h:22, CubeHandler.cpp:181-190).  A volume
+    created with room for 1024 blocks fuses the 5 mm wall scene (23 706 blocks): the batch that exhausts the pool poisons
+    the stream on the device (nothing is fused from it on), the host grows pool + hash table and replays from that batch --
+    several times here -- and the result is bit-equal to the oracle's: no frame lost, none applied twice."""
     hv = I.CubeHandler(max_blocks=1024)
     hv.SetVoxelResolution(0.005)
-    d, rgb, pose = S.wall_frame(0)
-    from onepiece_amd._lib import OnePieceHipError
-    with pytest.raises(OnePieceHipError) as e:
+    ov = oracle.Volume(voxel_res=0.005)
+    for i in range(5):
+        d, rgb, pose = S.wall_frame(i)
         hv.IntegrateImage(d, rgb, pose)
-        hv.Synchronize()
-    assert e.value.code == 3
+        ov.integrate(d, rgb, pose)
+    _compare(oracle, ov, hv)
+    anchor = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_wall_anchor.json")))
+    assert hv.BlockCount() == anchor["blocks"]
+    st = hv.Stats()
+    assert st["frames"] == 5 and st["voxels_updated"] == int(ov.export()[1][..., 1].sum())
+    # the same through the device-resident sequence path, growth in the middle of a 40-frame call (several batches in flight)
+    import torch
+    dev = torch.device("cuda:0")
+    depth, rgb, poses = S.room_sequence_torch(0, 40, dev)
+    torch.cuda.synchronize()
+    hs = I.CubeHandler(max_blocks=2048); hs.SetVoxelResolution(0.01)
+    hs.IntegrateSequence(depth, rgb, poses)
+    os_ = oracle.Volume(voxel_res=0.01)
+    dn, cn = depth.cpu().numpy(), rgb.cpu().numpy()
+    upd = 0
+    for k in range(40):
+        upd += os_.integrate(dn[k], cn[k], poses[k])[2]
+    _compare(oracle, os_, hs)
+    assert hs.Stats()["voxels_updated"] == upd and hs.Stats()["frames"] == 40
+    # PrepareCubes, AddCubes, Merge and Transform outgrow their pools too
+    hp = I.CubeHandler(max_blocks=512); hp.SetVoxelResolution(0.005)
+    d, rgb, pose = S.wall_frame(0)
+    ids = hp.PrepareCubes(d, pose)
+    ref_ids = oracle.Volume(voxel_res=0.005).prepare_cubes(d, pose)
+    ref_ids = ref_ids[0] if isinstance(ref_ids, tuple) else ref_ids
+    assert np.array_equal(np.asarray(ids[0] if isinstance(ids, tuple) else ids), ref_ids)
+    hm = I.CubeHandler(max_blocks=256); hm.SetVoxelResolution(0.01)
+    hm.Merge(hs)
+    _compare(oracle, os_, hm)
+    hu = I.CubeHandler(max_blocks=256); hu.SetVoxelResolution(0.01)
+    hu.SetCubeMap(*hs.GetCubeMap())
+    _compare(oracle, os_, hu)
 
 
 def test_device_resident_sequence_matches_per_frame(oracle):

@@ -210,14 +210,14 @@ def test_upload_is_ordered_after_queued_frames(oracle):
 
 
 def test_refused_unpack_keeps_the_local_volume(oracle):
-    """op_volume_unpack_sum validates before it clears: a union larger than the root's pool is refused and the locally fused
-    volume survives (the merge can then be retried with a larger volume)."""
+    """op_volume_unpack_sum validates before it clears: a union beyond the per-volume limit (2^24 blocks) or with null
+    buffers is refused and the locally fused volume survives.  (A union that merely exceeds the current pool grows it.)"""
     import ctypes as C
     import torch
     from onepiece_amd import _lib as L
     ov, hv = _pair(oracle, 0.02, frames=(0, 10))
     before_k, before_v = hv.GetCubeMap()
-    too_many = (1 << 16) + 1
+    too_many = (1 << 24) + 1
     keys = torch.zeros((too_many, 3), dtype=torch.int32, device="cuda")
     dummy = torch.zeros((1, 5, 512), dtype=torch.float32, device="cuda")
     rc = L.load().op_volume_unpack_sum(hv._h, C.c_void_p(keys.data_ptr()), too_many, C.c_void_p(dummy.data_ptr()))
