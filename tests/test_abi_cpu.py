@@ -89,15 +89,21 @@ def test_no_gpu_means_loud_failure_not_fallback(hip):
 
 
 def test_product_never_imports_the_oracle():
-    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
-    pkg = os.path.join(ROOT, "onepiece_amd")
-    for dirpath, _d, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
-                text = open(os.path.join(dirpath, f), errors="replace").read()
-                assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), f
-                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
-                assert "libonepiece_oracle" not in text and "dlopen" not in text, f
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/: the package, the C++ class
+    surface (host/), the C-ABI header and the drivers (examples/, tools/) never include, import, link or load it.  The one
+    run-time binding in the product is RCCL (csrc/merge_rccl.hip), and its dlopen names nothing else."""
+    for top in ("onepiece_amd", "host", "include", "examples", "tools"):
+        for dirpath, _d, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".sh")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), f
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                    assert "libonepiece_oracle" not in text and "onepiece_oracle.h" not in text, f
+                    if "dlopen" in text or "CDLL" in text:
+                        assert f in ("merge_rccl.hip", "_lib.py"), f
+                        for name in re.findall(r'"([^"]*\.so[^"]*)"', text):
+                            assert "rccl" in name or "onepiece_hip" in name, (f, name)
 
 
 def test_pixel_rounding_fast_path_equals_double_formula(hip):
