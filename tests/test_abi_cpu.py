@@ -100,7 +100,8 @@ def test_product_never_imports_the_oracle():
                     assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), f
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                     assert "libonepiece_oracle" not in text and "onepiece_oracle.h" not in text, f
-                    if "dlopen" in text or "CDLL" in text:
+                    code = re.sub(r"/\*.*?\*/|//[^\n]*", "", text, flags=re.S) if not f.endswith(".py") else text
+                    if "dlopen(" in code or "CDLL(" in code:
                         assert f in ("merge_rccl.hip", "_lib.py"), f
                         for name in re.findall(r'"([^"]*\.so[^"]*)"', text):
                             assert "rccl" in name or "onepiece_hip" in name, (f, name)

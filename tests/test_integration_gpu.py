@@ -160,7 +160,7 @@ def test_volume_grows_like_the_reference_map(oracle):
     anchor = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_wall_anchor.json")))
     assert hv.BlockCount() == anchor["blocks"]
     st = hv.Stats()
-    assert st["frames"] == 5 and st["voxels_updated"] == int(ov.export()[1][..., 1].sum())
+    assert st["frames"] == 5 and st["voxels_updated"] == int(ov.export()[1][..., 1].astype(np.float64).sum())
     # the same through the device-resident sequence path, growth in the middle of a 40-frame call (several batches in flight)
     import torch
     dev = torch.device("cuda:0")
