@@ -6,7 +6,9 @@
 // frames) and fuses each frame with its TRACKED pose -- the config-4 pipeline, one pair at a time.
 // With "icp": registration::PointToPlane of frame 1's cloud onto frame 0's (LoadFromDepth, EstimateNormals, 30 iterations,
 // threshold 0.01 -- ICPTest.cpp's configuration), `reps` times.
-// Build: hipcc -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o gpurun_out/prof_driver
+// With "host": one op_volume_integrate call per frame with pageable HOST images (float32 and uint16 depth), the
+// reference's call pattern (PCIe-inclusive rate).
+// Build: hipcc -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o tools/prof_driver.bin
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -93,6 +95,28 @@ int main(int argc, char** argv) {
                        ns, nt, dt * 1e3, 30 / dt, (unsigned long long)res.n_inliers, res.rmse);
             }
         op_icp_destroy(icp);
+        op_volume_destroy(v);
+        return 0;
+    }
+    if (argc > 4 && std::string(argv[4]) == "host") {
+        // the reference's own call pattern: one CubeHandler::IntegrateImage(cv::Mat depth, cv::Mat rgb, pose) per frame with
+        // PAGEABLE host images (std::vector storage here, like cv::Mat's), float32 depth and raw uint16 depth
+        std::vector<unsigned short> d16(depth.size());
+        for (size_t i = 0; i < depth.size(); ++i) { const float z = depth[i] * 1000.0f + 0.5f; d16[i] = (unsigned short)(z < 0 ? 0 : (z > 65535 ? 65535 : z)); }
+        for (int r = 0; r < reps; ++r)
+            for (int fmt = 0; fmt < 2; ++fmt) {
+                CK(op_volume_clear(v));
+                auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < n; ++i) {
+                    const void* dp = fmt == 0 ? (const void*)&depth[npx * i] : (const void*)&d16[npx * i];
+                    CK(op_volume_integrate(v, dp, fmt == 0 ? OP_DEPTH_F32 : OP_DEPTH_U16, &rgb[npx * 3 * i], OP_MEM_HOST, &poses[(size_t)i * 16], nullptr));
+                }
+                CK(op_volume_sync(v));
+                double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                size_t nb; CK(op_volume_block_count(v, &nb));
+                printf("rep %d host images, %s depth: %d frames, %.1f frames/s (%.1f us/frame, %.2f GB/s over PCIe), blocks %zu\n", r, fmt == 0 ? "float32" : "uint16", n,
+                       n / dt, dt / n * 1e6, n * (double)npx * (fmt == 0 ? 7 : 5) / dt / 1e9, nb);
+            }
         op_volume_destroy(v);
         return 0;
     }
