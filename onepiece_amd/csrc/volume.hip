@@ -424,7 +424,11 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
             b[c] = v;
         }
         const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        if (tot == 0) {
+        // A batch that ran out of pool / table space poisons the stream: its KC and every later batch do nothing (an empty
+        // candidate range here), so that the host can grow the volume and REPLAY from the failing batch on -- no frame is
+        // ever partially fused (vol_recover).  Read by one thread per workgroup: a per-thread load of this hot line next to
+        // the candidate loop doubled the kernel's time.
+        if (tot == 0 || (st->overflow & 3u)) {
             for (int c = 0; c < 6; ++c) s_range[c] = 0;
         } else {
             for (int c = 0; c < 3; ++c) {
@@ -450,10 +454,6 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
         ncand = 0;
     }
     if (blockIdx.x == 0 && tid == 0) st->n_cand[f] = ncand;
-
-    // A batch that ran out of pool / table space poisons the stream: its KC and every later batch do nothing, so that the
-    // host can grow the volume and REPLAY from the failing batch on -- no frame is ever partially fused (see vol_recover).
-    if (st->overflow & 3u) ncand = 0;
 
     const float cube_res = C.res * 8.0f; // CubeHandler.cpp:164
     const float half = C.res / 2;        // VoxelCube.h:47

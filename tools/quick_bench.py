@@ -7,7 +7,8 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 depth, rgb, poses = S.room_sequence_torch(0, n, dev)
 torch.cuda.synchronize()
-hv = I.CubeHandler(max_blocks=1 << 19); hv.SetVoxelResolution(0.005)
+mb = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # initial pool capacity in blocks (0 = library default; the pool grows on demand)
+hv = I.CubeHandler(max_blocks=mb); hv.SetVoxelResolution(0.005)
 hv.IntegrateSequence(depth[:10], rgb[:10], poses[:10]); hv.Synchronize()
 for rep in range(3):
     hv.Clear()
