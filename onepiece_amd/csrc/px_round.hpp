@@ -61,3 +61,42 @@ OP_HD int px_round_sp(float a, const PxSplit& s) {
     const bool integral = af == s.hm || af == s.h0 || af == s.h1;
     return integral ? fl : fl + 1;
 }
+
+// ---- in-image pixel of one axis (what the kernels use) ----------------------------------------------------------
+// The kernels only ever need the pixel when it lies INSIDE the image (Integrator.cpp:63 rejects everything else), and
+// inside the image the truncation above is a floor except on t in (-1, 0), which truncates to 0:
+//     0 <= trunc(t) <= extent - 1   <=>   -1 < t < extent   <=>   t_lo < a < t_hi,   t_lo = -(c + 1.5), t_hi = extent - c - 0.5
+//     trunc(t) = max(floor(t), 0) there,   floor(t) = trunc(a) + floor(K) - 1 + [af >= h0] + [af >= h1],
+// with K = c + 0.5, kf = K - floor(K), af = a - trunc(a) (exact), h0 = -kf, h1 = 1 - kf.  Two range compares on `a`, two
+// threshold compares on `af`, no integer range tests, no special handling of NaN / inf / huge values (they fail the range
+// compares).  Exact whenever t_lo, t_hi, h0, h1 are representable in fp32 and kf != 0 (then a tiny |a| cannot move the
+// reference's double sum across an integer); px_axis() checks that and callers fall back to the double formula otherwise.
+struct PxAxis {
+    float t_lo, t_hi, h0, h1;
+    int base;  // floor(c + 0.5) - 1
+    int exact;
+};
+
+OP_HD PxAxis px_axis(float c, int extent) {
+    PxAxis s;
+    const double K = (double)c + 0.5, ki = floor(K), kf = K - ki;
+    const double t_lo = -((double)c + 1.5), t_hi = (double)extent - (double)c - 0.5, h0 = -kf, h1 = 1.0 - kf;
+    s.t_lo = (float)t_lo; s.t_hi = (float)t_hi; s.h0 = (float)h0; s.h1 = (float)h1;
+    s.base = (int)ki - 1;
+    s.exact = (double)s.t_lo == t_lo && (double)s.t_hi == t_hi && (double)s.h0 == h0 && (double)s.h1 == h1 && kf != 0.0 &&
+              fabs((double)c) < 1.0e6 && extent > 0 && extent < (1 << 20);
+    return s;
+}
+
+// true + the pixel when it is inside [0, extent), false otherwise
+OP_HD bool px_pixel_sp(float a, const PxAxis& s, int& u) {
+    const float ai = truncf(a);
+    const float af = a - ai; // exact
+    const int fl = (int)ai + s.base + (af >= s.h0) + (af >= s.h1);
+    u = fl < 0 ? 0 : fl;
+    return a > s.t_lo && a < s.t_hi;
+}
+OP_HD bool px_pixel_dp(float a, float c, int extent, int& u) {
+    u = px_round_dp(a, c);
+    return u >= 0 && u < extent;
+}

@@ -85,8 +85,8 @@ constexpr int kCoordLimit = 1 << 20; // |block coordinate| < 2^20 (40 km at 4 cm
 struct CamParams {
     float fx, fy, cx, cy, depth_scale, res, trunc;
     int width, height, depth_u16;
-    PxSplit sx, sy; // exact splits of cx, cy for the fp32 pixel-rounding path
-    int fast_px;    // both splits exact -> use px_round_sp, else the double formula
+    PxAxis ax, ay;  // exact thresholds of the fp32 in-image pixel rounding (px_round.hpp), x and y axis
+    int fast_px;    // both exact -> use px_pixel_sp, else the double formula
 };
 struct PoseFwd { float pose[16]; float planes[24]; }; // planes: top, left, right, bottom, near, far
 struct PoseInv { float m[12]; };                      // rows 0..2 of pose^-1
@@ -140,13 +140,6 @@ __device__ __forceinline__ bool key_in_range(int x, int y, int z) {
 // Eigen's 3-term reduction order a0 + (a1 + a2).
 __device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
 
-// Integrator.cpp:20-21: int u = fx*X/Z + 0.5 + cx (see px_round.hpp for the exact semantics).
-template <bool FAST>
-__device__ __forceinline__ int project_px(float f, float X, float Z, float c, const PxSplit& sp) {
-    const float a = (f * X) / Z;
-    return FAST ? px_round_sp(a, sp) : px_round_dp(a, c);
-}
-
 // The two quotients (fx*X)/Z and (fy*Y)/Z of one projection with ONE reciprocal.  An IEEE float division is, on this
 // hardware, v_div_scale x2, v_rcp, two FMAs refining the reciprocal, mul + three FMAs for the quotient, v_div_fmas,
 // v_div_fixup (11 instructions; the six divisions of a voxel update were 37 % of KC's VALU work).  When v_div_scale does
@@ -166,36 +159,37 @@ __device__ __forceinline__ float div_shared_rcp(float n, float z, float y) {
     r = __builtin_fmaf(-z, q, n);
     return __builtin_fmaf(r, y, q);
 }
+// Pixel index v * width + u of the projection, or -1 when it falls outside the image (Integrator.cpp:20-21,61-63).
 template <bool FAST>
-__device__ __forceinline__ void project_uv(float fx, float fy, float X, float Y, float Z, float cx, float cy, const PxSplit& sx,
-                                           const PxSplit& sy, int& u, int& v) {
-    float nx = fx * X, ny = fy * Y, z = Z;
+__device__ __forceinline__ int project_pixel(const CamParams& C, float X, float Y, float Z) {
+    float nx = C.fx * X, ny = C.fy * Y, z = Z;
     const unsigned ez = (__float_as_uint(Z) >> 23) & 0xffu;    // biased exponent of Z
-    if (!(ez - 67u < 120u)) {                                  // outside 2^-60 <= |Z| < 2^60 (never, for a camera):
-        const float s = ez < 67u ? 0x1p96f : 0x1p-96f;         // rescale all three by an exact power of two, which is
-        z *= s; nx *= s; ny *= s;                              // what v_div_scale does; the quotients are unchanged
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ez - 67u < 120u)) != 0ull, 0)) { // some lane outside 2^-60 <= |Z| < 2^60 (never, for a camera):
+        if (!(ez - 67u < 120u)) {
+            const float sc = ez < 67u ? 0x1p96f : 0x1p-96f;     // rescale all three by an exact power of two, which is
+            z *= sc; nx *= sc; ny *= sc;                        // what v_div_scale does; the quotients are unchanged
+        }
     }
     float y = __builtin_amdgcn_rcpf(z);
     const float e = __builtin_fmaf(-z, y, 1.0f);
     y = __builtin_fmaf(e, y, y);
     const float ax = div_shared_rcp(nx, z, y), ay = div_shared_rcp(ny, z, y);
-    u = FAST ? px_round_sp(ax, sx) : px_round_dp(ax, cx);
-    v = FAST ? px_round_sp(ay, sy) : px_round_dp(ay, cy);
+    int u, v;
+    const bool in_u = FAST ? px_pixel_sp(ax, C.ax, u) : px_pixel_dp(ax, C.cx, C.width, u);
+    const bool in_v = FAST ? px_pixel_sp(ay, C.ay, v) : px_pixel_dp(ay, C.cy, C.height, v);
+    return (in_u && in_v) ? v * C.width + u : -1;
 }
 
 // test hook: both forms of the projection for n operand triples (see op_debug_project_uv)
-__global__ void k_debug_project_uv(float fx, float fy, float cx, float cy, const float* __restrict__ X, const float* __restrict__ Y,
+__global__ void k_debug_project_uv(CamParams C, const float* __restrict__ X, const float* __restrict__ Y,
                                    const float* __restrict__ Z, size_t n, int* __restrict__ out) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PxSplit sx = px_split(cx), sy = px_split(cy);
-    int u, v;
-    if (sx.exact && sy.exact) project_uv<true>(fx, fy, X[i], Y[i], Z[i], cx, cy, sx, sy, u, v);
-    else project_uv<false>(fx, fy, X[i], Y[i], Z[i], cx, cy, sx, sy, u, v);
-    out[4 * i] = u;
-    out[4 * i + 1] = v;
-    out[4 * i + 2] = px_round_dp((fx * X[i]) / Z[i], cx);   // the reference's formula with the plain division
-    out[4 * i + 3] = px_round_dp((fy * Y[i]) / Z[i], cy);
+    const int pix = C.fast_px ? project_pixel<true>(C, X[i], Y[i], Z[i]) : project_pixel<false>(C, X[i], Y[i], Z[i]);
+    out[4 * i] = pix < 0 ? INT_MIN : pix % C.width;
+    out[4 * i + 1] = pix < 0 ? INT_MIN : pix / C.width;
+    out[4 * i + 2] = px_round_dp((C.fx * X[i]) / Z[i], C.cx);   // the reference's formula with the plain division
+    out[4 * i + 3] = px_round_dp((C.fy * Y[i]) / Z[i], C.cy);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -481,10 +475,8 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
                 const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
                 const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
                 const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                int u, v;
-                project_uv<FAST>(C.fx, C.fy, q0, q1, q2, C.cx, C.cy, C.sx, C.sy, u, v);
                 zc[corner] = q2;
-                pix[corner] = (v < 0 || v >= C.height || u < 0 || u >= C.width) ? -1 : v * C.width + u;
+                pix[corner] = project_pixel<FAST>(C, q0, q1, q2);
             }
             float dd[8];
 #pragma unroll
@@ -544,7 +536,22 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
 // All per-frame gathers ({depth, rgba} records) are issued before the first dependent use.
 // Block ownership is exclusive, so the read-modify-write needs no atomics.
 // ---------------------------------------------------------------------------------------------
-template <bool FAST>
+typedef unsigned int kc_v2u __attribute__((ext_vector_type(2)));
+
+// PLAIN: the volume's content has only ever been written by this kernel since it was created / cleared (no upload, merge,
+// resampling or file in between; the host tracks it).  Then every stored voxel is either the default or a running mean
+// of finite in-band observations: weights are integers >= 1, colours are means of byte/255 values (non-negative, so their
+// numerators w*c + n never cancel), and the update can be evaluated
+//   * branch-free: an invalid voxel (TSDFVoxel::IsValid false) is the valid formula with weight 0 --
+//     (0*s + new)/(0 + 1) = new exactly for finite s -- instead of a second code path with five selects;
+//   * with ONE refined reciprocal of wsum shared by the four quotients (the compiler's own v_rcp + FMA sequence, spelled
+//     out as in project_uv): bit-identical to the IEEE division whenever v_div_scale would not rescale, i.e. for
+//     wsum in [1, 2^25] and a numerator that is 0 or >= 2^-100 in magnitude.  Colour numerators are 0 or >= 2^-32
+//     (no cancellation); the sdf numerator CAN cancel to something tiny, so it alone is guarded: a lane whose
+//     |w*s + new| is non-zero and below 2^-100 takes the plain division (never, in practice).
+// Without PLAIN (arbitrary uploaded data: NaN, infinities, denormals, fractional weights) the update is the reference's
+// two-branch form with four true divisions.
+template <bool FAST, bool PLAIN>
 __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                    int n_frames, unsigned long long* __restrict__ upd_partial,
                                                    unsigned long long* __restrict__ sel_partial) {
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
     const int vid = threadIdx.x;
     if (vid < 256) s_c255[vid] = (float)vid / 255.0f;
     __syncthreads();
-    const size_t npix = (size_t)C.width * C.height;
+    const unsigned npix = (unsigned)(C.width * C.height);
     const float half = C.res / 2;
     // VoxelCentroidOffSet[vid] (VoxelCube.h:48-61): x*res + half with x = vid & 7 etc.
     const float ox = (float)(vid & 7) * C.res + half;
@@ -565,6 +572,11 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
     const float __attribute__((address_space(4)))* kargs =
         (const float __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)B;
+    // The per-frame {depth, rgba} gathers go through a buffer resource over the frame's packed image (built from scalars
+    // per frame: the range check of a raw buffer covers voffset + soffset, so the frame cannot be a scalar offset into one
+    // resource): the lane offset is a 32-bit byte offset, and a lane whose projection falls outside the image asks for
+    // offset -8, beyond num_records, which the hardware answers with zeros (depth 0 = "no observation") -- no exec-mask
+    // branch around the load and no 64-bit address arithmetic in vector registers.
     unsigned upd = 0, sel = 0;
     // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): XCD x walks
     // the x-th contiguous eighth of the list, so list neighbours -- blocks along one viewing ray,
@@ -600,12 +612,12 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
 #pragma unroll
         for (int h = 0; h < kMaxBatch; h += KC_SUB) {
             if (((mask >> h) & ((1u << KC_SUB) - 1u)) == 0u) continue; // wave-uniform
-            uint2 rec[KC_SUB];
+            kc_v2u rec[KC_SUB];
             float zc[KC_SUB];
 #pragma unroll
             for (int g = 0; g < KC_SUB; ++g) {
                 const int f = h + g;
-                rec[g] = make_uint2(0u, 0u);
+                rec[g] = kc_v2u{0u, 0u};
                 zc[g] = 0.0f;
                 if ((mask >> f) & 1u) { // wave-uniform
                     // pose^-1 of frame f, fetched with scalar loads from the kernarg segment right here:
@@ -616,12 +628,12 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                     const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
                     const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
                     const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                    int u, v;
-                    project_uv<FAST>(C.fx, C.fy, q0, q1, q2, C.cx, C.cy, C.sx, C.sy, u, v);
                     zc[g] = q2;
-                    // uniform 64-bit frame base + 32-bit per-lane pixel offset (saddr addressing, no 64-bit VALU math)
-                    const uint2* __restrict__ fimg = pimg + (size_t)f * npix;
-                    if (!(v < 0 || v >= C.height || u < 0 || u >= C.width)) rec[g] = fimg[(unsigned)(v * C.width + u)];
+                    // off-image (Integrator.cpp:63: v < 0 || v >= height || u < 0 || u >= width) is pixel -1 = an offset the
+                    // buffer rejects
+                    const int pix = project_pixel<FAST>(C, q0, q1, q2);
+                    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc((void*)(pimg + (size_t)f * npix), 0, (int)(npix * 8u), 0x00020000);
+                    rec[g] = __builtin_amdgcn_raw_buffer_load_b64(frame, pix * 8, 0, 0);
                 }
             }
 #pragma unroll
@@ -635,7 +647,23 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                             changed = true;
                             const unsigned rgba = rec[g].y;
                             const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
-                            if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
+                            if (PLAIN) {
+                                // TSDFVoxel::IsValid (TSDFVoxel.h:75-78) false -> weight 0 in the same formula (see the header comment)
+                                const float wv = (s >= 1 || w <= 0) ? 0.0f : w;
+                                const float wsum = wv + 1.0f;
+                                float y = __builtin_amdgcn_rcpf(wsum);
+                                const float e = __builtin_fmaf(-wsum, y, 1.0f);
+                                y = __builtin_fmaf(e, y, y);
+                                const float ns = wv * s + 1.0f * new_sdf;
+                                const float m0 = wv * c0 + 1.0f * n0, m1 = wv * c1 + 1.0f * n1, m2 = wv * c2 + 1.0f * n2;
+                                float qs = div_shared_rcp(ns, wsum, y);
+                                if (!(fabsf(ns) >= 0x1p-100f) && ns != 0.0f) qs = ns / wsum; // a cancelled sdf numerator: plain division
+                                s = qs;
+                                c0 = div_shared_rcp(m0, wsum, y);
+                                c1 = div_shared_rcp(m1, wsum, y);
+                                c2 = div_shared_rcp(m2, wsum, y);
+                                w = wsum;
+                            } else if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
                                 // TSDFVoxel::operator+ with other = (new_sdf, 1.0, c) (TSDFVoxel.h:24-39)
                                 const float wsum = w + 1.0f;
                                 s = (w * s + 1.0f * new_sdf) / wsum;
@@ -1182,6 +1210,9 @@ struct op_volume {
     unsigned* hstat = nullptr;   // pinned + mapped: [0] = last batch known complete, [1] = n_blocks at that time
     unsigned* hstat_dev = nullptr;
     bool recovering = false;     // vol_recover is replaying: no nested growth checks
+    // true while every voxel was written by k_integrate only since create / clear (see k_integrate<., PLAIN>): any other
+    // writer (upload, merge, sum-form unpack, resampling result, file) clears it and fusion takes the general update
+    bool plain = true;
     bool grow_refused = false;   // an early growth could not get memory: stop asking before every batch (a real overflow still tries)
     // frames accepted by op_volume_integrate but not launched yet: single-frame calls are queued
     // and fused in batches of kMaxBatch (every accessor flushes first, so this is unobservable)
@@ -1389,8 +1420,8 @@ CamParams cam_params(const op_volume* v, int depth_fmt) {
     C.fx = v->cam.fx; C.fy = v->cam.fy; C.cx = v->cam.cx; C.cy = v->cam.cy;
     C.depth_scale = v->cam.depth_scale; C.res = v->res; C.trunc = v->trunc;
     C.width = v->cam.width; C.height = v->cam.height; C.depth_u16 = depth_fmt == OP_DEPTH_U16;
-    C.sx = px_split(C.cx); C.sy = px_split(C.cy);
-    C.fast_px = C.sx.exact && C.sy.exact;
+    C.ax = px_axis(C.cx, C.width); C.ay = px_axis(C.cy, C.height);
+    C.fast_px = C.ax.exact && C.ay.exact;
     return C;
 }
 
@@ -1463,12 +1494,13 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (sample) OP_HIP(hipEventRecord(ev[2], v->stream));
     if (select_only)
         hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, (const State*)v->state);
-    else if (C.fast_px)
-        hipLaunchKernelGGL(k_integrate<true>, dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, v->state, nf,
-                           v->upd_partial, v->sel_partial);
-    else
-        hipLaunchKernelGGL(k_integrate<false>, dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, v->state, nf,
-                           v->upd_partial, v->sel_partial);
+    else {
+#define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV>), dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
+                                                 v->state, nf, v->upd_partial, v->sel_partial)
+        if (C.fast_px) { if (v->plain) OP_KC(true, true); else OP_KC(true, false); }
+        else { if (v->plain) OP_KC(false, true); else OP_KC(false, false); }
+#undef OP_KC
+    }
     if (sample) {
         OP_HIP(hipEventRecord(ev[3], v->stream));
         for (auto e : ev) v->prof_events.push_back(e);
@@ -1691,7 +1723,11 @@ int op_debug_project_uv(float fx, float fy, float cx, float cy, const float* X, 
     if (e == hipSuccess) e = hipMemcpy(d_in + n, Y, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_in + 2 * n, Z, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_project_uv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fx, fy, cx, cy, (const float*)d_in,
+        CamParams C{};
+        C.fx = fx; C.fy = fy; C.cx = cx; C.cy = cy; C.width = 640; C.height = 480;
+        C.ax = px_axis(cx, C.width); C.ay = px_axis(cy, C.height);
+        C.fast_px = C.ax.exact && C.ay.exact;
+        hipLaunchKernelGGL(k_debug_project_uv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, C, (const float*)d_in,
                            (const float*)(d_in + n), (const float*)(d_in + 2 * n), n, d_out);
         e = hipMemcpy(out, d_out, 4 * n * sizeof(int), hipMemcpyDeviceToHost);
     }
@@ -1810,6 +1846,7 @@ int op_volume_clear(op_volume* v) {
     if (v->copy_stream) OP_HIP(hipStreamSynchronize(v->copy_stream));
     OP_HIP(hipStreamSynchronize(v->stream));
     v->log.clear(); // whatever was in flight (fused or poisoned) is wiped with the volume
+    v->plain = true;
     for (auto& r : v->ring) r.busy_seq = 0;
     if (v->hstat) v->hstat[1] = 0;
     OP_HIP(hipMemcpy(&n, v->n_blocks, sizeof(n), hipMemcpyDeviceToHost));
@@ -2075,6 +2112,7 @@ int op_volume_upload(op_volume* v, const int32_t* keys_xyz, const float* voxels_
         OP_TRY(vol_block_count(v, &nb));
         OP_TRY(vol_reserve(v, (unsigned long long)nb + uniq.size()));
     }
+    v->plain = false; // caller-supplied voxel data from here on
     const size_t chunk = 8192;
     int *d_keys = nullptr, *d_slots = nullptr;
     float* d_vox = nullptr;
@@ -2117,6 +2155,7 @@ int op_volume_merge(op_volume* dst, op_volume* src) {
     OP_TRY(vol_block_count(dst, &nd));
     if (!ns) return OP_OK;
     OP_TRY(vol_reserve(dst, (unsigned long long)nd + ns)); // worst case: no block in common
+    dst->plain = false; // merged means: general weights from here on
     int* d_slots = nullptr;
     OP_HIP(hipMalloc((void**)&d_slots, (size_t)ns * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((ns + 255) / 256), dim3(256), 0, dst->stream, dst->view(), (const int*)src->keys, (size_t)ns, d_slots, dst->state);
@@ -2156,6 +2195,7 @@ int op_volume_unpack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_uni
     OP_TRY(vol_reserve(v, n_union)); // grows the root's pool if the union needs it; a refusal leaves the volume as it was
     OP_TRY(op_volume_clear(v));
     if (n_union == 0) return OP_OK;
+    v->plain = false; // normalised sums of several ranks
     int* d_slots = nullptr;
     OP_HIP(hipMalloc((void**)&d_slots, n_union * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, d_slots, v->state);
@@ -2178,6 +2218,7 @@ int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, i
     if (max_blocks == 0) max_blocks = std::max<uint64_t>(8ull * ns + 4096ull, 1ull << 14);
     op_volume* dst = nullptr;
     OP_TRY(op_volume_create(&src->cam, dst_res, src->trunc, src->far_d, src->near_d, src->device, max_blocks, &dst));
+    dst->plain = false; // resampled values (the reference's own divisions may even leave NaN / inf in them)
     Mat4 M, Mi;
     std::memcpy(M.m, T, sizeof(M.m));
     if (T_inv) std::memcpy(Mi.m, T_inv, sizeof(Mi.m));

@@ -163,6 +163,65 @@ def test_pixel_rounding_fast_path_equals_double_formula(hip):
     assert lib.op_debug_project_px(-0.6, 0.0, 1) == 0 == lib.op_debug_project_px(-0.6, 0.0, 0)   # (-1,0) truncates to 0
 
 
+def test_in_image_pixel_rounding_equals_double_formula(hip):
+    """csrc/px_round.hpp px_pixel_sp -- what k_select / k_integrate use: "is the pixel inside the image, and which one" from
+    two range compares on a = f*X/Z and two threshold compares on its fraction.  Against the reference's double formula
+    (Integrator.cpp:20-21 + the bounds test of :63) on 5e7 values: every bit pattern class, pixel-scale values, values within
+    a few ulp of every rounding threshold and of both image borders, for the presets' principal points, random ones and
+    ragged image sizes; principal points whose thresholds are not exact in fp32 must be refused (the kernels then take the
+    double formula)."""
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent(r'''
+        #include <cstdio>
+        #include <cstdint>
+        #include <cstring>
+        #include "px_round.hpp"
+        int main() {
+            const float cs[10] = {318.771f, 238.447f, 318.6f, 255.3f, 79.69275f, 59.61175f, 756.24762f, 530.00418f, 1.25f, 0.0f};
+            const int ext[10] = {640, 480, 640, 480, 160, 120, 1440, 1080, 3, 1};
+            uint32_t st = 2463534242u; long bad = 0, n = 0, refused = 0;
+            auto rnd = [&]() { st ^= st << 13; st ^= st >> 17; st ^= st << 5; return st; };
+            if (px_axis(318.5f, 640).exact || px_axis(0.3f, 640).exact || px_axis(3.0e6f, 640).exact) { printf("inexact thresholds must be refused\n"); return 2; }
+            for (int rep = 0; rep < 3; ++rep)
+            for (int k = 0; k < 10; ++k) {
+                float c = cs[k]; int extent = ext[k];
+                if (rep == 1) { c = 1.0f + (float)(rnd() >> 8) * (2000.0f / 16777216.0f); extent = 1 + (int)(rnd() % 4000u); }
+                if (rep == 2) { c = (float)(int)(rnd() % 2000u) + 0.25f * (float)(rnd() % 4u) + 0.125f; extent = 1 + (int)(rnd() % 4000u); }
+                const PxAxis ax = px_axis(c, extent);
+                if (!ax.exact) { ++refused; continue; }
+                for (long it = 0; it < 1700000; ++it) {
+                    float a; const int mode = it % 8;
+                    if (mode < 2) { uint32_t b = rnd(); memcpy(&a, &b, 4); }                                   // any bit pattern
+                    else if (mode < 5) { a = ((int)(rnd() >> 8) % 6000000 - 3000000) / 1000.0f; a += (float)(rnd() >> 9) * 1.1920929e-10f; }
+                    else {                                                                                      // around thresholds / borders
+                        const int kk = (int)(rnd() >> 18) % (extent + 40) - 20;
+                        const double K = (double)c + 0.5;
+                        double tgt = mode == 5 ? (double)kk - K : (mode == 6 ? -1.0 - K + (rnd() & 1) * (double)(extent + 1) : (double)kk - K + 1.0e-6 * ((int)(rnd() % 5u) - 2));
+                        float base = (float)tgt; int32_t bi; memcpy(&bi, &base, 4); bi += (int)(rnd() >> 28) - 8; memcpy(&a, &bi, 4);
+                    }
+                    int u = -7;
+                    const bool in_sp = px_pixel_sp(a, ax, u);
+                    const int r = px_round_dp(a, c);
+                    const bool in_dp = r >= 0 && r < extent;
+                    ++n;
+                    if (in_sp != in_dp || (in_dp && u != r)) { if (bad < 5) printf("c=%.9g extent=%d a=%.9g dp=%d sp=%d/%d\n", c, extent, a, r, (int)in_sp, u); ++bad; }
+                }
+            }
+            printf("%ld %ld %ld\n", n, refused, bad);
+            return bad != 0;
+        }
+    ''')
+    with tempfile.TemporaryDirectory() as td:
+        cpp = os.path.join(td, "t.cpp")
+        open(cpp, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "onepiece_amd", "csrc"), cpp, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout
+        n, refused, bad = map(int, out.stdout.split()[-3:])
+        assert bad == 0 and n >= 30 * 1700000 - refused * 1700000 and n > 3.0e7
+
+
 def test_tracker_host_math_matches_eigen_golden(hip):
     """op_track_projection (K*R*K^-1, K*t) bit-exact and op_ldlt_solve6 within float rounding of Eigen's
     ldlt().solve() -- the host/device-shared arithmetic of csrc/odometry.hip, checked without a GPU."""

@@ -458,20 +458,21 @@ def test_projection_with_shared_reciprocal_equals_plain_division():
         L.check(lib.op_debug_project_uv(float(fx), float(fy), float(cx), float(cy), vp(X), vp(Y), vp(Z), len(X), 0, vp(out)))
         return out
 
-    def agree(out, limit=1 << 16):
-        inside = lambda a: (a >= 0) & (a < limit)
-        for k in (0, 1):
-            f, r = out[:, k], out[:, 2 + k]
-            bad = (f != r) & (inside(f) | inside(r))
-            assert not bad.any(), (k, np.flatnonzero(bad)[:5], f[bad][:5], r[bad][:5])
-        return inside(out[:, 2]).mean()
+    def agree(out, limits=(640, 480)):
+        # the kernels' projection reports the pixel only when BOTH coordinates are inside the (640 x 480) image, INT_MIN
+        # otherwise; the reference formula's pair is inside exactly then, and equal
+        r_in = (out[:, 2] >= 0) & (out[:, 2] < limits[0]) & (out[:, 3] >= 0) & (out[:, 3] < limits[1])
+        f_in = out[:, 0] != np.iinfo(np.int32).min
+        bad = (r_in != f_in) | (r_in & ((out[:, 0] != out[:, 2]) | (out[:, 1] != out[:, 3])))
+        assert not bad.any(), (np.flatnonzero(bad)[:5], out[bad][:5])
+        return r_in.mean()
 
     n = 1 << 21
     sign = lambda m: np.where(rng.random(m) < 0.5, -1.0, 1.0)
     # 1. camera-like operands: Z in [0.05, 20] m, X / Y within a few field-of-views
     Z = rng.uniform(0.05, 20.0, n) * np.where(rng.random(n) < 0.1, -1.0, 1.0)
     frac = agree(run(rng.uniform(-2, 2, n) * np.abs(Z), rng.uniform(-2, 2, n) * np.abs(Z), Z))
-    assert frac > 0.2
+    assert frac > 0.05
     # 2. log-uniform magnitudes across and beyond the fast window, every sign
     Z = sign(n) * np.exp2(rng.uniform(-80, 80, n))
     agree(run(sign(n) * np.exp2(rng.uniform(-149, 120, n)), sign(n) * np.exp2(rng.uniform(-149, 120, n)), Z))

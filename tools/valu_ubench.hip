@@ -1,0 +1,74 @@
+// valu_ubench.hip -- issue cost of the VALU operations k_integrate is made of, measured on the device it runs on.
+// One wave per SIMD (grid = CUs x 4 waves of 64 threads, 256-thread workgroups), each running a long unrolled chain of
+// INDEPENDENT instances of one operation (8 accumulators, so dependent-issue latency is hidden); s_memtime around the
+// loop gives shader cycles per wave-instruction.  With 2 or 4 waves per SIMD the figure per SIMD stays the same when the
+// operation is issue-bound.  Output: cycles per wave64 instruction.
+//   hipcc --offload-arch=gfx950 -O2 tools/valu_ubench.hip -o tools/valu_ubench.bin && tools/valu_ubench.bin
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#define REP4(x) x x x x
+#define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
+#define REP64(x) REP16(x) REP16(x) REP16(x) REP16(x)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* cyc, float a, float b) {
+    float x0 = a + threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    float2 p0 = make_float2(x0, x1), p1 = make_float2(x2, x3), p2 = make_float2(x4, x5), p3 = make_float2(x6, x7), pb = make_float2(b, b);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 64; ++it) {
+        if (OP == 0) { REP16(asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 1) { REP16(asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x0) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x1) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x2) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 2) { REP16(asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p3) : "v"(pb));) }
+        if (OP == 3) { REP16(asm volatile("v_rcp_f32 %0, %0" : "+v"(x0)); asm volatile("v_rcp_f32 %0, %0" : "+v"(x1)); asm volatile("v_rcp_f32 %0, %0" : "+v"(x2)); asm volatile("v_rcp_f32 %0, %0" : "+v"(x3));) }
+        if (OP == 4) { REP16(asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(x0) : "v"(b) : "vcc"); asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(x1) : "v"(b) : "vcc"); asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(x2) : "v"(b) : "vcc"); asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(x3) : "v"(b) : "vcc");) }
+        if (OP == 5) { REP16(asm volatile("v_div_fmas_f32 %0, %0, %1, %1" : "+v"(x0) : "v"(b) : "vcc"); asm volatile("v_div_fmas_f32 %0, %0, %1, %1" : "+v"(x1) : "v"(b) : "vcc"); asm volatile("v_div_fmas_f32 %0, %0, %1, %1" : "+v"(x2) : "v"(b) : "vcc"); asm volatile("v_div_fmas_f32 %0, %0, %1, %1" : "+v"(x3) : "v"(b) : "vcc");) }
+        if (OP == 6) { REP16(asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(x0) : "v"(b)); asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(x1) : "v"(b)); asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(x2) : "v"(b)); asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 7) { REP16(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(b) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x1) : "v"(b)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x2) : "v"(b)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x3) : "v"(b));) }
+        if (OP == 8) { REP16(asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x0), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x1), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x2), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x3), "v"(b) : "vcc");) }
+        if (OP == 9) { REP16(asm volatile("v_mov_b32 %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_mov_b32 %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_mov_b32 %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_mov_b32 %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 10) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p3) : "v"(pb));) }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int OP>
+void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, int cus) {
+    const int wgs = cus * waves_per_simd; // 256 threads = 4 waves = one wave per SIMD of a CU (per resident workgroup)
+    hipLaunchKernelGGL(k_bench<OP>, dim3(wgs), dim3(256), 0, 0, d_out, d_cyc, 1.0f, 1.0000001f);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> c((size_t)wgs * 4);
+    hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost);
+    double s = 0;
+    for (auto v : c) s += (double)v;
+    const double per = s / c.size() / (64.0 * 64.0); // 64 iterations x 64 instructions per wave
+    std::printf("%-18s waves/SIMD %d: %.2f s_memtime ticks per wave-instruction -> %.2f per SIMD-issue slot\n", name, waves_per_simd, per, per / waves_per_simd);
+}
+
+int main() {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    std::printf("%s, %d CUs, clock %d kHz; s_memtime ticks at a constant 100 MHz on gfx9 -- ratios between rows are what matter\n", p.gcnArchName, cus, p.clockRate);
+    float* d_out; unsigned long long* d_cyc;
+    hipMalloc((void**)&d_out, (size_t)cus * 8 * 256 * 4);
+    hipMalloc((void**)&d_cyc, (size_t)cus * 8 * 4 * 8);
+    for (int w : {1, 2, 4}) {
+        run<0>("v_mul_f32", w, d_out, d_cyc, cus);
+        run<1>("v_fma_f32", w, d_out, d_cyc, cus);
+        run<2>("v_pk_mul_f32", w, d_out, d_cyc, cus);
+        run<10>("v_pk_fma_f32", w, d_out, d_cyc, cus);
+        run<3>("v_rcp_f32", w, d_out, d_cyc, cus);
+        run<4>("v_div_scale_f32", w, d_out, d_cyc, cus);
+        run<5>("v_div_fmas_f32", w, d_out, d_cyc, cus);
+        run<6>("v_div_fixup_f32", w, d_out, d_cyc, cus);
+        run<7>("v_cndmask_b32", w, d_out, d_cyc, cus);
+        run<8>("v_cmp_lt_f32", w, d_out, d_cyc, cus);
+        run<9>("v_mov_b32", w, d_out, d_cyc, cus);
+    }
+    return 0;
+}
