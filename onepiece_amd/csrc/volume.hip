@@ -66,19 +66,19 @@ constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 
 #define KB_GRID 512
 #endif
 constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
-// KC grid: 512-thread workgroups that draw blocks of the batch's list from per-XCD counters (see k_integrate); 768 is
-// what is resident at the kernel's 76 VGPRs (3 workgroups of 8 waves per CU).  Must be a multiple of 8 (XCDs).
+// KC grid: 512-thread workgroups that draw blocks of the batch's list from per-XCD counters (see k_integrate); 1024 is
+// what is resident at the kernel's <= 64 VGPRs (4 workgroups of 8 waves per CU).  Must be a multiple of 8 (XCDs).
 #ifndef KC_GRID
-#define KC_GRID 768
+#define KC_GRID 1024
 #endif
 static_assert(KC_GRID % 8 == 0 && KC_GRID >= 8, "one drawing workgroup per XCD slab at least");
 constexpr int kIntegrateGrid = KC_GRID;
 constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
 #ifndef KC_SUB
-#define KC_SUB 16 // frames whose gathers are in flight together inside k_integrate (divides kMaxBatch)
+#define KC_SUB 8 // frames whose gathers are in flight together inside k_integrate (divides kMaxBatch)
 #endif
 #ifndef KC_MIN_WAVES
-#define KC_MIN_WAVES 6 // waves per SIMD the integrate kernel is compiled for: 3 workgroups of 8 waves per CU = KC_GRID
+#define KC_MIN_WAVES 8 // waves per SIMD the integrate kernel is compiled for: 4 workgroups of 8 waves per CU = KC_GRID
 #endif
 constexpr int kCoordLimit = 1 << 20; // |block coordinate| < 2^20 (40 km at 4 cm blocks)
 
@@ -177,7 +177,7 @@ __device__ __forceinline__ int project_pixel(const CamParams& C, float X, float 
     int u, v;
     const bool in_u = FAST ? px_pixel_sp(ax, C.ax, u) : px_pixel_dp(ax, C.cx, C.width, u);
     const bool in_v = FAST ? px_pixel_sp(ay, C.ay, v) : px_pixel_dp(ay, C.cy, C.height, v);
-    return (in_u && in_v) ? v * C.width + u : -1;
+    return (in_u && in_v) ? (int)__umul24((unsigned)v, (unsigned)C.width) + u : -1; // both factors < 2^20: one full-rate 24-bit multiply
 }
 
 // test hook: both forms of the projection for n operand triples (see op_debug_project_uv)
@@ -620,11 +620,14 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                 rec[g] = kc_v2u{0u, 0u};
                 zc[g] = 0.0f;
                 if ((mask >> f) & 1u) { // wave-uniform
-                    // pose^-1 of frame f, fetched with scalar loads from the kernarg segment right here:
-                    // keeping all 16 matrices (192 SGPRs) live across the block loop makes the compiler
-                    // spill SGPRs through v_writelane/v_readlane (15 % of the instruction stream).
-                    const float __attribute__((address_space(4)))* M = kargs + f * 12;
-                    asm volatile("" : "+s"(M));
+                    // pose^-1 of frame f, fetched with scalar loads from the kernarg segment right here: keeping all 16
+                    // matrices (192 SGPRs) live across the block loop makes the compiler spill SGPRs through
+                    // v_writelane / v_readlane.  The frame index is made opaque first, so that the per-frame ADDRESSES (pose
+                    // row pointer, buffer resource of the frame's image: 6 SGPRs x 16 frames) are recomputed with three
+                    // scalar instructions where they are used instead of being hoisted out of the block loop and spilled.
+                    int fo = f;
+                    asm volatile("" : "+s"(fo));
+                    const float __attribute__((address_space(4)))* M = kargs + fo * 12;
                     const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
                     const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
                     const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                     // off-image (Integrator.cpp:63: v < 0 || v >= height || u < 0 || u >= width) is pixel -1 = an offset the
                     // buffer rejects
                     const int pix = project_pixel<FAST>(C, q0, q1, q2);
-                    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc((void*)(pimg + (size_t)f * npix), 0, (int)(npix * 8u), 0x00020000);
+                    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pimg + (unsigned)fo * (npix * 8u)), 0, (int)(npix * 8u), 0x00020000);
                     rec[g] = __builtin_amdgcn_raw_buffer_load_b64(frame, pix * 8, 0, 0);
                 }
             }

@@ -55,7 +55,7 @@ def main():
     src, needle, extra = args[0], args[1], args[2:]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                                "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)] + extra, stderr=subprocess.DEVNULL)
         lines = open(out).read().splitlines()
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*%s\S*:" % re.escape(needle), l))
