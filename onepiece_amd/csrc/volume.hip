@@ -643,10 +643,11 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
             for (int g = 0; g < KC_SUB; ++g) {
                 if ((mask >> (h + g)) & 1u) {
                     const float d = __uint_as_float(rec[g].x); // off-image pixels carry d == 0 -> skipped like `continue`
-                    if (d > 0) {
-                        const float new_sdf = d - zc[g];
-                        if (fabsf(new_sdf) < C.trunc) {
-                            ++upd;
+                    const float new_sdf = d - zc[g];
+                    const bool hit = d > 0 && fabsf(new_sdf) < C.trunc; // Integrator.cpp:70,74 as ONE divergent region
+                    upd += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(hit));  // counted per wave on the scalar unit
+                    {
+                        if (hit) {
                             changed = true;
                             const unsigned rgba = rec[g].y;
                             const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
@@ -660,7 +661,12 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                                 const float ns = wv * s + 1.0f * new_sdf;
                                 const float m0 = wv * c0 + 1.0f * n0, m1 = wv * c1 + 1.0f * n1, m2 = wv * c2 + 1.0f * n2;
                                 float qs = div_shared_rcp(ns, wsum, y);
-                                if (!(fabsf(ns) >= 0x1p-100f) && ns != 0.0f) qs = ns / wsum; // a cancelled sdf numerator: plain division
+                                // a cancelled sdf numerator below 2^-100 (never, in practice): the plain division -- behind a
+                                // wave-uniform branch, or the compiler evaluates its 11 instructions on every frame and selects
+                                const bool tiny = !(fabsf(ns) >= 0x1p-100f) && ns != 0.0f;
+                                if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0ull, 0)) {
+                                    if (tiny) qs = ns / wsum;
+                                }
                                 s = qs;
                                 c0 = div_shared_rcp(m0, wsum, y);
                                 c1 = div_shared_rcp(m1, wsum, y);
@@ -690,8 +696,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
         j = s_next[slot];
     }
     // per-workgroup counters (each workgroup owns its slot: no atomics)
-    upd = wave_sum(upd);
-    if ((vid & 63) == 0) s_upd[vid >> 6] = upd;
+    if ((vid & 63) == 0) s_upd[vid >> 6] = upd; // `upd` is already the wave's total (ballot counts)
     __syncthreads();
     if (vid == 0) {
         unsigned t = 0;
