@@ -54,9 +54,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="only the warm-up and the timed region (for rocprofv3 --kernel-trace --stats runs: "
+                    "every k_integrate launch in the trace then has the timed region's batch shape)")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic / roofline.valu (~30 s)")
     ap.add_argument("--profile-every", type=int, default=1, help="HIP-event sample rate for the roofline (every k-th launch group)")
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_icp = args.no_tracking = args.no_counters = True
 
     import torch
     import torch.distributed as dist
@@ -177,6 +181,7 @@ def main():
                                  "exceed 1); `traffic` is the HBM traffic the PMC counters saw per launch, `batch1` is the same byte model where it IS "
                                  "a bound (one frame per launch), `valu` says what actually limits the batched kernel"},
         }
+    if rank == 0 and not args.timed_only:
         # -- the byte model where it is a roofline: one frame per launch (every voxel read + written once per frame)
         hv.Clear(); hv.ProfileEnable(1)
         nb1 = min(64, n_local)
@@ -232,7 +237,7 @@ def main():
     # images into the pinned staging ring (caller thread + 2 helper threads), the DMA runs on a copy stream and overlaps the
     # previous batch's kernels, frames are fused 16 per launch group.  (From C++ -- tools/prof_driver.cpp "host" -- the same
     # loop reaches ~13 k frames/s; here the Python interpreter sits in the loop.)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.timed_only:
         nh = min(300, n_local)
         dn, cn = depth[:nh].cpu().numpy(), rgb[:nh].cpu().numpy()
         d16h = np.clip(np.round(dn * 1000.0), 0, 65535).astype(np.uint16)
@@ -256,7 +261,7 @@ def main():
     # ---- the same K steps behind the drivers' depth front end (tool::ConvertDepthTo32F + tool::BilateralFilter,
     # ImageSequenceIntegration.cpp:36-38) from raw 16-bit depth, filter enqueued on the volume's stream.  Supplementary:
     # the filter is OpenCV's in the reference (unpinned), so the headline `value` above stays without it.
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.timed_only:
         from onepiece_amd import tool as T
         d16 = (depth * 1000.0).round().clamp(0, 65535).to(torch.uint16)
         fbuf = torch.empty_like(depth)

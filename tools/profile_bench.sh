@@ -6,6 +6,6 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-icp --no-tracking > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python $R/bench.py --timed-only > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 find /tmp/prof_bench -name '*kernel_stats.csv' -exec cp {} $OUT/bench_kernel_stats.csv \;
 tail -2 $OUT/bench_under_rocprof.err
