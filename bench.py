@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank fuses K x F frames; strong: the K x F frames are split over the ranks (BASELINE configs[4] as "
+                         "written: `--scaling strong --steps 80` = 8000 frames in total at any N)")
     ap.add_argument("--timed-only", action="store_true", help="only the warm-up and the timed region (for rocprofv3 --kernel-trace --stats runs: "
                     "every k_integrate launch in the trace then has the timed region's batch shape)")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic / roofline.valu (~30 s)")
@@ -79,7 +82,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ONEPIECE_BENCH_FORCE_DIST=1: run the whole distributed path (process group over RCCL, key all_gather, sliced reduce,
+    # normalisation) even with ONE rank -- how the RCCL merge is exercised on a single-GPU box.
+    force_dist = os.environ.get("ONEPIECE_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ["ONEPIECE_MERGE_FORCE"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ONEPIECE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -90,6 +99,10 @@ def main():
     from onepiece_amd import integration as I, synthetic as S, distributed as D
 
     K, Wm, F = args.steps, args.warmup, args.frames_per_step
+    if args.scaling == "strong":
+        if F % world:
+            raise SystemExit("--scaling strong needs --frames-per-step (%d) divisible by the number of GPUs (%d)" % (F, world))
+        F //= world     # the step's frames are split: the job fuses K x frames_per_step frames in total at any N
     n_local = K * F
     first = rank * n_local  # contiguous shard of the global sequence
     # ---- inputs: generated straight into HBM, not timed
@@ -111,7 +124,7 @@ def main():
         s = (w % K) * F
         hv.IntegrateSequence(depth[s:s + F], rgb[s:s + F], poses[s:s + F])
     hv.Synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         D.merge_volumes(ops, root=0)
     hv.Clear()
     hv.ProfileEnable(args.profile_every)
@@ -126,7 +139,7 @@ def main():
     t_fuse = time.perf_counter() - t0
     stats = hv.Stats()  # per-rank counters, read before the merge rewrites the root volume
     n_union = None
-    if world > 1:
+    if world > 1 or force_dist:
         n_union = D.merge_volumes(ops, root=0)
     barrier()
     dt = time.perf_counter() - t0
@@ -157,7 +170,7 @@ def main():
             "warmup": Wm,
             "ms_per_step": dt_max / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -496,7 +509,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

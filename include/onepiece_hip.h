@@ -198,6 +198,11 @@ int op_volume_keys_device(op_volume *v, int32_t *d_keys, size_t cap, size_t *n);
 int op_volume_pack_sum(op_volume *v, const int32_t *d_union_keys, size_t n_union, float *d_out);
 int op_volume_unpack_sum(op_volume *v, const int32_t *d_union_keys, size_t n_union,
                          const float *d_sum);
+/* The same in slices, so that the reduce of later slices overlaps the normalisation of earlier ones: _begin enters the
+ * union keys (growing the pool if needed; the volume's own content is dropped only after validation), _chunk writes
+ * union blocks [first, first + count) from a buffer holding just those (count x 5 x 512 floats). */
+int op_volume_unpack_sum_begin(op_volume *v, const int32_t *d_union_keys, size_t n_union);
+int op_volume_unpack_sum_chunk(op_volume *v, size_t first, size_t count, const float *d_sum_chunk);
 /* The whole merge as ONE call for a C/C++ host: all-gather of the per-rank block keys over RCCL, the
  * identical sorted union on every rank, sum-form pack, ONE ncclReduce(float32, sum) to `root`, normalisation on the
  * root -- i.e. CubeHandler::Merge (CubeHandler.h:145-167) across the ranks of a communicator.  nccl_comm is an

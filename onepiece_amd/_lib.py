@@ -106,6 +106,8 @@ SIGNATURES = {
     "op_volume_keys_device": (C.c_int, [_vp, _vp, C.c_size_t, _szp]),
     "op_volume_pack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "op_volume_unpack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "op_volume_unpack_sum_begin": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "op_volume_unpack_sum_chunk": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp]),
     "op_volume_merge_rccl": (C.c_int, [_vp, _vp, C.c_int, _szp]),
     "op_icp_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]),
     "op_icp_destroy": (C.c_int, [_vp]),

@@ -1221,6 +1221,8 @@ struct op_volume {
     // true while every voxel was written by k_integrate only since create / clear (see k_integrate<., PLAIN>): any other
     // writer (upload, merge, sum-form unpack, resampling result, file) clears it and fusion takes the general update
     bool plain = true;
+    int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
+    size_t unpack_n = 0;
     bool grow_refused = false;   // an early growth could not get memory: stop asking before every batch (a real overflow still tries)
     // frames accepted by op_volume_integrate but not launched yet: single-frame calls are queued
     // and fused in batches of kMaxBatch (every accessor flushes first, so this is unobservable)
@@ -1797,7 +1799,7 @@ int op_volume_destroy(op_volume* v) {
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
-                    v->partial, v->pimg, v->upd_partial, v->sel_partial, v->img_depth, v->img_rgb};
+                    v->partial, v->pimg, v->upd_partial, v->sel_partial, v->img_depth, v->img_rgb, v->unpack_slots};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
@@ -2195,23 +2197,41 @@ int op_volume_pack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_union
     return OP_OK;
 }
 
-int op_volume_unpack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_union, const float* d_sum) {
+// The root's side of the merge in two steps, so that a caller can normalise slices of the union while later slices are
+// still in the reduce: _begin validates, makes room (the pool grows if the union needs it), drops the volume's own
+// content and enters all union keys; _chunk writes the normalised voxels of union blocks [first, first + count).
+int op_volume_unpack_sum_begin(op_volume* v, const int32_t* d_union_keys, size_t n_union) {
     OP_VOL(v);
     // validate BEFORE the volume's own content is dropped: a refused unpack must leave the locally fused volume intact
-    if (n_union && (!d_union_keys || !d_sum)) return fail(OP_ERR_INVALID, "null argument");
+    if (n_union && !d_union_keys) return fail(OP_ERR_INVALID, "null argument");
     OP_TRY(vol_check(v));
     OP_TRY(vol_reserve(v, n_union)); // grows the root's pool if the union needs it; a refusal leaves the volume as it was
     OP_TRY(op_volume_clear(v));
+    if (v->unpack_slots) { OP_HIP(hipFree(v->unpack_slots)); v->unpack_slots = nullptr; }
+    v->unpack_n = n_union;
     if (n_union == 0) return OP_OK;
     v->plain = false; // normalised sums of several ranks
-    int* d_slots = nullptr;
-    OP_HIP(hipMalloc((void**)&d_slots, n_union * sizeof(int)));
-    hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, d_slots, v->state);
-    hipLaunchKernelGGL(k_unpack_sum, dim3((unsigned)n_union), dim3(512), 0, v->stream, v->pool, (const int*)d_slots, (const int*)v->tvals, d_sum);
-    hipError_t e = hipStreamSynchronize(v->stream);
-    (void)hipFree(d_slots);
-    if (e != hipSuccess) return fail(OP_ERR_HIP, "unpack failed: %s", hipGetErrorString(e));
+    OP_HIP(hipMalloc((void**)&v->unpack_slots, n_union * sizeof(int)));
+    hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, v->unpack_slots, v->state);
+    OP_HIP(hipGetLastError());
     return vol_check(v);
+}
+
+int op_volume_unpack_sum_chunk(op_volume* v, size_t first, size_t count, const float* d_sum_chunk) {
+    OP_VOL(v);
+    if (count == 0) return OP_OK;
+    if (!d_sum_chunk) return fail(OP_ERR_INVALID, "null argument");
+    if (!v->unpack_slots || first + count > v->unpack_n) return fail(OP_ERR_INVALID, "op_volume_unpack_sum_chunk: range outside the union given to _begin");
+    hipLaunchKernelGGL(k_unpack_sum, dim3((unsigned)count), dim3(512), 0, v->stream, v->pool, (const int*)(v->unpack_slots + first), (const int*)v->tvals, d_sum_chunk);
+    OP_HIP(hipGetLastError());
+    OP_HIP(hipStreamSynchronize(v->stream));
+    return OP_OK;
+}
+
+int op_volume_unpack_sum(op_volume* v, const int32_t* d_union_keys, size_t n_union, const float* d_sum) {
+    if (v && n_union && !d_sum) return fail(OP_ERR_INVALID, "null argument");
+    OP_TRY(op_volume_unpack_sum_begin(v, d_union_keys, n_union));
+    return op_volume_unpack_sum_chunk(v, 0, n_union, d_sum);
 }
 
 int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, int nearest, uint64_t max_blocks, op_volume** out) {

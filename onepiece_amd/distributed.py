@@ -60,16 +60,31 @@ class HipVolumeOps:
         n = union_keys.shape[0]
         L.check(L.load().op_volume_unpack_sum(self.h._h, C.c_void_p(union_keys.data_ptr()), n, C.c_void_p(summed.data_ptr())))
 
+    def unpack_begin(self, union_keys):
+        L.check(L.load().op_volume_unpack_sum_begin(self.h._h, C.c_void_p(union_keys.data_ptr()), union_keys.shape[0]))
 
-def merge_volumes(ops, root=0, group=None):
+    def unpack_chunk(self, first, summed_chunk):
+        L.check(L.load().op_volume_unpack_sum_chunk(self.h._h, first, summed_chunk.shape[0], C.c_void_p(summed_chunk.data_ptr())))
+
+
+def _forced():
+    import os
+    return os.environ.get("ONEPIECE_MERGE_FORCE") == "1"
+
+
+def merge_volumes(ops, root=0, group=None, chunk_blocks=32768):
     """Merge every rank's volume into `root`'s.  Returns the number of union blocks.
 
-    Works with world_size == 1 (no-op apart from the pack/normalise round trip being skipped).
+    The one reduce is issued in slices of `chunk_blocks` union blocks (320 MB each): while slice i is on the wire (RCCL's
+    own stream), slice i+1 is packed on the volume's stream and slice i-1 is normalised on the root -- the device steps
+    (~1 ms per GB) hide behind the transfer (~6 ms per GB over xGMI's point-to-point links).
+    With world_size == 1 there is nothing to merge (ONEPIECE_MERGE_FORCE=1 runs the exchange anyway: a one-rank
+    all_gather + reduce, which is how the RCCL path is exercised on a single-GPU box).
     """
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _forced()):
         return int(ops.keys().shape[0])
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -100,17 +115,45 @@ def merge_volumes(ops, root=0, group=None):
     n_union = int(union.shape[0])
     if n_union == 0:
         return 0
-    # 3.-4. sum-form pack, one reduce to the root.  `union` was produced by torch ops queued on torch's stream,
-    # k_pack_sum runs on the volume's own stream: make the keys final before the kernel reads them.
-    if union.is_cuda:
-        torch.cuda.current_stream(union.device).synchronize()
-    packed = ops.pack_sum(union).contiguous()
-    dist.reduce(packed, dst=root, op=dist.ReduceOp.SUM, group=group)
-    if packed.is_cuda:
-        # the collective is ordered on torch's stream; the volume's kernels run on the volume's own
-        # stream, so finish the reduce before handing the buffer to k_unpack_sum
-        torch.cuda.current_stream(packed.device).synchronize()
-    # 5. normalise on the root
-    if rank == root:
-        ops.unpack_sum(union, packed)
+    # `union` was produced by torch ops queued on torch's stream, the pack / unpack kernels run on the volume's own
+    # stream: make the keys final before those kernels read them.
+    sync = (lambda: torch.cuda.current_stream(union.device).synchronize()) if union.is_cuda else (lambda: None)
+    sync()
+    is_root = rank == root
+    chunk_blocks = max(1, int(chunk_blocks))
+    spans = [(lo, min(lo + chunk_blocks, n_union)) for lo in range(0, n_union, chunk_blocks)]
+    chunked = hasattr(ops, "unpack_begin") and len(spans) > 1
+    if not chunked:
+        # 3.-5. sum-form pack, one reduce to the root, normalise on the root
+        packed = ops.pack_sum(union).contiguous()
+        dist.reduce(packed, dst=root, op=dist.ReduceOp.SUM, group=group)
+        sync()  # the collective is ordered on torch's stream; the volume's kernels run on the volume's own stream
+        if is_root:
+            ops.unpack_sum(union, packed)
+        return n_union
+    # 3.-5. pipelined over slices of the union
+    return _merge_pipelined(ops, dist, union, spans, root, group, is_root, sync)
+
+
+def _merge_pipelined(ops, dist, union, spans, root, group, is_root, sync):
+    n_union = int(union.shape[0])
+    # The root's volume is both a source (its blocks are summed like everybody's) and the destination.  Its slices are
+    # therefore ALL packed before the first one is normalised into it: pack(i) happens at step i, unpack(i) at step
+    # i + 2 at the earliest, and unpack_begin (which clears the volume) only after the last pack.
+    bufs = [None] * len(spans)
+    works = [None] * len(spans)
+    for i, (lo, hi) in enumerate(spans):
+        bufs[i] = ops.pack_sum(union[lo:hi]).contiguous()
+        works[i] = dist.reduce(bufs[i], dst=root, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        if not is_root and i >= 2:                   # non-root ranks only need their send buffers until the slice is through
+            works[i - 2].wait(); sync(); bufs[i - 2] = None
+    if is_root:
+        ops.unpack_begin(union)
+    for i, (lo, hi) in enumerate(spans):
+        if works[i] is not None:
+            works[i].wait()
+            sync()
+        if is_root:
+            ops.unpack_chunk(lo, bufs[i])
+        bufs[i] = None
     return n_union

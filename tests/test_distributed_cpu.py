@@ -65,8 +65,38 @@ class OracleVolumeOps:
         self.vol.clear()
         self.vol.load(union_keys.numpy().astype(np.int32), vox)
 
+    # the sliced form (op_volume_unpack_sum_begin / _chunk)
+    def unpack_begin(self, union_keys):
+        self._union = union_keys.numpy().astype(np.int32)
+        self.vol.clear()
 
-def _worker(rank, world, port, outdir):
+    def unpack_chunk(self, first, summed_chunk):
+        keep, self.vol = self.vol, _Appender(self.vol)
+        try:
+            self.unpack_sum_into(self._union[first:first + summed_chunk.shape[0]], summed_chunk)
+        finally:
+            self.vol = keep
+
+    def unpack_sum_into(self, keys, summed):
+        import torch
+        tmp = OracleVolumeOps(self.vol)
+        tmp.unpack_sum(torch.from_numpy(keys), summed)
+
+
+class _Appender:
+    """Lets unpack_sum's clear() + load() append a slice instead of replacing the volume."""
+
+    def __init__(self, vol):
+        self._vol = vol
+
+    def clear(self):
+        pass
+
+    def load(self, keys, vox):
+        self._vol.load(keys, vox)
+
+
+def _worker(rank, world, port, outdir, chunk_blocks=32768):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -86,7 +116,7 @@ def _worker(rank, world, port, outdir):
         vol.integrate(d, c, pose)
     k, v = vol.export()
     np.savez(os.path.join(outdir, "shard%d.npz" % rank), k=k, v=v)
-    n_union = D.merge_volumes(OracleVolumeOps(vol), root=0)
+    n_union = D.merge_volumes(OracleVolumeOps(vol), root=0, chunk_blocks=chunk_blocks)
     if rank == 0:
         k, v = vol.export()
         np.savez(os.path.join(outdir, "merged.npz"), k=k, v=v, n_union=n_union)
@@ -125,6 +155,33 @@ def test_two_rank_gloo_merge_equals_reference_merge(oracle, tmp_path):
     # both shards really contributed and really overlapped
     k0 = {tuple(r) for r in s0["k"].tolist()}; k1 = {tuple(r) for r in s1["k"].tolist()}
     assert k0 - k1 and k1 - k0 and k0 & k1
+
+
+def test_four_rank_gloo_sliced_merge_equals_sequential_merge_chain(oracle, tmp_path):
+    """World size 4, the reduce issued in slices of 64 union blocks (pack / reduce / normalise pipelined, the root's volume
+    being source AND destination): rank 0's merged volume equals CubeHandler::Merge applied shard after shard -- keys and
+    weights exactly, sdf / colour to fp32 summation order."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(4, port, str(tmp_path), 64), nprocs=4, join=True)
+    from helpers import small_camera
+    cam = oracle.make_camera(*small_camera(4))
+    vols = []
+    for r in range(4):
+        sh = np.load(tmp_path / ("shard%d.npz" % r))
+        v = oracle.Volume(cam, voxel_res=0.02)
+        if len(sh["k"]):
+            v.load(sh["k"], sh["v"])
+        vols.append(v)
+    for v in vols[1:]:
+        assert vols[0].merge(v) == 0
+    rk, rv = vols[0].export()
+    m = np.load(tmp_path / "merged.npz")
+    assert int(m["n_union"]) == len(rk) > 3 * 64        # several slices were in flight
+    assert np.array_equal(m["k"], rk) and np.array_equal(m["v"][:, :, 1], rv[:, :, 1])
+    seen = rv[:, :, 1] > 0
+    assert np.abs(m["v"][:, :, 0] - rv[:, :, 0])[seen].max() <= 1e-4 * 0.1 and np.abs(m["v"][:, :, 2:] - rv[:, :, 2:])[seen].max() <= 1e-4
+    assert np.array_equal(m["v"][~seen], rv[~seen])
 
 
 def test_frame_prefetcher_yields_in_order(tmp_path):

@@ -292,6 +292,42 @@ def test_bench_multi_rank_flow_on_one_gpu(oracle, tmp_path):
     assert r["per_frame"]["final_blocks_rank0"] == r["merge_union_blocks"]
 
 
+def test_bench_distributed_path_over_rccl_with_one_rank(tmp_path):
+    """The WHOLE distributed path of bench.py on real RCCL (backend "nccl"): process group, all_gather of counts and keys,
+    the reduce issued in slices, normalisation on the root -- with the one rank a single-GPU box can host
+    (ONEPIECE_BENCH_FORCE_DIST=1; two ranks on one device are refused by RCCL).  The merged volume keeps every block."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ONEPIECE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--frames-per-step", "40", "--no-icp", "--no-tracking", "--no-cpu-baseline", "--no-counters"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["value"] > 0
+    assert r["merge_union_blocks"] == r["per_frame"]["final_blocks_rank0"] > 40000     # > 32768: two slices went through the reduce
+
+
+def test_bench_strong_scaling_four_ranks_on_one_gpu(tmp_path):
+    """bench.py --gpus 4 --scaling strong (BASELINE configs[4]'s shape: the total is fixed, each rank fuses a quarter) with
+    all ranks on cuda:0 over gloo: the job's frame count does not depend on N and rank 0 ends up with the union."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ONEPIECE_BENCH_SINGLE_DEVICE="1", ONEPIECE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--frames-per-step", "40", "--scaling", "strong", "--no-icp", "--no-tracking"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 4 and r["scaling"] == "strong" and r["config"]["frames_per_gpu"] == 20
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] - 80) < 1e-6            # 2 x 40 frames in total
+    assert r["per_frame"]["final_blocks_rank0"] == r["merge_union_blocks"]
+
+
 def test_survey_reference_run_anchor_on_the_gpu():
     """The HIP path against committed data only (no live oracle): the statistics the survey recorded from
     the REFERENCE ITSELF on the 5-frame wall scene (tests/golden/survey_wall_anchor.json)."""
