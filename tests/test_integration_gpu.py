@@ -307,7 +307,7 @@ def test_bench_distributed_path_over_rccl_with_one_rank(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 1 and r["value"] > 0
-    assert r["merge_union_blocks"] == r["per_frame"]["final_blocks_rank0"] > 40000     # > 32768: two slices went through the reduce
+    assert r["merge_union_blocks"] == r["per_frame"]["final_blocks_rank0"] > 32768     # more than one slice went through the reduce
 
 
 def test_bench_strong_scaling_four_ranks_on_one_gpu(tmp_path):
