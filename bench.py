@@ -350,8 +350,16 @@ def main():
         t = time.perf_counter()
         L.check(lib.op_icp_run(h, 1, fp(T0), iters, C.byref(res), None, 0, None, None))
         gpu_it_s = iters / (time.perf_counter() - t)
+        # the same call with the order-free fp64 finish: what is left is the iteration loop itself (the default finish --
+        # the reference's sequential float32 Kabsch over ~3e5 pairs on one host thread -- is ~0.8 ms per CALL, not per iteration)
+        L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_FINISH, L.OP_ICP_FINISH_FP64))
+        res64 = L.IcpResult()
+        t = time.perf_counter()
+        L.check(lib.op_icp_run(h, 1, fp(T0), iters, C.byref(res64), None, 0, None, None))
+        loop_it_s = iters / (time.perf_counter() - t)
         lib.op_icp_destroy(h)
-        out["icp"] = {"iters_per_s": gpu_it_s, "points": int(len(src)), "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31)",
+        out["icp"] = {"iters_per_s": gpu_it_s, "loop_only_iters_per_s": loop_it_s, "iterations_per_call": iters, "points": int(len(src)),
+                      "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31)",
                       "final_inliers": int(res.n_inliers), "estimate_normals_s": normals_s,
                       # 36 B per source point per iteration (source + matched target + normal); the kernel is
                       # a latency-bound gather (27-cell scan), so this is far from the HBM roof by construction
