@@ -342,6 +342,16 @@ typedef struct {
 
 int op_tracker_create(int device, op_tracker **out);
 int op_tracker_destroy(op_tracker *t);
+/* OP_TRACK_OPT_SUMS: how an iteration's normal equations are summed (DenseOdometryFunction.cpp:297-381).
+ *   OP_TRACK_SUMS_FP64 (default): fp64 reduction on the device, the whole coarse-to-fine loop without a host round trip.
+ *   OP_TRACK_SUMS_REFERENCE_F32: VALIDATION mode -- association, acceptance and Jacobian rows come from the kernels, but
+ *     every iteration's rows go to the host and are summed on one thread in raster order in float32 exactly like the
+ *     reference's loop, followed by the LDL^T solve / exp / pose update on the host (slow: a 17 MB transfer per
+ *     full-resolution iteration).  With it a run follows the CPU path step for step. */
+#define OP_TRACK_OPT_SUMS 0
+#define OP_TRACK_SUMS_FP64 0
+#define OP_TRACK_SUMS_REFERENCE_F32 1
+int op_tracker_set_option(op_tracker *t, int option, int value);
 /* Odometry::MultiScaleComputing + the result assembly of DenseTracking (Odometry.cpp:621-687,
  * :600-607).  iters_per_level[l] = iter_count_per_level[l] (Odometry.h:170, default {4,8,16});
  * levels are visited n_levels-1 .. 0.  full_width/full_height = camera.GetWidth()/GetHeight(), the

@@ -45,6 +45,7 @@ class TrackResult(C.Structure):
 
 
 OP_TRACK_HYBRID, OP_TRACK_PHOTO, OP_TRACK_DEPTH = 0, 1, 2
+OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_FP64, OP_TRACK_SUMS_REFERENCE_F32 = 0, 0, 1
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
@@ -129,6 +130,7 @@ SIGNATURES = {
     "op_points_from_depth": (C.c_int, [C.POINTER(Camera), _vp, C.c_int, C.c_int, C.c_int, _vp, _szp]),
     "op_tracker_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "op_tracker_destroy": (C.c_int, [_vp]),
+    "op_tracker_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "op_tracker_track": (C.c_int, [_vp, C.POINTER(TrackLevel), C.c_int, _ip, C.c_int, C.c_int, C.c_int, _fp,
                                    C.c_int, C.POINTER(TrackResult), _vp, _vp, C.c_size_t, _vp, _vp]),
     "op_tracker_correspondences": (C.c_int, [_vp, C.POINTER(TrackLevel), _fp, C.c_int, _vp, C.c_size_t, _szp]),

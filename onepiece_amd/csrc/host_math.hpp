@@ -494,6 +494,64 @@ OP_HD void ldlt_solve6(const double JTJ[36], const double JTr[6], float x[6]) {
             if (perm[i] == j) x[j] = static_cast<float>(y[i]);
 }
 
+// ---- validation mode of the dense tracker (OP_TRACK_SUMS_REFERENCE_F32) ---------------------------------------------
+// The reference's accumulation (DenseOdometryFunction.cpp:297-381): for every correspondence in raster order of the source
+// pixel, and for each of its Jacobian rows, `JTJ.noalias() += J * J^T; JTr += J * r` in float32 -- one rounded product and
+// one rounded add per entry, sequentially.  rows: 14 floats per SOURCE PIXEL ({J0[6], r0, J1[6], r1}), pair_t[s] >= 0 marks
+// the accepted pixels, rows_per_pixel = 2 for the hybrid term.
+inline void track_sums_reference_order(const float* rows, const int* pair_t, size_t npix, int rows_per_pixel, float JTJ[36], float JTr[6], size_t* n_pairs) {
+    for (int k = 0; k < 36; ++k) JTJ[k] = 0.0f;
+    for (int k = 0; k < 6; ++k) JTr[k] = 0.0f;
+    size_t n = 0;
+    for (size_t s = 0; s < npix; ++s) {
+        if (pair_t[s] < 0) continue;
+        ++n;
+        for (int m = 0; m < rows_per_pixel; ++m) {
+            const float* J = rows + 14 * s + 7 * m;
+            const float r = J[6];
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) JTJ[a * 6 + b] += J[a] * J[b];
+                JTr[a] += J[a] * r;
+            }
+        }
+    }
+    *n_pairs = n;
+}
+
+// x = JTJ.ldlt().solve(-JTr) (DenseOdometryFunction.cpp:404) from the float32 sums: symmetric-pivoted LDL^T in double, the
+// textbook loop (largest remaining diagonal first, zero pivots give zero components as Eigen's pseudo-inverse of D does).
+// The validation mode uses this form -- one fixed sequence of operations on the host -- rather than the register-resident
+// variants above, so that identical sums give an identical step.
+inline void ldlt_solve6_float_sums(const float JTJ[36], const float JTr[6], float x[6]) {
+    double A[36], b[6], y[6];
+    int perm[6];
+    for (int i = 0; i < 6; ++i) {
+        perm[i] = i; b[i] = -static_cast<double>(JTr[i]);
+        for (int j = 0; j < 6; ++j) A[i * 6 + j] = 0.5 * (static_cast<double>(JTJ[i * 6 + j]) + static_cast<double>(JTJ[j * 6 + i]));
+    }
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 6; ++i) if (fabs(A[i * 7]) > fabs(A[p * 7])) p = i;
+        if (p != k) {
+            for (int j = 0; j < 6; ++j) { const double t = A[k * 6 + j]; A[k * 6 + j] = A[p * 6 + j]; A[p * 6 + j] = t; }
+            for (int j = 0; j < 6; ++j) { const double t = A[j * 6 + k]; A[j * 6 + k] = A[j * 6 + p]; A[j * 6 + p] = t; }
+            const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+            const double tb = b[k]; b[k] = b[p]; b[p] = tb;
+        }
+        const double d = A[k * 7];
+        if (d == 0) continue;
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = A[i * 6 + k] / d;
+            for (int j = k + 1; j < 6; ++j) A[i * 6 + j] -= l * A[k * 6 + j];
+            A[i * 6 + k] = l;
+        }
+    }
+    for (int i = 0; i < 6; ++i) { double acc = b[i]; for (int j = 0; j < i; ++j) acc -= A[i * 6 + j] * y[j]; y[i] = acc; }
+    for (int i = 0; i < 6; ++i) y[i] = A[i * 7] != 0 ? y[i] / A[i * 7] : 0.0;
+    for (int i = 5; i >= 0; --i) { double acc = y[i]; for (int j = i + 1; j < 6; ++j) acc -= A[j * 6 + i] * y[j]; y[i] = acc; }
+    for (int i = 0; i < 6; ++i) x[perm[i]] = static_cast<float>(y[i]);
+}
+
 inline uint64_t hash_key(int32_t x, int32_t y, int32_t z) { // Geometry/Geometry.h:101-112
     return (static_cast<uint64_t>(static_cast<int64_t>(x)) * 73856093ULL) ^
            (static_cast<uint64_t>(static_cast<int64_t>(y)) * 19349663ULL) ^

@@ -133,6 +133,93 @@ __global__ __launch_bounds__(kThreads) void k_track_assoc(const TrackState* __re
 // instead of ~1 us per dependent L2/HBM gather).  Links that leave the window fall back to global.
 constexpr int kIterThreads = 1024;
 
+// Jacobian rows + residuals of one correspondence (source pixel s, target pixel t) at pose T (rows 0..2 of the 4x4):
+// DenseOdometryFunction.cpp:146-296, float, in the reference's operation order.  TERM 0 hybrid (photometric row, then
+// geometric row, each scaled by sqrt(0.5)), 1 photometric, 2 geometric.  Returns the row count.
+template <int TERM>
+__device__ __forceinline__ int track_rows_dev(const LevelDev& L, const float* T12, int s, int t, float J[2][6], float r[2]) {
+    const int i = s / L.w, j = s - i * L.w;
+    // source_XYZ[v_s][u_s] (Geometry.cpp:84-100)
+    const float z = L.sd[s];
+    float p0 = -1.0f, p1 = -1.0f, p2 = -1.0f;
+    if (z > 0) { p0 = ((float)j - L.cx) * z / L.fx; p1 = ((float)i - L.cy) * z / L.fy; p2 = z; }
+    const float q0 = sum3(T12[0] * p0, T12[1] * p1, T12[2] * p2) + T12[3];
+    const float q1 = sum3(T12[4] * p0, T12[5] * p1, T12[6] * p2) + T12[7];
+    const float q2 = sum3(T12[8] * p0, T12[9] * p1, T12[10] * p2) + T12[11];
+    const float invz = (float)(1.0 / (double)q2);
+    const float sq_img = (float)0.70710678118654757, sq_dep = (float)0.70710678118654757; // sqrt(1-0.5), sqrt(0.5)
+    int rows = 0;
+    if (TERM == 0 || TERM == 1) { // photometric row (:146-193 / :262-283)
+        const float diff = L.tc[t] - L.sc[s];
+        const float dIdx = 0.125f * L.tcdx[t], dIdy = 0.125f * L.tcdy[t]; // SOBEL_SCALE
+        const float c0 = dIdx * L.fx * invz, c1 = dIdy * L.fy * invz;
+        const float c2 = -(c0 * q0 + c1 * q1) * invz;
+        const float jr[6] = {c0, c1, c2, -q2 * c1 + q1 * c2, q2 * c0 - q0 * c2, -q1 * c0 + q0 * c1};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_img * jr[k] : jr[k];
+        r[rows] = TERM == 0 ? sq_img * diff : diff;
+        ++rows;
+    }
+    if (TERM == 0 || TERM == 2) { // geometric row (:194-241 / :284-294)
+        float dDdx = 0.125f * L.tddx[t], dDdy = 0.125f * L.tddy[t];
+        if (isnan(dDdx)) dDdx = 0.0f;
+        if (isnan(dDdy)) dDdy = 0.0f;
+        const float diff = L.td[t] - q2;
+        const float d0 = dDdx * L.fx * invz, d1 = dDdy * L.fy * invz;
+        const float d2 = -(d0 * q0 + d1 * q1) * invz;
+        const float jr[6] = {d0, d1, d2 - 1.0f, (-q2 * d1 + q1 * d2) - q1, (q2 * d0 - q0 * d2) + q0, -q1 * d0 + q0 * d1};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_dep * jr[k] : jr[k];
+        r[rows] = TERM == 0 ? sq_dep * diff : diff;
+        ++rows;
+    }
+    return rows;
+}
+
+// Validation mode (OP_TRACK_SUMS_REFERENCE_F32): the rows of every accepted pixel, written per source pixel
+// ({J0[6], r0, J1[6], r1} = 14 floats) so that the host can sum them in raster order in float32, as the reference's
+// sequential loop does (DenseOdometryFunction.cpp:297-381).
+template <int TERM>
+__global__ __launch_bounds__(kThreads) void k_track_rows(const TrackState* __restrict__ st, int l, const int* __restrict__ pair_t,
+                                                         float* __restrict__ rows) {
+    __shared__ float s_T[12];
+    const LevelDev L = st->lv[l];
+    if (threadIdx.x < 12) s_T[threadIdx.x] = st->T[threadIdx.x];
+    __syncthreads();
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= L.w * L.h) return;
+    const int t = pair_t[s];
+    if (t < 0) return;
+    float J[2][6], r[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        r[m] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[m][k] = 0.0f;
+    }
+    track_rows_dev<TERM>(L, s_T, s, t, J, r);
+    float* o = rows + (size_t)s * 14;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[7 * m + k] = J[m][k];
+        o[7 * m + 6] = r[m];
+    }
+}
+
+// The bookkeeping of k_track_solve for a pose computed on the host (validation mode).
+struct PoseArg { float m[16]; };
+__global__ void k_track_apply(TrackState* __restrict__ st, int l, int it, PoseArg T, unsigned long long n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < 16; ++i) st->T[i] = T.m[i];
+    st->n_last = n;
+    st->last_level = l;
+    st->iters_done = st->iters_done + 1;
+    st->per_iter_count[it] = (int)n;
+    for (int i = 0; i < 16; ++i) st->per_iter_T[16 * it + i] = T.m[i];
+    if ((double)((float)n / (float)(st->full_h * st->full_w)) > 0.9) st->stop_level = l;
+}
+
 template <int TERM>
 __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* __restrict__ st, int l, int win_cap,
                                                              const int* __restrict__ pair_p, const unsigned short* __restrict__ code,
@@ -218,44 +305,7 @@ __global__ __launch_bounds__(kIterThreads) void k_track_iter(const TrackState* _
 #pragma unroll
             for (int k = 0; k < 6; ++k) J[m][k] = 0.0f;
         }
-        if (accepted) {
-            const int t = pair_p[s];
-            const int i = s / L.w, j = s - i * L.w;
-            // source_XYZ[v_s][u_s] (Geometry.cpp:84-100)
-            const float z = L.sd[s];
-            float p0 = -1.0f, p1 = -1.0f, p2 = -1.0f;
-            if (z > 0) { p0 = ((float)j - L.cx) * z / L.fx; p1 = ((float)i - L.cy) * z / L.fy; p2 = z; }
-            const float q0 = sum3(s_T[0] * p0, s_T[1] * p1, s_T[2] * p2) + s_T[3];
-            const float q1 = sum3(s_T[4] * p0, s_T[5] * p1, s_T[6] * p2) + s_T[7];
-            const float q2 = sum3(s_T[8] * p0, s_T[9] * p1, s_T[10] * p2) + s_T[11];
-            const float invz = (float)(1.0 / (double)q2);
-            const float sq_img = (float)0.70710678118654757, sq_dep = (float)0.70710678118654757; // sqrt(1-0.5), sqrt(0.5)
-            int rows = 0;
-            if (TERM == 0 || TERM == 1) { // photometric row (:146-193 / :262-283)
-                const float diff = L.tc[t] - L.sc[s];
-                const float dIdx = 0.125f * L.tcdx[t], dIdy = 0.125f * L.tcdy[t]; // SOBEL_SCALE
-                const float c0 = dIdx * L.fx * invz, c1 = dIdy * L.fy * invz;
-                const float c2 = -(c0 * q0 + c1 * q1) * invz;
-                const float jr[6] = {c0, c1, c2, -q2 * c1 + q1 * c2, q2 * c0 - q0 * c2, -q1 * c0 + q0 * c1};
-#pragma unroll
-                for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_img * jr[k] : jr[k];
-                r[rows] = TERM == 0 ? sq_img * diff : diff;
-                ++rows;
-            }
-            if (TERM == 0 || TERM == 2) { // geometric row (:194-241 / :284-294)
-                float dDdx = 0.125f * L.tddx[t], dDdy = 0.125f * L.tddy[t];
-                if (isnan(dDdx)) dDdx = 0.0f;
-                if (isnan(dDdy)) dDdy = 0.0f;
-                const float diff = L.td[t] - q2;
-                const float d0 = dDdx * L.fx * invz, d1 = dDdy * L.fy * invz;
-                const float d2 = -(d0 * q0 + d1 * q1) * invz;
-                const float jr[6] = {d0, d1, d2 - 1.0f, (-q2 * d1 + q1 * d2) - q1, (q2 * d0 - q0 * d2) + q0, -q1 * d0 + q0 * d1};
-#pragma unroll
-                for (int k = 0; k < 6; ++k) J[rows][k] = TERM == 0 ? sq_dep * jr[k] : jr[k];
-                r[rows] = TERM == 0 ? sq_dep * diff : diff;
-                ++rows;
-            }
-        }
+        if (accepted) track_rows_dev<TERM>(L, s_T, s, pair_p[s], J, r);
         // sum k of the pixel: float products as the reference forms them, summed in double ([0..20] upper triangle of
         // J^T J row by row, [21..26] J^T r, [27] r^2, [28] count).  A row that does not exist is all zero.
         auto val = [&](auto kc) -> double {
@@ -586,6 +636,11 @@ struct op_tracker {
     int* pair_t = nullptr;           // per source pixel: accepted target pixel index or -1
     unsigned short* code = nullptr;  // per source pixel: acceptance link code
     int lds_cap = 0;                 // dynamic LDS bytes available to one k_track_iter workgroup
+    int sums = OP_TRACK_SUMS_FP64;   // OP_TRACK_OPT_SUMS
+    float* rows_dev = nullptr;       // validation mode: 14 floats per source pixel
+    float* rows_host = nullptr;      // pinned
+    int* pair_host = nullptr;        // pinned
+    size_t rows_cap = 0;             // pixels
     int lds_total = 0, lds_static = 0, n_cu = 256;
     double* partials = nullptr;
     unsigned* wg_count = nullptr;
@@ -693,10 +748,19 @@ int op_tracker_create(int device, op_tracker** out) {
     return OP_OK;
 }
 
+int op_tracker_set_option(op_tracker* t, int option, int value) {
+    if (!t) return fail(OP_ERR_INVALID, "null tracker");
+    if (option == OP_TRACK_OPT_SUMS && (value == OP_TRACK_SUMS_FP64 || value == OP_TRACK_SUMS_REFERENCE_F32)) { t->sums = value; return OP_OK; }
+    return fail(OP_ERR_INVALID, "op_tracker_set_option: unknown option %d / value %d", option, value);
+}
+
 int op_tracker_destroy(op_tracker* t) {
     if (!t) return OP_OK;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
+    (void)hipFree(t->rows_dev);
+    if (t->rows_host) (void)hipHostFree(t->rows_host);
+    if (t->pair_host) (void)hipHostFree(t->pair_host);
     (void)hipFree(t->pair_t); (void)hipFree(t->pair_p); (void)hipFree(t->code); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
     (void)hipFree(t->images); (void)hipFree(t->st); (void)hipFree(t->raw_rgb); (void)hipFree(t->raw_depth); (void)hipFree(t->pyr); (void)hipFree(t->norm_scales); (void)hipFree(t->prep_dev);
     if (t->prep_host) (void)hipHostFree(t->prep_host);
@@ -727,17 +791,54 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
     OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
     size_t max_pix = 0;
     int it = 0;
+    const bool strict = t->sums == OP_TRACK_SUMS_REFERENCE_F32;
+    float cur[16];
+    std::memcpy(cur, init_T, sizeof(cur));
     for (int l = n_levels - 1; l >= 0; --l) {
         const size_t np = (size_t)h->lv[l].w * h->lv[l].h;
         max_pix = np > max_pix ? np : max_pix;
         const int n_wg_a = (int)((np + kThreads - 1) / kThreads);
         const IterGeom g = iter_geom(t, np);
+        if (strict && np > t->rows_cap) {
+            if (t->rows_dev) OP_HIP(hipFree(t->rows_dev));
+            if (t->rows_host) OP_HIP(hipHostFree(t->rows_host));
+            if (t->pair_host) OP_HIP(hipHostFree(t->pair_host));
+            t->rows_dev = t->rows_host = nullptr; t->pair_host = nullptr; t->rows_cap = 0;
+            OP_HIP(hipMalloc(&t->rows_dev, np * 14 * sizeof(float)));
+            OP_HIP(hipHostMalloc(&t->rows_host, np * 14 * sizeof(float), hipHostMallocDefault));
+            OP_HIP(hipHostMalloc(&t->pair_host, np * sizeof(int), hipHostMallocDefault));
+            t->rows_cap = np;
+        }
         for (int j = 0; j < iters_per_level[l]; ++j, ++it) {
             hipLaunchKernelGGL(k_track_assoc, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, t->pair_p, t->code);
             if (term_type == 0) launch_iter<0>(t, l, g);
             else if (term_type == 1) launch_iter<1>(t, l, g);
             else launch_iter<2>(t, l, g);
-            hipLaunchKernelGGL(k_track_solve, dim3(1), dim3(1024), 0, t->stream, t->st, l, it, t->partials, g.n_wg);
+            if (!strict) {
+                hipLaunchKernelGGL(k_track_solve, dim3(1), dim3(1024), 0, t->stream, t->st, l, it, t->partials, g.n_wg);
+                continue;
+            }
+            // Validation mode: association, acceptance and the Jacobian rows come from the kernels; the sums are taken on
+            // ONE host thread in raster order in float32 like the reference's loop, the solve / exp / pose update follow on
+            // the host, and the new pose goes back to the device state for the next iteration.
+            if (term_type == 0) hipLaunchKernelGGL(k_track_rows<0>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
+            else if (term_type == 1) hipLaunchKernelGGL(k_track_rows<1>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
+            else hipLaunchKernelGGL(k_track_rows<2>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
+            OP_HIP(hipGetLastError());
+            OP_HIP(hipMemcpyAsync(t->rows_host, t->rows_dev, np * 14 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+            OP_HIP(hipMemcpyAsync(t->pair_host, t->pair_t, np * sizeof(int), hipMemcpyDeviceToHost, t->stream));
+            OP_HIP(hipStreamSynchronize(t->stream));
+            float JTJ[36], JTr[6], x[6], D[16];
+            size_t n_pairs = 0;
+            op_host::track_sums_reference_order(t->rows_host, t->pair_host, np, term_type == 0 ? 2 : 1, JTJ, JTr, &n_pairs);
+            op_host::ldlt_solve6_float_sums(JTJ, JTr, x);          // DenseOdometryFunction.cpp:404
+            op_host::se3_exp(x, D);
+            op_host::mat4_mul(D, cur, cur);                          // relative_pose = delta_matrix * relative_pose
+            PoseArg pa;
+            std::memcpy(pa.m, cur, sizeof(cur));
+            hipLaunchKernelGGL(k_track_apply, dim3(1), dim3(1), 0, t->stream, t->st, l, it, pa, (unsigned long long)n_pairs);
+            // Odometry.cpp:669: early-out of the level at ratio > MAX_INLIER_RATIO_DENSE (the device sets stop_level likewise)
+            if ((double)((float)n_pairs / (float)(full_height * full_width)) > 0.9) { it += 1; break; }
         }
     }
     const int n_wg_max = (int)((max_pix + kThreads - 1) / kThreads);
@@ -925,7 +1026,7 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
                                      ((unsigned long long)(unsigned)depth_fmt << 16) | (unsigned)t->lds_cap,
                                  0ull, (unsigned long long)(uintptr_t)t->pyr ^ ((unsigned long long)(uintptr_t)t->pair_p << 1)};
     for (int l = 0; l < n_levels; ++l) key[2] = key[2] * 1000003ull + (unsigned long long)(unsigned)iters_per_level[l] + 1ull;
-    const bool graph_path = t->graph_ok && mem == OP_MEM_DEVICE && !want_point_corr;
+    const bool graph_path = t->graph_ok && mem == OP_MEM_DEVICE && !want_point_corr && t->sums == OP_TRACK_SUMS_FP64; // the validation mode synchronises every iteration: not capturable
     if (graph_path && t->graph_exec && std::memcmp(key, t->graph_key, sizeof(key)) == 0) {
         OP_HIP(hipGraphLaunch(t->graph_exec, t->stream));
         t->pending = true; t->pending_logs = false; t->pending_points = false;

@@ -99,6 +99,12 @@ class Odometry:
     def SetCamera(self, camera):
         self.camera = camera
 
+    def SetSums(self, sums="fp64"):
+        """op_tracker_set_option(OP_TRACK_OPT_SUMS): "fp64" (default, device reduction) or "reference_f32" -- the validation
+        mode that sums every iteration's Jacobian rows sequentially in float32 on the host, as the reference does."""
+        L.check(L.load().op_tracker_set_option(self._h, L.OP_TRACK_OPT_SUMS,
+                                               {"fp64": L.OP_TRACK_SUMS_FP64, "reference_f32": L.OP_TRACK_SUMS_REFERENCE_F32}[sums]))
+
     def SetMultiScale(self, layer_count):
         """Odometry.h:100-104: resize(layer_count, 4) keeps existing entries, pads with 4."""
         self.multi_scale_level = int(layer_count)

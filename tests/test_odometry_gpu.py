@@ -449,3 +449,45 @@ def test_chains_longer_than_the_lds_window(oracle, odo):
     ref = oracle.pixel_correspondences(lv, T2)
     got = odo.ComputeCorrespondencePixelWise(lv, T2)
     assert np.array_equal(got, ref) and len(ref) > 0
+
+
+@pytest.mark.parametrize("i,j,scale,term,strict", TRACK_CASES)
+def test_multi_scale_tracking_with_reference_order_sums(oracle, i, j, scale, term, strict):
+    """The validation mode OP_TRACK_SUMS_REFERENCE_F32 on ALL of TRACK_CASES, the ill-conditioned ones included: when every
+    iteration's Jacobian rows (computed by the kernels) are summed sequentially in float32 like the reference's loop
+    (DenseOdometryFunction.cpp:297-381), the whole free-running coarse-to-fine loop follows the CPU path step for step --
+    identical correspondence counts at EVERY iteration, identical final pairs, poses to float rounding.  What the default
+    (fp64) mode differs by on the relaxed cases is therefore the summation order alone."""
+    levels, _ = track_levels(i, j, holes=True, scale=scale)
+    odo = O.Odometry(I.PinholeCamera("OPEN3D_DATASET"))
+    odo.SetSums("reference_f32")
+    odo.SetMultiScale(3); odo.iter_count_per_level = [4, 8, 16]
+    cam = I.PinholeCamera("OPEN3D_DATASET")
+    cam.width, cam.height = levels[0]["width"], levels[0]["height"]
+    odo.SetCamera(cam)
+    got = odo.MultiScaleComputing(levels, None, term, want_log=True)
+    ref = oracle.dense_track(levels, (4, 8, 16), term=term)
+    assert got.iterations == ref["iterations"]
+    assert np.array_equal(got.per_iter_count, ref["per_iter_count"])
+    assert np.array_equal(got.pixel_correspondence_set, ref["pixel_correspondences"])
+    assert rel_err(got.T, ref["T"]) <= 1e-6
+    assert np.abs(got.per_iter_T - ref["per_iter_T"]).max() <= 1e-6
+    assert got.tracking_success == ref["tracking_success"] and abs(got.rmse - ref["rmse"]) <= 1e-6 * max(ref["rmse"], 1e-9)
+
+
+def test_dense_slam_pose_chain_with_reference_order_sums(oracle):
+    """example/DenseFusion's tracking half over 12 frames with the validation mode: the chained poses equal the oracle's
+    chain to 1e-5 (the image preparation and NormalizeIntensity run on the device in both modes; only the loop's sums differ)."""
+    from onepiece_amd import dense_slam as DS, synthetic as S
+    n = 12
+    frames = [S.room_frame(600 + i) for i in range(n)]
+    slam = DS.DenseSlam(I.PinholeCamera("OPEN3D_DATASET"))
+    slam.rgbd_odometry.SetSums("reference_f32")
+    ref_poses = [np.eye(4, dtype=np.float32)]
+    for k, (d, c, _p) in enumerate(frames):
+        assert slam.UpdateFrame(c, d)
+        if k:
+            r = oracle.dense_tracking(oracle.make_camera(), frames[k - 1][1], c, frames[k - 1][0], d, (4, 8, 16), 0)
+            ref_poses.append(DS._mat4_mul_f32(ref_poses[-1], oracle.mat4_inverse(r["T"])))
+    err = max(rel_err(slam.global_poses[k], ref_poses[k]) for k in range(n))
+    assert err <= 1e-5, err
