@@ -23,6 +23,7 @@
 // into a hipGraph on first use and replayed afterwards.
 #include <cstddef>
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 #include "host_math.hpp"
@@ -1049,6 +1050,24 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
         const IterGeom g = iter_geom(t, np);
         hipLaunchKernelGGL(k_track_assoc, dim3(n_wg0), dim3(kThreads), 0, t->stream, t->st, 0, t->pair_p, t->code);
         launch_iter<3>(t, 0, g);
+        if (t->sums == OP_TRACK_SUMS_REFERENCE_F32) {
+            // validation mode: NormalizeIntensity's two means summed like the reference does (DenseOdometryFunction.cpp:131-141):
+            // sequentially in float32 over the identity-pose pairs in raster order, on one host thread
+            std::vector<int> pt(np);
+            std::vector<float> gs(np), gt(np);
+            OP_HIP(hipMemcpyAsync(pt.data(), t->pair_t, np * sizeof(int), hipMemcpyDeviceToHost, t->stream));
+            OP_HIP(hipMemcpyAsync(gs.data(), pyr_image(t, 0, 0, 0), np * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+            OP_HIP(hipMemcpyAsync(gt.data(), pyr_image(t, 1, 0, 0), np * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+            OP_HIP(hipStreamSynchronize(t->stream));
+            float mean_s = 0.0f, mean_t = 0.0f;
+            size_t cnt = 0;
+            for (size_t k = 0; k < np; ++k)
+                if (pt[k] >= 0) { mean_s += gs[k]; mean_t += gt[(size_t)pt[k]]; ++cnt; }
+            mean_s /= (float)cnt; mean_t /= (float)cnt;
+            const float sc[2] = {(float)(0.5 / (double)mean_s), (float)(0.5 / (double)mean_t)};
+            OP_HIP(hipMemcpyAsync(t->norm_scales, sc, sizeof(sc), hipMemcpyHostToDevice, t->stream));
+            OP_HIP(hipStreamSynchronize(t->stream)); // `sc` is a stack buffer
+        } else
         hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(1024), 0, t->stream, t->partials, g.n_wg, t->norm_scales);
         hipLaunchKernelGGL(k_norm_apply, dim3(n_wg0, 2), dim3(kThreads), 0, t->stream, pyr_image(t, 0, 0, 0), pyr_image(t, 1, 0, 0), (int)np,
                            t->norm_scales);

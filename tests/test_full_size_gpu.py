@@ -54,11 +54,12 @@ def test_config3_1000_frames_bit_equal(oracle, torch_dev):
     assert np.array_equal(hx.view(np.uint32), ox.view(np.uint32)), "voxel payload differs"
 
 
-def _chains(oracle, depth, rgb, poses):
+def _chains(oracle, depth, rgb, poses, sums="fp64"):
     """GPU DenseSlam chain and the oracle's chain over the same frames (DenseSlam.cpp:21-33)."""
     from onepiece_amd import dense_slam as DS
     n = depth.shape[0]
     slam = DS.DenseSlam(I.PinholeCamera("OPEN3D_DATASET"))
+    slam.rgbd_odometry.SetSums(sums)
     for i in range(n):
         assert slam.UpdateFrame(rgb[i], depth[i])
     hd, hc = depth.cpu().numpy(), rgb.cpu().numpy()
@@ -97,6 +98,23 @@ def test_config4_tracked_pose_chain_60_frames(oracle, torch_dev):
     assert (pair_err <= 1e-4).mean() >= 0.85
     assert chain_err.max() <= 3e-3
     assert np.abs(dg - dr).max() <= 0.005
+
+
+def test_config4_tracked_pose_chain_60_frames_reference_order_sums(oracle, torch_dev):
+    """The same 60-frame chain with the tracker's validation mode (OP_TRACK_SUMS_REFERENCE_F32: every iteration's rows and
+    NormalizeIntensity's means summed sequentially in float32 like the reference): every pair and every chained pose agrees
+    with the CPU path to 1e-5 -- north_star's 1e-4 with a decade to spare, on all 59 pairs.  What the default mode differs by
+    (previous test) is the order of summation and nothing else."""
+    import torch
+    n = 60
+    depth, rgb, poses = S.room_sequence_torch(0, n, torch_dev)
+    torch.cuda.synchronize()
+    slam, ref, pair_err, dg, dr = _chains(oracle, depth, rgb, poses, sums="reference_f32")
+    chain_err = np.array([rel_err(slam.global_poses[i], ref[i]) for i in range(n)])
+    print("\nconfig 4 pose chain, reference-order sums: per-pair rel err max %.2e, chain rel err max %.2e" % (pair_err.max(), chain_err.max()))
+    assert all(slam.tracking_success)
+    assert pair_err.max() <= 1e-5 and chain_err.max() <= 1e-5
+    assert np.abs(dg - dr).max() <= 1e-5
 
 
 def test_config4_2000_frames_tracking_and_fusion_properties(torch_dev):
