@@ -33,7 +33,10 @@ namespace {
 using op::fail;
 
 constexpr int kNSums = 32;      // doubles per partial: sums[0..26], [27] = sum_sq_err, [28] = inlier count
-constexpr int kIterThreads = 256;
+#ifndef ICP_THREADS
+#define ICP_THREADS 256
+#endif
+constexpr int kIterThreads = ICP_THREADS;
 constexpr int kScan = 8;          // candidates fetched per trip of the neighbour scan
 constexpr unsigned long long kMaxCells = 1ull << 26;
 
@@ -736,7 +739,10 @@ void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace, cons
                        (const float*)c->tgt_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials);
     const double* rows = c->partials;
     int n_rows = c->n_wg;
-    if (c->n_wg > 4 * kStage1) { // two-stage second pass: 1200 rows -> 32 rows -> 1
+#ifndef ICP_STAGE1_MIN
+#define ICP_STAGE1_MIN (4 * kStage1)
+#endif
+    if (c->n_wg > ICP_STAGE1_MIN) { // two-stage second pass: 1200 rows -> 32 rows -> 1
         hipLaunchKernelGGL(k_reduce_stage1, dim3(kStage1), dim3(256), 0, c->stream, (const double*)c->partials, c->n_wg, c->stage);
         rows = c->stage; n_rows = kStage1;
     }

@@ -1545,15 +1545,20 @@ class CopyPool {
     void copy2(void* d0, const void* s0, size_t n0, void* d1, const void* s1, size_t n1) {
         if (helpers_.empty() || n0 + n1 < (1u << 18)) { std::memcpy(d0, s0, n0); if (n1) std::memcpy(d1, s1, n1); return; }
         std::lock_guard<std::mutex> call(call_mutex_); // one copy at a time (volumes on several threads share the pool)
-        job_[0] = {(char*)d0, (const char*)s0, n0}; job_[1] = {(char*)d1, (const char*)s1, n1};
         const size_t chunks = (n0 + kChunk - 1) / kChunk + (n1 + kChunk - 1) / kChunk;
-        done_.store(0, std::memory_order_relaxed);
-        next_.store(0, std::memory_order_relaxed);
-        total_ = chunks;
-        { std::lock_guard<std::mutex> lk(m_); ++epoch_; }
+        {   // publish the job under the lock the helpers read the epoch under: a helper either sees all of it or none
+            std::lock_guard<std::mutex> lk(m_);
+            job_[0] = {(char*)d0, (const char*)s0, n0}; job_[1] = {(char*)d1, (const char*)s1, n1};
+            done_.store(0, std::memory_order_relaxed);
+            next_.store(0, std::memory_order_relaxed);
+            total_ = chunks;
+            ++epoch_;
+        }
         cv_.notify_all();
         work();
-        while (done_.load(std::memory_order_acquire) < chunks) __builtin_ia32_pause();
+        // every chunk copied AND no helper still inside work() (it would otherwise draw a chunk index of the NEXT job
+        // against this job's state): helpers count themselves in under m_ when they pick up an epoch
+        while (done_.load(std::memory_order_acquire) < chunks || active_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
     }
   private:
     static constexpr size_t kChunk = 1u << 17;
@@ -1580,18 +1585,32 @@ class CopyPool {
             done_.fetch_add(1, std::memory_order_release);
         }
     }
+    // picks up a new epoch (counting itself active under the lock) or reports that there is none / that it is time to stop
+    int poll(uint64_t& seen) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (stop_) return -1;
+        if (epoch_ == seen) return 0;
+        seen = epoch_;
+        active_.fetch_add(1, std::memory_order_acq_rel);
+        return 1;
+    }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
             // spin for a while (a frame arrives every < 100 us during a sequence), then sleep
-            bool have = false;
-            for (int spin = 0; spin < 20000 && !have; ++spin) {
-                { std::lock_guard<std::mutex> lk(m_); have = epoch_ != seen; }
-                if (!have) __builtin_ia32_pause();
+            int got = 0;
+            for (int spin = 0; spin < 20000 && got == 0; ++spin) {
+                got = poll(seen);
+                if (got == 0) __builtin_ia32_pause();
             }
-            if (!have) { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return epoch_ != seen; }); }
-            { std::lock_guard<std::mutex> lk(m_); seen = epoch_; if (stop_) return; }
+            if (got == 0) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+                continue; // poll() picks the epoch up (and counts this helper in) under the lock
+            }
+            if (got < 0) return;
             work();
+            active_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
     std::vector<std::thread> helpers_;
@@ -1602,6 +1621,7 @@ class CopyPool {
     Job job_[2];
     size_t total_ = 0;
     std::atomic<size_t> next_{0}, done_{0};
+    std::atomic<int> active_{0};
 };
 
 int vol_ring_alloc(op_volume* v) {
