@@ -1568,6 +1568,7 @@ class CopyPool {
             next_.store(0, std::memory_order_relaxed);
             total_ = chunks;
             ++epoch_;
+            epoch_hint_.store(epoch_, std::memory_order_release);
         }
         cv_.notify_all();
         work();
@@ -1585,7 +1586,7 @@ class CopyPool {
         for (int i = 0; i < n && i < 8; ++i) helpers_.emplace_back([this] { loop(); });
     }
     ~CopyPool() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; epoch_hint_.store(epoch_, std::memory_order_release); }
         cv_.notify_all();
         for (auto& t : helpers_) t.join();
     }
@@ -1602,6 +1603,7 @@ class CopyPool {
     }
     // picks up a new epoch (counting itself active under the lock) or reports that there is none / that it is time to stop
     int poll(uint64_t& seen) {
+        if (epoch_hint_.load(std::memory_order_acquire) == seen) return 0; // nothing new: do not touch the lock while spinning
         std::lock_guard<std::mutex> lk(m_);
         if (stop_) return -1;
         if (epoch_ == seen) return 0;
@@ -1637,6 +1639,7 @@ class CopyPool {
     size_t total_ = 0;
     std::atomic<size_t> next_{0}, done_{0};
     std::atomic<int> active_{0};
+    std::atomic<uint64_t> epoch_hint_{0}; // lock-free mirror of epoch_ for the spinning helpers
 };
 
 int vol_ring_alloc(op_volume* v) {
