@@ -23,6 +23,7 @@
 #include <climits>
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <vector>
 
 #include "common.hpp"
@@ -39,6 +40,7 @@ constexpr int kNSums = 32;      // doubles per partial: sums[0..26], [27] = sum_
 constexpr int kIterThreads = ICP_THREADS;
 constexpr int kScan = 8;          // candidates fetched per trip of the neighbour scan
 constexpr unsigned long long kMaxCells = 1ull << 26;
+constexpr size_t kMaxPoints = (size_t)1 << 28; // 16-byte records and 12-byte points are addressed with 32-bit byte offsets
 
 struct Grid {
     float ox, oy, oz, inv_cell; // origin and 1/cell
@@ -169,9 +171,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(const unsigned* __restrict__
     }
 }
 
-__global__ void k_cell_scatter(const float* __restrict__ xyz, const float* __restrict__ nrm, size_t m, Grid g,
-                               const unsigned* __restrict__ start, unsigned* __restrict__ fill, float4* __restrict__ sorted,
-                               float4* __restrict__ sorted_n) {
+__global__ void k_cell_scatter(const float* __restrict__ xyz, size_t m, Grid g,
+                               const unsigned* __restrict__ start, unsigned* __restrict__ fill, float4* __restrict__ sorted) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= m) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -181,21 +182,52 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, const float* __res
     const size_t c = ((size_t)cz * g.gy + cy) * g.gx + cx;
     const unsigned pos = start[c] + atomicAdd(&fill[c], 1u);
     sorted[pos] = make_float4(x, y, z, __int_as_float((int)i));
-    if (nrm) sorted_n[pos] = make_float4(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2], 0.0f);
 }
 
 // ---- per-iteration kernel ----------------------------------------------------------------------
 // MODE 1 (plane): sums[0..20] = upper triangle of JTJ (row-major), [21..26] = JTr.
 // MODE 0 (point): sums[0..2] = sum s', [3..5] = sum t, [6..14] = sum s' t^T.
 // MODE 2 (final): like MODE 0 but over the ORIGINAL source points and the stored nn[] (no search).
+//
+// The kernel also finishes the reduction itself (no second-pass kernels on the per-iteration critical path): every
+// workgroup writes its row of partial sums, the LAST workgroup of each group of `per_group` rows to arrive folds that
+// group into one stage row, and the last group to finish folds the stage rows, writes the totals and publishes them
+// to the host.  Who does the folding depends on timing, what is added in which order does not, so the sums are
+// reproducible bit for bit.  sync[0..kGroups-1] count the arrivals per group, sync[kGroups] the finished groups; the
+// workgroup that completes a count resets it for the next launch.
+constexpr int kGroups = 32;
+constexpr unsigned long long kNoKey = 0x7f7fffff00000000ull; // (FLT_MAX, index 0): no candidate compares below it
+
+template <class V>
+__device__ __forceinline__ V ld_off(const void* base, unsigned byte_off) { // base + zero-extended 32-bit offset (SGPR base + VGPR offset form)
+    return *reinterpret_cast<const V*>(static_cast<const char*>(base) + byte_off);
+}
+struct __attribute__((packed, aligned(4))) U4 { unsigned a, b, c, d; };
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+
+// Rows exchanged between workgroups of ONE launch live behind different L2s (one per XCD).  A release fence at agent
+// scope would write back the XCD's whole L2 (measured: 1200 of them cost 90 us per launch); instead the few values
+// that cross are stored and loaded with agent-scope accesses (write-through / L2-bypassing), the writer waits for its
+// stores to be acknowledged (s_waitcnt 0) before the barrier that precedes the arrival count, and the arrival count is
+// a relaxed agent-scope atomic.
+__device__ __forceinline__ double ld_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coherent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_stores_then_barrier() {
+    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0): every store of this wave has been acknowledged
+    __syncthreads();
+}
+
 template <int MODE>
-__global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restrict__ T, Mat4 T_arg, const float* __restrict__ src, size_t n, Grid g,
-                                                           const unsigned* __restrict__ cell_start, const unsigned* __restrict__ cell_count,
-                                                           const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
-                                                           const float* __restrict__ tgt_orig, double thr2, int* __restrict__ nn,
-                                                           int* __restrict__ inl, double* __restrict__ partials) {
+__global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restrict__ T, Mat4 T_arg, const float* __restrict__ src, unsigned n, Grid g,
+                                                           const unsigned* __restrict__ cell_start, const float4* __restrict__ tgt, unsigned dummy,
+                                                           const float* __restrict__ tgt_orig, const float* __restrict__ nrm_orig, double thr2,
+                                                           int* __restrict__ nn, int* __restrict__ inl, double* __restrict__ partials,
+                                                           double* __restrict__ stage, unsigned* __restrict__ sync, unsigned per_group,
+                                                           double* __restrict__ out, double* __restrict__ host_out, double seq) {
     __shared__ double s_red[kIterThreads / 64][kNSums];
+    __shared__ double s_fin[kIterThreads / 32][kNSums];
     __shared__ uint2 s_runs[8][kIterThreads]; // per lane: the [begin, end) runs of the rows it still has to scan
+    __shared__ int s_last;
     // what the point contributes to the sums; the 29 fp64 accumulators themselves are only formed after the search
     bool inlier = false;
     double e = 0.0;
@@ -206,9 +238,10 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     // XCD-aware: the source is in image order, so a contiguous slab of it meets a contiguous part of the cell-sorted
     // target; with the plain order every XCD's L2 would see all of target + normals + cell tables (> 4 MiB)
     const unsigned wg = op::xcd_slab_index(blockIdx.x, gridDim.x);
-    const size_t i = wg * (size_t)blockDim.x + threadIdx.x;
+    const unsigned i = wg * (unsigned)kIterThreads + threadIdx.x;
     if (i < n) {
-        const float s0 = src[3 * i], s1 = src[3 * i + 1], s2 = src[3 * i + 2];
+        const F3 sp = ld_off<F3>(src, 12u * i);
+        const float s0 = sp.x, s1 = sp.y, s2 = sp.z;
         // start_T: device memory when the update step runs on the device (T != nullptr), a by-value kernel
         // argument when the host does the solve (saves the per-iteration host-to-device copy)
         float M[16];
@@ -223,9 +256,11 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             const float q2 = ((M[8] * s0 + M[9] * s1) + M[10] * s2) + M[11] * 1.0f;
             const float q3 = ((M[12] * s0 + M[13] * s1) + M[14] * s2) + M[15] * 1.0f;
             tp0 = q0 / q3; tp1 = q1 / q3; tp2 = q2 / q3;
-            // exact 1-NN restricted to the 27 cells around the query (see header comment)
-            float best_d = FLT_MAX;
-            int best_pos = -1;
+            // exact 1-NN restricted to the 27 cells around the query (see header comment).  The running best is ONE
+            // 64-bit key (bits of the squared distance, original index): the distance is never negative, so its bit
+            // pattern orders like the value, and "nearer, ties to the smaller original index" is an unsigned minimum --
+            // the visiting order does not matter and a candidate costs one 64-bit compare and two selects.
+            unsigned long long best_key = kNoKey;
             if (fabsf(tp0) <= FLT_MAX && fabsf(tp1) <= FLT_MAX && fabsf(tp2) <= FLT_MAX) { // NaN / inf queries match nothing
                 // cell of the query, clamped to two cells outside the grid (beyond that nothing can be within a cell of it;
                 // keeps the int conversion and the +-1 neighbourhood arithmetic in range for far-away points)
@@ -244,7 +279,10 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                 if (x_lo <= x_hi) {
                     // the [begin, end) runs of all nine rows are fetched first (independent loads, one round trip) instead of
                     // one dependent round trip per visited row; the centre row's stays in registers, the other eight are
-                    // parked in the lane's LDS column (slot = q, skipping the centre) until the centre row has been scanned
+                    // parked in the lane's LDS column (slot = q, skipping the centre) until the centre row has been scanned.
+                    // cell_start is the exclusive scan over ALL cells (+4 entries of padding), so cells x_lo..x_hi own
+                    // [cell_start[x_lo], cell_start[x_hi + 1]) and one 16-byte load returns both ends.
+                    const int w = x_hi - x_lo; // 0..2
                     unsigned cb = 0u, ce = 0u;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
@@ -252,32 +290,31 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                         const int z = cz + dz, y = cy + dy;
                         unsigned rb = 0u, re = 0u;
                         if (!(z < 0 || z >= g.gz || y < 0 || y >= g.gy)) {
-                            const size_t row = ((size_t)z * g.gy + y) * g.gx;
-                            // cells x_lo..x_hi own one contiguous run of the sorted target
-                            rb = cell_start[row + x_lo];
-                            re = cell_start[row + x_hi] + cell_count[row + x_hi];
+                            const unsigned first = ((unsigned)z * (unsigned)g.gy + (unsigned)y) * (unsigned)g.gx + (unsigned)x_lo;
+                            const U4 u = ld_off<U4>(cell_start, 4u * first);
+                            rb = u.a;
+                            re = w == 0 ? u.b : (w == 1 ? u.c : u.d);
                         }
                         if (q == 4) { cb = rb; ce = re; }
                         else s_runs[q < 4 ? q : q - 1][threadIdx.x] = make_uint2(rb, re);
                     }
-                    // one candidate: min by (distance, original index), so the visiting order does not matter
-                    auto visit = [&](const float4& c, unsigned pos) {
+                    // one candidate.  Slots past the end of a lane's candidates read the dummy record tgt[dummy] (+inf
+                    // coordinates: its distance is +inf, above FLT_MAX, so it never wins), which keeps the scan free of
+                    // per-candidate branches.
+                    auto visit = [&](const float4& c) {
                         const float dx = tp0 - c.x, dyy = tp1 - c.y, dzz = tp2 - c.z;
                         const float d = dx * dx + dyy * dyy + dzz * dzz;
-                        const int ci = __float_as_int(c.w);
-                        if (d < best_d || (d == best_d && ci < best)) { best_d = d; best = ci; best_pos = (int)pos; }
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(c.w);
+                        best_key = key < best_key ? key : best_key;
                     };
                     // 1. the centre row (dy,dz) = (0,0), kScan candidates per trip: the loads are independent, so their
                     //    L2 round trips overlap (the scan is a latency chain otherwise)
                     for (unsigned p = cb; p < ce; p += kScan) {
                         float4 c[kScan];
 #pragma unroll
-                        for (int k = 0; k < kScan; ++k) c[k] = tgt[min(p + k, ce - 1)];
+                        for (int k = 0; k < kScan; ++k) c[k] = ld_off<float4>(tgt, 16u * (p + k < ce ? p + k : dummy));
 #pragma unroll
-                        for (int k = 0; k < kScan; ++k) {
-                            if (p + k >= ce) break;
-                            visit(c[k], p + k);
-                        }
+                        for (int k = 0; k < kScan; ++k) visit(c[k]);
                     }
                     // 2. the other 8 rows: those that can still hold the nearest neighbour are decided NOW, with the centre
                     //    row's best distance, and their runs are walked as ONE flattened candidate stream.  A wave then
@@ -285,6 +322,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                     //    ANY of its lanes still needs (the union over 64 lanes is almost always all 8 rows).  The runs of a
                     //    lane sit in its private LDS column, which a dynamic index reaches without scratch memory; the
                     //    survivors are compacted in place (nr never overtakes the slot being read).
+                    const float best_d = __uint_as_float((unsigned)(best_key >> 32));
                     int nr = 0;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
@@ -301,30 +339,25 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
 #pragma unroll
                         for (int k = 0; k < kScan; ++k) {
                             if (p == e && ri < nr) { const uint2 run = s_runs[ri][threadIdx.x]; p = run.x; e = run.y; ++ri; } // runs are non-empty
-                            idx[k] = p < e ? p++ : 0xffffffffu;
+                            idx[k] = p < e ? p++ : dummy;
                         }
                         float4 c[kScan];
 #pragma unroll
-                        for (int k = 0; k < kScan; ++k) c[k] = tgt[idx[k] != 0xffffffffu ? idx[k] : idx[0]];
+                        for (int k = 0; k < kScan; ++k) c[k] = ld_off<float4>(tgt, 16u * idx[k]);
 #pragma unroll
-                        for (int k = 0; k < kScan; ++k) {
-                            if (idx[k] == 0xffffffffu) break;
-                            visit(c[k], idx[k]);
-                        }
+                        for (int k = 0; k < kScan; ++k) visit(c[k]);
                     }
                 }
             }
+            best = best_key != kNoKey ? (int)(unsigned)best_key : -1;
             nn[i] = best;
-            if (best >= 0) {
-                const float4 c = tgt[best_pos];
-                t0 = c.x; t1 = c.y; t2 = c.z;
-                if (MODE == 1) { const float4 nv = tgt_n[best_pos]; n0 = nv.x; n1 = nv.y; n2 = nv.z; }
-            }
         } else {
             best = nn[i];
-            if (best >= 0) { t0 = tgt_orig[3 * best]; t1 = tgt_orig[3 * best + 1]; t2 = tgt_orig[3 * best + 2]; }
         }
         if (best >= 0) {
+            const F3 tv = ld_off<F3>(tgt_orig, 12u * (unsigned)best);
+            t0 = tv.x; t1 = tv.y; t2 = tv.z;
+            if (MODE == 1) { const F3 nv = ld_off<F3>(nrm_orig, 12u * (unsigned)best); n0 = nv.x; n1 = nv.y; n2 = nv.z; }
             // CountInliers (ICP.cpp:15-23): ||(R s + t) - target||^2 in float, compared in double
             const float d0 = (sum3(M[0] * s0, M[1] * s1, M[2] * s2) + M[3]) - t0;
             const float d1 = (sum3(M[4] * s0, M[5] * s1, M[6] * s2) + M[7]) - t1;
@@ -369,8 +402,76 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     if (threadIdx.x < kNSums) {
         double v = 0;
         for (int w = 0; w < kIterThreads / 64; ++w) v += s_red[w][threadIdx.x];
-        partials[(size_t)wg * kNSums + threadIdx.x] = v; // logical order: the second pass sums in source order as before
+        st_coherent(partials + (size_t)wg * kNSums + threadIdx.x, v); // logical order: the folds below sum in source order
     }
+
+    // ---- cross-workgroup finish ----
+    constexpr int kRows = kIterThreads / 32;      // row lanes of the folds below
+    const int fk = threadIdx.x & 31, fr = threadIdx.x >> 5;
+    const unsigned grp = wg / per_group, n_groups = (gridDim.x + per_group - 1) / per_group;
+    wait_stores_then_barrier(); // the partial row has reached memory before the arrival is counted
+    if (threadIdx.x == 0) {
+        const unsigned members = min(per_group, gridDim.x - grp * per_group);
+        const unsigned prev = __hip_atomic_fetch_add(&sync[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev + 1u == members;
+        if (s_last) __hip_atomic_store(&sync[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    {
+        const unsigned lo = grp * per_group, hi = min(lo + per_group, gridDim.x);
+        double v0 = 0, v1 = 0;
+        unsigned p = lo + fr;
+        for (; p + kRows < hi; p += 2 * kRows) { v0 += ld_coherent(partials + (size_t)p * kNSums + fk); v1 += ld_coherent(partials + (size_t)(p + kRows) * kNSums + fk); }
+        for (; p < hi; p += kRows) v0 += ld_coherent(partials + (size_t)p * kNSums + fk);
+        s_fin[fr][fk] = v0 + v1;
+        __syncthreads();
+        if (threadIdx.x < kNSums) {
+            double t = 0;
+            for (int r = 0; r < kRows; ++r) t += s_fin[r][threadIdx.x];
+            st_coherent(stage + (size_t)grp * kNSums + threadIdx.x, t);
+        }
+    }
+    wait_stores_then_barrier();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(&sync[kGroups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev + 1u == n_groups;
+        if (s_last) __hip_atomic_store(&sync[kGroups], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    {
+        double v = 0;
+        for (unsigned p = fr; p < n_groups; p += kRows) v += ld_coherent(stage + (size_t)p * kNSums + fk);
+        s_fin[fr][fk] = v;
+        __syncthreads();
+        if (threadIdx.x < kNSums) {
+            double t = 0;
+            for (int r = 0; r < kRows; ++r) t += s_fin[r][threadIdx.x];
+            out[threadIdx.x] = t;
+            if (host_out && threadIdx.x < kNSums - 1) // host-mapped pinned memory
+                __hip_atomic_store(&host_out[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (host_out) {
+            wait_stores_then_barrier();
+            if (threadIdx.x == 0) // publish: the host spins on this sequence number
+                __hip_atomic_store(&host_out[kNSums - 1], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// PointToPoint's per-iteration step on the device (ICP.cpp:76-79, :195-198): one thread does the Kabsch fit from the
+// totals and left-multiplies start_T, so the whole loop is enqueued without a host round trip.
+__global__ void k_point_update(const double* __restrict__ tot, float* __restrict__ T, int it, int* __restrict__ per_iter_inliers,
+                               float* __restrict__ per_iter_T) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float tmp_T[16], cur[16];
+    op_host::kabsch_from_sums(tot[28], tot, tot + 3, tot + 6, tmp_T); // ICP.cpp:79
+    for (int i = 0; i < 16; ++i) cur[i] = T[i];
+    op_host::mat4_mul(tmp_T, cur, cur);   // ICP.cpp:198: start_T = tmp_T * start_T
+    for (int i = 0; i < 16; ++i) T[i] = cur[i];
+    if (per_iter_inliers) per_iter_inliers[it] = (int)(tot[28] + 0.5);
+    if (per_iter_T) for (int i = 0; i < 16; ++i) per_iter_T[16 * it + i] = cur[i];
 }
 
 
@@ -565,8 +666,7 @@ __device__ __forceinline__ void sym3_smallest_eigvec(double a00, double a01, dou
     for (int k = 0; k < 3; ++k) v[k] = m2 ? V[k][2] : (m1 ? V[k][1] : V[k][0]);
 }
 
-__global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const unsigned* __restrict__ cell_start,
-                                                                  const unsigned* __restrict__ cell_count, const float4* __restrict__ pts,
+__global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const unsigned* __restrict__ cell_start, const float4* __restrict__ pts,
                                                                   size_t m, int knn, float radius, float cell, float* __restrict__ normals) {
     __shared__ float s_d[kNrmMaxK][kNrmThreads];
     __shared__ int s_p[kNrmMaxK][kNrmThreads]; // sorted position of the neighbour (its record is pts[pos])
@@ -592,7 +692,7 @@ __global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const 
                     x_lo = max(x_lo, 0); x_hi = min(x_hi, g.gx - 1);
                     if (x_lo > x_hi) continue;
                     const size_t row = ((size_t)z * g.gy + y) * g.gx;
-                    const unsigned beg = cell_start[row + x_lo], end = cell_start[row + x_hi] + cell_count[row + x_hi];
+                    const unsigned beg = cell_start[row + x_lo], end = cell_start[row + x_hi + 1]; // exclusive scan incl. the total
                     for (unsigned p = beg; p < end; ++p) {
                         const float4 c = pts[p];
                         const float dx = me.x - c.x, dy = me.y - c.y, dz = me.z - c.z;
@@ -703,8 +803,8 @@ struct op_icp {
     size_t ncell = 0;
     float* tgt_orig = nullptr; // m x 3 (original order)
     float4* tgt = nullptr;     // sorted by cell
-    float4* tgt_n = nullptr;
-    unsigned *cell_start = nullptr, *cell_count = nullptr;
+    unsigned* cell_start = nullptr; // exclusive scan of the per-cell counts, ncell + 4 entries
+    unsigned* sync = nullptr;       // arrival counters of k_icp_iter's cross-workgroup finish
     float* src = nullptr;
     size_t src_cap = 0;
     int *nn = nullptr, *inl = nullptr;
@@ -727,27 +827,19 @@ struct op_icp {
 
 namespace {
 
-// one fused pass (transform + NN + inliers + sums) followed by the reduce/update kernel; start_T is
-// read from c->T_dev.  update: see k_reduce_update.
+// one fused pass (transform + NN + inliers + sums + reduction); start_T is read from c->T_dev unless host_T is given.
 template <int MODE>
 void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace, const float* host_T = nullptr, double seq = 0.0) {
     Mat4 Tv;
     if (host_T) std::memcpy(Tv.m, host_T, sizeof(Tv.m)); else std::memset(Tv.m, 0, sizeof(Tv.m));
+    const unsigned per_group = (unsigned)((c->n_wg + kGroups - 1) / kGroups);
     hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
-                       (const float*)c->src, c->n,
-                       c->grid, (const unsigned*)c->cell_start, (const unsigned*)c->cell_count, (const float4*)c->tgt, (const float4*)c->tgt_n,
-                       (const float*)c->tgt_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials);
-    const double* rows = c->partials;
-    int n_rows = c->n_wg;
-#ifndef ICP_STAGE1_MIN
-#define ICP_STAGE1_MIN (4 * kStage1)
-#endif
-    if (c->n_wg > ICP_STAGE1_MIN) { // two-stage second pass: 1200 rows -> 32 rows -> 1
-        hipLaunchKernelGGL(k_reduce_stage1, dim3(kStage1), dim3(256), 0, c->stream, (const double*)c->partials, c->n_wg, c->stage);
-        rows = c->stage; n_rows = kStage1;
-    }
-    hipLaunchKernelGGL(k_reduce_update, dim3(1), dim3(1024), 0, c->stream, rows, n_rows, c->result, update, c->T_dev, it,
-                       trace ? c->it_inl_dev : nullptr, trace ? c->it_T_dev : nullptr, host_T ? c->result_host_dev : nullptr, seq);
+                       (const float*)c->src, (unsigned)c->n, c->grid, (const unsigned*)c->cell_start, (const float4*)c->tgt, (unsigned)c->m,
+                       (const float*)c->tgt_orig, (const float*)c->nrm_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials,
+                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq);
+    if (update) // point-to-point: the Kabsch step follows on the device
+        hipLaunchKernelGGL(k_point_update, dim3(1), dim3(64), 0, c->stream, (const double*)c->result, c->T_dev, it, trace ? c->it_inl_dev : nullptr,
+                           trace ? c->it_T_dev : nullptr);
 }
 
 int enqueue_pass(op_icp* c, int mode, bool write_inl, int update, int it, bool trace) {
@@ -820,7 +912,7 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     *out = nullptr;
     if (!tgt_xyz && m) return fail(OP_ERR_INVALID, "null target");
     if (!(threshold > 0)) return fail(OP_ERR_INVALID, "threshold must be > 0");
-    if (m > (size_t)INT_MAX) return fail(OP_ERR_INVALID, "target too large");
+    if (m >= kMaxPoints) return fail(OP_ERR_INVALID, "target too large (at most %zu points)", kMaxPoints - 1);
     OP_TRY(op::use_device(device));
     op_icp* c = new op_icp();
     c->device = device; c->m = m; c->threshold = threshold; c->has_normals = tgt_normals != nullptr;
@@ -829,12 +921,16 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     OP_HIP_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t m1 = m ? m : 1;
     OP_HIP_C(hipMalloc((void**)&c->tgt_orig, m1 * 3 * sizeof(float)));
-    OP_HIP_C(hipMalloc((void**)&c->tgt, m1 * sizeof(float4)));
+    OP_HIP_C(hipMalloc((void**)&c->tgt, (m + 1) * sizeof(float4))); // + the dummy record of the neighbour scan
+    {
+        const float inf = std::numeric_limits<float>::infinity();
+        const float dummy[4] = {inf, inf, inf, 0.0f};
+        OP_HIP_C(hipMemcpy(c->tgt + m, dummy, sizeof(dummy), hipMemcpyHostToDevice));
+    }
     float* d_nrm = nullptr;
     const hipMemcpyKind kind = mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (m) OP_HIP_C(hipMemcpy(c->tgt_orig, tgt_xyz, m * 3 * sizeof(float), kind));
     if (c->has_normals) {
-        OP_HIP_C(hipMalloc((void**)&c->tgt_n, m1 * sizeof(float4)));
         OP_HIP_C(hipMalloc((void**)&d_nrm, m1 * 3 * sizeof(float)));
         c->nrm_orig = d_nrm; // owned by the context from here on (freed by op_icp_destroy)
         if (m) OP_HIP_C(hipMemcpy(d_nrm, tgt_normals, m * 3 * sizeof(float), kind));
@@ -871,23 +967,30 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     c->grid.gy = (int)std::floor((mx[1] - mn[1]) / cell) + 2;
     c->grid.gz = (int)std::floor((mx[2] - mn[2]) / cell) + 2;
     c->ncell = (size_t)c->grid.gx * c->grid.gy * c->grid.gz;
-    OP_HIP_C(hipMalloc((void**)&c->cell_start, c->ncell * sizeof(unsigned)));
-    OP_HIP_C(hipMalloc((void**)&c->cell_count, c->ncell * sizeof(unsigned)));
-    unsigned* d_fill = nullptr;
-    OP_HIP_C(hipMalloc((void**)&d_fill, c->ncell * sizeof(unsigned)));
-    OP_HIP_C(hipMemsetAsync(c->cell_count, 0, c->ncell * sizeof(unsigned), c->stream));
-    OP_HIP_C(hipMemsetAsync(d_fill, 0, c->ncell * sizeof(unsigned), c->stream));
-    if (m) hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, c->grid, c->cell_count);
-    int rc = device_exclusive_scan(c->cell_count, c->ncell, c->cell_start, c->stream, nullptr);
-    if (rc != OP_OK) { (void)hipFree(d_fill); return bail(rc); }
-    if (m) hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, (const float*)d_nrm, m,
-                              c->grid, (const unsigned*)c->cell_start, d_fill, c->tgt, c->tgt_n);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_fill);
+    // cell_start = exclusive scan of the per-cell counts over ncell + 4 entries (the padding holds the total), so a
+    // run of x-adjacent cells is [cell_start[first], cell_start[last + 1]) and one 16-byte load sees both ends
+    const size_t n_tab = c->ncell + 4;
+    OP_HIP_C(hipMalloc((void**)&c->cell_start, n_tab * sizeof(unsigned)));
+    unsigned *d_count = nullptr, *d_fill = nullptr;
+    OP_HIP_C(hipMalloc((void**)&d_count, n_tab * sizeof(unsigned)));
+    if (hipMalloc((void**)&d_fill, c->ncell * sizeof(unsigned)) != hipSuccess) { (void)hipFree(d_count); return bail(fail(OP_ERR_HIP, "grid build: out of memory")); }
+    auto drop = [&]() { (void)hipFree(d_count); (void)hipFree(d_fill); };
+    hipError_t e = hipMemsetAsync(d_count, 0, n_tab * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_fill, 0, c->ncell * sizeof(unsigned), c->stream);
+    if (e != hipSuccess) { drop(); return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e))); }
+    if (m) hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, c->grid, d_count);
+    int rc = device_exclusive_scan(d_count, n_tab, c->cell_start, c->stream, nullptr);
+    if (rc != OP_OK) { drop(); return bail(rc); }
+    if (m) hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m,
+                              c->grid, (const unsigned*)c->cell_start, d_fill, c->tgt);
+    e = hipStreamSynchronize(c->stream);
+    drop();
     if (e != hipSuccess) return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e)));
+    OP_HIP_C(hipMalloc((void**)&c->sync, (kGroups + 1) * sizeof(unsigned)));
+    OP_HIP_C(hipMemset(c->sync, 0, (kGroups + 1) * sizeof(unsigned)));
     OP_HIP_C(hipMalloc((void**)&c->result, kNSums * sizeof(double)));
     OP_HIP_C(hipMalloc((void**)&c->T_dev, 16 * sizeof(float)));
-    OP_HIP_C(hipMalloc((void**)&c->stage, (size_t)kStage1 * kNSums * sizeof(double)));
+    OP_HIP_C(hipMalloc((void**)&c->stage, (size_t)std::max(kStage1, kGroups) * kNSums * sizeof(double)));
     OP_HIP_C(hipHostMalloc((void**)&c->result_host, kNSums * sizeof(double), hipHostMallocMapped));
     OP_HIP_C(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0));
     std::memset(c->result_host, 0, kNSums * sizeof(double));
@@ -900,7 +1003,7 @@ int op_icp_destroy(op_icp* c) {
     if (!c) return OP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->tgt_orig, c->tgt, c->tgt_n, c->cell_start, c->cell_count, c->src, c->nn, c->inl, c->partials, c->result,
+    void* ptrs[] = {c->tgt_orig, c->tgt, c->sync, c->cell_start, c->src, c->nn, c->inl, c->partials, c->result,
                     c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage, c->nrm_orig, c->flag, c->start, c->scan_tot, c->rows_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -922,6 +1025,7 @@ int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
     if (!c) return fail(OP_ERR_INVALID, "null icp");
     OP_HIP(hipSetDevice(c->device));
     if (!src_xyz && n) return fail(OP_ERR_INVALID, "null source");
+    if (n >= kMaxPoints) return fail(OP_ERR_INVALID, "source too large (at most %zu points)", kMaxPoints - 1);
     if (n > c->src_cap) {
         void* old[] = {c->src, c->nn, c->inl, c->partials};
         for (void* p : old)
@@ -980,6 +1084,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         c->it_cap = max_iteration;
     }
     if (max_iteration <= 0 && c->n) OP_HIP(hipMemsetAsync(c->nn, 0xff, c->n * sizeof(int), c->stream)); // corresponding_index stays -1
+    OP_HIP(hipMemsetAsync(c->sync, 0, (kGroups + 1) * sizeof(unsigned), c->stream)); // the counters reset themselves; this covers an aborted launch
     OP_HIP(hipMemcpyAsync(c->T_dev, init_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     // ICP.cpp:177-199.  Point-to-point: the Kabsch step is cheap enough for one GPU thread, so the
     // whole loop is enqueued back to back with the update in k_reduce_update (no host round trip).
@@ -1287,7 +1392,7 @@ int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int m
     if (e == hipSuccess) {
         const float cell = 1.0f / c->grid.inv_cell;
         hipLaunchKernelGGL(k_estimate_normals, dim3((unsigned)((n + kNrmThreads - 1) / kNrmThreads)), dim3(kNrmThreads), 0, c->stream, c->grid,
-                           (const unsigned*)c->cell_start, (const unsigned*)c->cell_count, (const float4*)c->tgt, n, knn, radius, cell, d_nrm);
+                           (const unsigned*)c->cell_start, (const float4*)c->tgt, n, knn, radius, cell, d_nrm);
         e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(normals_out, d_nrm, n * 12, mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);

@@ -94,6 +94,21 @@ int main(int argc, char** argv) {
                 printf("rep %d %s: %zu x %zu points, 30 iterations in %.3f ms (%.0f it/s), inliers %llu, rmse %.6g\n", r, mode ? "point-to-plane" : "point-to-point",
                        ns, nt, dt * 1e3, 30 / dt, (unsigned long long)res.n_inliers, res.rmse);
             }
+        // the loop alone: the difference of a 70- and a 10-iteration call (the final pass and the finish cancel)
+        for (int mode = 1; mode >= 0; --mode) {
+            double best[2] = {1e9, 1e9};
+            const int its[2] = {10, 70};
+            for (int r = 0; r < 5; ++r)
+                for (int k = 0; k < 2; ++k) {
+                    op_icp_result res;
+                    auto t0 = std::chrono::steady_clock::now();
+                    CK(op_icp_run(icp, mode, I4, its[k], &res, nullptr, 0, nullptr, nullptr));
+                    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (dt < best[k]) best[k] = dt;
+                }
+            printf("%s loop only: %.2f us/iteration (%.0f it/s); final pass + finish %.3f ms\n", mode ? "point-to-plane" : "point-to-point",
+                   (best[1] - best[0]) / 60 * 1e6, 60 / (best[1] - best[0]), (best[0] - 10 * (best[1] - best[0]) / 60) * 1e3);
+        }
         op_icp_destroy(icp);
         op_volume_destroy(v);
         return 0;
