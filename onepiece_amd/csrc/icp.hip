@@ -22,6 +22,7 @@
 #include <cfloat>
 #include <climits>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -38,7 +39,14 @@ constexpr int kNSums = 32;      // doubles per partial: sums[0..26], [27] = sum_
 #define ICP_THREADS 256
 #endif
 constexpr int kIterThreads = ICP_THREADS;
-constexpr int kScan = 8;          // candidates fetched per trip of the neighbour scan
+#ifndef ICP_SCAN_C
+#define ICP_SCAN_C 8
+#endif
+#ifndef ICP_SCAN_R
+#define ICP_SCAN_R 8
+#endif
+constexpr int kScanC = ICP_SCAN_C; // candidates fetched per trip of the neighbour scan: centre row,
+constexpr int kScan = ICP_SCAN_R;  // the other rows
 constexpr unsigned long long kMaxCells = 1ull << 26;
 constexpr size_t kMaxPoints = (size_t)1 << 28; // 16-byte records and 12-byte points are addressed with 32-bit byte offsets
 
@@ -191,8 +199,10 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, size_t m, Grid g,
 //
 // The kernel also finishes the reduction itself (no second-pass kernels on the per-iteration critical path): every
 // workgroup writes its row of partial sums, the LAST workgroup of each group of `per_group` rows to arrive folds that
-// group into one stage row, and the last group to finish folds the stage rows, writes the totals and publishes them
-// to the host.  Who does the folding depends on timing, what is added in which order does not, so the sums are
+// group into one stage row, and the last group to finish folds the stage rows and writes the totals.  In the
+// host-solve loop (host_out != nullptr) the chain is cut short: each group's row is written to host-mapped pinned
+// memory with a sequence number, and the host, which needs the totals anyway, adds the (at most 32) rows in group
+// order -- three device-memory round trips less on the critical path of every iteration.  Who does the folding depends on timing, what is added in which order does not, so the sums are
 // reproducible bit for bit.  sync[0..kGroups-1] count the arrivals per group, sync[kGroups] the finished groups; the
 // workgroup that completes a count resets it for the next launch.
 constexpr int kGroups = 32;
@@ -217,6 +227,13 @@ __device__ __forceinline__ void wait_stores_then_barrier() {
     __syncthreads();
 }
 
+#ifdef ICP_TRACE // development aid (make EXTRA=-DICP_TRACE): per-wave timestamps of the phases of the last launch, dumped by op_icp_destroy
+__device__ unsigned long long g_icp_trace[8 * 8192];
+#define ICP_STAMP(K) do { __builtin_amdgcn_s_waitcnt(0); if ((threadIdx.x & 63) == 0 && MODE == 1) g_icp_trace[(blockIdx.x * (kIterThreads / 64) + (threadIdx.x >> 6)) * 8 + (K)] = wall_clock64(); } while (0)
+#else
+#define ICP_STAMP(K) do { } while (0)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restrict__ T, Mat4 T_arg, const float* __restrict__ src, unsigned n, Grid g,
                                                            const unsigned* __restrict__ cell_start, const float4* __restrict__ tgt, unsigned dummy,
@@ -239,6 +256,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     // target; with the plain order every XCD's L2 would see all of target + normals + cell tables (> 4 MiB)
     const unsigned wg = op::xcd_slab_index(blockIdx.x, gridDim.x);
     const unsigned i = wg * (unsigned)kIterThreads + threadIdx.x;
+    ICP_STAMP(0);
     if (i < n) {
         const F3 sp = ld_off<F3>(src, 12u * i);
         const float s0 = sp.x, s1 = sp.y, s2 = sp.z;
@@ -298,6 +316,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                         if (q == 4) { cb = rb; ce = re; }
                         else s_runs[q < 4 ? q : q - 1][threadIdx.x] = make_uint2(rb, re);
                     }
+                    ICP_STAMP(1);
                     // one candidate.  Slots past the end of a lane's candidates read the dummy record tgt[dummy] (+inf
                     // coordinates: its distance is +inf, above FLT_MAX, so it never wins), which keeps the scan free of
                     // per-candidate branches.
@@ -309,12 +328,12 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                     };
                     // 1. the centre row (dy,dz) = (0,0), kScan candidates per trip: the loads are independent, so their
                     //    L2 round trips overlap (the scan is a latency chain otherwise)
-                    for (unsigned p = cb; p < ce; p += kScan) {
-                        float4 c[kScan];
+                    for (unsigned p = cb; p < ce; p += kScanC) {
+                        float4 c[kScanC];
 #pragma unroll
-                        for (int k = 0; k < kScan; ++k) c[k] = ld_off<float4>(tgt, 16u * (p + k < ce ? p + k : dummy));
+                        for (int k = 0; k < kScanC; ++k) c[k] = ld_off<float4>(tgt, 16u * (p + k < ce ? p + k : dummy));
 #pragma unroll
-                        for (int k = 0; k < kScan; ++k) visit(c[k]);
+                        for (int k = 0; k < kScanC; ++k) visit(c[k]);
                     }
                     // 2. the other 8 rows: those that can still hold the nearest neighbour are decided NOW, with the centre
                     //    row's best distance, and their runs are walked as ONE flattened candidate stream.  A wave then
@@ -322,6 +341,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                     //    ANY of its lanes still needs (the union over 64 lanes is almost always all 8 rows).  The runs of a
                     //    lane sit in its private LDS column, which a dynamic index reaches without scratch memory; the
                     //    survivors are compacted in place (nr never overtakes the slot being read).
+                    ICP_STAMP(2);
                     const float best_d = __uint_as_float((unsigned)(best_key >> 32));
                     int nr = 0;
 #pragma unroll
@@ -349,6 +369,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                     }
                 }
             }
+            ICP_STAMP(3);
             best = best_key != kNoKey ? (int)(unsigned)best_key : -1;
             nn[i] = best;
         } else {
@@ -369,6 +390,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         a0 = MODE == 2 ? s0 : tp0; a1 = MODE == 2 ? s1 : tp1; a2 = MODE == 2 ? s2 : tp2;
         if (inl) inl[i] = inlier ? best : -1;
     }
+    ICP_STAMP(4);
     double acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
@@ -405,6 +427,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         st_coherent(partials + (size_t)wg * kNSums + threadIdx.x, v); // logical order: the folds below sum in source order
     }
 
+    ICP_STAMP(5);
     // ---- cross-workgroup finish ----
     constexpr int kRows = kIterThreads / 32;      // row lanes of the folds below
     const int fk = threadIdx.x & 31, fr = threadIdx.x >> 5;
@@ -417,6 +440,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         if (s_last) __hip_atomic_store(&sync[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    ICP_STAMP(6);
     if (!s_last) return;
     {
         const unsigned lo = grp * per_group, hi = min(lo + per_group, gridDim.x);
@@ -429,10 +453,18 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         if (threadIdx.x < kNSums) {
             double t = 0;
             for (int r = 0; r < kRows; ++r) t += s_fin[r][threadIdx.x];
-            st_coherent(stage + (size_t)grp * kNSums + threadIdx.x, t);
+            if (host_out) { // host-solve loop: the group's row goes straight to host-mapped pinned memory, the host folds the rows
+                if (threadIdx.x < kNSums - 1) __hip_atomic_store(&host_out[(size_t)grp * kNSums + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                st_coherent(stage + (size_t)grp * kNSums + threadIdx.x, t);
+            }
         }
     }
     wait_stores_then_barrier();
+    if (host_out) { // publish the row: the host spins on this sequence number (one per group)
+        if (threadIdx.x == 0) __hip_atomic_store(&host_out[(size_t)grp * kNSums + kNSums - 1], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add(&sync[kGroups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev + 1u == n_groups;
@@ -449,13 +481,6 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             double t = 0;
             for (int r = 0; r < kRows; ++r) t += s_fin[r][threadIdx.x];
             out[threadIdx.x] = t;
-            if (host_out && threadIdx.x < kNSums - 1) // host-mapped pinned memory
-                __hip_atomic_store(&host_out[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if (host_out) {
-            wait_stores_then_barrier();
-            if (threadIdx.x == 0) // publish: the host spins on this sequence number
-                __hip_atomic_store(&host_out[kNSums - 1], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -991,9 +1016,9 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     OP_HIP_C(hipMalloc((void**)&c->result, kNSums * sizeof(double)));
     OP_HIP_C(hipMalloc((void**)&c->T_dev, 16 * sizeof(float)));
     OP_HIP_C(hipMalloc((void**)&c->stage, (size_t)std::max(kStage1, kGroups) * kNSums * sizeof(double)));
-    OP_HIP_C(hipHostMalloc((void**)&c->result_host, kNSums * sizeof(double), hipHostMallocMapped));
+    OP_HIP_C(hipHostMalloc((void**)&c->result_host, (size_t)kGroups * kNSums * sizeof(double), hipHostMallocMapped));
     OP_HIP_C(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0));
-    std::memset(c->result_host, 0, kNSums * sizeof(double));
+    std::memset(c->result_host, 0, (size_t)kGroups * kNSums * sizeof(double));
 #undef OP_HIP_C
     *out = c;
     return OP_OK;
@@ -1003,6 +1028,20 @@ int op_icp_destroy(op_icp* c) {
     if (!c) return OP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifdef ICP_TRACE
+    {
+        std::vector<unsigned long long> t(8 * 8192);
+        (void)hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_icp_trace), t.size() * 8);
+        const int nw = c->n_wg * (kIterThreads / 64);
+        unsigned long long t0 = ~0ull, t_end = 0;
+        for (int w = 0; w < nw; ++w) { t0 = std::min(t0, t[w * 8]); t_end = std::max(t_end, t[w * 8 + 6]); }
+        double sum[7] = {0}, mx[7] = {0};
+        for (int w = 0; w < nw; ++w)
+            for (int k = 0; k < 7; ++k) { const double d = (double)(t[w * 8 + k] - (k ? t[w * 8 + k - 1] : t0)); sum[k] += d; mx[k] = std::max(mx[k], d); }
+        fprintf(stderr, "icp trace (10 ns ticks, %d waves): span %llu; mean/max start %.0f/%.0f cells %.0f/%.0f centre %.0f/%.0f rest %.0f/%.0f gather %.0f/%.0f reduce %.0f/%.0f arrive %.0f/%.0f\n",
+                nw, t_end - t0, sum[0] / nw, mx[0], sum[1] / nw, mx[1], sum[2] / nw, mx[2], sum[3] / nw, mx[3], sum[4] / nw, mx[4], sum[5] / nw, mx[5], sum[6] / nw, mx[6]);
+    }
+#endif
     void* ptrs[] = {c->tgt_orig, c->tgt, c->sync, c->cell_start, c->src, c->nn, c->inl, c->partials, c->result,
                     c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage, c->nrm_orig, c->flag, c->start, c->scan_tot, c->rows_dev};
     for (void* p : ptrs)
@@ -1128,19 +1167,38 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         float cur[16], tmp_T[16];
         std::memcpy(cur, init_T, sizeof(cur));
         volatile double* pub = c->result_host;
+#ifdef ICP_TRACE
+        double tr_launch = 0, tr_wait = 0, tr_solve = 0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#endif
         for (int it = 0; it < max_iteration; ++it) {
             c->seq += 1.0;
+#ifdef ICP_TRACE
+            const double ta = now();
+#endif
             launch_pass<1>(c, false, 0, it, false, cur, c->seq);
             OP_HIP(hipGetLastError());
-            for (unsigned spin = 0; pub[kNSums - 1] != c->seq; ++spin) {
-                if ((spin & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) { // finished or failed
-                    OP_HIP(hipStreamSynchronize(c->stream));
-                    if (pub[kNSums - 1] != c->seq) return fail(OP_ERR_HIP, "icp: the reduce kernel did not publish its result");
-                    break;
+#ifdef ICP_TRACE
+            const double tb = now();
+#endif
+            // one row per group of workgroups, each published with the sequence number; added in group order
+            const int per_group = (c->n_wg + kGroups - 1) / kGroups, n_groups = (c->n_wg + per_group - 1) / per_group;
+            for (int k = 0; k < kNSums; ++k) r[k] = 0.0;
+            for (int g = 0; g < n_groups; ++g) {
+                volatile double* row = pub + (size_t)g * kNSums;
+                for (unsigned spin = 0; row[kNSums - 1] != c->seq; ++spin) {
+                    if ((spin & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) { // finished or failed
+                        OP_HIP(hipStreamSynchronize(c->stream));
+                        if (row[kNSums - 1] != c->seq) return fail(OP_ERR_HIP, "icp: the iteration kernel did not publish its sums");
+                        break;
+                    }
+                    __builtin_ia32_pause();
                 }
-                __builtin_ia32_pause();
+                for (int k = 0; k < kNSums - 1; ++k) r[k] += row[k];
             }
-            for (int k = 0; k < kNSums - 1; ++k) r[k] = pub[k];
+#ifdef ICP_TRACE
+            const double tc = now();
+#endif
             double JTJ[36], JTr[6];
             float x[6];
             expand_plane_sums(r, JTJ, JTr);
@@ -1149,7 +1207,15 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             op_host::mat4_mul(tmp_T, cur, cur); // ICP.cpp:198
             if (per_iter_inliers) per_iter_inliers[it] = (int32_t)(r[28] + 0.5);
             if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
+#ifdef ICP_TRACE
+            tr_launch += tb - ta; tr_wait += tc - tb; tr_solve += now() - tc;
+#endif
         }
+#ifdef ICP_TRACE
+        if (max_iteration > 0)
+            fprintf(stderr, "icp host trace: per iteration launch call %.2f us, wait for sums %.2f us, solve %.2f us\n", tr_launch / max_iteration * 1e6,
+                    tr_wait / max_iteration * 1e6, tr_solve / max_iteration * 1e6);
+#endif
         OP_HIP(hipMemcpyAsync(c->T_dev, cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
         OP_HIP(hipStreamSynchronize(c->stream)); // `cur` is a stack buffer
     }
