@@ -13,6 +13,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 
 #include "px_round.hpp" // OP_HD: __host__ __device__ under hipcc (the ICP update step also runs on the device)
 
@@ -293,24 +296,83 @@ OP_HD void kabsch_from_sums(double n, const double ss[3], const double st[3], co
 // entry; no FMA in its -msse4.2 build).  Over 3e5 near-planar pairs that rounding noise is ~1e-3 of the result, and it
 // is part of what RegistrationResult::T is -- so this is what op_icp_run returns by default.  pairs: n x 6 floats
 // (source xyz, target xyz) in correspondence_set order (ascending source index).
+//
+// KabschReferenceOrder does the two sequential passes incrementally (rows may arrive in chunks while the first pass
+// runs) and, on x86, four components per SSE instruction.  Every component still sees exactly the reference's
+// operations in the reference's order -- one rounded add per row and sum, one rounded multiply and one rounded add per
+// row and W entry (mulps/addps, never fused) -- so the result is bit-identical to the scalar loops; what the vector
+// form buys is that a row costs one add latency per pass instead of ~5 cycles of scalar issue.
+struct KabschReferenceOrder {
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+    __m128 sum_a = _mm_setzero_ps(), sum_b = _mm_setzero_ps(); // (s0,s1,s2,t0), (s2,t0,t1,t2): lanes 0,1 of sum_b are duplicates
+    // first pass (:122-127): rows [first, first + count) of n x 6 floats
+    void add_rows(const float* pairs, size_t count) {
+        __m128 a = sum_a, b = sum_b;
+        for (size_t i = 0; i < count; ++i) {
+            a = _mm_add_ps(a, _mm_loadu_ps(pairs + 6 * i));
+            b = _mm_add_ps(b, _mm_loadu_ps(pairs + 6 * i + 2));
+        }
+        sum_a = a; sum_b = b;
+    }
+    void sums(float ms[3], float mt[3]) const {
+        float a[4], b[4];
+        _mm_storeu_ps(a, sum_a); _mm_storeu_ps(b, sum_b);
+        ms[0] = a[0]; ms[1] = a[1]; ms[2] = a[2]; mt[0] = a[3]; mt[1] = b[2]; mt[2] = b[3];
+    }
+    // second pass (:130-133)
+    static void cross(const float* pairs, size_t n, const float ms[3], const float mt[3], float W[9]) {
+        const __m128 ma = _mm_setr_ps(ms[0], ms[1], ms[2], mt[0]), mb = _mm_setr_ps(ms[2], mt[0], mt[1], mt[2]);
+        __m128 w0 = _mm_setzero_ps(), w1 = _mm_setzero_ps(), w2 = _mm_setzero_ps(); // rows of W in lanes 1..3 (lane 0 unused)
+        for (size_t i = 0; i < n; ++i) {
+            const __m128 a = _mm_sub_ps(_mm_loadu_ps(pairs + 6 * i), ma);     // (a0, a1, a2, b0)
+            const __m128 b = _mm_sub_ps(_mm_loadu_ps(pairs + 6 * i + 2), mb); // (a2, b0, b1, b2)
+            w0 = _mm_add_ps(w0, _mm_mul_ps(_mm_shuffle_ps(a, a, _MM_SHUFFLE(0, 0, 0, 0)), b));
+            w1 = _mm_add_ps(w1, _mm_mul_ps(_mm_shuffle_ps(a, a, _MM_SHUFFLE(1, 1, 1, 1)), b));
+            w2 = _mm_add_ps(w2, _mm_mul_ps(_mm_shuffle_ps(a, a, _MM_SHUFFLE(2, 2, 2, 2)), b));
+        }
+        float r[3][4];
+        _mm_storeu_ps(r[0], w0); _mm_storeu_ps(r[1], w1); _mm_storeu_ps(r[2], w2);
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 3; ++c) W[k * 3 + c] = r[k][1 + c];
+    }
+#else
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    void add_rows(const float* pairs, size_t count) {
+        for (size_t i = 0; i < count; ++i)
+            for (int c = 0; c < 6; ++c) acc[c] += pairs[6 * i + c];
+    }
+    void sums(float ms[3], float mt[3]) const { for (int c = 0; c < 3; ++c) { ms[c] = acc[c]; mt[c] = acc[3 + c]; } }
+    static void cross(const float* pairs, size_t n, const float ms[3], const float mt[3], float W[9]) {
+        for (int k = 0; k < 9; ++k) W[k] = 0.0f;
+        for (size_t i = 0; i < n; ++i) {
+            float a[3], b[3];
+            for (int c = 0; c < 3; ++c) { a[c] = pairs[6 * i + c] - ms[c]; b[c] = pairs[6 * i + 3 + c] - mt[c]; }
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) W[r * 3 + c] += a[r] * b[c];
+        }
+    }
+#endif
+    // the fit, once add_rows has seen all n rows (rows n-1's loads read pairs[6n-4 .. 6n-1]: inside the array)
+    template <bool FULL>
+    void finish(const float* pairs, size_t n, float T[16]) const {
+        float ms[3], mt[3], W[9];
+        sums(ms, mt);
+        for (int c = 0; c < 3; ++c) { ms[c] /= static_cast<float>(n); mt[c] /= static_cast<float>(n); } // :128-129
+        cross(pairs, n, ms, mt, W);
+        double dms[3], dmt[3], dW[3][3];
+        for (int i = 0; i < 3; ++i) {
+            dms[i] = ms[i]; dmt[i] = mt[i];
+            for (int j = 0; j < 3; ++j) dW[i][j] = W[i * 3 + j];
+        }
+        kabsch_finish<FULL>(dms, dmt, dW, T);
+    }
+};
+
 template <bool FULL = false>
 inline void kabsch_reference_order(const float* pairs, size_t n, float T[16]) {
-    float ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0}, W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < n; ++i)
-        for (int c = 0; c < 3; ++c) { ms[c] += pairs[6 * i + c]; mt[c] += pairs[6 * i + 3 + c]; } // :122-127
-    for (int c = 0; c < 3; ++c) { ms[c] /= static_cast<float>(n); mt[c] /= static_cast<float>(n); } // :128-129
-    for (size_t i = 0; i < n; ++i) { // :130-133
-        float a[3], b[3];
-        for (int c = 0; c < 3; ++c) { a[c] = pairs[6 * i + c] - ms[c]; b[c] = pairs[6 * i + 3 + c] - mt[c]; }
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) W[r * 3 + c] += a[r] * b[c];
-    }
-    double dms[3], dmt[3], dW[3][3];
-    for (int i = 0; i < 3; ++i) {
-        dms[i] = ms[i]; dmt[i] = mt[i];
-        for (int j = 0; j < 3; ++j) dW[i][j] = W[i * 3 + j];
-    }
-    kabsch_finish<FULL>(dms, dmt, dW, T);
+    KabschReferenceOrder k;
+    k.add_rows(pairs, n);
+    k.finish<FULL>(pairs, n, T);
 }
 
 // registration::EstimateRigidTransformationPointToPlane's accumulation in the REFERENCE'S ORDER (ICP.cpp:121-136):

@@ -488,13 +488,13 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
 // PointToPoint's per-iteration step on the device (ICP.cpp:76-79, :195-198): one thread does the Kabsch fit from the
 // totals and left-multiplies start_T, so the whole loop is enqueued without a host round trip.
 __global__ void k_point_update(const double* __restrict__ tot, float* __restrict__ T, int it, int* __restrict__ per_iter_inliers,
-                               float* __restrict__ per_iter_T) {
+                               float* __restrict__ per_iter_T, float* __restrict__ T_pub /* host-mapped copy of start_T */) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float tmp_T[16], cur[16];
     op_host::kabsch_from_sums(tot[28], tot, tot + 3, tot + 6, tmp_T); // ICP.cpp:79
     for (int i = 0; i < 16; ++i) cur[i] = T[i];
     op_host::mat4_mul(tmp_T, cur, cur);   // ICP.cpp:198: start_T = tmp_T * start_T
-    for (int i = 0; i < 16; ++i) T[i] = cur[i];
+    for (int i = 0; i < 16; ++i) { T[i] = cur[i]; T_pub[i] = cur[i]; }
     if (per_iter_inliers) per_iter_inliers[it] = (int)(tot[28] + 0.5);
     if (per_iter_T) for (int i = 0; i < 16; ++i) per_iter_T[16 * it + i] = cur[i];
 }
@@ -837,6 +837,9 @@ struct op_icp {
     double* result_host = nullptr;      // pinned + mapped: k_reduce_update publishes the sums here (host-solve path)
     double* result_host_dev = nullptr;  // its device-side address
     double seq = 0.0;                   // publication sequence number
+    float* T_pub = nullptr;             // pinned + mapped: start_T as the device-side PointToPoint loop leaves it
+    float* T_pub_dev = nullptr;
+    hipEvent_t chunk_ev[8] = {};        // arrival of the chunks of inlier rows at the host (reference-order finish)
     float* T_dev = nullptr;        // start_T (16 floats)
     int* it_inl_dev = nullptr;     // per-iteration inlier counts
     float* it_T_dev = nullptr;     // per-iteration start_T
@@ -854,17 +857,38 @@ namespace {
 
 // one fused pass (transform + NN + inliers + sums + reduction); start_T is read from c->T_dev unless host_T is given.
 template <int MODE>
-void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace, const float* host_T = nullptr, double seq = 0.0) {
+void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace, const float* host_T = nullptr, double seq = 0.0, bool publish = false) {
     Mat4 Tv;
     if (host_T) std::memcpy(Tv.m, host_T, sizeof(Tv.m)); else std::memset(Tv.m, 0, sizeof(Tv.m));
     const unsigned per_group = (unsigned)((c->n_wg + kGroups - 1) / kGroups);
     hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
                        (const float*)c->src, (unsigned)c->n, c->grid, (const unsigned*)c->cell_start, (const float4*)c->tgt, (unsigned)c->m,
                        (const float*)c->tgt_orig, (const float*)c->nrm_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials,
-                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq);
+                       c->stage, c->sync, per_group, c->result, host_T || publish ? c->result_host_dev : nullptr, seq);
     if (update) // point-to-point: the Kabsch step follows on the device
         hipLaunchKernelGGL(k_point_update, dim3(1), dim3(64), 0, c->stream, (const double*)c->result, c->T_dev, it, trace ? c->it_inl_dev : nullptr,
-                           trace ? c->it_T_dev : nullptr);
+                           trace ? c->it_T_dev : nullptr, c->T_pub_dev);
+}
+
+// Waits for the rows of sums the launch with sequence number c->seq publishes (one per group of workgroups, in
+// host-mapped pinned memory) and adds them in group order.
+int wait_rows(op_icp* c, double r[kNSums]) {
+    volatile double* pub = c->result_host;
+    const int per_group = (c->n_wg + kGroups - 1) / kGroups, n_groups = (c->n_wg + per_group - 1) / per_group;
+    for (int k = 0; k < kNSums; ++k) r[k] = 0.0;
+    for (int g = 0; g < n_groups; ++g) {
+        volatile double* row = pub + (size_t)g * kNSums;
+        for (unsigned spin = 0; row[kNSums - 1] != c->seq; ++spin) {
+            if ((spin & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) { // finished or failed
+                OP_HIP(hipStreamSynchronize(c->stream));
+                if (row[kNSums - 1] != c->seq) return fail(OP_ERR_HIP, "icp: the iteration kernel did not publish its sums");
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        for (int k = 0; k < kNSums - 1; ++k) r[k] += row[k];
+    }
+    return OP_OK;
 }
 
 int enqueue_pass(op_icp* c, int mode, bool write_inl, int update, int it, bool trace) {
@@ -894,7 +918,7 @@ void expand_plane_sums(const double in[kNSums], double JTJ[36], double JTr[6]) {
 // Compacts the rows of the current inlier set (c->inl, written by a pass with write_inl) in ascending source
 // index, copies the first n_rows of them to pinned host memory and waits.  The transform is read from c->T_dev.
 int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
-    *rows = nullptr;
+    if (rows) *rows = nullptr;
     if (!c->n || !n_rows) return OP_OK;
     if (c->rows_cap < c->n) {
         void* old[] = {c->flag, c->start, c->scan_tot, c->rows_dev};
@@ -921,6 +945,7 @@ int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
     if (kind == 1) OP_EMIT(1); else if (kind == 2) OP_EMIT(2); else OP_EMIT(0);
 #undef OP_EMIT
     OP_HIP(hipGetLastError());
+    if (!rows) return OP_OK; // enqueue only: the caller copies c->rows_dev itself
     const size_t w = kind == 1 ? 9 : 6;
     OP_HIP(hipMemcpyAsync(c->rows_host, c->rows_dev, n_rows * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     OP_HIP(hipStreamSynchronize(c->stream));
@@ -1019,6 +1044,9 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     OP_HIP_C(hipHostMalloc((void**)&c->result_host, (size_t)kGroups * kNSums * sizeof(double), hipHostMallocMapped));
     OP_HIP_C(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0));
     std::memset(c->result_host, 0, (size_t)kGroups * kNSums * sizeof(double));
+    OP_HIP_C(hipHostMalloc((void**)&c->T_pub, 16 * sizeof(float), hipHostMallocMapped));
+    OP_HIP_C(hipHostGetDevicePointer((void**)&c->T_pub_dev, c->T_pub, 0));
+    for (hipEvent_t& ev : c->chunk_ev) OP_HIP_C(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 #undef OP_HIP_C
     *out = c;
     return OP_OK;
@@ -1047,6 +1075,9 @@ int op_icp_destroy(op_icp* c) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->result_host) (void)hipHostFree(c->result_host);
+    if (c->T_pub) (void)hipHostFree(c->T_pub);
+    for (hipEvent_t ev : c->chunk_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->rows_host) (void)hipHostFree(c->rows_host);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1159,14 +1190,12 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             if (per_iter_inliers) per_iter_inliers[it] = (int32_t)n_it;
             if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
         }
-        OP_HIP(hipMemcpyAsync(c->T_dev, cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
-        OP_HIP(hipStreamSynchronize(c->stream));
+        std::memcpy(start_T, cur, sizeof(cur));
     } else if (!host_path) {
         for (int it = 0; it < max_iteration; ++it) OP_TRY(enqueue_pass(c, 0, false, 2, it, true));
     } else {
         float cur[16], tmp_T[16];
         std::memcpy(cur, init_T, sizeof(cur));
-        volatile double* pub = c->result_host;
 #ifdef ICP_TRACE
         double tr_launch = 0, tr_wait = 0, tr_solve = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1181,21 +1210,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
 #ifdef ICP_TRACE
             const double tb = now();
 #endif
-            // one row per group of workgroups, each published with the sequence number; added in group order
-            const int per_group = (c->n_wg + kGroups - 1) / kGroups, n_groups = (c->n_wg + per_group - 1) / per_group;
-            for (int k = 0; k < kNSums; ++k) r[k] = 0.0;
-            for (int g = 0; g < n_groups; ++g) {
-                volatile double* row = pub + (size_t)g * kNSums;
-                for (unsigned spin = 0; row[kNSums - 1] != c->seq; ++spin) {
-                    if ((spin & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) { // finished or failed
-                        OP_HIP(hipStreamSynchronize(c->stream));
-                        if (row[kNSums - 1] != c->seq) return fail(OP_ERR_HIP, "icp: the iteration kernel did not publish its sums");
-                        break;
-                    }
-                    __builtin_ia32_pause();
-                }
-                for (int k = 0; k < kNSums - 1; ++k) r[k] += row[k];
-            }
+            OP_TRY(wait_rows(c, r));
 #ifdef ICP_TRACE
             const double tc = now();
 #endif
@@ -1216,19 +1231,26 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             fprintf(stderr, "icp host trace: per iteration launch call %.2f us, wait for sums %.2f us, solve %.2f us\n", tr_launch / max_iteration * 1e6,
                     tr_wait / max_iteration * 1e6, tr_solve / max_iteration * 1e6);
 #endif
-        OP_HIP(hipMemcpyAsync(c->T_dev, cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
-        OP_HIP(hipStreamSynchronize(c->stream)); // `cur` is a stack buffer
+        std::memcpy(start_T, cur, sizeof(cur));
     }
     // ICP.cpp:206-221: CountInliers with the final start_T over the last NN set, then Kabsch over
     // (original source, target) pairs
-    OP_TRY(enqueue_pass(c, 2, true, 0, 0, false));
-    OP_HIP(hipMemcpyAsync(r, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    OP_HIP(hipMemcpyAsync(start_T, c->T_dev, sizeof(start_T), hipMemcpyDeviceToHost, c->stream));
-    OP_HIP(hipStreamSynchronize(c->stream));
-    if (!host_path && per_iter_inliers && max_iteration > 0)
-        OP_HIP(hipMemcpy(per_iter_inliers, c->it_inl_dev, (size_t)max_iteration * sizeof(int), hipMemcpyDeviceToHost));
-    if (!host_path && per_iter_T && max_iteration > 0)
-        OP_HIP(hipMemcpy(per_iter_T, c->it_T_dev, (size_t)max_iteration * 16 * sizeof(float), hipMemcpyDeviceToHost));
+    // The sums of the final pass come back like the loop's (rows in host-mapped memory, no copy, no stream sync); the
+    // final start_T is already on the host in the host-solve loops, the device-side PointToPoint loop leaves it in T_pub.
+    c->seq += 1.0;
+    if (host_path) {
+        std::memcpy(c->T_pub, start_T, sizeof(start_T)); // T_dev is what the row emission below reads
+        OP_HIP(hipMemcpyAsync(c->T_dev, c->T_pub, sizeof(start_T), hipMemcpyHostToDevice, c->stream));
+        launch_pass<2>(c, true, 0, 0, false, start_T, c->seq);
+    } else {
+        launch_pass<2>(c, true, 0, 0, false, nullptr, c->seq, true);
+    }
+    OP_HIP(hipGetLastError());
+    OP_TRY(wait_rows(c, r));
+    if (!host_path) {
+        if (max_iteration > 0) std::memcpy(start_T, c->T_pub, sizeof(start_T)); // written by the last k_point_update, which precedes the final pass
+        else std::memcpy(start_T, init_T, sizeof(start_T));
+    }
     const double n_inl = r[28];
     result->n_inliers = (uint64_t)(n_inl + 0.5);
     result->rmse = std::sqrt(r[27] / n_inl);
@@ -1237,13 +1259,34 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     if (c->finish == OP_ICP_FINISH_REFERENCE) {
         // RegistrationResult::T as the reference forms it (ICP.cpp:215-221 -> Geometry.cpp:117-133): sequential
         // float32 sums over the correspondence_set in ascending source index
-        const float* rows = nullptr;
-        OP_TRY(emit_rows(c, 0, (size_t)result->n_inliers, &rows));
-        if (strict) op_host::kabsch_reference_order<true>(rows, (size_t)result->n_inliers, result->T);
-        else op_host::kabsch_reference_order(rows, (size_t)result->n_inliers, result->T);
+        // the rows come up in chunks and the first of the two sequential passes runs on each chunk as it lands
+        const size_t n_rows = (size_t)result->n_inliers;
+        OP_TRY(emit_rows(c, 0, n_rows, nullptr));
+        op_host::KabschReferenceOrder fit;
+        constexpr size_t kChunks = sizeof(c->chunk_ev) / sizeof(c->chunk_ev[0]);
+        const size_t per = (n_rows + kChunks - 1) / kChunks;
+        size_t n_ev = 0;
+        for (size_t lo = 0; lo < n_rows; lo += per, ++n_ev) {
+            const size_t cnt = std::min(per, n_rows - lo);
+            OP_HIP(hipMemcpyAsync(c->rows_host + 6 * lo, c->rows_dev + 6 * lo, cnt * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            OP_HIP(hipEventRecord(c->chunk_ev[n_ev], c->stream));
+        }
+        for (size_t k = 0, lo = 0; k < n_ev; ++k, lo += per) {
+            hipError_t q;
+            while ((q = hipEventQuery(c->chunk_ev[k])) == hipErrorNotReady) __builtin_ia32_pause();
+            if (q != hipSuccess) return fail(OP_ERR_HIP, "icp: copying the inlier rows failed: %s", hipGetErrorString(q));
+            fit.add_rows(c->rows_host + 6 * lo, std::min(per, n_rows - lo));
+        }
+        if (strict) fit.finish<true>(c->rows_host, n_rows, result->T);
+        else fit.finish<false>(c->rows_host, n_rows, result->T);
     } else {
         op_host::kabsch_from_sums(n_inl, r, r + 3, r + 6, result->T); // order-free fp64 reduction
     }
+    OP_HIP(hipStreamSynchronize(c->stream)); // the sums were read from published rows: the stream itself may still be draining
+    if (!host_path && per_iter_inliers && max_iteration > 0)
+        OP_HIP(hipMemcpy(per_iter_inliers, c->it_inl_dev, (size_t)max_iteration * sizeof(int), hipMemcpyDeviceToHost));
+    if (!host_path && per_iter_T && max_iteration > 0)
+        OP_HIP(hipMemcpy(per_iter_T, c->it_T_dev, (size_t)max_iteration * 16 * sizeof(float), hipMemcpyDeviceToHost));
     if (pairs && c->n) {
         std::vector<int> inl(c->n);
         OP_HIP(hipMemcpy(inl.data(), c->inl, c->n * sizeof(int), hipMemcpyDeviceToHost));
