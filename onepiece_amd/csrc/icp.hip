@@ -16,7 +16,7 @@
 // target is counting-sorted by cell into float4 records (xyz + original index) so candidate reads
 // are contiguous 16-byte loads.  One kernel per iteration fuses transform + NN + inlier test + the
 // normal-equation contributions; the 27 (plane) / 15 (point) sums are reduced in fp64 with
-// wave64 shuffles, then LDS across the 4 waves of a workgroup, then one tiny second-pass kernel.
+// wave64 shuffles, then LDS across the 4 waves of a workgroup, then across workgroups by the last ones to arrive.
 // The 6x6 solve / SE3 exp / Kabsch stay on the host (host_math.hpp) exactly as north_star asks;
 // this accumulation is 2*27*N flops -- not a dense contraction, so no MFMA.
 #include <cfloat>
