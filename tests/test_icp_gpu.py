@@ -253,3 +253,43 @@ def test_non_finite_points_are_ignored_not_fatal(oracle):
     # a target that is ONLY non-finite: empty grid, no inliers, no hang
     none = R.PointToPoint(R.PointCloud(src), R.PointCloud(bad), None, R.ICPParameter(2, 0.05))
     assert len(none.correspondence_set_index) == 0
+
+
+@pytest.mark.parametrize("n", [1, 63, 257, 8193, 70001])
+def test_iteration_sums_are_additive_over_a_split_of_the_source(n):
+    """The iteration kernel folds its per-workgroup rows itself (last workgroup of a group to arrive, then the last group).
+    Size-independent property: the sums over a source cloud equal the sums over its two halves -- exactly for the inlier
+    count, to fp64 rounding for the rest -- for ragged sizes (1 workgroup, partial workgroups, fewer groups than 32,
+    uneven groups) and both residual kinds; and the same call twice gives the same bits."""
+    import ctypes as C
+    from onepiece_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(n)
+    m = 20000
+    tgt = (rng.uniform(-1, 1, (m, 3)) * np.array([1.0, 0.7, 0.4])).astype(np.float32)
+    nrm = rng.normal(size=(m, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    src = (tgt[rng.integers(0, m, n)] + rng.normal(scale=0.004, size=(n, 3))).astype(np.float32)
+    T = np.eye(4, dtype=np.float32); T[0, 3] = 0.002
+    h = C.c_void_p()
+    L.check(lib.op_icp_create(C.c_void_p(tgt.ctypes.data), C.c_void_p(nrm.ctypes.data), m, C.c_double(0.02), L.OP_MEM_HOST, 0, C.byref(h)))
+
+    def sums(pts, mode):
+        pts = np.ascontiguousarray(pts)
+        L.check(lib.op_icp_set_source(h, C.c_void_p(pts.ctypes.data), len(pts), L.OP_MEM_HOST))
+        out = np.zeros(42, np.float64); cnt = C.c_uint64(); err = C.c_double()
+        L.check(lib.op_icp_iterate(h, T.ctypes.data_as(C.POINTER(C.c_float)), mode, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(err)))
+        return out, cnt.value, err.value
+    try:
+        for mode in (1, 0):
+            whole, c, e = sums(src, mode)
+            again, c2, e2 = sums(src, mode)
+            assert c == c2 and e == e2 and np.array_equal(whole, again)
+            k = n // 3
+            parts = [sums(p, mode) for p in (src[:k], src[k:]) if len(p)]
+            assert c == sum(p[1] for p in parts) and c > 0
+            tot = sum(p[0] for p in parts)
+            scale = np.maximum(np.abs(whole), 1e-300)
+            assert np.all(np.abs(tot - whole) <= 1e-11 * np.maximum(scale, np.abs(whole).max() * 1e-3))
+            assert abs(sum(p[2] for p in parts) - e) <= 1e-11 * max(e, 1e-30)
+    finally:
+        lib.op_icp_destroy(h)
