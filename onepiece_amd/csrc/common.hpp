@@ -61,15 +61,44 @@ __device__ __forceinline__ unsigned xcd_slab_index(unsigned p, unsigned n) {
 // mask M a lane keeps one half of its values and receives the partner's copy of that half, so the work
 // halves every step (16+8+4+2+1+1 = 32 fp64 adds per lane instead of 32 x 6 for a butterfly per value).
 // On return lane L holds in v[0] the wave total of element (L >> 1) & 31.
+//
+// How the halves change hands matters more than the 32 adds (tools/valu_ubench.hip, MI355X): `up ? a : b` on a double
+// is two VOP2 v_cndmask_b32 reading VCC, and BACK-TO-BACK VOP2 v_cndmask issue at ~11 cycles each instead of ~1.4 --
+// the four selects of a step cost 43 cycles, 1300 per reduction.  So:
+//   * lane masks 32 and 16 (24 of the 31 steps) use gfx950's v_permlane32_swap / v_permlane16_swap: swapping the odd
+//     rows of a (the value the lower half keeps) with the even rows of b (the value the upper half keeps) leaves
+//     {own a, partner's a} in the lower rows and {partner's b, own b} in the upper ones -- a' + b' is the step, with no
+//     select and no LDS permute;
+//   * the other masks select with v_bfi_b32 against an all-ones / all-zeros lane word.
+__device__ __forceinline__ double pack_d(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ double select_d(unsigned m, double if_set, double if_clear) { // m: all ones or all zeros
+    const unsigned sl = (unsigned)__double2loint(if_set), sh = (unsigned)__double2hiint(if_set);
+    const unsigned cl = (unsigned)__double2loint(if_clear), ch = (unsigned)__double2hiint(if_clear);
+    return pack_d((m & sl) | (~m & cl), (m & sh) | (~m & ch));
+}
+template <int M>
+__device__ __forceinline__ double halve_step(double a /* kept where (lane & M) == 0 */, double b /* kept elsewhere */, unsigned up_mask) {
+    if constexpr (M == 32 || M == 16) {
+        (void)up_mask;
+        const unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
+        const unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+        if constexpr (M == 32) {
+            const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false), h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+            return pack_d(l[0], h[0]) + pack_d(l[1], h[1]);
+        } else {
+            const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false), h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+            return pack_d(l[0], h[0]) + pack_d(l[1], h[1]);
+        }
+    } else {
+        const double keep = select_d(up_mask, b, a), give = select_d(up_mask, a, b);
+        return keep + __shfl_xor(give, M, 64);
+    }
+}
 template <int H, int M, int N>
 __device__ __forceinline__ void wave_halve(double (&v)[N], int lane) {
-    const bool up = (lane & M) != 0;
+    const unsigned up_mask = (lane & M) != 0 ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const double keep = up ? v[i + H] : v[i];
-        const double give = up ? v[i] : v[i + H];
-        v[i] = keep + __shfl_xor(give, M, 64);
-    }
+    for (int i = 0; i < H; ++i) v[i] = halve_step<M>(v[i], v[i + H], up_mask);
 }
 __device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
     const int lane = threadIdx.x & 63;
@@ -88,7 +117,8 @@ template <int I, class F>
 __device__ __forceinline__ void lazy_first_step(F& val, bool up, double (&v)[16]) {
     if constexpr (I < 16) {
         const double lo = val(index_c<I>{}), hi = val(index_c<I + 16>{});
-        v[I] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 32, 64);
+        (void)up;
+        v[I] = halve_step<32>(lo, hi, 0u);
         lazy_first_step<I + 1>(val, up, v);
     }
 }

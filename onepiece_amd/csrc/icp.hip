@@ -220,6 +220,15 @@ struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 // that cross are stored and loaded with agent-scope accesses (write-through / L2-bypassing), the writer waits for its
 // stores to be acknowledged (s_waitcnt 0) before the barrier that precedes the arrival count, and the arrival count is
 // a relaxed agent-scope atomic.
+// v = set-lanes ? if_set : v, with the lane mask in an SGPR pair (VOP3 encoding).  The compiler's own select after a
+// 64-bit compare is two VOP2 v_cndmask_b32 reading VCC back to back, which issue at ~11 cycles each on gfx950
+// (tools/valu_ubench.hip) -- for the neighbour scan that was more than the distance computation itself.
+__device__ __forceinline__ unsigned select_lanes(unsigned long long lane_mask, unsigned if_clear, unsigned if_set) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
+    return r;
+}
+
 __device__ __forceinline__ double ld_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coherent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wait_stores_then_barrier() {
@@ -323,8 +332,11 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                     auto visit = [&](const float4& c) {
                         const float dx = tp0 - c.x, dyy = tp1 - c.y, dzz = tp2 - c.z;
                         const float d = dx * dx + dyy * dyy + dzz * dzz;
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(c.w);
-                        best_key = key < best_key ? key : best_key;
+                        const unsigned kd = __float_as_uint(d), ki = __float_as_uint(c.w);
+                        const unsigned long long key = ((unsigned long long)kd << 32) | (unsigned long long)ki;
+                        const unsigned long long nearer = __builtin_amdgcn_ballot_w64(key < best_key);
+                        best_key = ((unsigned long long)select_lanes(nearer, (unsigned)(best_key >> 32), kd) << 32) |
+                                   (unsigned long long)select_lanes(nearer, (unsigned)best_key, ki);
                     };
                     // 1. the centre row (dy,dz) = (0,0), kScan candidates per trip: the loads are independent, so their
                     //    L2 round trips overlap (the scan is a latency chain otherwise)

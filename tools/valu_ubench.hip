@@ -29,6 +29,16 @@ __global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* c
         if (OP == 7) { REP16(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(b) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x1) : "v"(b)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x2) : "v"(b)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x3) : "v"(b));) }
         if (OP == 8) { REP16(asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x0), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x1), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x2), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x3), "v"(b) : "vcc");) }
         if (OP == 9) { REP16(asm volatile("v_mov_b32 %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_mov_b32 %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_mov_b32 %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_mov_b32 %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 11) { REP16(asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x0) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x1) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x2) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x3) : "v"(b));) }
+        if (OP == 12) { REP16(asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 13) { REP16(asm volatile("v_min_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_min_f32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_min_f32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_min_f32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 14) { REP16(asm volatile("v_max_u32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_max_u32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_max_u32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_max_u32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 15) { REP16(asm volatile("v_and_b32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 16) { REP16(asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 17) { REP16(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(x4)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x1) : "v"(x5)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x2) : "v"(x6)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x3) : "v"(x7));) }
+        if (OP == 18) { REP16(asm volatile("v_add_u32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 19) { REP16(asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p0), "v"(pb) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p1), "v"(pb) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p2), "v"(pb) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p3), "v"(pb) : "vcc");) }
+        if (OP == 20) { REP16(asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %0" : "+v"(x1)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x2) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
         if (OP == 10) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p3) : "v"(pb));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -55,9 +65,9 @@ int main() {
     const int cus = p.multiProcessorCount;
     std::printf("%s, %d CUs, clock %d kHz; s_memtime ticks at a constant 100 MHz on gfx9 -- ratios between rows are what matter\n", p.gcnArchName, cus, p.clockRate);
     float* d_out; unsigned long long* d_cyc;
-    hipMalloc((void**)&d_out, (size_t)cus * 8 * 256 * 4);
-    hipMalloc((void**)&d_cyc, (size_t)cus * 8 * 4 * 8);
-    for (int w : {1, 2, 4}) {
+    hipMalloc((void**)&d_out, (size_t)cus * 16 * 256 * 4);
+    hipMalloc((void**)&d_cyc, (size_t)cus * 16 * 4 * 8);
+    for (int w : {1, 4, 8}) {
         run<0>("v_mul_f32", w, d_out, d_cyc, cus);
         run<1>("v_fma_f32", w, d_out, d_cyc, cus);
         run<2>("v_pk_mul_f32", w, d_out, d_cyc, cus);
@@ -69,6 +79,16 @@ int main() {
         run<7>("v_cndmask_b32", w, d_out, d_cyc, cus);
         run<8>("v_cmp_lt_f32", w, d_out, d_cyc, cus);
         run<9>("v_mov_b32", w, d_out, d_cyc, cus);
+        run<11>("v_cndmask e64 sgpr", w, d_out, d_cyc, cus);
+        run<17>("v_cndmask vcc 2src", w, d_out, d_cyc, cus);
+        run<20>("sub/mul/cndmask/add", w, d_out, d_cyc, cus);
+        run<12>("v_bfi_b32", w, d_out, d_cyc, cus);
+        run<13>("v_min_f32", w, d_out, d_cyc, cus);
+        run<14>("v_max_u32", w, d_out, d_cyc, cus);
+        run<15>("v_and_b32", w, d_out, d_cyc, cus);
+        run<16>("v_add_f32", w, d_out, d_cyc, cus);
+        run<18>("v_add_u32", w, d_out, d_cyc, cus);
+        run<19>("v_cmp_lt_u64", w, d_out, d_cyc, cus);
     }
     return 0;
 }
