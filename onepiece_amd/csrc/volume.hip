@@ -474,9 +474,19 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
         bool first = false, rec = false;
         int pool_idx = -1;
         if (c < ncand) {
-            const int bk = k0 + (int)(c % (unsigned long long)nk);
-            const int bj = j0 + (int)((c / (unsigned long long)nk) % (unsigned long long)nj);
-            const int bi = i0 + (int)(c / (unsigned long long)(nk * nj));
+            // candidate rank -> (i, j, k), k fastest (CubeHandler.cpp:170-173).  64-bit division costs ~200 instructions on
+            // this chip and three of them were half of the kernel's VALU work; ranks below 2^32 (always, short of a
+            // 160 m bounding box) take two 32-bit divisions instead.
+            int bi, bj, bk;
+            if (ncand <= 0xffffffffULL) {
+                const unsigned c32 = (unsigned)c, nk32 = (unsigned)nk, nj32 = (unsigned)nj;
+                const unsigned q1 = c32 / nk32, q2 = q1 / nj32;
+                bk = k0 + (int)(c32 - q1 * nk32); bj = j0 + (int)(q1 - q2 * nj32); bi = i0 + (int)q2;
+            } else {
+                bk = k0 + (int)(c % (unsigned long long)nk);
+                bj = j0 + (int)((c / (unsigned long long)nk) % (unsigned long long)nj);
+                bi = i0 + (int)(c / (unsigned long long)(nk * nj));
+            }
             const float bx = (float)bi * cube_res, by = (float)bj * cube_res, bz = (float)bk * cube_res;
             // Integrator::GetSDF (Integrator.cpp:8-35) for the 8 corner voxels {0,7,56,63,448,455,504,511}:
             // all 8 projections first, then all 8 gathers in flight together, then the min
