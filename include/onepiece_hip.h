@@ -60,6 +60,12 @@ typedef struct op_tracker op_tracker; /* dense RGB-D tracker workspace (stream, 
 /* ---- library ----------------------------------------------------------------------------- */
 int op_abi_version(void);
 const char *op_last_error(void);
+/* Registration objects (op_icp, the contexts behind op_icp_register / op_estimate_normals / op_points_from_depth) are
+ * created and dropped per call, as registration::PointToPlane builds and drops its kd-tree (Registration/ICP.cpp:
+ * 166-170); their device and pinned buffers, streams and events are kept in a per-process cache when released and
+ * handed out again, so that a steady stream of calls does not allocate.  This empties the cache (at most 8 GB of
+ * device memory per GPU and 1 GB of pinned memory are ever held). */
+int op_release_cached_memory(void);
 int op_device_count(int *count);
 /* OPEN3D_DATASET / TUM_DATASET presets, Camera/Camera.h:76-104.  type: 0 = TUM, 1 = OPEN3D. */
 int op_camera_preset(int type, op_camera *out);

@@ -65,6 +65,7 @@ _u64p = C.POINTER(C.c_uint64)
 SIGNATURES = {
     "op_abi_version": (C.c_int, []),
     "op_last_error": (C.c_char_p, []),
+    "op_release_cached_memory": (C.c_int, []),
     "op_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "op_camera_preset": (C.c_int, [C.c_int, C.POINTER(Camera)]),
     "op_mat4_inverse": (C.c_int, [_fp, _fp]),

@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "../../include/onepiece_hip.h"
 
@@ -44,6 +46,145 @@ inline int use_device(int device) {
     if (device < 0 || device >= n) return fail(OP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
     OP_HIP(hipSetDevice(device));
     return OP_OK;
+}
+
+// ---- buffer cache -------------------------------------------------------------------------------------------------
+// The reference's callers create and drop objects per call (registration::PointToPlane builds its kd-tree inside the
+// call); the GPU equivalents -- a 216 MB cell table, an 11 MB pinned row buffer, a stream, events -- cost milliseconds
+// to allocate and free (hipFree synchronises the device), several times the 1-2 ms such a call computes for.  Released
+// buffers therefore go to a per-process cache and are handed out again to the next request of a similar size (best fit,
+// at most 25 % larger), so a steady stream of calls allocates nothing.  The cache holds at most kCacheDeviceBytes per
+// device and kCacheHostBytes of pinned memory (beyond that a released buffer is really freed); op_release_cached_memory()
+// empties it.  Owners synchronise their stream before releasing, so a cached buffer is idle.  Contents are NOT cleared.
+constexpr size_t kCacheDeviceBytes = 8ull << 30, kCacheHostBytes = 1ull << 30;
+struct BufferCache {
+    struct Slot { void* p; size_t bytes; int device; bool host; };
+    std::mutex mu;
+    std::vector<Slot> free_slots, live_slots;
+    std::vector<hipStream_t> streams;   // per device would be more precise; streams are tied to the device current at creation,
+    std::vector<int> stream_device;     // so the device is kept next to each
+    std::vector<hipEvent_t> events;
+    std::vector<int> event_device;
+    size_t cached(int device, bool host) const {
+        size_t t = 0;
+        for (const Slot& s : free_slots) if (s.host == host && (host || s.device == device)) t += s.bytes;
+        return t;
+    }
+};
+inline BufferCache& buffer_cache() { static BufferCache c; return c; }
+
+inline hipError_t cache_alloc(void** out, size_t bytes, bool host) {
+    *out = nullptr;
+    if (!bytes) bytes = 1;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    BufferCache& c = buffer_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < c.free_slots.size(); ++i) {
+            const BufferCache::Slot& s = c.free_slots[i];
+            if (s.host != host || (!host && s.device != device) || s.bytes < bytes || s.bytes > bytes + bytes / 4 + 4096) continue;
+            if (best == (size_t)-1 || s.bytes < c.free_slots[best].bytes) best = i;
+        }
+        if (best != (size_t)-1) {
+            c.live_slots.push_back(c.free_slots[best]);
+            *out = c.free_slots[best].p;
+            c.free_slots.erase(c.free_slots.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    void* p = nullptr;
+    e = host ? hipHostMalloc(&p, bytes, hipHostMallocMapped) : hipMalloc(&p, bytes);
+    if (e != hipSuccess) { // out of memory: give the cache back and try once more
+        std::vector<BufferCache::Slot> drop;
+        { std::lock_guard<std::mutex> lock(c.mu); drop.swap(c.free_slots); }
+        for (const BufferCache::Slot& s : drop) { if (s.host) (void)hipHostFree(s.p); else (void)hipFree(s.p); }
+        (void)hipGetLastError();
+        e = host ? hipHostMalloc(&p, bytes, hipHostMallocMapped) : hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.live_slots.push_back({p, bytes, device, host});
+    *out = p;
+    return hipSuccess;
+}
+inline hipError_t cached_malloc(void** out, size_t bytes) { return cache_alloc(out, bytes, false); }
+inline hipError_t cached_host_malloc(void** out, size_t bytes) { return cache_alloc(out, bytes, true); } // pinned + mapped
+
+// returns the buffer to the cache (or frees it when the cache is full); pointers not handed out by cache_alloc are freed directly
+inline void cached_free(void* p) {
+    if (!p) return;
+    BufferCache& c = buffer_cache();
+    BufferCache::Slot s{nullptr, 0, 0, false};
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (size_t i = 0; i < c.live_slots.size(); ++i)
+            if (c.live_slots[i].p == p) { s = c.live_slots[i]; c.live_slots.erase(c.live_slots.begin() + (long)i); break; }
+        if (s.p && c.cached(s.device, s.host) + s.bytes <= (s.host ? kCacheHostBytes : kCacheDeviceBytes)) { c.free_slots.push_back(s); return; }
+    }
+    if (!s.p) { (void)hipFree(p); return; } // not ours
+    if (s.host) (void)hipHostFree(p); else (void)hipFree(p);
+}
+inline hipError_t cached_stream(hipStream_t* out) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    BufferCache& c = buffer_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (size_t i = 0; i < c.streams.size(); ++i)
+            if (c.stream_device[i] == device) {
+                *out = c.streams[i];
+                c.streams.erase(c.streams.begin() + (long)i); c.stream_device.erase(c.stream_device.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+inline void release_stream(hipStream_t s, int device) { // the owner has synchronised it
+    if (!s) return;
+    BufferCache& c = buffer_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (c.streams.size() < 64) { c.streams.push_back(s); c.stream_device.push_back(device); } else (void)hipStreamDestroy(s);
+}
+inline hipError_t cached_event(hipEvent_t* out) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    BufferCache& c = buffer_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (size_t i = 0; i < c.events.size(); ++i)
+            if (c.event_device[i] == device) {
+                *out = c.events[i];
+                c.events.erase(c.events.begin() + (long)i); c.event_device.erase(c.event_device.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+inline void release_event(hipEvent_t ev, int device) {
+    if (!ev) return;
+    BufferCache& c = buffer_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (c.events.size() < 256) { c.events.push_back(ev); c.event_device.push_back(device); } else (void)hipEventDestroy(ev);
+}
+// frees everything the cache holds (buffers in use are unaffected)
+inline void release_cached_memory() {
+    BufferCache& c = buffer_cache();
+    std::vector<BufferCache::Slot> drop;
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> ev;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        drop.swap(c.free_slots); st.swap(c.streams); ev.swap(c.events);
+        c.stream_device.clear(); c.event_device.clear();
+    }
+    for (const BufferCache::Slot& s : drop) { if (s.host) (void)hipHostFree(s.p); else (void)hipFree(s.p); }
+    for (hipStream_t s : st) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
 }
 
 constexpr int kWave = 64; // gfx950 wavefront width

@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void k_depth_scatter(const void* __restrict__ 
 int device_exclusive_scan(const unsigned* d_count, size_t n, unsigned* d_start, hipStream_t stream, unsigned* total_out) {
     const size_t nwg = (n + kScanWg - 1) / kScanWg;
     unsigned* d_tot = nullptr;
-    OP_HIP(hipMalloc((void**)&d_tot, (nwg + 1) * sizeof(unsigned)));
+    OP_HIP(op::cached_malloc((void**)&d_tot, (nwg + 1) * sizeof(unsigned)));
     hipLaunchKernelGGL(k_scan_totals, dim3((unsigned)nwg), dim3(256), 0, stream, d_count, n, d_tot);
     hipLaunchKernelGGL(k_scan_of_totals, dim3(1), dim3(1024), 0, stream, d_tot, nwg);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nwg), dim3(256), 0, stream, d_count, n, (const unsigned*)d_tot, d_start);
@@ -823,7 +823,7 @@ int device_exclusive_scan(const unsigned* d_count, size_t n, unsigned* d_start, 
         if (e == hipSuccess) e = hipMemcpy(&last_count, d_count + (n - 1), 4, hipMemcpyDeviceToHost);
         *total_out = last_start + last_count;
     }
-    (void)hipFree(d_tot);
+    op::cached_free(d_tot);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "scan failed: %s", hipGetErrorString(e));
     return OP_OK;
 }
@@ -935,15 +935,15 @@ int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
     if (c->rows_cap < c->n) {
         void* old[] = {c->flag, c->start, c->scan_tot, c->rows_dev};
         for (void* p : old)
-            if (p) OP_HIP(hipFree(p));
-        if (c->rows_host) OP_HIP(hipHostFree(c->rows_host));
+            if (p) op::cached_free(p);
+        if (c->rows_host) op::cached_free(c->rows_host);
         c->flag = c->start = c->scan_tot = nullptr; c->rows_dev = c->rows_host = nullptr; c->rows_cap = 0;
         const size_t cap = c->src_cap;
-        OP_HIP(hipMalloc((void**)&c->flag, cap * sizeof(unsigned)));
-        OP_HIP(hipMalloc((void**)&c->start, cap * sizeof(unsigned)));
-        OP_HIP(hipMalloc((void**)&c->scan_tot, ((cap + kScanWg - 1) / kScanWg + 1) * sizeof(unsigned)));
-        OP_HIP(hipMalloc((void**)&c->rows_dev, cap * 9 * sizeof(float)));
-        OP_HIP(hipHostMalloc((void**)&c->rows_host, cap * 9 * sizeof(float), hipHostMallocDefault));
+        OP_HIP(op::cached_malloc((void**)&c->flag, cap * sizeof(unsigned)));
+        OP_HIP(op::cached_malloc((void**)&c->start, cap * sizeof(unsigned)));
+        OP_HIP(op::cached_malloc((void**)&c->scan_tot, ((cap + kScanWg - 1) / kScanWg + 1) * sizeof(unsigned)));
+        OP_HIP(op::cached_malloc((void**)&c->rows_dev, cap * 9 * sizeof(float)));
+        OP_HIP(op::cached_host_malloc((void**)&c->rows_host, cap * 9 * sizeof(float)));
         c->rows_cap = cap;
     }
     const size_t n = c->n, nwg = (n + kScanWg - 1) / kScanWg;
@@ -980,10 +980,10 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     c->device = device; c->m = m; c->threshold = threshold; c->has_normals = tgt_normals != nullptr;
     auto bail = [&](int rc) { op_icp_destroy(c); return rc; };
 #define OP_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(OP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
-    OP_HIP_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    OP_HIP_C(op::cached_stream(&c->stream));
     const size_t m1 = m ? m : 1;
-    OP_HIP_C(hipMalloc((void**)&c->tgt_orig, m1 * 3 * sizeof(float)));
-    OP_HIP_C(hipMalloc((void**)&c->tgt, (m + 1) * sizeof(float4))); // + the dummy record of the neighbour scan
+    OP_HIP_C(op::cached_malloc((void**)&c->tgt_orig, m1 * 3 * sizeof(float)));
+    OP_HIP_C(op::cached_malloc((void**)&c->tgt, (m + 1) * sizeof(float4))); // + the dummy record of the neighbour scan
     {
         const float inf = std::numeric_limits<float>::infinity();
         const float dummy[4] = {inf, inf, inf, 0.0f};
@@ -993,20 +993,20 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     const hipMemcpyKind kind = mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (m) OP_HIP_C(hipMemcpy(c->tgt_orig, tgt_xyz, m * 3 * sizeof(float), kind));
     if (c->has_normals) {
-        OP_HIP_C(hipMalloc((void**)&d_nrm, m1 * 3 * sizeof(float)));
+        OP_HIP_C(op::cached_malloc((void**)&d_nrm, m1 * 3 * sizeof(float)));
         c->nrm_orig = d_nrm; // owned by the context from here on (freed by op_icp_destroy)
         if (m) OP_HIP_C(hipMemcpy(d_nrm, tgt_normals, m * 3 * sizeof(float), kind));
     }
     // bounding box -> grid
     unsigned* d_box = nullptr;
-    OP_HIP_C(hipMalloc((void**)&d_box, 6 * sizeof(unsigned)));
+    OP_HIP_C(op::cached_malloc((void**)&d_box, 6 * sizeof(unsigned)));
     unsigned init[6] = {0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     OP_HIP_C(hipMemcpy(d_box, init, sizeof(init), hipMemcpyHostToDevice));
     if (m) hipLaunchKernelGGL(k_bbox, dim3(128), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, d_box);
     OP_HIP_C(hipStreamSynchronize(c->stream));
     unsigned box[6];
     OP_HIP_C(hipMemcpy(box, d_box, sizeof(box), hipMemcpyDeviceToHost));
-    (void)hipFree(d_box);
+    op::cached_free(d_box);
     float mx[3], mn[3];
     for (int k = 0; k < 3; ++k) { mx[k] = dec_f(box[k]); mn[k] = dec_f(box[3 + k]); }
     if (!m || !(mx[0] >= mn[0])) { for (int k = 0; k < 3; ++k) { mx[k] = 0; mn[k] = 0; } }
@@ -1032,11 +1032,11 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     // cell_start = exclusive scan of the per-cell counts over ncell + 4 entries (the padding holds the total), so a
     // run of x-adjacent cells is [cell_start[first], cell_start[last + 1]) and one 16-byte load sees both ends
     const size_t n_tab = c->ncell + 4;
-    OP_HIP_C(hipMalloc((void**)&c->cell_start, n_tab * sizeof(unsigned)));
+    OP_HIP_C(op::cached_malloc((void**)&c->cell_start, n_tab * sizeof(unsigned)));
     unsigned *d_count = nullptr, *d_fill = nullptr;
-    OP_HIP_C(hipMalloc((void**)&d_count, n_tab * sizeof(unsigned)));
-    if (hipMalloc((void**)&d_fill, c->ncell * sizeof(unsigned)) != hipSuccess) { (void)hipFree(d_count); return bail(fail(OP_ERR_HIP, "grid build: out of memory")); }
-    auto drop = [&]() { (void)hipFree(d_count); (void)hipFree(d_fill); };
+    OP_HIP_C(op::cached_malloc((void**)&d_count, n_tab * sizeof(unsigned)));
+    if (op::cached_malloc((void**)&d_fill, c->ncell * sizeof(unsigned)) != hipSuccess) { op::cached_free(d_count); return bail(fail(OP_ERR_HIP, "grid build: out of memory")); }
+    auto drop = [&]() { op::cached_free(d_count); op::cached_free(d_fill); };
     hipError_t e = hipMemsetAsync(d_count, 0, n_tab * sizeof(unsigned), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_fill, 0, c->ncell * sizeof(unsigned), c->stream);
     if (e != hipSuccess) { drop(); return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e))); }
@@ -1048,17 +1048,17 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     e = hipStreamSynchronize(c->stream);
     drop();
     if (e != hipSuccess) return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e)));
-    OP_HIP_C(hipMalloc((void**)&c->sync, (kGroups + 1) * sizeof(unsigned)));
+    OP_HIP_C(op::cached_malloc((void**)&c->sync, (kGroups + 1) * sizeof(unsigned)));
     OP_HIP_C(hipMemset(c->sync, 0, (kGroups + 1) * sizeof(unsigned)));
-    OP_HIP_C(hipMalloc((void**)&c->result, kNSums * sizeof(double)));
-    OP_HIP_C(hipMalloc((void**)&c->T_dev, 16 * sizeof(float)));
-    OP_HIP_C(hipMalloc((void**)&c->stage, (size_t)std::max(kStage1, kGroups) * kNSums * sizeof(double)));
-    OP_HIP_C(hipHostMalloc((void**)&c->result_host, (size_t)kGroups * kNSums * sizeof(double), hipHostMallocMapped));
+    OP_HIP_C(op::cached_malloc((void**)&c->result, kNSums * sizeof(double)));
+    OP_HIP_C(op::cached_malloc((void**)&c->T_dev, 16 * sizeof(float)));
+    OP_HIP_C(op::cached_malloc((void**)&c->stage, (size_t)std::max(kStage1, kGroups) * kNSums * sizeof(double)));
+    OP_HIP_C(op::cached_host_malloc((void**)&c->result_host, (size_t)kGroups * kNSums * sizeof(double)));
     OP_HIP_C(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0));
     std::memset(c->result_host, 0, (size_t)kGroups * kNSums * sizeof(double));
-    OP_HIP_C(hipHostMalloc((void**)&c->T_pub, 16 * sizeof(float), hipHostMallocMapped));
+    OP_HIP_C(op::cached_host_malloc((void**)&c->T_pub, 16 * sizeof(float)));
     OP_HIP_C(hipHostGetDevicePointer((void**)&c->T_pub_dev, c->T_pub, 0));
-    for (hipEvent_t& ev : c->chunk_ev) OP_HIP_C(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (hipEvent_t& ev : c->chunk_ev) OP_HIP_C(op::cached_event(&ev));
 #undef OP_HIP_C
     *out = c;
     return OP_OK;
@@ -1085,14 +1085,19 @@ int op_icp_destroy(op_icp* c) {
     void* ptrs[] = {c->tgt_orig, c->tgt, c->sync, c->cell_start, c->src, c->nn, c->inl, c->partials, c->result,
                     c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage, c->nrm_orig, c->flag, c->start, c->scan_tot, c->rows_dev};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
-    if (c->result_host) (void)hipHostFree(c->result_host);
-    if (c->T_pub) (void)hipHostFree(c->T_pub);
+        if (p) op::cached_free(p);
+    if (c->result_host) op::cached_free(c->result_host);
+    if (c->T_pub) op::cached_free(c->T_pub);
     for (hipEvent_t ev : c->chunk_ev)
-        if (ev) (void)hipEventDestroy(ev);
-    if (c->rows_host) (void)hipHostFree(c->rows_host);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+        op::release_event(ev, c->device);
+    if (c->rows_host) op::cached_free(c->rows_host);
+    op::release_stream(c->stream, c->device);
     delete c;
+    return OP_OK;
+}
+
+int op_release_cached_memory(void) {
+    op::release_cached_memory();
     return OP_OK;
 }
 
@@ -1111,11 +1116,11 @@ int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
     if (n > c->src_cap) {
         void* old[] = {c->src, c->nn, c->inl, c->partials};
         for (void* p : old)
-            if (p) OP_HIP(hipFree(p));
+            if (p) op::cached_free(p);
         c->src = nullptr; c->nn = nullptr; c->inl = nullptr; c->partials = nullptr; c->partials_cap = 0;
-        OP_HIP(hipMalloc((void**)&c->src, n * 3 * sizeof(float)));
-        OP_HIP(hipMalloc((void**)&c->nn, n * sizeof(int)));
-        OP_HIP(hipMalloc((void**)&c->inl, n * sizeof(int)));
+        OP_HIP(op::cached_malloc((void**)&c->src, n * 3 * sizeof(float)));
+        OP_HIP(op::cached_malloc((void**)&c->nn, n * sizeof(int)));
+        OP_HIP(op::cached_malloc((void**)&c->inl, n * sizeof(int)));
         c->src_cap = n;
     }
     c->n = n;
@@ -1123,9 +1128,9 @@ int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
     int wg = (int)((n + kIterThreads - 1) / kIterThreads); // one source point per thread
     if (wg < 1) wg = 1;
     if (!c->partials || wg > c->partials_cap) {
-        if (c->partials) OP_HIP(hipFree(c->partials));
+        op::cached_free(c->partials);
         c->partials = nullptr;
-        OP_HIP(hipMalloc((void**)&c->partials, (size_t)wg * kNSums * sizeof(double)));
+        OP_HIP(op::cached_malloc((void**)&c->partials, (size_t)wg * kNSums * sizeof(double)));
         c->partials_cap = wg;
     }
     c->n_wg = wg;
@@ -1158,11 +1163,11 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     float start_T[16];
     double r[kNSums];
     if (max_iteration > c->it_cap) {
-        if (c->it_inl_dev) OP_HIP(hipFree(c->it_inl_dev));
-        if (c->it_T_dev) OP_HIP(hipFree(c->it_T_dev));
+        op::cached_free(c->it_inl_dev);
+        op::cached_free(c->it_T_dev);
         c->it_inl_dev = nullptr; c->it_T_dev = nullptr; c->it_cap = 0;
-        OP_HIP(hipMalloc((void**)&c->it_inl_dev, (size_t)max_iteration * sizeof(int)));
-        OP_HIP(hipMalloc((void**)&c->it_T_dev, (size_t)max_iteration * 16 * sizeof(float)));
+        OP_HIP(op::cached_malloc((void**)&c->it_inl_dev, (size_t)max_iteration * sizeof(int)));
+        OP_HIP(op::cached_malloc((void**)&c->it_T_dev, (size_t)max_iteration * 16 * sizeof(float)));
         c->it_cap = max_iteration;
     }
     if (max_iteration <= 0 && c->n) OP_HIP(hipMemsetAsync(c->nn, 0xff, c->n * sizeof(int), c->stream)); // corresponding_index stays -1
@@ -1334,12 +1339,12 @@ static int pair_sums_run(int mode, const float* a, size_t na_floats, const float
     auto up = [&](const void* src, size_t bytes, void** dst) {
         if (e != hipSuccess || !src || !bytes) return;
         if (mem == OP_MEM_DEVICE) { *dst = const_cast<void*>(src); return; }
-        e = hipMalloc(dst, bytes);
+        e = op::cached_malloc(dst, bytes);
         if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     up(a, na_floats * 4, (void**)&d_a); up(b, nb_floats * 4, (void**)&d_b); up(nrm, nb_floats * 4, (void**)&d_n); up(inliers, n * 8, (void**)&d_i);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_part, (size_t)n_wg * kNSums * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_out, kNSums * sizeof(double));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_part, (size_t)n_wg * kNSums * sizeof(double));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_out, kNSums * sizeof(double));
     if (e == hipSuccess) {
         if (mode == 1) hipLaunchKernelGGL(k_pair_sums<1>, dim3(n_wg), dim3(kIterThreads), 0, nullptr, (const float*)d_a, (const float*)d_b, (const float*)d_n, (const int*)d_i, n, d_part);
         else hipLaunchKernelGGL(k_pair_sums<0>, dim3(n_wg), dim3(kIterThreads), 0, nullptr, (const float*)d_a, (const float*)nullptr, (const float*)nullptr, (const int*)nullptr, n, d_part);
@@ -1347,8 +1352,8 @@ static int pair_sums_run(int mode, const float* a, size_t na_floats, const float
                            (float*)nullptr, (double*)nullptr, 0.0);
         e = hipMemcpy(out, d_out, kNSums * sizeof(double), hipMemcpyDeviceToHost);
     }
-    if (mem != OP_MEM_DEVICE) { (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_n); (void)hipFree(d_i); }
-    (void)hipFree(d_part); (void)hipFree(d_out);
+    if (mem != OP_MEM_DEVICE) { op::cached_free(d_a); op::cached_free(d_b); op::cached_free(d_n); op::cached_free(d_i); }
+    op::cached_free(d_part); op::cached_free(d_out);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "pair sums failed: %s", hipGetErrorString(e));
     return OP_OK;
 }
@@ -1436,16 +1441,16 @@ static int points_from_images(const op_camera* cam, const void* depth, int depth
     hipError_t e = hipSuccess;
     const void* dsrc = depth;
     if (mem == OP_MEM_HOST) {
-        e = hipMalloc(&d_depth, dbytes);
+        e = op::cached_malloc(&d_depth, dbytes);
         if (e == hipSuccess) e = hipMemcpy(d_depth, depth, dbytes, hipMemcpyHostToDevice);
         dsrc = d_depth;
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&d_count, npix * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_start, npix * 4);
-    if (e == hipSuccess && mem == OP_MEM_HOST) e = hipMalloc((void**)&d_xyz, npix * 12);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_count, npix * 4);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_start, npix * 4);
+    if (e == hipSuccess && mem == OP_MEM_HOST) e = op::cached_malloc((void**)&d_xyz, npix * 12);
     if (e == hipSuccess && mem == OP_MEM_HOST && rgb) {
-        e = hipMalloc((void**)&d_col, npix * 12);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_rgb, npix * 3);
+        e = op::cached_malloc((void**)&d_col, npix * 12);
+        if (e == hipSuccess) e = op::cached_malloc((void**)&d_rgb, npix * 3);
         if (e == hipSuccess) e = hipMemcpy(d_rgb, rgb, npix * 3, hipMemcpyHostToDevice);
         rsrc = d_rgb;
     }
@@ -1464,12 +1469,12 @@ static int points_from_images(const op_camera* cam, const void* depth, int depth
             if (e == hipSuccess && mem == OP_MEM_HOST && total && rgb) e = hipMemcpy(colors_out, d_col, (size_t)total * 12, hipMemcpyDeviceToHost);
         }
     }
-    if (d_depth) (void)hipFree(d_depth);
-    if (d_count) (void)hipFree(d_count);
-    if (d_start) (void)hipFree(d_start);
-    if (d_xyz) (void)hipFree(d_xyz);
-    if (d_col) (void)hipFree(d_col);
-    if (d_rgb) (void)hipFree(d_rgb);
+    if (d_depth) op::cached_free(d_depth);
+    if (d_count) op::cached_free(d_count);
+    if (d_start) op::cached_free(d_start);
+    if (d_xyz) op::cached_free(d_xyz);
+    if (d_col) op::cached_free(d_col);
+    if (d_rgb) op::cached_free(d_rgb);
     if (rc != OP_OK) return rc;
     if (e != hipSuccess) return fail(OP_ERR_HIP, "points_from_depth failed: %s", hipGetErrorString(e));
     *n = total;
@@ -1508,7 +1513,7 @@ int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int m
     op_icp* c = nullptr;
     OP_TRY(op_icp_create(xyz, nullptr, n, cell_hint / 1.001, mem, device, &c));
     float* d_nrm = nullptr;
-    hipError_t e = hipMalloc((void**)&d_nrm, n * 12);
+    hipError_t e = op::cached_malloc((void**)&d_nrm, n * 12);
     if (e == hipSuccess) e = hipMemsetAsync(d_nrm, 0, n * 12, c->stream);
     if (e == hipSuccess) {
         const float cell = 1.0f / c->grid.inv_cell;
@@ -1517,7 +1522,7 @@ int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int m
         e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(normals_out, d_nrm, n * 12, mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
-    if (d_nrm) (void)hipFree(d_nrm);
+    if (d_nrm) op::cached_free(d_nrm);
     op_icp_destroy(c);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "estimate_normals failed: %s", hipGetErrorString(e));
     return OP_OK;

@@ -293,3 +293,34 @@ def test_iteration_sums_are_additive_over_a_split_of_the_source(n):
             assert abs(sum(p[2] for p in parts) - e) <= 1e-11 * max(e, 1e-30)
     finally:
         lib.op_icp_destroy(h)
+
+
+def test_contexts_reuse_cached_buffers_without_seeing_each_others_data(oracle):
+    """Registration contexts are created and dropped per call; their buffers (cell table, pinned rows of published sums,
+    streams, events) come from and go back to a per-process cache.  Calls on different clouds, interleaved, must give what
+    they give alone -- in particular a recycled pinned row buffer still holds the previous context's sequence numbers --
+    and emptying the cache changes nothing."""
+    import ctypes as C
+    from onepiece_amd import _lib as L
+    _, src_a, _ = room_cloud(101, scale=4)
+    _, tgt_a, nrm_a = room_cloud(100, scale=4)
+    _, src_b, _ = room_cloud(205, scale=2)
+    _, tgt_b, nrm_b = room_cloud(204, scale=2)
+    par = R.ICPParameter(8, 0.02)
+
+    def run_a():
+        g = R.PointToPlane(R.PointCloud(src_a), R.PointCloud(tgt_a, nrm_a), None, par)
+        return g.T.tobytes(), g.last_T.tobytes(), g.per_iter_inliers.tobytes(), g.correspondence_set_index.tobytes()
+
+    def run_b():
+        g = R.PointToPoint(R.PointCloud(src_b), R.PointCloud(tgt_b), None, par)
+        return g.T.tobytes(), g.last_T.tobytes(), g.per_iter_inliers.tobytes(), g.correspondence_set_index.tobytes()
+    L.check(L.load().op_release_cached_memory())
+    a0, b0 = run_a(), run_b()
+    for _ in range(3):
+        assert run_a() == a0 and run_b() == b0
+    L.check(L.load().op_release_cached_memory())
+    assert run_b() == b0 and run_a() == a0
+    ref = oracle.icp(src_a, tgt_a, nrm_a, None, 8, 0.02, point_to_plane=True)
+    got = R.PointToPlane(R.PointCloud(src_a), R.PointCloud(tgt_a, nrm_a), None, par)
+    assert np.array_equal(got.per_iter_inliers, ref["per_iter_inliers"]) and rel_err(got.T, ref["T"]) <= POSE_TOL

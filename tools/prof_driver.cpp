@@ -81,9 +81,19 @@ int main(int argc, char** argv) {
         size_t nt = 0, ns = 0;
         CK(op_points_from_depth(&cam, depth.data(), OP_DEPTH_F32, OP_MEM_HOST, 0, tgt.data(), &nt));
         CK(op_points_from_depth(&cam, depth.data() + npx, OP_DEPTH_F32, OP_MEM_HOST, 0, src.data(), &ns));
+        auto secs = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
         CK(op_estimate_normals(tgt.data(), nt, 0.1f, 30, OP_MEM_HOST, 0, nrm.data()));
-        op_icp* icp; CK(op_icp_create(tgt.data(), nrm.data(), nt, 0.01, OP_MEM_HOST, 0, &icp));
-        CK(op_icp_set_source(icp, src.data(), ns, OP_MEM_HOST));
+        op_icp* icp = nullptr;
+        for (int r = 0; r < 3; ++r) { // the fixed costs of one registration::PointToPlane call around the loop
+            if (icp) { auto t0 = std::chrono::steady_clock::now(); CK(op_icp_destroy(icp)); printf("op_icp_destroy %.3f ms; ", secs(t0) * 1e3); }
+            auto t0 = std::chrono::steady_clock::now();
+            CK(op_estimate_normals(tgt.data(), nt, 0.1f, 30, OP_MEM_HOST, 0, nrm.data()));
+            const double tn = secs(t0); t0 = std::chrono::steady_clock::now();
+            CK(op_icp_create(tgt.data(), nrm.data(), nt, 0.01, OP_MEM_HOST, 0, &icp));
+            const double tc = secs(t0); t0 = std::chrono::steady_clock::now();
+            CK(op_icp_set_source(icp, src.data(), ns, OP_MEM_HOST));
+            printf("op_estimate_normals %.3f ms, op_icp_create %.3f ms, op_icp_set_source %.3f ms (host arrays, %zu / %zu points)\n", tn * 1e3, tc * 1e3, secs(t0) * 1e3, nt, ns);
+        }
         const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         for (int r = 0; r < reps; ++r)
             for (int mode = 1; mode >= 0; --mode) {
