@@ -54,9 +54,9 @@ inline int use_device(int device) {
 // to allocate and free (hipFree synchronises the device), several times the 1-2 ms such a call computes for.  Released
 // buffers therefore go to a per-process cache and are handed out again to the next request of a similar size (best fit,
 // at most 25 % larger), so a steady stream of calls allocates nothing.  The cache holds at most kCacheDeviceBytes per
-// device and kCacheHostBytes of pinned memory (beyond that a released buffer is really freed); op_release_cached_memory()
+// device and kCacheHostBytes of pinned memory, nothing above kCacheLargest (beyond that a released buffer is really freed); op_release_cached_memory()
 // empties it.  Owners synchronise their stream before releasing, so a cached buffer is idle.  Contents are NOT cleared.
-constexpr size_t kCacheDeviceBytes = 8ull << 30, kCacheHostBytes = 1ull << 30;
+constexpr size_t kCacheDeviceBytes = 8ull << 30, kCacheHostBytes = 1ull << 30, kCacheLargest = 1ull << 30;
 struct BufferCache {
     struct Slot { void* p; size_t bytes; int device; bool host; };
     std::mutex mu;
@@ -122,7 +122,11 @@ inline void cached_free(void* p) {
         std::lock_guard<std::mutex> lock(c.mu);
         for (size_t i = 0; i < c.live_slots.size(); ++i)
             if (c.live_slots[i].p == p) { s = c.live_slots[i]; c.live_slots.erase(c.live_slots.begin() + (long)i); break; }
-        if (s.p && c.cached(s.device, s.host) + s.bytes <= (s.host ? kCacheHostBytes : kCacheDeviceBytes)) { c.free_slots.push_back(s); return; }
+        // buffers above 1 GB (a volume's block pool) are not kept: they are long-lived and would crowd everything else out
+        if (s.p && s.bytes <= kCacheLargest && c.cached(s.device, s.host) + s.bytes <= (s.host ? kCacheHostBytes : kCacheDeviceBytes)) {
+            c.free_slots.push_back(s);
+            return;
+        }
     }
     if (!s.p) { (void)hipFree(p); return; } // not ours
     if (s.host) (void)hipHostFree(p); else (void)hipFree(p);

@@ -132,12 +132,12 @@ extern "C" int op_bilateral_filter_depth(const void* depth, int depth_format, fl
     float* d_out = nullptr;
     BilateralArgs A{};
     if (mem == OP_MEM_HOST) {
-        OP_HIP(hipMalloc(&d_in, in_bytes));
-        hipError_t e = hipMalloc((void**)&d_out, npix * 4);
+        OP_HIP(op::cached_malloc(&d_in, in_bytes));
+        hipError_t e = op::cached_malloc((void**)&d_out, npix * 4);
         if (e == hipSuccess) e = hipMemcpyAsync(d_in, depth, in_bytes, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) {
-            (void)hipFree(d_in);
-            if (d_out) (void)hipFree(d_out);
+            op::cached_free(d_in);
+            if (d_out) op::cached_free(d_out);
             return fail(OP_ERR_HIP, "bilateral filter staging failed: %s", hipGetErrorString(e));
         }
         A.src = d_in;
@@ -164,8 +164,8 @@ extern "C" int op_bilateral_filter_depth(const void* depth, int depth_format, fl
     if (e == hipSuccess && mem == OP_MEM_HOST) e = hipMemcpyAsync(out, d_out, npix * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && !stream) e = hipStreamSynchronize(st);
     if (mem == OP_MEM_HOST) {
-        (void)hipFree(d_in);
-        (void)hipFree(d_out);
+        op::cached_free(d_in);
+        op::cached_free(d_out);
     }
     if (e != hipSuccess) return fail(OP_ERR_HIP, "bilateral filter failed: %s", hipGetErrorString(e));
     return OP_OK;

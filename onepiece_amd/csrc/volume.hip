@@ -1297,19 +1297,19 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     int *keys = nullptr, *blist = nullptr, *sel_list = nullptr, *tvals = nullptr;
     unsigned long long *sel_cand = nullptr, *tkeys = nullptr;
     unsigned* bmask = nullptr;
-    hipError_t e = hipMalloc((void**)&pool, sizeof(float) * kBlockFloats * (size_t)new_max);
-    if (e == hipSuccess) e = hipMalloc((void**)&keys, sizeof(int) * 3 * (size_t)new_max);
-    if (e == hipSuccess) e = hipMalloc((void**)&blist, sizeof(int) * (size_t)new_max);
-    if (e == hipSuccess) e = hipMalloc((void**)&sel_list, sizeof(int) * (size_t)new_max);
-    if (e == hipSuccess) e = hipMalloc((void**)&sel_cand, sizeof(unsigned long long) * (size_t)new_max);
-    if (e == hipSuccess) e = hipMalloc((void**)&tkeys, sizeof(unsigned long long) * (size_t)new_table);
-    if (e == hipSuccess) e = hipMalloc((void**)&tvals, sizeof(int) * (size_t)new_table);
-    if (e == hipSuccess) e = hipMalloc((void**)&bmask, sizeof(unsigned) * (size_t)new_table);
+    hipError_t e = op::cached_malloc((void**)&pool, sizeof(float) * kBlockFloats * (size_t)new_max);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&keys, sizeof(int) * 3 * (size_t)new_max);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&blist, sizeof(int) * (size_t)new_max);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&sel_list, sizeof(int) * (size_t)new_max);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&sel_cand, sizeof(unsigned long long) * (size_t)new_max);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&tkeys, sizeof(unsigned long long) * (size_t)new_table);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&tvals, sizeof(int) * (size_t)new_table);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&bmask, sizeof(unsigned) * (size_t)new_table);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         void* got[] = {pool, keys, blist, sel_list, sel_cand, tkeys, tvals, bmask};
         for (void* q : got)
-            if (q) (void)hipFree(q);
+            if (q) op::cached_free(q);
         return fail(OP_ERR_CAPACITY, "cannot grow the volume to %u blocks: %s", new_max, hipGetErrorString(e));
     }
     if (n_valid) {
@@ -1325,7 +1325,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     OP_HIP(hipStreamSynchronize(v->stream)); // n_valid is a stack variable; the old buffers are released next
     void* old[] = {v->pool, v->keys, v->blist, v->sel_list, v->sel_cand, v->tkeys, v->tvals, v->bmask};
     for (void* q : old)
-        if (q) (void)hipFree(q);
+        if (q) op::cached_free(q);
     v->pool = pool; v->keys = keys; v->blist = blist; v->sel_list = sel_list; v->sel_cand = sel_cand;
     v->tkeys = tkeys; v->tvals = tvals; v->bmask = bmask;
     v->max_blocks = new_max; v->table_size = new_table;
@@ -1434,11 +1434,11 @@ int vol_stage_images(op_volume* v, const void** depth, int depth_fmt, const unsi
     if (npx > v->img_cap_px) {
         OP_TRY(vol_flush(v));
         OP_HIP(hipStreamSynchronize(v->stream));
-        if (v->img_depth) OP_HIP(hipFree(v->img_depth));
-        if (v->img_rgb) OP_HIP(hipFree(v->img_rgb));
+        if (v->img_depth) op::cached_free(v->img_depth);
+        if (v->img_rgb) op::cached_free(v->img_rgb);
         v->img_depth = nullptr; v->img_rgb = nullptr; v->img_cap_px = 0;
-        OP_HIP(hipMalloc(&v->img_depth, npx * 4));
-        OP_HIP(hipMalloc((void**)&v->img_rgb, npx * 3));
+        OP_HIP(op::cached_malloc(&v->img_depth, npx * 4));
+        OP_HIP(op::cached_malloc((void**)&v->img_rgb, npx * 3));
         v->img_cap_px = npx;
     }
     void* d = (char*)v->img_depth + (size_t)slot * npx * 4;
@@ -1476,12 +1476,13 @@ void frame_params(const op_volume* v, const float pose[16], const float* pose_in
 int vol_ensure_frame_buffers(op_volume* v) {
     const size_t npx = (size_t)v->cam.width * v->cam.height;
     if (npx <= v->pimg_px) return OP_OK;
-    if (v->pimg) OP_HIP(hipFree(v->pimg));
-    if (v->partial) OP_HIP(hipFree(v->partial));
+    OP_HIP(hipStreamSynchronize(v->stream)); // released buffers go back to a cache and may be handed out at once
+    if (v->pimg) op::cached_free(v->pimg);
+    if (v->partial) op::cached_free(v->partial);
     v->pimg = nullptr; v->partial = nullptr; v->pimg_px = 0;
     const size_t g1 = (npx + kPixPerWg - 1) / kPixPerWg;
-    OP_HIP(hipMalloc((void**)&v->pimg, (size_t)kMaxBatch * npx * sizeof(uint2)));
-    OP_HIP(hipMalloc((void**)&v->partial, (size_t)kMaxBatch * g1 * 8 * sizeof(float)));
+    OP_HIP(op::cached_malloc((void**)&v->pimg, (size_t)kMaxBatch * npx * sizeof(uint2)));
+    OP_HIP(op::cached_malloc((void**)&v->partial, (size_t)kMaxBatch * g1 * 8 * sizeof(float)));
     v->pimg_px = npx;
     return OP_OK;
 }
@@ -1660,15 +1661,15 @@ int vol_ring_alloc(op_volume* v) {
     OP_TRY(vol_check(v)); // nothing in flight may still read the old slots
     if (!v->copy_stream) OP_HIP(hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking));
     for (auto& r : v->ring) {
-        if (r.d_depth) OP_HIP(hipFree(r.d_depth));
-        if (r.d_rgb) OP_HIP(hipFree(r.d_rgb));
-        if (r.h_depth) OP_HIP(hipHostFree(r.h_depth));
-        if (r.h_rgb) OP_HIP(hipHostFree(r.h_rgb));
+        if (r.d_depth) op::cached_free(r.d_depth);
+        if (r.d_rgb) op::cached_free(r.d_rgb);
+        if (r.h_depth) op::cached_free(r.h_depth);
+        if (r.h_rgb) op::cached_free(r.h_rgb);
         r.d_depth = r.h_depth = nullptr; r.d_rgb = r.h_rgb = nullptr; r.busy_seq = 0;
-        OP_HIP(hipMalloc(&r.d_depth, (size_t)kMaxBatch * npx * 4));
-        OP_HIP(hipMalloc((void**)&r.d_rgb, (size_t)kMaxBatch * npx * 3));
-        OP_HIP(hipHostMalloc(&r.h_depth, (size_t)kMaxBatch * npx * 4, hipHostMallocDefault));
-        OP_HIP(hipHostMalloc((void**)&r.h_rgb, (size_t)kMaxBatch * npx * 3, hipHostMallocDefault));
+        OP_HIP(op::cached_malloc(&r.d_depth, (size_t)kMaxBatch * npx * 4));
+        OP_HIP(op::cached_malloc((void**)&r.d_rgb, (size_t)kMaxBatch * npx * 3));
+        OP_HIP(op::cached_host_malloc(&r.h_depth, (size_t)kMaxBatch * npx * 4));
+        OP_HIP(op::cached_host_malloc((void**)&r.h_rgb, (size_t)kMaxBatch * npx * 3));
         if (!r.copied) OP_HIP(hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
     }
     v->ring_px = npx;
@@ -1777,8 +1778,8 @@ int op_debug_project_uv(float fx, float fy, float cx, float cy, const float* X, 
     if (n == 0) return OP_OK;
     float* d_in = nullptr;
     int* d_out = nullptr;
-    OP_HIP(hipMalloc((void**)&d_in, 3 * n * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&d_out, 4 * n * sizeof(int));
+    OP_HIP(op::cached_malloc((void**)&d_in, 3 * n * sizeof(float)));
+    hipError_t e = op::cached_malloc((void**)&d_out, 4 * n * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_in, X, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_in + n, Y, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_in + 2 * n, Z, n * 4, hipMemcpyHostToDevice);
@@ -1791,8 +1792,8 @@ int op_debug_project_uv(float fx, float fy, float cx, float cy, const float* X, 
                            (const float*)(d_in + n), (const float*)(d_in + 2 * n), n, d_out);
         e = hipMemcpy(out, d_out, 4 * n * sizeof(int), hipMemcpyDeviceToHost);
     }
-    (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
+    op::cached_free(d_in);
+    if (d_out) op::cached_free(d_out);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "op_debug_project_uv failed: %s", hipGetErrorString(e));
     return OP_OK;
 }
@@ -1819,19 +1820,19 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     auto cleanup = [&](int rc) { op_volume_destroy(v); return rc; };
 #define OP_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(OP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
     OP_HIP_C(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
-    OP_HIP_C(hipMalloc((void**)&v->tkeys, sizeof(unsigned long long) * (size_t)v->table_size));
-    OP_HIP_C(hipMalloc((void**)&v->tvals, sizeof(int) * (size_t)v->table_size));
-    OP_HIP_C(hipMalloc((void**)&v->bmask, sizeof(unsigned) * (size_t)v->table_size));
-    OP_HIP_C(hipMalloc((void**)&v->blist, sizeof(int) * (size_t)v->max_blocks));
-    OP_HIP_C(hipMalloc((void**)&v->sel_partial, sizeof(unsigned long long) * kIntegrateGrid));
-    OP_HIP_C(hipMalloc((void**)&v->keys, sizeof(int) * 3 * (size_t)v->max_blocks));
-    OP_HIP_C(hipMalloc((void**)&v->pool, sizeof(float) * kBlockFloats * (size_t)v->max_blocks));
-    OP_HIP_C(hipMalloc((void**)&v->n_blocks, sizeof(unsigned)));
-    OP_HIP_C(hipMalloc((void**)&v->sel_list, sizeof(int) * (size_t)v->max_blocks));
-    OP_HIP_C(hipMalloc((void**)&v->sel_cand, sizeof(unsigned long long) * (size_t)v->max_blocks));
-    OP_HIP_C(hipMalloc((void**)&v->state, sizeof(State)));
-    OP_HIP_C(hipMalloc((void**)&v->upd_partial, sizeof(unsigned long long) * kIntegrateGrid));
-    OP_HIP_C(hipHostMalloc((void**)&v->hstat, 2 * sizeof(unsigned), hipHostMallocMapped));
+    OP_HIP_C(op::cached_malloc((void**)&v->tkeys, sizeof(unsigned long long) * (size_t)v->table_size));
+    OP_HIP_C(op::cached_malloc((void**)&v->tvals, sizeof(int) * (size_t)v->table_size));
+    OP_HIP_C(op::cached_malloc((void**)&v->bmask, sizeof(unsigned) * (size_t)v->table_size));
+    OP_HIP_C(op::cached_malloc((void**)&v->blist, sizeof(int) * (size_t)v->max_blocks));
+    OP_HIP_C(op::cached_malloc((void**)&v->sel_partial, sizeof(unsigned long long) * kIntegrateGrid));
+    OP_HIP_C(op::cached_malloc((void**)&v->keys, sizeof(int) * 3 * (size_t)v->max_blocks));
+    OP_HIP_C(op::cached_malloc((void**)&v->pool, sizeof(float) * kBlockFloats * (size_t)v->max_blocks));
+    OP_HIP_C(op::cached_malloc((void**)&v->n_blocks, sizeof(unsigned)));
+    OP_HIP_C(op::cached_malloc((void**)&v->sel_list, sizeof(int) * (size_t)v->max_blocks));
+    OP_HIP_C(op::cached_malloc((void**)&v->sel_cand, sizeof(unsigned long long) * (size_t)v->max_blocks));
+    OP_HIP_C(op::cached_malloc((void**)&v->state, sizeof(State)));
+    OP_HIP_C(op::cached_malloc((void**)&v->upd_partial, sizeof(unsigned long long) * kIntegrateGrid));
+    OP_HIP_C(op::cached_host_malloc((void**)&v->hstat, 2 * sizeof(unsigned)));
     v->hstat[0] = 0; v->hstat[1] = 0;
     OP_HIP_C(hipHostGetDevicePointer((void**)&v->hstat_dev, v->hstat, 0));
 #undef OP_HIP_C
@@ -1851,16 +1852,16 @@ int op_volume_destroy(op_volume* v) {
     void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
                     v->partial, v->pimg, v->upd_partial, v->sel_partial, v->img_depth, v->img_rgb, v->unpack_slots};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) op::cached_free(p);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
     for (auto& r : v->ring) {
-        if (r.d_depth) (void)hipFree(r.d_depth);
-        if (r.d_rgb) (void)hipFree(r.d_rgb);
-        if (r.h_depth) (void)hipHostFree(r.h_depth);
-        if (r.h_rgb) (void)hipHostFree(r.h_rgb);
+        if (r.d_depth) op::cached_free(r.d_depth);
+        if (r.d_rgb) op::cached_free(r.d_rgb);
+        if (r.h_depth) op::cached_free(r.h_depth);
+        if (r.h_rgb) op::cached_free(r.h_rgb);
         if (r.copied) (void)hipEventDestroy(r.copied);
     }
-    if (v->hstat) (void)hipHostFree(v->hstat);
+    if (v->hstat) op::cached_free(v->hstat);
     if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
     if (v->stream) (void)hipStreamDestroy(v->stream);
     delete v;
@@ -2118,11 +2119,11 @@ int op_volume_has_cube(op_volume* v, int32_t x, int32_t y, int32_t z, int* prese
     if (!present) return fail(OP_ERR_INVALID, "null present");
     OP_TRY(vol_check(v));
     int* d_out = nullptr;
-    OP_HIP(hipMalloc((void**)&d_out, sizeof(int)));
+    OP_HIP(op::cached_malloc((void**)&d_out, sizeof(int)));
     hipLaunchKernelGGL(k_has_cube, dim3(1), dim3(1), 0, v->stream, v->view(), x, y, z, d_out); // cube_map.find (CubeHandler.h:129-132)
     hipError_t e = hipMemcpyAsync(present, d_out, sizeof(int), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
-    (void)hipFree(d_out);
+    op::cached_free(d_out);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "has_cube failed: %s", hipGetErrorString(e));
     return OP_OK;
 }
@@ -2137,16 +2138,16 @@ int op_volume_download(op_volume* v, int32_t* keys_xyz, float* voxels_aos, size_
     if (voxels_aos && take) {
         const size_t chunk = 8192; // 80 MiB of staging
         float* stage = nullptr;
-        OP_HIP(hipMalloc((void**)&stage, std::min(chunk, take) * kBlockFloats * sizeof(float)));
+        OP_HIP(op::cached_malloc((void**)&stage, std::min(chunk, take) * kBlockFloats * sizeof(float)));
         for (size_t first = 0; first < take; first += chunk) {
             const size_t cnt = std::min(chunk, take - first);
             hipLaunchKernelGGL(k_export_aos, dim3((unsigned)cnt), dim3(512), 0, v->stream, (const float*)v->pool, first, stage);
             hipError_t e = hipStreamSynchronize(v->stream);
             if (e == hipSuccess)
                 e = hipMemcpy(voxels_aos + first * kBlockFloats, stage, cnt * kBlockFloats * sizeof(float), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { (void)hipFree(stage); return fail(OP_ERR_HIP, "download failed: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) { op::cached_free(stage); return fail(OP_ERR_HIP, "download failed: %s", hipGetErrorString(e)); }
         }
-        OP_HIP(hipFree(stage));
+        op::cached_free(stage);
     }
     return OP_OK;
 }
@@ -2176,9 +2177,9 @@ int op_volume_upload(op_volume* v, const int32_t* keys_xyz, const float* voxels_
     const size_t chunk = 8192;
     int *d_keys = nullptr, *d_slots = nullptr;
     float* d_vox = nullptr;
-    OP_HIP(hipMalloc((void**)&d_keys, chunk * 3 * sizeof(int)));
-    OP_HIP(hipMalloc((void**)&d_slots, chunk * sizeof(int)));
-    OP_HIP(hipMalloc((void**)&d_vox, chunk * kBlockFloats * sizeof(float)));
+    OP_HIP(op::cached_malloc((void**)&d_keys, chunk * 3 * sizeof(int)));
+    OP_HIP(op::cached_malloc((void**)&d_slots, chunk * sizeof(int)));
+    OP_HIP(op::cached_malloc((void**)&d_vox, chunk * kBlockFloats * sizeof(float)));
     std::vector<int> hk(chunk * 3);
     std::vector<float> hv(chunk * kBlockFloats);
     int rc = OP_OK;
@@ -2197,7 +2198,7 @@ int op_volume_upload(op_volume* v, const int32_t* keys_xyz, const float* voxels_
         }
         if (e != hipSuccess) rc = fail(OP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d_keys); (void)hipFree(d_slots); (void)hipFree(d_vox);
+    op::cached_free(d_keys); op::cached_free(d_slots); op::cached_free(d_vox);
     if (rc != OP_OK) return rc;
     return vol_check(v);
 }
@@ -2217,11 +2218,11 @@ int op_volume_merge(op_volume* dst, op_volume* src) {
     OP_TRY(vol_reserve(dst, (unsigned long long)nd + ns)); // worst case: no block in common
     dst->plain = false; // merged means: general weights from here on
     int* d_slots = nullptr;
-    OP_HIP(hipMalloc((void**)&d_slots, (size_t)ns * sizeof(int)));
+    OP_HIP(op::cached_malloc((void**)&d_slots, (size_t)ns * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((ns + 255) / 256), dim3(256), 0, dst->stream, dst->view(), (const int*)src->keys, (size_t)ns, d_slots, dst->state);
     hipLaunchKernelGGL(k_merge_blocks, dim3(ns), dim3(512), 0, dst->stream, dst->pool, (const float*)src->pool, (const int*)d_slots, (const int*)dst->tvals);
     hipError_t e = hipStreamSynchronize(dst->stream);
-    (void)hipFree(d_slots);
+    op::cached_free(d_slots);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "merge failed: %s", hipGetErrorString(e));
     return vol_check(dst);
 }
@@ -2257,11 +2258,11 @@ int op_volume_unpack_sum_begin(op_volume* v, const int32_t* d_union_keys, size_t
     OP_TRY(vol_check(v));
     OP_TRY(vol_reserve(v, n_union)); // grows the root's pool if the union needs it; a refusal leaves the volume as it was
     OP_TRY(op_volume_clear(v));
-    if (v->unpack_slots) { OP_HIP(hipFree(v->unpack_slots)); v->unpack_slots = nullptr; }
+    if (v->unpack_slots) { op::cached_free(v->unpack_slots); v->unpack_slots = nullptr; }
     v->unpack_n = n_union;
     if (n_union == 0) return OP_OK;
     v->plain = false; // normalised sums of several ranks
-    OP_HIP(hipMalloc((void**)&v->unpack_slots, n_union * sizeof(int)));
+    OP_HIP(op::cached_malloc((void**)&v->unpack_slots, n_union * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, v->unpack_slots, v->state);
     OP_HIP(hipGetLastError());
     return vol_check(v);
@@ -2339,8 +2340,8 @@ int op_volume_point_cloud(op_volume* v, float* xyz, float* colors, size_t cap, s
     unsigned *d_counts = nullptr, *d_offsets = nullptr;
     float *d_xyz = nullptr, *d_col = nullptr;
     int rc = OP_OK;
-    hipError_t e = hipMalloc((void**)&d_counts, nb * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_offsets, nb * sizeof(unsigned));
+    hipError_t e = op::cached_malloc((void**)&d_counts, nb * sizeof(unsigned));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_offsets, nb * sizeof(unsigned));
     std::vector<unsigned> cnt(nb), off(nb);
     size_t total = 0;
     if (e == hipSuccess) {
@@ -2355,8 +2356,8 @@ int op_volume_point_cloud(op_volume* v, float* xyz, float* colors, size_t cap, s
         if (total > cap) rc = fail(OP_ERR_CAPACITY, "point cloud has %zu points, buffer holds %zu", total, cap);
         else {
             e = hipMemcpy(d_offsets, off.data(), nb * sizeof(unsigned), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMalloc((void**)&d_xyz, total * 12);
-            if (e == hipSuccess) e = hipMalloc((void**)&d_col, total * 12);
+            if (e == hipSuccess) e = op::cached_malloc((void**)&d_xyz, total * 12);
+            if (e == hipSuccess) e = op::cached_malloc((void**)&d_col, total * 12);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_point_cloud, dim3(nb), dim3(512), 0, v->stream, v->view(), v->res, v->trunc, (unsigned*)nullptr,
                                    (const unsigned*)d_offsets, d_xyz, d_col);
@@ -2368,7 +2369,7 @@ int op_volume_point_cloud(op_volume* v, float* xyz, float* colors, size_t cap, s
     }
     void* ptrs[] = {d_counts, d_offsets, d_xyz, d_col};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) op::cached_free(p);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "point cloud failed: %s", hipGetErrorString(e));
     return rc;
 }
@@ -2407,11 +2408,11 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
     int *d_tri = nullptr, *d_edge = nullptr;
     float *d_pts = nullptr, *d_col = nullptr;
     int rc = OP_OK;
-    hipError_t e = hipMalloc((void**)&d_list, nl * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_counts, nl * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_offsets, nl * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_tri, 256 * 16 * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_edge, 24 * sizeof(int));
+    hipError_t e = op::cached_malloc((void**)&d_list, nl * sizeof(unsigned));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_counts, nl * sizeof(unsigned));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_offsets, nl * sizeof(unsigned));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_tri, 256 * 16 * sizeof(int));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_edge, 24 * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_list, list.data(), nl * sizeof(unsigned), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_tri, tri_table, 256 * 16 * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_edge, edge_pairs, 24 * sizeof(int), hipMemcpyHostToDevice);
@@ -2431,8 +2432,8 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
         else if (total_tri > 0xffffffffull / 3) rc = fail(OP_ERR_CAPACITY, "mesh too large");
         else {
             e = hipMemcpy(d_offsets, off.data(), nl * sizeof(unsigned), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMalloc((void**)&d_pts, total * 12);
-            if (e == hipSuccess) e = hipMalloc((void**)&d_col, total * 12);
+            if (e == hipSuccess) e = op::cached_malloc((void**)&d_pts, total * 12);
+            if (e == hipSuccess) e = op::cached_malloc((void**)&d_col, total * 12);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const int*)d_tri, (const int*)d_edge,
                                    (const unsigned*)d_list, (unsigned*)nullptr, (const unsigned*)d_offsets, d_pts, d_col);
@@ -2444,7 +2445,7 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
     }
     void* ptrs[] = {d_list, d_counts, d_offsets, d_tri, d_edge, d_pts, d_col};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) op::cached_free(p);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "mesh extraction failed: %s", hipGetErrorString(e));
     return rc;
 }
@@ -2593,9 +2594,9 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     float *d_depth = depth_out, *d_nrm = normals_out, *d_col = colors_out;
     if (mem == OP_MEM_HOST) {
         d_depth = d_nrm = d_col = nullptr;
-        OP_HIP(hipMalloc((void**)&d_depth, npx * 4));
-        if (normals_out) OP_HIP(hipMalloc((void**)&d_nrm, npx * 12));
-        if (colors_out) OP_HIP(hipMalloc((void**)&d_col, npx * 12));
+        OP_HIP(op::cached_malloc((void**)&d_depth, npx * 4));
+        if (normals_out) OP_HIP(op::cached_malloc((void**)&d_nrm, npx * 12));
+        if (colors_out) OP_HIP(op::cached_malloc((void**)&d_col, npx * 12));
     }
     Mat4 P;
     std::memcpy(P.m, pose, sizeof(P.m));
@@ -2606,9 +2607,9 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
         if (e == hipSuccess) e = hipMemcpy(depth_out, d_depth, npx * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess && normals_out) e = hipMemcpy(normals_out, d_nrm, npx * 12, hipMemcpyDeviceToHost);
         if (e == hipSuccess && colors_out) e = hipMemcpy(colors_out, d_col, npx * 12, hipMemcpyDeviceToHost);
-        (void)hipFree(d_depth);
-        if (d_nrm) (void)hipFree(d_nrm);
-        if (d_col) (void)hipFree(d_col);
+        op::cached_free(d_depth);
+        if (d_nrm) op::cached_free(d_nrm);
+        if (d_col) op::cached_free(d_col);
     }
     if (e != hipSuccess) return fail(OP_ERR_HIP, "raycast failed: %s", hipGetErrorString(e));
     return OP_OK;
