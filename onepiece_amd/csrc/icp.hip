@@ -969,11 +969,14 @@ int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
 
 extern "C" {
 
-int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, double threshold, int mem, int device, op_icp** out) {
+// extent_divisor > 0: the cell is the largest extent of the bounding box / extent_divisor instead of the threshold
+// (EstimateNormals' k-NN grid; the box comes from the device either way)
+static int icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, double threshold, double extent_divisor, int mem, int device,
+                      op_icp** out) {
     if (!out) return fail(OP_ERR_INVALID, "null out");
     *out = nullptr;
     if (!tgt_xyz && m) return fail(OP_ERR_INVALID, "null target");
-    if (!(threshold > 0)) return fail(OP_ERR_INVALID, "threshold must be > 0");
+    if (!(threshold > 0) && !(extent_divisor > 0)) return fail(OP_ERR_INVALID, "threshold must be > 0");
     if (m >= kMaxPoints) return fail(OP_ERR_INVALID, "target too large (at most %zu points)", kMaxPoints - 1);
     OP_TRY(op::use_device(device));
     op_icp* c = new op_icp();
@@ -1013,6 +1016,11 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
     // cell >= threshold (slightly larger so that float rounding of the cell index cannot hide a
     // neighbour closer than threshold); grow it if the grid would exceed kMaxCells
     double cell = threshold * 1.001;
+    if (extent_divisor > 0) {
+        const float ext = std::max(mx[0] - mn[0], std::max(mx[1] - mn[1], mx[2] - mn[2]));
+        cell = ext > 0 ? (double)ext / extent_divisor : 1.0;
+        c->threshold = cell;
+    }
     for (int k = 0; k < 3; ++k)
         if (!std::isfinite(mx[k]) || !std::isfinite(mn[k]) || !std::isfinite((double)mx[k] - (double)mn[k]))
             return bail(fail(OP_ERR_INVALID, "target bounding box is not finite"));
@@ -1062,6 +1070,11 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
 #undef OP_HIP_C
     *out = c;
     return OP_OK;
+}
+
+int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, double threshold, int mem, int device, op_icp** out) {
+    if (!(threshold > 0)) return fail(OP_ERR_INVALID, "threshold must be > 0");
+    return icp_create(tgt_xyz, tgt_normals, m, threshold, 0.0, mem, device, out);
 }
 
 int op_icp_destroy(op_icp* c) {
@@ -1496,22 +1509,9 @@ int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int m
     if (knn < 1 || knn > kNrmMaxK) return fail(OP_ERR_INVALID, "knn must be in [1, %d]", kNrmMaxK);
     if (n == 0) return OP_OK;
     // grid cell ~ extent / 400: a 640x480 depth cloud (3 m, 4 mm spacing) gets ~7 mm cells and
-    // finds its 30 neighbours within 2 rings; op_icp_create turns the "threshold" into the cell size
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    std::vector<float> host;
-    const float* h = xyz;
-    if (mem == OP_MEM_DEVICE) {
-        OP_TRY(op::use_device(device));
-        host.resize(n * 3);
-        OP_HIP(hipMemcpy(host.data(), xyz, n * 12, hipMemcpyDeviceToHost));
-        h = host.data();
-    }
-    for (size_t i = 0; i < n; ++i)
-        for (int c = 0; c < 3; ++c) { const float v = h[3 * i + c]; if (v == v) { mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); } }
-    const float ext = std::max(mx[0] - mn[0], std::max(mx[1] - mn[1], mx[2] - mn[2]));
-    const double cell_hint = ext > 0 ? (double)ext / 400.0 : 1.0;
+    // finds its 30 neighbours within 2 rings
     op_icp* c = nullptr;
-    OP_TRY(op_icp_create(xyz, nullptr, n, cell_hint / 1.001, mem, device, &c));
+    OP_TRY(icp_create(xyz, nullptr, n, 0.0, 400.0, mem, device, &c));
     float* d_nrm = nullptr;
     hipError_t e = op::cached_malloc((void**)&d_nrm, n * 12);
     if (e == hipSuccess) e = hipMemsetAsync(d_nrm, 0, n * 12, c->stream);
