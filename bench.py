@@ -358,9 +358,19 @@ def main():
         L.check(lib.op_icp_run(h, 1, fp(T0), iters, C.byref(res64), None, 0, None, None))
         loop_it_s = iters / (time.perf_counter() - t)
         lib.op_icp_destroy(h)
+        # what a caller of registration::PointToPlane pays: the one-shot entry point builds the search grid, uploads both
+        # clouds, runs ICPTest's 30 iterations, forms the reference-order result and drops everything again
+        reg_ms = []
+        for _ in range(6):
+            r1 = L.IcpResult()
+            t = time.perf_counter()
+            L.check(lib.op_icp_register(1, fp(src.reshape(-1)), len(src), fp(tgt.reshape(-1)), fp(nrm.reshape(-1)), len(tgt), fp(T0), 30, 0.01, local_rank,
+                                        C.byref(r1), None, 0))
+            reg_ms.append((time.perf_counter() - t) * 1e3)
         out["icp"] = {"iters_per_s": gpu_it_s, "loop_only_iters_per_s": loop_it_s, "iterations_per_call": iters, "points": int(len(src)),
                       "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31)",
                       "final_inliers": int(res.n_inliers), "estimate_normals_s": normals_s,
+                      "register_call_ms": float(np.median(reg_ms[1:])), "register_call_iterations": 30,
                       # 36 B per source point per iteration (source + matched target + normal); the kernel is
                       # a latency-bound gather (27-cell scan), so this is far from the HBM roof by construction
                       "algorithmic_gbs": 36.0 * len(src) * gpu_it_s / 1e9}
