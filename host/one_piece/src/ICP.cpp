@@ -3,6 +3,8 @@
 
 #include "Bridge.h"
 
+#include <utility>
+
 namespace one_piece {
 namespace registration {
 
@@ -10,11 +12,15 @@ namespace {
 std::shared_ptr<RegistrationResult> Run(int mode, const geometry::PointCloud& _source, const geometry::PointCloud& _target,
                                         const geometry::TransformationMatrix& init_T, const ICPParameter& icp_para) {
     RegistrationResult result;
-    geometry::Point3List source = _source.points, target = _target.points;
-    if (icp_para.scaling != 1) { // ICP.cpp:37-43
-        for (size_t i = 0; i < source.size(); ++i) source[i] = source[i] * static_cast<float>(icp_para.scaling);
-        for (size_t i = 0; i < target.size(); ++i) target[i] = target[i] * static_cast<float>(icp_para.scaling);
+    // ICP.cpp:35-43 copies both clouds and scales the copies; the copies are only made here when there is something to scale
+    geometry::Point3List scaled_source, scaled_target;
+    if (icp_para.scaling != 1) {
+        scaled_source = _source.points; scaled_target = _target.points;
+        for (size_t i = 0; i < scaled_source.size(); ++i) scaled_source[i] = scaled_source[i] * static_cast<float>(icp_para.scaling);
+        for (size_t i = 0; i < scaled_target.size(); ++i) scaled_target[i] = scaled_target[i] * static_cast<float>(icp_para.scaling);
     }
+    const geometry::Point3List& source = icp_para.scaling != 1 ? scaled_source : _source.points;
+    const geometry::Point3List& target = icp_para.scaling != 1 ? scaled_target : _target.points;
     float T0[16];
     bridge::RowMajor(init_T, T0);
     op_icp_result r;
@@ -35,7 +41,7 @@ std::shared_ptr<RegistrationResult> Run(int mode, const geometry::PointCloud& _s
         result.correspondence_set_index.push_back(std::make_pair(s, t));
         result.correspondence_set.push_back(std::make_pair(_source.points[s], _target.points[t]));
     }
-    return std::make_shared<RegistrationResult>(result);
+    return std::make_shared<RegistrationResult>(std::move(result));
 }
 } // namespace
 
