@@ -497,21 +497,6 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     }
 }
 
-// PointToPoint's per-iteration step on the device (ICP.cpp:76-79, :195-198): one thread does the Kabsch fit from the
-// totals and left-multiplies start_T, so the whole loop is enqueued without a host round trip.
-__global__ void k_point_update(const double* __restrict__ tot, float* __restrict__ T, int it, int* __restrict__ per_iter_inliers,
-                               float* __restrict__ per_iter_T, float* __restrict__ T_pub /* host-mapped copy of start_T */) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float tmp_T[16], cur[16];
-    op_host::kabsch_from_sums(tot[28], tot, tot + 3, tot + 6, tmp_T); // ICP.cpp:79
-    for (int i = 0; i < 16; ++i) cur[i] = T[i];
-    op_host::mat4_mul(tmp_T, cur, cur);   // ICP.cpp:198: start_T = tmp_T * start_T
-    for (int i = 0; i < 16; ++i) { T[i] = cur[i]; T_pub[i] = cur[i]; }
-    if (per_iter_inliers) per_iter_inliers[it] = (int)(tot[28] + 0.5);
-    if (per_iter_T) for (int i = 0; i < 16; ++i) per_iter_T[16 * it + i] = cur[i];
-}
-
-
 // Sums over an EXPLICIT correspondence list -- registration::EstimateRigidTransformationPointToPlane
 // (ICP.cpp:108-144; MODE 1: rows [n ; s x n], r = n.s - n.t over inliers (source id, target id)) and
 // geometry::EstimateRigidTransformation (Geometry.cpp:107-151; MODE 0: sum s, sum t, sum s t^T over point
@@ -849,13 +834,8 @@ struct op_icp {
     double* result_host = nullptr;      // pinned + mapped: k_reduce_update publishes the sums here (host-solve path)
     double* result_host_dev = nullptr;  // its device-side address
     double seq = 0.0;                   // publication sequence number
-    float* T_pub = nullptr;             // pinned + mapped: start_T as the device-side PointToPoint loop leaves it
-    float* T_pub_dev = nullptr;
     hipEvent_t chunk_ev[8] = {};        // arrival of the chunks of inlier rows at the host (reference-order finish)
     float* T_dev = nullptr;        // start_T (16 floats)
-    int* it_inl_dev = nullptr;     // per-iteration inlier counts
-    float* it_T_dev = nullptr;     // per-iteration start_T
-    int it_cap = 0;
     int n_wg = 0, partials_cap = 0;
     // reference-order finish / strict sums (OP_ICP_OPT_*): ordered inlier rows
     int finish = OP_ICP_FINISH_REFERENCE, sums = OP_ICP_SUMS_FP64;
@@ -869,17 +849,14 @@ namespace {
 
 // one fused pass (transform + NN + inliers + sums + reduction); start_T is read from c->T_dev unless host_T is given.
 template <int MODE>
-void launch_pass(op_icp* c, bool write_inl, int update, int it, bool trace, const float* host_T = nullptr, double seq = 0.0, bool publish = false) {
+void launch_pass(op_icp* c, bool write_inl, const float* host_T = nullptr, double seq = 0.0) {
     Mat4 Tv;
     if (host_T) std::memcpy(Tv.m, host_T, sizeof(Tv.m)); else std::memset(Tv.m, 0, sizeof(Tv.m));
     const unsigned per_group = (unsigned)((c->n_wg + kGroups - 1) / kGroups);
     hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
                        (const float*)c->src, (unsigned)c->n, c->grid, (const unsigned*)c->cell_start, (const float4*)c->tgt, (unsigned)c->m,
                        (const float*)c->tgt_orig, (const float*)c->nrm_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials,
-                       c->stage, c->sync, per_group, c->result, host_T || publish ? c->result_host_dev : nullptr, seq);
-    if (update) // point-to-point: the Kabsch step follows on the device
-        hipLaunchKernelGGL(k_point_update, dim3(1), dim3(64), 0, c->stream, (const double*)c->result, c->T_dev, it, trace ? c->it_inl_dev : nullptr,
-                           trace ? c->it_T_dev : nullptr, c->T_pub_dev);
+                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq);
 }
 
 // Waits for the rows of sums the launch with sequence number c->seq publishes (one per group of workgroups, in
@@ -903,10 +880,10 @@ int wait_rows(op_icp* c, double r[kNSums]) {
     return OP_OK;
 }
 
-int enqueue_pass(op_icp* c, int mode, bool write_inl, int update, int it, bool trace) {
-    if (mode == 1) launch_pass<1>(c, write_inl, update, it, trace);
-    else if (mode == 0) launch_pass<0>(c, write_inl, update, it, trace);
-    else launch_pass<2>(c, write_inl, update, it, trace);
+int enqueue_pass(op_icp* c, int mode, bool write_inl) {
+    if (mode == 1) launch_pass<1>(c, write_inl);
+    else if (mode == 0) launch_pass<0>(c, write_inl);
+    else launch_pass<2>(c, write_inl);
     OP_HIP(hipGetLastError());
     return OP_OK;
 }
@@ -914,7 +891,7 @@ int enqueue_pass(op_icp* c, int mode, bool write_inl, int update, int it, bool t
 // host-synchronous single pass with an explicit T (op_icp_iterate)
 int run_pass(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]) {
     OP_HIP(hipMemcpyAsync(c->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    OP_TRY(enqueue_pass(c, mode, write_inl, 0, 0, false));
+    OP_TRY(enqueue_pass(c, mode, write_inl));
     OP_HIP(hipMemcpyAsync(out, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     OP_HIP(hipStreamSynchronize(c->stream));
     return OP_OK;
@@ -1064,8 +1041,6 @@ static int icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, 
     OP_HIP_C(op::cached_host_malloc((void**)&c->result_host, (size_t)kGroups * kNSums * sizeof(double)));
     OP_HIP_C(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0));
     std::memset(c->result_host, 0, (size_t)kGroups * kNSums * sizeof(double));
-    OP_HIP_C(op::cached_host_malloc((void**)&c->T_pub, 16 * sizeof(float)));
-    OP_HIP_C(hipHostGetDevicePointer((void**)&c->T_pub_dev, c->T_pub, 0));
     for (hipEvent_t& ev : c->chunk_ev) OP_HIP_C(op::cached_event(&ev));
 #undef OP_HIP_C
     *out = c;
@@ -1096,11 +1071,10 @@ int op_icp_destroy(op_icp* c) {
     }
 #endif
     void* ptrs[] = {c->tgt_orig, c->tgt, c->sync, c->cell_start, c->src, c->nn, c->inl, c->partials, c->result,
-                    c->T_dev, c->it_inl_dev, c->it_T_dev, c->stage, c->nrm_orig, c->flag, c->start, c->scan_tot, c->rows_dev};
+                    c->T_dev, c->stage, c->nrm_orig, c->flag, c->start, c->scan_tot, c->rows_dev};
     for (void* p : ptrs)
         if (p) op::cached_free(p);
     if (c->result_host) op::cached_free(c->result_host);
-    if (c->T_pub) op::cached_free(c->T_pub);
     for (hipEvent_t ev : c->chunk_ev)
         op::release_event(ev, c->device);
     if (c->rows_host) op::cached_free(c->rows_host);
@@ -1175,27 +1149,16 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     if (!c->src && c->n) return fail(OP_ERR_INVALID, "op_icp_set_source has not been called");
     float start_T[16];
     double r[kNSums];
-    if (max_iteration > c->it_cap) {
-        op::cached_free(c->it_inl_dev);
-        op::cached_free(c->it_T_dev);
-        c->it_inl_dev = nullptr; c->it_T_dev = nullptr; c->it_cap = 0;
-        OP_HIP(op::cached_malloc((void**)&c->it_inl_dev, (size_t)max_iteration * sizeof(int)));
-        OP_HIP(op::cached_malloc((void**)&c->it_T_dev, (size_t)max_iteration * 16 * sizeof(float)));
-        c->it_cap = max_iteration;
-    }
     if (max_iteration <= 0 && c->n) OP_HIP(hipMemsetAsync(c->nn, 0xff, c->n * sizeof(int), c->stream)); // corresponding_index stays -1
     OP_HIP(hipMemsetAsync(c->sync, 0, (kGroups + 1) * sizeof(unsigned), c->stream)); // the counters reset themselves; this covers an aborted launch
-    OP_HIP(hipMemcpyAsync(c->T_dev, init_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    // ICP.cpp:177-199.  Point-to-point: the Kabsch step is cheap enough for one GPU thread, so the
-    // whole loop is enqueued back to back with the update in k_reduce_update (no host round trip).
-    // Point-to-plane: the 29 reduced sums come back to the host, which does the 6x6 solve (JacobiSVD
-    // semantics incl. its rank threshold -- the synthetic room's JTJ has cond 1.5e8, so the threshold
-    // matters) and the SE3 exp as north_star prescribes.  The round trip is kept short: the pose goes
-    // down as a by-value kernel argument and the sums come up through host-mapped pinned memory that
-    // k_reduce_update publishes with a sequence number the host spins on (no memcpy, no stream sync).
+    // ICP.cpp:177-199.  The reduced sums of every iteration come back to the host, which does the 6x6 solve (JacobiSVD
+    // semantics incl. its rank threshold -- the synthetic room's JTJ has cond 1.5e8, so the threshold matters) and the SE3
+    // exp, or the Kabsch step of PointToPoint, as north_star prescribes.  The round trip is kept short: the pose goes
+    // down as a by-value kernel argument and the sums come up through host-mapped pinned memory that the iteration
+    // kernel publishes with a sequence number the host spins on (no memcpy, no stream sync).  (PointToPoint's step used to
+    // run in a one-thread kernel after every iteration: 6 us of single-lane fp64 against 1 us of the same code on the host.)
     const int pass_mode = mode == OP_ICP_POINT_TO_PLANE ? 1 : 0;
     const bool strict = c->sums == OP_ICP_SUMS_REFERENCE_F32;
-    const bool host_path = pass_mode == 1 || strict;
     if (strict) {
         // Validation mode: every iteration's inlier rows come to the host in inlier order and are summed there
         // sequentially in float32, as the reference's loops do (ICP.cpp:121-136 / Geometry.cpp:117-133 via :76-79);
@@ -1221,8 +1184,6 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
         }
         std::memcpy(start_T, cur, sizeof(cur));
-    } else if (!host_path) {
-        for (int it = 0; it < max_iteration; ++it) OP_TRY(enqueue_pass(c, 0, false, 2, it, true));
     } else {
         float cur[16], tmp_T[16];
         std::memcpy(cur, init_T, sizeof(cur));
@@ -1235,7 +1196,8 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
 #ifdef ICP_TRACE
             const double ta = now();
 #endif
-            launch_pass<1>(c, false, 0, it, false, cur, c->seq);
+            if (pass_mode == 1) launch_pass<1>(c, false, cur, c->seq);
+            else launch_pass<0>(c, false, cur, c->seq);
             OP_HIP(hipGetLastError());
 #ifdef ICP_TRACE
             const double tb = now();
@@ -1244,11 +1206,15 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
 #ifdef ICP_TRACE
             const double tc = now();
 #endif
-            double JTJ[36], JTr[6];
-            float x[6];
-            expand_plane_sums(r, JTJ, JTr);
-            op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
-            op_host::se3_exp(x, tmp_T);        // ICP.cpp:143
+            if (pass_mode == 1) {
+                double JTJ[36], JTr[6];
+                float x[6];
+                expand_plane_sums(r, JTJ, JTr);
+                op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
+                op_host::se3_exp(x, tmp_T);        // ICP.cpp:143
+            } else {
+                op_host::kabsch_from_sums(r[28], r, r + 3, r + 6, tmp_T); // ICP.cpp:79
+            }
             op_host::mat4_mul(tmp_T, cur, cur); // ICP.cpp:198
             if (per_iter_inliers) per_iter_inliers[it] = (int32_t)(r[28] + 0.5);
             if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
@@ -1265,22 +1231,12 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     }
     // ICP.cpp:206-221: CountInliers with the final start_T over the last NN set, then Kabsch over
     // (original source, target) pairs
-    // The sums of the final pass come back like the loop's (rows in host-mapped memory, no copy, no stream sync); the
-    // final start_T is already on the host in the host-solve loops, the device-side PointToPoint loop leaves it in T_pub.
+    // The sums of the final pass come back like the loop's (rows in host-mapped memory, no copy, no stream sync).
+    // (c->T_dev is not brought up to date: the row emission of the finish works on the ORIGINAL source points.)
     c->seq += 1.0;
-    if (host_path) {
-        std::memcpy(c->T_pub, start_T, sizeof(start_T)); // T_dev is what the row emission below reads
-        OP_HIP(hipMemcpyAsync(c->T_dev, c->T_pub, sizeof(start_T), hipMemcpyHostToDevice, c->stream));
-        launch_pass<2>(c, true, 0, 0, false, start_T, c->seq);
-    } else {
-        launch_pass<2>(c, true, 0, 0, false, nullptr, c->seq, true);
-    }
+    launch_pass<2>(c, true, start_T, c->seq);
     OP_HIP(hipGetLastError());
     OP_TRY(wait_rows(c, r));
-    if (!host_path) {
-        if (max_iteration > 0) std::memcpy(start_T, c->T_pub, sizeof(start_T)); // written by the last k_point_update, which precedes the final pass
-        else std::memcpy(start_T, init_T, sizeof(start_T));
-    }
     const double n_inl = r[28];
     result->n_inliers = (uint64_t)(n_inl + 0.5);
     result->rmse = std::sqrt(r[27] / n_inl);
@@ -1313,10 +1269,6 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         op_host::kabsch_from_sums(n_inl, r, r + 3, r + 6, result->T); // order-free fp64 reduction
     }
     OP_HIP(hipStreamSynchronize(c->stream)); // the sums were read from published rows: the stream itself may still be draining
-    if (!host_path && per_iter_inliers && max_iteration > 0)
-        OP_HIP(hipMemcpy(per_iter_inliers, c->it_inl_dev, (size_t)max_iteration * sizeof(int), hipMemcpyDeviceToHost));
-    if (!host_path && per_iter_T && max_iteration > 0)
-        OP_HIP(hipMemcpy(per_iter_T, c->it_T_dev, (size_t)max_iteration * 16 * sizeof(float), hipMemcpyDeviceToHost));
     if (pairs && c->n) {
         std::vector<int> inl(c->n);
         OP_HIP(hipMemcpy(inl.data(), c->inl, c->n * sizeof(int), hipMemcpyDeviceToHost));
