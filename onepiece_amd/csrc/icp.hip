@@ -581,36 +581,10 @@ __global__ __launch_bounds__(256) void k_emit_rows(const float* __restrict__ T, 
     if (KIND == 1) { o[6] = nrm_orig[3 * (size_t)b]; o[7] = nrm_orig[3 * (size_t)b + 1]; o[8] = nrm_orig[3 * (size_t)b + 2]; }
 }
 
-// Second pass, stage 1: kStage1 workgroups each fold a contiguous slice of the per-workgroup
-// partials (deterministic order), so the final single-workgroup kernel only sees kStage1 rows.
-constexpr int kStage1 = 32;
-__global__ __launch_bounds__(256) void k_reduce_stage1(const double* __restrict__ partials, int n_partials, double* __restrict__ stage) {
-    __shared__ double s[8][kNSums];
-    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5; // 8 groups x 32 sums
-    const int per = (n_partials + kStage1 - 1) / kStage1;
-    const int lo = blockIdx.x * per, hi = min(lo + per, n_partials);
-    double v0 = 0, v1 = 0;
-    int p = lo + grp;
-    for (; p + 8 < hi; p += 16) { v0 += partials[(size_t)p * kNSums + k]; v1 += partials[(size_t)(p + 8) * kNSums + k]; }
-    for (; p < hi; p += 8) v0 += partials[(size_t)p * kNSums + k];
-    s[grp][k] = v0 + v1;
-    __syncthreads();
-    if (threadIdx.x < kNSums) {
-        double t = 0;
-        for (int g = 0; g < 8; ++g) t += s[g][threadIdx.x];
-        stage[(size_t)blockIdx.x * kNSums + threadIdx.x] = t;
-    }
-}
-
-// Second pass of the reduction + the per-iteration update (ICP.cpp:195-198), so that a whole ICP
-// run is enqueued without a single host round trip: thread 0 solves the 6x6 system (or the Kabsch
-// fit), exponentiates, and left-multiplies start_T in device memory.
-// update: 0 = reduce only, 2 = point-to-point (Kabsch) step.
-__global__ __launch_bounds__(1024) void k_reduce_update(const double* __restrict__ partials, int n_partials, double* __restrict__ out,
-                                                        int update, float* __restrict__ T, int it, int* __restrict__ per_iter_inliers,
-                                                        float* __restrict__ per_iter_T, double* __restrict__ host_out, double seq) {
+// Second pass of the reduction for the stand-alone estimators (k_pair_sums): one workgroup folds the per-workgroup rows
+// in a fixed order.  (The ICP iteration kernel folds its own rows, see k_icp_iter.)
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int n_partials, double* __restrict__ out) {
     __shared__ double s[32][kNSums];
-    __shared__ double tot[kNSums];
     const int k = threadIdx.x & 31, grp = threadIdx.x >> 5; // 32 groups x 32 sums
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0;                  // independent chains: loads stay in flight
     int p = grp;
@@ -627,23 +601,6 @@ __global__ __launch_bounds__(1024) void k_reduce_update(const double* __restrict
         double t = 0;
         for (int g = 0; g < 32; ++g) t += s[g][threadIdx.x];
         out[threadIdx.x] = t;
-        tot[threadIdx.x] = t;
-        if (host_out && threadIdx.x < kNSums - 1) host_out[threadIdx.x] = t; // host-mapped pinned memory
-    }
-    if (host_out) __threadfence_system();
-    __syncthreads();
-    if (host_out && threadIdx.x == 0) { // publish: the host spins on this sequence number
-        __hip_atomic_store(&host_out[kNSums - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (threadIdx.x == 0 && update) {
-        float tmp_T[16], cur[16];
-        // point-to-point step (the point-to-plane 6x6 solve stays on the host, see op_icp_run)
-        op_host::kabsch_from_sums(tot[28], tot, tot + 3, tot + 6, tmp_T); // ICP.cpp:79
-        for (int i = 0; i < 16; ++i) cur[i] = T[i];
-        op_host::mat4_mul(tmp_T, cur, cur);   // ICP.cpp:198: start_T = tmp_T * start_T
-        for (int i = 0; i < 16; ++i) T[i] = cur[i];
-        if (per_iter_inliers) per_iter_inliers[it] = (int)(tot[28] + 0.5);
-        if (per_iter_T) for (int i = 0; i < 16; ++i) per_iter_T[16 * it + i] = cur[i];
     }
 }
 
@@ -1037,7 +994,7 @@ static int icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, 
     OP_HIP_C(hipMemset(c->sync, 0, (kGroups + 1) * sizeof(unsigned)));
     OP_HIP_C(op::cached_malloc((void**)&c->result, kNSums * sizeof(double)));
     OP_HIP_C(op::cached_malloc((void**)&c->T_dev, 16 * sizeof(float)));
-    OP_HIP_C(op::cached_malloc((void**)&c->stage, (size_t)std::max(kStage1, kGroups) * kNSums * sizeof(double)));
+    OP_HIP_C(op::cached_malloc((void**)&c->stage, (size_t)kGroups * kNSums * sizeof(double)));
     OP_HIP_C(op::cached_host_malloc((void**)&c->result_host, (size_t)kGroups * kNSums * sizeof(double)));
     OP_HIP_C(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0));
     std::memset(c->result_host, 0, (size_t)kGroups * kNSums * sizeof(double));
@@ -1313,8 +1270,7 @@ static int pair_sums_run(int mode, const float* a, size_t na_floats, const float
     if (e == hipSuccess) {
         if (mode == 1) hipLaunchKernelGGL(k_pair_sums<1>, dim3(n_wg), dim3(kIterThreads), 0, nullptr, (const float*)d_a, (const float*)d_b, (const float*)d_n, (const int*)d_i, n, d_part);
         else hipLaunchKernelGGL(k_pair_sums<0>, dim3(n_wg), dim3(kIterThreads), 0, nullptr, (const float*)d_a, (const float*)nullptr, (const float*)nullptr, (const int*)nullptr, n, d_part);
-        hipLaunchKernelGGL(k_reduce_update, dim3(1), dim3(1024), 0, nullptr, (const double*)d_part, n_wg, d_out, 0, (float*)nullptr, 0, (int*)nullptr,
-                           (float*)nullptr, (double*)nullptr, 0.0);
+        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, nullptr, (const double*)d_part, n_wg, d_out);
         e = hipMemcpy(out, d_out, kNSums * sizeof(double), hipMemcpyDeviceToHost);
     }
     if (mem != OP_MEM_DEVICE) { op::cached_free(d_a); op::cached_free(d_b); op::cached_free(d_n); op::cached_free(d_i); }
