@@ -1204,9 +1204,17 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         // float32 sums over the correspondence_set in ascending source index
         // the rows come up in chunks and the first of the two sequential passes runs on each chunk as it lands
         const size_t n_rows = (size_t)result->n_inliers;
+#ifdef ICP_TRACE
+        auto now2 = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tf1 = now2();
+#endif
         OP_TRY(emit_rows(c, 0, n_rows, nullptr));
         op_host::KabschReferenceOrder fit;
-        constexpr size_t kChunks = sizeof(c->chunk_ev) / sizeof(c->chunk_ev[0]);
+#ifndef ICP_ROW_CHUNKS
+#define ICP_ROW_CHUNKS 3 // copies run at 33 GB/s for 1 MB pieces and at 53 GB/s from 4 MB on (tests/tools/pcie_probe.py): few, large pieces
+#endif
+        constexpr size_t kChunks = ICP_ROW_CHUNKS;
+        static_assert(kChunks >= 1 && kChunks <= sizeof(c->chunk_ev) / sizeof(c->chunk_ev[0]), "one event per chunk");
         const size_t per = (n_rows + kChunks - 1) / kChunks;
         size_t n_ev = 0;
         for (size_t lo = 0; lo < n_rows; lo += per, ++n_ev) {
@@ -1215,13 +1223,19 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             OP_HIP(hipEventRecord(c->chunk_ev[n_ev], c->stream));
         }
         for (size_t k = 0, lo = 0; k < n_ev; ++k, lo += per) {
-            hipError_t q;
-            while ((q = hipEventQuery(c->chunk_ev[k])) == hipErrorNotReady) __builtin_ia32_pause();
+            // a blocking wait: polling hipEventQuery in a loop slowed the copies themselves down (290 -> 265 us for the 7.3 MB)
+            const hipError_t q = hipEventSynchronize(c->chunk_ev[k]);
             if (q != hipSuccess) return fail(OP_ERR_HIP, "icp: copying the inlier rows failed: %s", hipGetErrorString(q));
             fit.add_rows(c->rows_host + 6 * lo, std::min(per, n_rows - lo));
         }
+#ifdef ICP_TRACE
+        const double tf2 = now2();
+#endif
         if (strict) fit.finish<true>(c->rows_host, n_rows, result->T);
         else fit.finish<false>(c->rows_host, n_rows, result->T);
+#ifdef ICP_TRACE
+        fprintf(stderr, "icp finish trace: rows to host + first pass %.1f us, second pass + fit %.1f us\n", (tf2 - tf1) * 1e6, (now2() - tf2) * 1e6);
+#endif
     } else {
         op_host::kabsch_from_sums(n_inl, r, r + 3, r + 6, result->T); // order-free fp64 reduction
     }
