@@ -647,7 +647,14 @@ __device__ __forceinline__ void sym3_smallest_eigvec(double a00, double a01, dou
 
 __global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const unsigned* __restrict__ cell_start, const float4* __restrict__ pts,
                                                                   size_t m, int knn, float radius, float cell, float* __restrict__ normals) {
-    __shared__ float s_d[kNrmMaxK][kNrmThreads];
+    // The k best candidates of a lane live in its LDS column, UNSORTED while the search runs: a candidate is compared with
+    // the worst one kept (its key and slot are in registers) and, if better, overwrites it, after which the column is
+    // rescanned for the new worst -- k reads.  Keeping the column sorted instead costs a shift loop per accepted
+    // candidate whose trip count is the maximum over the 64 lanes, and some lane accepts almost every candidate: 72 k
+    // LDS operations per wave against 11 k here (1.03 -> 0.4 ms at 307 200 points).  Keys are (bits of the squared
+    // distance, original index): non-negative floats order like their bit patterns, so "nearer, ties to the smaller
+    // index" (nanoflann's order, KDTree.h:245-251) is one unsigned 64-bit compare.  The column is sorted once at the end.
+    __shared__ unsigned long long s_key[kNrmMaxK][kNrmThreads];
     __shared__ int s_p[kNrmMaxK][kNrmThreads]; // sorted position of the neighbour (its record is pts[pos])
     const int tid = threadIdx.x;
     const size_t q = blockIdx.x * (size_t)blockDim.x + tid;
@@ -655,8 +662,26 @@ __global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const 
     const float4 me = pts[q];
     const int cx = cell_coord(me.x, g.ox, g.inv_cell, g.gx), cy = cell_coord(me.y, g.oy, g.inv_cell, g.gy),
               cz = cell_coord(me.z, g.oz, g.inv_cell, g.gz);
-    int cnt = 0;
+    int cnt = 0, worst_slot = 0;
+    unsigned long long worst = 0ull;
     const int max_ring = max(g.gx, max(g.gy, g.gz));
+    auto offer = [&](const float4& c, unsigned p) __attribute__((always_inline)) {
+        const float dx = me.x - c.x, dy = me.y - c.y, dz = me.z - c.z;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(c.w);
+        if (cnt < knn) {
+            s_key[cnt][tid] = key; s_p[cnt][tid] = (int)p;
+            if (cnt == 0 || key > worst) { worst = key; worst_slot = cnt; }
+            ++cnt;
+        } else if (key < worst) {
+            s_key[worst_slot][tid] = key; s_p[worst_slot][tid] = (int)p;
+            worst = 0ull;
+            for (int k = 0; k < knn; ++k) {
+                const unsigned long long kk = s_key[k][tid];
+                if (kk >= worst) { worst = kk; worst_slot = k; }
+            }
+        }
+    };
     for (int ring = 0; ring <= max_ring; ++ring) {
         for (int z = cz - ring; z <= cz + ring; ++z) {
             if (z < 0 || z >= g.gz) continue;
@@ -672,34 +697,37 @@ __global__ __launch_bounds__(kNrmThreads) void k_estimate_normals(Grid g, const 
                     if (x_lo > x_hi) continue;
                     const size_t row = ((size_t)z * g.gy + y) * g.gx;
                     const unsigned beg = cell_start[row + x_lo], end = cell_start[row + x_hi + 1]; // exclusive scan incl. the total
-                    for (unsigned p = beg; p < end; ++p) {
-                        const float4 c = pts[p];
-                        const float dx = me.x - c.x, dy = me.y - c.y, dz = me.z - c.z;
-                        const float d = dx * dx + dy * dy + dz * dz;
-                        const int ci = __float_as_int(c.w);
-                        if (cnt == knn) {
-                            const float wd = s_d[cnt - 1][tid];
-                            if (!(d < wd || (d == wd && ci < __float_as_int(pts[s_p[cnt - 1][tid]].w)))) continue;
-                        }
-                        int pos = cnt < knn ? cnt++ : cnt - 1;
-                        while (pos > 0) {
-                            const float pd = s_d[pos - 1][tid];
-                            if (!(d < pd || (d == pd && ci < __float_as_int(pts[s_p[pos - 1][tid]].w)))) break;
-                            s_d[pos][tid] = pd; s_p[pos][tid] = s_p[pos - 1][tid];
-                            --pos;
-                        }
-                        s_d[pos][tid] = d; s_p[pos][tid] = (int)p;
+                    for (unsigned p = beg; p < end; p += 4) { // four candidates in flight per trip
+                        float4 c[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c[k] = pts[min(p + k, end - 1)];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (p + k < end) offer(c[k], p + k);
                     }
                 }
             }
         }
         // every point outside the scanned cube is farther than ring * cell from the query
         const float reach = (float)ring * cell;
-        if (cnt == knn && s_d[cnt - 1][tid] <= reach * reach) break;
+        if (cnt == knn && __uint_as_float((unsigned)(worst >> 32)) <= reach * reach) break;
         if (cnt == (int)min((size_t)knn, m) && ring >= max_ring) break;
     }
+    // ascending (distance, index): insertion sort of the lane's column
+    for (int i = 1; i < cnt; ++i) {
+        const unsigned long long key = s_key[i][tid];
+        const int pp = s_p[i][tid];
+        int j = i;
+        while (j > 0) {
+            const unsigned long long prev = s_key[j - 1][tid];
+            if (!(key < prev)) break;
+            s_key[j][tid] = prev; s_p[j][tid] = s_p[j - 1][tid];
+            --j;
+        }
+        s_key[j][tid] = key; s_p[j][tid] = pp;
+    }
     int used = 0;
-    while (used < cnt && !(s_d[used][tid] > radius)) ++used; // squared distance vs radius, as the reference does
+    while (used < cnt && !(__uint_as_float((unsigned)(s_key[used][tid] >> 32)) > radius)) ++used; // squared distance vs radius, as the reference does
     float nx = 0, ny = 0, nz = 0;
     if (used >= 3) {
         float s0 = 0, s1 = 0, s2 = 0;
@@ -1430,10 +1458,11 @@ int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int m
     if (!xyz || !normals_out) return fail(OP_ERR_INVALID, "null argument");
     if (knn < 1 || knn > kNrmMaxK) return fail(OP_ERR_INVALID, "knn must be in [1, %d]", kNrmMaxK);
     if (n == 0) return OP_OK;
-    // grid cell ~ extent / 400: a 640x480 depth cloud (3 m, 4 mm spacing) gets ~7 mm cells and
-    // finds its 30 neighbours within 2 rings
+    // grid cell = extent / 300: a 640x480 depth cloud of a 6 m room (4-10 mm spacing) gets 2 cm cells, and most points
+    // find their 30 neighbours within the first ring (27 cells); measured 1.35 / 1.03 / 1.12 / 1.12 / 1.46 ms for
+    // divisors 400 / 300 / 250 / 200 / 150 (tools/ab_normals_cell.sh)
     op_icp* c = nullptr;
-    OP_TRY(icp_create(xyz, nullptr, n, 0.0, 400.0, mem, device, &c));
+    OP_TRY(icp_create(xyz, nullptr, n, 0.0, 300.0, mem, device, &c));
     float* d_nrm = nullptr;
     hipError_t e = op::cached_malloc((void**)&d_nrm, n * 12);
     if (e == hipSuccess) e = hipMemsetAsync(d_nrm, 0, n * 12, c->stream);
