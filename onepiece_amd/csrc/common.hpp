@@ -54,7 +54,7 @@ inline int use_device(int device) {
 // to allocate and free (hipFree synchronises the device), several times the 1-2 ms such a call computes for.  Released
 // buffers therefore go to a per-process cache and are handed out again to the next request of a similar size (best fit,
 // at most 25 % larger), so a steady stream of calls allocates nothing.  The cache holds at most kCacheDeviceBytes per
-// device and kCacheHostBytes of pinned memory, nothing above kCacheLargest (beyond that a released buffer is really freed); op_release_cached_memory()
+// device and kCacheHostBytes of pinned memory per device, nothing above kCacheLargest (beyond that a released buffer is really freed); op_release_cached_memory()
 // empties it.  Owners synchronise their stream before releasing, so a cached buffer is idle.  Contents are NOT cleared.
 constexpr size_t kCacheDeviceBytes = 8ull << 30, kCacheHostBytes = 1ull << 30, kCacheLargest = 1ull << 30;
 struct BufferCache {
@@ -67,7 +67,7 @@ struct BufferCache {
     std::vector<int> event_device;
     size_t cached(int device, bool host) const {
         size_t t = 0;
-        for (const Slot& s : free_slots) if (s.host == host && (host || s.device == device)) t += s.bytes;
+        for (const Slot& s : free_slots) if (s.host == host && s.device == device) t += s.bytes;
         return t;
     }
 };
@@ -85,7 +85,8 @@ inline hipError_t cache_alloc(void** out, size_t bytes, bool host) {
         size_t best = (size_t)-1;
         for (size_t i = 0; i < c.free_slots.size(); ++i) {
             const BufferCache::Slot& s = c.free_slots[i];
-            if (s.host != host || (!host && s.device != device) || s.bytes < bytes || s.bytes > bytes + bytes / 4 + 4096) continue;
+            // pinned memory is handed back to the device it was allocated under as well (it was mapped in that context)
+            if (s.host != host || s.device != device || s.bytes < bytes || s.bytes > bytes + bytes / 4 + 4096) continue;
             if (best == (size_t)-1 || s.bytes < c.free_slots[best].bytes) best = i;
         }
         if (best != (size_t)-1) {

@@ -81,6 +81,11 @@ int main(int argc, char** argv) {
         size_t nt = 0, ns = 0;
         CK(op_points_from_depth(&cam, depth.data(), OP_DEPTH_F32, OP_MEM_HOST, 0, tgt.data(), &nt));
         CK(op_points_from_depth(&cam, depth.data() + npx, OP_DEPTH_F32, OP_MEM_HOST, 0, src.data(), &ns));
+        for (int r = 0; r < 3; ++r) {
+            auto t0 = std::chrono::steady_clock::now();
+            CK(op_points_from_depth(&cam, depth.data() + npx, OP_DEPTH_F32, OP_MEM_HOST, 0, src.data(), &ns));
+            printf("op_points_from_depth %.3f ms (host depth image -> host points)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+        }
         auto secs = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
         CK(op_estimate_normals(tgt.data(), nt, 0.1f, 30, OP_MEM_HOST, 0, nrm.data()));
         op_icp* icp = nullptr;
