@@ -194,3 +194,15 @@ def device_count():
     n = C.c_int(0)
     check(load().op_device_count(C.byref(n)))
     return n.value
+
+
+def torch_ready(t):
+    """Makes a CUDA torch tensor's contents final before a kernel on one of the LIBRARY's streams reads it: the library's
+    objects own their HIP streams and know nothing of torch's, so work still queued on torch's current stream (the
+    tensor's producer) would race with them.  A query when torch's stream is idle (~1 us), a synchronise otherwise."""
+    if getattr(t, "is_cuda", False):
+        import torch
+        s = torch.cuda.current_stream(t.device)
+        if not s.query():
+            s.synchronize()
+    return t

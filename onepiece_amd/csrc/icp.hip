@@ -956,11 +956,17 @@ static int icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, 
     }
     float* d_nrm = nullptr;
     const hipMemcpyKind kind = mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (m) OP_HIP_C(hipMemcpy(c->tgt_orig, tgt_xyz, m * 3 * sizeof(float), kind));
+    if (m) { // device sources: ordered on the context's stream (a device-to-device hipMemcpy does not block the host)
+        if (mem == OP_MEM_DEVICE) OP_HIP_C(hipMemcpyAsync(c->tgt_orig, tgt_xyz, m * 3 * sizeof(float), kind, c->stream));
+        else OP_HIP_C(hipMemcpy(c->tgt_orig, tgt_xyz, m * 3 * sizeof(float), kind));
+    }
     if (c->has_normals) {
         OP_HIP_C(op::cached_malloc((void**)&d_nrm, m1 * 3 * sizeof(float)));
         c->nrm_orig = d_nrm; // owned by the context from here on (freed by op_icp_destroy)
-        if (m) OP_HIP_C(hipMemcpy(d_nrm, tgt_normals, m * 3 * sizeof(float), kind));
+        if (m) {
+            if (mem == OP_MEM_DEVICE) OP_HIP_C(hipMemcpyAsync(d_nrm, tgt_normals, m * 3 * sizeof(float), kind, c->stream));
+            else OP_HIP_C(hipMemcpy(d_nrm, tgt_normals, m * 3 * sizeof(float), kind));
+        }
     }
     // bounding box -> grid
     unsigned* d_box = nullptr;
@@ -1096,7 +1102,10 @@ int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
         c->src_cap = n;
     }
     c->n = n;
-    if (n) OP_HIP(hipMemcpy(c->src, src_xyz, n * 3 * sizeof(float), mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    if (n) { // a device-to-device copy does not block the host: ordered on the context's stream, ahead of the kernels that read it
+        if (mem == OP_MEM_DEVICE) OP_HIP(hipMemcpyAsync(c->src, src_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        else OP_HIP(hipMemcpy(c->src, src_xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    }
     int wg = (int)((n + kIterThreads - 1) / kIterThreads); // one source point per thread
     if (wg < 1) wg = 1;
     if (!c->partials || wg > c->partials_cap) {
@@ -1472,7 +1481,12 @@ int op_estimate_normals(const float* xyz, size_t n, float radius, int knn, int m
                            (const unsigned*)c->cell_start, (const float4*)c->tgt, n, knn, radius, cell, d_nrm);
         e = hipStreamSynchronize(c->stream);
     }
-    if (e == hipSuccess) e = hipMemcpy(normals_out, d_nrm, n * 12, mem == OP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mem == OP_MEM_DEVICE) { // ordered on the stream and finished before d_nrm goes back to the buffer cache
+        e = hipMemcpyAsync(normals_out, d_nrm, n * 12, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    } else if (e == hipSuccess) {
+        e = hipMemcpy(normals_out, d_nrm, n * 12, hipMemcpyDeviceToHost);
+    }
     if (d_nrm) op::cached_free(d_nrm);
     op_icp_destroy(c);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "estimate_normals failed: %s", hipGetErrorString(e));

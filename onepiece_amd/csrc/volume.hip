@@ -2233,7 +2233,10 @@ int op_volume_keys_device(op_volume* v, int32_t* d_keys, size_t cap, size_t* n) 
     OP_TRY(vol_block_count(v, &nb));
     if (n) *n = nb;
     const size_t take = std::min((size_t)nb, cap);
-    if (d_keys && take) OP_HIP(hipMemcpy(d_keys, v->keys, take * 3 * sizeof(int), hipMemcpyDeviceToDevice));
+    if (d_keys && take) { // on the volume's stream and complete on return (a device-to-device hipMemcpy does not block the host)
+        OP_HIP(hipMemcpyAsync(d_keys, v->keys, take * 3 * sizeof(int), hipMemcpyDeviceToDevice, v->stream));
+        OP_HIP(hipStreamSynchronize(v->stream));
+    }
     return OP_OK;
 }
 

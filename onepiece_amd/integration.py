@@ -40,9 +40,9 @@ def _image_arg(img, kind):
     """-> (pointer, fmt, mem, keepalive).  kind: 'depth' | 'rgb'.
 
     CUDA torch tensors are used in place by kernels on the LIBRARY's streams (each volume / tracker / ICP object
-    owns one), not on torch's: the tensor's contents must be final when the call is made -- synchronise the torch
-    stream that produced it (`torch.cuda.current_stream().synchronize()`) if it was written by an asynchronous
-    torch op just before."""
+    owns one), not on torch's: the tensor's contents must be final when the kernels run, so torch's current stream is
+    drained first if it still has work queued (L.torch_ready; nothing when it is idle).  A tensor produced on ANOTHER
+    torch stream is the caller's to synchronise."""
     if hasattr(img, "data_ptr"):  # torch tensor
         if not img.is_cuda or not img.is_contiguous():
             raise ValueError("torch images must be contiguous CUDA tensors")
@@ -58,6 +58,7 @@ def _image_arg(img, kind):
             if img.dtype != torch.uint8:
                 raise ValueError("rgb must be uint8 (CV_8UC3)")
             fmt = 0
+        L.torch_ready(img)
         return C.c_void_p(img.data_ptr()), fmt, L.OP_MEM_DEVICE, img
     a = np.ascontiguousarray(img)
     if kind == "depth":

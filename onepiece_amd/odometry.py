@@ -61,6 +61,7 @@ def _image_ptr(a, h, w, keep):
     if a.dtype != torch.float32 or not a.is_contiguous() or tuple(a.shape) != (h, w):
         raise ValueError("device images must be contiguous float32 (h, w) tensors")
     keep.append(a)
+    L.torch_ready(a)
     return a.data_ptr(), (L.OP_MEM_DEVICE if a.is_cuda else L.OP_MEM_HOST)
 
 

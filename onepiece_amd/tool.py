@@ -29,6 +29,7 @@ def BilateralFilter(source, range=7, depth_scale=1000.0, device=0, stream=None, 
         import torch
         if not source.is_cuda or not source.is_contiguous():
             raise ValueError("torch images must be contiguous CUDA tensors")
+        L.torch_ready(source)
         if source.dtype == torch.float32:
             fmt = L.OP_DEPTH_F32
         elif source.dtype in (torch.uint16, torch.int16):
