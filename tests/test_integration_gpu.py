@@ -536,3 +536,26 @@ def test_projection_with_shared_reciprocal_equals_plain_division():
     assert np.all(out[~fin][:, :2] == np.iinfo(np.int32).min)
     # 5. an intrinsic whose fractional part is 0.5 takes the double-precision rounding path
     agree(run(rng.uniform(-2, 2, 4096), rng.uniform(-2, 2, 4096), rng.uniform(0.2, 5, 4096), cx=np.float32(320.5), cy=np.float32(240.5)))
+
+
+def test_torch_tensors_are_final_before_library_kernels_read_them():
+    """The library's objects own their HIP streams; a torch tensor handed to them may still be the target of work queued
+    on torch's stream.  Here the depth frames are written by a copy that sits behind ~30 ms of queued matrix products:
+    the mirrors must drain torch's stream before the fusion kernels read the tensor (L.torch_ready), not fuse zeros."""
+    import torch
+    dev = torch.device("cuda", 0)
+    depth, rgb, poses = S.room_sequence_torch(300, 6, dev)
+    torch.cuda.synchronize()
+    ref = I.CubeHandler(max_blocks=1 << 17); ref.SetVoxelResolution(0.01)
+    ref.IntegrateSequence(depth, rgb, poses)
+    want = ref.Stats()
+    late = torch.zeros_like(depth)
+    junk = torch.randn(4096, 4096, device=dev)
+    for _ in range(30):
+        junk = (junk @ junk) * 1e-4
+    late.copy_(depth)                     # queued behind the products, not done yet
+    hv = I.CubeHandler(max_blocks=1 << 17); hv.SetVoxelResolution(0.01)
+    hv.IntegrateSequence(late, rgb, poses)
+    got = hv.Stats()
+    assert got == want and got["voxels_updated"] > 0
+    del junk
