@@ -74,6 +74,7 @@ constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgro
 static_assert(KC_GRID % 8 == 0 && KC_GRID >= 8, "one drawing workgroup per XCD slab at least");
 constexpr int kIntegrateGrid = KC_GRID;
 constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
+constexpr int kAccSlots = 16;        // see State::acc
 #ifndef KC_SUB
 #define KC_SUB 8 // frames whose gathers are in flight together inside k_integrate (divides kMaxBatch)
 #endif
@@ -105,6 +106,11 @@ struct State {
     unsigned long long n_cand[kMaxBatch];
     float bbox[kMaxBatch][6]; // max xyz, min xyz
     unsigned n_inside[kMaxBatch];
+    // ComputeBounding of the batch's frames, accumulated by KA's workgroups with atomicMax / atomicAdd: [0..2] max xyz and
+    // [3..5] min xyz of the in-frustum points as order-preserving words (the minima complemented, so that 0 is the identity
+    // of all six), [6] their number.  Zeroed by whoever consumed them last (KC, k_finish_select) and by vol_reset.
+    unsigned acc[kMaxBatch][kAccSlots][8]; // kAccSlots sets per frame (workgroup x uses set x % kAccSlots): atomics on ONE
+                                            // address serialise at ~100 ns each, 300 of them cost KA 35 us
     unsigned kc_next[8 * 16]; // KC dynamic scheduling: next list position of each XCD's slab (one cache line each)
 };
 
@@ -283,11 +289,20 @@ __global__ void k_rehash(unsigned long long* __restrict__ tkeys, int* __restrict
 
 // After a select-only launch (PrepareCubes API): clear the batch masks again and translate the
 // recorded table slots into pool slots.
-__global__ void k_finish_select(VolView V, const State* st) {
+__global__ void k_finish_select(VolView V, State* st) {
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u; // as KC does
     const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
     const unsigned nr = st->n_rec < V.max_blocks ? st->n_rec : V.max_blocks;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) V.bmask[V.blist[i]] = 0u;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) V.sel_list[i] = V.tvals[V.sel_list[i]];
+}
+
+__device__ __forceinline__ unsigned ord_enc(float f) { // order-preserving float -> unsigned
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_dec(unsigned e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -372,6 +387,17 @@ __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C,
     } else if (tid == 6) {
         ((unsigned*)pout)[6] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
+    // ... and into the frame's accumulators, from which every KB workgroup takes the candidate range (they used to fold
+    // the frame's 300 partial rows each: a third of that kernel's time).  The rows stay for op_volume_compute_bounding.
+    if (tid < 7) {
+        const unsigned cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (cnt) { // a workgroup without an in-frustum point contributes nothing (its row is the identity)
+            unsigned* a = st->acc[f][blockIdx.x % kAccSlots];
+            if (tid < 3) atomicMax(&a[tid], ord_enc(pout[tid]));
+            else if (tid < 6) atomicMax(&a[tid], ~ord_enc(pout[tid]));
+            else atomicAdd(&a[6], cnt);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,9 +409,7 @@ __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C,
 // ---------------------------------------------------------------------------------------------
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg,
-                                                const float* __restrict__ partial, int n_partial, State* st, int record) {
-    __shared__ float s_red[4][6];
-    __shared__ unsigned s_cnt[4];
+                                                State* st, int record) {
     __shared__ int s_range[6]; // i0, j0, k0, ni, nj, nk
     __shared__ unsigned s_wa[4], s_wb[4], s_base[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,32 +433,26 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
     const float* M = B.f[f].m;
     const uint2* img = pimg + (size_t)f * C.width * C.height;
 
-    // -- finish ComputeBounding: reduce KA's partials of this frame (every workgroup, redundantly)
-    float mx0 = -FLT_MAX, mx1 = -FLT_MAX, mx2 = -FLT_MAX, mn0 = FLT_MAX, mn1 = FLT_MAX, mn2 = FLT_MAX;
-    unsigned inside = 0;
-    for (int g = tid; g < n_partial; g += 256) {
-        const float* p = partial + ((size_t)f * n_partial + g) * 8;
-        mx0 = fmaxf(mx0, p[0]); mx1 = fmaxf(mx1, p[1]); mx2 = fmaxf(mx2, p[2]);
-        mn0 = fminf(mn0, p[3]); mn1 = fminf(mn1, p[4]); mn2 = fminf(mn2, p[5]);
-        inside += ((const unsigned*)p)[6];
+    // -- finish ComputeBounding from the frame's accumulators (k_prepare_frames)
+    unsigned tot = 0, e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (wave == 0) { // lane k < kAccSlots reads set k (one round trip), then a 16-lane fold
+        if (lane < kAccSlots) {
+            const unsigned* a = st->acc[f][lane];
+            tot = a[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) e[c] = a[c];
+        }
+#pragma unroll
+        for (int o = kAccSlots / 2; o > 0; o >>= 1) {
+            tot += __shfl_xor(tot, o, 64);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { const unsigned x = __shfl_xor(e[c], o, 64); e[c] = x > e[c] ? x : e[c]; }
+        }
     }
-    mx0 = wave_max(mx0); mx1 = wave_max(mx1); mx2 = wave_max(mx2);
-    mn0 = wave_min(mn0); mn1 = wave_min(mn1); mn2 = wave_min(mn2);
-    inside = wave_sum(inside);
-    if (lane == 0) {
-        s_red[wave][0] = mx0; s_red[wave][1] = mx1; s_red[wave][2] = mx2;
-        s_red[wave][3] = mn0; s_red[wave][4] = mn1; s_red[wave][5] = mn2;
-        s_cnt[wave] = inside;
-    }
-    __syncthreads();
     if (tid == 0) {
         float b[6];
-        for (int c = 0; c < 6; ++c) {
-            float v = s_red[0][c];
-            for (int w = 1; w < 4; ++w) v = c < 3 ? fmaxf(v, s_red[w][c]) : fminf(v, s_red[w][c]);
-            b[c] = v;
-        }
-        const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        for (int c = 0; c < 6; ++c) // nothing in the frustum: the reference's lowest() / max() start values (CubeHandler.cpp:129-130)
+            b[c] = tot ? ord_dec(c < 3 ? e[c] : ~e[c]) : (c < 3 ? -FLT_MAX : FLT_MAX);
         // A batch that ran out of pool / table space poisons the stream: its KC and every later batch do nothing (an empty
         // candidate range here), so that the host can grow the volume and REPLAY from the failing batch on -- no frame is
         // ever partially fused (vol_recover).  Read by one thread per workgroup: a per-thread load of this hot line next to
@@ -584,6 +602,8 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                                                    unsigned long long* __restrict__ sel_partial) {
     __shared__ unsigned s_upd[8];
     __shared__ float s_c255[256]; // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
+    // KB has consumed the frames' bounding accumulators: back to the identity for the next batch (also when poisoned)
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u;
     if (st->overflow & 3u) return; // pool / table exhausted in this or an earlier batch: nothing is fused, the host replays
     const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
     const int vid = threadIdx.x;
@@ -1525,13 +1545,13 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
     if (C.fast_px)
         hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
-                           (const float*)v->partial, g1, v->state, record ? 1 : 0);
+                           v->state, record ? 1 : 0);
     else
         hipLaunchKernelGGL(k_select<false>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
-                           (const float*)v->partial, g1, v->state, record ? 1 : 0);
+                           v->state, record ? 1 : 0);
     if (sample) OP_HIP(hipEventRecord(ev[2], v->stream));
     if (select_only)
-        hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, (const State*)v->state);
+        hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, v->state);
     else {
 #define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV>), dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
                                                  v->state, nf, v->upd_partial, v->sel_partial)
@@ -1956,6 +1976,8 @@ int op_volume_compute_bounding(op_volume* v, const void* depth, int depth_fmt, i
     hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state, (unsigned)(++v->seq),
                        (const unsigned*)v->n_blocks, v->hstat_dev);
     OP_HIP(hipGetLastError());
+    // no KB / KC follows to consume and zero the frame's bounding accumulators: do it here (the rows are read below)
+    OP_HIP(hipMemsetAsync(reinterpret_cast<char*>(v->state) + offsetof(State, acc), 0, sizeof(State::acc), v->stream));
     OP_HIP(hipStreamSynchronize(v->stream));
     std::vector<float> part((size_t)g1 * 8);
     OP_HIP(hipMemcpy(part.data(), v->partial, part.size() * sizeof(float), hipMemcpyDeviceToHost));
