@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const unsigned* __restrict__
 }
 
 __global__ void k_cell_scatter(const float* __restrict__ xyz, size_t m, Grid g,
-                               const unsigned* __restrict__ start, unsigned* __restrict__ fill, float4* __restrict__ sorted) {
+                               const unsigned* __restrict__ start, unsigned* __restrict__ left, float4* __restrict__ sorted) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= m) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -188,7 +188,9 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, size_t m, Grid g,
     const int cx = cell_coord(x, g.ox, g.inv_cell, g.gx), cy = cell_coord(y, g.oy, g.inv_cell, g.gy),
               cz = cell_coord(z, g.oz, g.inv_cell, g.gz);
     const size_t c = ((size_t)cz * g.gy + cy) * g.gx + cx;
-    const unsigned pos = start[c] + atomicAdd(&fill[c], 1u);
+    // `left` is the cell's count from k_cell_count, counted down: the order inside a cell is arbitrary either way (the search
+    // orders candidates by (distance, original index)), and no second per-cell array has to be allocated and zeroed
+    const unsigned pos = start[c] + (atomicSub(&left[c], 1u) - 1u);
     sorted[pos] = make_float4(x, y, z, __int_as_float((int)i));
 }
 
@@ -1009,18 +1011,16 @@ static int icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, 
     // run of x-adjacent cells is [cell_start[first], cell_start[last + 1]) and one 16-byte load sees both ends
     const size_t n_tab = c->ncell + 4;
     OP_HIP_C(op::cached_malloc((void**)&c->cell_start, n_tab * sizeof(unsigned)));
-    unsigned *d_count = nullptr, *d_fill = nullptr;
+    unsigned* d_count = nullptr;
     OP_HIP_C(op::cached_malloc((void**)&d_count, n_tab * sizeof(unsigned)));
-    if (op::cached_malloc((void**)&d_fill, c->ncell * sizeof(unsigned)) != hipSuccess) { op::cached_free(d_count); return bail(fail(OP_ERR_HIP, "grid build: out of memory")); }
-    auto drop = [&]() { op::cached_free(d_count); op::cached_free(d_fill); };
+    auto drop = [&]() { op::cached_free(d_count); };
     hipError_t e = hipMemsetAsync(d_count, 0, n_tab * sizeof(unsigned), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_fill, 0, c->ncell * sizeof(unsigned), c->stream);
     if (e != hipSuccess) { drop(); return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e))); }
     if (m) hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m, c->grid, d_count);
     int rc = device_exclusive_scan(d_count, n_tab, c->cell_start, c->stream, nullptr);
     if (rc != OP_OK) { drop(); return bail(rc); }
     if (m) hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->tgt_orig, m,
-                              c->grid, (const unsigned*)c->cell_start, d_fill, c->tgt);
+                              c->grid, (const unsigned*)c->cell_start, d_count, c->tgt);
     e = hipStreamSynchronize(c->stream);
     drop();
     if (e != hipSuccess) return bail(fail(OP_ERR_HIP, "grid build failed: %s", hipGetErrorString(e)));
