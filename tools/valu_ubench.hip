@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* c
         if (OP == 18) { REP16(asm volatile("v_add_u32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
         if (OP == 19) { REP16(asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p0), "v"(pb) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p1), "v"(pb) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p2), "v"(pb) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p3), "v"(pb) : "vcc");) }
         if (OP == 20) { REP16(asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %0" : "+v"(x1)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x2) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 21) { REP16(asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc"); asm volatile("s_add_u32 s21, s21, 1" ::: "s21", "scc"); asm volatile("s_add_u32 s22, s22, 1" ::: "s22", "scc"); asm volatile("s_add_u32 s23, s23, 1" ::: "s23", "scc");) }
+        if (OP == 22) { REP16(asm volatile("s_and_b64 s[20:21], s[20:21], exec" ::: "s20", "s21", "scc"); asm volatile("s_or_b64 s[22:23], s[22:23], exec" ::: "s22", "s23", "scc"); asm volatile("s_and_b64 s[24:25], s[24:25], exec" ::: "s24", "s25", "scc"); asm volatile("s_or_b64 s[26:27], s[26:27], exec" ::: "s26", "s27", "scc");) }
+        if (OP == 23) { REP16(asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc"); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("s_add_u32 s21, s21, 1" ::: "s21", "scc");) }
+        if (OP == 24) { REP16(asm volatile("s_nop 0"); asm volatile("s_nop 0"); asm volatile("s_nop 0"); asm volatile("s_nop 0");) }
         if (OP == 10) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p3) : "v"(pb));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -89,6 +93,10 @@ int main() {
         run<16>("v_add_f32", w, d_out, d_cyc, cus);
         run<18>("v_add_u32", w, d_out, d_cyc, cus);
         run<19>("v_cmp_lt_u64", w, d_out, d_cyc, cus);
+        run<21>("s_add_u32", w, d_out, d_cyc, cus);
+        run<22>("s_and/or_b64", w, d_out, d_cyc, cus);
+        run<23>("v_mul + s_add mixed", w, d_out, d_cyc, cus);
+        run<24>("s_nop 0", w, d_out, d_cyc, cus);
     }
     return 0;
 }
