@@ -103,6 +103,7 @@ struct State {
     unsigned cur_seq;   // sequence number of the batch whose kernels are running (written by KA)
     unsigned pad[3];
     unsigned long long stat_frames;
+    unsigned long long stat_launches; // k_integrate launches that fused something (a poisoned launch does not count)
     unsigned long long n_cand[kMaxBatch];
     float bbox[kMaxBatch][6]; // max xyz, min xyz
     unsigned n_inside[kMaxBatch];
@@ -599,8 +600,8 @@ typedef unsigned int kc_v2u __attribute__((ext_vector_type(2)));
 template <bool FAST, bool PLAIN>
 __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                    int n_frames, unsigned long long* __restrict__ upd_partial,
-                                                   unsigned long long* __restrict__ sel_partial) {
-    __shared__ unsigned s_upd[8];
+                                                   unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial) {
+    __shared__ unsigned s_upd[8], s_chg[8];
     __shared__ float s_c255[256]; // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
     // KB has consumed the frames' bounding accumulators: back to the identity for the next batch (also when poisoned)
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u;
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
     // resource): the lane offset is a 32-bit byte offset, and a lane whose projection falls outside the image asks for
     // offset -8, beyond num_records, which the hardware answers with zeros (depth 0 = "no observation") -- no exec-mask
     // branch around the load and no 64-bit address arithmetic in vector registers.
-    unsigned upd = 0, sel = 0;
+    unsigned upd = 0, sel = 0, chg = 0, nblk = 0; // chg / nblk: voxels written / blocks read by THIS launch (the batch-level byte model)
     // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): XCD x walks
     // the x-th contiguous eighth of the list, so list neighbours -- blocks along one viewing ray,
     // which gather the same pixels -- are processed on one XCD close in time and share its L2.
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
         if (idx >= 0) {
         const unsigned mask = V.bmask[V.blist[b]];
         sel += __popc(mask);
+        ++nblk;
         const int kx = V.keys[3 * idx], ky = V.keys[3 * idx + 1], kz = V.keys[3 * idx + 2];
         float* vox = V.pool + (size_t)idx * kBlockFloats + vid;
         float s = vox[0], w = vox[kVox], c0 = vox[2 * kVox], c1 = vox[3 * kVox], c2 = vox[4 * kVox];
@@ -736,6 +738,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
             }
         }
         if (changed) { vox[0] = s; vox[kVox] = w; vox[2 * kVox] = c0; vox[3 * kVox] = c1; vox[4 * kVox] = c2; }
+        chg += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(changed));
         }
         __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
         if (b < n && vid == 0) V.bmask[V.blist[b]] = 0u;   // the owner clears it for the next batch
@@ -743,14 +746,16 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
         j = s_next[slot];
     }
     // per-workgroup counters (each workgroup owns its slot: no atomics)
-    if ((vid & 63) == 0) s_upd[vid >> 6] = upd; // `upd` is already the wave's total (ballot counts)
+    if ((vid & 63) == 0) { s_upd[vid >> 6] = upd; s_chg[vid >> 6] = chg; } // already the wave's totals (ballot counts)
     __syncthreads();
     if (vid == 0) {
-        unsigned t = 0;
-        for (int k = 0; k < 8; ++k) t += s_upd[k];
+        unsigned t = 0, c = 0;
+        for (int k = 0; k < 8; ++k) { t += s_upd[k]; c += s_chg[k]; }
         upd_partial[blockIdx.x] += t;
         sel_partial[blockIdx.x] += sel;
-        if (blockIdx.x == 0) st->stat_frames += (unsigned long long)n_frames;
+        chg_partial[blockIdx.x] += c;
+        chg_partial[kIntegrateGrid + blockIdx.x] += nblk;
+        if (blockIdx.x == 0) { st->stat_frames += (unsigned long long)n_frames; st->stat_launches += 1ull; }
     }
 }
 
@@ -1229,6 +1234,7 @@ struct op_volume {
     size_t pimg_px = 0;
     unsigned long long* upd_partial = nullptr;
     unsigned long long* sel_partial = nullptr;
+    unsigned long long* chg_partial = nullptr; // [0, grid): voxels written, [grid, 2 grid): blocks read, summed over launches
     // optional HIP-event timing (op_volume_profile_*): every `prof_every`-th batch gets four events
     // on the volume's stream (before KA, after KA, after KB, after KC); prof_frames = frames per sample
     int prof_every = 0;
@@ -1298,6 +1304,7 @@ int vol_reset(op_volume* v) {
     OP_HIP(hipMemsetAsync(v->state, 0, sizeof(State), v->stream));
     OP_HIP(hipMemsetAsync(v->upd_partial, 0, sizeof(unsigned long long) * kIntegrateGrid, v->stream));
     OP_HIP(hipMemsetAsync(v->sel_partial, 0, sizeof(unsigned long long) * kIntegrateGrid, v->stream));
+    OP_HIP(hipMemsetAsync(v->chg_partial, 0, sizeof(unsigned long long) * 2 * kIntegrateGrid, v->stream));
     OP_HIP(hipGetLastError());
     return OP_OK;
 }
@@ -1554,7 +1561,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, v->state);
     else {
 #define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV>), dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
-                                                 v->state, nf, v->upd_partial, v->sel_partial)
+                                                 v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial)
         if (C.fast_px) { if (v->plain) OP_KC(true, true); else OP_KC(true, false); }
         else { if (v->plain) OP_KC(false, true); else OP_KC(false, false); }
 #undef OP_KC
@@ -1852,6 +1859,7 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     OP_HIP_C(op::cached_malloc((void**)&v->sel_cand, sizeof(unsigned long long) * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->state, sizeof(State)));
     OP_HIP_C(op::cached_malloc((void**)&v->upd_partial, sizeof(unsigned long long) * kIntegrateGrid));
+    OP_HIP_C(op::cached_malloc((void**)&v->chg_partial, sizeof(unsigned long long) * 2 * kIntegrateGrid));
     OP_HIP_C(op::cached_host_malloc((void**)&v->hstat, 2 * sizeof(unsigned)));
     v->hstat[0] = 0; v->hstat[1] = 0;
     OP_HIP_C(hipHostGetDevicePointer((void**)&v->hstat_dev, v->hstat, 0));
@@ -1870,7 +1878,7 @@ int op_volume_destroy(op_volume* v) {
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
-                    v->partial, v->pimg, v->upd_partial, v->sel_partial, v->img_depth, v->img_rgb, v->unpack_slots};
+                    v->partial, v->pimg, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots};
     for (void* p : ptrs)
         if (p) op::cached_free(p);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
@@ -2100,6 +2108,21 @@ int op_volume_stats(op_volume* v, uint64_t* frames, uint64_t* blocks_selected, u
     if (blocks_selected) *blocks_selected = sel;
     if (voxels_visited) *voxels_visited = sel * (uint64_t)kVox;
     if (voxels_updated) *voxels_updated = upd;
+    return OP_OK;
+}
+
+int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_read, uint64_t* voxels_written) {
+    OP_VOL(v);
+    OP_TRY(vol_check(v));
+    State st;
+    OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> part(2 * kIntegrateGrid);
+    OP_HIP(hipMemcpy(part.data(), v->chg_partial, 2 * kIntegrateGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long chg = 0, blk = 0;
+    for (int i = 0; i < kIntegrateGrid; ++i) { chg += part[i]; blk += part[kIntegrateGrid + i]; }
+    if (launches) *launches = st.stat_launches;
+    if (blocks_read) *blocks_read = blk;
+    if (voxels_written) *voxels_written = chg;
     return OP_OK;
 }
 

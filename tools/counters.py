@@ -31,7 +31,7 @@ def build_driver():
     if os.path.exists(DRIVER) and os.path.getmtime(DRIVER) >= os.path.getmtime(os.path.join(ROOT, "tools", "prof_driver.cpp")):
         return DRIVER
     lib = os.path.join(ROOT, "onepiece_amd")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "prof_driver.cpp"),
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "prof_driver.cpp"),
                            "-L", lib, "-lonepiece_hip", "-Wl,-rpath," + lib, "-o", DRIVER])
     return DRIVER
 

@@ -8,7 +8,10 @@
 // threshold 0.01 -- ICPTest.cpp's configuration), `reps` times.
 // With "host": one op_volume_integrate call per frame with pageable HOST images (float32 and uint16 depth), the
 // reference's call pattern (PCIe-inclusive rate).
-// Build: hipcc -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o tools/prof_driver.bin
+// With "batch=N" (N = 1..16): the default fusion loop, but the sequence is handed over N frames per call, so every
+// k_integrate launch fuses N frames (batch=1: one frame per launch, where SURVEY 8(d)'s byte model is a lower bound of
+// the launch's HBM traffic).
+// Build: hipcc --offload-arch=gfx950 -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o tools/prof_driver.bin
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -39,8 +42,8 @@ int main(int argc, char** argv) {
     fclose(f);
     float* d_depth; unsigned char* d_rgb;
     if (hipMalloc((void**)&d_depth, depth.size() * 4) != hipSuccess || hipMalloc((void**)&d_rgb, rgb.size()) != hipSuccess) return 1;
-    hipMemcpy(d_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(d_rgb, rgb.data(), rgb.size(), hipMemcpyHostToDevice);
+    if (hipMemcpy(d_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    if (hipMemcpy(d_rgb, rgb.data(), rgb.size(), hipMemcpyHostToDevice) != hipSuccess) return 1;
     op_camera cam; CK(op_camera_preset(1, &cam));
     cam.width = w; cam.height = h;
     op_volume* v; CK(op_volume_create(&cam, voxel, 0.1f, 5.0f, 0.5f, 0, 1u << 18, &v));
@@ -150,15 +153,23 @@ int main(int argc, char** argv) {
         op_volume_destroy(v);
         return 0;
     }
+    int batch = n;
+    if (argc > 4 && std::string(argv[4]).rfind("batch=", 0) == 0) batch = atoi(argv[4] + 6);
+    if (batch < 1) batch = 1;
     for (int r = 0; r < reps; ++r) {
         CK(op_volume_clear(v));
         auto t0 = std::chrono::steady_clock::now();
-        CK(op_volume_integrate_sequence(v, d_depth, npx * 4, OP_DEPTH_F32, d_rgb, npx * 3, poses.data(), (size_t)n));
+        for (int f0 = 0; f0 < n; f0 += batch) {
+            const int nf = n - f0 < batch ? n - f0 : batch;
+            CK(op_volume_integrate_sequence(v, d_depth + npx * f0, npx * 4, OP_DEPTH_F32, d_rgb + npx * 3 * f0, npx * 3, poses.data() + (size_t)f0 * 16, (size_t)nf));
+        }
         CK(op_volume_sync(v));
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         uint64_t fr, sel, vis, upd; CK(op_volume_stats(v, &fr, &sel, &vis, &upd));
+        uint64_t ln, br, vw; CK(op_volume_stats_launches(v, &ln, &br, &vw));
         size_t nb; CK(op_volume_block_count(v, &nb));
-        printf("rep %d: %d frames %.3f ms/frame  sel/frame %.0f  upd/frame %.0f  blocks %zu\n", r, n, dt / n * 1e3, (double)sel / fr, (double)upd / fr, nb);
+        printf("rep %d: %d frames %.3f ms/frame  sel/frame %.0f  upd/frame %.0f  blocks %zu | k_integrate launches %llu (%.2f frames each): blocks read %.0f, "
+               "voxels written %.0f per launch\n", r, n, dt / n * 1e3, (double)sel / fr, (double)upd / fr, nb, (unsigned long long)ln, (double)fr / ln, (double)br / ln, (double)vw / ln);
     }
     op_volume_destroy(v);
     return 0;

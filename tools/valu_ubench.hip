@@ -50,6 +50,16 @@ __global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* c
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// s_memtime ticks per microsecond of wall time: the same wave reads s_memtime and s_memrealtime (constant 100 MHz) around a
+// ~1 ms busy loop, so the per-instruction figures above convert to time (and to a fraction of a kernel's duration)
+__global__ void k_clock(unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < 100000ull) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[0] = t1 - t0; out[1] = r1 - r0;
+}
+
 template <int OP>
 void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, int cus) {
     const int wgs = cus * waves_per_simd; // 256 threads = 4 waves = one wave per SIMD of a CU (per resident workgroup)
@@ -71,6 +81,13 @@ int main() {
     float* d_out; unsigned long long* d_cyc;
     hipMalloc((void**)&d_out, (size_t)cus * 16 * 256 * 4);
     hipMalloc((void**)&d_cyc, (size_t)cus * 16 * 4 * 8);
+    {
+        hipLaunchKernelGGL(k_clock, dim3(1), dim3(1), 0, 0, d_cyc);
+        hipDeviceSynchronize();
+        unsigned long long c[2];
+        hipMemcpy(c, d_cyc, 16, hipMemcpyDeviceToHost);
+        std::printf("clock: %llu s_memtime ticks in %llu s_memrealtime ticks (100 MHz) -> %.2f s_memtime ticks per microsecond\n", c[0], c[1], (double)c[0] / ((double)c[1] / 100.0));
+    }
     for (int w : {1, 4, 8}) {
         run<0>("v_mul_f32", w, d_out, d_cyc, cus);
         run<1>("v_fma_f32", w, d_out, d_cyc, cus);
