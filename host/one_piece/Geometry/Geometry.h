@@ -8,6 +8,9 @@
 // The arithmetic behind the functions lives in libonepiece_hip.so (C-ABI, include/onepiece_hip.h).
 #pragma once
 #include <cstddef>
+#include <iostream> // the reference's Geometry.h brings it in, and its callers print with std::cout (example/ICPTest.cpp:11)
+#include <memory>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -42,6 +45,7 @@ typedef Eigen::Matrix<scalar, 2, 1> Vector2;
 typedef Eigen::Matrix<scalar, 3, 1> Vector3;
 typedef Eigen::Matrix<scalar, 4, 1> Vector4;
 typedef Eigen::Matrix<scalar, 6, 1> Vector6;
+typedef Eigen::Matrix<scalar, 2, 2> Matrix2;
 typedef Eigen::Matrix<scalar, 3, 3> Matrix3;
 typedef Eigen::Matrix<scalar, 4, 4> Matrix4;
 typedef Eigen::Matrix<scalar, 6, 6> Matrix6;
@@ -55,6 +59,7 @@ typedef compat::Mat<scalar, 2, 1> Vector2;
 typedef compat::Mat<scalar, 3, 1> Vector3;
 typedef compat::Mat<scalar, 4, 1> Vector4;
 typedef compat::Mat<scalar, 6, 1> Vector6;
+typedef compat::Mat<scalar, 2, 2> Matrix2;
 typedef compat::Mat<scalar, 3, 3> Matrix3;
 typedef compat::Mat<scalar, 4, 4> Matrix4;
 typedef compat::Mat<scalar, 6, 6> Matrix6;
@@ -69,7 +74,10 @@ typedef Matrix4 TransformationMatrix;
 typedef Vector3 Point3;
 typedef Vector2 Point2;
 typedef Vector6 Se3;
+typedef Vector3 So3;
+typedef Vector4 Plane; // (normal, d) with normal . p + d = 0 (Geometry.h:85)
 typedef Matrix4 SE3;
+typedef Matrix3 SO3;
 
 typedef std::pair<Point3, Point3> PointCorrespondence;
 typedef std::vector<PointCorrespondence> PointCorrespondenceSet;
@@ -82,6 +90,7 @@ typedef ONEPIECE_ALIGNED_VECTOR(Point3i) Point3iList;
 typedef ONEPIECE_ALIGNED_VECTOR(Point3ui) Point3uiList;
 typedef ONEPIECE_ALIGNED_VECTOR(Matrix4) Mat4List;
 typedef Mat4List SE3List;
+typedef std::vector<Point3List> ImageXYZ; // Geometry.h:79
 
 // Geometry.cpp:9-13 (Sophus SE3::exp; x = (upsilon, omega)) -> op_se3_exp
 Matrix4 Se3ToSE3(const Vector6& input);
@@ -89,6 +98,10 @@ Matrix4 Se3ToSE3(const Vector6& input);
 void TransformPoints(const Matrix4& T, Point3List& points);
 Point3 TransformPoint(const Matrix4& T, const Point3& point);
 void TransformNormals(const Matrix4& T, Point3List& normals);
+// Geometry.cpp:165-171: unit normal of (p2 - p1) x (p3 - p1) and d = -p1 . normal
+Plane GetPlane(const Point3& p1, const Point3& p2, const Point3& p3);
+// Geometry.cpp:47-60: sqrt(mean squared distance of camera_pose * first to second), accumulated in double
+double ComputeReprojectionError3D(const PointCorrespondenceSet& correspondence_set, const SE3& camera_pose);
 // Geometry.cpp:107-151 (Kabsch in the reference's sequential float32 order) -> op_estimate_rigid_transformation
 TransformationMatrix EstimateRigidTransformation(const PointCorrespondenceSet& correspondence_set);
 

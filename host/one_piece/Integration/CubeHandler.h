@@ -26,6 +26,7 @@
 #include "Geometry/Geometry.h"
 #include "Geometry/RGBDFrame.h"
 #include "Geometry/TriangleMesh.h"
+#include "Integration/Frustum.h" // the reference's CubeHandler.h brings it in (CubeHandler.h:5; example/ImageIntegration.cpp:30)
 #include "Integration/Integrator.h"
 #include "Integration/MarchingCube.h"
 #include "Integration/VoxelCube.h"
@@ -50,7 +51,7 @@ class CubeHandler {
     void SetVoxelResolution(float resolution);
     bool ReadFromFile(const std::string& filename);
     bool ReadFromFileFloat(const std::string& filename);
-    bool WriteToFile(const std::string& filename);
+    bool WriteToFile(const std::string& filename) const;
     bool HasCube(const CubeID& cube_id) const;
     void Clear();
     void SetCamera(const camera::PinholeCamera& _camera);
@@ -63,6 +64,10 @@ class CubeHandler {
     void IntegrateImage(const geometry::RGBDFrame& rgbd, const geometry::TransformationMatrix& pose);
     CubeID GetCubeID(const geometry::Point3& point) const { return c_para.GetCubeID(point); }
     void AddCube(const CubeID& cube_id);
+    // allocate the blocks the voxel centres of v_cube land in after trans: their eight trilinear neighbours / the voxel
+    // that contains them (the allocation passes of Transform / TransformNearest, CubeHandler.h:199-241)
+    void AddTransformedCube(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans);
+    void AddTransformedCubeNearest(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans);
     void ExtractTriangleMesh(geometry::TriangleMesh& mesh);
     void GenerateMeshByCube(const CubeID& cube_id, geometry::TriangleMesh& mesh);
     std::shared_ptr<geometry::PointCloud> GetPointCloud() const;
@@ -94,6 +99,7 @@ class CubeHandler {
   private:
     bool Ensure() const;                 // creates the device volume on first use; false (after a message) without a GPU
     static void Report(const char* where);
+    void AddTransformedCubes(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans, bool nearest);
     mutable op_volume* vol = nullptr;
     explicit CubeHandler(op_volume* adopted, const CubeHandler& like, float resolution);
 };

@@ -117,6 +117,23 @@ class VoxelCube {
         }
         ++ptr;
     }
+    // One block of the older float stream CubeHandler::ReadFromFileFloat reads (:168-193): a size word, {index, sdf,
+    // weight}* -2, then a count and that many {index, r, g, b (0..255), colour weight} records (colour = rgb / 255 / weight)
+    void ReadFromBufferFloat(const std::vector<float>& buffer, size_t& ptr) {
+        ++ptr; // size
+        for (; buffer[ptr] != -2.0f; ptr += 3) {
+            TSDFVoxel& t = voxels[static_cast<int>(buffer[ptr])];
+            t.sdf = buffer[ptr + 1]; t.weight = buffer[ptr + 2];
+        }
+        ++ptr;
+        const size_t count = static_cast<size_t>(buffer[ptr++]);
+        for (size_t c = 0; c < count; ++c, ptr += 5) {
+            TSDFVoxel& t = voxels[static_cast<int>(buffer[ptr])];
+            // the reference divides a float by the double literal 255.0 and stores a float, then divides by the weight
+            t.color = geometry::Point3(static_cast<float>(buffer[ptr + 1] / 255.0), static_cast<float>(buffer[ptr + 2] / 255.0), static_cast<float>(buffer[ptr + 3] / 255.0));
+            t.color /= buffer[ptr + 4];
+        }
+    }
 };
 
 } // namespace integration

@@ -6,7 +6,8 @@
 // the same headers are compiled against the small column-major matrix below, which offers the members the hot-path
 // surface and its callers touch: operator()(r,c) / (i), data(), Zero(), Identity(), setZero(), +, -, scalar *, /,
 // matrix products, transpose(), inverse() for 4x4 (through the C-ABI's op_mat4_inverse, i.e. Eigen's own order),
-// stream output.  Storage order, size and alignment of the 3-vectors match Eigen's (12-byte xyz), so
+// normalize() / normalized(), read-only head<N>() / tail<N>() / block<P,Q>(r,c) / col(c) / row(r) (copies, which is all
+// the drivers of the path need: `T.block<3,3>(0,0)`, `plane.head<3>().dot(p)`), stream output.  Storage order, size and alignment of the 3-vectors match Eigen's (12-byte xyz), so
 // std::vector<Point3> is the same contiguous float array either way.
 #pragma once
 #include <cmath>
@@ -59,6 +60,14 @@ struct Mat {
     T dot(const Mat& o) const { T s = T(0); for (int i = 0; i < R * C; ++i) s += v[i] * o.v[i]; return s; }
     T squaredNorm() const { return dot(*this); }
     T norm() const { return std::sqrt(squaredNorm()); }
+    // Eigen's normalize(): divides by the norm when it is positive
+    void normalize() { const T n = norm(); if (n > T(0)) for (int i = 0; i < R * C; ++i) v[i] /= n; }
+    Mat normalized() const { Mat m = *this; m.normalize(); return m; }
+    template <int N> Mat<T, N, 1> head() const { static_assert(C == 1 && N <= R, "head<N>() of a column vector"); Mat<T, N, 1> m; for (int i = 0; i < N; ++i) m(i) = v[i]; return m; }
+    template <int N> Mat<T, N, 1> tail() const { static_assert(C == 1 && N <= R, "tail<N>() of a column vector"); Mat<T, N, 1> m; for (int i = 0; i < N; ++i) m(i) = v[R - N + i]; return m; }
+    template <int P, int Q> Mat<T, P, Q> block(int r0, int c0) const { Mat<T, P, Q> m; for (int r = 0; r < P; ++r) for (int c = 0; c < Q; ++c) m(r, c) = (*this)(r0 + r, c0 + c); return m; }
+    Mat<T, R, 1> col(int c) const { Mat<T, R, 1> m; for (int r = 0; r < R; ++r) m(r) = (*this)(r, c); return m; }
+    Mat<T, 1, C> row(int r) const { Mat<T, 1, C> m; for (int c = 0; c < C; ++c) m(0, c) = (*this)(r, c); return m; }
     Mat cross(const Mat& o) const {
         static_assert(R * C == 3, "cross product of 3-vectors");
         return Mat(v[1] * o.v[2] - v[2] * o.v[1], v[2] * o.v[0] - v[0] * o.v[2], v[0] * o.v[1] - v[1] * o.v[0]);

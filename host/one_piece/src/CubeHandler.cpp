@@ -1,6 +1,9 @@
 // CubeHandler.cpp -- integration::CubeHandler over the C-ABI (include/onepiece_hip.h).  See the header for the contract.
 #include "Integration/CubeHandler.h"
 
+#include <cmath>
+#include <unordered_set>
+
 #include "Bridge.h"
 
 namespace one_piece {
@@ -91,6 +94,25 @@ void CubeHandler::AddCube(const CubeID& cube_id) {
     for (int v = 0; v < 512; ++v) { fresh[5 * v] = 999; fresh[5 * v + 1] = 0; fresh[5 * v + 2] = fresh[5 * v + 3] = fresh[5 * v + 4] = -1; }
     if (op_volume_upload(vol, key, fresh.data(), 1) != OP_OK) Report("AddCube");
 }
+
+// CubeHandler.h:199-241 of the reference: ALLOCATE (AddCube) the blocks that the voxel centres of `v_cube` land in after
+// `trans` -- the eight trilinear neighbours of the moved centre, or the one voxel that contains it.  The arithmetic is the
+// reference's (4x4 * (p,1) accumulated column by column, division by w, float division by the resolution, floor).
+void CubeHandler::AddTransformedCubes(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans, bool nearest) {
+    if (!Ensure()) return;
+    const float res = c_para.VoxelResolution, half = res / 2;
+    std::unordered_set<CubeID, CubeHasher> wanted;
+    for (size_t voxel_id = 0; voxel_id != v_cube.voxels.size(); ++voxel_id) {
+        geometry::Point3 p = geometry::TransformPoint(trans, c_para.GetGlobalPoint(v_cube.cube_id, static_cast<int>(voxel_id)));
+        if (!nearest) p = p - geometry::Point3(half, half, half);
+        const geometry::Point3i base(static_cast<int>(std::floor(p(0) / res)), static_cast<int>(std::floor(p(1) / res)), static_cast<int>(std::floor(p(2) / res)));
+        for (int n = 0; n < (nearest ? 1 : 8); ++n)
+            wanted.insert(c_para.GetCubeID(geometry::Point3i(base(0) + (n & 1), base(1) + ((n >> 1) & 1), base(2) + (n >> 2))));
+    }
+    for (std::unordered_set<CubeID, CubeHasher>::const_iterator it = wanted.begin(); it != wanted.end(); ++it) AddCube(*it);
+}
+void CubeHandler::AddTransformedCube(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans) { AddTransformedCubes(v_cube, trans, false); }
+void CubeHandler::AddTransformedCubeNearest(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans) { AddTransformedCubes(v_cube, trans, true); }
 
 void CubeHandler::ComputeBounding(const cv::Mat& depth, const geometry::TransformationMatrix& pose, geometry::Point3& max_pos, geometry::Point3& min_pos) {
     if (!Ensure()) return;
@@ -248,7 +270,7 @@ void CubeHandler::SetCubeMap(const CubeMap& _cube_map) {
     if (!keys.empty() && op_volume_upload(vol, keys.data(), vox.data(), keys.size() / 3) != OP_OK) Report("SetCubeMap");
 }
 
-bool CubeHandler::WriteToFile(const std::string& filename) {
+bool CubeHandler::WriteToFile(const std::string& filename) const {
     if (Ensure() && op_volume_write_file(vol, filename.c_str()) != OP_OK) Report("WriteToFile");
     else std::cout << GREEN << "[CubeHandler]::[INFO]::Write TSDF field done!(To BinaryFile) " << RESET << std::endl;
     return true; // the reference's file calls always return true (SURVEY 8b "Errors")

@@ -1,12 +1,12 @@
-// PointCloud.cpp -- geometry::PointCloud / TriangleMesh members of the hot-path surface.
+// PointCloud.cpp -- geometry::PointCloud members (the loaders and EstimateNormals forward to the GPU library).
 #include "Geometry/PointCloud.h"
 
-#include <cstdio>
-#include <fstream>
+#include <cmath>
+#include <unordered_map>
 
 #include "Bridge.h"
 #include "Geometry/RGBDFrame.h"
-#include "Geometry/TriangleMesh.h"
+#include "MeshIO.h"
 
 namespace one_piece {
 namespace geometry {
@@ -55,54 +55,64 @@ void PointCloud::Transform(const TransformationMatrix& T) {
     if (HasNormals()) TransformNormals(T, normals);
 }
 
-namespace {
-// binary little-endian PLY: x y z [nx ny nz] [red green blue] per vertex, optional triangle list
-bool WritePly(const std::string& file, const Point3List& pts, const Point3List& nrm, const Point3List& col, const Point3uiList* tri) {
-    std::ofstream os(file.c_str(), std::ios::binary);
-    if (!os) {
-        std::cout << RED << "[ERROR]::[WriteToPLY]::cannot open " << file << RESET << std::endl;
-        return false;
-    }
-    const bool has_n = nrm.size() == pts.size() && !pts.empty(), has_c = col.size() == pts.size() && !pts.empty();
-    os << "ply\nformat binary_little_endian 1.0\nelement vertex " << pts.size() << "\nproperty float x\nproperty float y\nproperty float z\n";
-    if (has_n) os << "property float nx\nproperty float ny\nproperty float nz\n";
-    if (has_c) os << "property uchar red\nproperty uchar green\nproperty uchar blue\n";
-    if (tri) os << "element face " << tri->size() << "\nproperty list uchar uint vertex_indices\n";
-    os << "end_header\n";
-    for (size_t i = 0; i < pts.size(); ++i) {
-        os.write(reinterpret_cast<const char*>(pts[i].data()), 12);
-        if (has_n) os.write(reinterpret_cast<const char*>(nrm[i].data()), 12);
-        if (has_c) {
-            unsigned char rgb[3];
-            for (int k = 0; k < 3; ++k) {
-                const float v = col[i](k) * 255.0f;
-                rgb[k] = static_cast<unsigned char>(v < 0 ? 0 : (v > 255 ? 255 : v));
-            }
-            os.write(reinterpret_cast<const char*>(rgb), 3);
+bool PointCloud::WriteToPLY(const std::string& fileName) const { return meshio::WritePly(fileName, points, normals, colors, nullptr); }
+bool PointCloud::WriteToOBJ(const std::string& filename) { return meshio::WriteObj(filename, points, normals, colors, nullptr); }
+bool PointCloud::LoadFromPLY(const std::string& filename) { Reset(); return meshio::ReadPly(filename, points, normals, colors, nullptr); }
+bool PointCloud::LoadFromOBJ(const std::string& filename) { Reset(); return meshio::ReadObj(filename, points, normals, colors, nullptr); }
+bool PointCloud::LoadFromFile(const std::string& filename) {
+    const size_t dot = filename.rfind('.');
+    const std::string ext = dot == std::string::npos ? std::string() : filename.substr(dot + 1);
+    if (ext == "obj") return LoadFromOBJ(filename);
+    if (ext == "ply") return LoadFromPLY(filename);
+    std::cout << YELLOW << "[WARNING]::[LoadFromFile]::only obj and ply files are supported." << RESET << std::endl;
+    return false;
+}
+
+void PointCloud::LoadFromXYZ(const ImageXYZ& xyz) {
+    Reset();
+    for (size_t i = 0; i != xyz.size(); ++i)
+        for (size_t j = 0; j != xyz[i].size(); ++j)
+            if (xyz[i][j](2) > 0) points.push_back(xyz[i][j]);
+}
+
+void PointCloud::MergePCD(const PointCloud& another_pcd) {
+    const size_t np = points.size() + another_pcd.points.size();
+    const size_t nc = colors.size() + another_pcd.colors.size(), nn = normals.size() + another_pcd.normals.size();
+    if (np != nc && nc > 0) { std::cout << RED << "[Error]::[MergePCD]::The color are not matching." << RESET << std::endl; return; }
+    if (np != nn && nn > 0) { std::cout << RED << "[Error]::[MergePCD]::The normal are not matching." << RESET << std::endl; return; }
+    points.insert(points.end(), another_pcd.points.begin(), another_pcd.points.end());
+    colors.insert(colors.end(), another_pcd.colors.begin(), another_pcd.colors.end());
+    normals.insert(normals.end(), another_pcd.normals.begin(), another_pcd.normals.end());
+}
+
+std::shared_ptr<PointCloud> PointCloud::DownSample(float grid_len) const {
+    std::shared_ptr<PointCloud> out = std::make_shared<PointCloud>();
+    const bool has_c = HasColors(), has_n = HasNormals();
+    std::unordered_map<Point3i, std::pair<size_t, int>, VoxelGridHasher> cells; // cell -> (output index, members)
+    for (size_t i = 0; i != points.size(); ++i) {
+        const Point3& p = points[i];
+        const Point3i id(static_cast<int>(std::floor(p(0) / grid_len)), static_cast<int>(std::floor(p(1) / grid_len)), static_cast<int>(std::floor(p(2) / grid_len)));
+        std::unordered_map<Point3i, std::pair<size_t, int>, VoxelGridHasher>::iterator it = cells.find(id);
+        if (it == cells.end()) {
+            cells.insert(std::make_pair(id, std::make_pair(out->points.size(), 1)));
+            out->points.push_back(p);
+            if (has_c) out->colors.push_back(colors[i]);
+            if (has_n) out->normals.push_back(normals[i]);
+        } else {
+            out->points[it->second.first] += p;
+            if (has_c) out->colors[it->second.first] += colors[i];
+            if (has_n) out->normals[it->second.first] += normals[i];
+            it->second.second += 1;
         }
     }
-    if (tri)
-        for (size_t i = 0; i < tri->size(); ++i) {
-            const unsigned char three = 3;
-            os.write(reinterpret_cast<const char*>(&three), 1);
-            os.write(reinterpret_cast<const char*>((*tri)[i].data()), 12);
-        }
-    return static_cast<bool>(os);
+    for (std::unordered_map<Point3i, std::pair<size_t, int>, VoxelGridHasher>::const_iterator it = cells.begin(); it != cells.end(); ++it) {
+        const float n = static_cast<float>(it->second.second);
+        out->points[it->second.first] /= n;
+        if (has_c) out->colors[it->second.first] /= n;
+        if (has_n) out->normals[it->second.first] /= n;
+    }
+    return out;
 }
-} // namespace
-
-bool PointCloud::WriteToPLY(const std::string& fileName) const { return WritePly(fileName, points, normals, colors, nullptr); }
-
-void TriangleMesh::Transform(const geometry::TransformationMatrix& T) {
-    TransformPoints(T, points);
-    if (HasNormals()) TransformNormals(T, normals);
-}
-std::shared_ptr<geometry::PointCloud> TriangleMesh::GetPointCloud() const {
-    std::shared_ptr<PointCloud> pcd = std::make_shared<PointCloud>();
-    pcd->points = points; pcd->normals = normals; pcd->colors = colors;
-    return pcd;
-}
-bool TriangleMesh::WriteToPLY(const std::string& fileName) const { return WritePly(fileName, points, normals, colors, &triangles); }
 
 } // namespace geometry
 } // namespace one_piece

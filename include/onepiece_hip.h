@@ -79,6 +79,22 @@ uint64_t op_hash_key(int32_t x, int32_t y, int32_t z);
 /* Frustum::ComputeFromCamera (Integration/Frustum.cpp:7-46): planes top,left,right,bottom,near,far. */
 int op_frustum_planes(const op_camera *cam, const float pose[16], float far_dist, float near_dist,
                       float planes[24]);
+/* The whole integration::Frustum object (Integration/Frustum.h:10-105): the six planes as above plus, when
+ * corners != NULL, the eight corner points in the order of the reference's public `corners` member
+ * (Frustum.cpp:49-56: far top-left, far top-right, far bottom-left, far bottom-right, near bottom-right,
+ * near top-left, near top-right, near bottom-left).  op_frustum_from_camera = Frustum::ComputeFromCamera
+ * (Frustum.cpp:7-24), op_frustum_from_vectors = Frustum::ComputeFromVectors (:25-94).  Host arithmetic in
+ * the reference's float order; no device needed. */
+int op_frustum_from_camera(const op_camera *cam, const float pose[16], float far_dist, float near_dist,
+                           float planes[24], float corners[24]);
+int op_frustum_from_vectors(const float forward[3], const float position[3], const float right[3],
+                            const float up[3], float far_dist, float near_dist, float fov, float aspect,
+                            float planes[24], float corners[24]);
+/* Integrator::GetSDF (Integrator.cpp:8-35) for one world point against a HOST depth image: 999 when the point projects
+ * off the image or onto a pixel without depth, else depth - z.  pose_inv may be NULL (computed as op_mat4_inverse).
+ * A host scalar in the reference's float / double order; the kernels evaluate the same expression for every probe. */
+int op_get_sdf(const op_camera *cam, const float point[3], const float pose[16], const float *pose_inv,
+               const void *depth, int depth_fmt, float *sdf);
 /* Test hook: the pixel rounding of Integrator.cpp:20-21 applied to a = fx*X/Z and c = cx.
  * fast = 0: the reference's double formula; fast = 1: the fp32/integer evaluation the kernels use
  * (valid when |c| >= 1 or c == 0).  Both return INT_MIN for values no int can hold. */
@@ -125,6 +141,11 @@ int op_volume_prepare_cubes(op_volume *v, const void *depth, int depth_fmt, int 
  * synchronising call. */
 int op_volume_integrate(op_volume *v, const void *depth, int depth_fmt, const uint8_t *rgb,
                         int mem, const float pose[16], const float *pose_inv);
+/* Integrator::IntegrateImage(depth, rgb, pose, camera, voxel_cube, c_para) (Integrator.cpp:36-94), the reference's
+ * public per-cube member, for a caller-chosen list of n cube ids: the frame is fused into exactly those cubes
+ * (allocated when absent; a cube listed twice is fused once), without PrepareCubes' selection.  Synchronous. */
+int op_volume_integrate_cubes(op_volume *v, const void *depth, int depth_fmt, const uint8_t *rgb, int mem,
+                              const float pose[16], const float *pose_inv, const int32_t *keys_xyz, size_t n);
 /* Multi-frame form of the same call for frames already resident on the device: frame f uses
  * depth + f*depth_stride_bytes, rgb + f*rgb_stride_bytes, poses + 16*f.  Results are bit-identical
  * to n_frames sequential op_volume_integrate calls: frames are fused in batches of up to 16 per

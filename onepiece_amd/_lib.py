@@ -71,6 +71,9 @@ SIGNATURES = {
     "op_mat4_inverse": (C.c_int, [_fp, _fp]),
     "op_hash_key": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32]),
     "op_frustum_planes": (C.c_int, [C.POINTER(Camera), _fp, C.c_float, C.c_float, _fp]),
+    "op_frustum_from_camera": (C.c_int, [C.POINTER(Camera), _fp, C.c_float, C.c_float, _fp, _fp]),
+    "op_frustum_from_vectors": (C.c_int, [_fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp]),
+    "op_get_sdf": (C.c_int, [C.POINTER(Camera), _fp, _fp, _fp, _vp, C.c_int, _fp]),
     "op_se3_exp": (C.c_int, [_fp, _fp]),
     "op_debug_project_px": (C.c_int, [C.c_float, C.c_float, C.c_int]),
     "op_debug_project_uv": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
@@ -92,6 +95,7 @@ SIGNATURES = {
     "op_volume_integrate": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _fp, _fp]),
     "op_volume_integrate_sequence": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, _fp,
                                                C.c_size_t]),
+    "op_volume_integrate_cubes": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _fp, _fp, _vp, C.c_size_t]),
     "op_volume_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "op_volume_stats_launches": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
     "op_volume_profile_enable": (C.c_int, [_vp, C.c_int]),

@@ -89,18 +89,13 @@ inline void plane_from_points(const float* p1, const float* p2, const float* p3,
 
 struct CameraPOD { float fx, fy, cx, cy; int32_t width, height; float depth_scale; };
 
-// planes: top, left, right, bottom, near, far -- the order Frustum::ContainPoint tests them in
-// (Integration/Frustum.h:74-103).
-inline void frustum_planes(const CameraPOD& cam, const float pose[16], float far_d, float near_d, float planes[24]) {
-    const float height = static_cast<float>(cam.height), width = static_cast<float>(cam.width);
-    const float right[3] = {pose[0], pose[4], pose[8]};
-    const float up[3] = {-pose[1], -pose[5], -pose[9]};
-    const float fwd[3] = {pose[2], pose[6], pose[10]};
-    const float pos[3] = {pose[3], pose[7], pose[11]};
-    const float aspect = (cam.fy * width) / (cam.fx * height);
-    // atan2 / tan: the reference calls the unqualified C functions on floats -> double versions.
-    const float fov = static_cast<float>(std::atan2(static_cast<double>(cam.cy), static_cast<double>(cam.fy)) +
-                                         std::atan2(static_cast<double>(height - cam.cy), static_cast<double>(cam.fy)));
+// Frustum::ComputeFromVectors (Integration/Frustum.cpp:25-94).  planes: top, left, right, bottom, near, far -- the order
+// Frustum::ContainPoint tests them in (Integration/Frustum.h:74-103); corners (optional) in the order of the reference's
+// public `corners` member (:61-68): far top-left, far top-right, far bottom-left, far bottom-right, near bottom-right,
+// near top-left, near top-right, near bottom-left.
+inline void frustum_from_vectors(const float fwd[3], const float pos[3], const float right[3], const float up[3], float far_d, float near_d,
+                                 float fov, float aspect, float planes[24], float* corners24) {
+    // tan: the reference calls the unqualified C function on a float -> double version.
     const float tangent = static_cast<float>(std::tan(static_cast<double>(fov / 2)));
     const float hf = tangent * far_d, wf = hf * aspect, hn = tangent * near_d, wn = hn * aspect;
     float corner[8][3]; // ftl ftr fbl fbr ntl ntr nbl nbr
@@ -123,6 +118,25 @@ inline void frustum_planes(const CameraPOD& cam, const float pose[16], float far
     plane_from_points(nbr, fbl, nbl, planes + 12); // bottom
     plane_from_points(nbl, ntl, nbr, planes + 16); // near
     plane_from_points(ftr, ftl, fbr, planes + 20); // far
+    if (corners24) {
+        const float* order[8] = {ftl, ftr, fbl, fbr, nbr, ntl, ntr, nbl};
+        for (int k = 0; k < 8; ++k)
+            for (int i = 0; i < 3; ++i) corners24[3 * k + i] = order[k][i];
+    }
+}
+
+// Frustum::ComputeFromCamera (Integration/Frustum.cpp:7-24)
+inline void frustum_planes(const CameraPOD& cam, const float pose[16], float far_d, float near_d, float planes[24], float* corners24 = nullptr) {
+    const float height = static_cast<float>(cam.height), width = static_cast<float>(cam.width);
+    const float right[3] = {pose[0], pose[4], pose[8]};
+    const float up[3] = {-pose[1], -pose[5], -pose[9]};
+    const float fwd[3] = {pose[2], pose[6], pose[10]};
+    const float pos[3] = {pose[3], pose[7], pose[11]};
+    const float aspect = (cam.fy * width) / (cam.fx * height);
+    // atan2: the reference calls the unqualified C function on floats -> double version.
+    const float fov = static_cast<float>(std::atan2(static_cast<double>(cam.cy), static_cast<double>(cam.fy)) +
+                                         std::atan2(static_cast<double>(height - cam.cy), static_cast<double>(cam.fy)));
+    frustum_from_vectors(fwd, pos, right, up, far_d, near_d, fov, aspect, planes, corners24);
 }
 
 // ---- SE3 exponential, Sophus convention x = (upsilon, omega) (3rdparty/Sophus/sophus/se3.hpp:468-489).

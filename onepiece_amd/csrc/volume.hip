@@ -298,6 +298,22 @@ __global__ void k_finish_select(VolView V, State* st) {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) V.sel_list[i] = V.tvals[V.sel_list[i]];
 }
 
+// Integrator::IntegrateImage for a caller-chosen cube list (op_volume_integrate_cubes): takes KB's place in a one-frame
+// batch -- every listed cube is found or allocated and put on the batch list with the frame's bit, no selection test.
+__global__ void k_mark_cubes(VolView V, State* st, const int* __restrict__ keys, unsigned n) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (st->overflow & 3u)) return;
+    const int x = keys[3 * i], y = keys[3 * i + 1], z = keys[3 * i + 2];
+    if (!key_in_range(x, y, z)) { atomicOr(&st->overflow, 8u); return; }
+    bool created;
+    const int slot = table_claim(V, st, x, y, z, &created);
+    if (slot < 0) return;
+    if (atomicOr(&V.bmask[slot], 1u) == 0u) { // a key listed twice is fused once
+        const unsigned pos = atomicAdd(&st->n_batch, 1u);
+        if (pos < V.max_blocks) V.blist[pos] = slot;
+    }
+}
+
 __device__ __forceinline__ unsigned ord_enc(float f) { // order-preserving float -> unsigned
     const unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -1311,7 +1327,8 @@ int vol_reset(op_volume* v) {
 
 constexpr unsigned kHardMaxBlocks = 1u << 24; // 172 GB of pool: what one 288 GB MI355X can hold next to its inputs
 
-int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const BatchPtrs& Q, int nf, int depth_fmt, bool select_only, bool record);
+int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const BatchPtrs& Q, int nf, int depth_fmt, bool select_only, bool record,
+                      const int* cube_keys = nullptr, unsigned n_cubes = 0);
 
 // Grows the pool to new_max blocks (and the hash table to twice that), keeping the first n_valid blocks.  The stream
 // must be idle.  The new buffers are allocated before the old ones are released, so a failed allocation leaves the
@@ -1516,7 +1533,10 @@ int vol_ensure_frame_buffers(op_volume* v) {
 
 // Enqueue one batch (1..kMaxBatch frames whose images are on the device): KA, KB and, unless
 // select_only, KC.  No host synchronisation.
-int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const BatchPtrs& Q, int nf, int depth_fmt, bool select_only, bool record) {
+// With cube_keys (device array of n_cubes ids, nf == 1): KB is replaced by k_mark_cubes -- the frame is fused into exactly
+// those cubes (op_volume_integrate_cubes); the caller has reserved the room and synchronises, so the batch is not logged.
+int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const BatchPtrs& Q, int nf, int depth_fmt, bool select_only, bool record,
+                      const int* cube_keys, unsigned n_cubes) {
     OP_TRY(vol_ensure_frame_buffers(v));
     // Look at the device's lagging progress report (no synchronisation): retire confirmed batches and, when the pool is
     // about to run full, grow it NOW -- between batches -- instead of paying for a replay later.
@@ -1535,7 +1555,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         v->hstat[1] = n;
     }
     const unsigned seq = (unsigned)(++v->seq);
-    if (!select_only) v->log.push_back(op_volume::BatchRec{v->seq, F, I, Q, nf, depth_fmt, -1});
+    if (!select_only && !cube_keys) v->log.push_back(op_volume::BatchRec{v->seq, F, I, Q, nf, depth_fmt, -1});
     const CamParams C = cam_params(v, depth_fmt);
     const int npix = C.width * C.height;
     const int g1 = (npix + kPixPerWg - 1) / kPixPerWg;
@@ -1550,7 +1570,9 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state, seq,
                        (const unsigned*)v->n_blocks, v->hstat_dev);
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
-    if (C.fast_px)
+    if (cube_keys)
+        hipLaunchKernelGGL(k_mark_cubes, dim3((n_cubes + 255u) / 256u), dim3(256), 0, v->stream, V, v->state, cube_keys, n_cubes);
+    else if (C.fast_px)
         hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
                            v->state, record ? 1 : 0);
     else
@@ -1792,6 +1814,41 @@ int op_frustum_planes(const op_camera* cam, const float pose[16], float far_dist
     if (!pose || !planes) return fail(OP_ERR_INVALID, "null argument");
     op_host::CameraPOD c{cam->fx, cam->fy, cam->cx, cam->cy, cam->width, cam->height, cam->depth_scale};
     op_host::frustum_planes(c, pose, far_dist, near_dist, planes);
+    return OP_OK;
+}
+
+int op_frustum_from_camera(const op_camera* cam, const float pose[16], float far_dist, float near_dist, float planes[24], float corners[24]) {
+    OP_TRY(check_cam(cam));
+    if (!pose || !planes) return fail(OP_ERR_INVALID, "null argument");
+    op_host::CameraPOD c{cam->fx, cam->fy, cam->cx, cam->cy, cam->width, cam->height, cam->depth_scale};
+    op_host::frustum_planes(c, pose, far_dist, near_dist, planes, corners);
+    return OP_OK;
+}
+
+int op_frustum_from_vectors(const float forward[3], const float position[3], const float right[3], const float up[3], float far_dist, float near_dist,
+                            float fov, float aspect, float planes[24], float corners[24]) {
+    if (!forward || !position || !right || !up || !planes) return fail(OP_ERR_INVALID, "null argument");
+    op_host::frustum_from_vectors(forward, position, right, up, far_dist, near_dist, fov, aspect, planes, corners);
+    return OP_OK;
+}
+
+int op_get_sdf(const op_camera* cam, const float point[3], const float pose[16], const float* pose_inv, const void* depth, int depth_fmt, float* sdf) {
+    OP_TRY(check_cam(cam));
+    if (!point || !pose || !depth || !sdf) return fail(OP_ERR_INVALID, "null argument");
+    float inv[16];
+    if (pose_inv) std::memcpy(inv, pose_inv, sizeof(inv));
+    else op_host::mat4_inverse(pose, inv);                          // Integrator.cpp:18
+    // (pose_inv * (p, 1)).head<3>() accumulated column by column (:19)
+    float q[3];
+    for (int r = 0; r < 3; ++r) q[r] = ((inv[4 * r] * point[0] + inv[4 * r + 1] * point[1]) + inv[4 * r + 2] * point[2]) + inv[4 * r + 3] * 1.0f;
+    const int u = px_round_dp((cam->fx * q[0]) / q[2], cam->cx);    // :20-21: float product and quotient, the sum in double, truncated
+    const int w = px_round_dp((cam->fy * q[1]) / q[2], cam->cy);
+    *sdf = 999.0f;
+    if (w < 0 || w >= cam->height || u < 0 || u >= cam->width) return OP_OK;   // :23-24
+    const size_t at = (size_t)w * cam->width + u;
+    const float d = depth_fmt == OP_DEPTH_U16 ? (float)((const unsigned short*)depth)[at] / cam->depth_scale : ((const float*)depth)[at]; // :26-29
+    if (d <= 0) return OP_OK;                                        // :30
+    *sdf = d - q[2];
     return OP_OK;
 }
 
@@ -2067,6 +2124,36 @@ int op_volume_integrate(op_volume* v, const void* depth, int depth_fmt, const ui
     v->pend_fmt = depth_fmt;
     if (++v->pend_n == kMaxBatch) return vol_flush(v);
     return OP_OK;
+}
+
+int op_volume_integrate_cubes(op_volume* v, const void* depth, int depth_fmt, const uint8_t* rgb, int mem, const float pose[16], const float* pose_inv,
+                              const int32_t* keys_xyz, size_t n) {
+    OP_VOL(v);
+    if (!depth || !rgb || !pose || (n && !keys_xyz)) return fail(OP_ERR_INVALID, "null argument");
+    if (n == 0) return OP_OK;
+    if (n > kHardMaxBlocks) return fail(OP_ERR_CAPACITY, "%zu cubes exceed the limit of %u blocks per volume", n, kHardMaxBlocks);
+    unsigned have = 0;
+    OP_TRY(vol_block_count(v, &have)); // flushes, synchronises, recovers
+    OP_TRY(vol_reserve(v, (unsigned long long)have + n));
+    const unsigned char* c = rgb;
+    OP_TRY(vol_stage_images(v, &depth, depth_fmt, &c, mem));
+    int* d_keys = nullptr;
+    OP_HIP(op::cached_malloc((void**)&d_keys, n * 3 * sizeof(int)));
+    hipError_t e = hipMemcpyAsync(d_keys, keys_xyz, n * 3 * sizeof(int), hipMemcpyHostToDevice, v->stream);
+    int rc = OP_OK;
+    if (e == hipSuccess) {
+        BatchFwd F;
+        BatchInv I;
+        BatchPtrs Q{};
+        frame_params(v, pose, pose_inv, &F.f[0], &I.f[0]);
+        Q.depth[0] = depth; Q.rgb[0] = c;
+        rc = vol_enqueue_batch(v, F, I, Q, 1, depth_fmt, false, false, d_keys, (unsigned)n);
+        if (rc == OP_OK) rc = vol_check(v);
+    }
+    (void)hipStreamSynchronize(v->stream);
+    op::cached_free(d_keys);
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "copying the cube list failed: %s", hipGetErrorString(e));
+    return rc;
 }
 
 int op_volume_integrate_sequence(op_volume* v, const void* depth, size_t depth_stride_bytes, int depth_fmt, const uint8_t* rgb,

@@ -157,6 +157,18 @@ class CubeHandler:
         if mem == L.OP_MEM_DEVICE:
             self._alive.append((_k1, _k2))
 
+    def IntegrateCubes(self, depth, rgb, pose, cube_ids, pose_inv=None):
+        """Integrator::IntegrateImage (Integrator.cpp:36-94) for a caller-chosen cube list (n x 3 int32): the frame is fused
+        into exactly those cubes, allocated when absent, without PrepareCubes' selection.  Synchronous."""
+        pd, fmt, mem, _k1 = _image_arg(depth, "depth")
+        pr, _f, mem2, _k2 = _image_arg(rgb, "rgb")
+        if mem != mem2:
+            raise ValueError("depth and rgb must both be host arrays or both be device tensors")
+        pose = _f32(pose).reshape(16)
+        pinv = _f32(pose_inv).reshape(16) if pose_inv is not None else None
+        ids = np.ascontiguousarray(cube_ids, np.int32).reshape(-1, 3)
+        L.check(self._lib.op_volume_integrate_cubes(self._h, pd, fmt, pr, mem, _fp(pose), _fp(pinv) if pinv is not None else None, _ip(ids), len(ids)))
+
     def IntegrateFrame(self, rgbd, pose, pose_inv=None):
         """CubeHandler::IntegrateImage(const geometry::RGBDFrame&, pose) (CubeHandler.cpp:211-214)."""
         return self.IntegrateImage(rgbd.depth, rgbd.rgb, pose, pose_inv)

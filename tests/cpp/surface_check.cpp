@@ -100,6 +100,29 @@ int main(int argc, char** argv) {
     f.PrepareCubes(depth[0], poses[0], list);
     geometry::Point3 mx, mn;
     f.ComputeBounding(depth[0], poses[0], mx, mn);
+    // the reference's public per-cube members: Integrator::IntegrateImage on ONE host VoxelCube (two frames), Integrator::GetSDF,
+    // and the allocation pass of Transform for one cube
+    integration::Integrator integrator;
+    integration::CubePara c_para;
+    c_para.SetVoxelResolution(voxel);
+    const integration::CubeID single_id = list[list.size() / 2];
+    integration::VoxelCube single(single_id);
+    integrator.IntegrateImage(depth[0], rgb[0], poses[0], camera, single, c_para);
+    integrator.IntegrateImage(depth[1], rgb[1], poses[1], camera, single, c_para);
+    integration::CubeHandler g(camera);
+    g.SetVoxelResolution(voxel);
+    integration::CubeMap one_cube;
+    one_cube[single_id] = single;
+    g.SetCubeMap(one_cube);
+    g.WriteToFile(out + "/single.map");
+    const float sdf_centre = integrator.GetSDF(c_para.GetGlobalPoint(single_id, 292), camera, poses[0], depth[0]);
+    const float sdf_off = integrator.GetSDF(geometry::TransformPoint(poses[0], geometry::Point3(50, 0, 1)), camera, poses[0], depth[0]);
+    integration::CubeHandler h(camera);
+    h.SetVoxelResolution(voxel);
+    h.AddTransformedCube(single, T);
+    const size_t n_h = h.GetCubeCount();
+    h.AddTransformedCubeNearest(single, T);
+    const size_t n_h2 = h.GetCubeCount();
     // registration through the class surface
     geometry::PointCloud s_pcd, t_pcd;
     s_pcd.LoadFromDepth(depth[1], camera);
@@ -126,7 +149,8 @@ int main(int argc, char** argv) {
               << "], \"trunc\": " << a.Truncation() << ", \"res\": " << a.Resolution() << ", \"far\": " << a.Far() << ", \"plane_inliers\": "
               << plane->correspondence_set_index.size() << ", \"plane_pairs\": " << plane->correspondence_set.size() << ", \"plane_rmse\": " << plane->rmse
               << ", \"refused_inliers\": " << refused->correspondence_set_index.size() << ", \"point_inliers\": " << point->correspondence_set_index.size()
-              << ", \"plane_T\": [";
+              << ", \"single_id\": [" << single_id(0) << ", " << single_id(1) << ", " << single_id(2) << "], \"sdf_centre\": " << sdf_centre << ", \"sdf_off\": " << sdf_off
+              << ", \"added_trilinear\": " << n_h << ", \"added_nearest\": " << n_h2 << ", \"plane_T\": [";
     for (int r = 0; r < 4; ++r) for (int cc = 0; cc < 4; ++cc) std::cout << (r + cc ? ", " : "") << plane->T(r, cc);
     std::cout << "], \"kabsch_T\": [";
     for (int r = 0; r < 4; ++r) for (int cc = 0; cc < 4; ++cc) std::cout << (r + cc ? ", " : "") << kab(r, cc);

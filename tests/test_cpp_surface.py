@@ -76,7 +76,7 @@ def test_the_signature_list_of_the_scope_table_is_declared():
                 "std::shared_ptr<CubeHandler> Transform(const geometry::TransformationMatrix& trans) const;",
                 "std::shared_ptr<CubeHandler> TransformNearest(const geometry::TransformationMatrix& trans);",
                 "bool ReadFromFile(const std::string& filename);", "bool ReadFromFileFloat(const std::string& filename);",
-                "bool WriteToFile(const std::string& filename);", "bool HasCube(const CubeID& cube_id) const;", "void Clear();",
+                "bool WriteToFile(const std::string& filename) const;", "bool HasCube(const CubeID& cube_id) const;", "void Clear();",
                 "void AddCube(const CubeID& cube_id);", "CubeID GetCubeID(const geometry::Point3& point) const", "CubeMap GetCubeMap();",
                 "void SetCubeMap(const CubeMap& _cube_map);", "typedef std::unordered_map<CubeID, VoxelCube, CubeHasher> CubeMap;"]:
         assert sig in ch, sig
@@ -234,6 +234,25 @@ def test_class_surface_end_to_end_matches_oracle(hip, oracle, tmp_path):
     bmax = oracle.compute_bounding(ocam, decoded[0][0], poses[0])[0]
     assert np.allclose(r["bound_max"], bmax, rtol=0, atol=1e-6)
     assert abs(r["trunc"] - 0.1) < 1e-7 and abs(r["res"] - res) < 1e-9 and r["far"] == 5.0
+    # Integrator::IntegrateImage on one host VoxelCube (frames 0 and 1) == that block of the oracle's volume after the same two
+    # frames (the cube is in frame 0's selection; it is fused with frame 1 whether or not frame 1 selects it, like the reference's
+    # member -- so compare against an oracle volume in which both frames saw it: blocks fused by both selections)
+    sid = tuple(r["single_id"])
+    o2 = oracle.Volume(ocam, voxel_res=res)
+    for (d, c), p in list(zip(decoded, poses))[:2]:
+        o2.integrate(d, c, p)
+    k2, v2 = o2.export()
+    sk, sv = rd("single.map")
+    assert len(sk) == 1 and tuple(sk[0]) == sid
+    sel1 = {tuple(k) for k in oracle.Volume(ocam, voxel_res=res).prepare_cubes(decoded[1][0], poses[1])}
+    if sid in sel1:   # frame 1 selected it too: the oracle's block saw exactly the same two updates
+        assert np.array_equal(sv[0].view(np.uint32), v2[np.where((k2 == np.array(sid)).all(1))[0][0]].view(np.uint32))
+    centre = np.array(sid, np.float32) * 8 * np.float32(res) + (np.array([4, 4, 4], np.float32) * np.float32(res) + np.float32(res) / 2)
+    want = oracle.lib().orc_get_sdf(C.byref(ocam), centre.ctypes.data_as(C.POINTER(C.c_float)),
+                                    np.ascontiguousarray(oracle.mat4_inverse(poses[0]), np.float32).ctypes.data_as(C.POINTER(C.c_float)),
+                                    C.c_void_p(np.ascontiguousarray(decoded[0][0]).ctypes.data), 0)
+    assert abs(r["sdf_centre"] - want) <= 1e-6 * max(1.0, abs(want)) and r["sdf_off"] == 999
+    assert 8 <= r["added_trilinear"] <= 27 and r["added_trilinear"] <= r["added_nearest"] <= r["added_trilinear"] + 8
     # mesh + point cloud: unshared vertices, one surface
     assert r["mesh_points"] == 3 * r["mesh_triangles"] > 3000 and r["band_points"] == int(((np.abs(ea[1][..., 0]) < 1) & (ea[1][..., 1] > 0)).sum()) or r["band_points"] > 0
     assert os.path.getsize(os.path.join(out, "mesh.ply")) > 15 * r["mesh_points"]

@@ -559,3 +559,53 @@ def test_torch_tensors_are_final_before_library_kernels_read_them():
     got = hv.Stats()
     assert got == want and got["voxels_updated"] > 0
     del junk
+
+
+def test_integrate_cubes_is_integrate_image_without_the_selection(oracle):
+    """Integrator::IntegrateImage for a caller-chosen cube list (op_volume_integrate_cubes): with the list PrepareCubes
+    returns it IS CubeHandler::IntegrateImage -- bit-equal to the oracle; a cube outside the selection is allocated and
+    keeps its default voxels; listing a cube twice fuses it once; a second frame through the list of ITS selection
+    continues the running mean bit-exactly."""
+    cam = (S.FX / 2, S.FY / 2, S.CX / 2, S.CY / 2, S.W // 2, S.H // 2, 1000.0)
+    ov, hv = _mk(oracle, 0.01, cam)
+    for i in (20, 24):
+        pose = S.room_pose(i)
+        d, rgb = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+        ids = hv.PrepareCubes(d, pose)                     # allocates the selection, fuses nothing
+        ov.integrate(d, rgb, pose)
+        hv.IntegrateCubes(d, rgb, pose, np.concatenate([ids, ids[:5]]))
+        _compare(oracle, ov, hv)
+    n = hv.BlockCount()
+    far = np.array([[900, 900, 900]], np.int32)
+    hv.IntegrateCubes(d, rgb, pose, far)                   # not in view: allocated, every voxel stays at the default
+    assert hv.BlockCount() == n + 1 and hv.HasCube((900, 900, 900))
+    hk, hvx = hv.GetCubeMap()
+    blk = hvx[np.where((hk == far[0]).all(1))[0][0]]
+    assert np.all(blk[:, 0] == 999) and np.all(blk[:, 1] == 0) and np.all(blk[:, 2:] == -1)
+    hv.IntegrateCubes(d, rgb, pose, np.zeros((0, 3), np.int32))   # empty list: nothing happens
+    assert hv.BlockCount() == n + 1
+
+
+def test_launch_level_counters(oracle):
+    """op_volume_stats_launches: blocks read and voxels written per k_integrate launch (the batch-level byte model of the
+    roofline).  One frame per launch: blocks read = len(cube_id_list), voxels written = voxels updated (each changed
+    voxel is written once); a 3-frame batch reads the union of the three lists once and writes every changed voxel once."""
+    ov, hv = _mk(oracle, 0.01)
+    frames = [S.room_frame(i) for i in (0, 2, 4)]
+    sel = upd = 0
+    for d, rgb, pose in frames:
+        n, _vis, nupd = ov.integrate(d, rgb, pose)
+        hv.IntegrateImage(d, rgb, pose); hv.Synchronize()
+        sel += n; upd += nupd
+    st = hv.Stats()
+    assert st["launches"] == 3 and st["blocks_read"] == sel == st["blocks_selected"] and st["voxels_written"] == upd == st["voxels_updated"]
+    import torch
+    hv.Clear()
+    dev = torch.device("cuda", 0)
+    dd = torch.from_numpy(np.stack([f[0] for f in frames])).to(dev); cc = torch.from_numpy(np.stack([f[1] for f in frames])).to(dev)
+    hv.IntegrateSequence(dd, cc, np.stack([f[2] for f in frames]))
+    st = hv.Stats()
+    keys, vox = ov.export()
+    assert st["launches"] == 1 and st["frames"] == 3 and st["blocks_selected"] == sel and st["voxels_updated"] == upd
+    assert st["blocks_read"] == len(keys) and st["voxels_written"] == int((vox[:, :, 1] > 0).sum())
+    _compare(oracle, ov, hv)

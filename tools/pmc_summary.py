@@ -7,7 +7,7 @@
   one per XCD / SE instance of the counter -- are summed first), the sum and the mean per dispatch;
 * `*kernel_trace.csv` -> `<prefix>.durations.csv`: per kernel, launches and total / mean / min / max duration in microseconds
   (with --pmc the kernels run serialised and slower: quote durations from a --stats pass, not from a counter pass).
-Kernel names are cut at the first '(' and of their template arguments only the part up to 80 characters is kept."""
+Kernel names lose `void`, the anonymous namespace and their argument list (template arguments stay)."""
 import collections
 import csv
 import glob
@@ -16,9 +16,8 @@ import sys
 
 
 def short(name):
-    name = name.split("(")[0]
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return name[:80]
+    return name.split("(")[0][:80]
 
 
 def main():

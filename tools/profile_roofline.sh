@@ -28,9 +28,11 @@ pass() { # name, counters ("" = --stats), command...
 }
 rocprofv3-avail list 2>/dev/null | grep -i -E "TCC_EA0|FETCH|WRITE_SIZE|TCC_REQ|TCC_READ|TCC_WRITE|MALL|HBM" | head -80 > $OUT/avail_tcc.txt
 timeout 120 $R/tools/valu_ubench.bin > $OUT/valu_ubench.txt 2>&1
+if [ -z "$SKIP_CALIB" ]; then
 # ---- known-traffic calibration (1 repetition per kernel under the counters)
 timeout 120 $R/tools/hbm_calib.bin 4096 3 > $OUT/calib.timing.txt 2>&1
 for C in "${HBM_GROUPS[@]}"; do pass calib "$C" $R/tools/hbm_calib.bin 4096 1; done
+fi
 # ---- fusion: one frame per launch, and full batches
 python $R/tools/dump_frames.py /tmp/frames.bin ${NFRAMES:-96} 0 > /dev/null
 $R/tools/prof_driver.bin /tmp/frames.bin 2 0.005 batch=1 > $OUT/batch1.driver.txt 2>&1
