@@ -28,6 +28,9 @@ pass() { # name, counters ("" = --stats), command...
 }
 rocprofv3-avail list 2>/dev/null | grep -i -E "TCC_EA0|FETCH|WRITE_SIZE|TCC_REQ|TCC_READ|TCC_WRITE|MALL|HBM" | head -80 > $OUT/avail_tcc.txt
 timeout 120 $R/tools/valu_ubench.bin > $OUT/valu_ubench.txt 2>&1
+# issue costs in GRBM_GUI_ACTIVE cycles: the microbenchmark at k_integrate's occupancy under the same counter (tools/issue_model.py)
+pass ubench "GRBM_GUI_ACTIVE GRBM_COUNT" $R/tools/valu_ubench.bin 2048 8
+python $R/tools/issue_model.py calibrate "$OUT/ubench.GRBM_GUI_ACTIVE_GRBM_COUNT.pmc.csv" 2048 8 $OUT/issue_costs.json > /dev/null
 if [ -z "$SKIP_CALIB" ]; then
 # ---- known-traffic calibration (1 repetition per kernel under the counters)
 timeout 120 $R/tools/hbm_calib.bin 4096 3 > $OUT/calib.timing.txt 2>&1
@@ -47,5 +50,7 @@ for C in "${SQ_GROUPS[@]}"; do
   pass batch1 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=1
   pass batch16 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=16
 done
-cat $OUT/*.log > $OUT/all_logs.txt 2>/dev/null; rm -f $OUT/*.log
+cat $OUT/*.log > $OUT/all_logs.txt 2>/dev/null; python $R/tools/issue_model.py model_pmc $OUT/issue_costs.json $OUT batch16 > $OUT/batch16.issue_model.json
+python $R/tools/issue_model.py model_pmc $OUT/issue_costs.json $OUT batch1 > $OUT/batch1.issue_model.json
+rm -f $OUT/*.log
 ls $OUT | head -100

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define REP4(x) x x x x
@@ -14,11 +15,15 @@
 #define REP64(x) REP16(x) REP16(x) REP16(x) REP16(x)
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* cyc, float a, float b) {
+__global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* cyc, float a, float b, int iters) {
     float x0 = a + threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
     float2 p0 = make_float2(x0, x1), p1 = make_float2(x2, x3), p2 = make_float2(x4, x5), p3 = make_float2(x6, x7), pb = make_float2(b, b);
+    __shared__ float s_lds[256];
+    s_lds[threadIdx.x] = a;
+    const unsigned lds_off = threadIdx.x * 4u;
+    __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < 64; ++it) {
+    for (int it = 0; it < iters; ++it) {
         if (OP == 0) { REP16(asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
         if (OP == 1) { REP16(asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x0) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x1) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x2) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x3) : "v"(b));) }
         if (OP == 2) { REP16(asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p3) : "v"(pb));) }
@@ -43,6 +48,17 @@ __global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* c
         if (OP == 22) { REP16(asm volatile("s_and_b64 s[20:21], s[20:21], exec" ::: "s20", "s21", "scc"); asm volatile("s_or_b64 s[22:23], s[22:23], exec" ::: "s22", "s23", "scc"); asm volatile("s_and_b64 s[24:25], s[24:25], exec" ::: "s24", "s25", "scc"); asm volatile("s_or_b64 s[26:27], s[26:27], exec" ::: "s26", "s27", "scc");) }
         if (OP == 23) { REP16(asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc"); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("s_add_u32 s21, s21, 1" ::: "s21", "scc");) }
         if (OP == 24) { REP16(asm volatile("s_nop 0"); asm volatile("s_nop 0"); asm volatile("s_nop 0"); asm volatile("s_nop 0");) }
+        if (OP == 25) { REP16(asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x0) : "v"(b)); asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x1) : "v"(b)); asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x2) : "v"(b)); asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 26) { REP16(asm volatile("v_trunc_f32 %0, %0" : "+v"(x0)); asm volatile("v_trunc_f32 %0, %0" : "+v"(x1)); asm volatile("v_trunc_f32 %0, %0" : "+v"(x2)); asm volatile("v_trunc_f32 %0, %0" : "+v"(x3));) }
+        if (OP == 27) { REP16(asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x0)); asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x1)); asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x2)); asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x3));) }
+        if (OP == 28) { REP16(asm volatile("v_max_i32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_max_i32 %0, %0, %1" : "+v"(x1) : "v"(b)); asm volatile("v_max_i32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_max_i32 %0, %0, %1" : "+v"(x3) : "v"(b));) }
+        if (OP == 29) { REP16(asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x0)); asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x1)); asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x2)); asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x3));) }
+        if (OP == 30) { REP16(asm volatile("s_mul_i32 s20, s20, 3" ::: "s20"); asm volatile("s_mul_i32 s21, s21, 3" ::: "s21"); asm volatile("s_mul_i32 s22, s22, 3" ::: "s22"); asm volatile("s_mul_i32 s23, s23, 3" ::: "s23");) }
+        if (OP == 31) { REP16(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");) }
+        if (OP == 32) { asm volatile("s_cmp_eq_u32 s20, s20" ::: "scc"); REP16(asm volatile("s_cbranch_scc0 0" ::: ); asm volatile("s_cbranch_scc0 0" ::: ); asm volatile("s_cbranch_scc0 0" ::: ); asm volatile("s_cbranch_scc0 0" ::: );) }
+        if (OP == 33) { REP16(asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(x0) : "s20"); asm volatile("v_readlane_b32 s21, %0, 3" :: "v"(x1) : "s21"); asm volatile("v_readlane_b32 s22, %0, 3" :: "v"(x2) : "s22"); asm volatile("v_readlane_b32 s23, %0, 3" :: "v"(x3) : "s23");) }
+        if (OP == 34) { REP16(asm volatile("ds_read_b32 %0, %1" : "=v"(x4) : "v"(lds_off)); asm volatile("ds_read_b32 %0, %1" : "=v"(x5) : "v"(lds_off)); asm volatile("ds_read_b32 %0, %1" : "=v"(x6) : "v"(lds_off)); asm volatile("ds_read_b32 %0, %1" : "=v"(x7) : "v"(lds_off));) asm volatile("s_waitcnt lgkmcnt(0)"); }
+        if (OP == 35) { REP16(asm volatile("s_load_dword s20, %0, 0x0" :: "s"(cyc) : "s20"); asm volatile("s_load_dword s21, %0, 0x0" :: "s"(cyc) : "s21"); asm volatile("s_load_dword s22, %0, 0x0" :: "s"(cyc) : "s22"); asm volatile("s_load_dword s23, %0, 0x0" :: "s"(cyc) : "s23");) asm volatile("s_waitcnt lgkmcnt(0)"); }
         if (OP == 10) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p3) : "v"(pb));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -61,19 +77,24 @@ __global__ void k_clock(unsigned long long* out) {
 }
 
 template <int OP>
-void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, int cus) {
+void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, int cus, int iters) {
     const int wgs = cus * waves_per_simd; // 256 threads = 4 waves = one wave per SIMD of a CU (per resident workgroup)
-    hipLaunchKernelGGL(k_bench<OP>, dim3(wgs), dim3(256), 0, 0, d_out, d_cyc, 1.0f, 1.0000001f);
+    hipLaunchKernelGGL(k_bench<OP>, dim3(wgs), dim3(256), 0, 0, d_out, d_cyc, 1.0f, 1.0000001f, iters);
     hipDeviceSynchronize();
     std::vector<unsigned long long> c((size_t)wgs * 4);
     hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost);
     double s = 0;
     for (auto v : c) s += (double)v;
-    const double per = s / c.size() / (64.0 * 64.0); // 64 iterations x 64 instructions per wave
-    std::printf("%-18s waves/SIMD %d: %.2f s_memtime ticks per wave-instruction -> %.2f per SIMD-issue slot\n", name, waves_per_simd, per, per / waves_per_simd);
+    const double per = s / c.size() / (64.0 * iters); // iters iterations x 64 instructions per wave
+    std::printf("%-18s OP %2d waves/SIMD %d iters %d: %.2f s_memtime ticks per wave-instruction -> %.2f per SIMD-issue slot\n", name, OP, waves_per_simd, iters, per, per / waves_per_simd);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // argv[1]: loop iterations per kernel (64 instructions each; default 64).  With a large count (e.g. 1024) and ONE wave configuration
+    // (argv[2] = waves per SIMD) the run is meant for `rocprofv3 --pmc GRBM_GUI_ACTIVE`: kernel cycles / (iters x 64 x waves) is then the
+    // issue cost in the SAME clock the fusion kernels' GRBM_GUI_ACTIVE is counted in (tools/issue_model.py).
+    const int iters = argc > 1 ? std::atoi(argv[1]) : 64;
+    const int only_w = argc > 2 ? std::atoi(argv[2]) : 0;
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
@@ -89,31 +110,43 @@ int main() {
         std::printf("clock: %llu s_memtime ticks in %llu s_memrealtime ticks (100 MHz) -> %.2f s_memtime ticks per microsecond\n", c[0], c[1], (double)c[0] / ((double)c[1] / 100.0));
     }
     for (int w : {1, 4, 8}) {
-        run<0>("v_mul_f32", w, d_out, d_cyc, cus);
-        run<1>("v_fma_f32", w, d_out, d_cyc, cus);
-        run<2>("v_pk_mul_f32", w, d_out, d_cyc, cus);
-        run<10>("v_pk_fma_f32", w, d_out, d_cyc, cus);
-        run<3>("v_rcp_f32", w, d_out, d_cyc, cus);
-        run<4>("v_div_scale_f32", w, d_out, d_cyc, cus);
-        run<5>("v_div_fmas_f32", w, d_out, d_cyc, cus);
-        run<6>("v_div_fixup_f32", w, d_out, d_cyc, cus);
-        run<7>("v_cndmask_b32", w, d_out, d_cyc, cus);
-        run<8>("v_cmp_lt_f32", w, d_out, d_cyc, cus);
-        run<9>("v_mov_b32", w, d_out, d_cyc, cus);
-        run<11>("v_cndmask e64 sgpr", w, d_out, d_cyc, cus);
-        run<17>("v_cndmask vcc 2src", w, d_out, d_cyc, cus);
-        run<20>("sub/mul/cndmask/add", w, d_out, d_cyc, cus);
-        run<12>("v_bfi_b32", w, d_out, d_cyc, cus);
-        run<13>("v_min_f32", w, d_out, d_cyc, cus);
-        run<14>("v_max_u32", w, d_out, d_cyc, cus);
-        run<15>("v_and_b32", w, d_out, d_cyc, cus);
-        run<16>("v_add_f32", w, d_out, d_cyc, cus);
-        run<18>("v_add_u32", w, d_out, d_cyc, cus);
-        run<19>("v_cmp_lt_u64", w, d_out, d_cyc, cus);
-        run<21>("s_add_u32", w, d_out, d_cyc, cus);
-        run<22>("s_and/or_b64", w, d_out, d_cyc, cus);
-        run<23>("v_mul + s_add mixed", w, d_out, d_cyc, cus);
-        run<24>("s_nop 0", w, d_out, d_cyc, cus);
+        if (only_w && w != only_w) continue;
+        run<0>("v_mul_f32", w, d_out, d_cyc, cus, iters);
+        run<1>("v_fma_f32", w, d_out, d_cyc, cus, iters);
+        run<2>("v_pk_mul_f32", w, d_out, d_cyc, cus, iters);
+        run<10>("v_pk_fma_f32", w, d_out, d_cyc, cus, iters);
+        run<3>("v_rcp_f32", w, d_out, d_cyc, cus, iters);
+        run<4>("v_div_scale_f32", w, d_out, d_cyc, cus, iters);
+        run<5>("v_div_fmas_f32", w, d_out, d_cyc, cus, iters);
+        run<6>("v_div_fixup_f32", w, d_out, d_cyc, cus, iters);
+        run<7>("v_cndmask_b32", w, d_out, d_cyc, cus, iters);
+        run<8>("v_cmp_lt_f32", w, d_out, d_cyc, cus, iters);
+        run<9>("v_mov_b32", w, d_out, d_cyc, cus, iters);
+        run<11>("v_cndmask e64 sgpr", w, d_out, d_cyc, cus, iters);
+        run<17>("v_cndmask vcc 2src", w, d_out, d_cyc, cus, iters);
+        run<20>("sub/mul/cndmask/add", w, d_out, d_cyc, cus, iters);
+        run<12>("v_bfi_b32", w, d_out, d_cyc, cus, iters);
+        run<13>("v_min_f32", w, d_out, d_cyc, cus, iters);
+        run<14>("v_max_u32", w, d_out, d_cyc, cus, iters);
+        run<15>("v_and_b32", w, d_out, d_cyc, cus, iters);
+        run<16>("v_add_f32", w, d_out, d_cyc, cus, iters);
+        run<18>("v_add_u32", w, d_out, d_cyc, cus, iters);
+        run<19>("v_cmp_lt_u64", w, d_out, d_cyc, cus, iters);
+        run<21>("s_add_u32", w, d_out, d_cyc, cus, iters);
+        run<22>("s_and/or_b64", w, d_out, d_cyc, cus, iters);
+        run<23>("v_mul + s_add mixed", w, d_out, d_cyc, cus, iters);
+        run<24>("s_nop 0", w, d_out, d_cyc, cus, iters);
+        run<25>("v_fmac_f32", w, d_out, d_cyc, cus, iters);
+        run<26>("v_trunc_f32", w, d_out, d_cyc, cus, iters);
+        run<27>("v_cvt_i32_f32", w, d_out, d_cyc, cus, iters);
+        run<28>("v_max_i32", w, d_out, d_cyc, cus, iters);
+        run<29>("v_lshlrev_b32", w, d_out, d_cyc, cus, iters);
+        run<30>("s_mul_i32", w, d_out, d_cyc, cus, iters);
+        run<31>("s_waitcnt (idle)", w, d_out, d_cyc, cus, iters);
+        run<32>("s_cbranch not taken", w, d_out, d_cyc, cus, iters);
+        run<33>("v_readlane_b32", w, d_out, d_cyc, cus, iters);
+        run<34>("ds_read_b32", w, d_out, d_cyc, cus, iters);
+        run<35>("s_load_dword", w, d_out, d_cyc, cus, iters);
     }
     return 0;
 }
