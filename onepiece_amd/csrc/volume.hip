@@ -1622,21 +1622,24 @@ class CopyPool {
     void copy2(void* d0, const void* s0, size_t n0, void* d1, const void* s1, size_t n1) {
         if (helpers_.empty() || n0 + n1 < (1u << 18)) { std::memcpy(d0, s0, n0); if (n1) std::memcpy(d1, s1, n1); return; }
         std::lock_guard<std::mutex> call(call_mutex_); // one copy at a time (volumes on several threads share the pool)
+        Job job[2] = {{(char*)d0, (const char*)s0, n0}, {(char*)d1, (const char*)s1, n1}};
         const size_t chunks = (n0 + kChunk - 1) / kChunk + (n1 + kChunk - 1) / kChunk;
-        {   // publish the job under the lock the helpers read the epoch under: a helper either sees all of it or none
+        uint64_t epoch;
+        {   // publish the job under the lock the helpers take their snapshot under: a helper sees all of it or none
             std::lock_guard<std::mutex> lk(m_);
-            job_[0] = {(char*)d0, (const char*)s0, n0}; job_[1] = {(char*)d1, (const char*)s1, n1};
-            done_.store(0, std::memory_order_relaxed);
-            next_.store(0, std::memory_order_relaxed);
+            job_[0] = job[0]; job_[1] = job[1];
             total_ = chunks;
-            ++epoch_;
+            epoch = ++epoch_;
+            done_.store(0, std::memory_order_relaxed);
+            next_.store((epoch & 0xffffffffull) << 32, std::memory_order_release); // chunk counter tagged with the epoch
             epoch_hint_.store(epoch_, std::memory_order_release);
         }
         cv_.notify_all();
-        work();
-        // every chunk copied AND no helper still inside work() (it would otherwise draw a chunk index of the NEXT job
-        // against this job's state): helpers count themselves in under m_ when they pick up an epoch
-        while (done_.load(std::memory_order_acquire) < chunks || active_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        work(epoch, job, chunks);
+        // Every chunk is DRAWN with a compare-exchange on the epoch-tagged counter and counted in done_ after its memcpy, so
+        // done_ == chunks means nobody is still copying.  A helper that wakes up late holds a snapshot of THIS job and this
+        // epoch: its first draw fails against the next job's tag and it leaves without touching anything.
+        while (done_.load(std::memory_order_acquire) < chunks) __builtin_ia32_pause();
     }
   private:
     static constexpr size_t kChunk = 1u << 17;
@@ -1652,44 +1655,51 @@ class CopyPool {
         cv_.notify_all();
         for (auto& t : helpers_) t.join();
     }
-    void work() {
-        const size_t c0 = (job_[0].n + kChunk - 1) / kChunk;
+    // copies chunks of the job of `epoch` (the caller's own copy of it) until none is left or the shared counter has moved on
+    void work(uint64_t epoch, const Job job[2], size_t total) {
+        const size_t c0 = (job[0].n + kChunk - 1) / kChunk;
+        const uint64_t tag = (epoch & 0xffffffffull) << 32;
         for (;;) {
-            const size_t c = next_.fetch_add(1, std::memory_order_acq_rel);
-            if (c >= total_) return;
-            const Job& j = c < c0 ? job_[0] : job_[1];
+            uint64_t v = next_.load(std::memory_order_acquire);
+            for (;;) {
+                if ((v & 0xffffffff00000000ull) != tag || (v & 0xffffffffull) >= total) return;
+                if (next_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) break;
+            }
+            const size_t c = (size_t)(v & 0xffffffffull);
+            const Job& j = c < c0 ? job[0] : job[1];
             const size_t off = (c < c0 ? c : c - c0) * kChunk;
             std::memcpy(j.d + off, j.s + off, std::min(kChunk, j.n - off));
             done_.fetch_add(1, std::memory_order_release);
         }
     }
-    // picks up a new epoch (counting itself active under the lock) or reports that there is none / that it is time to stop
-    int poll(uint64_t& seen) {
+    // takes a snapshot of a new epoch's job under the lock, or reports that there is none / that it is time to stop
+    int poll(uint64_t& seen, Job job[2], size_t& total) {
         if (epoch_hint_.load(std::memory_order_acquire) == seen) return 0; // nothing new: do not touch the lock while spinning
         std::lock_guard<std::mutex> lk(m_);
         if (stop_) return -1;
         if (epoch_ == seen) return 0;
         seen = epoch_;
-        active_.fetch_add(1, std::memory_order_acq_rel);
+        job[0] = job_[0]; job[1] = job_[1]; total = total_;
         return 1;
     }
     void loop() {
         uint64_t seen = 0;
+        Job job[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+        size_t total = 0;
         for (;;) {
             // spin for a while (a frame arrives every < 100 us during a sequence), then sleep
             int got = 0;
             for (int spin = 0; spin < 20000 && got == 0; ++spin) {
-                got = poll(seen);
+                got = poll(seen, job, total);
                 if (got == 0) __builtin_ia32_pause();
             }
             if (got == 0) {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-                continue; // poll() picks the epoch up (and counts this helper in) under the lock
+                continue; // poll() takes the snapshot under the lock
             }
             if (got < 0) return;
-            work();
-            active_.fetch_sub(1, std::memory_order_acq_rel);
+            work(seen, job, total);
         }
     }
     std::vector<std::thread> helpers_;
@@ -1699,8 +1709,8 @@ class CopyPool {
     bool stop_ = false;
     Job job_[2];
     size_t total_ = 0;
-    std::atomic<size_t> next_{0}, done_{0};
-    std::atomic<int> active_{0};
+    std::atomic<uint64_t> next_{0};       // (epoch & 0xffffffff) << 32 | next chunk index
+    std::atomic<size_t> done_{0};
     std::atomic<uint64_t> epoch_hint_{0}; // lock-free mirror of epoch_ for the spinning helpers
 };
 
@@ -1757,8 +1767,10 @@ int vol_ring_stage(op_volume* v, const void** depth, int depth_fmt, const unsign
 }
 
 int check_cam(const op_camera* cam) {
-    if (!cam || cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > (1LL << 30))
-        return fail(OP_ERR_INVALID, "invalid camera");
+    // 2^24 pixels (4096 x 4096): the fusion kernels address a batch of 16 packed frames with 32-bit byte offsets
+    // (16 x 2^24 x 8 B = 2^31) and multiply image rows with 24-bit integer multiplies
+    if (!cam || cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > (1LL << 24))
+        return fail(OP_ERR_INVALID, "invalid camera (images of up to 2^24 pixels are supported)");
     return OP_OK;
 }
 
@@ -1957,29 +1969,36 @@ int op_volume_destroy(op_volume* v) {
     if (!(v)) return fail(OP_ERR_INVALID, "null volume");      \
     OP_HIP(hipSetDevice((v)->device))
 
+// Queued and in-flight frames were accepted under the old setting: a CHANGE of resolution, truncation or camera waits until
+// they are fused for good (vol_check: flush, synchronise, grow + replay if a batch ran out of pool).  A replay rebuilds its
+// kernel parameters from the volume's current settings (BatchRec keeps poses, frustum planes and image pointers only), so no
+// batch may still be replayable when a setting changes.
 int op_volume_set_resolution(op_volume* v, float voxel_res) {
     OP_VOL(v);
-    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
     if (!(voxel_res > 0)) return fail(OP_ERR_INVALID, "voxel_res must be > 0");
+    if (voxel_res == v->res) return OP_OK;
+    OP_TRY(vol_check(v));
     v->res = voxel_res;
     return OP_OK;
 }
 int op_volume_set_truncation(op_volume* v, float truncation) {
     OP_VOL(v);
-    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
+    if (truncation == v->trunc) return OP_OK;
+    OP_TRY(vol_check(v));
     v->trunc = truncation;
     return OP_OK;
 }
 int op_volume_set_camera(op_volume* v, const op_camera* cam) {
     OP_VOL(v);
-    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
     OP_TRY(check_cam(cam));
+    if (std::memcmp(cam, &v->cam, sizeof(op_camera)) == 0) return OP_OK;
+    OP_TRY(vol_check(v));
     v->cam = *cam;
     return OP_OK;
 }
 int op_volume_set_near_far(op_volume* v, float near_dist, float far_dist) {
     OP_VOL(v);
-    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting
+    OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting; launched batches carry their frustum planes with them
     v->near_d = near_dist; v->far_d = far_dist;
     return OP_OK;
 }

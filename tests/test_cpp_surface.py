@@ -244,7 +244,7 @@ def test_class_surface_end_to_end_matches_oracle(hip, oracle, tmp_path):
     k2, v2 = o2.export()
     sk, sv = rd("single.map")
     assert len(sk) == 1 and tuple(sk[0]) == sid
-    sel1 = {tuple(k) for k in oracle.Volume(ocam, voxel_res=res).prepare_cubes(decoded[1][0], poses[1])}
+    sel1 = {tuple(int(x) for x in k) for k in oracle.Volume(ocam, voxel_res=res).prepare_cubes(decoded[1][0], poses[1])[0]}
     if sid in sel1:   # frame 1 selected it too: the oracle's block saw exactly the same two updates
         assert np.array_equal(sv[0].view(np.uint32), v2[np.where((k2 == np.array(sid)).all(1))[0][0]].view(np.uint32))
     centre = np.array(sid, np.float32) * 8 * np.float32(res) + (np.array([4, 4, 4], np.float32) * np.float32(res) + np.float32(res) / 2)
