@@ -157,10 +157,13 @@ def main():
         n_upd_frame = stats["voxels_updated"] / max(stats["frames"], 1)
         alg_bytes_frame = 40.0 * n_upd_frame + 7.0 * W * H  # B_frame = 40*N_upd + 7*W*H
         frames_per_launch = prof["frames"] / max(prof["launches"], 1)  # k_integrate fuses a batch of frames per launch
-        alg_bytes = alg_bytes_frame * frames_per_launch             # algorithmic bytes of the units one launch processes
+        alg_bytes = alg_bytes_frame * frames_per_launch             # SURVEY 8d's figure for the units one launch processes
         k3_s = prof["integrate_ms"] * 1e-3
-        achieved = alg_bytes / k3_s / 1e9 if k3_s > 0 else float("nan")
-        traffic = None  # filled in below from live PMC passes of this very step (tools/counters.py)
+        n_launch = max(stats["launches"], 1)
+        kc_cycles = stats["integrate_shader_cycles"] / n_launch     # shader cycles per launch (s_memtime span of the resident workgroups)
+        # what a batched launch MUST move through HBM whatever the number of frames it fuses: every selected block read once
+        # (20 B x 512 voxels), every voxel that changed written once (20 B), every packed {depth, rgba} image read once (8 B/px)
+        batch_bytes = 10240.0 * stats["blocks_read"] / n_launch + 20.0 * stats["voxels_written"] / n_launch + 8.0 * W * H * frames_per_launch
         out = {
             "metric": "RGB-D frames/sec fused (640x480, 5 mm voxel TSDF)",
             "value": total_frames / dt_max,
@@ -185,14 +188,23 @@ def main():
                           "voxels_updated": n_upd_frame, "final_blocks_rank0": hv.BlockCount()},
             "kernels_ms_per_launch": {"prepare_frames": prof["prepare_ms"], "select": prof["select_ms"], "integrate": prof["integrate_ms"],
                                       "event_sampled_launches": prof["launches"], "frames_per_launch": frames_per_launch},
-            "roofline": {"kernel": "k_integrate (Integrator::IntegrateImage, %.0f frames per launch)" % frames_per_launch,
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_frame": alg_bytes_frame, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": prof["integrate_ms"], "traffic": traffic,
-                         "note": "achieved = SURVEY 8(d)'s ALGORITHMIC bytes (40 B per updated voxel per frame + images) / launch time.  A launch fuses "
-                                 "a batch of frames and touches each voxel once per BATCH, so this figure is not bounded by the HBM peak (frac can "
-                                 "exceed 1); `traffic` is the HBM traffic the PMC counters saw per launch, `batch1` is the same byte model where it IS "
-                                 "a bound (one frame per launch), `valu` says what actually limits the batched kernel"},
+            # The integrate kernel with full batches is bound by instruction ISSUE: `frac` is filled in below from the SQ counters of this
+            # very step (tools/issue_model.py).  Until then (--no-counters, N > 1) the object carries the HBM view, which is a true
+            # fraction too: the bytes a batched launch must move / launch time / 8 TB/s.
+            "roofline": {"kernel": "k_integrate (Integrator::IntegrateImage, %.1f frames per launch)" % frames_per_launch,
+                         "bound": "hbm", "achieved": batch_bytes / k3_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": batch_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
+                         "avg_launch_ms": prof["integrate_ms"], "traffic": None,
+                         "hbm": {"bound": "hbm", "model_bytes_per_launch": batch_bytes, "model_gbs": batch_bytes / k3_s / 1e9, "peak": HBM_PEAK_GBS,
+                                 "model_frac": batch_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
+                                 "blocks_read_per_launch": stats["blocks_read"] / n_launch, "voxels_written_per_launch": stats["voxels_written"] / n_launch,
+                                 "note": "model = 10 240 B x blocks read + 20 B x voxels written + 8 B x W*H x frames per launch (counted on the device, "
+                                         "op_volume_stats_launches): a LOWER bound of the launch's HBM traffic"},
+                         "algorithmic_model": {"bytes_per_frame": alg_bytes_frame, "bytes_per_launch": alg_bytes, "gbs": alg_bytes / k3_s / 1e9,
+                                               "ratio_to_hbm_peak": alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
+                                               "note": "SURVEY 8(d): 40 B per updated voxel per FRAME + images, / launch time.  NOT a bound for a batched launch "
+                                                       "(it touches each voxel once per batch of up to 16 frames, so this ratio may exceed 1); it is one for "
+                                                       "a one-frame launch: see batch1"},
+                         "shader_cycles_per_launch": kc_cycles, "shader_clock_ghz": kc_cycles / k3_s / 1e9 if k3_s > 0 else None},
         }
     if rank == 0 and not args.timed_only:
         # -- the byte model where it is a roofline: one frame per launch (every voxel read + written once per frame)
@@ -205,14 +217,20 @@ def main():
         hv.ProfileEnable(0)
         b1 = 40.0 * st1["voxels_updated"] / max(st1["frames"], 1) + 7.0 * W * H
         a1 = b1 / (p1["integrate_ms"] * 1e-3) / 1e9
-        out["roofline"]["batch1"] = {"frames": nb1, "avg_launch_ms": p1["integrate_ms"], "algorithmic_bytes_per_launch": b1, "achieved": a1, "unit": "GB/s",
-                                     "frac": a1 / HBM_PEAK_GBS, "note": "k_integrate with ONE frame per launch: the algorithmic bytes are then a lower bound of "
-                                     "the real traffic, so this fraction is a true HBM roofline fraction"}
+        m1 = (10240.0 * st1["blocks_read"] + 20.0 * st1["voxels_written"]) / max(st1["launches"], 1) + 8.0 * W * H
+        out["roofline"]["batch1"] = {"frames": nb1, "bound": "hbm", "avg_launch_ms": p1["integrate_ms"], "algorithmic_bytes_per_launch": b1, "achieved": a1, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic_model_bytes_per_launch": m1, "traffic_model_frac": m1 / (p1["integrate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "evidence": "profiles/r03_batch1.kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/prof_driver.bin ... batch=1), "
+                                                 "profiles/r03_batch1.FETCH_SIZE.pmc.csv / WRITE_SIZE.pmc.csv: 393 MB per launch measured = 0.62 of the 8 TB/s peak, the rate the "
+                                                 "read-modify-write calibration kernel of the same shape reaches (profiles/r03_calib.timing.txt: 5.0 TB/s)",
+                                     "note": "k_integrate with ONE frame per launch: SURVEY 8(d)'s algorithmic bytes are then a lower bound of the real traffic, "
+                                             "so this is a true HBM roofline fraction (north_star: >= 50 % of HBM roofline on the integrate kernel)"}
         # -- live PMC passes (separate rocprofv3 --pmc runs of the torch-free driver on a dump of this step's frames)
         if world == 1 and not args.no_counters:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import counters as CT
+                import issue_model as IM
                 import tempfile
                 nfc = F
                 with tempfile.NamedTemporaryFile(prefix="opc_frames_", suffix=".bin", dir="/tmp", delete=False) as tf:
@@ -226,21 +244,31 @@ def main():
                 finally:
                     os.unlink(fname)
                 kc = cnt["k_integrate"]
-                clk = kc["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0   # per XCD
-                out["roofline"]["traffic"] = kc["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_detail"] = {"hbm_read_bytes_per_launch": kc["hbm_read_bytes_per_launch"], "hbm_write_bytes_per_launch": kc["hbm_write_bytes_per_launch"],
-                                                     "gbs": kc["hbm_bytes_per_launch"] / k3_s / 1e9, "frac_of_hbm_peak": kc["hbm_bytes_per_launch"] / k3_s / 1e9 / HBM_PEAK_GBS,
-                                                     "over_algorithmic": kc["hbm_bytes_per_launch"] / alg_bytes,
-                                                     "source": "rocprofv3 --pmc FETCH_SIZE (x2: 128 B requests tallied as 64 B on gfx950) and WRITE_SIZE, separate "
-                                                               "passes, tools/prof_driver.bin on the first %d frames of this run (same batching)" % nfc}
-                out["roofline"]["valu"] = {"bound": "valu", "insts_per_launch": kc["SQ_INSTS_VALU"]["mean_per_launch"], "kernel_cycles": clk,
-                                           "issue_frac": kc["SQ_INSTS_VALU"]["mean_per_launch"] * 2.0 / (1024.0 * clk),
-                                           "wave_cycles": {k: kc[k]["mean_per_launch"] for k in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
-                                           "insts_per_voxel_frame_wave": kc["SQ_INSTS_VALU"]["mean_per_launch"] / (stats["blocks_selected"] / max(stats["frames"], 1) * frames_per_launch * 8.0),
-                                           "note": "issue_frac = VALU wave-instructions x 2 cycles (wave64 on a SIMD-32) / (1024 SIMDs x kernel cycles): a LOWER bound "
-                                                   "of the VALU pipes' occupancy (VOP3-encoded and transcendental instructions take longer, tools/valu_ubench.hip); "
-                                                   "kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs"}
-                out["roofline"]["counters"] = {k: {c: v["mean_per_launch"] for c, v in r.items() if isinstance(v, dict) and "mean_per_launch" in v} for k, r in cnt.items()}
+                R = out["roofline"]
+                R["traffic"] = kc["hbm_bytes_per_launch"]
+                R["hbm"].update({"traffic_bytes_per_launch": kc["hbm_bytes_per_launch"], "read_bytes_per_launch": kc["hbm_read_bytes_per_launch"],
+                                 "write_bytes_per_launch": kc["hbm_write_bytes_per_launch"], "achieved": kc["hbm_bytes_per_launch"] / k3_s / 1e9, "unit": "GB/s",
+                                 "frac": kc["hbm_bytes_per_launch"] / k3_s / 1e9 / HBM_PEAK_GBS, "traffic_over_model": kc["hbm_bytes_per_launch"] / batch_bytes,
+                                 "source": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950, calibrated for this kernel's 4 B/lane plane rows: profiles/r03_calib.FETCH_SIZE.pmc.csv) "
+                                           "and WRITE_SIZE (exact: profiles/r03_calib.WRITE_SIZE.pmc.csv), separate passes, tools/prof_driver.bin on the first %d frames "
+                                           "of this run (same batching)" % nfc})
+                costs_file = os.path.join(ROOT, "profiles", "r03_issue_costs.json")
+                cj = json.load(open(costs_file))
+                counts = {c: kc[c]["mean_per_launch"] for c in kc if isinstance(kc[c], dict) and "mean_per_launch" in kc[c]}
+                counts["kernel_cycles"] = kc_cycles
+                im = IM.model(cj["costs"], cj["valu_mix_k_integrate_plain"], counts)
+                # the binding resource goes to the top of the object: a fraction <= 1 of the SIMDs' instruction-issue capacity
+                R.update({"bound": "issue", "achieved": im["issue_cycles_per_launch"], "peak": im["simd_cycles_per_launch"],
+                          "unit": "SIMD issue cycles per launch (shader clock)", "frac": im["frac"]})
+                R["issue"] = {"classes": im["classes"], "valu_cycles_each": im["valu_cycles_each"], "kernel_cycles": im["kernel_cycles"],
+                              "insts_per_voxel_frame_wave": {"valu": counts["SQ_INSTS_VALU"] / (stats["blocks_selected"] / max(stats["frames"], 1) * frames_per_launch * 8.0),
+                                                             "salu": counts.get("SQ_INSTS_SALU", 0.0) / (stats["blocks_selected"] / max(stats["frames"], 1) * frames_per_launch * 8.0)},
+                              "costs": "profiles/r03_issue_costs.json (tools/valu_ubench.hip at 8 waves per SIMD, shader cycles per wave64 instruction and SIMD; "
+                                       "VALU classes weighted by the kernel's static opcode histogram)",
+                              "note": "frac = sum over classes of wave-instructions (SQ_INSTS_* of this step's launches) x issue cost / (1024 SIMDs x the launch's "
+                                      "shader cycles): the share of the chip's instruction-issue slots the kernel fills.  HBM is far from binding for a batched launch "
+                                      "(roofline.hbm), so the way to make it faster is fewer instructions per voxel and frame"}
+                R["counters"] = {k: {c: v["mean_per_launch"] for c, v in r.items() if isinstance(v, dict) and "mean_per_launch" in v} for k, r in cnt.items()}
             except Exception as e:  # rocprofv3 missing / failing must not take the bench line down
                 out["roofline"]["traffic_error"] = repr(e)[:300]
 

@@ -162,8 +162,11 @@ int op_volume_stats(op_volume *v, uint64_t *frames, uint64_t *blocks_selected, u
  * Integrator::IntegrateImage runs as ONE kernel launch per batch of up to 16 frames that reads every
  * selected block once and writes every voxel that changed once, so the HBM traffic of a launch is
  * bounded below by 20 B x 512 x blocks_read + 20 B x voxels_written (+ the packed images), whatever
- * the number of frames in the batch.  launches = k_integrate launches that fused something. */
-int op_volume_stats_launches(op_volume *v, uint64_t *launches, uint64_t *blocks_read, uint64_t *voxels_written);
+ * the number of frames in the batch.  launches = k_integrate launches that fused something; shader_cycles = their summed
+ * durations in SHADER clock cycles (the longest s_memtime span of one of the launch's resident workgroups) --
+ * the denominator of the kernel's instruction-issue utilisation, whatever the clock did while it ran. */
+int op_volume_stats_launches(op_volume *v, uint64_t *launches, uint64_t *blocks_read, uint64_t *voxels_written,
+                             uint64_t *shader_cycles);
 
 /* Measurement hook (no reference counterpart): with sample_every = k > 0, every k-th launch group
  * (one group = one op_volume_integrate call, or one batch of up to 16 frames of

@@ -104,6 +104,12 @@ struct State {
     unsigned pad[3];
     unsigned long long stat_frames;
     unsigned long long stat_launches; // k_integrate launches that fused something (a poisoned launch does not count)
+    // Shader-clock duration of k_integrate (s_memtime counts shader cycles on this part, tools/valu_ubench.hip; its value is
+    // not synchronised between CUs, so every workgroup measures ITSELF): the longest s_memtime span of a workgroup of the
+    // running launch -- the workgroups are resident from the kernel's start to its end -- one slot per XCD, folded into
+    // stat_kc_ticks by the next batch's KA or by the host.
+    unsigned long long kc_t[8];
+    unsigned long long stat_kc_ticks;
     unsigned long long n_cand[kMaxBatch];
     float bbox[kMaxBatch][6]; // max xyz, min xyz
     unsigned n_inside[kMaxBatch];
@@ -337,6 +343,12 @@ __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C,
     if (blockIdx.x == 0 && f == 0 && tid == 0) {
         st->n_batch = 0; st->n_rec = 0; // new batch: empty lists
         st->cur_seq = seq;
+        unsigned long long kc = 0; // the previous launch's k_integrate duration in shader cycles: the longest XCD
+        for (int x = 0; x < 8; ++x) {
+            if (st->kc_t[x] > kc) kc = st->kc_t[x];
+            st->kc_t[x] = 0ull;
+        }
+        st->stat_kc_ticks += kc;
         // Progress report for the host (host-mapped pinned memory, read without any synchronisation): this kernel starting
         // means every earlier batch has finished; unless the stream is poisoned by an overflow they all completed.  The host
         // uses it to retire its replay log / staging slots and to grow the pool BEFORE it runs full.
@@ -618,7 +630,8 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
                                                    int n_frames, unsigned long long* __restrict__ upd_partial,
                                                    unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial) {
     __shared__ unsigned s_upd[8], s_chg[8];
-    __shared__ float s_c255[256]; // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
+    __shared__ float s_c255[256];
+    const unsigned long long t_in = __builtin_amdgcn_s_memtime(); // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
     // KB has consumed the frames' bounding accumulators: back to the identity for the next batch (also when poisoned)
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u;
     if (st->overflow & 3u) return; // pool / table exhausted in this or an earlier batch: nothing is fused, the host replays
@@ -772,6 +785,7 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
         chg_partial[blockIdx.x] += c;
         chg_partial[kIntegrateGrid + blockIdx.x] += nblk;
         if (blockIdx.x == 0) { st->stat_frames += (unsigned long long)n_frames; st->stat_launches += 1ull; }
+        atomicMax(&st->kc_t[blockIdx.x & 7u], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
     }
 }
 
@@ -2217,7 +2231,7 @@ int op_volume_stats(op_volume* v, uint64_t* frames, uint64_t* blocks_selected, u
     return OP_OK;
 }
 
-int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_read, uint64_t* voxels_written) {
+int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_read, uint64_t* voxels_written, uint64_t* shader_cycles) {
     OP_VOL(v);
     OP_TRY(vol_check(v));
     State st;
@@ -2226,6 +2240,12 @@ int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_
     OP_HIP(hipMemcpy(part.data(), v->chg_partial, 2 * kIntegrateGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long chg = 0, blk = 0;
     for (int i = 0; i < kIntegrateGrid; ++i) { chg += part[i]; blk += part[kIntegrateGrid + i]; }
+    if (shader_cycles) { // the last launch has not been folded by a following batch yet
+        unsigned long long kc = 0;
+        for (int x = 0; x < 8; ++x)
+            if (st.kc_t[x] > kc) kc = st.kc_t[x];
+        *shader_cycles = st.stat_kc_ticks + kc;
+    }
     if (launches) *launches = st.stat_launches;
     if (blocks_read) *blocks_read = blk;
     if (voxels_written) *voxels_written = chg;

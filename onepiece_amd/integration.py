@@ -198,10 +198,10 @@ class CubeHandler:
     def Stats(self):
         f, b, vis, upd = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         L.check(self._lib.op_volume_stats(self._h, C.byref(f), C.byref(b), C.byref(vis), C.byref(upd)))
-        ln, br, vw = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        L.check(self._lib.op_volume_stats_launches(self._h, C.byref(ln), C.byref(br), C.byref(vw)))
+        ln, br, vw, sc = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib.op_volume_stats_launches(self._h, C.byref(ln), C.byref(br), C.byref(vw), C.byref(sc)))
         return {"frames": f.value, "blocks_selected": b.value, "voxels_visited": vis.value, "voxels_updated": upd.value,
-                "launches": ln.value, "blocks_read": br.value, "voxels_written": vw.value}
+                "launches": ln.value, "blocks_read": br.value, "voxels_written": vw.value, "integrate_shader_cycles": sc.value}
 
     def ProfileEnable(self, sample_every=1):
         """HIP-event timing of K1/K2/K3 on the volume's own stream (measurement hook)."""

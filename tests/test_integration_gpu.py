@@ -599,6 +599,7 @@ def test_launch_level_counters(oracle):
         sel += n; upd += nupd
     st = hv.Stats()
     assert st["launches"] == 3 and st["blocks_read"] == sel == st["blocks_selected"] and st["voxels_written"] == upd == st["voxels_updated"]
+    assert 3 * 5e3 < st["integrate_shader_cycles"] < 3 * 5e6      # three launches of 5 us .. 2 ms each at ~2 GHz
     import torch
     hv.Clear()
     dev = torch.device("cuda", 0)

@@ -3,8 +3,10 @@
 counter collection segfaults under python + torch) fed with a dump of the very frames the bench fuses.  bench.py calls
 measure() for its `roofline.traffic` / `roofline.valu` fields; run as a script it prints the JSON.
 
-gfx950 corrections (same guide): FETCH_SIZE is tallied in 64 B units while the requests are 128 B wide (TCC_EA0_RDREQ_32B = 0)
--> doubled; WRITE_SIZE is in KiB and exact (calibrated on k_fill_pool in round 1: 2.684e9 B written, 2.62144e6 KiB reported).
+gfx950 corrections (same guide), CALIBRATED in round 3 on kernels with known traffic in this path's access shapes
+(tools/hbm_calib.hip, profiles/r03_calib.*): 4 GiB read with 4, 8 or 16 bytes per lane, as plane rows, or as a read-modify-write
+all report FETCH_SIZE = 2 097 1xx KiB = exactly half (TCC_EA0_RDREQ = 4 GiB / 128 B: read requests are 128 B wide and tallied as
+64 B) -> doubled for every access width; 4 GiB written report WRITE_SIZE = 4 194 304 KiB (write requests are 64 B) -> exact.
 """
 import csv
 import glob
@@ -22,6 +24,7 @@ GROUPS = {
     "traffic_read": ["FETCH_SIZE"],
     "traffic_write": ["WRITE_SIZE"],
     "sq_insts": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES"],
+    "sq_insts2": ["SQ_INSTS_SMEM", "SQ_INSTS_BRANCH"],
     "sq_cycles": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],
     "grbm": ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
 }
@@ -36,7 +39,7 @@ def build_driver():
     return DRIVER
 
 
-def _pass(counters, frames_file, reps, voxel, timeout):
+def _pass(counters, frames_file, reps, voxel, timeout, batch=None):
     """One rocprofv3 pass -> {kernel short name: {counter: (dispatches, sum)}} + kernel durations if traced."""
     td = tempfile.mkdtemp(prefix="opc_", dir="/tmp")
     try:
@@ -45,7 +48,7 @@ def _pass(counters, frames_file, reps, voxel, timeout):
             cmd += ["--pmc"] + counters
         else:
             cmd += ["--stats"]
-        cmd += ["--", DRIVER, frames_file, str(reps), repr(float(voxel))]
+        cmd += ["--", DRIVER, frames_file, str(reps), repr(float(voxel))] + (["batch=%d" % batch] if batch else [])
         env = dict(os.environ, TMPDIR="/tmp")
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
         out = {}
@@ -70,14 +73,14 @@ def _pass(counters, frames_file, reps, voxel, timeout):
         shutil.rmtree(td, ignore_errors=True)
 
 
-def measure(frames_file, voxel=0.005, groups=("traffic_read", "traffic_write", "sq_insts", "sq_cycles", "grbm"), timeout=180):
+def measure(frames_file, voxel=0.005, groups=("traffic_read", "traffic_write", "sq_insts", "sq_insts2", "sq_cycles", "grbm"), timeout=180, batch=None):
     """-> {"k_integrate": {...}, "k_select": {...}}: per-launch means of every counter, HBM bytes per launch, durations."""
     if shutil.which("rocprofv3") is None:
         raise RuntimeError("rocprofv3 not on PATH")
     build_driver()
     res = {}
     for g in groups:
-        out, durs = _pass(GROUPS[g], frames_file, 1, voxel, timeout)
+        out, durs = _pass(GROUPS[g], frames_file, 1, voxel, timeout, batch)
         for kern, cs in out.items():
             for c, per_dispatch in cs.items():
                 vals = list(per_dispatch.values())

@@ -3,19 +3,20 @@
 
 k_integrate with full batches is bound by instruction issue, not by HBM, so its roofline is
     frac = sum over instruction classes (wave-instructions executed x issue cost of the class) / (1024 SIMDs x kernel cycles)
-with
+with everything in SHADER clock cycles (s_memtime counts them on gfx950: its rate follows the clock -- 2.1 GHz while
+k_integrate runs, 1.2 GHz while the pure-VALU microbenchmark has the chip power-throttled -- whereas GRBM_GUI_ACTIVE keeps
+counting at ~2.1 GHz; measured in profiles/r03_valu_ubench_*.txt):
   * wave-instructions per class from the SQ counters of the launch (SQ_INSTS_VALU / SALU / SMEM / BRANCH / LDS / VMEM_RD / VMEM_WR,
     rocprofv3 --pmc, tools/counters.py / tools/profile_roofline.sh);
   * the VALU count split over cost classes in the proportions of the kernel's STATIC opcode histogram (tools/isa_histogram.py:
     the hot loop is straight-line code executed once per frame bit, so static and dynamic proportions agree closely);
-  * issue costs per class measured by tools/valu_ubench.hip at 8 waves per SIMD (k_integrate's occupancy) and expressed in the
-    SAME clock as `kernel cycles`: the microbenchmark runs under `rocprofv3 --pmc GRBM_GUI_ACTIVE` and
-        cost = (GRBM_GUI_ACTIVE / 8 XCDs) / (iterations x 64 instructions x waves per SIMD);
-  * kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs of the k_integrate dispatch.
+  * issue costs per class = s_memtime ticks per wave64 instruction and SIMD measured by tools/valu_ubench.hip at 8 waves per SIMD
+    (k_integrate's occupancy); they do not depend on how long the microbenchmark runs (64 .. 4096 iterations);
+  * kernel cycles = the longest s_memtime span of one of the launch's resident workgroups (op_volume_stats_launches).
 
-    python tools/issue_model.py calibrate <ubench .pmc.csv> <iters> <waves> <out.json>     # -> issue costs (commit under profiles/)
-    python tools/issue_model.py model <costs.json> <counters.json>                          # counters: {"SQ_INSTS_VALU": .., "GRBM_GUI_ACTIVE": ..}
-    python tools/issue_model.py model_pmc <costs.json> <dir> <prefix>                       # counters from <dir>/<prefix>.*.pmc.csv (tools/pmc_summary.py)
+    python tools/issue_model.py calibrate <valu_ubench output .txt> <out.json>             # -> issue costs (commit under profiles/)
+    python tools/issue_model.py model <costs.json> <counters.json>                          # counters: {"SQ_INSTS_VALU": .., "kernel_cycles": ..}
+    python tools/issue_model.py model_pmc <costs.json> <dir> <prefix> <kernel cycles>       # counters from <dir>/<prefix>.*.pmc.csv (tools/pmc_summary.py)
 """
 import csv
 import json
@@ -35,13 +36,13 @@ UBENCH_OPS = {0: "v_mul_f32", 1: "v_fma_f32", 2: "v_pk_mul_f32", 10: "v_pk_fma_f
               34: "ds_read_b32", 35: "s_load_dword"}
 
 
-def calibrate(pmc_csv, iters, waves):
-    """ubench under rocprofv3 --pmc GRBM_GUI_ACTIVE (tools/pmc_summary.py output) -> {row name: cycles per wave-instruction per SIMD}"""
+def calibrate(ubench_txt, waves=8):
+    """output of tools/valu_ubench.bin -> {row name: shader cycles per wave64 instruction and SIMD} at `waves` waves per SIMD"""
     costs = {}
-    for r in csv.DictReader(open(pmc_csv)):
-        m = re.match(r"k_bench<(\d+)>", r["kernel"])
-        if m and r["counter"] == "GRBM_GUI_ACTIVE":
-            costs[UBENCH_OPS[int(m.group(1))]] = float(r["mean_per_dispatch"]) / 8.0 / (iters * 64.0 * waves)
+    for line in open(ubench_txt):
+        m = re.search(r"OP\s+(\d+) waves/SIMD (\d+) iters \d+: [\d.]+ s_memtime ticks per wave-instruction -> ([\d.]+) per SIMD-issue slot", line)
+        if m and int(m.group(2)) == waves:
+            costs[UBENCH_OPS[int(m.group(1))]] = float(m.group(3))
     return costs
 
 
@@ -105,18 +106,20 @@ def static_valu_mix(kernel_substr="k_integrateILb1ELb1", src="volume.hip"):
 
 
 def model(costs, mix, counters):
-    """counters: per-launch means {SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_INSTS_SMEM, SQ_INSTS_BRANCH, SQ_INSTS_LDS, SQ_INSTS_VMEM_RD, SQ_INSTS_VMEM_WR, GRBM_GUI_ACTIVE}"""
+    """counters: per-launch means {SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_INSTS_SMEM, SQ_INSTS_BRANCH, SQ_INSTS_LDS, SQ_INSTS_VMEM_RD, SQ_INSTS_VMEM_WR} and
+    kernel_cycles = the launch's duration in shader cycles"""
     valu_cost = sum(share * costs[row] for row, share in mix.items())
-    kernel_cycles = counters["GRBM_GUI_ACTIVE"] / 8.0
-    # SQ_INSTS_SALU counts every scalar ALU instruction; SMEM and branches are counted by their own counters.  LDS / VMEM instructions
-    # occupy an issue slot like a VALU instruction of the plain class (their data path is elsewhere): priced at the measured ds_read / the plain VALU cost.
+    kernel_cycles = float(counters["kernel_cycles"])
+    # SQ_INSTS_SALU counts the scalar ALU instructions; SMEM and branches have their own counters.  The back-to-back costs of s_load and
+    # ds_read measured by the microbenchmark contain the wait for their data, which other waves' instructions fill in a real kernel:
+    # SMEM, LDS and VMEM instructions are priced at what they take from the issue port, a scalar / plain vector slot.
     classes = {
         "valu": (counters["SQ_INSTS_VALU"], valu_cost),
         "salu": (counters.get("SQ_INSTS_SALU", 0.0), costs["s_add_u32"]),
-        "smem": (counters.get("SQ_INSTS_SMEM", 0.0), costs.get("s_load_dword", costs["s_add_u32"])),
+        "smem": (counters.get("SQ_INSTS_SMEM", 0.0), costs["s_add_u32"]),
         "branch": (counters.get("SQ_INSTS_BRANCH", 0.0), costs.get("s_cbranch_not_taken", costs["s_add_u32"])),
-        "lds": (counters.get("SQ_INSTS_LDS", 0.0), costs.get("ds_read_b32", costs["v_and_b32"])),
-        "vmem": (counters.get("SQ_INSTS_VMEM_RD", 0.0) + counters.get("SQ_INSTS_VMEM_WR", 0.0), costs["v_and_b32"]),
+        "lds": (counters.get("SQ_INSTS_LDS", 0.0), costs["v_mov_b32"]),
+        "vmem": (counters.get("SQ_INSTS_VMEM_RD", 0.0) + counters.get("SQ_INSTS_VMEM_WR", 0.0), costs["v_mov_b32"]),
     }
     issue = {k: n * c for k, (n, c) in classes.items()}
     total, cap = sum(issue.values()), SIMDS * kernel_cycles
@@ -138,14 +141,15 @@ def counters_from_summaries(directory, prefix, kernel="k_integrate"):
 
 if __name__ == "__main__":
     if sys.argv[1] == "calibrate":
-        c = calibrate(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
-        out = {"unit": "GRBM_GUI_ACTIVE cycles per wave64 instruction per SIMD at %s waves per SIMD (tools/valu_ubench.bin %s %s under rocprofv3 --pmc GRBM_GUI_ACTIVE)" % (sys.argv[4], sys.argv[3], sys.argv[4]),
-               "costs": c, "valu_mix_k_integrate_plain": static_valu_mix()}
-        json.dump(out, open(sys.argv[5], "w"), indent=1)
+        out = {"unit": "shader cycles (s_memtime ticks) per wave64 instruction and SIMD at 8 waves per SIMD, from " + os.path.basename(sys.argv[2]),
+               "costs": calibrate(sys.argv[2]), "valu_mix_k_integrate_plain": static_valu_mix()}
+        json.dump(out, open(sys.argv[3], "w"), indent=1)
         print(json.dumps(out, indent=1))
-    elif sys.argv[1] == "model_pmc":   # model_pmc <costs.json> <directory> <prefix>
+    elif sys.argv[1] == "model_pmc":
         cj = json.load(open(sys.argv[2]))
-        print(json.dumps(model(cj["costs"], cj["valu_mix_k_integrate_plain"], counters_from_summaries(sys.argv[3], sys.argv[4])), indent=1))
+        cnt = counters_from_summaries(sys.argv[3], sys.argv[4])
+        cnt["kernel_cycles"] = float(sys.argv[5])
+        print(json.dumps(model(cj["costs"], cj["valu_mix_k_integrate_plain"], cnt), indent=1))
     else:
         cj = json.load(open(sys.argv[2]))
         print(json.dumps(model(cj["costs"], cj["valu_mix_k_integrate_plain"], json.load(open(sys.argv[3]))), indent=1))

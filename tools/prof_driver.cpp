@@ -166,10 +166,10 @@ int main(int argc, char** argv) {
         CK(op_volume_sync(v));
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         uint64_t fr, sel, vis, upd; CK(op_volume_stats(v, &fr, &sel, &vis, &upd));
-        uint64_t ln, br, vw; CK(op_volume_stats_launches(v, &ln, &br, &vw));
+        uint64_t ln, br, vw, sc; CK(op_volume_stats_launches(v, &ln, &br, &vw, &sc));
         size_t nb; CK(op_volume_block_count(v, &nb));
         printf("rep %d: %d frames %.3f ms/frame  sel/frame %.0f  upd/frame %.0f  blocks %zu | k_integrate launches %llu (%.2f frames each): blocks read %.0f, "
-               "voxels written %.0f per launch\n", r, n, dt / n * 1e3, (double)sel / fr, (double)upd / fr, nb, (unsigned long long)ln, (double)fr / ln, (double)br / ln, (double)vw / ln);
+               "voxels written %.0f, %.0f shader cycles per launch\n", r, n, dt / n * 1e3, (double)sel / fr, (double)upd / fr, nb, (unsigned long long)ln, (double)fr / ln, (double)br / ln, (double)vw / ln, (double)sc / ln);
     }
     op_volume_destroy(v);
     return 0;

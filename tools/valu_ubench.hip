@@ -79,14 +79,21 @@ __global__ void k_clock(unsigned long long* out) {
 template <int OP>
 void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, int cus, int iters) {
     const int wgs = cus * waves_per_simd; // 256 threads = 4 waves = one wave per SIMD of a CU (per resident workgroup)
+    static hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!e0) { hipEventCreate(&e0); hipEventCreate(&e1); }
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_bench<OP>, dim3(wgs), dim3(256), 0, 0, d_out, d_cyc, 1.0f, 1.0000001f, iters);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> c((size_t)wgs * 4);
     hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost);
     double s = 0;
     for (auto v : c) s += (double)v;
     const double per = s / c.size() / (64.0 * iters); // iters iterations x 64 instructions per wave
-    std::printf("%-18s OP %2d waves/SIMD %d iters %d: %.2f s_memtime ticks per wave-instruction -> %.2f per SIMD-issue slot\n", name, OP, waves_per_simd, iters, per, per / waves_per_simd);
+    std::printf("%-18s OP %2d waves/SIMD %d iters %d: %.2f s_memtime ticks per wave-instruction -> %.2f per SIMD-issue slot; kernel %.1f us = %.3f ns per instruction and SIMD (%.0f ticks per us while it ran)\n", name, OP, waves_per_simd, iters, per, per / waves_per_simd,
+                ms * 1e3, ms * 1e6 / (64.0 * iters * waves_per_simd), (s / c.size()) / (ms * 1e3));
 }
 
 int main(int argc, char** argv) {
