@@ -81,6 +81,19 @@ constexpr int kAccSlots = 16;        // see State::acc
 #ifndef KC_MIN_WAVES
 #define KC_MIN_WAVES 8 // waves per SIMD the integrate kernel is compiled for: 4 workgroups of 8 waves per CU = KC_GRID
 #endif
+// column form of KC (k_integrate_col): voxels of one (x, y) column per thread, waves per SIMD it is compiled for, and its grid
+#ifndef KC_ZT
+#define KC_ZT 4
+#endif
+#ifndef KC_COL_MIN_WAVES
+#define KC_COL_MIN_WAVES 4
+#endif
+#ifndef KC_COL_GRID
+#define KC_COL_GRID (256 * KC_COL_MIN_WAVES * 4 / (8 / KC_ZT)) // resident workgroups: 256 CUs x 4 SIMDs x waves per SIMD / waves per workgroup
+#endif
+constexpr int kColGrid = KC_ZT ? KC_COL_GRID : KC_GRID;
+static_assert(kColGrid % 8 == 0, "one drawing workgroup per XCD slab at least");
+constexpr int kPartialGrid = kColGrid > KC_GRID ? kColGrid : KC_GRID; // slots of the per-workgroup counter arrays
 constexpr int kCoordLimit = 1 << 20; // |block coordinate| < 2^20 (40 km at 4 cm blocks)
 
 struct CamParams {
@@ -783,7 +796,177 @@ __global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, Cam
         upd_partial[blockIdx.x] += t;
         sel_partial[blockIdx.x] += sel;
         chg_partial[blockIdx.x] += c;
-        chg_partial[kIntegrateGrid + blockIdx.x] += nblk;
+        chg_partial[kPartialGrid + blockIdx.x] += nblk;
+        if (blockIdx.x == 0) { st->stat_frames += (unsigned long long)n_frames; st->stat_launches += 1ull; }
+        atomicMax(&st->kc_t[blockIdx.x & 7u], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KC, column form.  The same fusion as k_integrate with the work of a block laid out differently: a thread owns ZT voxels
+// of one (x, y) column of the block (z = zg*ZT .. zg*ZT + ZT-1), a wave owns ZT z-slices, a workgroup of 8/ZT waves owns
+// the block.  What that buys, per voxel and frame:
+//   * everything that is uniform over the wave -- the frame's bit test, the three s_load_dwordx4 of its pose rows, the buffer
+//     resource of its packed image, the loop control -- is paid once per ZT voxels instead of once per voxel (a third of the
+//     issue slots of the one-voxel-per-thread kernel go to scalar and branch instructions, profiles/r03_issue_costs.json);
+//   * the partial sums M[r][0]*px + M[r][1]*py of the three pose rows depend on x and y only and are shared by the ZT voxels
+//     (the same two rounded products and one rounded sum the reference forms for each of them: bit-identical);
+//   * ZT independent dependency chains per thread hide the VALU and gather latencies that eight waves per SIMD hid before,
+//     so the kernel runs at a lower occupancy with a larger register budget.
+// A plane row of a z-slice is still one 256-byte wave access.  Frames are applied in ascending order; the gathers of the
+// NEXT selected frame are issued before the current frame's updates (two record sets, the frame loop unrolled by two).
+// ---------------------------------------------------------------------------------------------
+template <bool PLAIN>
+__device__ __forceinline__ void voxel_update(float& s, float& w, float& c0, float& c1, float& c2, float new_sdf, unsigned rgba, const float* s_c255) {
+    const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
+    if (PLAIN) {
+        // TSDFVoxel::IsValid (TSDFVoxel.h:75-78) false -> weight 0 in the same formula (see k_integrate's header comment)
+        const float wv = (s >= 1 || w <= 0) ? 0.0f : w;
+        const float wsum = wv + 1.0f;
+        float y = __builtin_amdgcn_rcpf(wsum);
+        const float e = __builtin_fmaf(-wsum, y, 1.0f);
+        y = __builtin_fmaf(e, y, y);
+        const float ns = wv * s + 1.0f * new_sdf;
+        const float m0 = wv * c0 + 1.0f * n0, m1 = wv * c1 + 1.0f * n1, m2 = wv * c2 + 1.0f * n2;
+        float qs = div_shared_rcp(ns, wsum, y);
+        const bool tiny = !(fabsf(ns) >= 0x1p-100f) && ns != 0.0f;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0ull, 0)) {
+            if (tiny) qs = ns / wsum;
+        }
+        s = qs;
+        c0 = div_shared_rcp(m0, wsum, y);
+        c1 = div_shared_rcp(m1, wsum, y);
+        c2 = div_shared_rcp(m2, wsum, y);
+        w = wsum;
+    } else if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
+        const float wsum = w + 1.0f;  // TSDFVoxel::operator+ with other = (new_sdf, 1.0, c) (TSDFVoxel.h:24-39)
+        s = (w * s + 1.0f * new_sdf) / wsum;
+        c0 = (w * c0 + 1.0f * n0) / wsum;
+        c1 = (w * c1 + 1.0f * n1) / wsum;
+        c2 = (w * c2 + 1.0f * n2) / wsum;
+        w = wsum;
+    } else {
+        s = new_sdf; w = 1.0f; c0 = n0; c1 = n1; c2 = n2;
+    }
+}
+
+template <bool FAST, bool PLAIN, int ZT>
+__global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate_col(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
+                                                                            int n_frames, unsigned long long* __restrict__ upd_partial,
+                                                                            unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial) {
+    constexpr int kWaves = 8 / ZT;            // waves per workgroup = z-groups per block
+    __shared__ unsigned s_cnt[kWaves][2];
+    __shared__ float s_c255[256];             // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
+    __shared__ unsigned s_next[2];
+    const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+    // KB has consumed the frames' bounding accumulators: back to the identity for the next batch (also when poisoned)
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u;
+    if (st->overflow & 3u) return; // pool / table exhausted in this or an earlier batch: nothing is fused, the host replays
+    const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
+    const int tid = threadIdx.x, lane = tid & 63, zg = tid >> 6;
+    for (int k = tid; k < 256; k += blockDim.x) s_c255[k] = (float)k / 255.0f;
+    const unsigned npix = (unsigned)(C.width * C.height);
+    const float half = C.res / 2;
+    // VoxelCentroidOffSet (VoxelCube.h:48-61): x*res + half with x = lane & 7, y = lane >> 3
+    const float ox = (float)(lane & 7) * C.res + half;
+    const float oy = (float)(lane >> 3) * C.res + half;
+    const float __attribute__((address_space(4)))* kargs =
+        (const float __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr(); // BatchInv B = offset 0 of the kernarg segment
+    (void)B;
+    unsigned upd = 0, sel = 0, chg = 0, nblk = 0;
+    const unsigned per_xcd = (n + 7u) / 8u;   // XCD-aware order and dynamic scheduling as in k_integrate
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned* ctr = &st->kc_next[xcd * 16u];
+    if (tid == 0) s_next[0] = atomicAdd(ctr, 1u);
+    __syncthreads();
+    unsigned slot = 0u;
+    for (unsigned j = s_next[0]; j < per_xcd;) {
+        if (tid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
+        const unsigned b = xcd * per_xcd + j;
+        const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
+        if (idx >= 0) {
+            const unsigned mask = V.bmask[V.blist[b]];
+            if (zg == 0) { sel += __popc(mask); ++nblk; }
+            const int kx = V.keys[3 * idx], ky = V.keys[3 * idx + 1], kz = V.keys[3 * idx + 2];
+            float* vox = V.pool + (size_t)idx * kBlockFloats + (zg * ZT) * 64 + lane;
+            float s[ZT], w[ZT], c0[ZT], c1[ZT], c2[ZT], pz[ZT];
+#pragma unroll
+            for (int z = 0; z < ZT; ++z) {
+                s[z] = vox[z * 64]; w[z] = vox[kVox + z * 64]; c0[z] = vox[2 * kVox + z * 64]; c1[z] = vox[3 * kVox + z * 64]; c2[z] = vox[4 * kVox + z * 64];
+                // GetGlobalPoint (VoxelCube.h:75-80): Point3(id) * CUBE_SIZE * VoxelResolution + offset
+                pz[z] = ((float)kz * 8.0f) * C.res + ((float)(zg * ZT + z) * C.res + half);
+            }
+            const float px = ((float)kx * 8.0f) * C.res + ox;
+            const float py = ((float)ky * 8.0f) * C.res + oy;
+            unsigned changed = 0u;
+            // one selected frame: projections of the thread's ZT voxels and their {depth, rgba} gathers
+            auto project = [&](int f, kc_v2u (&rec)[ZT], float (&zc)[ZT]) {
+                int fo = f;
+                asm volatile("" : "+s"(fo));
+                const float __attribute__((address_space(4)))* M = kargs + fo * 12;
+                const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pimg + (unsigned)fo * (npix * 8u)), 0, (int)(npix * 8u), 0x00020000);
+                const float a0 = M[0] * px + M[1] * py, a1 = M[4] * px + M[5] * py, a2 = M[8] * px + M[9] * py;
+#pragma unroll
+                for (int z = 0; z < ZT; ++z) {
+                    const float q0 = (a0 + M[2] * pz[z]) + M[3] * 1.0f;
+                    const float q1 = (a1 + M[6] * pz[z]) + M[7] * 1.0f;
+                    const float q2 = (a2 + M[10] * pz[z]) + M[11] * 1.0f;
+                    zc[z] = q2;
+                    const int pix = project_pixel<FAST>(C, q0, q1, q2); // off-image: pixel -1 = an offset the buffer answers with zeros
+                    rec[z] = __builtin_amdgcn_raw_buffer_load_b64(frame, pix * 8, 0, 0);
+                }
+            };
+            auto apply = [&](const kc_v2u (&rec)[ZT], const float (&zc)[ZT]) {
+#pragma unroll
+                for (int z = 0; z < ZT; ++z) {
+                    const float d = __uint_as_float(rec[z].x); // off-image pixels carry d == 0 -> skipped like `continue`
+                    const float new_sdf = d - zc[z];
+                    const bool hit = d > 0 && fabsf(new_sdf) < C.trunc; // Integrator.cpp:70,74 as ONE divergent region
+                    upd += hit ? 1u : 0u;                              // per lane; summed over the wave at the end
+                    if (hit) {
+                        changed |= 1u << z;
+                        voxel_update<PLAIN>(s[z], w[z], c0[z], c1[z], c2[z], new_sdf, rec[z].y, s_c255);
+                    }
+                }
+            };
+            kc_v2u recA[ZT], recB[ZT];
+            float zcA[ZT], zcB[ZT];
+            unsigned m = mask;                                    // wave-uniform
+            if (m) {
+                int f = __builtin_ctz(m); m &= m - 1u;
+                project(f, recA, zcA);
+                for (;;) {
+                    const bool more1 = m != 0u;
+                    if (more1) { f = __builtin_ctz(m); m &= m - 1u; project(f, recB, zcB); }
+                    apply(recA, zcA);
+                    if (!more1) break;
+                    const bool more2 = m != 0u;
+                    if (more2) { f = __builtin_ctz(m); m &= m - 1u; project(f, recA, zcA); }
+                    apply(recB, zcB);
+                    if (!more2) break;
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < ZT; ++z)
+                if ((changed >> z) & 1u) { vox[z * 64] = s[z]; vox[kVox + z * 64] = w[z]; vox[2 * kVox + z * 64] = c0[z]; vox[3 * kVox + z * 64] = c1[z]; vox[4 * kVox + z * 64] = c2[z]; }
+            chg += (unsigned)__popc(changed);
+        }
+        __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
+        if (b < n && tid == 0) V.bmask[V.blist[b]] = 0u;   // the owner clears it for the next batch
+        slot ^= 1u;
+        j = s_next[slot];
+    }
+    // per-workgroup counters (each workgroup owns its slot: no atomics)
+    upd = wave_sum(upd); chg = wave_sum(chg);
+    if (lane == 0) { s_cnt[zg][0] = upd; s_cnt[zg][1] = chg; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned t = 0, c = 0;
+        for (int k = 0; k < kWaves; ++k) { t += s_cnt[k][0]; c += s_cnt[k][1]; }
+        upd_partial[blockIdx.x] += t;
+        sel_partial[blockIdx.x] += sel;
+        chg_partial[blockIdx.x] += c;
+        chg_partial[kPartialGrid + blockIdx.x] += nblk;
         if (blockIdx.x == 0) { st->stat_frames += (unsigned long long)n_frames; st->stat_launches += 1ull; }
         atomicMax(&st->kc_t[blockIdx.x & 7u], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
     }
@@ -1332,9 +1515,9 @@ int vol_reset(op_volume* v) {
     OP_HIP(hipMemsetAsync(v->n_blocks, 0, sizeof(unsigned), v->stream));
     OP_HIP(hipMemsetAsync(v->bmask, 0, sizeof(unsigned) * (size_t)v->table_size, v->stream));
     OP_HIP(hipMemsetAsync(v->state, 0, sizeof(State), v->stream));
-    OP_HIP(hipMemsetAsync(v->upd_partial, 0, sizeof(unsigned long long) * kIntegrateGrid, v->stream));
-    OP_HIP(hipMemsetAsync(v->sel_partial, 0, sizeof(unsigned long long) * kIntegrateGrid, v->stream));
-    OP_HIP(hipMemsetAsync(v->chg_partial, 0, sizeof(unsigned long long) * 2 * kIntegrateGrid, v->stream));
+    OP_HIP(hipMemsetAsync(v->upd_partial, 0, sizeof(unsigned long long) * kPartialGrid, v->stream));
+    OP_HIP(hipMemsetAsync(v->sel_partial, 0, sizeof(unsigned long long) * kPartialGrid, v->stream));
+    OP_HIP(hipMemsetAsync(v->chg_partial, 0, sizeof(unsigned long long) * 2 * kPartialGrid, v->stream));
     OP_HIP(hipGetLastError());
     return OP_OK;
 }
@@ -1596,8 +1779,13 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (select_only)
         hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, v->state);
     else {
+#if KC_ZT
+#define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate_col<FASTPX, PLAINV, KC_ZT>), dim3(kColGrid), dim3(512 / KC_ZT), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
+                                                 v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial)
+#else
 #define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV>), dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
                                                  v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial)
+#endif
         if (C.fast_px) { if (v->plain) OP_KC(true, true); else OP_KC(true, false); }
         else { if (v->plain) OP_KC(false, true); else OP_KC(false, false); }
 #undef OP_KC
@@ -1934,15 +2122,15 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     OP_HIP_C(op::cached_malloc((void**)&v->tvals, sizeof(int) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->bmask, sizeof(unsigned) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->blist, sizeof(int) * (size_t)v->max_blocks));
-    OP_HIP_C(op::cached_malloc((void**)&v->sel_partial, sizeof(unsigned long long) * kIntegrateGrid));
+    OP_HIP_C(op::cached_malloc((void**)&v->sel_partial, sizeof(unsigned long long) * kPartialGrid));
     OP_HIP_C(op::cached_malloc((void**)&v->keys, sizeof(int) * 3 * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->pool, sizeof(float) * kBlockFloats * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->n_blocks, sizeof(unsigned)));
     OP_HIP_C(op::cached_malloc((void**)&v->sel_list, sizeof(int) * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->sel_cand, sizeof(unsigned long long) * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->state, sizeof(State)));
-    OP_HIP_C(op::cached_malloc((void**)&v->upd_partial, sizeof(unsigned long long) * kIntegrateGrid));
-    OP_HIP_C(op::cached_malloc((void**)&v->chg_partial, sizeof(unsigned long long) * 2 * kIntegrateGrid));
+    OP_HIP_C(op::cached_malloc((void**)&v->upd_partial, sizeof(unsigned long long) * kPartialGrid));
+    OP_HIP_C(op::cached_malloc((void**)&v->chg_partial, sizeof(unsigned long long) * 2 * kPartialGrid));
     OP_HIP_C(op::cached_host_malloc((void**)&v->hstat, 2 * sizeof(unsigned)));
     v->hstat[0] = 0; v->hstat[1] = 0;
     OP_HIP_C(hipHostGetDevicePointer((void**)&v->hstat_dev, v->hstat, 0));
@@ -2219,11 +2407,11 @@ int op_volume_stats(op_volume* v, uint64_t* frames, uint64_t* blocks_selected, u
     OP_TRY(vol_check(v));
     State st;
     OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
-    std::vector<unsigned long long> part(2 * kIntegrateGrid);
-    OP_HIP(hipMemcpy(part.data(), v->upd_partial, kIntegrateGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    OP_HIP(hipMemcpy(part.data() + kIntegrateGrid, v->sel_partial, kIntegrateGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> part(2 * kPartialGrid);
+    OP_HIP(hipMemcpy(part.data(), v->upd_partial, kPartialGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    OP_HIP(hipMemcpy(part.data() + kPartialGrid, v->sel_partial, kPartialGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long upd = 0, sel = 0;
-    for (int i = 0; i < kIntegrateGrid; ++i) { upd += part[i]; sel += part[kIntegrateGrid + i]; }
+    for (int i = 0; i < kPartialGrid; ++i) { upd += part[i]; sel += part[kPartialGrid + i]; }
     if (frames) *frames = st.stat_frames;
     if (blocks_selected) *blocks_selected = sel;
     if (voxels_visited) *voxels_visited = sel * (uint64_t)kVox;
@@ -2236,10 +2424,10 @@ int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_
     OP_TRY(vol_check(v));
     State st;
     OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
-    std::vector<unsigned long long> part(2 * kIntegrateGrid);
-    OP_HIP(hipMemcpy(part.data(), v->chg_partial, 2 * kIntegrateGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> part(2 * kPartialGrid);
+    OP_HIP(hipMemcpy(part.data(), v->chg_partial, 2 * kPartialGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long chg = 0, blk = 0;
-    for (int i = 0; i < kIntegrateGrid; ++i) { chg += part[i]; blk += part[kIntegrateGrid + i]; }
+    for (int i = 0; i < kPartialGrid; ++i) { chg += part[i]; blk += part[kPartialGrid + i]; }
     if (shader_cycles) { // the last launch has not been folded by a following batch yet
         unsigned long long kc = 0;
         for (int x = 0; x < 8; ++x)
