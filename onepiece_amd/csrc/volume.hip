@@ -83,10 +83,10 @@ constexpr int kAccSlots = 16;        // see State::acc
 #endif
 // column form of KC (k_integrate_col): voxels of one (x, y) column per thread, waves per SIMD it is compiled for, and its grid
 #ifndef KC_ZT
-#define KC_ZT 4
+#define KC_ZT 2
 #endif
 #ifndef KC_COL_MIN_WAVES
-#define KC_COL_MIN_WAVES 4
+#define KC_COL_MIN_WAVES 8
 #endif
 #ifndef KC_COL_GRID
 #define KC_COL_GRID (256 * KC_COL_MIN_WAVES * 4 / (8 / KC_ZT)) // resident workgroups: 256 CUs x 4 SIMDs x waves per SIMD / waves per workgroup
@@ -921,7 +921,10 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate_col(Ba
                 for (int z = 0; z < ZT; ++z) {
                     const float d = __uint_as_float(rec[z].x); // off-image pixels carry d == 0 -> skipped like `continue`
                     const float new_sdf = d - zc[z];
-                    const bool hit = d > 0 && fabsf(new_sdf) < C.trunc; // Integrator.cpp:70,74 as ONE divergent region
+                    // Integrator.cpp:70,74 (d > 0 and |sdf| < truncation) as ONE compare and one divergent region: an absent
+                    // observation takes the place of an out-of-band one
+                    const float band = d > 0 ? fabsf(new_sdf) : C.trunc;
+                    const bool hit = band < C.trunc;
                     upd += hit ? 1u : 0u;                              // per lane; summed over the wave at the end
                     if (hit) {
                         changed |= 1u << z;

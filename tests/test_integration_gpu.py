@@ -557,6 +557,7 @@ def test_torch_tensors_are_final_before_library_kernels_read_them():
     hv = I.CubeHandler(max_blocks=1 << 17); hv.SetVoxelResolution(0.01)
     hv.IntegrateSequence(late, rgb, poses)
     got = hv.Stats()
+    got.pop("integrate_shader_cycles"); want.pop("integrate_shader_cycles")   # a duration, not a result
     assert got == want and got["voxels_updated"] > 0
     del junk
 
