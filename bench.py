@@ -138,6 +138,7 @@ def main():
     hv.Synchronize()
     t_fuse = time.perf_counter() - t0
     stats = hv.Stats()  # per-rank counters, read before the merge rewrites the root volume
+    growth = hv.GrowthStats()
     n_union = None
     if world > 1 or force_dist:
         n_union = D.merge_volumes(ops, root=0)
@@ -182,6 +183,7 @@ def main():
                        "frames_per_step": F, "frames_per_gpu": n_local, "sharding": "contiguous frames per GPU, one RCCL reduce at end",
                        "voxel_m": args.voxel},
             "fusion_only_frames_per_s": total_frames / t_fuse_max,
+            "pool": growth,   # the pool starts at 2^18 blocks and grows on demand INSIDE the timed region (grows / replayed batches since create)
             "merge_union_blocks": n_union,
             "per_frame": {"blocks_selected": stats["blocks_selected"] / max(stats["frames"], 1),
                           "voxels_visited": stats["voxels_visited"] / max(stats["frames"], 1),

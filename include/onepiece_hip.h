@@ -168,6 +168,10 @@ int op_volume_stats(op_volume *v, uint64_t *frames, uint64_t *blocks_selected, u
 int op_volume_stats_launches(op_volume *v, uint64_t *launches, uint64_t *blocks_read, uint64_t *voxels_written,
                              uint64_t *shader_cycles);
 
+/* The volume grows like the reference's std::unordered_map (CubeHandler.h:22): current capacity in blocks, how often the
+ * pool has been enlarged since create, and how many batches were launched a second time because a batch had exhausted the
+ * pool before the host noticed (results are unaffected; the replays cost time).  Does not synchronise. */
+int op_volume_growth_stats(op_volume *v, uint64_t *max_blocks, uint64_t *grows, uint64_t *replayed_batches);
 /* Measurement hook (no reference counterpart): with sample_every = k > 0, every k-th launch group
  * (one group = one op_volume_integrate call, or one batch of up to 16 frames of
  * op_volume_integrate_sequence) is bracketed by HIP events on the volume's stream.  profile_read

@@ -98,6 +98,7 @@ SIGNATURES = {
     "op_volume_integrate_cubes": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _fp, _fp, _vp, C.c_size_t]),
     "op_volume_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "op_volume_stats_launches": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
+    "op_volume_growth_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
     "op_volume_profile_enable": (C.c_int, [_vp, C.c_int]),
     "op_volume_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), _u64p, _u64p]),
     "op_volume_download": (C.c_int, [_vp, _ip, _fp, C.c_size_t, _szp]),

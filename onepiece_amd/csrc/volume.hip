@@ -66,22 +66,14 @@ constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 
 #define KB_GRID 512
 #endif
 constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
-// KC grid: 512-thread workgroups that draw blocks of the batch's list from per-XCD counters (see k_integrate); 1024 is
-// what is resident at the kernel's <= 64 VGPRs (4 workgroups of 8 waves per CU).  Must be a multiple of 8 (XCDs).
-#ifndef KC_GRID
-#define KC_GRID 1024
-#endif
-static_assert(KC_GRID % 8 == 0 && KC_GRID >= 8, "one drawing workgroup per XCD slab at least");
-constexpr int kIntegrateGrid = KC_GRID;
 constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
 constexpr int kAccSlots = 16;        // see State::acc
-#ifndef KC_SUB
-#define KC_SUB 8 // frames whose gathers are in flight together inside k_integrate (divides kMaxBatch)
-#endif
-#ifndef KC_MIN_WAVES
-#define KC_MIN_WAVES 8 // waves per SIMD the integrate kernel is compiled for: 4 workgroups of 8 waves per CU = KC_GRID
-#endif
-// column form of KC (k_integrate_col): voxels of one (x, y) column per thread, waves per SIMD it is compiled for, and its grid
+// KC (k_integrate): ZT voxels of one (x, y) column of a block per thread (a workgroup of 8 / ZT waves owns a block), the waves
+// per SIMD it is compiled for, and its grid = exactly the workgroups that are resident then (they draw blocks of the batch's
+// list from per-XCD counters; a multiple of 8 = the XCDs).  Measured per 16-frame launch (tools/ab_variants.sh,
+// profiles/r03_ab_column_kernel.txt): ZT 1 at 8 waves 380 us, ZT 2 at 8 waves 357 us, ZT 2 at 6 waves 367 us, ZT 4 at 5 waves 381 us,
+// ZT 4 at 4 waves 416 us, ZT 8 at 3 waves 446 us -- the instructions a bigger ZT saves are lost again to the lower occupancy (a wave
+// issues at most one instruction every ~5 cycles, so instruction throughput needs the eight waves).
 #ifndef KC_ZT
 #define KC_ZT 2
 #endif
@@ -91,9 +83,10 @@ constexpr int kAccSlots = 16;        // see State::acc
 #ifndef KC_COL_GRID
 #define KC_COL_GRID (256 * KC_COL_MIN_WAVES * 4 / (8 / KC_ZT)) // resident workgroups: 256 CUs x 4 SIMDs x waves per SIMD / waves per workgroup
 #endif
-constexpr int kColGrid = KC_ZT ? KC_COL_GRID : KC_GRID;
+constexpr int kColGrid = KC_COL_GRID;
 static_assert(kColGrid % 8 == 0, "one drawing workgroup per XCD slab at least");
-constexpr int kPartialGrid = kColGrid > KC_GRID ? kColGrid : KC_GRID; // slots of the per-workgroup counter arrays
+constexpr int kPartialGrid = 1024; // slots of the counter arrays k_integrate's workgroups add to (workgroup b -> slot b % 1024).  Not more: the host reads
+                                   // them with small pageable copies, and a 16 KB device-to-host copy takes the runtime's pinned-staging path (milliseconds)
 constexpr int kCoordLimit = 1 << 20; // |block coordinate| < 2^20 (40 km at 4 cm blocks)
 
 struct CamParams {
@@ -615,13 +608,7 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
 }
 
 // ---------------------------------------------------------------------------------------------
-// KC: Integrator::IntegrateImage (Integrator.cpp:36-94) for all frames of the batch.  One
-// 512-thread workgroup per block of the batch list (thread = voxel, wave = z-slice); the resident
-// workgroups draw blocks from per-XCD counters.  The voxel is read ONCE, every frame that selected the block is applied to it in frame
-// order in registers (bit-identical to the reference's frame-by-frame running mean), and it is
-// written once -- HBM traffic per voxel drops from 40 B per frame to 40 B per batch.
-// All per-frame gathers ({depth, rgba} records) are issued before the first dependent use.
-// Block ownership is exclusive, so the read-modify-write needs no atomics.
+// KC: Integrator::IntegrateImage (Integrator.cpp:36-94) for all frames of the batch (k_integrate below).
 // ---------------------------------------------------------------------------------------------
 typedef unsigned int kc_v2u __attribute__((ext_vector_type(2)));
 
@@ -638,177 +625,16 @@ typedef unsigned int kc_v2u __attribute__((ext_vector_type(2)));
 //     |w*s + new| is non-zero and below 2^-100 takes the plain division (never, in practice).
 // Without PLAIN (arbitrary uploaded data: NaN, infinities, denormals, fractional weights) the update is the reference's
 // two-branch form with four true divisions.
-template <bool FAST, bool PLAIN>
-__global__ __launch_bounds__(512, KC_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
-                                                   int n_frames, unsigned long long* __restrict__ upd_partial,
-                                                   unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial) {
-    __shared__ unsigned s_upd[8], s_chg[8];
-    __shared__ float s_c255[256];
-    const unsigned long long t_in = __builtin_amdgcn_s_memtime(); // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
-    // KB has consumed the frames' bounding accumulators: back to the identity for the next batch (also when poisoned)
-    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u;
-    if (st->overflow & 3u) return; // pool / table exhausted in this or an earlier batch: nothing is fused, the host replays
-    const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
-    const int vid = threadIdx.x;
-    if (vid < 256) s_c255[vid] = (float)vid / 255.0f;
-    __syncthreads();
-    const unsigned npix = (unsigned)(C.width * C.height);
-    const float half = C.res / 2;
-    // VoxelCentroidOffSet[vid] (VoxelCube.h:48-61): x*res + half with x = vid & 7 etc.
-    const float ox = (float)(vid & 7) * C.res + half;
-    const float oy = (float)((vid >> 3) & 7) * C.res + half;
-    const float oz = (float)(vid >> 6) * C.res + half;
-    // BatchInv B is the first kernel argument = offset 0 of the kernarg segment
-    const float __attribute__((address_space(4)))* kargs =
-        (const float __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)B;
-    // The per-frame {depth, rgba} gathers go through a buffer resource over the frame's packed image (built from scalars
-    // per frame: the range check of a raw buffer covers voffset + soffset, so the frame cannot be a scalar offset into one
-    // resource): the lane offset is a 32-bit byte offset, and a lane whose projection falls outside the image asks for
-    // offset -8, beyond num_records, which the hardware answers with zeros (depth 0 = "no observation") -- no exec-mask
-    // branch around the load and no 64-bit address arithmetic in vector registers.
-    unsigned upd = 0, sel = 0, chg = 0, nblk = 0; // chg / nblk: voxels written / blocks read by THIS launch (the batch-level byte model)
-    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): XCD x walks
-    // the x-th contiguous eighth of the list, so list neighbours -- blocks along one viewing ray,
-    // which gather the same pixels -- are processed on one XCD close in time and share its L2.
-    const unsigned per_xcd = (n + 7u) / 8u;
-    // Dynamic scheduling: blocks differ in work (1..16 frames touch them), so the workgroups of XCD x DRAW list positions
-    // of slab x from one counter instead of owning a fixed stride (static grids: 1024 workgroups 691 us per 14-frame
-    // launch, 2048 -> 648; drawn: 623, the grid being exactly what is resident).  The next position is requested before
-    // the current block is processed, so the atomic's round trip is hidden.
-    __shared__ unsigned s_next[2];
-    const unsigned xcd = blockIdx.x & 7u;
-    unsigned* ctr = &st->kc_next[xcd * 16u];
-    if (vid == 0) s_next[0] = atomicAdd(ctr, 1u);
-    __syncthreads();
-    unsigned slot = 0u;
-    for (unsigned j = s_next[0]; j < per_xcd;) {
-        if (vid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
-        const unsigned b = xcd * per_xcd + j;
-        const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
-        if (idx >= 0) {
-        const unsigned mask = V.bmask[V.blist[b]];
-        sel += __popc(mask);
-        ++nblk;
-        const int kx = V.keys[3 * idx], ky = V.keys[3 * idx + 1], kz = V.keys[3 * idx + 2];
-        float* vox = V.pool + (size_t)idx * kBlockFloats + vid;
-        float s = vox[0], w = vox[kVox], c0 = vox[2 * kVox], c1 = vox[3 * kVox], c2 = vox[4 * kVox];
-        // GetGlobalPoint (VoxelCube.h:75-80): Point3(id) * CUBE_SIZE * VoxelResolution + offset
-        const float px = ((float)kx * 8.0f) * C.res + ox;
-        const float py = ((float)ky * 8.0f) * C.res + oy;
-        const float pz = ((float)kz * 8.0f) * C.res + oz;
-        bool changed = false;
-        // frames are applied in order, KC_SUB at a time: all gathers of a sub-batch are issued before
-        // the first dependent use, while the register footprint stays small enough for KC_MIN_WAVES
-#pragma unroll
-        for (int h = 0; h < kMaxBatch; h += KC_SUB) {
-            if (((mask >> h) & ((1u << KC_SUB) - 1u)) == 0u) continue; // wave-uniform
-            kc_v2u rec[KC_SUB];
-            float zc[KC_SUB];
-#pragma unroll
-            for (int g = 0; g < KC_SUB; ++g) {
-                const int f = h + g;
-                rec[g] = kc_v2u{0u, 0u};
-                zc[g] = 0.0f;
-                if ((mask >> f) & 1u) { // wave-uniform
-                    // pose^-1 of frame f, fetched with scalar loads from the kernarg segment right here: keeping all 16
-                    // matrices (192 SGPRs) live across the block loop makes the compiler spill SGPRs through
-                    // v_writelane / v_readlane.  The frame index is made opaque first, so that the per-frame ADDRESSES (pose
-                    // row pointer, buffer resource of the frame's image: 6 SGPRs x 16 frames) are recomputed with three
-                    // scalar instructions where they are used instead of being hoisted out of the block loop and spilled.
-                    int fo = f;
-                    asm volatile("" : "+s"(fo));
-                    const float __attribute__((address_space(4)))* M = kargs + fo * 12;
-                    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-                    const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-                    const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                    zc[g] = q2;
-                    // off-image (Integrator.cpp:63: v < 0 || v >= height || u < 0 || u >= width) is pixel -1 = an offset the
-                    // buffer rejects
-                    const int pix = project_pixel<FAST>(C, q0, q1, q2);
-                    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pimg + (unsigned)fo * (npix * 8u)), 0, (int)(npix * 8u), 0x00020000);
-                    rec[g] = __builtin_amdgcn_raw_buffer_load_b64(frame, pix * 8, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < KC_SUB; ++g) {
-                if ((mask >> (h + g)) & 1u) {
-                    const float d = __uint_as_float(rec[g].x); // off-image pixels carry d == 0 -> skipped like `continue`
-                    const float new_sdf = d - zc[g];
-                    const bool hit = d > 0 && fabsf(new_sdf) < C.trunc; // Integrator.cpp:70,74 as ONE divergent region
-                    upd += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(hit));  // counted per wave on the scalar unit
-                    {
-                        if (hit) {
-                            changed = true;
-                            const unsigned rgba = rec[g].y;
-                            const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
-                            if (PLAIN) {
-                                // TSDFVoxel::IsValid (TSDFVoxel.h:75-78) false -> weight 0 in the same formula (see the header comment)
-                                const float wv = (s >= 1 || w <= 0) ? 0.0f : w;
-                                const float wsum = wv + 1.0f;
-                                float y = __builtin_amdgcn_rcpf(wsum);
-                                const float e = __builtin_fmaf(-wsum, y, 1.0f);
-                                y = __builtin_fmaf(e, y, y);
-                                const float ns = wv * s + 1.0f * new_sdf;
-                                const float m0 = wv * c0 + 1.0f * n0, m1 = wv * c1 + 1.0f * n1, m2 = wv * c2 + 1.0f * n2;
-                                float qs = div_shared_rcp(ns, wsum, y);
-                                // a cancelled sdf numerator below 2^-100 (never, in practice): the plain division -- behind a
-                                // wave-uniform branch, or the compiler evaluates its 11 instructions on every frame and selects
-                                const bool tiny = !(fabsf(ns) >= 0x1p-100f) && ns != 0.0f;
-                                if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0ull, 0)) {
-                                    if (tiny) qs = ns / wsum;
-                                }
-                                s = qs;
-                                c0 = div_shared_rcp(m0, wsum, y);
-                                c1 = div_shared_rcp(m1, wsum, y);
-                                c2 = div_shared_rcp(m2, wsum, y);
-                                w = wsum;
-                            } else if (!(s >= 1 || w <= 0)) { // TSDFVoxel::IsValid (TSDFVoxel.h:75-78)
-                                // TSDFVoxel::operator+ with other = (new_sdf, 1.0, c) (TSDFVoxel.h:24-39)
-                                const float wsum = w + 1.0f;
-                                s = (w * s + 1.0f * new_sdf) / wsum;
-                                c0 = (w * c0 + 1.0f * n0) / wsum;
-                                c1 = (w * c1 + 1.0f * n1) / wsum;
-                                c2 = (w * c2 + 1.0f * n2) / wsum;
-                                w = wsum;
-                            } else {
-                                s = new_sdf; w = 1.0f; c0 = n0; c1 = n1; c2 = n2;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (changed) { vox[0] = s; vox[kVox] = w; vox[2 * kVox] = c0; vox[3 * kVox] = c1; vox[4 * kVox] = c2; }
-        chg += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(changed));
-        }
-        __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
-        if (b < n && vid == 0) V.bmask[V.blist[b]] = 0u;   // the owner clears it for the next batch
-        slot ^= 1u;
-        j = s_next[slot];
-    }
-    // per-workgroup counters (each workgroup owns its slot: no atomics)
-    if ((vid & 63) == 0) { s_upd[vid >> 6] = upd; s_chg[vid >> 6] = chg; } // already the wave's totals (ballot counts)
-    __syncthreads();
-    if (vid == 0) {
-        unsigned t = 0, c = 0;
-        for (int k = 0; k < 8; ++k) { t += s_upd[k]; c += s_chg[k]; }
-        upd_partial[blockIdx.x] += t;
-        sel_partial[blockIdx.x] += sel;
-        chg_partial[blockIdx.x] += c;
-        chg_partial[kPartialGrid + blockIdx.x] += nblk;
-        if (blockIdx.x == 0) { st->stat_frames += (unsigned long long)n_frames; st->stat_launches += 1ull; }
-        atomicMax(&st->kc_t[blockIdx.x & 7u], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// KC, column form.  The same fusion as k_integrate with the work of a block laid out differently: a thread owns ZT voxels
+// KC.  One workgroup per block of the batch list; the resident workgroups draw blocks from per-XCD counters.  Every voxel is
+// read ONCE, every frame that selected the block is applied to it in frame order in registers (bit-identical to the
+// reference's frame-by-frame running mean) and it is written once -- HBM traffic per voxel drops from 40 B per frame to
+// 40 B per batch; block ownership is exclusive, so the read-modify-write needs no atomics.  A thread owns ZT voxels
 // of one (x, y) column of the block (z = zg*ZT .. zg*ZT + ZT-1), a wave owns ZT z-slices, a workgroup of 8/ZT waves owns
 // the block.  What that buys, per voxel and frame:
 //   * everything that is uniform over the wave -- the frame's bit test, the three s_load_dwordx4 of its pose rows, the buffer
 //     resource of its packed image, the loop control -- is paid once per ZT voxels instead of once per voxel (a third of the
-//     issue slots of the one-voxel-per-thread kernel go to scalar and branch instructions, profiles/r03_issue_costs.json);
+//     issue slots of a one-voxel-per-thread kernel go to scalar and branch instructions, profiles/r03_issue_costs.json);
 //   * the partial sums M[r][0]*px + M[r][1]*py of the three pose rows depend on x and y only and are shared by the ZT voxels
 //     (the same two rounded products and one rounded sum the reference forms for each of them: bit-identical);
 //   * ZT independent dependency chains per thread hide the VALU and gather latencies that eight waves per SIMD hid before,
@@ -820,7 +646,7 @@ template <bool PLAIN>
 __device__ __forceinline__ void voxel_update(float& s, float& w, float& c0, float& c1, float& c2, float new_sdf, unsigned rgba, const float* s_c255) {
     const float n0 = s_c255[rgba & 0xffu], n1 = s_c255[(rgba >> 8) & 0xffu], n2 = s_c255[(rgba >> 16) & 0xffu];
     if (PLAIN) {
-        // TSDFVoxel::IsValid (TSDFVoxel.h:75-78) false -> weight 0 in the same formula (see k_integrate's header comment)
+        // TSDFVoxel::IsValid (TSDFVoxel.h:75-78) false -> weight 0 in the same formula (see the PLAIN comment above)
         const float wv = (s >= 1 || w <= 0) ? 0.0f : w;
         const float wsum = wv + 1.0f;
         float y = __builtin_amdgcn_rcpf(wsum);
@@ -851,7 +677,7 @@ __device__ __forceinline__ void voxel_update(float& s, float& w, float& c0, floa
 }
 
 template <bool FAST, bool PLAIN, int ZT>
-__global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate_col(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
+__global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                                             int n_frames, unsigned long long* __restrict__ upd_partial,
                                                                             unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial) {
     constexpr int kWaves = 8 / ZT;            // waves per workgroup = z-groups per block
@@ -959,17 +785,18 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate_col(Ba
         slot ^= 1u;
         j = s_next[slot];
     }
-    // per-workgroup counters (each workgroup owns its slot: no atomics)
+    // per-workgroup counters into kPartialGrid slots
     upd = wave_sum(upd); chg = wave_sum(chg);
     if (lane == 0) { s_cnt[zg][0] = upd; s_cnt[zg][1] = chg; }
     __syncthreads();
     if (tid == 0) {
         unsigned t = 0, c = 0;
         for (int k = 0; k < kWaves; ++k) { t += s_cnt[k][0]; c += s_cnt[k][1]; }
-        upd_partial[blockIdx.x] += t;
-        sel_partial[blockIdx.x] += sel;
-        chg_partial[blockIdx.x] += c;
-        chg_partial[kPartialGrid + blockIdx.x] += nblk;
+        const unsigned slot_c = blockIdx.x % (unsigned)kPartialGrid;
+        atomicAdd(&upd_partial[slot_c], (unsigned long long)t);
+        atomicAdd(&sel_partial[slot_c], (unsigned long long)sel);
+        atomicAdd(&chg_partial[slot_c], (unsigned long long)c);
+        atomicAdd(&chg_partial[kPartialGrid + slot_c], (unsigned long long)nblk);
         if (blockIdx.x == 0) { st->stat_frames += (unsigned long long)n_frames; st->stat_launches += 1ull; }
         atomicMax(&st->kc_t[blockIdx.x & 7u], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
     }
@@ -1492,6 +1319,7 @@ struct op_volume {
     bool plain = true;
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
     size_t unpack_n = 0;
+    uint64_t n_grows = 0, n_replayed = 0; // pool growths and batches launched again after one (op_volume_growth_stats)
     bool grow_refused = false;   // an early growth could not get memory: stop asking before every batch (a real overflow still tries)
     // frames accepted by op_volume_integrate but not launched yet: single-frame calls are queued
     // and fused in batches of kMaxBatch (every accessor flushes first, so this is unobservable)
@@ -1573,6 +1401,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     v->pool = pool; v->keys = keys; v->blist = blist; v->sel_list = sel_list; v->sel_cand = sel_cand;
     v->tkeys = tkeys; v->tvals = tvals; v->bmask = bmask;
     v->max_blocks = new_max; v->table_size = new_table;
+    ++v->n_grows;
     return OP_OK;
 }
 
@@ -1638,6 +1467,7 @@ int vol_recover(op_volume* v, unsigned* flags_out) {
         int rrc = OP_OK;
         for (auto& r : replay) {
             rrc = vol_enqueue_batch(v, r.F, r.I, r.P, r.nf, r.fmt, false, false); // assigns a new sequence number
+            ++v->n_replayed;
             if (rrc != OP_OK) break;
             if (r.ring_slot >= 0) v->ring[r.ring_slot].busy_seq = v->seq;
             v->log.back().ring_slot = r.ring_slot;
@@ -1782,13 +1612,8 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (select_only)
         hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, v->state);
     else {
-#if KC_ZT
-#define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate_col<FASTPX, PLAINV, KC_ZT>), dim3(kColGrid), dim3(512 / KC_ZT), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
+#define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, KC_ZT>), dim3(kColGrid), dim3(512 / KC_ZT), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
                                                  v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial)
-#else
-#define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV>), dim3(kIntegrateGrid), dim3(512), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
-                                                 v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial)
-#endif
         if (C.fast_px) { if (v->plain) OP_KC(true, true); else OP_KC(true, false); }
         else { if (v->plain) OP_KC(false, true); else OP_KC(false, false); }
 #undef OP_KC
@@ -2440,6 +2265,14 @@ int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_
     if (launches) *launches = st.stat_launches;
     if (blocks_read) *blocks_read = blk;
     if (voxels_written) *voxels_written = chg;
+    return OP_OK;
+}
+
+int op_volume_growth_stats(op_volume* v, uint64_t* max_blocks, uint64_t* grows, uint64_t* replayed_batches) {
+    OP_VOL(v);
+    if (max_blocks) *max_blocks = v->max_blocks;
+    if (grows) *grows = v->n_grows;
+    if (replayed_batches) *replayed_batches = v->n_replayed;
     return OP_OK;
 }
 

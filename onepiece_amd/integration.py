@@ -203,6 +203,12 @@ class CubeHandler:
         return {"frames": f.value, "blocks_selected": b.value, "voxels_visited": vis.value, "voxels_updated": upd.value,
                 "launches": ln.value, "blocks_read": br.value, "voxels_written": vw.value, "integrate_shader_cycles": sc.value}
 
+    def GrowthStats(self):
+        """capacity in blocks, pool growths, batches launched again after a growth (no synchronisation)"""
+        m, g, r = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib.op_volume_growth_stats(self._h, C.byref(m), C.byref(g), C.byref(r)))
+        return {"max_blocks": m.value, "grows": g.value, "replayed_batches": r.value}
+
     def ProfileEnable(self, sample_every=1):
         """HIP-event timing of K1/K2/K3 on the volume's own stream (measurement hook)."""
         L.check(self._lib.op_volume_profile_enable(self._h, int(sample_every)))
