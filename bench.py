@@ -299,7 +299,51 @@ def main():
         out["host_images_frames_per_s"] = rates["float32_depth"]
         out["host_images"] = {"frames": nh, "float32_depth_frames_per_s": rates["float32_depth"], "uint16_depth_frames_per_s": rates["uint16_depth"],
                               "call_pattern": "one IntegrateImage(depth, rgb, pose) per frame, pageable numpy buffers, Python loop; pinned staging ring + copy stream"}
+        # (a) the same loop from C++ (tools/prof_driver.bin host): no interpreter between the calls -- the reference's actual call pattern
+        try:
+            import subprocess, tempfile, re as _re
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import counters as CT
+            CT.build_driver()
+            with tempfile.NamedTemporaryFile(prefix="opc_host_", suffix=".bin", dir="/tmp", delete=False) as tf:
+                np.array([nh, W, H], np.int32).tofile(tf)
+                for i in range(nh):
+                    poses[i].astype(np.float32).tofile(tf); dn[i].tofile(tf); cn[i].tofile(tf)
+                hname = tf.name
+            try:
+                txt = subprocess.run([CT.DRIVER, hname, "3", repr(float(args.voxel)), "host"], capture_output=True, text=True, timeout=300).stdout
+            finally:
+                os.unlink(hname)
+            best_cpp = {}
+            for m in _re.finditer(r"host images, (float32|uint16) depth: \d+ frames, ([\d.]+) frames/s", txt):
+                best_cpp[m.group(1)] = max(best_cpp.get(m.group(1), 0.0), float(m.group(2)))
+            out["host_images"]["cpp_float32_depth_frames_per_s"] = best_cpp.get("float32")
+            out["host_images"]["cpp_uint16_depth_frames_per_s"] = best_cpp.get("uint16")
+            out["host_images"]["cpp_driver"] = "tools/prof_driver.bin <frames> 3 <voxel> host: one op_volume_integrate per frame from C++ with pageable images, best of 3"
+        except Exception as e:
+            out["host_images"]["cpp_error"] = repr(e)[:200]
         del dn, cn, d16h
+
+    # ---- fusing into a volume that was NOT written by the integrate kernel alone (after SetCubeMap / ReadFromFile / Merge -- the reference's
+    # MergeMultipleSubmaps / FBAFusion pattern): the update then takes the general form (two branches, four true divisions per voxel)
+    if rank == 0 and world == 1 and not args.timed_only:
+        ng = min(400, n_local)
+        rates = {}
+        for name in ("plain", "after_upload"):
+            hv.Clear()
+            hv.IntegrateSequence(depth[:20], rgb[:20], poses[:20])
+            if name == "after_upload":
+                k_, v_ = hv.GetCubeMap(sort=False)
+                hv.SetCubeMap(k_, v_)                       # same content, but now "foreign" data: k_integrate<., PLAIN=false>
+                del k_, v_
+            hv.Synchronize()
+            t = time.perf_counter()
+            hv.IntegrateSequence(depth[20:ng], rgb[20:ng], poses[20:ng])
+            hv.Synchronize()
+            rates[name] = (ng - 20) / (time.perf_counter() - t)
+        out["general_update_path"] = {"frames": ng - 20, "plain_frames_per_s": rates["plain"], "after_upload_frames_per_s": rates["after_upload"],
+                                      "note": "frames/s of IntegrateSequence into a volume holding 20 fused frames: as fused (shared-reciprocal update) vs after the "
+                                              "same content went through GetCubeMap / SetCubeMap (general update with IEEE divisions; results identical)"}
 
     # ---- the same K steps behind the drivers' depth front end (tool::ConvertDepthTo32F + tool::BilateralFilter,
     # ImageSequenceIntegration.cpp:36-38) from raw 16-bit depth, filter enqueued on the volume's stream.  Supplementary:
@@ -387,6 +431,15 @@ def main():
         t = time.perf_counter()
         L.check(lib.op_icp_run(h, 1, fp(T0), iters, C.byref(res64), None, 0, None, None))
         loop_it_s = iters / (time.perf_counter() - t)
+        # the price of exactness: the validation mode that sums every iteration's rows in the reference's sequential float32 order on the
+        # host (identical per-iteration inlier counts and pairs at this size, tests/test_icp_gpu.py)
+        L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_FINISH, L.OP_ICP_FINISH_REFERENCE))
+        L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_SUMS, L.OP_ICP_SUMS_REFERENCE_F32))
+        res_ref = L.IcpResult()
+        it_ref = 20
+        t = time.perf_counter()
+        L.check(lib.op_icp_run(h, 1, fp(T0), it_ref, C.byref(res_ref), None, 0, None, None))
+        ref_it_s = it_ref / (time.perf_counter() - t)
         lib.op_icp_destroy(h)
         # what a caller of registration::PointToPlane pays: the one-shot entry point builds the search grid, uploads both
         # clouds, runs ICPTest's 30 iterations, forms the reference-order result and drops everything again
@@ -397,7 +450,7 @@ def main():
             L.check(lib.op_icp_register(1, fp(src.reshape(-1)), len(src), fp(tgt.reshape(-1)), fp(nrm.reshape(-1)), len(tgt), fp(T0), 30, 0.01, local_rank,
                                         C.byref(r1), None, 0))
             reg_ms.append((time.perf_counter() - t) * 1e3)
-        out["icp"] = {"iters_per_s": gpu_it_s, "loop_only_iters_per_s": loop_it_s, "iterations_per_call": iters, "points": int(len(src)),
+        out["icp"] = {"iters_per_s": gpu_it_s, "loop_only_iters_per_s": loop_it_s, "reference_order_sums_iters_per_s": ref_it_s, "iterations_per_call": iters, "points": int(len(src)),
                       "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31)",
                       "final_inliers": int(res.n_inliers), "estimate_normals_s": normals_s,
                       "register_call_ms": float(np.median(reg_ms[1:])), "register_call_iterations": 30,
@@ -483,7 +536,15 @@ def main():
         for _ in range(n_tr):
             run()
         tr_s = n_tr / (time.perf_counter() - t)
-        out["tracking"] = {"tracks_per_s": tr_s, "ms_per_track": 1e3 / tr_s, "from_raw_frames_tracks_per_s": full_s, "levels": 3, "iters_per_level": [4, 8, 16],
+        odo.SetSums("reference_f32")       # validation mode: rows of every iteration summed sequentially in float32 on the host
+        for _ in range(2):
+            run()
+        t = time.perf_counter()
+        for _ in range(20):
+            run()
+        tr_ref_s = 20 / (time.perf_counter() - t)
+        odo.SetSums("fp64")
+        out["tracking"] = {"tracks_per_s": tr_s, "ms_per_track": 1e3 / tr_s, "reference_order_tracks_per_s": tr_ref_s, "from_raw_frames_tracks_per_s": full_s, "levels": 3, "iters_per_level": [4, 8, 16],
                            "iterations_executed": int(tres.iterations), "term": "hybrid", "resolution": [W, H],
                            "correspondences": int(tres.n_correspondences), "tracking_success": bool(tres.tracking_success),
                            "input": "pyramids resident in HBM (boundary = Odometry::MultiScaleComputing inputs)"}
@@ -527,22 +588,41 @@ def main():
         _s1, _nb1, dt_seq = dense_fusion_pass(1)
         slam, nb, dt = dense_fusion_pass(4)
         if world == 1 and not args.no_cpu_baseline:
-            # the same pipeline on one host core (the reference's tracker and integrator are serial): 4 frames
+            # the same pipeline on one host core (the reference's tracker and integrator are serial): 4 frames fused, then tracking alone
+            # over a 24-frame prefix for the pose-chain parity
             from oracle import oracle as O
             ocam = O.make_camera()
             ovol = O.Volume(ocam, voxel_res=0.005)
-            hd, hc = depth[:4].cpu().numpy(), rgb[:4].cpu().numpy()
+            n_par = min(24, n_df)
+            hd, hc = depth[:n_par].cpu().numpy(), rgb[:n_par].cpu().numpy()
             t0 = time.perf_counter()
             gp = np.eye(4, dtype=np.float32)
             ovol.integrate(hd[0], hc[0], gp)
+            ref_chain = [gp]
             for i in range(1, 4):
                 r = O.dense_tracking(ocam, hc[i - 1], hc[i], hd[i - 1], hd[i], (4, 8, 16), 0)
                 gp = DS._mat4_mul_f32(gp, O.mat4_inverse(r["T"]))
+                ref_chain.append(gp)
                 ovol.integrate(hd[i], hc[i], gp)
             out["cpu_baseline"]["dense_fusion_frames_per_s"] = 4 / (time.perf_counter() - t0)
-            # pose chain parity on those frames (per-pair bar as in tests/test_odometry_gpu.py)
-            out["dense_fusion_parity_pose3_rel_err_vs_cpu"] = float(np.linalg.norm(np.asarray(slam.global_poses[3], np.float64) - gp) /
-                                                                    np.linalg.norm(gp.astype(np.float64)))
+            for i in range(4, n_par):
+                r = O.dense_tracking(ocam, hc[i - 1], hc[i], hd[i - 1], hd[i], (4, 8, 16), 0)
+                ref_chain.append(DS._mat4_mul_f32(ref_chain[-1], O.mat4_inverse(r["T"])))
+            rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+            pair = lambda chain, i: np.linalg.inv(np.asarray(chain[i - 1], np.float64)) @ np.asarray(chain[i], np.float64)
+            g0p = np.linalg.inv(poses[0].astype(np.float64))
+            drift_of = lambda chain: [float(np.abs(np.asarray(chain[i], np.float64) - g0p @ poses[i].astype(np.float64))[:3, 3].max()) for i in range(n_par)]
+            par = {"frames": n_par, "oracle_chain_max_translation_drift_m": max(drift_of(ref_chain))}
+            for mode_name in ("fp64", "reference_f32"):
+                chk = DS.DenseSlam(hv.camera, device=local_rank)
+                chk.rgbd_odometry.SetSums(mode_name)
+                for i in range(n_par):
+                    chk.UpdateFrame(rgb[i], depth[i])
+                pe = [rel(pair(chk.global_poses, i), pair(ref_chain, i)) for i in range(1, n_par)]
+                ce = [rel(chk.global_poses[i], ref_chain[i]) for i in range(n_par)]
+                par[mode_name] = {"pair_rel_err_max": max(pe), "pair_rel_err_median": float(np.median(pe)), "pairs_within_1e-4": int(sum(e <= 1e-4 for e in pe)),
+                                  "pairs": len(pe), "chain_rel_err_max": max(ce), "max_translation_drift_m": max(drift_of(chk.global_poses))}
+            out["dense_fusion_parity"] = par
         g0 = np.linalg.inv(poses[0].astype(np.float64))
         drift = max(float(np.abs(np.asarray(slam.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max())
                     for i in range(n_df))

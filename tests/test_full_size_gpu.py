@@ -81,7 +81,8 @@ def test_config4_tracked_pose_chain_60_frames(oracle, torch_dev):
     """example/DenseFusion's tracking over 60 consecutive 640x480 frames: every pose of the GPU chain against the CPU
     oracle's chain.  Stated tolerances (measured: tests/tools/measure_chain.py): the reference sums
     JTJ/JTr sequentially in float32 and its own result moves by up to 2e-4 per pair when it sums in double instead; the
-    HIP path reduces in fp64.  Per pair: <= 1e-3 always, <= 1e-4 (north_star's bar) on at least 85 % of the pairs;
+    HIP path reduces in fp64.  Per pair: <= 5e-4 always (measured worst 4.5e-4), <= 1e-4 (north_star's bar) on at least 90 % of
+    the pairs (measured 55 of 59) -- the bars sit at what was measured, so that a regression of the default mode shows;
     chained pose i: <= 3e-3; the drift of the GPU chain from the ground-truth trajectory stays within 5 mm of the
     drift of the oracle's own chain at every frame (both are printed)."""
     import torch
@@ -94,8 +95,8 @@ def test_config4_tracked_pose_chain_60_frames(oracle, torch_dev):
           " drift vs ground truth: gpu max %.4f m final %.4f m | oracle max %.4f m final %.4f m"
           % (n, pair_err.max(), np.median(pair_err), (pair_err <= 1e-4).sum(), len(pair_err), chain_err.max(), dg.max(), dg[-1], dr.max(), dr[-1]))
     assert all(slam.tracking_success) and slam.last_tracking_frame_id == n - 1
-    assert pair_err.max() <= 1e-3
-    assert (pair_err <= 1e-4).mean() >= 0.85
+    assert pair_err.max() <= 5e-4
+    assert (pair_err <= 1e-4).mean() >= 0.90
     assert chain_err.max() <= 3e-3
     assert np.abs(dg - dr).max() <= 0.005
 
