@@ -140,8 +140,12 @@ def main():
     stats = hv.Stats()  # per-rank counters, read before the merge rewrites the root volume
     growth = hv.GrowthStats()
     n_union = None
+    local_blocks = hv.BlockCount()
+    t_m0 = time.perf_counter()
     if world > 1 or force_dist:
         n_union = D.merge_volumes(ops, root=0)
+        hv.Synchronize(); torch.cuda.synchronize()
+    t_merge = time.perf_counter() - t_m0
     barrier()
     dt = time.perf_counter() - t0
     prof = hv.ProfileRead()
@@ -152,6 +156,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max, t_fuse_max = float(tmax[0]), float(tmax[1])
     total_frames = n_local * world
+    # what every rank did, so that a 1 -> 8 GPU curve decomposes into fusion and merge (gathered outside the timed region)
+    mine = {"rank": rank, "frames": n_local, "fusion_ms": t_fuse * 1e3, "merge_ms": t_merge * 1e3, "local_blocks": int(local_blocks)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     out = None
     if rank == 0:
@@ -185,6 +195,12 @@ def main():
             "fusion_only_frames_per_s": total_frames / t_fuse_max,
             "pool": growth,   # the pool starts at 2^18 blocks and grows on demand INSIDE the timed region (grows / replayed batches since create)
             "merge_union_blocks": n_union,
+            "multi_gpu": {"ranks_in_process_group": (dist.get_world_size() if (world > 1 or force_dist) else 1),
+                          "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
+                          "merge_bytes_per_rank": (int(n_union) * 10240 if n_union else 0), "merge_slices": (-(-int(n_union) // 32768) if n_union else 0),
+                          "per_rank": per_rank,
+                          "note": "weak scaling: every rank fuses its own frames without communication (fusion_ms), then ONE merge: all_gather of the block keys, "
+                                  "sum-form pack, sliced reduce(SUM) to rank 0 over RCCL, normalisation (merge_ms, inside the timed region)"},
             "per_frame": {"blocks_selected": stats["blocks_selected"] / max(stats["frames"], 1),
                           "voxels_visited": stats["voxels_visited"] / max(stats["frames"], 1),
                           "voxels_updated": n_upd_frame, "final_blocks_rank0": hv.BlockCount()},

@@ -53,6 +53,8 @@ int main(int argc, char* argv[]) {
     std::vector<op_volume*> vols(gpus, nullptr);
     std::vector<int> status(gpus, 0);
     std::vector<size_t> local_blocks(gpus, 0);
+    std::vector<op_merge_stats> mstats(gpus);
+    std::vector<double> fuse_ms(gpus, 0.0);
     size_t n_union = 0;
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> workers;
@@ -70,8 +72,11 @@ int main(int argc, char* argv[]) {
                 rc = op_volume_integrate(vols[g], refined.data, OP_DEPTH_F32, rgb.data, OP_MEM_HOST, p, nullptr);
             }
             if (rc == OP_OK) rc = op_volume_block_count(vols[g], &local_blocks[g]);
+            fuse_ms[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             size_t merged = 0;
-            if (rc == OP_OK) rc = op_volume_merge_rccl(vols[g], comms[g], 0, &merged);
+            // every rank calls the merge, also one whose fusion failed: it announces the failure there and all ranks leave together
+            const int mrc = op_volume_merge_rccl_stats(vols[g], comms[g], 0, &merged, &mstats[g]);
+            if (rc == OP_OK) rc = mrc;
             if (g == 0) n_union = merged;
             status[g] = rc;
         });
@@ -84,7 +89,12 @@ int main(int argc, char* argv[]) {
     if (!bad) op_volume_block_count(vols[0], &final_blocks);
     if (!bad && !map_file.empty()) op_volume_write_file(vols[0], map_file.c_str());
     std::cout << "{\"gpus\": " << gpus << ", \"frames\": " << poses.size() << ", \"seconds\": " << seconds << ", \"union_blocks\": " << n_union
-              << ", \"root_blocks\": " << final_blocks << ", \"rank0_local_blocks\": " << local_blocks[0] << ", \"ok\": " << (bad ? "false" : "true") << "}" << std::endl;
+              << ", \"root_blocks\": " << final_blocks << ", \"rank0_local_blocks\": " << local_blocks[0] << ", \"per_rank\": [";
+    for (int g = 0; g < gpus; ++g)
+        std::cout << (g ? ", " : "") << "{\"rank\": " << mstats[g].rank << ", \"rccl_ranks\": " << mstats[g].ranks << ", \"local_blocks\": " << local_blocks[g]
+                  << ", \"fusion_ms\": " << fuse_ms[g] << ", \"merge_ms\": " << mstats[g].total_ms << ", \"merge_prepare_ms\": " << mstats[g].prepare_ms
+                  << ", \"merge_transfer_ms\": " << mstats[g].transfer_ms << ", \"merge_bytes\": " << mstats[g].reduce_bytes << ", \"slices\": " << mstats[g].slices << "}";
+    std::cout << "], \"ok\": " << (bad ? "false" : "true") << "}" << std::endl;
     for (int g = 0; g < gpus; ++g) { if (vols[g]) op_volume_destroy(vols[g]); ncclCommDestroy(comms[g]); }
     return bad;
 }

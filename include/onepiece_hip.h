@@ -250,6 +250,15 @@ int op_volume_unpack_sum_chunk(op_volume *v, size_t first, size_t count, const f
  * are left untouched.  *n_union (may be NULL) = number of blocks in the merged volume.  RCCL is bound at run time
  * (dlopen), so the library does not need it until this entry point is used. */
 int op_volume_merge_rccl(op_volume *v, void *nccl_comm, int root, size_t *n_union);
+/* The same call, reporting how the time was spent (for the N > 1 bench line): ranks / rank of the communicator, blocks
+ * in the union, bytes this rank put into the reduce, the number of reduce slices, host wall time of the preparation
+ * (all-gathers, union), of the pack / reduce / normalise pipeline, and of the whole call, in milliseconds. */
+typedef struct op_merge_stats {
+    int32_t ranks, rank;
+    uint64_t union_blocks, reduce_bytes, slices;
+    double prepare_ms, transfer_ms, total_ms;
+} op_merge_stats;
+int op_volume_merge_rccl_stats(op_volume *v, void *nccl_comm, int root, size_t *n_union, op_merge_stats *stats);
 
 /* ---- registration (Registration/ICP.h:13-26, RegistrationResult.h:9-16) ------------------- */
 typedef struct {

@@ -26,6 +26,12 @@ class Camera(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("depth_scale", C.c_float)]
 
 
+class MergeStats(C.Structure):
+    """op_merge_stats of op_volume_merge_rccl_stats."""
+    _fields_ = [("ranks", C.c_int32), ("rank", C.c_int32), ("union_blocks", C.c_uint64), ("reduce_bytes", C.c_uint64), ("slices", C.c_uint64),
+                ("prepare_ms", C.c_double), ("transfer_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 class IcpResult(C.Structure):
     _fields_ = [("T", C.c_float * 16), ("last_T", C.c_float * 16), ("rmse", C.c_double),
                 ("n_inliers", C.c_uint64), ("iterations", C.c_int32)]
@@ -117,6 +123,7 @@ SIGNATURES = {
     "op_volume_unpack_sum_begin": (C.c_int, [_vp, _vp, C.c_size_t]),
     "op_volume_unpack_sum_chunk": (C.c_int, [_vp, C.c_size_t, C.c_size_t, _vp]),
     "op_volume_merge_rccl": (C.c_int, [_vp, _vp, C.c_int, _szp]),
+    "op_volume_merge_rccl_stats": (C.c_int, [_vp, _vp, C.c_int, _szp, _vp]),
     "op_icp_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]),
     "op_icp_destroy": (C.c_int, [_vp]),
     "op_icp_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),

@@ -1319,6 +1319,7 @@ struct op_volume {
     bool plain = true;
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
     size_t unpack_n = 0;
+    uint64_t generation = 0, unpack_gen = 0; // bumped by whatever moves or drops table slots (growth, clear) or fuses frames; _chunk checks it
     uint64_t n_grows = 0, n_replayed = 0; // pool growths and batches launched again after one (op_volume_growth_stats)
     bool grow_refused = false;   // an early growth could not get memory: stop asking before every batch (a real overflow still tries)
     // frames accepted by op_volume_integrate but not launched yet: single-frame calls are queued
@@ -1342,6 +1343,7 @@ namespace {
 int vol_flush(op_volume* v); // launches the frames queued by op_volume_integrate
 
 int vol_reset(op_volume* v) {
+    ++v->generation;
     hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, v->tkeys, v->tvals, (size_t)v->table_size);
     OP_HIP(hipMemsetAsync(v->n_blocks, 0, sizeof(unsigned), v->stream));
     OP_HIP(hipMemsetAsync(v->bmask, 0, sizeof(unsigned) * (size_t)v->table_size, v->stream));
@@ -1401,7 +1403,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     v->pool = pool; v->keys = keys; v->blist = blist; v->sel_list = sel_list; v->sel_cand = sel_cand;
     v->tkeys = tkeys; v->tvals = tvals; v->bmask = bmask;
     v->max_blocks = new_max; v->table_size = new_table;
-    ++v->n_grows;
+    ++v->n_grows; ++v->generation;
     return OP_OK;
 }
 
@@ -1585,6 +1587,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         v->hstat[1] = n;
     }
     const unsigned seq = (unsigned)(++v->seq);
+    ++v->generation;
     if (!select_only && !cube_keys) v->log.push_back(op_volume::BatchRec{v->seq, F, I, Q, nf, depth_fmt, -1});
     const CamParams C = cam_params(v, depth_fmt);
     const int npix = C.width * C.height;
@@ -2463,7 +2466,9 @@ int op_volume_unpack_sum_begin(op_volume* v, const int32_t* d_union_keys, size_t
     OP_HIP(op::cached_malloc((void**)&v->unpack_slots, n_union * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, v->unpack_slots, v->state);
     OP_HIP(hipGetLastError());
-    return vol_check(v);
+    OP_TRY(vol_check(v));
+    v->unpack_gen = v->generation;
+    return OP_OK;
 }
 
 int op_volume_unpack_sum_chunk(op_volume* v, size_t first, size_t count, const float* d_sum_chunk) {
@@ -2471,6 +2476,8 @@ int op_volume_unpack_sum_chunk(op_volume* v, size_t first, size_t count, const f
     if (count == 0) return OP_OK;
     if (!d_sum_chunk) return fail(OP_ERR_INVALID, "null argument");
     if (!v->unpack_slots || first + count > v->unpack_n) return fail(OP_ERR_INVALID, "op_volume_unpack_sum_chunk: range outside the union given to _begin");
+    if (v->unpack_gen != v->generation) // growth re-hashes the table, clear drops it, fusion may do either: the slots of _begin are stale
+        return fail(OP_ERR_INVALID, "op_volume_unpack_sum_chunk: the volume was cleared, grown or fused into since op_volume_unpack_sum_begin");
     hipLaunchKernelGGL(k_unpack_sum, dim3((unsigned)count), dim3(512), 0, v->stream, v->pool, (const int*)(v->unpack_slots + first), (const int*)v->tvals, d_sum_chunk);
     OP_HIP(hipGetLastError());
     OP_HIP(hipStreamSynchronize(v->stream));

@@ -322,12 +322,16 @@ def test_cpp_multi_gpu_driver_runs_the_rccl_merge(hip, oracle, tmp_path):
     seq = str(tmp_path / "seq")
     decoded, poses = _write_sequence(seq, 6, cam, first=100, step=3)
     mp = str(tmp_path / "merged.map")
-    env = dict(os.environ, ONEPIECE_RCCL_FORCE="1")
+    env = dict(os.environ, ONEPIECE_RCCL_FORCE="1", ONEPIECE_MERGE_SLICE_BLOCKS="1500")   # several reduce slices on this small volume
     run = subprocess.run([os.path.join(EX, "MultiGpuSequenceIntegration.bin"), seq, "--gpus", str(gpus), "--voxel", "0.01", "--map", mp],
                          capture_output=True, text=True, env=env)
     assert run.returncode == 0, run.stdout + run.stderr
     r = json.loads(run.stdout.strip().splitlines()[-1])
     assert r["ok"] is True and r["gpus"] == gpus
+    # what the call reports per rank: the communicator's size, the sliced reduce, where the time went
+    assert [p["rank"] for p in r["per_rank"]] == list(range(gpus)) and all(p["rccl_ranks"] == gpus for p in r["per_rank"])
+    assert all(p["slices"] == -(-r["union_blocks"] // 1500) >= 2 and p["merge_bytes"] == r["union_blocks"] * 10240 for p in r["per_rank"])
+    assert all(0 < p["merge_prepare_ms"] < p["merge_ms"] and 0 < p["merge_transfer_ms"] < p["merge_ms"] for p in r["per_rank"])
     # the oracle: per-shard volumes merged sequentially into shard 0's (CubeHandler::Merge)
     ocam = oracle.make_camera()
     shards = []

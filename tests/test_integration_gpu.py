@@ -308,6 +308,9 @@ def test_bench_distributed_path_over_rccl_with_one_rank(tmp_path):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 1 and r["value"] > 0
     assert r["merge_union_blocks"] == r["per_frame"]["final_blocks_rank0"] > 32768     # more than one slice went through the reduce
+    mg = r["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["ranks_in_process_group"] == 1 and mg["merge_slices"] >= 2 and mg["merge_bytes_per_rank"] == r["merge_union_blocks"] * 10240
+    assert len(mg["per_rank"]) == 1 and mg["per_rank"][0]["frames"] == 80 and mg["per_rank"][0]["merge_ms"] > 0 and mg["per_rank"][0]["fusion_ms"] > 0
 
 
 def test_bench_strong_scaling_four_ranks_on_one_gpu(tmp_path):
@@ -325,6 +328,9 @@ def test_bench_strong_scaling_four_ranks_on_one_gpu(tmp_path):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 4 and r["scaling"] == "strong" and r["config"]["frames_per_gpu"] == 20
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] - 80) < 1e-6            # 2 x 40 frames in total
+    mg = r["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["ranks_in_process_group"] == 4 and [p["rank"] for p in mg["per_rank"]] == [0, 1, 2, 3]
+    assert all(p["frames"] == 20 and p["local_blocks"] > 0 for p in mg["per_rank"]) and r["merge_union_blocks"] >= max(p["local_blocks"] for p in mg["per_rank"])
     assert r["per_frame"]["final_blocks_rank0"] == r["merge_union_blocks"]
 
 
