@@ -45,6 +45,8 @@
 #include <thread>
 
 #include "common.hpp"
+
+#include <type_traits>
 #include "host_math.hpp"
 #include "px_round.hpp"
 
@@ -679,7 +681,8 @@ __device__ __forceinline__ void voxel_update(float& s, float& w, float& c0, floa
 template <bool FAST, bool PLAIN, int ZT>
 __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                                             int n_frames, unsigned long long* __restrict__ upd_partial,
-                                                                            unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial) {
+                                                                            unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial,
+                                                                            unsigned plain_from) {
     constexpr int kWaves = 8 / ZT;            // waves per workgroup = z-groups per block
     __shared__ unsigned s_cnt[kWaves][2];
     __shared__ float s_c255[256];             // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
@@ -742,7 +745,12 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
                     rec[z] = __builtin_amdgcn_raw_buffer_load_b64(frame, pix * 8, 0, 0);
                 }
             };
-            auto apply = [&](const kc_v2u (&rec)[ZT], const float (&zc)[ZT]) {
+            // PLAIN: every block of the volume was written by this kernel only.  Otherwise (the volume has seen an upload, a merge, a
+            // sum-form unpack or a file): the blocks that existed then (pool slots below plain_from) hold arbitrary data and take the
+            // general update; blocks allocated since are this kernel's own and keep the fast one.  Uniform per block.
+            const bool plain_block = PLAIN || (unsigned)idx >= plain_from;
+            auto apply = [&](const kc_v2u (&rec)[ZT], const float (&zc)[ZT], auto plain_c) {
+                constexpr bool kPlain = decltype(plain_c)::value;
 #pragma unroll
                 for (int z = 0; z < ZT; ++z) {
                     const float d = __uint_as_float(rec[z].x); // off-image pixels carry d == 0 -> skipped like `continue`
@@ -754,27 +762,29 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
                     upd += hit ? 1u : 0u;                              // per lane; summed over the wave at the end
                     if (hit) {
                         changed |= 1u << z;
-                        voxel_update<PLAIN>(s[z], w[z], c0[z], c1[z], c2[z], new_sdf, rec[z].y, s_c255);
+                        voxel_update<kPlain>(s[z], w[z], c0[z], c1[z], c2[z], new_sdf, rec[z].y, s_c255);
                     }
                 }
             };
             kc_v2u recA[ZT], recB[ZT];
             float zcA[ZT], zcB[ZT];
-            unsigned m = mask;                                    // wave-uniform
-            if (m) {
+            auto frames = [&](auto plain_c) {
+                unsigned m = mask;                                // wave-uniform
+                if (!m) return;
                 int f = __builtin_ctz(m); m &= m - 1u;
                 project(f, recA, zcA);
                 for (;;) {
                     const bool more1 = m != 0u;
                     if (more1) { f = __builtin_ctz(m); m &= m - 1u; project(f, recB, zcB); }
-                    apply(recA, zcA);
+                    apply(recA, zcA, plain_c);
                     if (!more1) break;
                     const bool more2 = m != 0u;
                     if (more2) { f = __builtin_ctz(m); m &= m - 1u; project(f, recA, zcA); }
-                    apply(recB, zcB);
+                    apply(recB, zcB, plain_c);
                     if (!more2) break;
                 }
-            }
+            };
+            if (PLAIN || plain_block) frames(std::true_type{}); else frames(std::false_type{});
 #pragma unroll
             for (int z = 0; z < ZT; ++z)
                 if ((changed >> z) & 1u) { vox[z * 64] = s[z]; vox[kVox + z * 64] = w[z]; vox[2 * kVox + z * 64] = c0[z]; vox[3 * kVox + z * 64] = c1[z]; vox[4 * kVox + z * 64] = c2[z]; }
@@ -1317,6 +1327,7 @@ struct op_volume {
     // true while every voxel was written by k_integrate only since create / clear (see k_integrate<., PLAIN>): any other
     // writer (upload, merge, sum-form unpack, resampling result, file) clears it and fusion takes the general update
     bool plain = true;
+    unsigned plain_from = 0;     // with !plain: pool slots below this bound may hold foreign data (general update); later blocks are k_integrate's own
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
     size_t unpack_n = 0;
     uint64_t generation = 0, unpack_gen = 0; // bumped by whatever moves or drops table slots (growth, clear) or fuses frames; _chunk checks it
@@ -1341,6 +1352,13 @@ struct op_volume {
 namespace {
 
 int vol_flush(op_volume* v); // launches the frames queued by op_volume_integrate
+
+// Every block with a pool slot below `bound` may hold data k_integrate did not write (see its PLAIN comment).
+void vol_mark_foreign(op_volume* v, unsigned long long bound) {
+    v->plain = false;
+    const unsigned b = bound > 0xffffffffull ? 0xffffffffu : (unsigned)bound;
+    if (b > v->plain_from) v->plain_from = b;
+}
 
 int vol_reset(op_volume* v) {
     ++v->generation;
@@ -1616,7 +1634,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, v->state);
     else {
 #define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, KC_ZT>), dim3(kColGrid), dim3(512 / KC_ZT), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
-                                                 v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial)
+                                                 v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial, v->plain_from)
         if (C.fast_px) { if (v->plain) OP_KC(true, true); else OP_KC(true, false); }
         else { if (v->plain) OP_KC(false, true); else OP_KC(false, false); }
 #undef OP_KC
@@ -2044,7 +2062,7 @@ int op_volume_clear(op_volume* v) {
     if (v->copy_stream) OP_HIP(hipStreamSynchronize(v->copy_stream));
     OP_HIP(hipStreamSynchronize(v->stream));
     v->log.clear(); // whatever was in flight (fused or poisoned) is wiped with the volume
-    v->plain = true;
+    v->plain = true; v->plain_from = 0;
     for (auto& r : v->ring) r.busy_seq = 0;
     if (v->hstat) v->hstat[1] = 0;
     OP_HIP(hipMemcpy(&n, v->n_blocks, sizeof(n), hipMemcpyDeviceToHost));
@@ -2371,7 +2389,7 @@ int op_volume_upload(op_volume* v, const int32_t* keys_xyz, const float* voxels_
         OP_TRY(vol_block_count(v, &nb));
         OP_TRY(vol_reserve(v, (unsigned long long)nb + uniq.size()));
     }
-    v->plain = false; // caller-supplied voxel data from here on
+    { unsigned nb = 0; OP_TRY(vol_block_count(v, &nb)); vol_mark_foreign(v, (unsigned long long)nb + uniq.size()); } // caller-supplied voxel data in every block that exists after this call
     const size_t chunk = 8192;
     int *d_keys = nullptr, *d_slots = nullptr;
     float* d_vox = nullptr;
@@ -2414,7 +2432,7 @@ int op_volume_merge(op_volume* dst, op_volume* src) {
     OP_TRY(vol_block_count(dst, &nd));
     if (!ns) return OP_OK;
     OP_TRY(vol_reserve(dst, (unsigned long long)nd + ns)); // worst case: no block in common
-    dst->plain = false; // merged means: general weights from here on
+    vol_mark_foreign(dst, (unsigned long long)nd + ns); // merged means: general weights in the blocks that exist after this call
     int* d_slots = nullptr;
     OP_HIP(op::cached_malloc((void**)&d_slots, (size_t)ns * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((ns + 255) / 256), dim3(256), 0, dst->stream, dst->view(), (const int*)src->keys, (size_t)ns, d_slots, dst->state);
@@ -2462,7 +2480,7 @@ int op_volume_unpack_sum_begin(op_volume* v, const int32_t* d_union_keys, size_t
     if (v->unpack_slots) { op::cached_free(v->unpack_slots); v->unpack_slots = nullptr; }
     v->unpack_n = n_union;
     if (n_union == 0) return OP_OK;
-    v->plain = false; // normalised sums of several ranks
+    vol_mark_foreign(v, n_union); // normalised sums of several ranks
     OP_HIP(op::cached_malloc((void**)&v->unpack_slots, n_union * sizeof(int)));
     hipLaunchKernelGGL(k_insert_keys, dim3((unsigned)((n_union + 255) / 256)), dim3(256), 0, v->stream, v->view(), (const int*)d_union_keys, n_union, v->unpack_slots, v->state);
     OP_HIP(hipGetLastError());
@@ -2502,7 +2520,7 @@ int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, i
     if (max_blocks == 0) max_blocks = std::max<uint64_t>(8ull * ns + 4096ull, 1ull << 14);
     op_volume* dst = nullptr;
     OP_TRY(op_volume_create(&src->cam, dst_res, src->trunc, src->far_d, src->near_d, src->device, max_blocks, &dst));
-    dst->plain = false; // resampled values (the reference's own divisions may even leave NaN / inf in them)
+    vol_mark_foreign(dst, max_blocks); // resampled values (the reference's own divisions may even leave NaN / inf in them); the bound is tightened below
     Mat4 M, Mi;
     std::memcpy(M.m, T, sizeof(M.m));
     if (T_inv) std::memcpy(Mi.m, T_inv, sizeof(Mi.m));
@@ -2524,6 +2542,7 @@ int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, i
         }
     }
     if (rc != OP_OK) { op_volume_destroy(dst); return rc; }
+    { unsigned nd = 0; if (vol_block_count(dst, &nd) == OP_OK) dst->plain_from = nd; } // exactly the resampled blocks
     *out = dst;
     return OP_OK;
 }

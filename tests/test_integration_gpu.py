@@ -617,3 +617,32 @@ def test_launch_level_counters(oracle):
     assert st["launches"] == 1 and st["frames"] == 3 and st["blocks_selected"] == sel and st["voxels_updated"] == upd
     assert st["blocks_read"] == len(keys) and st["voxels_written"] == int((vox[:, :, 1] > 0).sum())
     _compare(oracle, ov, hv)
+
+
+def test_fusion_after_upload_mixes_general_and_fast_updates_bit_exactly(oracle):
+    """After SetCubeMap the blocks that existed take the general update (the reference's two-branch form with true divisions), blocks
+    allocated later keep the shared-reciprocal one -- chosen per block inside one launch.  The uploaded blocks here carry data the fast
+    path may not see (fractional and huge weights, sdf exactly 1, denormal colours): the result equals the oracle's bit for bit."""
+    cam = (S.FX / 2, S.FY / 2, S.CX / 2, S.CY / 2, S.W // 2, S.H // 2, 1000.0)
+    ov, hv = _mk(oracle, 0.01, cam)
+    frames = []
+    for i in (0, 6, 12, 18, 24, 30):
+        pose = S.room_pose(i)
+        d, rgb = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+        frames.append((d, rgb, pose))
+    for d, rgb, pose in frames[:2]:
+        ov.integrate(d, rgb, pose); hv.IntegrateImage(d, rgb, pose)
+    keys, vox = hv.GetCubeMap()
+    rng = np.random.default_rng(7)
+    odd = vox.copy()
+    pick = rng.random(odd.shape[:2]) < 0.05
+    odd[..., 1][pick] = rng.choice(np.array([0.37, 2.5, 3.0e7, 1.0e-3], np.float32), pick.sum())
+    odd[..., 0][rng.random(odd.shape[:2]) < 0.01] = 1.0
+    odd[..., 2][rng.random(odd.shape[:2]) < 0.01] = 1e-41
+    hv.SetCubeMap(keys, odd)
+    ov.load(keys, odd)
+    n_before = hv.BlockCount()
+    for d, rgb, pose in frames[2:]:
+        ov.integrate(d, rgb, pose); hv.IntegrateImage(d, rgb, pose)
+    assert hv.BlockCount() > n_before + 200          # later frames allocate blocks of their own (fast update) next to the uploaded ones
+    _compare(oracle, ov, hv)
