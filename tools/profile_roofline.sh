@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun).  Everything the `roofline` object of bench.py cites, as small csv / txt files under
 # gpurun_out/$TAG/ (copy into profiles/ with the round prefix):
-#   valu_ubench.txt                issue cost per instruction class + s_memtime ticks per microsecond
+#   valu_ubench*.txt, issue_costs.json   issue cost per instruction class in shader cycles (s_memtime ticks)
 #   calib.*                        tools/hbm_calib.bin: known-traffic kernels under FETCH_SIZE / WRITE_SIZE / TCC_EA0 request counters
 #   batch1.*  / batch16.*          tools/prof_driver.bin with ONE frame per k_integrate launch / with full batches:
 #                                  --kernel-trace --stats durations, HBM counters, SQ instruction and cycle counters
@@ -28,9 +28,9 @@ pass() { # name, counters ("" = --stats), command...
 }
 rocprofv3-avail list 2>/dev/null | grep -i -E "TCC_EA0|FETCH|WRITE_SIZE|TCC_REQ|TCC_READ|TCC_WRITE|MALL|HBM" | head -80 > $OUT/avail_tcc.txt
 timeout 120 $R/tools/valu_ubench.bin > $OUT/valu_ubench.txt 2>&1
-# issue costs in GRBM_GUI_ACTIVE cycles: the microbenchmark at k_integrate's occupancy under the same counter (tools/issue_model.py)
-pass ubench "GRBM_GUI_ACTIVE GRBM_COUNT" $R/tools/valu_ubench.bin 2048 8
-python $R/tools/issue_model.py calibrate "$OUT/ubench.GRBM_GUI_ACTIVE_GRBM_COUNT.pmc.csv" 2048 8 $OUT/issue_costs.json > /dev/null
+# issue costs in shader cycles: the microbenchmark at k_integrate's occupancy, long enough for stable figures (tools/issue_model.py)
+timeout 300 $R/tools/valu_ubench.bin 4096 8 > $OUT/valu_ubench_iters4096.txt 2>&1
+python $R/tools/issue_model.py calibrate $OUT/valu_ubench_iters4096.txt $OUT/issue_costs.json > /dev/null
 if [ -z "$SKIP_CALIB" ]; then
 # ---- known-traffic calibration (1 repetition per kernel under the counters)
 timeout 120 $R/tools/hbm_calib.bin 4096 3 > $OUT/calib.timing.txt 2>&1
@@ -50,7 +50,9 @@ for C in "${SQ_GROUPS[@]}"; do
   pass batch1 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=1
   pass batch16 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=16
 done
-cat $OUT/*.log > $OUT/all_logs.txt 2>/dev/null; python $R/tools/issue_model.py model_pmc $OUT/issue_costs.json $OUT batch16 > $OUT/batch16.issue_model.json
-python $R/tools/issue_model.py model_pmc $OUT/issue_costs.json $OUT batch1 > $OUT/batch1.issue_model.json
+cat $OUT/*.log > $OUT/all_logs.txt 2>/dev/null; for B in batch1 batch16; do  # the launch's duration in shader cycles is printed by the driver (op_volume_stats_launches)
+  CYC=$(tail -1 $OUT/$B.driver.txt | sed 's/.* \([0-9]*\) shader cycles per launch.*/\1/')
+  python $R/tools/issue_model.py model_pmc $OUT/issue_costs.json $OUT $B $CYC > $OUT/$B.issue_model.json
+done
 rm -f $OUT/*.log
 ls $OUT | head -100
