@@ -264,3 +264,53 @@ def test_only_test_infrastructure_touches_the_oracle():
                 if f.endswith((".py", ".sh", ".cpp", ".hpp", ".h")):
                     text = open(os.path.join(dirpath, f), errors="replace").read()
                     assert not re.search(r"\b(from|import)\s+oracle\b|oracle/|onepiece_oracle|from helpers import track_levels", text), os.path.join(dirpath, f)
+
+
+def test_frustum_entry_points_and_argument_checks(hip, oracle):
+    """op_frustum_from_camera / _from_vectors (integration::Frustum's arithmetic, host side, no device needed): planes bit-equal to the
+    oracle's restatement of Frustum.cpp, the two entry points agree with each other, corners optional, null arguments and an oversized
+    camera are refused with a message."""
+    import ctypes as C
+    lib = hip.load()
+    fp = C.POINTER(C.c_float)
+    cam_o = oracle.make_camera()
+    cam_h = hip.Camera(cam_o.fx, cam_o.fy, cam_o.cx, cam_o.cy, cam_o.width, cam_o.height, cam_o.depth_scale)
+    rng = np.random.default_rng(11)
+    for _ in range(50):
+        T = np.eye(4, dtype=np.float32)
+        q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        T[:3, :3] = q.astype(np.float32); T[:3, 3] = (rng.normal(size=3) * 2).astype(np.float32)
+        planes, corners = np.zeros(24, np.float32), np.zeros(24, np.float32)
+        hip.check(lib.op_frustum_from_camera(C.byref(cam_h), T.ctypes.data_as(fp), 5.0, 0.5, planes.ctypes.data_as(fp), corners.ctypes.data_as(fp)))
+        assert np.array_equal(planes.view(np.uint32), oracle.frustum_planes(cam_o, T).reshape(24).view(np.uint32))
+        # the same frustum from its vectors (Frustum.cpp:14-23: right = R col 0, up = -R col 1, forward = R col 2, position = t)
+        fwd, pos, right, up = (np.ascontiguousarray(v, np.float32) for v in (T[:3, 2], T[:3, 3], T[:3, 0], -T[:3, 1]))
+        aspect = np.float32(np.float32(cam_o.fy * np.float32(cam_o.width)) / np.float32(cam_o.fx * np.float32(cam_o.height)))
+        fov = np.float32(np.arctan2(np.float64(cam_o.cy), np.float64(cam_o.fy)) + np.arctan2(np.float64(np.float32(cam_o.height) - np.float32(cam_o.cy)), np.float64(cam_o.fy)))
+        p2, c2 = np.zeros(24, np.float32), np.zeros(24, np.float32)
+        hip.check(lib.op_frustum_from_vectors(fwd.ctypes.data_as(fp), pos.ctypes.data_as(fp), right.ctypes.data_as(fp), up.ctypes.data_as(fp), 5.0, 0.5,
+                                              float(fov), float(aspect), p2.ctypes.data_as(fp), c2.ctypes.data_as(fp)))
+        assert np.array_equal(p2.view(np.uint32), planes.view(np.uint32)) and np.array_equal(c2.view(np.uint32), corners.view(np.uint32))
+        p3 = np.zeros(24, np.float32)
+        hip.check(lib.op_frustum_from_camera(C.byref(cam_h), T.ctypes.data_as(fp), 5.0, 0.5, p3.ctypes.data_as(fp), None))   # corners are optional
+        assert np.array_equal(p3, planes)
+    assert lib.op_frustum_from_camera(C.byref(cam_h), None, 5.0, 0.5, planes.ctypes.data_as(fp), None) == hip.OP_ERR_INVALID
+    assert lib.op_frustum_from_vectors(None, pos.ctypes.data_as(fp), right.ctypes.data_as(fp), up.ctypes.data_as(fp), 5.0, 0.5, 1.0, 1.0, planes.ctypes.data_as(fp), None) == hip.OP_ERR_INVALID
+    big = hip.Camera(500.0, 500.0, 4096.0, 4096.0, 8192, 8192, 1000.0)      # 2^26 pixels: beyond what the fusion kernels address
+    assert lib.op_frustum_from_camera(C.byref(big), T.ctypes.data_as(fp), 5.0, 0.5, planes.ctypes.data_as(fp), None) == hip.OP_ERR_INVALID
+    assert b"2^24" in lib.op_last_error()
+    got = C.c_float(0)
+    assert lib.op_get_sdf(C.byref(cam_h), None, T.ctypes.data_as(fp), None, C.c_void_p(planes.ctypes.data), hip.OP_DEPTH_F32, C.byref(got)) == hip.OP_ERR_INVALID
+
+
+def test_new_volume_entry_points_refuse_without_a_volume(hip):
+    """The entry points added in round 3 check their handle like the others (no device work without a valid volume)."""
+    import ctypes as C
+    lib = hip.load()
+    u = C.c_uint64(0)
+    assert lib.op_volume_stats_launches(None, C.byref(u), C.byref(u), C.byref(u), C.byref(u)) != 0
+    assert lib.op_volume_growth_stats(None, C.byref(u), C.byref(u), C.byref(u)) != 0
+    assert lib.op_volume_integrate_cubes(None, None, 0, None, 0, None, None, None, 0) != 0
+    n = C.c_size_t(0)
+    st = hip.MergeStats()
+    assert lib.op_volume_merge_rccl_stats(None, None, 0, C.byref(n), C.byref(st)) == hip.OP_ERR_INVALID and st.ranks == 0
