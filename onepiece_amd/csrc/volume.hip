@@ -703,7 +703,17 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
         (const float __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr(); // BatchInv B = offset 0 of the kernarg segment
     (void)B;
     unsigned upd = 0, sel = 0, chg = 0, nblk = 0;
-    const unsigned per_xcd = (n + 7u) / 8u;   // XCD-aware order and dynamic scheduling as in k_integrate
+#ifndef KC_CHUNK
+#define KC_CHUNK 32
+#endif
+    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2; list neighbours -- blocks along one viewing ray, which gather
+    // the same pixels -- should meet in one L2) and dynamic scheduling (blocks differ in work: 1..16 frames touch them; the workgroups of an XCD
+    // DRAW list positions from one counter, the next one before the current block is processed so that the atomic's round trip is hidden).
+    // The list is cut into chunks of KC_CHUNK blocks that are dealt round-robin to the XCDs: still contiguous runs for the L2, but every XCD gets
+    // a sample of the whole list.  With ONE contiguous eighth per XCD (KC_CHUNK == 0) the eighths differ in work and the launch ends with most XCDs
+    // idle: 309 us per 14-frame launch against 291 us with chunks of 32 (297 / 293 / 306 us with 8 / 128 / 512; tools/ab_bench.sh).
+    const unsigned n_chunks = KC_CHUNK ? (n + KC_CHUNK - 1u) / (KC_CHUNK ? KC_CHUNK : 1u) : 0u;
+    const unsigned per_xcd = KC_CHUNK ? ((n_chunks + 7u) / 8u) * KC_CHUNK : (n + 7u) / 8u;
     const unsigned xcd = blockIdx.x & 7u;
     unsigned* ctr = &st->kc_next[xcd * 16u];
     if (tid == 0) s_next[0] = atomicAdd(ctr, 1u);
@@ -711,7 +721,7 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
     unsigned slot = 0u;
     for (unsigned j = s_next[0]; j < per_xcd;) {
         if (tid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
-        const unsigned b = xcd * per_xcd + j;
+        const unsigned b = KC_CHUNK ? ((j / (KC_CHUNK ? KC_CHUNK : 1u)) * 8u + xcd) * KC_CHUNK + j % (KC_CHUNK ? KC_CHUNK : 1u) : xcd * per_xcd + j;
         const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
         if (idx >= 0) {
             const unsigned mask = V.bmask[V.blist[b]];
