@@ -452,21 +452,20 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroup -> (frame, slot within the frame).  Consecutive workgroups land on consecutive XCDs, each with its own 4 MiB
     // L2, and a candidate's 8 corner probes gather from its frame's 2.4 MB packed image.
-#ifndef KB_NO_XCD_FRAMES
-    // XCD x owns frames x, x + 8, ... (its L2 then sees 2 of the 16 images instead of all of them: 84 -> 79 us per launch) ...
+    // The batch is nf x 8 work units (a frame's candidate chunks c with c % 8 == q); XCD x takes units [x nf, (x + 1) nf) in frame-major
+    // order, i.e. exactly nf / 8 frames' worth whatever nf is, and walks them frame after frame (dispatch order ~ j), so that its L2 holds ONE
+    // 2.4 MB image at a time.  (Whole frames per XCD -- frames x, x + 8, ... -- left some XCDs with two frames and others with one whenever
+    // nf is not a multiple of 8: a 14-frame batch took as long as a 16-frame one.)
     int f, wslot, wstride;
     {
         const int nf = (int)gridDim.y, id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-        if (nf >= 8) {
-            const int x = id & 7, j = id >> 3, fx = (nf - x + 7) >> 3, per_xcd = (int)(gridDim.x * gridDim.y) >> 3;
-            const int spf = (per_xcd + fx - 1) / fx;      // ... one frame after the other (dispatch order ~ j): the L2 then holds
-            f = x + 8 * min(j / spf, fx - 1);             // ONE 2.4 MB image at a time instead of both (75 -> 69 us per launch)
-            wslot = j / spf < fx ? j % spf : 0x7fffffff; wstride = spf;
-        } else { f = blockIdx.y; wslot = blockIdx.x; wstride = gridDim.x; }
+        const int per_unit = (int)gridDim.x >> 3;        // workgroups per unit (grid.x = 512: 64)
+        const int x = id & 7, j = id >> 3;               // j = 0 .. nf * per_unit - 1 on this XCD
+        const int u = x * nf + j / per_unit;             // global unit
+        f = u >> 3;
+        wslot = (u & 7) + 8 * (j % per_unit);            // 0 .. grid.x - 1; slot 0 of a frame also publishes the frame's statistics
+        wstride = (int)gridDim.x;
     }
-#else
-    const int f = blockIdx.y, wslot = blockIdx.x, wstride = gridDim.x;
-#endif
     const float* M = B.f[f].m;
     const uint2* img = pimg + (size_t)f * C.width * C.height;
 
