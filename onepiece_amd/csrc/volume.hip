@@ -63,7 +63,8 @@ constexpr int kBlockFloats = 5 * kVox;
 constexpr unsigned long long kEmptyKey = ~0ULL; // table slot never used
 constexpr int kPending = -1;         // slot claimed, pool slot not published yet
 constexpr int kDead = -3;            // slot claimed but the pool was full
-constexpr int kPixPerWg = 1024;      // KA: pixels per workgroup (256 threads x 4)
+constexpr int kKaW = 64, kKaH = 16;   // KA: a workgroup's pixel rectangle (256 threads x 4 consecutive pixels of a row)
+constexpr int kTile = 16;             // KA -> KB: min / max valid depth per 16 x 16 pixel tile (k_select's coarse test); a KA rectangle = 4 tiles
 #ifndef KB_GRID
 #define KB_GRID 512
 #endif
@@ -103,6 +104,12 @@ struct BatchFwd { PoseFwd f[kMaxBatch]; };
 struct BatchInv { PoseInv f[kMaxBatch]; };
 struct BatchPtrs { const void* depth[kMaxBatch]; const unsigned char* rgb[kMaxBatch]; }; // device images of each frame
 
+#ifndef KC_SHARES
+#define KC_SHARES 8
+#endif
+constexpr int kKcShares = KC_SHARES; // k_integrate: the batch list is dealt to this many draw counters (a multiple of 8: workgroup b draws from share b % kKcShares, on XCD b % 8)
+static_assert(kKcShares % 8 == 0 && kKcShares <= 256, "whole XCDs");
+constexpr int kKcTSlots = 256; // k_integrate's workgroup b reports its duration to slot b % 256 (atomics on one address serialise at ~100 ns each)
 struct State {
     unsigned n_batch;   // length of the batch block list
     unsigned overflow;  // bit0 pool full, bit1 table full, bit2 bbox too large, bit3 coordinate range
@@ -114,9 +121,9 @@ struct State {
     unsigned long long stat_launches; // k_integrate launches that fused something (a poisoned launch does not count)
     // Shader-clock duration of k_integrate (s_memtime counts shader cycles on this part, tools/valu_ubench.hip; its value is
     // not synchronised between CUs, so every workgroup measures ITSELF): the longest s_memtime span of a workgroup of the
-    // running launch -- the workgroups are resident from the kernel's start to its end -- one slot per XCD, folded into
+    // running launch -- the workgroups are resident from the kernel's start to its end -- kKcTSlots slots, folded into
     // stat_kc_ticks by the next batch's KA or by the host.
-    unsigned long long kc_t[8];
+    unsigned long long kc_t[kKcTSlots];
     unsigned long long stat_kc_ticks;
     unsigned long long n_cand[kMaxBatch];
     float bbox[kMaxBatch][6]; // max xyz, min xyz
@@ -126,7 +133,7 @@ struct State {
     // of all six), [6] their number.  Zeroed by whoever consumed them last (KC, k_finish_select) and by vol_reset.
     unsigned acc[kMaxBatch][kAccSlots][8]; // kAccSlots sets per frame (workgroup x uses set x % kAccSlots): atomics on ONE
                                             // address serialise at ~100 ns each, 300 of them cost KA 35 us
-    unsigned kc_next[8 * 16]; // KC dynamic scheduling: next list position of each XCD's slab (one cache line each)
+    unsigned kc_next[kKcShares * 16]; // KC dynamic scheduling: next list position of each share of the batch list (one cache line each)
 };
 
 struct VolView {
@@ -339,24 +346,25 @@ __device__ __forceinline__ float ord_dec(unsigned e) {
 // ---------------------------------------------------------------------------------------------
 // KA: per-frame preparation = ComputeBounding (CubeHandler.cpp:116-145: back-project, transform,
 // frustum test, min/max) + packing of the frame into one {depth, rgba} record per pixel so that
-// the later gathers are single 8-byte loads.  grid = (ceil(W*H/1024), n_frames).
+// the later gathers are single 8-byte loads + the smallest and largest valid depth of every 16 x 16
+// pixel tile (what k_select's coarse test looks at).  grid = (ka_grid(W, H), n_frames); a workgroup
+// owns a 64 x 16 pixel rectangle, a thread 4 consecutive pixels of one row.
 // One bounding partial per workgroup (no atomics): [max x,y,z, min x,y,z, inside, pad].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C, BatchPtrs Q, uint2* __restrict__ pimg,
+__host__ __device__ inline int ka_grid(int w, int h) { return ((w + kKaW - 1) / kKaW) * ((h + kKaH - 1) / kKaH); }
+__host__ __device__ inline int tiles_w(int w) { return (w + kTile - 1) / kTile; }
+__host__ __device__ inline int tiles_h(int h) { return (h + kTile - 1) / kTile; }
+
+__global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C, BatchPtrs Q, uint2* __restrict__ pimg, float2* __restrict__ ptile,
                                                         float* __restrict__ partial, State* st, unsigned seq,
                                                         const unsigned* __restrict__ n_blocks, unsigned* __restrict__ hstat) {
     __shared__ float s_red[4][6];
     __shared__ unsigned s_cnt[4];
+    __shared__ float s_tile[4][4][2];
     const int tid = threadIdx.x, f = blockIdx.y;
     if (blockIdx.x == 0 && f == 0 && tid == 0) {
         st->n_batch = 0; st->n_rec = 0; // new batch: empty lists
         st->cur_seq = seq;
-        unsigned long long kc = 0; // the previous launch's k_integrate duration in shader cycles: the longest XCD
-        for (int x = 0; x < 8; ++x) {
-            if (st->kc_t[x] > kc) kc = st->kc_t[x];
-            st->kc_t[x] = 0ull;
-        }
-        st->stat_kc_ticks += kc;
         // Progress report for the host (host-mapped pinned memory, read without any synchronisation): this kernel starting
         // means every earlier batch has finished; unless the stream is poisoned by an overflow they all completed.  The host
         // uses it to retire its replay log / staging slots and to grow the pool BEFORE it runs full.
@@ -366,56 +374,115 @@ __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C,
             __hip_atomic_store(&hstat[0], seq - 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (blockIdx.x == 0 && f == 0 && tid < 8) st->kc_next[tid * 16] = 0u;
+    if (blockIdx.x == 0 && f == 0 && tid < kKcShares) st->kc_next[tid * 16] = 0u;
+    if (blockIdx.x == 0 && f == 0) { // the previous launch's k_integrate duration in shader cycles: its longest workgroup
+        static_assert(kKcTSlots == 256, "one slot per thread");
+        unsigned long long kc = st->kc_t[tid];
+        st->kc_t[tid] = 0ull;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(kc, o, 64); kc = x > kc ? x : kc; }
+        __shared__ unsigned long long s_kc[4];
+        if ((tid & 63) == 0) s_kc[tid >> 6] = kc;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) kc = s_kc[w] > kc ? s_kc[w] : kc;
+            st->stat_kc_ticks += kc;
+        }
+    }
     const PoseFwd& P = B.f[f];
     const int npix = C.width * C.height;
     const void* dptr = Q.depth[f];
     const unsigned char* cptr = Q.rgb[f];
     uint2* out = pimg + (size_t)f * npix;
+    const int wgx = (C.width + kKaW - 1) / kKaW;
+    const int gy = (int)blockIdx.x / wgx, gx = (int)blockIdx.x - gy * wgx;
+    const int row = gy * kKaH + (tid >> 4), col0 = gx * kKaW + (tid & 15) * 4;
     float mx0 = -FLT_MAX, mx1 = -FLT_MAX, mx2 = -FLT_MAX, mn0 = FLT_MAX, mn1 = FLT_MAX, mn2 = FLT_MAX;
+    float tmin = __builtin_inff(), tmax = -__builtin_inff(); // valid depths of the thread's pixels
     unsigned inside = 0;
-#pragma unroll
-    for (int r = 0; r < kPixPerWg / 256; ++r) {
-        const int pix = blockIdx.x * kPixPerWg + r * 256 + tid;
-        if (pix >= npix) continue;
-        // Integrator.cpp:26-29 / PointCloud.cpp:83-86: float depth, or uint16 / depth_scale
-        const float z = C.depth_u16 ? (float)((const unsigned short*)dptr)[pix] / C.depth_scale : ((const float*)dptr)[pix];
-        unsigned rgba = 0;
-        if (cptr) rgba = (unsigned)cptr[3 * (size_t)pix] | ((unsigned)cptr[3 * (size_t)pix + 1] << 8) | ((unsigned)cptr[3 * (size_t)pix + 2] << 16);
-        out[pix] = make_uint2(__float_as_uint(z), rgba);
-        if (!(z > 0)) continue;
-        const int i = pix / C.width, j = pix - i * C.width;
-        const float x = ((float)j - C.cx) * z / C.fx; // PointCloud.cpp:90-93
-        const float y = ((float)i - C.cy) * z / C.fy;
-        const float* M = P.pose;                       // Geometry.cpp:19-27
-        const float q0 = ((M[0] * x + M[1] * y) + M[2] * z) + M[3] * 1.0f;
-        const float q1 = ((M[4] * x + M[5] * y) + M[6] * z) + M[7] * 1.0f;
-        const float q2 = ((M[8] * x + M[9] * y) + M[10] * z) + M[11] * 1.0f;
-        const float q3 = ((M[12] * x + M[13] * y) + M[14] * z) + M[15] * 1.0f;
-        const float p0 = q0 / q3, p1 = q1 / q3, p2 = q2 / q3;
-        bool in = true; // Frustum::ContainPoint incl. its early "== 0 -> true" (Frustum.h:74-103)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const float dist = sum3(P.planes[4 * k] * p0, P.planes[4 * k + 1] * p1, P.planes[4 * k + 2] * p2) + P.planes[4 * k + 3];
-            if (dist < 0) { in = false; break; }
-            if (dist == 0) break;
+    if (row < C.height && col0 < C.width) {
+        const int pix0 = row * C.width + col0;
+        float zz[4];
+        unsigned cc[4] = {0u, 0u, 0u, 0u};
+        const int nv = C.width - col0 < 4 ? C.width - col0 : 4; // pixels of the row this thread has
+        // Integrator.cpp:26-29 / PointCloud.cpp:83-86: float depth, or uint16 / depth_scale.  Aligned rows take one wide load per thread.
+        const bool wide = nv == 4 && (C.width & 3) == 0 && ((size_t)dptr & 15u) == 0 && ((size_t)cptr & 3u) == 0;
+        if (wide) {
+            if (C.depth_u16) {
+                const ushort4 d = *reinterpret_cast<const ushort4*>((const unsigned short*)dptr + pix0);
+                zz[0] = (float)d.x / C.depth_scale; zz[1] = (float)d.y / C.depth_scale; zz[2] = (float)d.z / C.depth_scale; zz[3] = (float)d.w / C.depth_scale;
+            } else {
+                const float4 d = *reinterpret_cast<const float4*>((const float*)dptr + pix0);
+                zz[0] = d.x; zz[1] = d.y; zz[2] = d.z; zz[3] = d.w;
+            }
+            if (cptr) {
+                const unsigned* c3 = reinterpret_cast<const unsigned*>(cptr + 3 * (size_t)pix0); // 12 bytes = 4 pixels, 4-byte aligned
+                const unsigned d0 = c3[0], d1 = c3[1], d2 = c3[2];
+                cc[0] = d0 & 0xffffffu; cc[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8); cc[2] = (d1 >> 16) | ((d2 & 0xffu) << 16); cc[3] = d2 >> 8;
+            }
+            uint4* o4 = reinterpret_cast<uint4*>(out + pix0);
+            o4[0] = make_uint4(__float_as_uint(zz[0]), cc[0], __float_as_uint(zz[1]), cc[1]);
+            o4[1] = make_uint4(__float_as_uint(zz[2]), cc[2], __float_as_uint(zz[3]), cc[3]);
+        } else {
+            for (int e = 0; e < nv; ++e) {
+                const int pix = pix0 + e;
+                zz[e] = C.depth_u16 ? (float)((const unsigned short*)dptr)[pix] / C.depth_scale : ((const float*)dptr)[pix];
+                if (cptr) cc[e] = (unsigned)cptr[3 * (size_t)pix] | ((unsigned)cptr[3 * (size_t)pix + 1] << 8) | ((unsigned)cptr[3 * (size_t)pix + 2] << 16);
+                out[pix] = make_uint2(__float_as_uint(zz[e]), cc[e]);
+            }
         }
-        if (in) {
-            ++inside;
-            mx0 = p0 > mx0 ? p0 : mx0; mx1 = p1 > mx1 ? p1 : mx1; mx2 = p2 > mx2 ? p2 : mx2;
-            mn0 = p0 < mn0 ? p0 : mn0; mn1 = p1 < mn1 ? p1 : mn1; mn2 = p2 < mn2 ? p2 : mn2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e >= nv) break;
+            const float z = zz[e];
+            if (!(z > 0)) continue;
+            tmin = fminf(tmin, z); tmax = fmaxf(tmax, z);
+            const int i = row, j = col0 + e;
+            const float x = ((float)j - C.cx) * z / C.fx; // PointCloud.cpp:90-93
+            const float y = ((float)i - C.cy) * z / C.fy;
+            const float* M = P.pose;                       // Geometry.cpp:19-27
+            const float q0 = ((M[0] * x + M[1] * y) + M[2] * z) + M[3] * 1.0f;
+            const float q1 = ((M[4] * x + M[5] * y) + M[6] * z) + M[7] * 1.0f;
+            const float q2 = ((M[8] * x + M[9] * y) + M[10] * z) + M[11] * 1.0f;
+            const float q3 = ((M[12] * x + M[13] * y) + M[14] * z) + M[15] * 1.0f;
+            const float p0 = q0 / q3, p1 = q1 / q3, p2 = q2 / q3;
+            bool in = true; // Frustum::ContainPoint incl. its early "== 0 -> true" (Frustum.h:74-103)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float dist = sum3(P.planes[4 * k] * p0, P.planes[4 * k + 1] * p1, P.planes[4 * k + 2] * p2) + P.planes[4 * k + 3];
+                if (dist < 0) { in = false; break; }
+                if (dist == 0) break;
+            }
+            if (in) {
+                ++inside;
+                mx0 = p0 > mx0 ? p0 : mx0; mx1 = p1 > mx1 ? p1 : mx1; mx2 = p2 > mx2 ? p2 : mx2;
+                mn0 = p0 < mn0 ? p0 : mn0; mn1 = p1 < mn1 ? p1 : mn1; mn2 = p2 < mn2 ? p2 : mn2;
+            }
         }
     }
+    // tiles: 4 lanes share a 16-pixel row segment, lane bits 4 and 5 are the wave's 4 rows, the 4 waves are the tile's 16 rows
+    tmin = fminf(tmin, __shfl_xor(tmin, 1, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 1, 64));
+    tmin = fminf(tmin, __shfl_xor(tmin, 2, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 2, 64));
+    tmin = fminf(tmin, __shfl_xor(tmin, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmin = fminf(tmin, __shfl_xor(tmin, 32, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     mx0 = wave_max(mx0); mx1 = wave_max(mx1); mx2 = wave_max(mx2);
     mn0 = wave_min(mn0); mn1 = wave_min(mn1); mn2 = wave_min(mn2);
     inside = wave_sum(inside);
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) {
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) {
         s_red[wave][0] = mx0; s_red[wave][1] = mx1; s_red[wave][2] = mx2;
         s_red[wave][3] = mn0; s_red[wave][4] = mn1; s_red[wave][5] = mn2;
         s_cnt[wave] = inside;
     }
+    if ((lane & 0x33) == 0) { s_tile[wave][lane >> 2][0] = tmin; s_tile[wave][lane >> 2][1] = tmax; }
     __syncthreads();
+    if (tid < 4) {
+        const int tx = gx * (kKaW / kTile) + tid, tw = tiles_w(C.width);
+        if (tx < tw && gy < tiles_h(C.height)) {
+            float lo = s_tile[0][tid][0], hi = s_tile[0][tid][1];
+            for (int w = 1; w < 4; ++w) { lo = fminf(lo, s_tile[w][tid][0]); hi = fmaxf(hi, s_tile[w][tid][1]); }
+            ptile[((size_t)f * tiles_h(C.height) + gy) * tw + tx] = make_float2(lo, hi);
+        }
+    }
     float* pout = partial + ((size_t)f * gridDim.x + blockIdx.x) * 8;
     if (tid < 6) {
         float v = s_red[0][tid];
@@ -439,27 +506,55 @@ __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C,
 
 // ---------------------------------------------------------------------------------------------
 // KB: PrepareCubes (CubeHandler.cpp:147-196) for every frame of the batch (blockIdx.y = frame).
-// One thread per candidate block of the bbox +-1 range; 8 corner-voxel GetSDF probes; a selected
-// block is looked up / inserted in the hash table, its batch mask gets the frame's bit, and the
-// first selection in the batch appends it to the batch list (append aggregated per workgroup chunk).
-// record != 0 (single-frame PrepareCubes API): also emits (pool slot, candidate rank) pairs.
+// The reference probes EVERY block of the bbox +-1 range (8 corner-voxel GetSDF probes each); ~13 % are selected.  Here the range is cut
+// into super-blocks of kSB^3 blocks, and a super-block is first tested as a whole against the tiles' depth range (k_prepare_frames):
+//   * its 8 extreme voxel centres are transformed into the camera; all of them farther than 5 cm in front of it => every voxel centre of
+//     the super-block projects inside the pixel bounding box of those 8 projections (a projective map keeps convex hulls while z > 0);
+//   * the box widened by 2 px + 0.1 % lies outside the image => every probe is off-image (GetSDF = 999), nothing is selected;
+//   * else, with [dmin, dmax] the valid depths of the tiles the box touches: dmin - zmax >= truncation + 1 mm or zmin - dmax >= truncation
+//     + 1 mm (or no valid depth at all) => every probe has |sdf| >= truncation, nothing is selected.
+// The margins are orders of magnitude above the float rounding of either side, so a super-block is only ever dropped when the exact
+// per-block test below would reject every one of its blocks; the selected set is the reference's, bit for bit (parity suite, fuzz).
+// Surviving super-blocks go through the exact test: one wave per super-block, one lane per block, 8 probes per lane.  A selected block
+// is looked up / inserted in the hash table, its batch mask gets the frame's bit, and the first selection in the batch appends it to
+// the batch list (collected in LDS, one global append per workgroup).  record != 0 (single-frame PrepareCubes API): also emits
+// (table slot, candidate rank) pairs.
 // ---------------------------------------------------------------------------------------------
+#ifndef KB_SB
+#define KB_SB 4
+#endif
+constexpr int kSB = KB_SB;                      // super-block edge in blocks
+constexpr int kSBVol = kSB * kSB * kSB;         // 64 blocks = one wave
+#ifndef KB_SBPERWG
+#define KB_SBPERWG 8
+#endif
+constexpr int kSBPerWg = KB_SBPERWG;                    // super-blocks a workgroup tests at a time (8 lanes each)
+constexpr int kSelTiles = 64;                   // a super-block whose pixel box touches more tiles skips the depth test (it is close to the camera)
+static_assert(kSBVol == 64, "one lane per block of a super-block");
+
+#ifndef KB_MINWAVES
+#define KB_MINWAVES 6
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg,
+__global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, const float2* __restrict__ ptile,
                                                 State* st, int record) {
     __shared__ int s_range[6]; // i0, j0, k0, ni, nj, nk
-    __shared__ unsigned s_wa[4], s_wb[4], s_base[2];
+    __shared__ unsigned s_nsurv, s_nfirst, s_nrec, s_base[2];
+    __shared__ unsigned s_surv[kSBPerWg];
+    __shared__ int s_first[kSBPerWg * kSBVol];
+    __shared__ int s_rslot[kSBPerWg * kSBVol];
+    __shared__ unsigned long long s_rcand[kSBPerWg * kSBVol];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroup -> (frame, slot within the frame).  Consecutive workgroups land on consecutive XCDs, each with its own 4 MiB
     // L2, and a candidate's 8 corner probes gather from its frame's 2.4 MB packed image.
-    // The batch is nf x 8 work units (a frame's candidate chunks c with c % 8 == q); XCD x takes units [x nf, (x + 1) nf) in frame-major
+    // The batch is nf x 8 work units (a frame's chunks c with c % 8 == q); XCD x takes units [x nf, (x + 1) nf) in frame-major
     // order, i.e. exactly nf / 8 frames' worth whatever nf is, and walks them frame after frame (dispatch order ~ j), so that its L2 holds ONE
     // 2.4 MB image at a time.  (Whole frames per XCD -- frames x, x + 8, ... -- left some XCDs with two frames and others with one whenever
     // nf is not a multiple of 8: a 14-frame batch took as long as a 16-frame one.)
     int f, wslot, wstride;
     {
         const int nf = (int)gridDim.y, id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-        const int per_unit = (int)gridDim.x >> 3;        // workgroups per unit (grid.x = 512: 64)
+        const int per_unit = (int)gridDim.x >> 3;        // workgroups per unit
         const int x = id & 7, j = id >> 3;               // j = 0 .. nf * per_unit - 1 on this XCD
         const int u = x * nf + j / per_unit;             // global unit
         f = u >> 3;
@@ -468,6 +563,8 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
     }
     const float* M = B.f[f].m;
     const uint2* img = pimg + (size_t)f * C.width * C.height;
+    const int tw = tiles_w(C.width), th = tiles_h(C.height);
+    const float2* tiles = ptile + (size_t)f * tw * th;
 
     // -- finish ComputeBounding from the frame's accumulators (k_prepare_frames)
     unsigned tot = 0, e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
@@ -509,14 +606,15 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
             for (int c = 0; c < 6; ++c) st->bbox[f][c] = b[c];
             st->n_inside[f] = tot;
         }
+        s_nsurv = 0u; s_nfirst = 0u; s_nrec = 0u;
     }
     __syncthreads();
     const int i0 = s_range[0], j0 = s_range[1], k0 = s_range[2];
-    const long long ni = s_range[3], nj = s_range[4], nk = s_range[5];
-    unsigned long long ncand = (unsigned long long)(ni * nj * nk);
+    int ni = s_range[3], nj = s_range[4], nk = s_range[5];
+    unsigned long long ncand = (unsigned long long)((long long)ni * nj * nk);
     if (ni > 4096 || nj > 4096 || nk > 4096) { // > 160 m at 5 mm: treat as a bad frame, select nothing
         if (wslot == 0 && tid == 0) atomicOr(&st->overflow, 4u);
-        ncand = 0;
+        ncand = 0; ni = nj = nk = 0;
     }
     if (wslot == 0 && tid == 0) st->n_cand[f] = ncand;
 
@@ -524,87 +622,159 @@ __global__ __launch_bounds__(256) void k_select(BatchInv B, CamParams C, VolView
     const float half = C.res / 2;        // VoxelCube.h:47
     const float o_lo = 0.0f * C.res + half, o_hi = 7.0f * C.res + half; // VoxelCentroidOffSet of x = 0 / 7
     const unsigned fbit = 1u << f;
+    // super-block grid of the frame's range (<= 1024^3 < 2^32 entries)
+    const unsigned nsi = (unsigned)(ni + kSB - 1) / kSB, nsj = (unsigned)(nj + kSB - 1) / kSB, nsk = (unsigned)(nk + kSB - 1) / kSB;
+    const unsigned n_super = nsi * nsj * nsk;
 
-    for (unsigned long long chunk = (unsigned long long)wslot; chunk * 256ULL < ncand; chunk += (unsigned long long)wstride) {
-        const unsigned long long c = chunk * 256ULL + tid;
-        bool first = false, rec = false;
-        int pool_idx = -1;
-        if (c < ncand) {
-            // candidate rank -> (i, j, k), k fastest (CubeHandler.cpp:170-173).  64-bit division costs ~200 instructions on
-            // this chip and three of them were half of the kernel's VALU work; ranks below 2^32 (always, short of a
-            // 160 m bounding box) take two 32-bit divisions instead.
-            int bi, bj, bk;
-            if (ncand <= 0xffffffffULL) {
-                const unsigned c32 = (unsigned)c, nk32 = (unsigned)nk, nj32 = (unsigned)nj;
-                const unsigned q1 = c32 / nk32, q2 = q1 / nj32;
-                bk = k0 + (int)(c32 - q1 * nk32); bj = j0 + (int)(q1 - q2 * nj32); bi = i0 + (int)q2;
-            } else {
-                bk = k0 + (int)(c % (unsigned long long)nk);
-                bj = j0 + (int)((c / (unsigned long long)nk) % (unsigned long long)nj);
-                bi = i0 + (int)(c / (unsigned long long)(nk * nj));
-            }
-            const float bx = (float)bi * cube_res, by = (float)bj * cube_res, bz = (float)bk * cube_res;
-            // Integrator::GetSDF (Integrator.cpp:8-35) for the 8 corner voxels {0,7,56,63,448,455,504,511}:
-            // all 8 projections first, then all 8 gathers in flight together, then the min
-            int pix[8];
-            float zc[8];
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const float px = bx + ((corner & 1) ? o_hi : o_lo);
-                const float py = by + ((corner & 2) ? o_hi : o_lo);
-                const float pz = bz + ((corner & 4) ? o_hi : o_lo);
+    for (unsigned chunk = (unsigned)wslot; (unsigned long long)chunk * kSBPerWg < n_super; chunk += (unsigned)wstride) {
+        // ---- coarse test: 8 lanes per super-block (one per corner), waves 0 and 1
+        if (tid < kSBPerWg * 8) {
+            const unsigned sb = chunk * kSBPerWg + (unsigned)(tid >> 3);
+            const int corner = tid & 7;
+            bool survive = false;
+            if (sb < n_super) {
+                const unsigned q1 = sb / nsk, q2 = q1 / nsj;
+                const int sk = (int)(sb - q1 * nsk), sj = (int)(q1 - q2 * nsj), si = (int)q2;
+                // first and last block of the super-block inside the range, per axis
+                const int bi0 = i0 + si * kSB, bj0 = j0 + sj * kSB, bk0 = k0 + sk * kSB;
+                const int bi1 = min(bi0 + kSB - 1, i0 + ni - 1), bj1 = min(bj0 + kSB - 1, j0 + nj - 1), bk1 = min(bk0 + kSB - 1, k0 + nk - 1);
+                const float px = (corner & 1) ? (float)bi1 * cube_res + o_hi : (float)bi0 * cube_res + o_lo;
+                const float py = (corner & 2) ? (float)bj1 * cube_res + o_hi : (float)bj0 * cube_res + o_lo;
+                const float pz = (corner & 4) ? (float)bk1 * cube_res + o_hi : (float)bk0 * cube_res + o_lo;
                 const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-                const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-                const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                zc[corner] = q2;
-                pix[corner] = project_pixel<FAST>(C, q0, q1, q2);
-            }
-            float dd[8];
+                const float qy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+                const float qz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+                float zmin = qz, zmax = qz;
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) dd[corner] = pix[corner] >= 0 ? __uint_as_float(img[(unsigned)pix[corner]].x) : 0.0f;
-            float min_sdf = FLT_MAX;
+                for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o, 64)); zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64)); }
+                survive = true;
+                if (zmin > 0.05f) { // all 8 extreme centres well in front of the camera (else: no shortcut)
+                    const float uf = C.fx * q0 / qz + C.cx, vf = C.fy * qy / qz + C.cy;
+                    float umin = uf, umax = uf, vmin = vf, vmax = vf;
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const float sdf = dd[corner] <= 0 ? 999.0f : dd[corner] - zc[corner]; // off-image or d <= 0 -> 999
-                const float a = fabsf(sdf);
-                if (min_sdf > a) min_sdf = a;
-            }
-            if (min_sdf < C.trunc) {
-                if (!key_in_range(bi, bj, bk)) {
-                    atomicOr(&st->overflow, 8u);
-                } else {
-                    bool created;
-                    pool_idx = table_claim(V, st, bi, bj, bk, &created); // table slot; KC translates it
-                    if (pool_idx >= 0) {
-                        first = atomicOr(&V.bmask[pool_idx], fbit) == 0u;
-                        rec = record != 0;
+                    for (int o = 1; o < 8; o <<= 1) {
+                        umin = fminf(umin, __shfl_xor(umin, o, 64)); umax = fmaxf(umax, __shfl_xor(umax, o, 64));
+                        vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+                    }
+                    const float mu = 2.0f + 1e-3f * fmaxf(fabsf(umin), fabsf(umax)), mv = 2.0f + 1e-3f * fmaxf(fabsf(vmin), fabsf(vmax));
+                    const float u_lo = umin - mu, u_hi = umax + mu, v_lo = vmin - mv, v_hi = vmax + mv;
+                    const float wmax = (float)(C.width - 1), hmax = (float)(C.height - 1);
+                    if (!(u_hi >= 0.0f && u_lo <= wmax && v_hi >= 0.0f && v_lo <= hmax)) {
+                        survive = !(u_hi < 0.0f || u_lo > wmax || v_hi < 0.0f || v_lo > hmax); // NaN somewhere: no shortcut
+                    } else {
+                        const int x0 = (int)fmaxf(u_lo, 0.0f), x1 = (int)fminf(u_hi, wmax), y0 = (int)fmaxf(v_lo, 0.0f), y1 = (int)fminf(v_hi, hmax);
+                        const int tx0 = x0 / kTile, tx1 = x1 / kTile, ty0 = y0 / kTile, ty1 = y1 / kTile;
+                        const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
+                        if (nt <= kSelTiles) {
+                            float dmin = __builtin_inff(), dmax = -__builtin_inff();
+                            for (int t = corner; t < nt; t += 8) {
+                                const int ty = t / ntx, tx = t - ty * ntx;
+                                const float2 d = tiles[(ty0 + ty) * tw + tx0 + tx];
+                                dmin = fminf(dmin, d.x); dmax = fmaxf(dmax, d.y);
+                            }
+#pragma unroll
+                            for (int o = 1; o < 8; o <<= 1) { dmin = fminf(dmin, __shfl_xor(dmin, o, 64)); dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); }
+                            const float guard = C.trunc + 1e-3f;
+                            // (no valid depth in the tiles: dmin = +inf, dmax = -inf, both differences are +inf)
+                            if (dmin - zmax >= guard || zmin - dmax >= guard) survive = false;
+                        }
                     }
                 }
             }
+            if (survive && corner == 0) s_surv[atomicAdd(&s_nsurv, 1u)] = chunk * kSBPerWg + (unsigned)(tid >> 3);
         }
-        // workgroup-aggregated appends: batch list (first selection in this batch) and record list
-        const unsigned long long m_a = __ballot(first), m_b = __ballot(rec);
-        const unsigned long long below = (1ULL << lane) - 1ULL;
-        unsigned r_a = __popcll(m_a & below), r_b = __popcll(m_b & below);
-        if (lane == 0) { s_wa[wave] = __popcll(m_a); s_wb[wave] = __popcll(m_b); }
         __syncthreads();
+        const unsigned nsurv = s_nsurv;
+        // ---- exact test: one wave per surviving super-block, one lane per block
+        for (unsigned sv = (unsigned)wave; sv < nsurv; sv += 4u) {
+            const unsigned sb = s_surv[sv];
+            const unsigned q1 = sb / nsk, q2 = q1 / nsj;
+            const int sk = (int)(sb - q1 * nsk), sj = (int)(q1 - q2 * nsj), si = (int)q2;
+            const int ci = si * kSB + (lane >> 4), cj = sj * kSB + ((lane >> 2) & 3), ck = sk * kSB + (lane & 3); // position in the range
+            bool first = false, rec = false;
+            int pool_idx = -1;
+            if (ci < ni && cj < nj && ck < nk) {
+                const int bi = i0 + ci, bj = j0 + cj, bk = k0 + ck;
+                const float bx = (float)bi * cube_res, by = (float)bj * cube_res, bz = (float)bk * cube_res;
+                // Integrator::GetSDF (Integrator.cpp:8-35) for the 8 corner voxels {0,7,56,63,448,455,504,511}:
+                // all 8 projections first, then all 8 gathers in flight together, then the min
+                int pix[8];
+                float zc[8];
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) {
+                    const float px = bx + ((corner & 1) ? o_hi : o_lo);
+                    const float py = by + ((corner & 2) ? o_hi : o_lo);
+                    const float pz = bz + ((corner & 4) ? o_hi : o_lo);
+                    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+                    const float q1c = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+                    const float q2c = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+                    zc[corner] = q2c;
+                    pix[corner] = project_pixel<FAST>(C, q0, q1c, q2c);
+                }
+                float dd[8];
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) dd[corner] = pix[corner] >= 0 ? __uint_as_float(img[(unsigned)pix[corner]].x) : 0.0f;
+                float min_sdf = FLT_MAX;
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) {
+                    const float sdf = dd[corner] <= 0 ? 999.0f : dd[corner] - zc[corner]; // off-image or d <= 0 -> 999
+                    const float a = fabsf(sdf);
+                    if (min_sdf > a) min_sdf = a;
+                }
+                if (min_sdf < C.trunc) {
+                    if (!key_in_range(bi, bj, bk)) {
+                        atomicOr(&st->overflow, 8u);
+                    } else {
+                        bool created;
+                        pool_idx = table_claim(V, st, bi, bj, bk, &created); // table slot; KC translates it
+                        if (pool_idx >= 0) {
+                            first = atomicOr(&V.bmask[pool_idx], fbit) == 0u;
+                            rec = record != 0;
+                        }
+                    }
+                }
+            }
+            // wave-aggregated appends to the workgroup's lists: batch list (first selection in this batch) and record list
+            const unsigned long long m_a = __ballot(first), m_b = __ballot(rec);
+            const unsigned long long below = (1ULL << lane) - 1ULL;
+            if (m_a) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_nfirst, (unsigned)__popcll(m_a));
+                base = __shfl(base, 0, 64);
+                if (first) s_first[base + __popcll(m_a & below)] = pool_idx;
+            }
+            if (m_b) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_nrec, (unsigned)__popcll(m_b));
+                base = __shfl(base, 0, 64);
+                if (rec) {
+                    const unsigned r = base + __popcll(m_b & below);
+                    s_rslot[r] = pool_idx;
+                    // candidate rank == position in the reference's i, j, k loop nest, k fastest (CubeHandler.cpp:170-173)
+                    s_rcand[r] = ((unsigned long long)ci * (unsigned long long)nj + (unsigned long long)cj) * (unsigned long long)nk + (unsigned long long)ck;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- one global append per workgroup and list
+        const unsigned nfirst = s_nfirst, nrec = s_nrec;
         if (tid == 0) {
-            const unsigned ta = s_wa[0] + s_wa[1] + s_wa[2] + s_wa[3];
-            const unsigned tb = s_wb[0] + s_wb[1] + s_wb[2] + s_wb[3];
-            s_base[0] = ta ? atomicAdd(&st->n_batch, ta) : 0u;
-            s_base[1] = tb ? atomicAdd(&st->n_rec, tb) : 0u;
+            s_base[0] = nfirst ? atomicAdd(&st->n_batch, nfirst) : 0u;
+            s_base[1] = nrec ? atomicAdd(&st->n_rec, nrec) : 0u;
+            s_nsurv = 0u;
         }
         __syncthreads();
-        for (int w = 0; w < wave; ++w) { r_a += s_wa[w]; r_b += s_wb[w]; }
-        if (first) {
-            const unsigned pos = s_base[0] + r_a;
-            if (pos < V.max_blocks) V.blist[pos] = pool_idx;
+        for (unsigned k = (unsigned)tid; k < nfirst; k += 256u) {
+            const unsigned pos = s_base[0] + k;
+            if (pos < V.max_blocks) V.blist[pos] = s_first[k];
         }
-        if (rec) {
-            const unsigned pos = s_base[1] + r_b;
-            if (pos < V.max_blocks) { V.sel_list[pos] = pool_idx; V.sel_cand[pos] = c; }
+        for (unsigned k = (unsigned)tid; k < nrec; k += 256u) {
+            const unsigned pos = s_base[1] + k;
+            if (pos < V.max_blocks) { V.sel_list[pos] = s_rslot[k]; V.sel_cand[pos] = s_rcand[k]; }
         }
-        __syncthreads(); // s_wa / s_base are reused by the next chunk
+        __syncthreads(); // the lists are reused by the next chunk
+        if (tid == 0) { s_nfirst = 0u; s_nrec = 0u; }
+        // (the next chunk's coarse test does not touch s_nfirst / s_nrec; its __syncthreads orders the reset before their next use)
     }
 }
 
@@ -712,15 +882,15 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
     // a sample of the whole list.  With ONE contiguous eighth per XCD (KC_CHUNK == 0) the eighths differ in work and the launch ends with most XCDs
     // idle: 309 us per 14-frame launch against 291 us with chunks of 32 (297 / 293 / 306 us with 8 / 128 / 512; tools/ab_bench.sh).
     const unsigned n_chunks = KC_CHUNK ? (n + KC_CHUNK - 1u) / (KC_CHUNK ? KC_CHUNK : 1u) : 0u;
-    const unsigned per_xcd = KC_CHUNK ? ((n_chunks + 7u) / 8u) * KC_CHUNK : (n + 7u) / 8u;
-    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned per_xcd = KC_CHUNK ? ((n_chunks + (unsigned)kKcShares - 1u) / (unsigned)kKcShares) * KC_CHUNK : (n + (unsigned)kKcShares - 1u) / (unsigned)kKcShares;
+    const unsigned xcd = blockIdx.x % (unsigned)kKcShares;
     unsigned* ctr = &st->kc_next[xcd * 16u];
     if (tid == 0) s_next[0] = atomicAdd(ctr, 1u);
     __syncthreads();
     unsigned slot = 0u;
     for (unsigned j = s_next[0]; j < per_xcd;) {
         if (tid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
-        const unsigned b = KC_CHUNK ? ((j / (KC_CHUNK ? KC_CHUNK : 1u)) * 8u + xcd) * KC_CHUNK + j % (KC_CHUNK ? KC_CHUNK : 1u) : xcd * per_xcd + j;
+        const unsigned b = KC_CHUNK ? ((j / (KC_CHUNK ? KC_CHUNK : 1u)) * (unsigned)kKcShares + xcd) * KC_CHUNK + j % (KC_CHUNK ? KC_CHUNK : 1u) : xcd * per_xcd + j;
         const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
         if (idx >= 0) {
             const unsigned mask = V.bmask[V.blist[b]];
@@ -817,7 +987,7 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
         atomicAdd(&chg_partial[slot_c], (unsigned long long)c);
         atomicAdd(&chg_partial[kPartialGrid + slot_c], (unsigned long long)nblk);
         if (blockIdx.x == 0) { st->stat_frames += (unsigned long long)n_frames; st->stat_launches += 1ull; }
-        atomicMax(&st->kc_t[blockIdx.x & 7u], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
+        atomicMax(&st->kc_t[blockIdx.x % (unsigned)kKcTSlots], (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
     }
 }
 
@@ -1291,9 +1461,11 @@ struct op_volume {
     int* sel_list = nullptr;
     unsigned long long* sel_cand = nullptr;
     State* state = nullptr;
-    float* partial = nullptr;   // kMaxBatch x g1 x 8
+    float* partial = nullptr;   // kMaxBatch x ka_grid x 8
     uint2* pimg = nullptr;      // kMaxBatch x W*H packed {depth, rgba}
+    float2* ptile = nullptr;    // kMaxBatch x tiles: {min, max} valid depth of every 16 x 16 pixel tile (KA -> KB)
     size_t pimg_px = 0;
+    int pimg_w = 0, pimg_h = 0;
     unsigned long long* upd_partial = nullptr;
     unsigned long long* sel_partial = nullptr;
     unsigned long long* chg_partial = nullptr; // [0, grid): voxels written, [grid, 2 grid): blocks read, summed over launches
@@ -1578,15 +1750,17 @@ void frame_params(const op_volume* v, const float pose[16], const float* pose_in
 
 int vol_ensure_frame_buffers(op_volume* v) {
     const size_t npx = (size_t)v->cam.width * v->cam.height;
-    if (npx <= v->pimg_px) return OP_OK;
+    if (npx <= v->pimg_px && v->cam.width == v->pimg_w && v->cam.height == v->pimg_h) return OP_OK; // (KA's grid and the tile grid depend on both)
     OP_HIP(hipStreamSynchronize(v->stream)); // released buffers go back to a cache and may be handed out at once
     if (v->pimg) op::cached_free(v->pimg);
     if (v->partial) op::cached_free(v->partial);
-    v->pimg = nullptr; v->partial = nullptr; v->pimg_px = 0;
-    const size_t g1 = (npx + kPixPerWg - 1) / kPixPerWg;
+    if (v->ptile) op::cached_free(v->ptile);
+    v->pimg = nullptr; v->partial = nullptr; v->ptile = nullptr; v->pimg_px = 0; v->pimg_w = v->pimg_h = 0;
+    const size_t g1 = (size_t)ka_grid(v->cam.width, v->cam.height);
     OP_HIP(op::cached_malloc((void**)&v->pimg, (size_t)kMaxBatch * npx * sizeof(uint2)));
     OP_HIP(op::cached_malloc((void**)&v->partial, (size_t)kMaxBatch * g1 * 8 * sizeof(float)));
-    v->pimg_px = npx;
+    OP_HIP(op::cached_malloc((void**)&v->ptile, (size_t)kMaxBatch * tiles_w(v->cam.width) * tiles_h(v->cam.height) * sizeof(float2)));
+    v->pimg_px = npx; v->pimg_w = v->cam.width; v->pimg_h = v->cam.height;
     return OP_OK;
 }
 
@@ -1617,8 +1791,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     ++v->generation;
     if (!select_only && !cube_keys) v->log.push_back(op_volume::BatchRec{v->seq, F, I, Q, nf, depth_fmt, -1});
     const CamParams C = cam_params(v, depth_fmt);
-    const int npix = C.width * C.height;
-    const int g1 = (npix + kPixPerWg - 1) / kPixPerWg;
+    const int g1 = ka_grid(C.width, C.height);
     const VolView V = v->view();
     const bool sample = !select_only && v->prof_every > 0 && (v->prof_batch++ % (uint64_t)v->prof_every) == 0 &&
                         v->prof_events.size() < 4 * 65536;
@@ -1627,16 +1800,16 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         for (auto& e : ev) OP_HIP(hipEventCreate(&e));
         OP_HIP(hipEventRecord(ev[0], v->stream));
     }
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state, seq,
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->ptile, v->partial, v->state, seq,
                        (const unsigned*)v->n_blocks, v->hstat_dev);
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
     if (cube_keys)
         hipLaunchKernelGGL(k_mark_cubes, dim3((n_cubes + 255u) / 256u), dim3(256), 0, v->stream, V, v->state, cube_keys, n_cubes);
     else if (C.fast_px)
-        hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
+        hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg, (const float2*)v->ptile,
                            v->state, record ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_select<false>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg,
+        hipLaunchKernelGGL(k_select<false>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg, (const float2*)v->ptile,
                            v->state, record ? 1 : 0);
     if (sample) OP_HIP(hipEventRecord(ev[2], v->stream));
     if (select_only)
@@ -2007,7 +2180,7 @@ int op_volume_destroy(op_volume* v) {
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
-                    v->partial, v->pimg, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots};
+                    v->partial, v->pimg, v->ptile, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots};
     for (void* p : ptrs)
         if (p) op::cached_free(p);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
@@ -2116,8 +2289,8 @@ int op_volume_compute_bounding(op_volume* v, const void* depth, int depth_fmt, i
     frame_params(v, pose, nullptr, &F.f[0], &I.f[0]);
     Q.depth[0] = depth;
     const CamParams C = cam_params(v, depth_fmt);
-    const int npix = C.width * C.height, g1 = (npix + kPixPerWg - 1) / kPixPerWg;
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->partial, v->state, (unsigned)(++v->seq),
+    const int g1 = ka_grid(C.width, C.height);
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->ptile, v->partial, v->state, (unsigned)(++v->seq),
                        (const unsigned*)v->n_blocks, v->hstat_dev);
     OP_HIP(hipGetLastError());
     // no KB / KC follows to consume and zero the frame's bounding accumulators: do it here (the rows are read below)
@@ -2288,7 +2461,7 @@ int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_
     for (int i = 0; i < kPartialGrid; ++i) { chg += part[i]; blk += part[kPartialGrid + i]; }
     if (shader_cycles) { // the last launch has not been folded by a following batch yet
         unsigned long long kc = 0;
-        for (int x = 0; x < 8; ++x)
+        for (int x = 0; x < kKcTSlots; ++x)
             if (st.kc_t[x] > kc) kc = st.kc_t[x];
         *shader_cycles = st.stat_kc_ticks + kc;
     }

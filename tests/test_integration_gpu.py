@@ -646,3 +646,58 @@ def test_fusion_after_upload_mixes_general_and_fast_updates_bit_exactly(oracle):
         ov.integrate(d, rgb, pose); hv.IntegrateImage(d, rgb, pose)
     assert hv.BlockCount() > n_before + 200          # later frames allocate blocks of their own (fast update) next to the uploaded ones
     _compare(oracle, ov, hv)
+
+
+def test_coarse_selection_test_never_drops_a_block(oracle):
+    """k_select rejects whole 4 x 4 x 4 groups of blocks against the depth range of the image tiles they project into before it runs
+    the reference's per-block test.  The selected list must stay the reference's, entry for entry, on the inputs that stress that
+    shortcut: image sizes that are no multiple of the tile / of KA's rectangle, slanted and stepped surfaces (wide depth range per tile),
+    surfaces closer than the near plane and within centimetres of the camera, holes / NaN / negative / huge depths, 16-bit depth,
+    cameras whose principal point lies outside the image, random rigid poses."""
+    rng = np.random.default_rng(20260929)
+    sizes = [(160, 120), (37, 29), (65, 17), (16, 16), (129, 97), (200, 3), (1, 1), (64, 16), (63, 47)]
+    n_sel = 0
+    for case in range(27):
+        w, h = sizes[case % len(sizes)]
+        f = rng.uniform(0.6, 1.4) * w
+        cx, cy = (w * rng.uniform(0.3, 0.7), h * rng.uniform(0.3, 0.7)) if case % 5 else (-0.3 * w, 1.4 * h)
+        cam = (float(f), float(f * rng.uniform(0.9, 1.1)), float(cx), float(cy), w, h, 1000.0)
+        res = float(rng.choice([0.004, 0.01, 0.02]))
+        ov, hv = _mk(oracle, res, cam=cam, max_blocks=1 << 15)
+        u, v = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+        kind = case % 6
+        if kind == 0:    # slanted plane
+            d = 1.0 + 0.004 * u * rng.uniform(-1, 1) + 0.006 * v * rng.uniform(-1, 1)
+        elif kind == 1:  # steps: foreground object in front of a wall
+            d = np.where((u // max(1, w // 5) + v // max(1, h // 3)) % 2 == 0, 0.7, 2.6)
+        elif kind == 2:  # within centimetres of the camera .. near plane
+            d = np.where((u + v) % 5 == 0, rng.uniform(0.02, 0.3), 0.55 + 2.5 * u / max(w, 1) + 0.05 * np.sin(v / 7.0))
+        elif kind == 3:  # noise
+            d = rng.uniform(0.3, 4.5, (h, w))
+        elif kind == 4:  # bowl
+            d = 1.2 + 0.8 * (((u - w / 2) / max(w, 1)) ** 2 + ((v - h / 2) / max(h, 1)) ** 2)
+        else:            # far wall beyond the far plane next to a near one
+            d = np.where(u < w / 2, 6.5, 0.9)
+        d = np.broadcast_to(np.asarray(d, np.float32), (h, w)).copy()
+        d[rng.random((h, w)) < 0.05] = 0.0
+        d[rng.random((h, w)) < 0.01] = np.nan
+        d[rng.random((h, w)) < 0.01] = -2.0
+        d[rng.random((h, w)) < 0.005] = 1e7
+        x = np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-1.5, 1.5, 3)]).astype(np.float32)
+        pose = oracle.se3_exp(x) if case % 4 else np.eye(4, dtype=np.float32)
+        if case % 7 == 3:
+            d = np.round(np.nan_to_num(np.clip(d, 0, 60.0)) * 1000.0).astype(np.uint16)
+        oids, ocand = ov.prepare_cubes(d, pose)
+        hids, hcand = hv.PrepareCubes(d, pose, return_candidates=True)
+        assert ocand == hcand, "case %d: candidate count" % case
+        assert np.array_equal(oids, hids), "case %d (%dx%d, %s voxel): cube_id_list differs" % (case, w, h, res)
+        n_sel += len(oids)
+        omx, omn, oin = oracle.compute_bounding(ov.cam, d, pose)
+        hmx, hmn, hin = hv.ComputeBounding(d, pose)
+        assert oin == hin and np.array_equal(omx, hmx) and np.array_equal(omn, hmn), "case %d: bounding" % case
+        # and the fused result (KA's wide / narrow loads, tile outputs, KB, KC) on a second view of the same surface
+        c = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ov.integrate(d, c, pose)
+        hv.IntegrateImage(d, c, pose)
+        _compare(oracle, ov, hv)
+    assert n_sel > 20000, "the cases must select something (%d)" % n_sel
