@@ -220,7 +220,7 @@ def main():
                          "algorithmic_model": {"bytes_per_frame": alg_bytes_frame, "bytes_per_launch": alg_bytes, "gbs": alg_bytes / k3_s / 1e9,
                                                "ratio_to_hbm_peak": alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
                                                "note": "SURVEY 8(d): 40 B per updated voxel per FRAME + images, / launch time.  NOT a bound for a batched launch "
-                                                       "(it touches each voxel once per batch of up to 16 frames, so this ratio may exceed 1); it is one for "
+                                                       "(it touches each voxel once per batch of up to 32 frames, so this ratio may exceed 1); it is one for "
                                                        "a one-frame launch: see batch1"},
                          "shader_cycles_per_launch": kc_cycles, "shader_clock_ghz": kc_cycles / k3_s / 1e9 if k3_s > 0 else None},
         }
@@ -230,6 +230,7 @@ def main():
         nb1 = min(64, n_local)
         for k in range(nb1):
             hv.IntegrateSequence(depth[k:k + 1], rgb[k:k + 1], poses[k:k + 1])
+            hv.Flush()   # one frame per launch
         hv.Synchronize()
         st1, p1 = hv.Stats(), hv.ProfileRead()
         hv.ProfileEnable(0)
@@ -250,7 +251,7 @@ def main():
                 import counters as CT
                 import issue_model as IM
                 import tempfile
-                nfc = F
+                nfc = F if F < 32 else F // 32 * 32   # whole 32-frame batches, like the timed region's launches
                 with tempfile.NamedTemporaryFile(prefix="opc_frames_", suffix=".bin", dir="/tmp", delete=False) as tf:
                     np.array([nfc, W, H], np.int32).tofile(tf)
                     dh, ch = depth[:nfc].cpu().numpy(), rgb[:nfc].cpu().numpy()
@@ -263,13 +264,22 @@ def main():
                     os.unlink(fname)
                 kc = cnt["k_integrate"]
                 R = out["roofline"]
+                # the driver's launches fuse nfc / ceil(nfc / 32) frames each, the timed region's frames_per_launch (its last launch may be
+                # shorter): per-launch counts are scaled by the ratio (they are proportional to the frames of a launch to within a few %)
+                fpl_driver = nfc / float(-(-nfc // 32))
+                scale = frames_per_launch / fpl_driver
+                for key in ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch"):
+                    kc[key] *= scale
+                for c in kc:
+                    if isinstance(kc[c], dict) and "mean_per_launch" in kc[c]:
+                        kc[c]["mean_per_launch"] *= scale
                 R["traffic"] = kc["hbm_bytes_per_launch"]
                 R["hbm"].update({"traffic_bytes_per_launch": kc["hbm_bytes_per_launch"], "read_bytes_per_launch": kc["hbm_read_bytes_per_launch"],
                                  "write_bytes_per_launch": kc["hbm_write_bytes_per_launch"], "achieved": kc["hbm_bytes_per_launch"] / k3_s / 1e9, "unit": "GB/s",
                                  "frac": kc["hbm_bytes_per_launch"] / k3_s / 1e9 / HBM_PEAK_GBS, "traffic_over_model": kc["hbm_bytes_per_launch"] / batch_bytes,
                                  "source": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950, calibrated for this kernel's 4 B/lane plane rows: profiles/r03_calib.FETCH_SIZE.pmc.csv) "
                                            "and WRITE_SIZE (exact: profiles/r03_calib.WRITE_SIZE.pmc.csv), separate passes, tools/prof_driver.bin on the first %d frames "
-                                           "of this run (same batching)" % nfc})
+                                           "of this run (32-frame launches; per-launch figures scaled by %.3f to the timed region's %.1f frames per launch)" % (nfc, scale, frames_per_launch)})
                 costs_file = os.path.join(ROOT, "profiles", "r03_issue_costs.json")
                 cj = json.load(open(costs_file))
                 counts = {c: kc[c]["mean_per_launch"] for c in kc if isinstance(kc[c], dict) and "mean_per_launch" in kc[c]}
@@ -294,7 +304,7 @@ def main():
     # ---- the reference's own call pattern: one CubeHandler::IntegrateImage(cv::Mat depth, cv::Mat rgb, pose) per frame with
     # PAGEABLE host images (CubeHandler.cpp:197-210).  PCIe-inclusive, never the headline `value`: each call copies its two
     # images into the pinned staging ring (caller thread + 2 helper threads), the DMA runs on a copy stream and overlaps the
-    # previous batch's kernels, frames are fused 16 per launch group.  (From C++ -- tools/prof_driver.cpp "host" -- the same
+    # previous batch's kernels, frames are fused up to 32 per launch group.  (From C++ -- tools/prof_driver.cpp "host" -- the same
     # loop reaches ~13 k frames/s; here the Python interpreter sits in the loop.)
     if rank == 0 and world == 1 and not args.timed_only:
         nh = min(300, n_local)

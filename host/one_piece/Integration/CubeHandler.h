@@ -6,7 +6,7 @@
 // the reference holds a std::unordered_map<CubeID, VoxelCube> on the host; here the object owns a device-resident
 // volume (op_volume, include/onepiece_hip.h) and every member forwards to the C-ABI:
 //
-//   IntegrateImage      -> op_volume_integrate   (enqueues; frames are fused in batches of up to 16 per launch)
+//   IntegrateImage      -> op_volume_integrate   (enqueues; frames are fused in batches of up to 32 per launch)
 //   every reader        -> flushes + synchronises first (GetCubeMap, HasCube, ExtractTriangleMesh, WriteToFile, ...),
 //                          so the deferral cannot be observed (SURVEY 8b "Threading")
 //   GetCubeMap()        -> downloads into a fresh CubeMap and returns it BY VALUE, as the reference does

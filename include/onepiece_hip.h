@@ -119,6 +119,10 @@ int op_volume_set_camera(op_volume *v, const op_camera *cam); /* CubeHandler.h:1
 int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* CubeHandler.h:339-346 */
 int op_volume_clear(op_volume *v);                            /* CubeHandler.h:133-136 */
 int op_volume_sync(op_volume *v);
+/* Launches the frames op_volume_integrate / op_volume_integrate_sequence have queued (a batch smaller than 32), without
+ * waiting for them: for callers that want the GPU to start now although more frames will follow.  No reference counterpart
+ * (the reference fuses inside the call). */
+int op_volume_flush(op_volume *v);
 int op_volume_block_count(op_volume *v, size_t *n);
 int op_volume_has_cube(op_volume *v, int32_t x, int32_t y, int32_t z, int *present); /* :129-132 */
 /* Raw HIP stream handle of the volume (hipStream_t), for callers that time with HIP events. */
@@ -135,7 +139,7 @@ int op_volume_prepare_cubes(op_volume *v, const void *depth, int depth_fmt, int 
                             const float pose[16], const float *pose_inv, int32_t *ids_xyz,
                             size_t cap, size_t *n, size_t *n_candidates);
 /* CubeHandler::IntegrateImage(depth, rgb, pose) (CubeHandler.cpp:197-210 -> Integrator.cpp:36-94).
- * Asynchronous: frames are queued and fused up to 16 at a time (results identical to frame-by-frame
+ * Asynchronous: frames are queued and fused up to 32 at a time (results identical to frame-by-frame
  * fusion); every accessor / setter / op_volume_sync flushes the queue first.  OP_MEM_HOST images are
  * copied before the call returns; OP_MEM_DEVICE images must stay valid until the next
  * synchronising call. */
@@ -148,8 +152,9 @@ int op_volume_integrate_cubes(op_volume *v, const void *depth, int depth_fmt, co
                               const float pose[16], const float *pose_inv, const int32_t *keys_xyz, size_t n);
 /* Multi-frame form of the same call for frames already resident on the device: frame f uses
  * depth + f*depth_stride_bytes, rgb + f*rgb_stride_bytes, poses + 16*f.  Results are bit-identical
- * to n_frames sequential op_volume_integrate calls: frames are fused in batches of up to 16 per
- * kernel launch, and inside a batch every voxel applies its frames in order in registers. */
+ * to n_frames sequential op_volume_integrate calls -- the frames join the same queue: they are fused in batches of
+ * up to 32 per kernel launch (inside a batch every voxel applies its frames in order in registers), a remainder
+ * waits for the next frames or the next flushing call, and the images must stay valid until then. */
 int op_volume_integrate_sequence(op_volume *v, const void *depth, size_t depth_stride_bytes,
                                  int depth_fmt, const uint8_t *rgb, size_t rgb_stride_bytes,
                                  const float *poses, size_t n_frames);
@@ -159,7 +164,7 @@ int op_volume_integrate_sequence(op_volume *v, const void *depth, size_t depth_s
 int op_volume_stats(op_volume *v, uint64_t *frames, uint64_t *blocks_selected, uint64_t *voxels_visited,
                     uint64_t *voxels_updated);
 /* Launch-level counters since create/clear (synchronises; measurement hook, no reference counterpart):
- * Integrator::IntegrateImage runs as ONE kernel launch per batch of up to 16 frames that reads every
+ * Integrator::IntegrateImage runs as ONE kernel launch per batch of up to 32 frames that reads every
  * selected block once and writes every voxel that changed once, so the HBM traffic of a launch is
  * bounded below by 20 B x 512 x blocks_read + 20 B x voxels_written (+ the packed images), whatever
  * the number of frames in the batch.  launches = k_integrate launches that fused something; shader_cycles = their summed
@@ -173,7 +178,7 @@ int op_volume_stats_launches(op_volume *v, uint64_t *launches, uint64_t *blocks_
  * pool before the host noticed (results are unaffected; the replays cost time).  Does not synchronise. */
 int op_volume_growth_stats(op_volume *v, uint64_t *max_blocks, uint64_t *grows, uint64_t *replayed_batches);
 /* Measurement hook (no reference counterpart): with sample_every = k > 0, every k-th launch group
- * (one group = one op_volume_integrate call, or one batch of up to 16 frames of
+ * (one group = one op_volume_integrate call, or one batch of up to 32 frames of
  * op_volume_integrate_sequence) is bracketed by HIP events on the volume's stream.  profile_read
  * synchronises and returns the summed durations in ms of the three kernels -- [0] frame
  * preparation + ComputeBounding (KA), [1] PrepareCubes (KB), [2] Integrator::IntegrateImage (KC) --

@@ -92,6 +92,7 @@ SIGNATURES = {
     "op_volume_set_near_far": (C.c_int, [_vp, C.c_float, C.c_float]),
     "op_volume_clear": (C.c_int, [_vp]),
     "op_volume_sync": (C.c_int, [_vp]),
+    "op_volume_flush": (C.c_int, [_vp]),
     "op_volume_block_count": (C.c_int, [_vp, _szp]),
     "op_volume_has_cube": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int)]),
     "op_volume_stream": (C.c_int, [_vp, C.POINTER(_vp)]),

@@ -69,7 +69,12 @@ constexpr int kTile = 16;             // KA -> KB: min / max valid depth per 16 
 #define KB_GRID 512
 #endif
 constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
-constexpr int kMaxBatch = 16;        // frames fused per launch by op_volume_integrate_sequence
+#ifndef OP_MAX_BATCH
+#define OP_MAX_BATCH 32
+#endif
+constexpr int kMaxBatch = OP_MAX_BATCH; // frames fused per launch by op_volume_integrate_sequence (<= 32: one bit of the batch mask each)
+constexpr int kKaFrames = 16;        // frames per k_prepare_frames launch (its poses + frustum planes travel as kernel arguments: 160 B per frame)
+static_assert(kMaxBatch <= 32 && kMaxBatch % kKaFrames == 0, "batch mask is 32 bits; KA takes kKaFrames frames per launch");
 constexpr int kAccSlots = 16;        // see State::acc
 // KC (k_integrate): ZT voxels of one (x, y) column of a block per thread (a workgroup of 8 / ZT waves owns a block), the waves
 // per SIMD it is compiled for, and its grid = exactly the workgroups that are resident then (they draw blocks of the batch's
@@ -101,6 +106,7 @@ struct CamParams {
 struct PoseFwd { float pose[16]; float planes[24]; }; // planes: top, left, right, bottom, near, far
 struct PoseInv { float m[12]; };                      // rows 0..2 of pose^-1
 struct BatchFwd { PoseFwd f[kMaxBatch]; };
+struct KaFwd { PoseFwd f[kKaFrames]; };            // the slice of a BatchFwd one KA launch gets
 struct BatchInv { PoseInv f[kMaxBatch]; };
 struct BatchPtrs { const void* depth[kMaxBatch]; const unsigned char* rgb[kMaxBatch]; }; // device images of each frame
 
@@ -355,13 +361,13 @@ __host__ __device__ inline int ka_grid(int w, int h) { return ((w + kKaW - 1) / 
 __host__ __device__ inline int tiles_w(int w) { return (w + kTile - 1) / kTile; }
 __host__ __device__ inline int tiles_h(int h) { return (h + kTile - 1) / kTile; }
 
-__global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C, BatchPtrs Q, uint2* __restrict__ pimg, float2* __restrict__ ptile,
+__global__ __launch_bounds__(256) void k_prepare_frames(KaFwd B, int f0, CamParams C, BatchPtrs Q, uint2* __restrict__ pimg, float2* __restrict__ ptile,
                                                         float* __restrict__ partial, State* st, unsigned seq,
                                                         const unsigned* __restrict__ n_blocks, unsigned* __restrict__ hstat) {
     __shared__ float s_red[4][6];
     __shared__ unsigned s_cnt[4];
     __shared__ float s_tile[4][4][2];
-    const int tid = threadIdx.x, f = blockIdx.y;
+    const int tid = threadIdx.x, f = f0 + (int)blockIdx.y; // frame of the batch
     if (blockIdx.x == 0 && f == 0 && tid == 0) {
         st->n_batch = 0; st->n_rec = 0; // new batch: empty lists
         st->cur_seq = seq;
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256) void k_prepare_frames(BatchFwd B, CamParams C,
             st->stat_kc_ticks += kc;
         }
     }
-    const PoseFwd& P = B.f[f];
+    const PoseFwd& P = B.f[blockIdx.y];
     const int npix = C.width * C.height;
     const void* dptr = Q.depth[f];
     const unsigned char* cptr = Q.rgb[f];
@@ -1800,8 +1806,13 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         for (auto& e : ev) OP_HIP(hipEventCreate(&e));
         OP_HIP(hipEventRecord(ev[0], v->stream));
     }
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, nf), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->ptile, v->partial, v->state, seq,
-                       (const unsigned*)v->n_blocks, v->hstat_dev);
+    for (int f0 = 0; f0 < nf; f0 += kKaFrames) {
+        KaFwd A;
+        const int na = nf - f0 < kKaFrames ? nf - f0 : kKaFrames;
+        std::memcpy(A.f, F.f + f0, sizeof(PoseFwd) * (size_t)na);
+        hipLaunchKernelGGL(k_prepare_frames, dim3(g1, na), dim3(256), 0, v->stream, A, f0, C, Q, v->pimg, v->ptile, v->partial, v->state, seq,
+                           (const unsigned*)v->n_blocks, v->hstat_dev);
+    }
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
     if (cube_keys)
         hipLaunchKernelGGL(k_mark_cubes, dim3((n_cubes + 255u) / 256u), dim3(256), 0, v->stream, V, v->state, cube_keys, n_cubes);
@@ -2260,6 +2271,11 @@ int op_volume_sync(op_volume* v) {
     return vol_check(v);
 }
 
+int op_volume_flush(op_volume* v) {
+    OP_VOL(v);
+    return vol_flush(v);
+}
+
 int op_volume_stream(op_volume* v, void** stream) {
     OP_VOL(v);
     if (!stream) return fail(OP_ERR_INVALID, "null stream out");
@@ -2290,7 +2306,9 @@ int op_volume_compute_bounding(op_volume* v, const void* depth, int depth_fmt, i
     Q.depth[0] = depth;
     const CamParams C = cam_params(v, depth_fmt);
     const int g1 = ka_grid(C.width, C.height);
-    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, F, C, Q, v->pimg, v->ptile, v->partial, v->state, (unsigned)(++v->seq),
+    KaFwd A;
+    A.f[0] = F.f[0];
+    hipLaunchKernelGGL(k_prepare_frames, dim3(g1, 1), dim3(256), 0, v->stream, A, 0, C, Q, v->pimg, v->ptile, v->partial, v->state, (unsigned)(++v->seq),
                        (const unsigned*)v->n_blocks, v->hstat_dev);
     OP_HIP(hipGetLastError());
     // no KB / KC follows to consume and zero the frame's bounding accumulators: do it here (the rows are read below)
@@ -2412,23 +2430,17 @@ int op_volume_integrate_sequence(op_volume* v, const void* depth, size_t depth_s
                                  size_t rgb_stride_bytes, const float* poses, size_t n_frames) {
     OP_VOL(v);
     if (!depth || !rgb || !poses) return fail(OP_ERR_INVALID, "null argument");
-    OP_TRY(vol_flush(v));
-    BatchFwd F;
-    BatchInv I;
-    BatchPtrs Q{};
-    // balanced batches (sizes differ by at most one): 100 frames -> 7 launches of 14-15 frames
-    // rather than 6 x 16 + 4, so no launch group is left with a poorly amortised tail
-    const size_t n_batches = (n_frames + kMaxBatch - 1) / kMaxBatch;
-    size_t f0 = 0;
-    for (size_t b = 0; b < n_batches; ++b) {
-        const int nf = (int)(n_frames / n_batches + (b < n_frames % n_batches ? 1 : 0));
-        for (int f = 0; f < nf; ++f) {
-            frame_params(v, poses + 16 * (f0 + f), nullptr, &F.f[f], &I.f[f]);
-            Q.depth[f] = (const char*)depth + (f0 + f) * depth_stride_bytes;
-            Q.rgb[f] = rgb + (f0 + f) * rgb_stride_bytes;
-        }
-        OP_TRY(vol_enqueue_batch(v, F, I, Q, nf, depth_fmt, false, false));
-        f0 += (size_t)nf;
+    // The frames join the queue op_volume_integrate fills: full batches are launched as they complete, the remainder waits for the next
+    // frames (of this or the next call) or for the first call that flushes -- a stream of calls fuses kMaxBatch frames per launch
+    // whatever the calls' lengths are.  (The device images must stay valid until the next synchronising call, as for op_volume_integrate.)
+    if (v->pend_n > 0 && v->pend_fmt != depth_fmt) OP_TRY(vol_flush(v));
+    for (size_t f = 0; f < n_frames; ++f) {
+        const int slot = v->pend_n;
+        frame_params(v, poses + 16 * f, nullptr, &v->pend_F.f[slot], &v->pend_I.f[slot]);
+        v->pend_P.depth[slot] = (const char*)depth + f * depth_stride_bytes;
+        v->pend_P.rgb[slot] = rgb + f * rgb_stride_bytes;
+        v->pend_fmt = depth_fmt;
+        if (++v->pend_n == kMaxBatch) OP_TRY(vol_flush(v));
     }
     return OP_OK;
 }

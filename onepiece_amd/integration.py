@@ -156,6 +156,8 @@ class CubeHandler:
         L.check(self._lib.op_volume_integrate(self._h, pd, fmt, pr, mem, _fp(pose), _fp(pinv) if pinv is not None else None))
         if mem == L.OP_MEM_DEVICE:
             self._alive.append((_k1, _k2))
+            if len(self._alive) > 4096:
+                self.Synchronize()
 
     def IntegrateCubes(self, depth, rgb, pose, cube_ids, pose_inv=None):
         """Integrator::IntegrateImage (Integrator.cpp:36-94) for a caller-chosen cube list (n x 3 int32): the frame is fused
@@ -185,6 +187,14 @@ class CubeHandler:
         npx = self.camera.width * self.camera.height
         dstride = npx * (2 if fmt == L.OP_DEPTH_U16 else 4)
         L.check(self._lib.op_volume_integrate_sequence(self._h, pd, dstride, fmt, pr, npx * 3, _fp(poses), n))
+        # a remainder of the call waits in the library's queue for the next frames: the tensors stay referenced until the next Synchronize
+        self._alive.append((_k1, _k2))
+        if len(self._alive) > 4096:
+            self.Synchronize()
+
+    def Flush(self):
+        """launch the queued frames now (a batch smaller than 32) without waiting for them"""
+        L.check(self._lib.op_volume_flush(self._h))
 
     def Synchronize(self):
         L.check(self._lib.op_volume_sync(self._h))

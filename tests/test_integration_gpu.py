@@ -237,8 +237,8 @@ def test_sum_form_merge_kernels_match_reference_merge(oracle):
 
 
 def test_batched_sequence_over_batch_boundary_matches_oracle(oracle):
-    """37 device-resident frames = batches of 16 + 16 + 5 inside op_volume_integrate_sequence; a
-    voxel sees its frames in order inside a batch, so the result must stay bit-identical to the
+    """37 device-resident frames = a batch of 32 + a remainder of 5 that waits in the queue (the second pass joins it: 5 + 27, then 10
+    launched by the accessor); a voxel sees its frames in order inside a batch, so the result must stay bit-identical to the
     oracle's frame-by-frame fusion.  Includes frames that revisit the same blocks."""
     import torch
     dev = torch.device("cuda:0")
@@ -701,3 +701,31 @@ def test_coarse_selection_test_never_drops_a_block(oracle):
         hv.IntegrateImage(d, c, pose)
         _compare(oracle, ov, hv)
     assert n_sel > 20000, "the cases must select something (%d)" % n_sel
+
+
+def test_sequence_calls_share_one_queue_with_single_frames(oracle):
+    """op_volume_integrate_sequence and op_volume_integrate fill the same queue: calls of 3, 1 (single frame), 40, 7 frames, an explicit
+    Flush in between and a format change give launches of every size from 1 to 32 -- the volume equals frame-by-frame fusion."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 3 + 1 + 40 + 7 + 33
+    depth, rgb, poses = S.room_sequence_torch(100, n, dev)
+    torch.cuda.synchronize()
+    ov, hv = _mk(oracle, 0.01)
+    dn, cn = depth.cpu().numpy(), rgb.cpu().numpy()
+    k = 0
+    hv.IntegrateSequence(depth[k:k + 3], rgb[k:k + 3], poses[k:k + 3]); k += 3
+    hv.IntegrateImage(depth[k], rgb[k], poses[k]); k += 1                      # device tensors, single-frame call: same queue
+    hv.IntegrateSequence(depth[k:k + 40], rgb[k:k + 40], poses[k:k + 40]); k += 40
+    hv.Flush()                                                                 # 12 queued frames go now
+    hv.IntegrateSequence(depth[k:k + 7], rgb[k:k + 7], poses[k:k + 7]); k += 7
+    d16 = (depth[k:k + 33] * 1000.0).round().to(torch.int16)                   # format change flushes the 7
+    hv.IntegrateSequence(d16, rgb[k:k + 33], poses[k:k + 33])
+    for i in range(k):
+        ov.integrate(dn[i], cn[i], poses[i])
+    d16n = d16.cpu().numpy().view(np.uint16)
+    for i in range(33):
+        ov.integrate(d16n[i], cn[k + i], poses[k + i])
+    st = hv.Stats()
+    assert st["frames"] == n and st["launches"] == 5, st   # 32 + 12 | 7 | 32 + 1
+    _compare(oracle, ov, hv)

@@ -8,7 +8,7 @@
 // threshold 0.01 -- ICPTest.cpp's configuration), `reps` times.
 // With "host": one op_volume_integrate call per frame with pageable HOST images (float32 and uint16 depth), the
 // reference's call pattern (PCIe-inclusive rate).
-// With "batch=N" (N = 1..16): the default fusion loop, but the sequence is handed over N frames per call, so every
+// With "batch=N" (N = 1..32): the default fusion loop, but the sequence is handed over N frames per call, so every
 // k_integrate launch fuses N frames (batch=1: one frame per launch, where SURVEY 8(d)'s byte model is a lower bound of
 // the launch's HBM traffic).
 // Build: hipcc --offload-arch=gfx950 -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o tools/prof_driver.bin
@@ -154,7 +154,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     int batch = n;
-    if (argc > 4 && std::string(argv[4]).rfind("batch=", 0) == 0) batch = atoi(argv[4] + 6);
+    bool per_call_launch = false; // batch=N: every call's frames are launched as their own batch (else they join the library's queue: 32 per launch)
+    if (argc > 4 && std::string(argv[4]).rfind("batch=", 0) == 0) { batch = atoi(argv[4] + 6); per_call_launch = true; }
     if (batch < 1) batch = 1;
     for (int r = 0; r < reps; ++r) {
         CK(op_volume_clear(v));
@@ -162,6 +163,7 @@ int main(int argc, char** argv) {
         for (int f0 = 0; f0 < n; f0 += batch) {
             const int nf = n - f0 < batch ? n - f0 : batch;
             CK(op_volume_integrate_sequence(v, d_depth + npx * f0, npx * 4, OP_DEPTH_F32, d_rgb + npx * 3 * f0, npx * 3, poses.data() + (size_t)f0 * 16, (size_t)nf));
+            if (per_call_launch) CK(op_volume_flush(v));
         }
         CK(op_volume_sync(v));
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

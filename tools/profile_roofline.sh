@@ -3,7 +3,7 @@
 # gpurun_out/$TAG/ (copy into profiles/ with the round prefix):
 #   valu_ubench*.txt, issue_costs.json   issue cost per instruction class in shader cycles (s_memtime ticks)
 #   calib.*                        tools/hbm_calib.bin: known-traffic kernels under FETCH_SIZE / WRITE_SIZE / TCC_EA0 request counters
-#   batch1.*  / batch16.*          tools/prof_driver.bin with ONE frame per k_integrate launch / with full batches:
+#   batch1.*  / batch32.*          tools/prof_driver.bin with ONE frame per k_integrate launch / with full batches:
 #                                  --kernel-trace --stats durations, HBM counters, SQ instruction and cycle counters
 # Every --pmc group is its own pass (never combined with other trace domains).
 TAG=${TAG:-r03}
@@ -39,18 +39,18 @@ fi
 # ---- fusion: one frame per launch, and full batches
 python $R/tools/dump_frames.py /tmp/frames.bin ${NFRAMES:-96} 0 > /dev/null
 $R/tools/prof_driver.bin /tmp/frames.bin 2 0.005 batch=1 > $OUT/batch1.driver.txt 2>&1
-$R/tools/prof_driver.bin /tmp/frames.bin 2 0.005 batch=16 > $OUT/batch16.driver.txt 2>&1
+$R/tools/prof_driver.bin /tmp/frames.bin 2 0.005 batch=32 > $OUT/batch32.driver.txt 2>&1
 pass batch1 "" $R/tools/prof_driver.bin /tmp/frames.bin 2 0.005 batch=1
-pass batch16 "" $R/tools/prof_driver.bin /tmp/frames.bin 2 0.005 batch=16
+pass batch32 "" $R/tools/prof_driver.bin /tmp/frames.bin 2 0.005 batch=32
 for C in "${HBM_GROUPS[@]}"; do
   pass batch1 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=1
-  pass batch16 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=16
+  pass batch32 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=32
 done
 for C in "${SQ_GROUPS[@]}"; do
   pass batch1 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=1
-  pass batch16 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=16
+  pass batch32 "$C" $R/tools/prof_driver.bin /tmp/frames.bin 1 0.005 batch=32
 done
-cat $OUT/*.log > $OUT/all_logs.txt 2>/dev/null; for B in batch1 batch16; do  # the launch's duration in shader cycles is printed by the driver (op_volume_stats_launches)
+cat $OUT/*.log > $OUT/all_logs.txt 2>/dev/null; for B in batch1 batch32; do  # the launch's duration in shader cycles is printed by the driver (op_volume_stats_launches)
   CYC=$(tail -1 $OUT/$B.driver.txt | sed 's/.* \([0-9]*\) shader cycles per launch.*/\1/')
   python $R/tools/issue_model.py model_pmc $OUT/issue_costs.json $OUT $B $CYC > $OUT/$B.issue_model.json
 done
