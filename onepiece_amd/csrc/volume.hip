@@ -74,7 +74,12 @@ constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgro
 #endif
 constexpr int kMaxBatch = OP_MAX_BATCH; // frames fused per launch by op_volume_integrate_sequence (<= 32: one bit of the batch mask each)
 constexpr int kKaFrames = 16;        // frames per k_prepare_frames launch (its poses + frustum planes travel as kernel arguments: 160 B per frame)
-static_assert(kMaxBatch <= 32 && kMaxBatch % kKaFrames == 0, "batch mask is 32 bits; KA takes kKaFrames frames per launch");
+static_assert(kMaxBatch <= 64 && kMaxBatch % kKaFrames == 0, "one bit of the batch mask per frame; KA takes kKaFrames frames per launch");
+typedef std::conditional<(kMaxBatch > 32), unsigned long long, unsigned>::type bmask_t; // a block's batch mask: which frames of the batch selected it
+__host__ __device__ inline int mask_ctz(unsigned m) { return __builtin_ctz(m); }
+__host__ __device__ inline int mask_ctz(unsigned long long m) { return __builtin_ctzll(m); }
+__device__ inline unsigned mask_popc(unsigned m) { return (unsigned)__popc(m); }
+__device__ inline unsigned mask_popc(unsigned long long m) { return (unsigned)__popcll(m); }
 constexpr int kAccSlots = 16;        // see State::acc
 // KC (k_integrate): ZT voxels of one (x, y) column of a block per thread (a workgroup of 8 / ZT waves owns a block), the waves
 // per SIMD it is compiled for, and its grid = exactly the workgroups that are resident then (they draw blocks of the batch's
@@ -150,7 +155,7 @@ struct VolView {
     float* pool;
     unsigned max_blocks;
     unsigned* n_blocks;
-    unsigned* bmask;           // per TABLE slot: which frames of the current batch selected the block
+    bmask_t* bmask;            // per TABLE slot: which frames of the current batch selected the block
     int* blist;                // table slots touched by the current batch
     int* sel_list;             // record mode (PrepareCubes): table slot (translated to pool slot by k_finish_select) + candidate rank
     unsigned long long* sel_cand;
@@ -321,7 +326,7 @@ __global__ void k_finish_select(VolView V, State* st) {
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u; // as KC does
     const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
     const unsigned nr = st->n_rec < V.max_blocks ? st->n_rec : V.max_blocks;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) V.bmask[V.blist[i]] = 0u;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) V.bmask[V.blist[i]] = (bmask_t)0;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) V.sel_list[i] = V.tvals[V.sel_list[i]];
 }
 
@@ -335,7 +340,7 @@ __global__ void k_mark_cubes(VolView V, State* st, const int* __restrict__ keys,
     bool created;
     const int slot = table_claim(V, st, x, y, z, &created);
     if (slot < 0) return;
-    if (atomicOr(&V.bmask[slot], 1u) == 0u) { // a key listed twice is fused once
+    if (atomicOr(&V.bmask[slot], (bmask_t)1) == (bmask_t)0) { // a key listed twice is fused once
         const unsigned pos = atomicAdd(&st->n_batch, 1u);
         if (pos < V.max_blocks) V.blist[pos] = slot;
     }
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
     const float cube_res = C.res * 8.0f; // CubeHandler.cpp:164
     const float half = C.res / 2;        // VoxelCube.h:47
     const float o_lo = 0.0f * C.res + half, o_hi = 7.0f * C.res + half; // VoxelCentroidOffSet of x = 0 / 7
-    const unsigned fbit = 1u << f;
+    const bmask_t fbit = (bmask_t)1 << f;
     // super-block grid of the frame's range (<= 1024^3 < 2^32 entries)
     const unsigned nsi = (unsigned)(ni + kSB - 1) / kSB, nsj = (unsigned)(nj + kSB - 1) / kSB, nsk = (unsigned)(nk + kSB - 1) / kSB;
     const unsigned n_super = nsi * nsj * nsk;
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
                         bool created;
                         pool_idx = table_claim(V, st, bi, bj, bk, &created); // table slot; KC translates it
                         if (pool_idx >= 0) {
-                            first = atomicOr(&V.bmask[pool_idx], fbit) == 0u;
+                            first = atomicOr(&V.bmask[pool_idx], fbit) == (bmask_t)0;
                             rec = record != 0;
                         }
                     }
@@ -899,8 +904,8 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
         const unsigned b = KC_CHUNK ? ((j / (KC_CHUNK ? KC_CHUNK : 1u)) * (unsigned)kKcShares + xcd) * KC_CHUNK + j % (KC_CHUNK ? KC_CHUNK : 1u) : xcd * per_xcd + j;
         const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
         if (idx >= 0) {
-            const unsigned mask = V.bmask[V.blist[b]];
-            if (zg == 0) { sel += __popc(mask); ++nblk; }
+            const bmask_t mask = V.bmask[V.blist[b]];
+            if (zg == 0) { sel += mask_popc(mask); ++nblk; }
             const int kx = V.keys[3 * idx], ky = V.keys[3 * idx + 1], kz = V.keys[3 * idx + 2];
             float* vox = V.pool + (size_t)idx * kBlockFloats + (zg * ZT) * 64 + lane;
             float s[ZT], w[ZT], c0[ZT], c1[ZT], c2[ZT], pz[ZT];
@@ -954,17 +959,17 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
             kc_v2u recA[ZT], recB[ZT];
             float zcA[ZT], zcB[ZT];
             auto frames = [&](auto plain_c) {
-                unsigned m = mask;                                // wave-uniform
+                bmask_t m = mask;                                 // wave-uniform
                 if (!m) return;
-                int f = __builtin_ctz(m); m &= m - 1u;
+                int f = mask_ctz(m); m &= m - 1u;
                 project(f, recA, zcA);
                 for (;;) {
                     const bool more1 = m != 0u;
-                    if (more1) { f = __builtin_ctz(m); m &= m - 1u; project(f, recB, zcB); }
+                    if (more1) { f = mask_ctz(m); m &= m - 1u; project(f, recB, zcB); }
                     apply(recA, zcA, plain_c);
                     if (!more1) break;
                     const bool more2 = m != 0u;
-                    if (more2) { f = __builtin_ctz(m); m &= m - 1u; project(f, recA, zcA); }
+                    if (more2) { f = mask_ctz(m); m &= m - 1u; project(f, recA, zcA); }
                     apply(recB, zcB, plain_c);
                     if (!more2) break;
                 }
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
             chg += (unsigned)__popc(changed);
         }
         __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
-        if (b < n && tid == 0) V.bmask[V.blist[b]] = 0u;   // the owner clears it for the next batch
+        if (b < n && tid == 0) V.bmask[V.blist[b]] = (bmask_t)0; // the owner clears it for the next batch
         slot ^= 1u;
         j = s_next[slot];
     }
@@ -1462,7 +1467,7 @@ struct op_volume {
     int* keys = nullptr;
     float* pool = nullptr;
     unsigned* n_blocks = nullptr;
-    unsigned* bmask = nullptr;
+    bmask_t* bmask = nullptr;
     int* blist = nullptr;
     int* sel_list = nullptr;
     unsigned long long* sel_cand = nullptr;
@@ -1551,7 +1556,7 @@ int vol_reset(op_volume* v) {
     ++v->generation;
     hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, v->tkeys, v->tvals, (size_t)v->table_size);
     OP_HIP(hipMemsetAsync(v->n_blocks, 0, sizeof(unsigned), v->stream));
-    OP_HIP(hipMemsetAsync(v->bmask, 0, sizeof(unsigned) * (size_t)v->table_size, v->stream));
+    OP_HIP(hipMemsetAsync(v->bmask, 0, sizeof(bmask_t) * (size_t)v->table_size, v->stream));
     OP_HIP(hipMemsetAsync(v->state, 0, sizeof(State), v->stream));
     OP_HIP(hipMemsetAsync(v->upd_partial, 0, sizeof(unsigned long long) * kPartialGrid, v->stream));
     OP_HIP(hipMemsetAsync(v->sel_partial, 0, sizeof(unsigned long long) * kPartialGrid, v->stream));
@@ -1575,7 +1580,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     float* pool = nullptr;
     int *keys = nullptr, *blist = nullptr, *sel_list = nullptr, *tvals = nullptr;
     unsigned long long *sel_cand = nullptr, *tkeys = nullptr;
-    unsigned* bmask = nullptr;
+    bmask_t* bmask = nullptr;
     hipError_t e = op::cached_malloc((void**)&pool, sizeof(float) * kBlockFloats * (size_t)new_max);
     if (e == hipSuccess) e = op::cached_malloc((void**)&keys, sizeof(int) * 3 * (size_t)new_max);
     if (e == hipSuccess) e = op::cached_malloc((void**)&blist, sizeof(int) * (size_t)new_max);
@@ -1583,7 +1588,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     if (e == hipSuccess) e = op::cached_malloc((void**)&sel_cand, sizeof(unsigned long long) * (size_t)new_max);
     if (e == hipSuccess) e = op::cached_malloc((void**)&tkeys, sizeof(unsigned long long) * (size_t)new_table);
     if (e == hipSuccess) e = op::cached_malloc((void**)&tvals, sizeof(int) * (size_t)new_table);
-    if (e == hipSuccess) e = op::cached_malloc((void**)&bmask, sizeof(unsigned) * (size_t)new_table);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&bmask, sizeof(bmask_t) * (size_t)new_table);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         void* got[] = {pool, keys, blist, sel_list, sel_cand, tkeys, tvals, bmask};
@@ -1597,7 +1602,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     }
     hipLaunchKernelGGL(k_fill_pool, dim3(4096), dim3(256), 0, v->stream, pool, (size_t)n_valid, (size_t)(new_max - n_valid));
     hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, tkeys, tvals, (size_t)new_table);
-    OP_HIP(hipMemsetAsync(bmask, 0, sizeof(unsigned) * (size_t)new_table, v->stream));
+    OP_HIP(hipMemsetAsync(bmask, 0, sizeof(bmask_t) * (size_t)new_table, v->stream));
     if (n_valid) hipLaunchKernelGGL(k_rehash, dim3((n_valid + 255) / 256), dim3(256), 0, v->stream, tkeys, tvals, new_table - 1, (const int*)keys, n_valid);
     OP_HIP(hipMemcpyAsync(v->n_blocks, &n_valid, sizeof(unsigned), hipMemcpyHostToDevice, v->stream));
     OP_HIP(hipGetLastError());
@@ -2162,7 +2167,7 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     OP_HIP_C(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
     OP_HIP_C(op::cached_malloc((void**)&v->tkeys, sizeof(unsigned long long) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->tvals, sizeof(int) * (size_t)v->table_size));
-    OP_HIP_C(op::cached_malloc((void**)&v->bmask, sizeof(unsigned) * (size_t)v->table_size));
+    OP_HIP_C(op::cached_malloc((void**)&v->bmask, sizeof(bmask_t) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->blist, sizeof(int) * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->sel_partial, sizeof(unsigned long long) * kPartialGrid));
     OP_HIP_C(op::cached_malloc((void**)&v->keys, sizeof(int) * 3 * (size_t)v->max_blocks));
