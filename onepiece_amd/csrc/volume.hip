@@ -455,7 +455,10 @@ __global__ __launch_bounds__(256) void k_prepare_frames(KaFwd B, int f0, CamPara
             const float q1 = ((M[4] * x + M[5] * y) + M[6] * z) + M[7] * 1.0f;
             const float q2 = ((M[8] * x + M[9] * y) + M[10] * z) + M[11] * 1.0f;
             const float q3 = ((M[12] * x + M[13] * y) + M[14] * z) + M[15] * 1.0f;
-            const float p0 = q0 / q3, p1 = q1 / q3, p2 = q2 / q3;
+            // TransformPoints divides by w (Geometry.cpp:24-26).  A rigid pose has the bottom row (0, 0, 0, 1), so w is exactly 1 and x / 1 = x:
+            // the three IEEE divisions (33 of the ~220 instructions per pixel) only run when some lane's w is not 1 (a projective "pose", NaN).
+            float p0 = q0, p1 = q1, p2 = q2;
+            if (__builtin_amdgcn_ballot_w64(q3 != 1.0f) != 0ull) { p0 = q0 / q3; p1 = q1 / q3; p2 = q2 / q3; }
             bool in = true; // Frustum::ContainPoint incl. its early "== 0 -> true" (Frustum.h:74-103)
 #pragma unroll
             for (int k = 0; k < 6; ++k) {

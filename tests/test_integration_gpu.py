@@ -729,3 +729,23 @@ def test_sequence_calls_share_one_queue_with_single_frames(oracle):
     st = hv.Stats()
     assert st["frames"] == n and st["launches"] == 5, st   # 32 + 12 | 7 | 32 + 1
     _compare(oracle, ov, hv)
+
+
+def test_poses_whose_bottom_row_is_not_0001(oracle):
+    """TransformPoints divides by w (Geometry.cpp:24-26); k_prepare_frames skips the division while every lane's w is exactly 1.  Poses with a
+    scaled or projective bottom row take the dividing path and must agree with the oracle bit for bit as well (bounding, list, volume)."""
+    cam = (128.7, 128.8, 79.7, 59.6, 160, 120, 1000.0)
+    d, rgb, _ = S.room_frame(12)
+    d = np.ascontiguousarray(d[::4, ::4]); rgb = np.ascontiguousarray(rgb[::4, ::4])
+    base = S.room_pose(12).astype(np.float32)
+    for bottom in ((0.0, 0.0, 0.0, 2.0), (1e-3, -2e-3, 5e-4, 1.0), (0.0, 0.0, 0.0, 1.0)):
+        pose = base.copy(); pose[3] = bottom
+        ov, hv = _mk(oracle, 0.02, cam=cam)
+        omx, omn, oin = oracle.compute_bounding(ov.cam, d, pose)
+        hmx, hmn, hin = hv.ComputeBounding(d, pose)
+        assert oin == hin and np.array_equal(omx, hmx) and np.array_equal(omn, hmn), bottom
+        oids, ocand = ov.prepare_cubes(d, pose)
+        hids, hcand = hv.PrepareCubes(d, pose, return_candidates=True)
+        assert ocand == hcand and np.array_equal(oids, hids), bottom
+        ov.integrate(d, rgb, pose); hv.IntegrateImage(d, rgb, pose)
+        _compare(oracle, ov, hv)
