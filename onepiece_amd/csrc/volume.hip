@@ -582,6 +582,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
 
     // -- finish ComputeBounding from the frame's accumulators (k_prepare_frames)
     unsigned tot = 0, e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    const unsigned poisoned = tid == 0 ? (st->overflow & 3u) : 0u; // issued together with the accumulator loads: one round trip, not two
     if (wave == 0) { // lane k < kAccSlots reads set k (one round trip), then a 16-lane fold
         if (lane < kAccSlots) {
             const unsigned* a = st->acc[f][lane];
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
         // candidate range here), so that the host can grow the volume and REPLAY from the failing batch on -- no frame is
         // ever partially fused (vol_recover).  Read by one thread per workgroup: a per-thread load of this hot line next to
         // the candidate loop doubled the kernel's time.
-        if (tot == 0 || (st->overflow & 3u)) {
+        if (tot == 0 || poisoned) {
             for (int c = 0; c < 6; ++c) s_range[c] = 0;
         } else {
             for (int c = 0; c < 3; ++c) {
