@@ -66,7 +66,7 @@ constexpr int kDead = -3;            // slot claimed but the pool was full
 constexpr int kKaW = 64, kKaH = 16;   // KA: a workgroup's pixel rectangle (256 threads x 4 consecutive pixels of a row)
 constexpr int kTile = 16;             // KA -> KB: min / max valid depth per 16 x 16 pixel tile (k_select's coarse test); a KA rectangle = 4 tiles
 #ifndef KB_GRID
-#define KB_GRID 512
+#define KB_GRID 384
 #endif
 constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
 #ifndef OP_MAX_BATCH
@@ -547,7 +547,7 @@ constexpr int kSelTiles = 64;                   // a super-block whose pixel box
 static_assert(kSBVol == 64, "one lane per block of a super-block");
 
 #ifndef KB_MINWAVES
-#define KB_MINWAVES 6
+#define KB_MINWAVES 7
 #endif
 template <bool FAST>
 __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, const float2* __restrict__ ptile,
