@@ -69,6 +69,7 @@ constexpr int kTile = 16;             // KA -> KB: min / max valid depth per 16 
 #define KB_GRID 384
 #endif
 constexpr int kSelectGrid = KB_GRID; // KB persistent grid.x (256-thread workgroups) per frame
+static_assert(kSelectGrid % 8 == 0 && kSelectGrid >= 8, "k_select deals a frame's workgroups to the 8 XCDs in equal shares");
 #ifndef OP_MAX_BATCH
 #define OP_MAX_BATCH 32
 #endif
