@@ -7,7 +7,9 @@
 // OpenCV's with -DONEPIECE_HAVE_OPENCV, compat/MiniCv.h's container otherwise.
 // The arithmetic behind the functions lives in libonepiece_hip.so (C-ABI, include/onepiece_hip.h).
 #pragma once
+#include <cassert>  // <Eigen/Core> and <opencv2/opencv.hpp> bring <cassert> and <fstream> into the reference's Geometry.h; its examples rely on that
 #include <cstddef>
+#include <fstream>  // (example/MergeMultipleSubmaps.cpp:18,26)
 #include <iostream> // the reference's Geometry.h brings it in, and its callers print with std::cout (example/ICPTest.cpp:11)
 #include <memory>
 #include <string>

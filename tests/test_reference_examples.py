@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 HOST = os.path.join(ROOT, "host", "one_piece")
 EXDIR = os.path.join(ROOT, "oracle", "_ref", "examples")
-EXAMPLES = ("ImageIntegration", "ImageSequenceIntegration", "ICPTest")
+EXAMPLES = ("ImageIntegration", "ImageSequenceIntegration", "ICPTest", "MergeMultipleSubmaps", "MCGenerateMesh", "EstimateNormals", "ReadRGBD",
+            "ConvertImageSequenceToPCD", "ReadPLYPointCloud", "ReadPLYMesh")
 have_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "example")), reason="reference tree not present on this machine")
 
 
@@ -36,7 +37,7 @@ def _host_lib():
 # compile + link, unchanged
 # --------------------------------------------------------------------------------------------------------------------
 @have_ref
-def test_reference_examples_compile_and_link_unchanged(hip):
+def test_reference_examples_compile_and_link_unchanged(hip, tmp_path):
     """g++ -std=c++11 on the reference's example sources IN PLACE; -I host/one_piece, -I include and the headless viewer."""
     _host_lib()
     for ex in EXAMPLES:
@@ -49,8 +50,9 @@ def test_reference_examples_compile_and_link_unchanged(hip):
         exe = os.path.join(EXDIR, ex + ".bin")
         assert os.path.exists(exe), ex
         # the binary starts, resolves every symbol (lazy binding off) and prints the example's own usage line
-        run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, LD_BIND_NOW="1"))
-        assert run.returncode in (0, 1) and ("usage" in run.stdout.lower()), (ex, run.stdout, run.stderr)
+        run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, LD_BIND_NOW="1"), cwd=str(tmp_path), timeout=120)
+        # (EstimateNormals.cpp takes no arguments: it goes straight to work and ends in the viewer)
+        assert run.returncode in (0, 1) and ("usage" in run.stdout.lower() or "[headless viewer]" in run.stdout), (ex, run.stdout, run.stderr)
     # nothing of the reference was copied next to the binaries
     assert sorted(os.listdir(EXDIR)) == sorted(e + ".bin" for e in EXAMPLES)
 
@@ -404,3 +406,169 @@ def test_reference_icp_example_runs_on_the_gpu(hip, oracle, tmp_path):
     ref = oracle.icp(src, tgt, nrm, None, 30, 0.01, True)
     err = np.linalg.norm(T - ref["T"].astype(np.float64)) / np.linalg.norm(ref["T"].astype(np.float64))
     assert err <= 1e-4, (err, T, ref["T"])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# more of the reference's examples on this path: submap merging, marching cubes from a .map, normals, point clouds
+# --------------------------------------------------------------------------------------------------------------------
+def _write_legacy_map(path, keys, vox):
+    """A volume in the all-float stream ReadFromFileFloat reads (CubeHandler.h:73-109, VoxelCube.h:168-193): per cube the id and a size slot,
+    (index, sdf, weight)* of its observed voxels, -2, then the number of coloured voxels and (index, r, g, b, colour weight)* with the
+    colours as weighted sums of 0..255 values."""
+    buf = [0.0, float(len(keys))]
+    for k, v in zip(keys, vox):
+        buf += [float(k[0]), float(k[1]), float(k[2]), 0.0]
+        obs = np.nonzero((v[:, 1] > 0) & (v[:, 0] < 1))[0]
+        for i in obs:
+            buf += [float(i), float(v[i, 0]), float(v[i, 1])]
+        buf.append(-2.0)
+        col = [i for i in obs if v[i, 2] >= 0]
+        buf.append(float(len(col)))
+        for i in col:
+            buf += [float(i), float(v[i, 2]) * 255.0, float(v[i, 3]) * 255.0, float(v[i, 4]) * 255.0, 1.0]
+    np.array(buf, np.float32).tofile(str(path))
+
+
+def _submaps(oracle, tmp_path, n_sub=3, per_sub=4, res=0.02):
+    """n_sub small volumes, each fused in the frame of its own first camera, as legacy .map files + the pose file of
+    example/MergeMultipleSubmaps.cpp (count, then per submap: id, R row-major, t).  -> list of submap poses"""
+    poses = []
+    d = tmp_path / "maps"; d.mkdir()
+    with open(str(tmp_path / "poses.txt"), "w") as pf:
+        pf.write("%d\n" % n_sub)
+        for s_ in range(n_sub):
+            frames = [S.room_frame(40 * s_ + 5 * k) for k in range(per_sub)]
+            base = frames[0][2].astype(np.float64)
+            ov = oracle.Volume(oracle.make_camera(), voxel_res=res)
+            for dd, cc, pp in frames:
+                ov.integrate(dd, cc, (np.linalg.inv(base) @ pp.astype(np.float64)).astype(np.float32))
+            k, v = ov.export()
+            _write_legacy_map(d / ("m%d.map" % s_), k, v)
+            T = base.astype(np.float32)
+            poses.append(T)
+            pf.write("%d %s %s\n" % (s_, " ".join(repr(float(x)) for x in T[:3, :3].reshape(-1)), " ".join(repr(float(x)) for x in T[:3, 3])))
+    return poses
+
+
+@pytest.mark.gpu
+def test_reference_merge_multiple_submaps_example_runs_on_the_gpu(hip, oracle, tmp_path):
+    """example/MergeMultipleSubmaps.cpp, unedited: ReadFromFileFloat of every submap, Transform by its pose (trilinear resampling),
+    Merge, ExtractTriangleMesh, ClusteringSimplify(0.01), ./merged_mesh.ply -- rows I6, I8, I9 and N2 behind the reference's own driver.
+    The surface it writes is the one the CPU oracle gets from the same files with the same calls."""
+    exe = _example("MergeMultipleSubmaps")
+    res = 0.02
+    poses = _submaps(oracle, tmp_path, res=res)
+    run = subprocess.run([exe, str(tmp_path / "maps"), str(tmp_path / "poses.txt")], capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    for i in range(len(poses)):
+        assert "merge %dth submap" % i in run.stdout
+    pts, nrm, tris = _read_ply(str(tmp_path / "merged_mesh.ply"))
+    assert len(pts) > 5000 and len(tris) > 10000 and tris.max() < len(pts) and nrm is not None
+    total = oracle.Volume(voxel_res=0.01)        # the example's CubeHandler is default-constructed: Transform keeps the SOURCE resolution...
+    first = True
+    for i, T in enumerate(poses):
+        sub = oracle.Volume(voxel_res=0.01)
+        assert sub.read_file(tmp_path / "maps" / ("m%d.map" % i), legacy_float=True) == 0
+        moved = sub.transform(T, nearest=False)
+        if first:
+            total, first = moved, False          # ... and Merge into an EMPTY handler of another resolution is refused by the reference
+        else:
+            total.merge(moved)
+    tab, edges = _default_mc_tables()
+    want, _ = total.extract_mesh(tab, edges)
+    if len(want) == 0:
+        pytest.skip("oracle produced no surface for this configuration")
+    d_gw, d_wg, q99 = _surfaces_agree(pts, want[::5], 0.03)
+    assert d_gw < 0.05 and q99 < 0.03, (d_gw, d_wg, q99)
+
+
+@pytest.mark.gpu
+def test_reference_mc_generate_mesh_example_runs_on_the_gpu(hip, oracle, tmp_path):
+    """example/MCGenerateMesh.cpp, unedited: ReadFromFileFloat + ExtractTriangleMesh + ComputeNormals -> ./mc_mesh.ply.  Same triangle
+    soup as the oracle's marching cubes of the same file (vertex for vertex after sorting)."""
+    exe = _example("MCGenerateMesh")
+    ov = oracle.Volume(oracle.make_camera(), voxel_res=0.01)
+    for k in range(3):
+        ov.integrate(*S.room_frame(7 * k))
+    keys, vox = ov.export()
+    _write_legacy_map(tmp_path / "room.map", keys, vox)
+    run = subprocess.run([exe, str(tmp_path / "room.map")], capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    pts, nrm, tris = _read_ply(str(tmp_path / "mc_mesh.ply"))
+    ref = oracle.Volume(voxel_res=0.01)
+    assert ref.read_file(tmp_path / "room.map", legacy_float=True) == 0
+    tab, edges = _default_mc_tables()
+    want, _ = ref.extract_mesh(tab, edges)
+    assert len(pts) == len(want) > 30000 and len(tris) * 3 == len(pts) and nrm is not None
+    order = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    assert np.array_equal(order(np.ascontiguousarray(pts)), order(np.ascontiguousarray(want, np.float32)))
+
+
+@pytest.mark.gpu
+def test_reference_estimate_normals_example_runs_on_the_gpu(hip, tmp_path):
+    """example/EstimateNormals.cpp, unedited: 100 x 100 points of the plane x + 2y + 3z + 4 = 0, PointCloud::EstimateNormals() with its
+    defaults, ./bunny_n.ply.  Every normal is +-(1, 2, 3)/sqrt(14)."""
+    exe = _example("EstimateNormals")
+    run = subprocess.run([exe], capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    pts, nrm, _ = _read_ply(str(tmp_path / "bunny_n.ply"))
+    assert len(pts) == 10000 and nrm is not None
+    n0 = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    assert np.abs(np.abs(nrm @ n0) - 1.0).max() < 1e-3
+    assert np.abs(pts @ np.array([1.0, 2.0, 3.0]) + 4.0).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_reference_point_cloud_examples_run_on_the_gpu(hip, oracle, tmp_path):
+    """example/ReadRGBD.cpp and example/ConvertImageSequenceToPCD.cpp, unedited: PointCloud::LoadFromRGBD of 16-bit depth + colour PNGs
+    (the first with its own camera literal, the second with the default camera over a TUM-format sequence), WriteToPLY.  The points are
+    the oracle's LoadFromDepth of the same images, in order."""
+    from PIL import Image
+    d, c, _ = S.room_frame(21)
+    d16 = np.clip(np.round(d * 1000), 0, 65535).astype(np.uint16)
+    d16[100:140, 200:260] = 0
+    Image.fromarray(d16).save(str(tmp_path / "d.png"))
+    Image.fromarray(np.ascontiguousarray(c[:, :, ::-1])).save(str(tmp_path / "c.png"))
+    run = subprocess.run([_example("ReadRGBD"), str(tmp_path / "c.png"), str(tmp_path / "d.png")], capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    pts, _n, _t = _read_ply(str(tmp_path / "0.ply"))
+    cam = oracle.make_camera(914.494141, 914.377991, 958.065430 / 3, 548.986206 * 4 / 9, 640, 480, 1000.0)   # example/ReadRGBD.cpp:13
+    want = oracle.load_from_depth(cam, d16)
+    assert pts.shape == want.shape and np.array_equal(pts.view(np.uint32), want.view(np.uint32))
+    # the sequence converter
+    seq = str(tmp_path / "seq")
+    frames = [S.room_frame(9 * i) for i in range(3)]
+    Q.WriteImageSequence(seq, [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], 1000.0)
+    (tmp_path / "pcd").mkdir()
+    run = subprocess.run([_example("ConvertImageSequenceToPCD"), seq], capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    rgb_files, depth_files = Q.ReadImageSequence(seq)
+    for i in range(3):
+        pts, _n, _t = _read_ply(str(tmp_path / "pcd" / ("%d.ply" % i)))
+        want = oracle.load_from_depth(oracle.make_camera(), Q.imread(depth_files[i], unchanged=True))
+        assert pts.shape == want.shape and np.array_equal(pts.view(np.uint32), want.view(np.uint32)), i
+
+
+def test_reference_ply_examples_run_on_the_host(hip, tmp_path):
+    """example/ReadPLYPointCloud.cpp and example/ReadPLYMesh.cpp, unedited (host-only members: LoadFromPLY, WriteToPLY, DownSample,
+    TriangleMesh::LoadFromFile, ComputeNormals): the cloud comes back as written, the down-sampled one is smaller."""
+    exe = _example("ReadPLYPointCloud")
+    rng = np.random.default_rng(5)
+    p = rng.uniform(-1, 1, (5000, 3)).astype("<f4")
+    with open(str(tmp_path / "in.ply"), "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n" % len(p)).encode())
+        f.write(p.tobytes())
+    run = subprocess.run([exe, str(tmp_path / "in.ply"), "0.25"], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    pts, _n, _t = _read_ply(str(tmp_path / "transformed_pcd.ply"))
+    assert np.array_equal(pts, p)
+    m = [l for l in run.stdout.splitlines() if l.startswith("down sample: from 5000 to ")]
+    assert m and 100 < int(m[0].split()[-1]) <= 512          # 8^3 cells of 0.25 over [-1, 1]^3
+    # a mesh: the unit square as two triangles
+    with open(str(tmp_path / "mesh.ply"), "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                b"element face 2\nproperty list uchar int vertex_indices\nend_header\n")
+        f.write(np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], "<f4").tobytes())
+        f.write(np.array([(3, (0, 1, 2)), (3, (0, 2, 3))], np.dtype([("n", "u1"), ("v", "<i4", 3)])).tobytes())
+    run = subprocess.run([_example("ReadPLYMesh"), str(tmp_path / "mesh.ply")], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    assert run.returncode == 0 and "[headless viewer] mesh with 4 vertices, 2 triangles" in run.stdout, run.stdout + run.stderr
