@@ -24,7 +24,7 @@ REF = "/root/reference"
 HOST = os.path.join(ROOT, "host", "one_piece")
 EXDIR = os.path.join(ROOT, "oracle", "_ref", "examples")
 EXAMPLES = ("ImageIntegration", "ImageSequenceIntegration", "ICPTest", "MergeMultipleSubmaps", "MCGenerateMesh", "EstimateNormals", "ReadRGBD",
-            "ConvertImageSequenceToPCD", "ReadPLYPointCloud", "ReadPLYMesh")
+            "ConvertImageSequenceToPCD", "ReadPLYPointCloud", "ReadPLYMesh", "DenseOdometry")
 have_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "example")), reason="reference tree not present on this machine")
 
 
@@ -132,10 +132,17 @@ EXEMPT = {
     ("RGBDFrame", "IsPreprocessedDense"): "sparse / dense odometry caches of the reference's Odometry class: the tracker here keeps its pyramids on the device",
     ("RGBDFrame", "IsPreprocessedSparse"): "as above",
 }
+_SPARSE = "sparse odometry (ORB features, brute-force / MILD matching, RANSAC on OpenCV): out of scope, SURVEY section 2"
+_ON_DEVICE = "the pyramids live on the GPU here: exposed as op_tracker_track / op_tracker_read_pyramid in the C-ABI"
+for _name in ("Find2DMathes", "SparseTracking", "SparseTrackingMILD", "ComputeTransformation", "GetLocalPointsFromKeyPoints", "GetCorrespondencesFromMatches",
+              "SetFeatureNumber", "GetFeatureNumber"):
+    EXEMPT[("Odometry", _name)] = _SPARSE
+for _name in ("CreateImagePyramid", "CreateImageXYZPyramid", "MultiScaleComputing", "InitializeRGBDDenseTracking"):
+    EXEMPT[("Odometry", _name)] = _ON_DEVICE
 SURFACE = [("Integration/CubeHandler.h", "CubeHandler"), ("Integration/Frustum.h", "Frustum"), ("Integration/Integrator.h", "Integrator"),
            ("Integration/VoxelCube.h", "VoxelCube"), ("Integration/VoxelCube.h", "CubePara"), ("Integration/TSDFVoxel.h", "TSDFVoxel"),
            ("Geometry/PointCloud.h", "PointCloud"), ("Geometry/TriangleMesh.h", "TriangleMesh"), ("Geometry/RGBDFrame.h", "RGBDFrame"),
-           ("Camera/Camera.h", "PinholeCamera"), ("Registration/RegistrationResult.h", "RegistrationResult")]
+           ("Camera/Camera.h", "PinholeCamera"), ("Registration/RegistrationResult.h", "RegistrationResult"), ("Odometry/Odometry.h", "Odometry")]
 
 
 @have_ref
@@ -572,3 +579,40 @@ def test_reference_ply_examples_run_on_the_host(hip, tmp_path):
         f.write(np.array([(3, (0, 1, 2)), (3, (0, 2, 3))], np.dtype([("n", "u1"), ("v", "<i4", 3)])).tobytes())
     run = subprocess.run([_example("ReadPLYMesh"), str(tmp_path / "mesh.ply")], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
     assert run.returncode == 0 and "[headless viewer] mesh with 4 vertices, 2 triangles" in run.stdout, run.stdout + run.stderr
+
+
+@pytest.mark.gpu
+def test_reference_dense_odometry_example_runs_on_the_gpu(hip, oracle, tmp_path):
+    """example/DenseOdometry.cpp, unedited: odometry::Odometry(camera).DenseTracking(source_frame, target_frame, identity, 0) on two
+    RGB-D pairs read from PNGs, prints success and T.  The printed pose is the oracle's DenseTracking of the same images (to the
+    agreement the default summation mode has with the reference's float32 sums, tests/test_odometry_gpu.py)."""
+    from PIL import Image
+    exe = _example("DenseOdometry")
+    files = []
+    frames = []
+    for k, i in enumerate((301, 300)):
+        d, c, _ = S.room_frame(i)
+        d16 = np.clip(np.round(d * 1000), 0, 65535).astype(np.uint16)
+        Image.fromarray(d16).save(str(tmp_path / ("d%d.png" % k)))
+        Image.fromarray(np.ascontiguousarray(c[:, :, ::-1])).save(str(tmp_path / ("c%d.png" % k)))
+        frames.append((Q.imread(str(tmp_path / ("c%d.png" % k))), Q.imread(str(tmp_path / ("d%d.png" % k)), unchanged=True)))
+        files += [str(tmp_path / ("c%d.png" % k)), str(tmp_path / ("d%d.png" % k))]
+    run = subprocess.run([exe] + files, capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "Successful Matching!" in run.stdout
+    rows = []
+    for line in run.stdout.splitlines():
+        try:
+            vals = [float(t) for t in line.split()]
+        except ValueError:
+            rows = []
+            continue
+        rows = rows + [vals] if len(vals) == 4 else []
+        if len(rows) == 4:
+            break
+    assert len(rows) == 4, run.stdout[-1500:]
+    T = np.array(rows, np.float64)
+    ref = oracle.dense_tracking(oracle.make_camera(), frames[0][0], frames[1][0], frames[0][1], frames[1][1], (4, 8, 16), 0)
+    assert ref["tracking_success"]
+    err = np.linalg.norm(T - ref["T"].astype(np.float64)) / np.linalg.norm(ref["T"].astype(np.float64))
+    assert err <= 1e-3, (err, T, ref["T"])          # printed with 6 significant digits; per-pair agreement of the default mode is 1e-4..1e-3
