@@ -14,7 +14,7 @@ OUT=$ROOT/oracle/_ref/examples
 mkdir -p "$OUT"
 HOST=$ROOT/host/one_piece
 [ -f "$HOST/libone_piece_hip_host.so" ] || make -C "$HOST"
-for ex in ImageIntegration ImageSequenceIntegration ICPTest MergeMultipleSubmaps MCGenerateMesh EstimateNormals ReadRGBD ConvertImageSequenceToPCD ReadPLYPointCloud ReadPLYMesh DenseOdometry; do
+for ex in ImageIntegration ImageSequenceIntegration ICPTest MergeMultipleSubmaps MCGenerateMesh EstimateNormals ReadRGBD ConvertImageSequenceToPCD ReadPLYPointCloud ReadPLYMesh DenseOdometry SimplifyMeshClustering PruneMesh EigenTest; do
   if [ "$1" = "-fsyntax-only" ]; then
     g++ -std=c++11 -fsyntax-only -I"$HOST" -I"$ROOT/include" -I"$ROOT/tests/cpp/headless" "$REF/example/$ex.cpp"
   else

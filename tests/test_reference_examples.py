@@ -24,7 +24,8 @@ REF = "/root/reference"
 HOST = os.path.join(ROOT, "host", "one_piece")
 EXDIR = os.path.join(ROOT, "oracle", "_ref", "examples")
 EXAMPLES = ("ImageIntegration", "ImageSequenceIntegration", "ICPTest", "MergeMultipleSubmaps", "MCGenerateMesh", "EstimateNormals", "ReadRGBD",
-            "ConvertImageSequenceToPCD", "ReadPLYPointCloud", "ReadPLYMesh", "DenseOdometry")
+            "ConvertImageSequenceToPCD", "ReadPLYPointCloud", "ReadPLYMesh", "DenseOdometry", "SimplifyMeshClustering",
+            "PruneMesh", "EigenTest")
 have_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "example")), reason="reference tree not present on this machine")
 
 
@@ -616,3 +617,34 @@ def test_reference_dense_odometry_example_runs_on_the_gpu(hip, oracle, tmp_path)
     assert ref["tracking_success"]
     err = np.linalg.norm(T - ref["T"].astype(np.float64)) / np.linalg.norm(ref["T"].astype(np.float64))
     assert err <= 1e-3, (err, T, ref["T"])          # printed with 6 significant digits; per-pair agreement of the default mode is 1e-4..1e-3
+
+
+def test_reference_mesh_tool_examples_run_on_the_host(hip, tmp_path):
+    """example/SimplifyMeshClustering.cpp and example/PruneMesh.cpp, unedited, on a 40 x 40 grid mesh plus a stray triangle: the clustered
+    mesh keeps the surface with fewer vertices (one per occupied cell), pruning drops the small component."""
+    n = 40
+    gx, gy = np.meshgrid(np.arange(n, dtype=np.float32) * 0.01, np.arange(n, dtype=np.float32) * 0.01)
+    v = np.stack([gx.ravel(), gy.ravel(), np.zeros(n * n, np.float32)], 1)
+    idx = lambda i, j: i * n + j
+    t = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            t += [(idx(i, j), idx(i, j + 1), idx(i + 1, j + 1)), (idx(i, j), idx(i + 1, j + 1), idx(i + 1, j))]
+    v = np.concatenate([v, np.array([[5, 5, 5], [5.01, 5, 5], [5, 5.01, 5]], np.float32)])   # a component of 3 points far away
+    t.append((n * n, n * n + 1, n * n + 2))
+    with open(str(tmp_path / "grid.ply"), "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                 "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(v), len(t))).encode())
+        f.write(np.ascontiguousarray(v, "<f4").tobytes())
+        f.write(np.array([(3, tri) for tri in t], np.dtype([("n", "u1"), ("v", "<i4", 3)])).tobytes())
+    run = subprocess.run([_example("SimplifyMeshClustering"), str(tmp_path / "grid.ply"), "0.04", str(tmp_path / "clustered.ply")],
+                         capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    pts, _n, tris = _read_ply(str(tmp_path / "clustered.ply"))
+    assert 50 < len(pts) < 200 and len(tris) > 100 and tris.max() < len(pts)           # ~10 x 10 cells of 4 cm over 0.39 m (+ the stray one)
+    on_sheet = pts[pts[:, 2] < 1]
+    assert np.abs(on_sheet[:, 2]).max() < 1e-6 and on_sheet[:, :2].min() >= 0 and on_sheet[:, :2].max() <= 0.39 + 1e-6
+    run = subprocess.run([_example("PruneMesh"), str(tmp_path / "grid.ply"), "10"], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    pts, _n, tris = _read_ply(str(tmp_path / "grid.ply_pruned.ply"))
+    assert len(pts) == n * n and len(tris) == 2 * (n - 1) * (n - 1) and pts.max() < 1
