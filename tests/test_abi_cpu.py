@@ -311,6 +311,7 @@ def test_new_volume_entry_points_refuse_without_a_volume(hip):
     assert lib.op_volume_stats_launches(None, C.byref(u), C.byref(u), C.byref(u), C.byref(u)) != 0
     assert lib.op_volume_growth_stats(None, C.byref(u), C.byref(u), C.byref(u)) != 0
     assert lib.op_volume_integrate_cubes(None, None, 0, None, 0, None, None, None, 0) != 0
+    assert lib.op_volume_flush(None) != 0
     n = C.c_size_t(0)
     st = hip.MergeStats()
     assert lib.op_volume_merge_rccl_stats(None, None, 0, C.byref(n), C.byref(st)) == hip.OP_ERR_INVALID and st.ranks == 0
