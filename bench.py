@@ -26,6 +26,12 @@ import time
 
 import numpy as np
 
+# The tracking + fusion pipeline keeps four frame pairs in flight, each tracker on its own HIP stream, next to the volume's streams.  The
+# runtime maps streams onto 4 hardware queues by default, so two of those streams would share a queue and serialise (2.6 k instead of 4.5 k
+# frames/s in tools/prof_driver.bin track=4); with more than four ACTIVE queues the rate collapses again, so the pipeline depth stays 4.
+# Read once, when the HIP runtime initialises -- hence here, before anything touches the GPU.  No effect on the fusion / ICP figures.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -660,6 +666,36 @@ def main():
                                            "no submap registration / BA (out of scope).  pairs_in_flight independent frame pairs are tracked "
                                            "concurrently on separate HIP streams (speculating on the success flag, resolved in order): "
                                            "identical poses, the latency-bound tracker no longer leaves the chip idle"}
+        # the same pipeline from C++ over the C-ABI (tools/prof_driver.bin track=4: op_tracker_dense_tracking_enqueue / op_tracker_wait on four
+        # trackers, op_volume_integrate with the chained pose): the interpreter's ~250 us per frame are what limits the figure above
+        if world == 1:
+            try:
+                import subprocess, tempfile, re as _re
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import counters as CT
+                CT.build_driver()
+                n_cpp = min(200, n_local)
+                with tempfile.NamedTemporaryFile(prefix="opc_track_", suffix=".bin", dir="/tmp", delete=False) as tf:
+                    np.array([n_cpp, W, H], np.int32).tofile(tf)
+                    dh, ch = depth[:n_cpp].cpu().numpy(), rgb[:n_cpp].cpu().numpy()
+                    for i in range(n_cpp):
+                        poses[i].astype(np.float32).tofile(tf); dh[i].tofile(tf); ch[i].tofile(tf)
+                    tname = tf.name
+                try:
+                    rates_cpp = {}
+                    for k in (1, 4):
+                        txt = subprocess.run([CT.DRIVER, tname, "3", "0.005", "track=%d" % k], capture_output=True, text=True, timeout=300).stdout
+                        m = _re.findall(r"tracked (\d+)/(\d+) frames, ([\d.]+) frames/s", txt)
+                        rates_cpp[k] = (max(float(x[2]) for x in m), int(m[-1][0]), int(m[-1][1])) if m else None
+                finally:
+                    os.unlink(tname)
+                if rates_cpp.get(4):
+                    out["dense_fusion"].update({"cpp_frames_per_s": rates_cpp[4][0], "cpp_one_pair_at_a_time_frames_per_s": rates_cpp[1][0] if rates_cpp.get(1) else None,
+                                                "cpp_tracked": rates_cpp[4][1], "cpp_frames": rates_cpp[4][2],
+                                                "cpp_driver": "tools/prof_driver.bin <frames> 3 0.005 track=4: the same pipeline over the C-ABI without the interpreter, "
+                                                              "best of 3; GPU_MAX_HW_QUEUES=8 so that every tracker stream has a hardware queue of its own"})
+            except Exception as e:
+                out["dense_fusion"]["cpp_error"] = repr(e)[:200]
 
     if rank == 0:
         print(json.dumps(out))

@@ -2,6 +2,7 @@
 // when the profiled process is python+torch).  Reads a frame dump written by tools/dump_frames.py:
 //   int32 n, w, h;  then n x { float pose[16]; float depth[w*h]; uint8 rgb[w*h*3] }
 // uploads the frames to HBM once, then fuses them `reps` times into a fresh 5 mm volume.
+// With "track=K": tracking + fusion with K frame pairs in flight (one tracker each).
 // With a 5th argument "track": instead tracks every consecutive frame pair (op_tracker_dense_tracking, device
 // frames) and fuses each frame with its TRACKED pose -- the config-4 pipeline, one pair at a time.
 // With "icp": registration::PointToPlane of frame 1's cloud onto frame 0's (LoadFromDepth, EstimateNormals, 30 iterations,
@@ -13,6 +14,7 @@
 // the launch's HBM traffic).
 // Build: hipcc --offload-arch=gfx950 -O2 -I include tools/prof_driver.cpp -L onepiece_amd -lonepiece_hip -o tools/prof_driver.bin
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +25,7 @@
 #define CK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, op_last_error()); return 1; } } while (0)
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0); // one hardware queue per tracker stream in the track=K mode (the runtime's default is 4; read at HIP initialisation)
     const char* path = argc > 1 ? argv[1] : "/tmp/frames.bin";
     const int reps = argc > 2 ? atoi(argv[2]) : 1;
     const float voxel = argc > 3 ? (float)atof(argv[3]) : 0.005f;
@@ -47,6 +50,47 @@ int main(int argc, char** argv) {
     op_camera cam; CK(op_camera_preset(1, &cam));
     cam.width = w; cam.height = h;
     op_volume* v; CK(op_volume_create(&cam, voxel, 0.1f, 5.0f, 0.5f, 0, 1u << 18, &v));
+    if (argc > 4 && std::string(argv[4]).rfind("track=", 0) == 0) {
+        // "track=K": tracking + fusion with K frame pairs in flight, each on its own tracker (stream): pair i is enqueued while pairs
+        // i-K+1 .. i-1 are still running; results are taken in order, the pose is chained and the frame fused -- the C-ABI pipeline behind
+        // onepiece_amd/dense_slam.py, without the interpreter in the loop.
+        const int K = std::max(1, atoi(argv[4] + 6));
+        std::vector<op_tracker*> trk((size_t)K);
+        for (auto& t : trk) CK(op_tracker_create(0, &t));
+        const int32_t iters[3] = {4, 8, 16};
+        const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int r = 0; r < reps; ++r) {
+            CK(op_volume_clear(v));
+            float g[16]; for (int k = 0; k < 16; ++k) g[k] = I4[k];
+            int ok = 1;
+            auto resolve = [&](int j) {                         // frame j >= 1: result of the pair (j - 1, j)
+                op_track_result res;
+                CK(op_tracker_wait(trk[(size_t)((j - 1) % K)], &res, nullptr, nullptr, 0));
+                ok += res.tracking_success;
+                float inv[16], ng[16];                          // global = global_last * T^-1 (DenseSlam.cpp:31)
+                CK(op_mat4_inverse(res.T, inv));
+                for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) ng[a * 4 + b] = ((g[a * 4] * inv[b] + g[a * 4 + 1] * inv[4 + b]) + g[a * 4 + 2] * inv[8 + b]) + g[a * 4 + 3] * inv[12 + b];
+                for (int k = 0; k < 16; ++k) g[k] = ng[k];
+                CK(op_volume_integrate(v, d_depth + npx * j, OP_DEPTH_F32, d_rgb + npx * 3 * j, OP_MEM_DEVICE, g, nullptr));
+                return 0;
+            };
+            auto t0 = std::chrono::steady_clock::now();
+            CK(op_volume_integrate(v, d_depth, OP_DEPTH_F32, d_rgb, OP_MEM_DEVICE, g, nullptr));
+            for (int i = 1; i < n; ++i) {
+                if (i - 1 >= K && resolve(i - K)) return 1;     // frees the tracker this pair will use
+                CK(op_tracker_dense_tracking_enqueue(trk[(size_t)((i - 1) % K)], &cam, 3, iters, d_rgb + npx * 3 * (i - 1), d_rgb + npx * 3 * i, d_depth + npx * (i - 1),
+                                                     d_depth + npx * i, OP_DEPTH_F32, I4, OP_TRACK_HYBRID, OP_MEM_DEVICE, 0));
+            }
+            for (int j = std::max(1, n - K); j < n; ++j) if (resolve(j)) return 1;
+            CK(op_volume_sync(v));
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            size_t nb; CK(op_volume_block_count(v, &nb));
+            printf("rep %d: %d pairs in flight, tracked %d/%d frames, %.1f frames/s (tracking + fusion), blocks %zu, final t = (%.4f %.4f %.4f)\n", r, K, ok, n, n / dt, nb, g[3], g[7], g[11]);
+        }
+        for (auto t : trk) op_tracker_destroy(t);
+        op_volume_destroy(v);
+        return 0;
+    }
     const bool track = argc > 4 && std::string(argv[4]) == "track";
     if (track) {
         op_tracker* trk; CK(op_tracker_create(0, &trk));
