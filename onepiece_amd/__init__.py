@@ -6,3 +6,9 @@ CubeHandler / ICP surface over that ABI), distributed.py (frame-sharded multi-GP
 synthetic.py (input generators for tests and bench).  No CPU fallback exists.
 """
 __all__ = ["integration", "registration", "synthetic", "distributed"]
+
+# Several trackers / volumes working concurrently own one HIP stream each; the runtime maps streams onto 4 hardware queues unless told
+# otherwise, and streams that share a queue serialise (DESIGN.md section 7: 2.6 k instead of 4.5 k frames/s with four frame pairs in flight).
+# The variable is read once, when the HIP runtime initialises -- importing this package before the first GPU call is early enough.
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
