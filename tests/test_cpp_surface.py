@@ -350,3 +350,37 @@ def test_cpp_multi_gpu_driver_runs_the_rccl_merge(hip, oracle, tmp_path):
     obs = ev[..., 1] > 0
     assert np.abs(gv[..., 0] - ev[..., 0])[obs].max() <= 1e-6 and np.abs(gv[..., 2:] - ev[..., 2:])[obs].max() <= 1e-6
     assert np.array_equal(gv[~obs].view(np.uint32), ev[~obs].view(np.uint32))       # unobserved voxels keep the sentinel
+
+
+@pytest.mark.gpu
+def test_cpp_dense_fusion_driver_tracks_and_fuses(hip, oracle, tmp_path):
+    """examples/cpp/DenseFusion.cpp -- odometry::Odometry::DenseTracking + pose chaining + CubeHandler::IntegrateImage with the TRACKED
+    pose, from the C++ class surface only (the tracking + fusion core of the reference's example/DenseFusion).  Every pair tracks, the pose
+    chain is the oracle's DenseTracking chain of the same decoded images, and the volume is the oracle's fusion with those poses."""
+    _build_host(); _make(cwd=EX)
+    cam = (S.FX, S.FY, S.CX, S.CY, S.W, S.H, 1000.0)
+    seq = str(tmp_path / "seq")
+    n = 6
+    Q.WriteImageSequence(seq, *[list(x) for x in zip(*[S.room_frame(600 + i) for i in range(n)])], 1000.0)
+    rgb_files, depth_files = Q.ReadImageSequence(seq)
+    raw = [(Q.imread(rf), Q.imread(df, unchanged=True)) for rf, df in zip(rgb_files, depth_files)]
+    pf = str(tmp_path / "poses.txt")
+    run = subprocess.run([os.path.join(EX, "DenseFusion.bin"), seq, "--voxel", "0.01", "--poses", pf, "--ply", str(tmp_path / "m.ply")], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    r = json.loads(run.stdout.strip().splitlines()[-1])
+    assert r["frames"] == n and r["tracked"] == n and r["triangles"] > 10000
+    got = np.loadtxt(pf).reshape(-1, 4, 4)
+    assert len(got) == n and np.array_equal(got[0], np.eye(4))
+    from onepiece_amd import dense_slam as DS
+    chain = [np.eye(4, dtype=np.float32)]
+    ocam = oracle.make_camera()
+    for i in range(1, n):
+        t = oracle.dense_tracking(ocam, raw[i][0], raw[i - 1][0], raw[i][1], raw[i - 1][1], (4, 8, 16), 0)
+        assert t["tracking_success"]
+        chain.append(DS._mat4_mul_f32(chain[-1], oracle.mat4_inverse(t["T"])))
+    for i in range(n):
+        assert rel_err(got[i], chain[i]) <= 1e-3, i            # per-pair agreement of the default summation mode is 1e-4 .. 1e-3 (test_odometry_gpu.py)
+    ov = oracle.Volume(ocam, voxel_res=0.01)                      # the volume: exactly the fusion of the decoded frames with the poses the driver printed
+    for i in range(n):
+        ov.integrate(Q.ConvertDepthTo32F(raw[i][1], 1000.0), raw[i][0], got[i].astype(np.float32))
+    assert r["blocks"] == ov.block_count()
