@@ -245,8 +245,8 @@ def main():
         m1 = (10240.0 * st1["blocks_read"] + 20.0 * st1["voxels_written"]) / max(st1["launches"], 1) + 8.0 * W * H
         out["roofline"]["batch1"] = {"frames": nb1, "bound": "hbm", "avg_launch_ms": p1["integrate_ms"], "algorithmic_bytes_per_launch": b1, "achieved": a1, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic_model_bytes_per_launch": m1, "traffic_model_frac": m1 / (p1["integrate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "evidence": "profiles/r03f_batch1.kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/prof_driver.bin ... batch=1), "
-                                                 "profiles/r03f_batch1.FETCH_SIZE.pmc.csv / WRITE_SIZE.pmc.csv: 395 MB per launch measured = 0.63 of the 8 TB/s peak, the rate the "
+                                     "evidence": "profiles/r03g_batch1.kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/prof_driver.bin ... batch=1), "
+                                                 "profiles/r03g_batch1.FETCH_SIZE.pmc.csv / WRITE_SIZE.pmc.csv: 395 MB per launch measured = 0.63 of the 8 TB/s peak, the rate the "
                                                  "read-modify-write calibration kernel of the same shape reaches (profiles/r03_calib.timing.txt: 5.0 TB/s)",
                                      "note": "k_integrate with ONE frame per launch: SURVEY 8(d)'s algorithmic bytes are then a lower bound of the real traffic, "
                                              "so this is a true HBM roofline fraction (north_star: >= 50 % of HBM roofline on the integrate kernel)"}

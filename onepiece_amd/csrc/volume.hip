@@ -888,25 +888,37 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
         (const float __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr(); // BatchInv B = offset 0 of the kernarg segment
     (void)B;
     unsigned upd = 0, sel = 0, chg = 0, nblk = 0;
-#ifndef KC_CHUNK
-#define KC_CHUNK 32
+#ifndef KC_CHUNK_LOG2
+#define KC_CHUNK_LOG2 5
+#endif
+#ifndef KC_STEAL_MIN_FRAMES
+#define KC_STEAL_MIN_FRAMES 24
 #endif
     // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2; list neighbours -- blocks along one viewing ray, which gather
-    // the same pixels -- should meet in one L2) and dynamic scheduling (blocks differ in work: 1..16 frames touch them; the workgroups of an XCD
+    // the same pixels -- should meet in one L2) and dynamic scheduling (blocks differ in work: 1..32 frames touch them; the workgroups of an XCD
     // DRAW list positions from one counter, the next one before the current block is processed so that the atomic's round trip is hidden).
-    // The list is cut into chunks of KC_CHUNK blocks that are dealt round-robin to the XCDs: still contiguous runs for the L2, but every XCD gets
-    // a sample of the whole list.  With ONE contiguous eighth per XCD (KC_CHUNK == 0) the eighths differ in work and the launch ends with most XCDs
-    // idle: 309 us per 14-frame launch against 291 us with chunks of 32 (297 / 293 / 306 us with 8 / 128 / 512; tools/ab_bench.sh).
-    const unsigned n_chunks = KC_CHUNK ? (n + KC_CHUNK - 1u) / (KC_CHUNK ? KC_CHUNK : 1u) : 0u;
-    const unsigned per_xcd = KC_CHUNK ? ((n_chunks + (unsigned)kKcShares - 1u) / (unsigned)kKcShares) * KC_CHUNK : (n + (unsigned)kKcShares - 1u) / (unsigned)kKcShares;
-    const unsigned xcd = blockIdx.x % (unsigned)kKcShares;
+    // Two ways of dealing the list to the eight draw counters:
+    //  * full batches (>= KC_STEAL_MIN_FRAMES frames): every XCD starts on ONE contiguous eighth of the list; the eighths hold the same number of
+    //    blocks but not the same work, so a workgroup whose share is exhausted reads all eight counters (one round trip) and goes on with the share
+    //    that has the most left.  Per 32-frame launch: eighths alone 689 us, with stealing 627-631 us;
+    //  * short batches: chunks of 32 blocks dealt round-robin (every XCD a sample of the whole list), no stealing.  Same 638 us for 32 frames but
+    //    18 % more L2 misses (FETCH_SIZE 559 against 472 MB x 2); for ONE frame per launch, where the kernel is HBM-bound and the work per
+    //    block uniform, 79 us against 95 us with stealing (its last look costs a short launch more than it can win).
+    //    Measured crossover (tools/prof_driver.bin batch=N under the tracer, stealing vs chunks): 8 frames 207 vs 194 us, 16: 360 vs 356, 24: 524 vs 527,
+    //    32: 677 vs 687.
+    const bool eighths = n_frames >= KC_STEAL_MIN_FRAMES;
+    constexpr unsigned kChunk = 1u << KC_CHUNK_LOG2;
+    const unsigned n_chunks = (n + kChunk - 1u) >> KC_CHUNK_LOG2;
+    const unsigned per_xcd = eighths ? (n + (unsigned)kKcShares - 1u) / (unsigned)kKcShares : ((n_chunks + (unsigned)kKcShares - 1u) / (unsigned)kKcShares) << KC_CHUNK_LOG2;
+    unsigned xcd = blockIdx.x % (unsigned)kKcShares;          // the share this workgroup draws from: its own first
+    for (;;) {
     unsigned* ctr = &st->kc_next[xcd * 16u];
     if (tid == 0) s_next[0] = atomicAdd(ctr, 1u);
     __syncthreads();
     unsigned slot = 0u;
     for (unsigned j = s_next[0]; j < per_xcd;) {
         if (tid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
-        const unsigned b = KC_CHUNK ? ((j / (KC_CHUNK ? KC_CHUNK : 1u)) * (unsigned)kKcShares + xcd) * KC_CHUNK + j % (KC_CHUNK ? KC_CHUNK : 1u) : xcd * per_xcd + j;
+        const unsigned b = eighths ? xcd * per_xcd + j : (((j >> KC_CHUNK_LOG2) * (unsigned)kKcShares + xcd) << KC_CHUNK_LOG2) + (j & (kChunk - 1u));
         const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
         if (idx >= 0) {
             const bmask_t mask = V.bmask[V.blist[b]];
@@ -989,6 +1001,26 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
         if (b < n && tid == 0) V.bmask[V.blist[b]] = (bmask_t)0; // the owner clears it for the next batch
         slot ^= 1u;
         j = s_next[slot];
+    }
+    if (!eighths) break;
+    // the share is exhausted: look at all the draw counters at once (one round trip) and go on with the share that has the most left
+    __syncthreads();                                          // everybody has read the last draw
+    if (tid < 64) {
+        unsigned left = 0u;
+        if (tid < kKcShares) {
+            const unsigned c = __hip_atomic_load(&st->kc_next[(unsigned)tid * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            left = c < per_xcd ? per_xcd - c : 0u;
+        }
+        unsigned key = (left << 8) | (unsigned)tid;            // most left, ties to the higher share index (any fixed rule)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned x = __shfl_xor(key, o, 64); key = x > key ? x : key; }
+        if (tid == 0) s_next[0] = key;
+    }
+    __syncthreads();
+    const unsigned key = s_next[0];
+    if ((key >> 8) == 0u) break;                              // nothing left anywhere
+    xcd = key & 0xffu;
+    __syncthreads();                                          // s_next[0] is written again at the top
     }
     // per-workgroup counters into kPartialGrid slots
     upd = wave_sum(upd); chg = wave_sum(chg);
