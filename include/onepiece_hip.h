@@ -60,6 +60,11 @@ typedef struct op_tracker op_tracker; /* dense RGB-D tracker workspace (stream, 
 /* ---- library ----------------------------------------------------------------------------- */
 int op_abi_version(void);
 const char *op_last_error(void);
+/* Hardware queues the HIP runtime was asked for (GPU_MAX_HW_QUEUES).  Every volume and every tracker owns a stream, and streams that
+ * share a hardware queue serialise; the library therefore sets the variable to 8 when it is LOADED unless the caller has set it (the
+ * runtime reads it at its first API call: load or link the library before the process touches HIP).  Four tracker streams + one
+ * fusing volume need five queues for the pipelined tracking + fusion rate quoted in DESIGN.md. */
+int op_runtime_hw_queues(int *requested);
 /* Registration objects (op_icp, the contexts behind op_icp_register / op_estimate_normals / op_points_from_depth) are
  * created and dropped per call, as registration::PointToPlane builds and drops its kd-tree (Registration/ICP.cpp:
  * 166-170); their device and pinned buffers, streams and events are kept in a per-process cache when released and
@@ -117,6 +122,18 @@ int op_volume_set_resolution(op_volume *v, float voxel_res);  /* CubeHandler.h:3
 int op_volume_set_truncation(op_volume *v, float truncation); /* CubeHandler.h:141-144 */
 int op_volume_set_camera(op_volume *v, const op_camera *cam); /* CubeHandler.h:137-140 */
 int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* CubeHandler.h:339-346 */
+/* OP_VOLUME_OPT_UPDATE: how the frames of a batch reach a voxel (TSDFVoxel::operator+, Integration/TSDFVoxel.h:24-39; Integrator.cpp:74-87).
+ *   OP_VOLUME_UPDATE_EXACT (default): frame by frame in frame order, every product, sum and quotient rounded as the reference rounds it --
+ *     voxels bit-identical to the reference's CPU path.
+ *   OP_VOLUME_UPDATE_SUM_FORM: the observations a batch of frames (<= 32) makes of a voxel are summed and the weighted mean with the stored
+ *     voxel is formed once per batch.  Same blocks, same pixels, same weights; sdf and colour agree with the reference to float rounding
+ *     (<= 1e-6 of the truncation distance / of 1 in practice; the path's bar is 1e-4 relative).  The integrate kernel executes a third
+ *     fewer instructions per voxel and frame.
+ * Changing the option waits for the frames accepted so far (they are fused under the old setting). */
+#define OP_VOLUME_OPT_UPDATE 0
+#define OP_VOLUME_UPDATE_EXACT 0
+#define OP_VOLUME_UPDATE_SUM_FORM 1
+int op_volume_set_option(op_volume *v, int option, int value);
 int op_volume_clear(op_volume *v);                            /* CubeHandler.h:133-136 */
 int op_volume_sync(op_volume *v);
 /* Launches the frames op_volume_integrate / op_volume_integrate_sequence have queued (a batch smaller than 32), without

@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libonepiece_hip.so")
+# ONEPIECE_HIP_LIBRARY: another build of the same library (the 64-frames-per-batch variant, `make -C onepiece_amd/csrc b64`)
+SO_PATH = os.environ.get("ONEPIECE_HIP_LIBRARY") or os.path.join(_HERE, "libonepiece_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 
@@ -53,6 +54,7 @@ class TrackResult(C.Structure):
 OP_TRACK_HYBRID, OP_TRACK_PHOTO, OP_TRACK_DEPTH = 0, 1, 2
 OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_FP64, OP_TRACK_SUMS_REFERENCE_F32 = 0, 0, 1
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
+OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_EXACT, OP_VOLUME_UPDATE_SUM_FORM = 0, 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
 OP_ICP_OPT_FINISH, OP_ICP_OPT_SUMS = 0, 1
@@ -71,6 +73,7 @@ _u64p = C.POINTER(C.c_uint64)
 SIGNATURES = {
     "op_abi_version": (C.c_int, []),
     "op_last_error": (C.c_char_p, []),
+    "op_runtime_hw_queues": (C.c_int, [C.POINTER(C.c_int)]),
     "op_release_cached_memory": (C.c_int, []),
     "op_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "op_camera_preset": (C.c_int, [C.c_int, C.POINTER(Camera)]),
@@ -90,6 +93,7 @@ SIGNATURES = {
     "op_volume_set_truncation": (C.c_int, [_vp, C.c_float]),
     "op_volume_set_camera": (C.c_int, [_vp, C.POINTER(Camera)]),
     "op_volume_set_near_far": (C.c_int, [_vp, C.c_float, C.c_float]),
+    "op_volume_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "op_volume_clear": (C.c_int, [_vp]),
     "op_volume_sync": (C.c_int, [_vp]),
     "op_volume_flush": (C.c_int, [_vp]),

@@ -14,8 +14,8 @@
 // Temporaries come from the library's buffer cache (a steady stream of merges allocates nothing); rank-local failures are
 // agreed on over the communicator before the bulk transfer, so no rank is left waiting inside RCCL.
 // Keys and weights are exact for any rank count; sdf / colour differ from a sequential Merge chain only in fp32
-// summation order (<= 1e-6 relative).  RCCL is bound at run time (dlopen "librccl.so.1"): a host that never merges --
-// or a Python process whose torch already carries its own RCCL -- does not need it at link time.
+// summation order (<= 1e-6 relative).  RCCL is bound at run time (dlopen "librccl.so.1", or the library ONEPIECE_RCCL_LIBRARY names): a host
+// that never merges -- or a Python process whose torch already carries its own RCCL -- does not need it at link time.
 // Threading: call from one host thread (or process) per rank, like any NCCL collective without group semantics.
 #include "common.hpp"
 
@@ -51,8 +51,13 @@ const Rccl& rccl() {
     static Rccl r = [] {
         Rccl t;
         void* h = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        // ONEPIECE_RCCL_LIBRARY names the library to bind instead of the system's RCCL (a site-specific build; the test suite points it at
+        // tests/cpp/librccl_double.so to run several ranks on ONE device, which the real RCCL refuses).  When set it is the only candidate.
+        const char* forced = std::getenv("ONEPIECE_RCCL_LIBRARY");
+        if (forced && *forced) h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        else
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
         if (!h) {
             const char* e = dlerror();
             std::snprintf(t.why, sizeof(t.why), "%s", e ? e : "dlopen failed");
@@ -126,11 +131,15 @@ extern "C" int op_volume_merge_rccl_stats(op_volume* v, void* nccl_comm, int roo
     size_t n_local = 0;
     int rc = op_volume_block_count(v, &n_local); // flushes queued frames, synchronises, selects nothing yet
     void* sv = nullptr;
-    if (rc == OP_OK) rc = op_volume_stream(v, &sv);
+    { // the stream is needed ALSO when the volume has failed: the failure is announced to the other ranks over it (counts all-gather below)
+        const int src = op_volume_stream(v, &sv);
+        if (rc == OP_OK) rc = src;
+    }
     hipStream_t stream = (hipStream_t)sv, cstream = nullptr;
     hipDevice_t dev = 0;
-    if (rc == OP_OK && hipStreamGetDevice(stream, &dev) != hipSuccess) rc = fail(OP_ERR_HIP, "hipStreamGetDevice failed");
-    if (rc == OP_OK && hipSetDevice((int)dev) != hipSuccess) rc = fail(OP_ERR_HIP, "hipSetDevice failed");
+    // (also for a volume that has failed: its announcement needs a few bytes of memory on ITS device)
+    if (stream && hipStreamGetDevice(stream, &dev) != hipSuccess && rc == OP_OK) rc = fail(OP_ERR_HIP, "hipStreamGetDevice failed");
+    if (stream && hipSetDevice((int)dev) != hipSuccess && rc == OP_OK) rc = fail(OP_ERR_HIP, "hipSetDevice failed");
     // one rank: nothing to merge.  (ONEPIECE_RCCL_FORCE=1 runs the whole exchange anyway -- a one-rank all-gather and
     // reduce -- so that the RCCL path can be exercised on a single-GPU box; sdf / colour then pass through the sum form,
     // (w*s)/w, and may move by one rounding.)
@@ -154,11 +163,12 @@ extern "C" int op_volume_merge_rccl_stats(op_volume* v, void* nccl_comm, int roo
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 
     // 1. counts (a rank that has already failed announces -1 and everybody leaves), then padded keys
-    OP_LOCAL(op::cached_malloc((void**)&d_small, (size_t)(world + 2) * sizeof(int)));
-    if (!d_small) return rc; // nothing was communicated yet, but without device memory this rank cannot say so: the caller must abort the communicator
+    // (unconditionally -- not OP_LOCAL, which does nothing once rc is set: a rank that ENTERS with a failed volume must still announce it)
+    if (op::cached_malloc((void**)&d_small, (size_t)(world + 2) * sizeof(int)) != hipSuccess) d_small = nullptr;
+    if (!d_small) return rc != OP_OK ? rc : fail(OP_ERR_HIP, "no device memory for the merge's counters"); // nothing was communicated yet, but without device memory this rank cannot say so: the caller must abort the communicator
     {
         const int n_mine = rc == OP_OK ? (int)n_local : -1;
-        OP_LOCAL(hipMemcpyAsync(d_small, &n_mine, sizeof(int), hipMemcpyHostToDevice, stream));
+        if (hipMemcpyAsync(d_small, &n_mine, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) { if (rc == OP_OK) rc = fail(OP_ERR_HIP, "count upload failed"); fatal = true; goto done; }
         OP_NCCL(rccl().AllGather(d_small, d_small + 1, 1, ncclInt32, comm, stream));
         if (hipMemcpyAsync(counts.data(), d_small + 1, world * sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
             rc = fail(OP_ERR_HIP, "reading the gathered block counts failed"); fatal = true; goto done;

@@ -54,6 +54,13 @@ namespace op {
 thread_local char g_last_error[512] = "";
 }
 
+// Load-time defaults of the HIP runtime this library relies on.  Every volume and every tracker owns a HIP stream; the runtime maps
+// streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and streams that share a queue serialise: four trackers in
+// flight + the fusing volume reach 2.6 k frames/s on 4 queues and 4.5 k on 8.  The runtime reads the variable when
+// it initialises (its first API call), so setting it when this library is LOADED is early enough for every consumer that links it or
+// dlopens it before touching HIP; a value the caller has set is never overwritten.  op_runtime_hw_queues() reports what is in force.
+__attribute__((constructor)) static void op_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 namespace {
 
 using op::fail;
@@ -121,9 +128,25 @@ struct BatchPtrs { const void* depth[kMaxBatch]; const unsigned char* rgb[kMaxBa
 #endif
 constexpr int kKcShares = KC_SHARES; // k_integrate: the batch list is dealt to this many draw counters (a multiple of 8: workgroup b draws from share b % kKcShares, on XCD b % 8)
 static_assert(kKcShares % 8 == 0 && kKcShares <= 256, "whole XCDs");
+// The batch's block list can be kept as kBands lists (-DKC_BANDS=1).  A FULL batch (>= KC_STEAL_MIN_FRAMES frames) then files a block under the
+// horizontal image band its first selecting frame sees it in (k_select), and k_integrate's XCD x starts on list x: the workgroups of one XCD -- one
+// 4 MiB L2 -- gather from one eighth of every packed frame of the batch instead of from all of them.  Measured (round 4, profiles/r04_ab_bands.txt,
+// 32-frame launches of the bench scene): L2 misses fall by 16 % (exact update: FETCH_SIZE 469 -> 393 MB x 2 per launch) to 20 % (sum form: 410 -> 327),
+// the launch takes the SAME time with the exact update (676 us both ways) and 5 % LONGER with the sum form (524 -> 551 us): the kernel is bound by
+// instruction issue, not by its L2 misses (which the 256 MB MALL serves), and lists of unequal length drain less evenly than equal shares of one
+// list.  Not the default.  Short batches use list 0 only in either build, dealt to the XCDs in chunks.
+#ifndef KC_BANDS
+#define KC_BANDS 0
+#endif
+#ifndef KC_STEAL_MIN_FRAMES
+#define KC_STEAL_MIN_FRAMES 24
+#endif
+constexpr int kBands = 8;
+static_assert(kBands == kKcShares, "one list per draw counter");
 constexpr int kKcTSlots = 256; // k_integrate's workgroup b reports its duration to slot b % 256 (atomics on one address serialise at ~100 ns each)
 struct State {
-    unsigned n_batch;   // length of the batch block list
+    // (the first 32 bytes are what the host's synchronous paths read: StateHead below)
+    unsigned n_batch;   // (unused since the batch list became kBands lists: n_list below)
     unsigned overflow;  // bit0 pool full, bit1 table full, bit2 bbox too large, bit3 coordinate range
     unsigned n_rec;     // PrepareCubes record mode: entries in sel_list / sel_cand
     unsigned fail_seq;  // sequence number of the batch that first ran out of pool / table space (valid while overflow & 3)
@@ -146,7 +169,11 @@ struct State {
     unsigned acc[kMaxBatch][kAccSlots][8]; // kAccSlots sets per frame (workgroup x uses set x % kAccSlots): atomics on ONE
                                             // address serialise at ~100 ns each, 300 of them cost KA 35 us
     unsigned kc_next[kKcShares * 16]; // KC dynamic scheduling: next list position of each share of the batch list (one cache line each)
+    unsigned n_list[kBands];          // lengths of the batch's block lists (list b = blist + b * max_blocks); a short batch only fills list 0
 };
+
+struct StateHead { unsigned n_batch, overflow, n_rec, fail_seq, cur_seq, pad[3]; }; // = the first 32 bytes of State
+static_assert(sizeof(StateHead) == 32 && offsetof(State, stat_frames) == 32, "StateHead mirrors the head of State");
 
 struct VolView {
     unsigned long long* tkeys; // packed block id or kEmptyKey
@@ -157,7 +184,7 @@ struct VolView {
     unsigned max_blocks;
     unsigned* n_blocks;
     bmask_t* bmask;            // per TABLE slot: which frames of the current batch selected the block
-    int* blist;                // table slots touched by the current batch
+    int* blist;                // table slots touched by the current batch: kBands lists of max_blocks entries each (State::n_list)
     int* sel_list;             // record mode (PrepareCubes): table slot (translated to pool slot by k_finish_select) + candidate rank
     unsigned long long* sel_cand;
 };
@@ -325,7 +352,7 @@ __global__ void k_rehash(unsigned long long* __restrict__ tkeys, int* __restrict
 // recorded table slots into pool slots.
 __global__ void k_finish_select(VolView V, State* st) {
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u; // as KC does
-    const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
+    const unsigned n = st->n_list[0] < V.max_blocks ? st->n_list[0] : V.max_blocks; // a one-frame batch: list 0 only
     const unsigned nr = st->n_rec < V.max_blocks ? st->n_rec : V.max_blocks;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) V.bmask[V.blist[i]] = (bmask_t)0;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) V.sel_list[i] = V.tvals[V.sel_list[i]];
@@ -342,7 +369,7 @@ __global__ void k_mark_cubes(VolView V, State* st, const int* __restrict__ keys,
     const int slot = table_claim(V, st, x, y, z, &created);
     if (slot < 0) return;
     if (atomicOr(&V.bmask[slot], (bmask_t)1) == (bmask_t)0) { // a key listed twice is fused once
-        const unsigned pos = atomicAdd(&st->n_batch, 1u);
+        const unsigned pos = atomicAdd(&st->n_list[0], 1u);
         if (pos < V.max_blocks) V.blist[pos] = slot;
     }
 }
@@ -375,7 +402,8 @@ __global__ __launch_bounds__(256) void k_prepare_frames(KaFwd B, int f0, CamPara
     __shared__ float s_tile[4][4][2];
     const int tid = threadIdx.x, f = f0 + (int)blockIdx.y; // frame of the batch
     if (blockIdx.x == 0 && f == 0 && tid == 0) {
-        st->n_batch = 0; st->n_rec = 0; // new batch: empty lists
+        st->n_rec = 0; // new batch: empty lists
+        for (int b = 0; b < kBands; ++b) st->n_list[b] = 0;
         st->cur_seq = seq;
         // Progress report for the host (host-mapped pinned memory, read without any synchronisation): this kernel starting
         // means every earlier batch has finished; unless the stream is poisoned by an overflow they all completed.  The host
@@ -431,15 +459,15 @@ __global__ __launch_bounds__(256) void k_prepare_frames(KaFwd B, int f0, CamPara
                 const unsigned d0 = c3[0], d1 = c3[1], d2 = c3[2];
                 cc[0] = d0 & 0xffffffu; cc[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8); cc[2] = (d1 >> 16) | ((d2 & 0xffu) << 16); cc[3] = d2 >> 8;
             }
-            uint4* o4 = reinterpret_cast<uint4*>(out + pix0);
-            o4[0] = make_uint4(__float_as_uint(zz[0]), cc[0], __float_as_uint(zz[1]), cc[1]);
-            o4[1] = make_uint4(__float_as_uint(zz[2]), cc[2], __float_as_uint(zz[3]), cc[3]);
+            uint4* o4 = reinterpret_cast<uint4*>(out + pix0); // byte 3 of the colour word = 1: the observation count k_integrate's sum form adds up
+            o4[0] = make_uint4(__float_as_uint(zz[0]), cc[0] | 0x01000000u, __float_as_uint(zz[1]), cc[1] | 0x01000000u);
+            o4[1] = make_uint4(__float_as_uint(zz[2]), cc[2] | 0x01000000u, __float_as_uint(zz[3]), cc[3] | 0x01000000u);
         } else {
             for (int e = 0; e < nv; ++e) {
                 const int pix = pix0 + e;
                 zz[e] = C.depth_u16 ? (float)((const unsigned short*)dptr)[pix] / C.depth_scale : ((const float*)dptr)[pix];
                 if (cptr) cc[e] = (unsigned)cptr[3 * (size_t)pix] | ((unsigned)cptr[3 * (size_t)pix + 1] << 8) | ((unsigned)cptr[3 * (size_t)pix + 2] << 16);
-                out[pix] = make_uint2(__float_as_uint(zz[e]), cc[e]);
+                out[pix] = make_uint2(__float_as_uint(zz[e]), cc[e] | 0x01000000u);
             }
         }
 #pragma unroll
@@ -557,6 +585,8 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
     __shared__ unsigned s_nsurv, s_nfirst, s_nrec, s_base[2];
     __shared__ unsigned s_surv[kSBPerWg];
     __shared__ int s_first[kSBPerWg * kSBVol];
+    __shared__ unsigned short s_fpos[kSBPerWg * kSBVol]; // band (3 bits) | rank within the workgroup's entries of that band << 3
+    __shared__ unsigned s_bcnt[kBands], s_bbase[kBands];
     __shared__ int s_rslot[kSBPerWg * kSBVol];
     __shared__ unsigned long long s_rcand[kSBPerWg * kSBVol];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -624,7 +654,11 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
         }
         s_nsurv = 0u; s_nfirst = 0u; s_nrec = 0u;
     }
+    if (tid < kBands) s_bcnt[tid] = 0u;
     __syncthreads();
+    // full batches file a block under the image band (eighths of the image height) it is first seen in; see kBands
+    const bool bands = KC_BANDS != 0 && (int)gridDim.y >= KC_STEAL_MIN_FRAMES && record == 0;
+    const float band_scale = 8.0f / (float)(C.width * C.height);
     const int i0 = s_range[0], j0 = s_range[1], k0 = s_range[2];
     int ni = s_range[3], nj = s_range[4], nk = s_range[5];
     unsigned long long ncand = (unsigned long long)((long long)ni * nj * nk);
@@ -708,7 +742,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
             const int sk = (int)(sb - q1 * nsk), sj = (int)(q1 - q2 * nsj), si = (int)q2;
             const int ci = si * kSB + (lane >> 4), cj = sj * kSB + ((lane >> 2) & 3), ck = sk * kSB + (lane & 3); // position in the range
             bool first = false, rec = false;
-            int pool_idx = -1;
+            int pool_idx = -1, band = 0;
             if (ci < ni && cj < nj && ck < nk) {
                 const int bi = i0 + ci, bj = j0 + cj, bk = k0 + ck;
                 const float bx = (float)bi * cube_res, by = (float)bj * cube_res, bz = (float)bk * cube_res;
@@ -728,8 +762,9 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
                     pix[corner] = project_pixel<FAST>(C, q0, q1c, q2c);
                 }
                 float dd[8];
+                int pmax = pix[0]; // the lowest on-image corner (largest pixel index): files the block under an image band below
 #pragma unroll
-                for (int corner = 0; corner < 8; ++corner) dd[corner] = pix[corner] >= 0 ? __uint_as_float(img[(unsigned)pix[corner]].x) : 0.0f;
+                for (int corner = 0; corner < 8; ++corner) { dd[corner] = pix[corner] >= 0 ? __uint_as_float(img[(unsigned)pix[corner]].x) : 0.0f; pmax = max(pmax, pix[corner]); }
                 float min_sdf = FLT_MAX;
 #pragma unroll
                 for (int corner = 0; corner < 8; ++corner) {
@@ -746,6 +781,8 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
                         if (pool_idx >= 0) {
                             first = atomicOr(&V.bmask[pool_idx], fbit) == (bmask_t)0;
                             rec = record != 0;
+                            // the image row of the block's lowest on-image corner (pixel index / pixels per band; a heuristic, any band is correct)
+                            if (bands) band = min(kBands - 1, (int)((float)max(pmax, 0) * band_scale));
                         }
                     }
                 }
@@ -757,7 +794,11 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(&s_nfirst, (unsigned)__popcll(m_a));
                 base = __shfl(base, 0, 64);
-                if (first) s_first[base + __popcll(m_a & below)] = pool_idx;
+                if (first) {
+                    const unsigned k = base + __popcll(m_a & below);
+                    s_first[k] = pool_idx;
+                    s_fpos[k] = (unsigned short)((unsigned)band | ((bands ? atomicAdd(&s_bcnt[band], 1u) : k) << 3));
+                }
             }
             if (m_b) {
                 unsigned base = 0;
@@ -774,15 +815,19 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
         __syncthreads();
         // ---- one global append per workgroup and list
         const unsigned nfirst = s_nfirst, nrec = s_nrec;
+        if (tid < kBands) { // one global append per list
+            const unsigned c = bands ? s_bcnt[tid] : (tid == 0 ? nfirst : 0u);
+            s_bbase[tid] = c ? atomicAdd(&st->n_list[tid], c) : 0u;
+        }
         if (tid == 0) {
-            s_base[0] = nfirst ? atomicAdd(&st->n_batch, nfirst) : 0u;
             s_base[1] = nrec ? atomicAdd(&st->n_rec, nrec) : 0u;
             s_nsurv = 0u;
         }
         __syncthreads();
         for (unsigned k = (unsigned)tid; k < nfirst; k += 256u) {
-            const unsigned pos = s_base[0] + k;
-            if (pos < V.max_blocks) V.blist[pos] = s_first[k];
+            const unsigned fp = s_fpos[k], b = fp & 7u;
+            const unsigned pos = s_bbase[b] + (fp >> 3);
+            if (pos < V.max_blocks) V.blist[(size_t)b * V.max_blocks + pos] = s_first[k];
         }
         for (unsigned k = (unsigned)tid; k < nrec; k += 256u) {
             const unsigned pos = s_base[1] + k;
@@ -790,7 +835,8 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
         }
         __syncthreads(); // the lists are reused by the next chunk
         if (tid == 0) { s_nfirst = 0u; s_nrec = 0u; }
-        // (the next chunk's coarse test does not touch s_nfirst / s_nrec; its __syncthreads orders the reset before their next use)
+        if (tid < kBands) s_bcnt[tid] = 0u;
+        // (the next chunk's coarse test does not touch s_nfirst / s_nrec / s_bcnt; its __syncthreads orders the reset before their next use)
     }
 }
 
@@ -863,7 +909,13 @@ __device__ __forceinline__ void voxel_update(float& s, float& w, float& c0, floa
     }
 }
 
-template <bool FAST, bool PLAIN, int ZT>
+// SUMF (opt-in, OP_VOLUME_UPDATE_SUM_FORM): the frames of the batch are not applied one by one.  Per voxel the kernel keeps the NUMBER of in-band
+// observations of the batch, the sum of their sdf values and the sums of their colour bytes (exact integers), and forms the weighted mean with the
+// stored voxel ONCE per batch: s' = (w s + sum sdf) / (w + n), c' = (w c + sum bytes / 255) / (w + n), w' = w + n -- TSDFVoxel::operator+
+// (TSDFVoxel.h:24-39) applied n times in exact arithmetic.  Same blocks, same pixels, same weights (integers); sdf and colour differ from the
+// frame-by-frame running mean by float rounding only (a few 1e-7 relative; north_star's bar is 1e-4).  Per voxel and frame the ~35 instructions
+// of the exactly rounded update shrink to 7 (two selects, one float add, two byte-pair adds with their masks).
+template <bool FAST, bool PLAIN, int ZT, bool SUMF = false>
 __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                                             int n_frames, unsigned long long* __restrict__ upd_partial,
                                                                             unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial,
@@ -876,9 +928,8 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
     // KB has consumed the frames' bounding accumulators: back to the identity for the next batch (also when poisoned)
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u;
     if (st->overflow & 3u) return; // pool / table exhausted in this or an earlier batch: nothing is fused, the host replays
-    const unsigned n = st->n_batch < V.max_blocks ? st->n_batch : V.max_blocks;
     const int tid = threadIdx.x, lane = tid & 63, zg = tid >> 6;
-    for (int k = tid; k < 256; k += blockDim.x) s_c255[k] = (float)k / 255.0f;
+    if (!SUMF) for (int k = tid; k < 256; k += blockDim.x) s_c255[k] = (float)k / 255.0f;
     const unsigned npix = (unsigned)(C.width * C.height);
     const float half = C.res / 2;
     // VoxelCentroidOffSet (VoxelCube.h:48-61): x*res + half with x = lane & 7, y = lane >> 3
@@ -891,55 +942,71 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
 #ifndef KC_CHUNK_LOG2
 #define KC_CHUNK_LOG2 5
 #endif
-#ifndef KC_STEAL_MIN_FRAMES
-#define KC_STEAL_MIN_FRAMES 24
-#endif
-    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2; list neighbours -- blocks along one viewing ray, which gather
-    // the same pixels -- should meet in one L2) and dynamic scheduling (blocks differ in work: 1..32 frames touch them; the workgroups of an XCD
-    // DRAW list positions from one counter, the next one before the current block is processed so that the atomic's round trip is hidden).
-    // Two ways of dealing the list to the eight draw counters:
-    //  * full batches (>= KC_STEAL_MIN_FRAMES frames): every XCD starts on ONE contiguous eighth of the list; the eighths hold the same number of
-    //    blocks but not the same work, so a workgroup whose share is exhausted reads all eight counters (one round trip) and goes on with the share
-    //    that has the most left.  Per 32-frame launch: eighths alone 689 us, with stealing 627-631 us;
-    //  * short batches: chunks of 32 blocks dealt round-robin (every XCD a sample of the whole list), no stealing.  Same 638 us for 32 frames but
-    //    18 % more L2 misses (FETCH_SIZE 559 against 472 MB x 2); for ONE frame per launch, where the kernel is HBM-bound and the work per
-    //    block uniform, 79 us against 95 us with stealing (its last look costs a short launch more than it can win).
-    //    Measured crossover (tools/prof_driver.bin batch=N under the tracer, stealing vs chunks): 8 frames 207 vs 194 us, 16: 360 vs 356, 24: 524 vs 527,
-    //    32: 677 vs 687.
+    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2; blocks that gather the same pixels should meet in one L2)
+    // and dynamic scheduling (blocks differ in work: 1..32 frames touch them; the workgroups of an XCD DRAW list positions from one counter,
+    // the next one before the current block is processed so that the atomic's round trip is hidden).  Two ways of dealing the batch's blocks
+    // to the eight draw counters:
+    //  * full batches (>= KC_STEAL_MIN_FRAMES frames): XCD x starts on the x-th contiguous eighth of the list (with -DKC_BANDS=1 on list x, see
+    //    kBands); the eighths hold the same number of blocks but not the same work, so a workgroup whose share is exhausted reads all eight
+    //    counters (one round trip) and goes on with the share that has the most left.
+    //    Per 32-frame launch: eighths alone 689 us, with stealing 627-631 us;
+    //  * short batches: list 0, chunks of 32 blocks dealt round-robin (every XCD a sample of the whole list), no stealing: for ONE frame per
+    //    launch, where the kernel is HBM-bound and the work per block uniform, 79 us against 95 us with stealing (its last look costs a short
+    //    launch more than it can win).  Measured crossover (tools/prof_driver.bin batch=N under the tracer, stealing vs chunks): 8 frames
+    //    207 vs 194 us, 16: 360 vs 356, 24: 524 vs 527, 32: 677 vs 687.
     const bool eighths = n_frames >= KC_STEAL_MIN_FRAMES;
+    const bool lists = eighths && KC_BANDS != 0;              // one list per share
     constexpr unsigned kChunk = 1u << KC_CHUNK_LOG2;
-    const unsigned n_chunks = (n + kChunk - 1u) >> KC_CHUNK_LOG2;
-    const unsigned per_xcd = eighths ? (n + (unsigned)kKcShares - 1u) / (unsigned)kKcShares : ((n_chunks + (unsigned)kKcShares - 1u) / (unsigned)kKcShares) << KC_CHUNK_LOG2;
+    const unsigned n0 = st->n_list[0] < V.max_blocks ? st->n_list[0] : V.max_blocks;
+    const unsigned n_chunks = (n0 + kChunk - 1u) >> KC_CHUNK_LOG2;
+    const unsigned per0 = eighths ? (n0 + (unsigned)kKcShares - 1u) / (unsigned)kKcShares : ((n_chunks + (unsigned)kKcShares - 1u) / (unsigned)kKcShares) << KC_CHUNK_LOG2;
     unsigned xcd = blockIdx.x % (unsigned)kKcShares;          // the share this workgroup draws from: its own first
     for (;;) {
     unsigned* ctr = &st->kc_next[xcd * 16u];
     if (tid == 0) s_next[0] = atomicAdd(ctr, 1u);
+    // positions j < per_xcd of share xcd; its blocks are list[j] (one list per share) or positions of list 0
+    unsigned per_xcd = per0, n = n0;
+    const int* list = V.blist;
+    if (lists) {
+        const unsigned nl = st->n_list[xcd];
+        per_xcd = n = nl < V.max_blocks ? nl : V.max_blocks;
+        list = V.blist + (size_t)xcd * V.max_blocks;
+    }
     __syncthreads();
     unsigned slot = 0u;
     for (unsigned j = s_next[0]; j < per_xcd;) {
         if (tid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
-        const unsigned b = eighths ? xcd * per_xcd + j : (((j >> KC_CHUNK_LOG2) * (unsigned)kKcShares + xcd) << KC_CHUNK_LOG2) + (j & (kChunk - 1u));
-        const int idx = b < n ? V.tvals[V.blist[b]] : -1; // idx < 0: pool overflow (reported through st->overflow)
+        const unsigned b = lists ? j : (eighths ? xcd * per_xcd + j : (((j >> KC_CHUNK_LOG2) * (unsigned)kKcShares + xcd) << KC_CHUNK_LOG2) + (j & (kChunk - 1u)));
+        const int tslot = b < n ? list[b] : -1;
+        const int idx = tslot >= 0 ? V.tvals[tslot] : -1; // idx < 0: pool overflow (reported through st->overflow)
         if (idx >= 0) {
-            const bmask_t mask = V.bmask[V.blist[b]];
+            const bmask_t mask = V.bmask[tslot];
             if (zg == 0) { sel += mask_popc(mask); ++nblk; }
             const int kx = V.keys[3 * idx], ky = V.keys[3 * idx + 1], kz = V.keys[3 * idx + 2];
             float* vox = V.pool + (size_t)idx * kBlockFloats + (zg * ZT) * 64 + lane;
             float s[ZT], w[ZT], c0[ZT], c1[ZT], c2[ZT], pz[ZT];
 #pragma unroll
             for (int z = 0; z < ZT; ++z) {
-                s[z] = vox[z * 64]; w[z] = vox[kVox + z * 64]; c0[z] = vox[2 * kVox + z * 64]; c1[z] = vox[3 * kVox + z * 64]; c2[z] = vox[4 * kVox + z * 64];
+                // (the sum form needs the stored voxel only after the frames: it is loaded there, and the registers are free until then)
+                if (!SUMF) { s[z] = vox[z * 64]; w[z] = vox[kVox + z * 64]; c0[z] = vox[2 * kVox + z * 64]; c1[z] = vox[3 * kVox + z * 64]; c2[z] = vox[4 * kVox + z * 64]; }
                 // GetGlobalPoint (VoxelCube.h:75-80): Point3(id) * CUBE_SIZE * VoxelResolution + offset
                 pz[z] = ((float)kz * 8.0f) * C.res + ((float)(zg * ZT + z) * C.res + half);
             }
             const float px = ((float)kx * 8.0f) * C.res + ox;
             const float py = ((float)ky * 8.0f) * C.res + oy;
             unsigned changed = 0u;
+            // sum form: sdf sum, byte sums of colour channels 0 and 2 in the two halves of one word, of channel 1 in the low half of another whose
+            // high half counts the observations (<= 64 frames x 255 < 2^16)
+            float ssum[ZT];
+            unsigned acc02[ZT], acc1n[ZT];
+#pragma unroll
+            for (int z = 0; z < ZT; ++z) { ssum[z] = 0.0f; acc02[z] = 0u; acc1n[z] = 0u; }
             // one selected frame: projections of the thread's ZT voxels and their {depth, rgba} gathers
             auto project = [&](int f, kc_v2u (&rec)[ZT], float (&zc)[ZT]) {
                 int fo = f;
                 asm volatile("" : "+s"(fo));
                 const float __attribute__((address_space(4)))* M = kargs + fo * 12;
+                // (frame base in 32 bits: check_cam keeps kMaxBatch x npix x 8 below 2^32)
                 const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pimg + (unsigned)fo * (npix * 8u)), 0, (int)(npix * 8u), 0x00020000);
                 const float a0 = M[0] * px + M[1] * py, a1 = M[4] * px + M[5] * py, a2 = M[8] * px + M[9] * py;
 #pragma unroll
@@ -967,7 +1034,12 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
                     const float band = d > 0 ? fabsf(new_sdf) : C.trunc;
                     const bool hit = band < C.trunc;
                     upd += hit ? 1u : 0u;                              // per lane; summed over the wave at the end
-                    if (hit) {
+                    if (SUMF) { // branch-free: an observation that misses adds zeros
+                        ssum[z] += hit ? new_sdf : 0.0f;
+                        const unsigned t = hit ? rec[z].y : 0u;           // byte 3 of a packed pixel is 1 (k_prepare_frames): the count
+                        acc02[z] += t & 0x00ff00ffu;
+                        acc1n[z] += (t >> 8) & 0x00ff00ffu;
+                    } else if (hit) {
                         changed |= 1u << z;
                         voxel_update<kPlain>(s[z], w[z], c0[z], c1[z], c2[z], new_sdf, rec[z].y, s_c255);
                     }
@@ -991,14 +1063,36 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
                     if (!more2) break;
                 }
             };
-            if (PLAIN || plain_block) frames(std::true_type{}); else frames(std::false_type{});
+            if (SUMF || PLAIN || plain_block) frames(std::true_type{}); else frames(std::false_type{});
+            if (SUMF) {
+#pragma unroll
+                for (int z = 0; z < ZT; ++z)
+                    if (acc1n[z] >> 16) { s[z] = vox[z * 64]; w[z] = vox[kVox + z * 64]; c0[z] = vox[2 * kVox + z * 64]; c1[z] = vox[3 * kVox + z * 64]; c2[z] = vox[4 * kVox + z * 64]; }
+#pragma unroll
+                for (int z = 0; z < ZT; ++z) {
+                    const unsigned cnt = acc1n[z] >> 16;
+                    if (cnt) {
+                        changed |= 1u << z;
+                        // TSDFVoxel::operator+ (TSDFVoxel.h:24-39) for the batch's observations at once; an invalid voxel (IsValid false,
+                        // :75-78) is replaced by their mean, as the first observation would have replaced it
+                        const bool valid = !(s[z] >= 1 || w[z] <= 0);
+                        const float wv = valid ? w[z] : 0.0f, nf = (float)cnt, wsum = wv + nf;
+                        const float b0 = (float)(acc02[z] & 0xffffu) / 255.0f, b1 = (float)(acc1n[z] & 0xffffu) / 255.0f, b2 = (float)(acc02[z] >> 16) / 255.0f;
+                        s[z] = ((valid ? wv * s[z] : 0.0f) + ssum[z]) / wsum;
+                        c0[z] = ((valid ? wv * c0[z] : 0.0f) + b0) / wsum;
+                        c1[z] = ((valid ? wv * c1[z] : 0.0f) + b1) / wsum;
+                        c2[z] = ((valid ? wv * c2[z] : 0.0f) + b2) / wsum;
+                        w[z] = wsum;
+                    }
+                }
+            }
 #pragma unroll
             for (int z = 0; z < ZT; ++z)
                 if ((changed >> z) & 1u) { vox[z * 64] = s[z]; vox[kVox + z * 64] = w[z]; vox[2 * kVox + z * 64] = c0[z]; vox[3 * kVox + z * 64] = c1[z]; vox[4 * kVox + z * 64] = c2[z]; }
             chg += (unsigned)__popc(changed);
         }
         __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
-        if (b < n && tid == 0) V.bmask[V.blist[b]] = (bmask_t)0; // the owner clears it for the next batch
+        if (tslot >= 0 && tid == 0) V.bmask[tslot] = (bmask_t)0; // the owner clears it for the next batch
         slot ^= 1u;
         j = s_next[slot];
     }
@@ -1009,9 +1103,11 @@ __global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchI
         unsigned left = 0u;
         if (tid < kKcShares) {
             const unsigned c = __hip_atomic_load(&st->kc_next[(unsigned)tid * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            left = c < per_xcd ? per_xcd - c : 0u;
+            unsigned len = per0;
+            if (lists) { const unsigned nl = st->n_list[tid]; len = nl < V.max_blocks ? nl : V.max_blocks; }
+            left = c < len ? len - c : 0u;
         }
-        unsigned key = (left << 8) | (unsigned)tid;            // most left, ties to the higher share index (any fixed rule)
+        unsigned key = ((left < 0x7fffffu ? left : 0x7fffffu) << 8) | (unsigned)tid; // most left, ties to the higher share index (any fixed rule)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned x = __shfl_xor(key, o, 64); key = x > key ? x : key; }
         if (tid == 0) s_next[0] = key;
@@ -1556,6 +1652,7 @@ struct op_volume {
     // true while every voxel was written by k_integrate only since create / clear (see k_integrate<., PLAIN>): any other
     // writer (upload, merge, sum-form unpack, resampling result, file) clears it and fusion takes the general update
     bool plain = true;
+    int update_mode = 0;         // OP_VOLUME_OPT_UPDATE: OP_VOLUME_UPDATE_EXACT (the reference's frame-by-frame running mean, bit for bit) or _SUM_FORM
     unsigned plain_from = 0;     // with !plain: pool slots below this bound may hold foreign data (general update); later blocks are k_integrate's own
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
     size_t unpack_n = 0;
@@ -1620,7 +1717,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     bmask_t* bmask = nullptr;
     hipError_t e = op::cached_malloc((void**)&pool, sizeof(float) * kBlockFloats * (size_t)new_max);
     if (e == hipSuccess) e = op::cached_malloc((void**)&keys, sizeof(int) * 3 * (size_t)new_max);
-    if (e == hipSuccess) e = op::cached_malloc((void**)&blist, sizeof(int) * (size_t)new_max);
+    if (e == hipSuccess) e = op::cached_malloc((void**)&blist, sizeof(int) * (size_t)(KC_BANDS ? kBands : 1) * (size_t)new_max);
     if (e == hipSuccess) e = op::cached_malloc((void**)&sel_list, sizeof(int) * (size_t)new_max);
     if (e == hipSuccess) e = op::cached_malloc((void**)&sel_cand, sizeof(unsigned long long) * (size_t)new_max);
     if (e == hipSuccess) e = op::cached_malloc((void**)&tkeys, sizeof(unsigned long long) * (size_t)new_table);
@@ -1684,7 +1781,7 @@ void vol_retire(op_volume* v) {
 // (bad frames) are left for the caller to report.
 int vol_recover(op_volume* v, unsigned* flags_out) {
     for (;;) {
-        State st;
+        StateHead st; // the head only: State is ~20 KB, and a pageable device-to-host copy of 16 KB or more takes the runtime's pinned-staging path (ms)
         OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
         if (flags_out) *flags_out = st.overflow;
         if ((st.overflow & 3u) == 0u) {
@@ -1868,10 +1965,11 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (select_only)
         hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, v->state);
     else {
-#define OP_KC(FASTPX, PLAINV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, KC_ZT>), dim3(kColGrid), dim3(512 / KC_ZT), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
+#define OP_KC(FASTPX, PLAINV, SUMFV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, KC_ZT, SUMFV>), dim3(kColGrid), dim3(512 / KC_ZT), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
                                                  v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial, v->plain_from)
-        if (C.fast_px) { if (v->plain) OP_KC(true, true); else OP_KC(true, false); }
-        else { if (v->plain) OP_KC(false, true); else OP_KC(false, false); }
+        if (v->update_mode == OP_VOLUME_UPDATE_SUM_FORM) { if (C.fast_px) OP_KC(true, true, true); else OP_KC(false, true, true); }
+        else if (C.fast_px) { if (v->plain) OP_KC(true, true, false); else OP_KC(true, false, false); }
+        else { if (v->plain) OP_KC(false, true, false); else OP_KC(false, false, false); }
 #undef OP_KC
     }
     if (sample) {
@@ -2052,11 +2150,14 @@ int vol_ring_stage(op_volume* v, const void** depth, int depth_fmt, const unsign
     return OP_OK;
 }
 
+// The fusion kernels address a batch of kMaxBatch packed frames (8 B per pixel) with 32-bit byte offsets -- frame f starts at f * npix * 8
+// (k_integrate's buffer resource) -- and multiply image rows with 24-bit integer multiplies: 2^24 pixels (4096 x 4096) with batches of
+// up to 32 frames, 2^23 with the 64-frame build (-DOP_MAX_BATCH=64).
+constexpr long long kMaxPixels = (1LL << 29) / kMaxBatch < (1LL << 24) ? (1LL << 29) / kMaxBatch : (1LL << 24);
+static_assert((unsigned long long)kMaxBatch * (unsigned long long)kMaxPixels * 8ull <= (1ull << 32), "the last frame of a batch must start and end below 2^32 bytes");
 int check_cam(const op_camera* cam) {
-    // 2^24 pixels (4096 x 4096): the fusion kernels address a batch of 16 packed frames with 32-bit byte offsets
-    // (16 x 2^24 x 8 B = 2^31) and multiply image rows with 24-bit integer multiplies
-    if (!cam || cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > (1LL << 24))
-        return fail(OP_ERR_INVALID, "invalid camera (images of up to 2^24 pixels are supported)");
+    if (!cam || cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > kMaxPixels)
+        return fail(OP_ERR_INVALID, "invalid camera (images of up to %lld pixels are supported)", kMaxPixels);
     return OP_OK;
 }
 
@@ -2081,6 +2182,13 @@ void for_block_ranges(size_t n, F f) {
 extern "C" {
 
 int op_abi_version(void) { return OP_ABI_VERSION; }
+
+int op_runtime_hw_queues(int* requested) {
+    if (!requested) return fail(OP_ERR_INVALID, "null argument");
+    const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+    *requested = e ? std::atoi(e) : 4; // 4 = the runtime's own default
+    return OP_OK;
+}
 const char* op_last_error(void) { return op::g_last_error; }
 
 int op_device_count(int* count) {
@@ -2205,7 +2313,7 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     OP_HIP_C(op::cached_malloc((void**)&v->tkeys, sizeof(unsigned long long) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->tvals, sizeof(int) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->bmask, sizeof(bmask_t) * (size_t)v->table_size));
-    OP_HIP_C(op::cached_malloc((void**)&v->blist, sizeof(int) * (size_t)v->max_blocks));
+    OP_HIP_C(op::cached_malloc((void**)&v->blist, sizeof(int) * (size_t)(KC_BANDS ? kBands : 1) * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->sel_partial, sizeof(unsigned long long) * kPartialGrid));
     OP_HIP_C(op::cached_malloc((void**)&v->keys, sizeof(int) * 3 * (size_t)v->max_blocks));
     OP_HIP_C(op::cached_malloc((void**)&v->pool, sizeof(float) * kBlockFloats * (size_t)v->max_blocks));
@@ -2286,6 +2394,16 @@ int op_volume_set_near_far(op_volume* v, float near_dist, float far_dist) {
     OP_VOL(v);
     OP_TRY(vol_flush(v)); // queued frames were accepted under the old setting; launched batches carry their frustum planes with them
     v->near_d = near_dist; v->far_d = far_dist;
+    return OP_OK;
+}
+
+int op_volume_set_option(op_volume* v, int option, int value) {
+    OP_VOL(v);
+    if (option != OP_VOLUME_OPT_UPDATE) return fail(OP_ERR_INVALID, "op_volume_set_option: unknown option %d", option);
+    if (value != OP_VOLUME_UPDATE_EXACT && value != OP_VOLUME_UPDATE_SUM_FORM) return fail(OP_ERR_INVALID, "op_volume_set_option: bad value %d", value);
+    if (value == v->update_mode) return OP_OK;
+    OP_TRY(vol_check(v)); // queued and replayable batches were accepted under the old setting (see op_volume_set_resolution)
+    v->update_mode = value;
     return OP_OK;
 }
 
@@ -2392,11 +2510,13 @@ int op_volume_prepare_cubes(op_volume* v, const void* depth, int depth_fmt, int 
         OP_TRY(vol_check(v));
         if (v->max_blocks == cap_before) break;
     }
-    State st;
+    StateHead st;
     OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
+    unsigned long long n_cand0 = 0;
+    OP_HIP(hipMemcpy(&n_cand0, reinterpret_cast<const char*>(v->state) + offsetof(State, n_cand), sizeof(n_cand0), hipMemcpyDeviceToHost));
     const size_t ns = std::min((size_t)st.n_rec, (size_t)v->max_blocks);
     if (n) *n = ns;
-    if (n_candidates) *n_candidates = (size_t)st.n_cand[0];
+    if (n_candidates) *n_candidates = (size_t)n_cand0;
     if (ids_xyz && ns) {
         std::vector<int> list(ns);
         std::vector<unsigned long long> cand(ns);
@@ -2428,6 +2548,9 @@ int op_volume_integrate(op_volume* v, const void* depth, int depth_fmt, const ui
     // caller's buffers are only borrowed for the call); device images are used in place at flush.
     if (v->pend_n > 0 && v->pend_fmt != depth_fmt) OP_TRY(vol_flush(v));
     const unsigned char* c = rgb;
+    // The first host image of a volume (or a larger one) allocates the staging ring, and that launches whatever is queued
+    // (vol_ring_alloc -> vol_check -> vol_flush): the queue position is only valid afterwards.
+    if (mem == OP_MEM_HOST) OP_TRY(vol_ring_alloc(v));
     const int slot = v->pend_n;
     if (mem == OP_MEM_HOST) OP_TRY(vol_ring_stage(v, &depth, depth_fmt, &c, slot));
     frame_params(v, pose, pose_inv, &v->pend_F.f[slot], &v->pend_I.f[slot]);
@@ -2490,14 +2613,14 @@ int op_volume_integrate_sequence(op_volume* v, const void* depth, size_t depth_s
 int op_volume_stats(op_volume* v, uint64_t* frames, uint64_t* blocks_selected, uint64_t* voxels_visited, uint64_t* voxels_updated) {
     OP_VOL(v);
     OP_TRY(vol_check(v));
-    State st;
-    OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
+    unsigned long long stat_frames = 0;
+    OP_HIP(hipMemcpy(&stat_frames, reinterpret_cast<const char*>(v->state) + offsetof(State, stat_frames), sizeof(stat_frames), hipMemcpyDeviceToHost));
     std::vector<unsigned long long> part(2 * kPartialGrid);
     OP_HIP(hipMemcpy(part.data(), v->upd_partial, kPartialGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     OP_HIP(hipMemcpy(part.data() + kPartialGrid, v->sel_partial, kPartialGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long upd = 0, sel = 0;
     for (int i = 0; i < kPartialGrid; ++i) { upd += part[i]; sel += part[kPartialGrid + i]; }
-    if (frames) *frames = st.stat_frames;
+    if (frames) *frames = stat_frames;
     if (blocks_selected) *blocks_selected = sel;
     if (voxels_visited) *voxels_visited = sel * (uint64_t)kVox;
     if (voxels_updated) *voxels_updated = upd;
@@ -2507,8 +2630,9 @@ int op_volume_stats(op_volume* v, uint64_t* frames, uint64_t* blocks_selected, u
 int op_volume_stats_launches(op_volume* v, uint64_t* launches, uint64_t* blocks_read, uint64_t* voxels_written, uint64_t* shader_cycles) {
     OP_VOL(v);
     OP_TRY(vol_check(v));
-    State st;
-    OP_HIP(hipMemcpy(&st, v->state, sizeof(st), hipMemcpyDeviceToHost));
+    struct { unsigned long long stat_frames, stat_launches, kc_t[kKcTSlots], stat_kc_ticks; } st; // that stretch of State (2 KB), not all 20 KB of it
+    static_assert(offsetof(State, stat_kc_ticks) - offsetof(State, stat_frames) + 8 == sizeof(st), "contiguous statistics fields of State");
+    OP_HIP(hipMemcpy(&st, reinterpret_cast<const char*>(v->state) + offsetof(State, stat_frames), sizeof(st), hipMemcpyDeviceToHost));
     std::vector<unsigned long long> part(2 * kPartialGrid);
     OP_HIP(hipMemcpy(part.data(), v->chg_partial, 2 * kPartialGrid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long chg = 0, blk = 0;

@@ -118,6 +118,13 @@ class CubeHandler:
     def Clear(self):
         L.check(self._lib.op_volume_clear(self._h))
 
+    def SetUpdateMode(self, mode):
+        """Extension (op_volume_set_option / OP_VOLUME_OPT_UPDATE): "exact" (default; the reference's frame-by-frame running mean, voxels
+        bit-identical to the CPU path) or "sum_form" (one weighted mean per batch of frames: same blocks and weights, sdf / colour to
+        float rounding; a faster integrate kernel)."""
+        value = {"exact": L.OP_VOLUME_UPDATE_EXACT, "sum_form": L.OP_VOLUME_UPDATE_SUM_FORM}[mode]
+        L.check(self._lib.op_volume_set_option(self._h, L.OP_VOLUME_OPT_UPDATE, value))
+
     # -- the hot path
     def ComputeBounding(self, depth, pose):
         """CubeHandler.cpp:116-145 -> (max_pos, min_pos, n_points_inside_frustum)."""

@@ -298,7 +298,7 @@ def test_frustum_entry_points_and_argument_checks(hip, oracle):
     assert lib.op_frustum_from_vectors(None, pos.ctypes.data_as(fp), right.ctypes.data_as(fp), up.ctypes.data_as(fp), 5.0, 0.5, 1.0, 1.0, planes.ctypes.data_as(fp), None) == hip.OP_ERR_INVALID
     big = hip.Camera(500.0, 500.0, 4096.0, 4096.0, 8192, 8192, 1000.0)      # 2^26 pixels: beyond what the fusion kernels address
     assert lib.op_frustum_from_camera(C.byref(big), T.ctypes.data_as(fp), 5.0, 0.5, planes.ctypes.data_as(fp), None) == hip.OP_ERR_INVALID
-    assert b"2^24" in lib.op_last_error()
+    assert b"16777216 pixels" in lib.op_last_error()     # 2^24 with batches of up to 32 frames (2^23 in the 64-frame build)
     got = C.c_float(0)
     assert lib.op_get_sdf(C.byref(cam_h), None, T.ctypes.data_as(fp), None, C.c_void_p(planes.ctypes.data), hip.OP_DEPTH_F32, C.byref(got)) == hip.OP_ERR_INVALID
 

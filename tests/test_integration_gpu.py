@@ -749,3 +749,113 @@ def test_poses_whose_bottom_row_is_not_0001(oracle):
         assert ocand == hcand and np.array_equal(oids, hids), bottom
         ov.integrate(d, rgb, pose); hv.IntegrateImage(d, rgb, pose)
         _compare(oracle, ov, hv)
+
+
+def test_first_host_frame_after_queued_device_frames(oracle):
+    """A volume's FIRST host image allocates the staging ring, which launches whatever is queued; the new frame must then take position 0 of
+    the next batch, not the stale position (it used to be dropped and the previous batch's frame 0 fused twice).  Device frames from a sequence
+    call (their remainder stays queued), then host frames, then device frames again."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 11
+    depth, rgb, poses = S.room_sequence_torch(40, n, dev)
+    torch.cuda.synchronize()
+    dn, cn = depth.cpu().numpy(), rgb.cpu().numpy()
+    ov, hv = _mk(oracle, 0.01)
+    hv.IntegrateSequence(depth[:5], rgb[:5], poses[:5])        # 5 device frames queued, nothing launched
+    hv.IntegrateImage(dn[5], cn[5], poses[5])                  # first host frame: ring allocation flushes the 5
+    hv.IntegrateImage(dn[6], cn[6], poses[6])
+    hv.IntegrateSequence(depth[7:9], rgb[7:9], poses[7:9])     # device frames join the batch the host frames started
+    hv.IntegrateImage(dn[9], cn[9], poses[9])
+    hv.IntegrateImage(depth[10], rgb[10], poses[10])
+    for i in range(n):
+        ov.integrate(dn[i], cn[i], poses[i])
+    st = hv.Stats()
+    assert st["frames"] == n, st
+    _compare(oracle, ov, hv)
+
+
+def test_sum_form_update_matches_the_reference_to_tolerance(oracle):
+    """OP_VOLUME_UPDATE_SUM_FORM (opt-in): a batch's observations of a voxel are summed and averaged into it once per batch.  Same blocks, same
+    pixels, same (integer) weights; sdf within 1e-4 of the truncation distance and colour within 1e-4 of the oracle's frame-by-frame running
+    mean (north_star's bar; measured: a few 1e-7).  Full batches, a partial one, re-fusion into existing voxels, uint16 depth with holes."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 75
+    depth, rgb, poses = S.room_sequence_torch(200, n, dev)
+    d16 = (depth * 1000.0).round().to(torch.int16)
+    d16[:, 100:160, 200:300] = 0
+    torch.cuda.synchronize()
+    dn, cn = d16.cpu().numpy().view(np.uint16), rgb.cpu().numpy()
+    ov, hv = _mk(oracle, 0.01)
+    hv.SetUpdateMode("sum_form")
+    hv.IntegrateSequence(d16[:70], rgb[:70], poses[:70])       # 32 + 32 + 6
+    hv.Synchronize()
+    hv.IntegrateSequence(d16[70:], rgb[70:], poses[70:])       # a short batch into the same voxels
+    upd = 0
+    for i in range(n):
+        upd += ov.integrate(dn[i], cn[i], poses[i])[2]
+    st = hv.Stats()
+    assert st["frames"] == n and st["voxels_updated"] == upd      # the same observations
+    ok, ovx = _compare(oracle, ov, hv, exact=False)
+    hk, hvx = hv.GetCubeMap()
+    obs = ovx[:, :, 1] > 0
+    e_sdf = np.abs(hvx[:, :, 0] - ovx[:, :, 0])[obs].max() / 0.1
+    e_col = np.abs(hvx[:, :, 2:] - ovx[:, :, 2:])[obs].max()
+    assert e_sdf <= 1e-5 and e_col <= 1e-5, (e_sdf, e_col)       # far inside the bar: float rounding only
+    assert np.array_equal(hvx[~obs].view(np.uint32), ovx[~obs].view(np.uint32))   # unobserved voxels untouched
+    # back to the exact update: later frames are applied the reference's way to the sum-form volume (still within tolerance of the oracle)
+    hv.SetUpdateMode("exact")
+    d, c, p = S.room_frame(200 + n)
+    ov.integrate(d, c, p); hv.IntegrateImage(d, c, p)
+    _compare(oracle, ov, hv, exact=False)
+
+
+def test_sum_form_update_after_upload_and_on_the_wall_scene(oracle):
+    """The sum form's once-per-batch mean is the GENERAL TSDFVoxel::operator+ (true divisions, IsValid test): it also applies to voxels that
+    came from an upload; and the survey's 5-frame wall scene keeps its block and weight statistics."""
+    ov, hv = _mk(oracle, 0.005)
+    hv.SetUpdateMode("sum_form")
+    for i in range(5):
+        d, rgb, pose = S.wall_frame(i)
+        ov.integrate(d, rgb, pose)
+        hv.IntegrateImage(d, rgb, pose)
+    ok, ovx = _compare(oracle, ov, hv, exact=False)
+    assert len(ok) == 23706 and int((ovx[:, :, 1] > 0).sum()) == 8671233 and int(ovx[:, :, 1].astype(np.float64).sum()) == 37033130
+    k, v = hv.GetCubeMap()
+    ov2, hv2 = _mk(oracle, 0.005)
+    hv2.SetUpdateMode("sum_form")
+    hv2.SetCubeMap(k, v); ov2.load(k, v)
+    for i in range(5, 8):
+        d, rgb, pose = S.wall_frame(i)
+        ov2.integrate(d, rgb, pose)
+        hv2.IntegrateImage(d, rgb, pose)
+    _compare(oracle, ov2, hv2, exact=False)
+
+
+def test_batch64_build_on_the_largest_image_it_admits(tmp_path):
+    """The documented build option -DOP_MAX_BATCH=64 (64-bit batch masks).  k_integrate addresses a batch's packed frames with 32-bit byte offsets,
+    so the 64-frame build admits images of up to 2^23 pixels (the default: 2^24).  On a 4096 x 2048 image -- its limit -- 70 frames fused in
+    64-frame launches give bit for bit the volume the default build fuses in 32-frame launches (frames 32..63 of a batch are the ones a wrapped
+    offset would have read from the wrong frame), and a 4096 x 4096 camera is refused by the one and admitted by the other."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b64 = os.path.join(root, "onepiece_amd", "libonepiece_hip_b64.so")
+    if not os.path.exists(b64):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "onepiece_amd", "csrc"), "b64"])
+    script = os.path.join(root, "tests", "tools", "batch_build_check.py")
+    res = {}
+    for name, lib in (("b32", ""), ("b64", b64)):
+        env = dict(os.environ)
+        env.pop("ONEPIECE_HIP_LIBRARY", None)
+        if lib:
+            env["ONEPIECE_HIP_LIBRARY"] = lib
+        run = subprocess.run([sys.executable, script, "4096", "2048", "70", "0.04", "4096", "4096"], capture_output=True, text=True, env=env, timeout=900)
+        assert run.returncode == 0, run.stdout + run.stderr
+        res[name] = json.loads(run.stdout.strip().splitlines()[-1])
+    a, b = res["b32"], res["b64"]
+    assert a["library"] == "libonepiece_hip.so" and b["library"] == "libonepiece_hip_b64.so"
+    assert a["frames"] == b["frames"] == 70 and a["launches"] == 3 and b["launches"] == 2, (a, b)      # 32 + 32 + 6 | 64 + 6
+    assert a["blocks"] == b["blocks"] > 200 and a["voxels_updated"] == b["voxels_updated"] > 10 ** 7   # 32 cm blocks: a few hundred hold the room
+    assert a["keys_sha"] == b["keys_sha"] and a["voxels_sha"] == b["voxels_sha"]
+    assert a["probe_admitted"] is True and b["probe_admitted"] is False and "pixels" in b["probe_error"]

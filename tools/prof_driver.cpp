@@ -25,7 +25,7 @@
 #define CK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, op_last_error()); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0); // one hardware queue per tracker stream in the track=K mode (the runtime's default is 4; read at HIP initialisation)
+    // (libonepiece_hip.so asks for 8 hardware queues when it is loaded -- one per tracker stream in the track=K mode; nothing to set here)
     const char* path = argc > 1 ? argv[1] : "/tmp/frames.bin";
     const int reps = argc > 2 ? atoi(argv[2]) : 1;
     const float voxel = argc > 3 ? (float)atof(argv[3]) : 0.005f;
@@ -50,6 +50,8 @@ int main(int argc, char** argv) {
     op_camera cam; CK(op_camera_preset(1, &cam));
     cam.width = w; cam.height = h;
     op_volume* v; CK(op_volume_create(&cam, voxel, 0.1f, 5.0f, 0.5f, 0, 1u << 18, &v));
+    if (const char* e = getenv("PD_UPDATE")) // PD_UPDATE=sum_form: the opt-in once-per-batch update (OP_VOLUME_UPDATE_SUM_FORM)
+        if (std::string(e) == "sum_form") CK(op_volume_set_option(v, OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_SUM_FORM));
     if (argc > 4 && std::string(argv[4]).rfind("track=", 0) == 0) {
         // "track=K": tracking + fusion with K frame pairs in flight, each on its own tracker (stream): pair i is enqueued while pairs
         // i-K+1 .. i-1 are still running; results are taken in order, the pose is chained and the frame fused -- the C-ABI pipeline behind

@@ -9,6 +9,8 @@ depth, rgb, poses = S.room_sequence_torch(0, n, dev)
 torch.cuda.synchronize()
 mb = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # initial pool capacity in blocks (0 = library default; the pool grows on demand)
 hv = I.CubeHandler(max_blocks=mb); hv.SetVoxelResolution(0.005)
+if os.environ.get("QB_UPDATE"):   # QB_UPDATE=sum_form: the opt-in once-per-batch update
+    hv.SetUpdateMode(os.environ["QB_UPDATE"])
 hv.IntegrateSequence(depth[:10], rgb[:10], poses[:10]); hv.Synchronize()
 for rep in range(3):
     hv.Clear()
