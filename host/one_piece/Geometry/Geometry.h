@@ -51,6 +51,7 @@ typedef Eigen::Matrix<scalar, 2, 2> Matrix2;
 typedef Eigen::Matrix<scalar, 3, 3> Matrix3;
 typedef Eigen::Matrix<scalar, 4, 4> Matrix4;
 typedef Eigen::Matrix<scalar, 6, 6> Matrix6;
+typedef Eigen::Matrix<scalar, Eigen::Dynamic, 1> VectorX;
 typedef Eigen::Matrix<int, 2, 1> Point2i;
 typedef Eigen::Matrix<int, 3, 1> Point3i;
 typedef Eigen::Matrix<unsigned int, 2, 1> Point2ui;
@@ -65,6 +66,7 @@ typedef compat::Mat<scalar, 2, 2> Matrix2;
 typedef compat::Mat<scalar, 3, 3> Matrix3;
 typedef compat::Mat<scalar, 4, 4> Matrix4;
 typedef compat::Mat<scalar, 6, 6> Matrix6;
+typedef compat::VecX<scalar> VectorX;
 typedef compat::Mat<int, 2, 1> Point2i;
 typedef compat::Mat<int, 3, 1> Point3i;
 typedef compat::Mat<unsigned int, 2, 1> Point2ui;
@@ -90,6 +92,7 @@ typedef ONEPIECE_ALIGNED_VECTOR(Point2) Point2List;
 typedef ONEPIECE_ALIGNED_VECTOR(Point3) Point3List;
 typedef ONEPIECE_ALIGNED_VECTOR(Point3i) Point3iList;
 typedef ONEPIECE_ALIGNED_VECTOR(Point3ui) Point3uiList;
+typedef ONEPIECE_ALIGNED_VECTOR(VectorX) PointXList; // Geometry.h:69
 typedef ONEPIECE_ALIGNED_VECTOR(Matrix4) Mat4List;
 typedef Mat4List SE3List;
 typedef std::vector<Point3List> ImageXYZ; // Geometry.h:79

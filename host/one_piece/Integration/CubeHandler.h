@@ -14,8 +14,10 @@
 //   Transform* / GetPointCloud     -> std::shared_ptr to freshly made objects
 //   errors              -> a coloured line on std::cout and an early return; nothing throws (reference behaviour)
 //
-// The `cube_map` member of the reference is kept only as the return type of GetCubeMap / argument of SetCubeMap: there is
-// no host copy of the volume to go stale.  Device selection: environment variable ONEPIECE_HIP_DEVICE (default 0).
+// The reference's protected `CubeMap cube_map` member (CubeHandler.h:359) is a MIRROR here (CubeMapMirror below): a derived class
+// that reads it gets a host copy refreshed from the device when the volume has changed since its last look, and what it writes
+// through it is uploaded before the next member call touches the volume.  Device selection: environment variable
+// ONEPIECE_HIP_DEVICE (default 0).
 #pragma once
 #include <memory>
 #include <string>
@@ -39,6 +41,57 @@ namespace one_piece {
 namespace integration {
 
 typedef std::unordered_map<CubeID, VoxelCube, CubeHasher> CubeMap;
+
+class CubeHandler;
+
+// The protected `cube_map` of the reference's CubeHandler (CubeHandler.h:359), for classes derived from it.  The volume itself lives in HBM; this
+// object hands out a host-side CubeMap that is downloaded lazily -- on the first access after the device volume changed -- and uploaded
+// lazily: access through a non-const member marks it edited, and the handler pushes it to the device before its next member call looks at
+// or changes the volume (or at CommitCubeMap()).  The container members derived classes use are forwarded; anything else is reachable
+// through get() / edit().  A full download / upload per change of ownership: meant for inspection and small edits, not for per-frame use.
+class CubeMapMirror {
+  public:
+    typedef CubeMap::iterator iterator;
+    typedef CubeMap::const_iterator const_iterator;
+    typedef CubeMap::key_type key_type;
+    typedef CubeMap::mapped_type mapped_type;
+    typedef CubeMap::value_type value_type;
+    typedef CubeMap::size_type size_type;
+
+    const CubeMap& get() const; // refreshed from the device if stale
+    CubeMap& edit();            // refreshed, and marked edited
+    operator const CubeMap&() const { return get(); }
+
+    size_type size() const { return get().size(); }
+    bool empty() const { return get().empty(); }
+    size_type count(const key_type& k) const { return get().count(k); }
+    const_iterator find(const key_type& k) const { return get().find(k); }
+    const_iterator begin() const { return get().begin(); }
+    const_iterator end() const { return get().end(); }
+    const_iterator cbegin() const { return get().begin(); }
+    const_iterator cend() const { return get().end(); }
+    const mapped_type& at(const key_type& k) const { return get().at(k); }
+    iterator find(const key_type& k) { return edit().find(k); }
+    iterator begin() { return edit().begin(); }
+    iterator end() { return edit().end(); }
+    mapped_type& at(const key_type& k) { return edit().at(k); }
+    mapped_type& operator[](const key_type& k) { return edit()[k]; }
+    std::pair<iterator, bool> insert(const value_type& v) { return edit().insert(v); }
+    size_type erase(const key_type& k) { return edit().erase(k); }
+    void clear() { edit().clear(); }
+    void reserve(size_type n) { edit().reserve(n); }
+    CubeMapMirror& operator=(const CubeMap& m) { edit() = m; return *this; }
+
+  private:
+    friend class CubeHandler;
+    explicit CubeMapMirror(CubeHandler* o) : owner(o) {}
+    CubeMapMirror(const CubeMapMirror&);            // a mirror belongs to one handler: not copyable
+    CubeMapMirror& operator=(const CubeMapMirror&);
+    CubeHandler* owner;
+    mutable CubeMap host;
+    mutable unsigned long long seen = 0; // the handler's change counter at the last download / upload (0 = never)
+    mutable bool edited = false;
+};
 
 class CubeHandler {
   public:
@@ -89,18 +142,29 @@ class CubeHandler {
     // the C-ABI handle (created on first use), for callers that mix in direct op_volume_* calls
     op_volume* Handle() const;
 
+    // pushes what a derived class wrote through `cube_map` to the device now (it happens by itself before the next member call)
+    void CommitCubeMap();
+
   protected:
     camera::PinholeCamera camera;
     Integrator integrator;
     CubePara c_para;
     float far = 5.0;
     float near = 0.5;
+    CubeMapMirror cube_map; // CubeHandler.h:359: see CubeMapMirror
 
   private:
+    friend class CubeMapMirror;
+    void Pending() const;                // uploads an edited mirror; first statement of every member that looks at or changes the volume
+    void Touch() const { ++changes; }    // the device volume has (possibly) changed: the mirror is stale
+    mutable unsigned long long changes = 1;
     bool Ensure() const;                 // creates the device volume on first use; false (after a message) without a GPU
     static void Report(const char* where);
     void AddTransformedCubes(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans, bool nearest);
     mutable op_volume* vol = nullptr;
+    // device images of frames that were fused in place (RGBDFrame::on_device): held until the volume is known to be done with them
+    mutable std::vector<std::shared_ptr<void> > borrowed_;
+    void ReleaseBorrowed() const { borrowed_.clear(); } // call only right after a synchronising C-ABI call
     explicit CubeHandler(op_volume* adopted, const CubeHandler& like, float resolution);
 };
 

@@ -9,6 +9,7 @@
 // (CreateImagePyramid, CreateImageXYZPyramid, MultiScaleComputing, InitializeRGBDDenseTracking: the C-ABI exposes them
 // as op_tracker_track / op_tracker_read_pyramid).
 #pragma once
+#include <deque>
 #include <iostream>
 #include <memory>
 #include <vector>
@@ -17,6 +18,7 @@
 #include "Geometry/Geometry.h"
 #include "Geometry/RGBDFrame.h"
 #include "OdometryPredefined.h"
+#include "Tool/ImageProcessing.h" // the reference's Odometry.h brings it in (Odometry.h:10), and example/DenseFusion/DenseFusion.cpp:92-93 relies on that
 
 struct op_tracker; // include/onepiece_hip.h
 
@@ -60,6 +62,20 @@ class Odometry {
     std::shared_ptr<DenseTrackingResult> DenseTracking(geometry::RGBDFrame& source_frame, geometry::RGBDFrame& target_frame,
                                                        const geometry::TransformationMatrix& initial_T, int term_type = 0);
 
+    // ---- beyond the reference's surface: several frame pairs in flight ---------------------------------------------------------------
+    // One 640x480 track is 28 strictly sequential small problems that leave most of the GPU idle; four pairs in flight on four streams run at
+    // ~3x the rate of one pair at a time.  DenseTrackingEnqueue uploads the two frames unless they are on the device
+    // already (RGBDFrame::on_device: a frame is source once and target once, its pixels cross PCIe once), enqueues the whole call on a
+    // tracker of its own and returns; DenseTrackingWait returns the OLDEST outstanding result (T, rmse, tracking_success; the correspondence
+    // sets stay empty -- use DenseTracking when they are needed).  At most `SetPipelineDepth` (default 4) pairs are outstanding: enqueueing
+    // one more waits for the oldest, whose result is then kept for the next DenseTrackingWait.  A caller that chains poses assumes
+    // success when it enqueues pair (i, i+1) before pair (i-1, i) is known (examples/cpp/DenseFusion.cpp shows the resolution in order).
+    void SetPipelineDepth(int pairs_in_flight);
+    bool DenseTrackingEnqueue(geometry::RGBDFrame& source_frame, geometry::RGBDFrame& target_frame, const geometry::TransformationMatrix& initial_T,
+                              int term_type = 0);
+    std::shared_ptr<DenseTrackingResult> DenseTrackingWait();
+    size_t DenseTrackingPending() const { return inflight_.size() + ready_.size(); }
+
     void SetCamera(const camera::PinholeCamera& _camera) { camera = _camera; }
     void SetCameraPara(float _fx, float _fy, float _cx, float _cy, int _width, int _height, float depthScale, float* _distortion = nullptr) {
         camera.SetPara(_fx, _fy, _cx, _cy, _width, _height, depthScale, _distortion);
@@ -85,6 +101,13 @@ class Odometry {
 
   private:
     op_tracker* tracker_ = nullptr; // created at the first DenseTracking call
+    struct InFlight { int slot; std::shared_ptr<void> source, target; };
+    std::shared_ptr<DenseTrackingResult> Finish(const InFlight& job);
+    std::vector<op_tracker*> pipe_;  // one tracker (one HIP stream) per pair in flight
+    std::deque<InFlight> inflight_;  // oldest first
+    std::deque<std::shared_ptr<DenseTrackingResult> > ready_; // results taken early to free a tracker
+    int pipe_depth_ = 4;
+    unsigned long long enqueued_ = 0;
 };
 
 } // namespace odometry

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstddef>
 #include <ostream>
+#include <vector>
 
 #include "onepiece_hip.h"
 
@@ -86,6 +87,34 @@ struct Mat {
 
 template <class T, int R, int C>
 inline Mat<T, R, C> operator*(T s, const Mat<T, R, C>& m) { return m * s; }
+
+// Run-time sized column vector (the reference's geometry::VectorX = Eigen::Matrix<scalar, Dynamic, 1>, Geometry/Geometry.h:45): what a 33-bin
+// FPFH feature is stored in (Registration/3DFeature.h).  The members the feature / registration code and its callers touch.
+template <class T>
+struct VecX {
+    std::vector<T> v;
+    VecX() {}
+    explicit VecX(int n) : v(static_cast<size_t>(n), T(0)) {}
+    void resize(int n) { v.resize(static_cast<size_t>(n)); }
+    void setZero() { for (size_t i = 0; i < v.size(); ++i) v[i] = T(0); }
+    int rows() const { return static_cast<int>(v.size()); }
+    int cols() const { return 1; }
+    int size() const { return static_cast<int>(v.size()); }
+    T& operator()(int i) { return v[static_cast<size_t>(i)]; }
+    const T& operator()(int i) const { return v[static_cast<size_t>(i)]; }
+    T& operator[](int i) { return v[static_cast<size_t>(i)]; }
+    const T& operator[](int i) const { return v[static_cast<size_t>(i)]; }
+    T* data() { return v.data(); }
+    const T* data() const { return v.data(); }
+    VecX& operator+=(const VecX& o) { for (size_t i = 0; i < v.size() && i < o.v.size(); ++i) v[i] += o.v[i]; return *this; }
+    VecX operator*(T s) const { VecX m = *this; for (size_t i = 0; i < m.v.size(); ++i) m.v[i] *= s; return m; }
+    T sum() const { T s = T(0); for (size_t i = 0; i < v.size(); ++i) s += v[i]; return s; }
+};
+template <class T>
+inline std::ostream& operator<<(std::ostream& os, const VecX<T>& m) {
+    for (int i = 0; i < m.rows(); ++i) os << (i ? "\n" : "") << m(i);
+    return os;
+}
 
 // matrix product, accumulated column by column as Eigen's coefficient-based product does
 template <class T, int R, int K, int C>

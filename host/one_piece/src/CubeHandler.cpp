@@ -5,6 +5,7 @@
 #include <unordered_set>
 
 #include "Bridge.h"
+#include "DeviceFrame.h"
 
 namespace one_piece {
 namespace integration {
@@ -20,11 +21,49 @@ bool CubeHandler::Ensure() const {
     return true;
 }
 
-CubeHandler::CubeHandler() { c_para.InitializeVoxelCube(); }
-CubeHandler::CubeHandler(const camera::PinholeCamera& _camera) : camera(_camera) { c_para.InitializeVoxelCube(); }
+CubeHandler::CubeHandler() : cube_map(this) { c_para.InitializeVoxelCube(); }
+CubeHandler::CubeHandler(const camera::PinholeCamera& _camera) : camera(_camera), cube_map(this) { c_para.InitializeVoxelCube(); }
+
+// ---- the protected cube_map mirror -----------------------------------------------------------------------------------
+const CubeMap& CubeMapMirror::get() const {
+    if (!edited && seen != owner->changes) { // stale: the volume changed on the device since the last look
+        host = owner->GetCubeMap();          // (commits nothing: `edited` is false here)
+        seen = owner->changes;
+    }
+    return host;
+}
+CubeMap& CubeMapMirror::edit() {
+    get();
+    edited = true;
+    return host;
+}
+void CubeHandler::Pending() const {
+    if (cube_map.edited) const_cast<CubeHandler*>(this)->CommitCubeMap();
+}
+void CubeHandler::CommitCubeMap() {
+    if (!cube_map.edited) return;
+    cube_map.edited = false; // first: the upload below goes through members that call Pending()
+    if (!Ensure()) return;
+    if (op_volume_clear(vol) != OP_OK) { Report("CommitCubeMap"); return; }
+    std::vector<int32_t> keys;
+    std::vector<float> vox;
+    keys.reserve(3 * cube_map.host.size());
+    vox.reserve(cube_map.host.size() * 512 * 5);
+    for (CubeMap::const_iterator it = cube_map.host.begin(); it != cube_map.host.end(); ++it) {
+        for (int k = 0; k < 3; ++k) keys.push_back(it->first(k));
+        for (int v = 0; v < 512; ++v) {
+            const TSDFVoxel& t = it->second.voxels[v];
+            const float rec[5] = {t.sdf, t.weight, t.color(0), t.color(1), t.color(2)};
+            vox.insert(vox.end(), rec, rec + 5);
+        }
+    }
+    if (!keys.empty() && op_volume_upload(vol, keys.data(), vox.data(), keys.size() / 3) != OP_OK) Report("CommitCubeMap");
+    Touch();
+    cube_map.seen = changes; // the mirror IS the volume's content
+}
 
 CubeHandler::CubeHandler(op_volume* adopted, const CubeHandler& like, float resolution)
-    : camera(like.camera), integrator(like.integrator), far(like.far), near(like.near), vol(adopted) {
+    : camera(like.camera), integrator(like.integrator), far(like.far), near(like.near), cube_map(this), vol(adopted) {
     c_para.VoxelResolution = resolution;
     c_para.InitializeVoxelCube();
 }
@@ -32,11 +71,15 @@ CubeHandler::CubeHandler(op_volume* adopted, const CubeHandler& like, float reso
 // value semantics: the copy owns its own device volume with the same content (Merge into an empty volume copies
 // every block verbatim)
 CubeHandler::CubeHandler(const CubeHandler& other)
-    : camera(other.camera), integrator(other.integrator), c_para(other.c_para), far(other.far), near(other.near) {
+    : camera(other.camera), integrator(other.integrator), c_para(other.c_para), far(other.far), near(other.near), cube_map(this) {
+    other.Pending();
     if (other.vol && Ensure() && op_volume_merge(vol, other.vol) != OP_OK) Report("copy");
 }
 CubeHandler& CubeHandler::operator=(const CubeHandler& other) {
     if (this == &other) return *this;
+    other.Pending();
+    cube_map.edited = false; // whatever was pending here is overwritten
+    Touch();
     if (vol) { op_volume_destroy(vol); vol = nullptr; }
     camera = other.camera; integrator = other.integrator; c_para = other.c_para; far = other.far; near = other.near;
     if (other.vol && Ensure() && op_volume_merge(vol, other.vol) != OP_OK) Report("assign");
@@ -46,9 +89,10 @@ CubeHandler::~CubeHandler() {
     if (vol) op_volume_destroy(vol);
 }
 
-op_volume* CubeHandler::Handle() const { return Ensure() ? vol : nullptr; }
+op_volume* CubeHandler::Handle() const { Pending(); Touch(); return Ensure() ? vol : nullptr; } // (the caller may change the volume through the handle)
 
 void CubeHandler::SetVoxelResolution(float resolution) {
+    Pending();
     c_para.SetVoxelResolution(resolution);
     if (vol && op_volume_set_resolution(vol, resolution) != OP_OK) Report("SetVoxelResolution");
 }
@@ -70,25 +114,34 @@ void CubeHandler::SetNearPlane(float _near) {
 }
 
 void CubeHandler::Clear() {
+    cube_map.edited = false; // pending edits would be wiped with the volume
+    Touch();
     if (vol && op_volume_clear(vol) != OP_OK) Report("Clear");
 }
 bool CubeHandler::HasCube(const CubeID& cube_id) const {
+    Pending();
     if (!vol) return false;
     int present = 0;
     if (op_volume_has_cube(vol, cube_id(0), cube_id(1), cube_id(2), &present) != OP_OK) Report("HasCube");
     return present != 0;
 }
 size_t CubeHandler::GetCubeCount() const {
+    Pending();
     size_t n = 0;
     if (vol && op_volume_block_count(vol, &n) != OP_OK) Report("GetCubeCount");
+    else ReleaseBorrowed(); // op_volume_block_count synchronises
     return n;
 }
 void CubeHandler::Synchronize() const {
+    Pending();
     if (vol && op_volume_sync(vol) != OP_OK) Report("Synchronize");
+    else ReleaseBorrowed();
 }
 
 void CubeHandler::AddCube(const CubeID& cube_id) {
+    Pending();
     if (!Ensure() || HasCube(cube_id)) return;
+    Touch();
     const int32_t key[3] = {cube_id(0), cube_id(1), cube_id(2)};
     std::vector<float> fresh(512 * 5);
     for (int v = 0; v < 512; ++v) { fresh[5 * v] = 999; fresh[5 * v + 1] = 0; fresh[5 * v + 2] = fresh[5 * v + 3] = fresh[5 * v + 4] = -1; }
@@ -115,6 +168,7 @@ void CubeHandler::AddTransformedCube(const VoxelCube& v_cube, const geometry::Tr
 void CubeHandler::AddTransformedCubeNearest(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans) { AddTransformedCubes(v_cube, trans, true); }
 
 void CubeHandler::ComputeBounding(const cv::Mat& depth, const geometry::TransformationMatrix& pose, geometry::Point3& max_pos, geometry::Point3& min_pos) {
+    Pending();
     if (!Ensure()) return;
     float p[16], mx[3], mn[3];
     bridge::RowMajor(pose, p);
@@ -126,7 +180,9 @@ void CubeHandler::ComputeBounding(const cv::Mat& depth, const geometry::Transfor
 
 void CubeHandler::PrepareCubes(const cv::Mat& depth, const geometry::TransformationMatrix& pose, std::vector<CubeID>& cube_id_list) {
     cube_id_list.clear();
+    Pending();
     if (!Ensure()) return;
+    Touch(); // PrepareCubes allocates the blocks it selects (CubeHandler.cpp:181-190)
     float p[16], pi[16];
     bridge::RowMajor(pose, p);
     bridge::RowMajor(pose.inverse(), pi); // the caller's own Eigen inverse when built with Eigen (Integrator.cpp:18)
@@ -143,7 +199,9 @@ void CubeHandler::PrepareCubes(const cv::Mat& depth, const geometry::Transformat
 }
 
 void CubeHandler::IntegrateImage(const cv::Mat& depth, const cv::Mat& rgb, const geometry::TransformationMatrix& pose) {
+    Pending();
     if (!Ensure()) return;
+    Touch();
     float p[16], pi[16];
     bridge::RowMajor(pose, p);
     bridge::RowMajor(pose.inverse(), pi);
@@ -154,14 +212,33 @@ void CubeHandler::IntegrateImage(const cv::Mat& depth, const cv::Mat& rgb, const
     static const bool verbose = std::getenv("ONEPIECE_HIP_VERBOSE") != nullptr;
     if (verbose) std::cout << GREEN << "[IntegrateImage]::[Info]::Image queued for integration." << RESET << std::endl;
 }
-void CubeHandler::IntegrateImage(const geometry::RGBDFrame& rgbd, const geometry::TransformationMatrix& pose) { IntegrateImage(rgbd.depth, rgbd.rgb, pose); }
+void CubeHandler::IntegrateImage(const geometry::RGBDFrame& rgbd, const geometry::TransformationMatrix& pose) {
+    if (!rgbd.on_device) { IntegrateImage(rgbd.depth, rgbd.rgb, pose); return; }
+    // the frame's images are on the device already (the tracker put them there): fused in place, nothing crosses PCIe again
+    Pending();
+    if (!Ensure()) return;
+    Touch();
+    std::shared_ptr<bridge::DeviceImages> d = std::static_pointer_cast<bridge::DeviceImages>(rgbd.on_device);
+    float p[16], pi[16];
+    bridge::RowMajor(pose, p);
+    bridge::RowMajor(pose.inverse(), pi);
+    if (borrowed_.size() >= 512) { // bounded: wait for the queued batches, then let the old frames go
+        if (op_volume_sync(vol) != OP_OK) { Report("IntegrateImage"); return; }
+        ReleaseBorrowed();
+    }
+    if (op_volume_integrate(vol, d->depth, d->depth_fmt, static_cast<const uint8_t*>(d->rgb), OP_MEM_DEVICE, p, pi) != OP_OK) { Report("IntegrateImage"); return; }
+    borrowed_.push_back(rgbd.on_device);
+}
 
 void CubeHandler::Merge(const CubeHandler& another) {
     if (c_para.VoxelResolution != another.c_para.VoxelResolution) {
         std::cout << YELLOW << "[Warning]::[MergeVoxelHash]::Voxel resolution is not identical." << RESET << std::endl;
         return;
     }
+    Pending();
+    another.Pending();
     if (!another.vol || !Ensure()) return;
+    Touch();
     if (op_volume_merge(vol, another.vol) != OP_OK) Report("Merge");
 }
 void CubeHandler::Merge(const CubeHandler& another, const geometry::TransformationMatrix& trans) {
@@ -174,6 +251,7 @@ void CubeHandler::Merge(const CubeHandler& another, const geometry::Transformati
 }
 
 std::shared_ptr<CubeHandler> CubeHandler::Transform(const geometry::TransformationMatrix& trans) const {
+    Pending();
     if (!Ensure()) return std::shared_ptr<CubeHandler>();
     float T[16], Ti[16];
     bridge::RowMajor(trans, T);
@@ -183,6 +261,7 @@ std::shared_ptr<CubeHandler> CubeHandler::Transform(const geometry::Transformati
     return std::shared_ptr<CubeHandler>(new CubeHandler(out, *this, c_para.VoxelResolution));
 }
 std::shared_ptr<CubeHandler> CubeHandler::TransformNearest(const geometry::TransformationMatrix& trans) {
+    Pending();
     if (!Ensure()) return std::shared_ptr<CubeHandler>();
     float T[16], Ti[16];
     bridge::RowMajor(trans, T);
@@ -195,6 +274,7 @@ std::shared_ptr<CubeHandler> CubeHandler::TransformNearest(const geometry::Trans
 
 std::shared_ptr<geometry::PointCloud> CubeHandler::GetPointCloud() const {
     std::shared_ptr<geometry::PointCloud> pcd = std::make_shared<geometry::PointCloud>();
+    Pending();
     if (!vol) return pcd;
     size_t n = 0;
     if (op_volume_point_cloud(vol, nullptr, nullptr, 0, &n) != OP_OK) { Report("GetPointCloud"); return pcd; }
@@ -223,18 +303,21 @@ void AppendMesh(op_volume* vol, const int32_t* only_block, geometry::TriangleMes
 
 void CubeHandler::ExtractTriangleMesh(geometry::TriangleMesh& mesh) {
     mesh.Reset(); // CubeHandler.cpp:11
+    Pending();
     if (!vol) return;
     AppendMesh(vol, nullptr, mesh, "ExtractTriangleMesh");
     std::cout << BLUE << "[ExtractTriangleMesh]::[INFO]::Finish Extracting Mesh, " << mesh.triangles.size() << " triangles." << RESET << std::endl;
 }
 void CubeHandler::GenerateMeshByCube(const CubeID& cube_id, geometry::TriangleMesh& mesh) {
+    Pending();
     if (!vol) return;
     const int32_t only[3] = {cube_id(0), cube_id(1), cube_id(2)};
     AppendMesh(vol, only, mesh, "GenerateMeshByCube");
 }
 
 CubeMap CubeHandler::GetCubeMap() {
-    CubeMap cube_map;
+    Pending();
+    CubeMap cube_map; // (a fresh copy BY VALUE, as the reference returns one; not the mirror member)
     if (!vol) return cube_map;
     size_t n = 0;
     if (op_volume_block_count(vol, &n) != OP_OK) { Report("GetCubeMap"); return cube_map; }
@@ -253,6 +336,8 @@ CubeMap CubeHandler::GetCubeMap() {
 
 void CubeHandler::SetCubeMap(const CubeMap& _cube_map) {
     std::cout << YELLOW << "[WARNING]::[SetCubeMap]::Note that you are changing the hashing map directly." << RESET << std::endl;
+    this->cube_map.edited = false; // replaced wholesale
+    Touch();
     if (!Ensure()) return;
     if (op_volume_clear(vol) != OP_OK) { Report("SetCubeMap"); return; }
     std::vector<int32_t> keys;
@@ -271,20 +356,27 @@ void CubeHandler::SetCubeMap(const CubeMap& _cube_map) {
 }
 
 bool CubeHandler::WriteToFile(const std::string& filename) const {
+    Pending();
     if (Ensure() && op_volume_write_file(vol, filename.c_str()) != OP_OK) Report("WriteToFile");
     else std::cout << GREEN << "[CubeHandler]::[INFO]::Write TSDF field done!(To BinaryFile) " << RESET << std::endl;
     return true; // the reference's file calls always return true (SURVEY 8b "Errors")
 }
 bool CubeHandler::ReadFromFile(const std::string& filename) {
+    cube_map.edited = false;
+    Touch();
     if (Ensure() && op_volume_read_file(vol, filename.c_str(), 0) != OP_OK) Report("ReadFromFile");
     return true;
 }
 bool CubeHandler::ReadFromFileFloat(const std::string& filename) {
+    cube_map.edited = false;
+    Touch();
     if (Ensure() && op_volume_read_file(vol, filename.c_str(), 1) != OP_OK) Report("ReadFromFileFloat");
     return true;
 }
 
 bool CubeHandler::MergeAcrossRanks(void* nccl_comm, int root) {
+    Pending();
+    Touch();
     if (!Ensure()) return false;
     if (op_volume_merge_rccl(vol, nccl_comm, root, nullptr) != OP_OK) { Report("MergeAcrossRanks"); return false; }
     return true;

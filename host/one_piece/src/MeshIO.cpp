@@ -97,6 +97,14 @@ bool ReadPly(const std::string& file, geometry::Point3List& points, geometry::Po
         }
     }
     if (!known_format) { Message("unsupported PLY format (ascii and binary_little_endian are read) in", file); return false; }
+    // The header is not trusted: an element cannot have more entries than the rest of the file has bytes (every entry takes at least one),
+    // list counts are bounded the same way, and face indices must name vertices that exist (ReadObj checks the same).
+    const std::streampos body_at = is.tellg();
+    is.seekg(0, std::ios::end);
+    const size_t body_bytes = body_at < is.tellg() ? static_cast<size_t>(is.tellg() - body_at) : 0;
+    is.seekg(body_at);
+    for (size_t e = 0; e < elements.size(); ++e)
+        if (!elements[e].props.empty() && elements[e].count > body_bytes) { Message("element count exceeds the file size in", file); return false; }
     Body body = {is, ascii, true};
     points.clear(); normals.clear(); colors.clear();
     if (triangles) triangles->clear();
@@ -117,7 +125,13 @@ bool ReadPly(const std::string& file, geometry::Point3List& points, geometry::Po
                 float v[9] = {0};
                 for (size_t k = 0; k < el.props.size(); ++k) {
                     const Property& p = el.props[k];
-                    if (p.is_list) { const size_t n = static_cast<size_t>(body.Next(p.count_type)); for (size_t j = 0; j < n; ++j) body.Next(p.type); continue; }
+                    if (p.is_list) {
+                        const double cnt = body.Next(p.count_type);
+                        if (!(cnt >= 0) || cnt > static_cast<double>(body_bytes)) { body.ok = false; break; } // negative, NaN or larger than the file
+                        const size_t n = static_cast<size_t>(cnt);
+                        for (size_t j = 0; j < n && body.ok; ++j) body.Next(p.type);
+                        continue;
+                    }
                     const double d = body.Next(p.type);
                     const int s = Slot(p.name);
                     if (s >= 0) v[s] = static_cast<float>(d);
@@ -132,16 +146,23 @@ bool ReadPly(const std::string& file, geometry::Point3List& points, geometry::Po
                 for (size_t k = 0; k < el.props.size(); ++k) {
                     const Property& p = el.props[k];
                     if (!p.is_list) { body.Next(p.type); continue; }
-                    const size_t n = static_cast<size_t>(body.Next(p.count_type));
+                    const double cnt = body.Next(p.count_type);
+                    if (!(cnt >= 0) || cnt > static_cast<double>(body_bytes)) { body.ok = false; break; }
+                    const size_t n = static_cast<size_t>(cnt);
                     const bool indices = faces && triangles && (p.name == "vertex_indices" || p.name == "vertex_index");
                     unsigned first = 0, prev = 0;
-                    for (size_t j = 0; j < n; ++j) {
-                        const unsigned id = static_cast<unsigned>(body.Next(p.type));
+                    bool valid = true; // a face that names a vertex the file does not have is dropped
+                    const size_t before = indices ? triangles->size() : 0;
+                    for (size_t j = 0; j < n && body.ok; ++j) {
+                        const double raw = body.Next(p.type);
                         if (!indices) continue;
+                        if (!(raw >= 0) || raw >= static_cast<double>(points.size())) { valid = false; continue; }
+                        const unsigned id = static_cast<unsigned>(raw);
                         if (j == 0) first = id;
-                        else if (j >= 2) triangles->push_back(geometry::Point3ui(first, prev, id)); // fan
+                        else if (j >= 2 && valid) triangles->push_back(geometry::Point3ui(first, prev, id)); // fan
                         prev = id;
                     }
+                    if (indices && !valid) triangles->resize(before);
                 }
         }
     }

@@ -65,6 +65,13 @@ const char *op_last_error(void);
  * runtime reads it at its first API call: load or link the library before the process touches HIP).  Four tracker streams + one
  * fusing volume need five queues for the pipelined tracking + fusion rate quoted in DESIGN.md. */
 int op_runtime_hw_queues(int *requested);
+/* Images that are used more than once -- a frame is tracked against twice and fused once (example/DenseFusion/DenseSlam.cpp:24-33,
+ * DenseFusion.cpp:86-96) -- can be brought to the device ONCE and then handed to op_tracker_dense_tracking(_enqueue) /
+ * op_volume_integrate with OP_MEM_DEVICE.  op_device_upload copies `bytes` from host memory into a buffer of the library's buffer cache
+ * (blocking: complete on return); op_device_release returns the buffer.  The caller keeps it alive until the last consumer has finished
+ * (op_tracker_wait; for a volume: its next synchronising call). */
+int op_device_upload(const void *host, size_t bytes, int device, void **device_ptr);
+int op_device_release(void *device_ptr, int device);
 /* Registration objects (op_icp, the contexts behind op_icp_register / op_estimate_normals / op_points_from_depth) are
  * created and dropped per call, as registration::PointToPlane builds and drops its kd-tree (Registration/ICP.cpp:
  * 166-170); their device and pinned buffers, streams and events are kept in a per-process cache when released and

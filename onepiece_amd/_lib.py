@@ -74,6 +74,8 @@ SIGNATURES = {
     "op_abi_version": (C.c_int, []),
     "op_last_error": (C.c_char_p, []),
     "op_runtime_hw_queues": (C.c_int, [C.POINTER(C.c_int)]),
+    "op_device_upload": (C.c_int, [_vp, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "op_device_release": (C.c_int, [_vp, C.c_int]),
     "op_release_cached_memory": (C.c_int, []),
     "op_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "op_camera_preset": (C.c_int, [C.c_int, C.POINTER(Camera)]),

@@ -2183,6 +2183,25 @@ extern "C" {
 
 int op_abi_version(void) { return OP_ABI_VERSION; }
 
+int op_device_upload(const void* host, size_t bytes, int device, void** device_ptr) {
+    if (!host || !device_ptr || bytes == 0) return fail(OP_ERR_INVALID, "op_device_upload: null argument");
+    *device_ptr = nullptr;
+    OP_TRY(op::use_device(device));
+    void* d = nullptr;
+    OP_HIP(op::cached_malloc(&d, bytes));
+    const hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice); // blocking: the caller's buffer is free and the copy is complete on return
+    if (e != hipSuccess) { op::cached_free(d); return fail(OP_ERR_HIP, "op_device_upload: %s", hipGetErrorString(e)); }
+    *device_ptr = d;
+    return OP_OK;
+}
+
+int op_device_release(void* device_ptr, int device) {
+    if (!device_ptr) return OP_OK;
+    OP_TRY(op::use_device(device));
+    op::cached_free(device_ptr);
+    return OP_OK;
+}
+
 int op_runtime_hw_queues(int* requested) {
     if (!requested) return fail(OP_ERR_INVALID, "null argument");
     const char* e = std::getenv("GPU_MAX_HW_QUEUES");

@@ -14,13 +14,20 @@ OUT=$ROOT/oracle/_ref/examples
 mkdir -p "$OUT"
 HOST=$ROOT/host/one_piece
 [ -f "$HOST/libone_piece_hip_host.so" ] || make -C "$HOST"
-for ex in ImageIntegration ImageSequenceIntegration ICPTest MergeMultipleSubmaps MCGenerateMesh EstimateNormals ReadRGBD ConvertImageSequenceToPCD ReadPLYPointCloud ReadPLYMesh DenseOdometry SimplifyMeshClustering PruneMesh EigenTest; do
-  if [ "$1" = "-fsyntax-only" ]; then
-    g++ -std=c++11 -fsyntax-only -I"$HOST" -I"$ROOT/include" -I"$ROOT/tests/cpp/headless" "$REF/example/$ex.cpp"
+build_one() { # name, sources...
+  local name=$1; shift
+  if [ "$MODE" = "-fsyntax-only" ]; then
+    for src in "$@"; do g++ -std=c++11 -fsyntax-only -I"$HOST" -I"$ROOT/include" -I"$ROOT/tests/cpp/headless" "$src"; done
   else
-    g++ -std=c++11 -O2 -I"$HOST" -I"$ROOT/include" -I"$ROOT/tests/cpp/headless" "$REF/example/$ex.cpp" -o "$OUT/$ex.bin" \
+    g++ -std=c++11 -O2 -I"$HOST" -I"$ROOT/include" -I"$ROOT/tests/cpp/headless" "$@" -o "$OUT/$name.bin" \
         -L"$HOST" -lone_piece_hip_host -L"$ROOT/onepiece_amd" -lonepiece_hip -lz \
         -Wl,-rpath,'$ORIGIN/../../../host/one_piece' -Wl,-rpath,'$ORIGIN/../../../onepiece_amd'
   fi
-  echo "built $ex"
+  echo "built $name"
+}
+MODE=$1
+for ex in ImageIntegration ImageSequenceIntegration ICPTest MergeMultipleSubmaps MCGenerateMesh EstimateNormals ReadRGBD ConvertImageSequenceToPCD ReadPLYPointCloud ReadPLYMesh DenseOdometry SimplifyMeshClustering PruneMesh EigenTest; do
+  build_one $ex "$REF/example/$ex.cpp"
 done
+# example/DenseFusion (named by BASELINE.json's north_star): two translation units, tracking + submap registration + pose-graph optimisation + fusion
+build_one DenseFusion "$REF/example/DenseFusion/DenseFusion.cpp" "$REF/example/DenseFusion/DenseSlam.cpp"

@@ -19,6 +19,7 @@ class Visualizer {
     void AddTriangleMesh(const geometry::TriangleMesh& mesh) {
         std::cout << "[headless viewer] mesh with " << mesh.points.size() << " vertices, " << mesh.triangles.size() << " triangles" << std::endl;
     }
+    void AddCameraSet(const geometry::SE3List&, const geometry::Point3List&) {}
     void Show() { std::cout << "[headless viewer] Show()" << std::endl; }
     void ShowOnce() {}
     void Initialize(const std::string& = "OnePiece") {}

@@ -4,6 +4,7 @@
 // Prints "name value..." lines that tests/test_reference_examples.py compares with its own numpy evaluation.
 #include <cmath>
 #include <cstdio>
+#include <fstream>
 #include <string>
 
 #include "Geometry/Geometry.h"
@@ -68,6 +69,16 @@ int main(int argc, char** argv) {
     for (size_t v = 0; v < cl->points.size(); ++v) { char n[24]; std::snprintf(n, sizeof n, "clustered_p%zu", v); P3(n, cl->points[v]); }
     std::shared_ptr<geometry::TriangleMesh> bad = m.ClusteringSimplify(0.0f);
     std::printf("clustered_zero_grid %zu %zu\n", bad->GetPointSize(), bad->GetTriangleSize());
+    // malformed PLY files are refused or repaired, never trusted: a vertex count far beyond the file, a face that names a missing vertex,
+    // a negative list count
+    {
+        { std::ofstream f((out + "/huge.ply").c_str(), std::ios::binary); f << "ply\nformat binary_little_endian 1.0\nelement vertex 4000000000\nproperty float x\nproperty float y\nproperty float z\nend_header\nabc"; }
+        { std::ofstream f((out + "/badface.ply").c_str()); f << "ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n3 0 1 99\n"; }
+        { std::ofstream f((out + "/neglist.ply").c_str()); f << "ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nelement face 1\nproperty list int int vertex_indices\nend_header\n0 0 0\n-5 0 0 0\n"; }
+        geometry::TriangleMesh h1, h2, h3;
+        const bool r1 = h1.LoadFromPLY(out + "/huge.ply"), r2 = h2.LoadFromPLY(out + "/badface.ply"), r3 = h3.LoadFromPLY(out + "/neglist.ply");
+        std::printf("malformed_ply %d %zu %d %zu %zu %d\n", r1 ? 1 : 0, h1.points.size(), r2 ? 1 : 0, h2.points.size(), h2.triangles.size(), r3 ? 1 : 0);
+    }
     // PLY / OBJ round trips
     m.WriteToPLY(out + "/mesh.ply"); m.WriteToOBJ(out + "/mesh.obj");
     geometry::TriangleMesh rp, ro, rf;

@@ -19,6 +19,17 @@ struct Peek : integration::CubeHandler { // protected members stay reachable fro
     float Truncation() const { return integrator.truncation; }
     float Resolution() const { return c_para.VoxelResolution; }
     float Far() const { return far; }
+    // the reference's protected cube_map (CubeHandler.h:359), read and written the way a derived class would
+    size_t MapSize() const { return cube_map.size(); }
+    size_t MapObserved() const {
+        size_t n = 0;
+        for (integration::CubeMap::const_iterator it = cube_map.begin(); it != cube_map.end(); ++it)
+            for (size_t v = 0; v < it->second.voxels.size(); ++v) n += it->second.voxels[v].weight > 0 ? 1 : 0;
+        return n;
+    }
+    bool MapHas(const integration::CubeID& id) const { return cube_map.find(id) != cube_map.end(); }
+    void MapDrop(const integration::CubeID& id) { cube_map.erase(id); }
+    void MapPut(const integration::CubeID& id) { cube_map[id] = integration::VoxelCube(id); }
 };
 
 int main(int argc, char** argv) {
@@ -138,8 +149,25 @@ int main(int argc, char** argv) {
     std::shared_ptr<registration::RegistrationResult> refused = registration::PointToPlane(s_pcd, no_normals);
     const geometry::TransformationMatrix kab = geometry::EstimateRigidTransformation(plane->correspondence_set);
 
+    // the protected cube_map mirror through a derived class: follows the device volume, and edits reach the device
+    Peek m(camera);
+    m.SetVoxelResolution(voxel);
+    const size_t mirror_empty = m.MapSize();
+    m.IntegrateImage(depth[0], rgb[0], poses[0]);
+    const size_t mirror_n1 = m.MapSize(), mirror_obs1 = m.MapObserved();
+    m.IntegrateImage(depth[1], rgb[1], poses[1]);               // the mirror is stale now: the next look downloads again
+    const size_t mirror_n2 = m.MapSize(), mirror_count2 = m.GetCubeCount();
+    const integration::CubeID drop_id = list[0], put_id(12345, -2, 7);
+    const bool had = m.MapHas(drop_id);
+    m.MapDrop(drop_id);
+    m.MapPut(put_id);
+    const size_t mirror_after_edit = m.GetCubeCount();          // a member call: the edited mirror is uploaded first
+    const bool dropped = !m.HasCube(drop_id), put = m.HasCube(put_id);
+    m.WriteToFile(out + "/mirror.map");
+
     std::cout.precision(9);
-    std::cout << "{\"n_a\": " << n_a << ", \"n_a_after\": " << n_a_after << ", \"n_b\": " << n_b << ", \"map_present\": " << present
+    std::cout << "{\"mirror\": [" << mirror_empty << ", " << mirror_n1 << ", " << mirror_obs1 << ", " << mirror_n2 << ", " << mirror_count2 << ", " << (had ? 1 : 0)
+              << ", " << mirror_after_edit << ", " << (dropped ? 1 : 0) << ", " << (put ? 1 : 0) << "], \"n_a\": " << n_a << ", \"n_a_after\": " << n_a_after << ", \"n_b\": " << n_b << ", \"map_present\": " << present
               << ", \"observed\": " << observed << ", \"far_absent\": " << (far_absent ? 1 : 0) << ", \"n_c\": " << n_c << ", \"n_e\": " << n_e
               << ", \"n_e_cleared\": " << n_e_cleared << ", \"probe\": [" << probe(0) << ", " << probe(1) << ", " << probe(2) << "]"
               << ", \"transform_blocks\": " << tri->GetCubeCount() << ", \"nearest_blocks\": " << nea->GetCubeCount()

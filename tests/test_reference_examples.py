@@ -25,7 +25,7 @@ HOST = os.path.join(ROOT, "host", "one_piece")
 EXDIR = os.path.join(ROOT, "oracle", "_ref", "examples")
 EXAMPLES = ("ImageIntegration", "ImageSequenceIntegration", "ICPTest", "MergeMultipleSubmaps", "MCGenerateMesh", "EstimateNormals", "ReadRGBD",
             "ConvertImageSequenceToPCD", "ReadPLYPointCloud", "ReadPLYMesh", "DenseOdometry", "SimplifyMeshClustering",
-            "PruneMesh", "EigenTest")
+            "PruneMesh", "EigenTest", "DenseFusion")
 have_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "example")), reason="reference tree not present on this machine")
 
 
@@ -231,6 +231,7 @@ def test_frustum_and_host_geometry_members(hip, oracle, tmp_path):
     cells = np.floor(pts[:, :2] / np.float32(0.25)).astype(int)
     assert len({tuple(c) for c in cells}) == 16 and cells.min() == 0 and cells.max() == 3 and np.allclose(pts[:, 2], 0.1 * pts[:, 0], atol=1e-6)
     assert r["clustered_zero_grid"] == ["103", "163"]                                            # refused, mesh unchanged
+    assert r["malformed_ply"] == ["0", "0", "1", "3", "1", "0"]      # absurd vertex count refused; the face naming vertex 99 dropped, the good one kept; negative list count refused
     rt = r["roundtrip"]
     assert rt[:4] == ["1", "1", "1", "0"] and rt[5] == "1" and float(rt[7]) == 0 and float(rt[9]) == 0 and float(rt[11]) < 3 ** 0.5 / 255 + 1e-6 and float(rt[13]) == 0
     assert rt[15] == "1" and rt[17] == "1"
@@ -648,3 +649,41 @@ def test_reference_mesh_tool_examples_run_on_the_host(hip, tmp_path):
     assert run.returncode == 0, run.stdout + run.stderr
     pts, _n, tris = _read_ply(str(tmp_path / "grid.ply_pruned.ply"))
     assert len(pts) == n * n and len(tris) == 2 * (n - 1) * (n - 1) and pts.max() < 1
+
+
+@pytest.mark.gpu
+def test_reference_dense_fusion_example_runs_on_the_gpu(hip, tmp_path):
+    """example/DenseFusion/{DenseFusion,DenseSlam}.cpp -- the link target BASELINE.json's north_star names -- compiled unedited against
+    host/one_piece and run headless on a 118-frame synthetic sequence: every frame is tracked against the last tracked one
+    (odometry::Odometry::DenseTracking on the GPU), submaps of 49 frames are registered (submap 1 against 0 by one ICP iteration on the GPU,
+    submap 2 against 0 by FPFH + RANSAC on the host, registration::RansacRegistration), the submap poses go through optimization::Optimizer::
+    FastBA, every 8th frame is fused with its optimised pose (ConvertDepthTo32F + BilateralFilter + CubeHandler::IntegrateImage on the GPU),
+    the mesh is extracted, simplified and written.  Checked: the example's own progress lines, one trajectory line per frame with rigid poses
+    that stay within centimetres of the synthetic ground truth, a mesh of the room.  (FPFH / RANSAC / FastBA are host code with no pinned
+    parity: the reference seeds its RANSAC from std::random_device.)"""
+    exe = _example("DenseFusion")
+    seq = str(tmp_path / "seq")
+    n = 118
+    frames = [S.room_frame(600 + i) for i in range(n)]
+    Q.WriteImageSequence(seq, [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], 1000.0)
+    run = subprocess.run([exe, seq, "0.01"], capture_output=True, text=True, cwd=str(tmp_path), timeout=1500)
+    assert run.returncode == 1, run.stdout[-3000:] + run.stderr[-3000:]        # the example's main ends with `return 1;` (DenseFusion.cpp:110)
+    out = run.stdout
+    assert "Process on %dth image" % (n - 1) in out and out.count("tracking successful!") == n
+    assert "Matching 0 ..." in out and "Matching 1 ..." in out                   # submap 1 vs 0 (ICP), submap 2 vs 0 (RANSAC) and vs 1 (ICP)
+    assert "[ERROR]" not in out and "There are unconnected components" not in out
+    for i in range(0, n, 8):
+        assert "Processing on %dth image" % i in out
+    got = np.loadtxt(os.path.join(seq, "trajectory.txt")).reshape(-1, 4, 4)
+    assert len(got) == n
+    g0 = np.linalg.inv(frames[0][2].astype(np.float64))
+    for i in range(n):
+        R = got[i][:3, :3]
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-3 and abs(np.linalg.det(R) - 1) < 1e-3 and np.array_equal(got[i][3], [0, 0, 0, 1]), i
+        want = g0 @ frames[i][2].astype(np.float64)
+        assert np.abs(got[i][:3, 3] - want[:3, 3]).max() < 0.05 and np.abs(R - want[:3, :3]).max() < 0.03, (i, got[i], want)
+    step = np.linalg.norm(np.diff(got[:, :3, 3], axis=0), axis=1)
+    assert step.max() < 0.02                                                       # a smooth camera path, also across submap borders after FastBA
+    pts, nrm, tris = _read_ply(str(tmp_path / "densefusion_generated_mesh.ply"))
+    assert len(pts) > 20000 and len(tris) > 40000 and tris.max() < len(pts)
+    assert "[headless viewer] mesh with" in out
