@@ -6,7 +6,7 @@
 // is chained (global = global_last * T^-1, DenseSlam.cpp:31) and the frame is fused in place with its TRACKED pose (CubeHandler::
 // IntegrateImage(const RGBDFrame&, pose)).  Poses, flags and the fused volume are those of the one-pair-at-a-time loop (--pipeline 1).
 // The reference's own example/DenseFusion -- with submap registration and pose-graph optimisation -- compiles and runs unedited against the
-// same surface (oracle/tools/build_ref_examples.sh); this driver is the throughput-oriented form of its tracking + fusion part.
+// same surface (tests/test_reference_examples.py); this driver is the throughput-oriented form of its tracking + fusion part.
 //
 //   DenseFusion <dataset_path> [--voxel 0.01] [--stride 1] [--pipeline 4] [--preload] [--filter] [--ply out.ply] [--poses out.txt]
 //   --preload: decode all PNGs before the clock starts (the rate then measures tracking + fusion, not the PNG decoder)
