@@ -243,6 +243,8 @@ def main():
         b1 = 40.0 * st1["voxels_updated"] / max(st1["frames"], 1) + 7.0 * W * H
         a1 = b1 / (p1["integrate_ms"] * 1e-3) / 1e9
         m1 = (10240.0 * st1["blocks_read"] + 20.0 * st1["voxels_written"]) / max(st1["launches"], 1) + 8.0 * W * H
+        out["roofline"]["batch1_frac"] = a1 / HBM_PEAK_GBS   # SURVEY 8(d)'s bytes where they ARE a bound (one frame per launch) / time / 8 TB/s: north_star's ">= 50 % of HBM roofline"
+        out["roofline"]["hbm_frac"] = None                    # measured traffic of the batched launch / time / 8 TB/s; filled in by the counter passes below
         out["roofline"]["batch1"] = {"frames": nb1, "bound": "hbm", "avg_launch_ms": p1["integrate_ms"], "algorithmic_bytes_per_launch": b1, "achieved": a1, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic_model_bytes_per_launch": m1, "traffic_model_frac": m1 / (p1["integrate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "evidence": "profiles/r03g_batch1.kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/prof_driver.bin ... batch=1), "
@@ -250,6 +252,33 @@ def main():
                                                  "read-modify-write calibration kernel of the same shape reaches (profiles/r03_calib.timing.txt: 5.0 TB/s)",
                                      "note": "k_integrate with ONE frame per launch: SURVEY 8(d)'s algorithmic bytes are then a lower bound of the real traffic, "
                                              "so this is a true HBM roofline fraction (north_star: >= 50 % of HBM roofline on the integrate kernel)"}
+        # -- the opt-in sum-form update (OP_VOLUME_UPDATE_SUM_FORM): the same frames, one weighted mean per batch instead of one rounded update per frame
+        fuse_all = lambda: [hv.IntegrateSequence(depth[k * F:(k + 1) * F], rgb[k * F:(k + 1) * F], poses[k * F:(k + 1) * F]) for k in range(K)]
+        hv.Clear(); hv.SetUpdateMode("sum_form"); hv.ProfileEnable(args.profile_every)
+        best_sf = 0.0
+        for _rep in range(2):
+            hv.Clear()
+            hv.Synchronize(); torch.cuda.synchronize()
+            t_sf = time.perf_counter()
+            fuse_all()
+            hv.Synchronize()
+            best_sf = max(best_sf, n_local / (time.perf_counter() - t_sf))
+        psf = hv.ProfileRead()
+        hv.ProfileEnable(0)
+        out["sum_form"] = {"frames_per_s": best_sf, "integrate_ms_per_launch": psf["integrate_ms"], "frames_per_launch": psf["frames"] / max(psf["launches"], 1),
+                           "note": "op_volume_set_option(OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_SUM_FORM): opt-in; `value` above is the default exact update"}
+        if n_local <= 1000:   # the two volumes side by side (1.7 GB of host memory each at 1000 frames)
+            k_sf, v_sf = hv.GetCubeMap()
+            hv.SetUpdateMode("exact"); hv.Clear()
+            fuse_all()
+            k_ex, v_ex = hv.GetCubeMap()
+            obs = v_ex[..., 1] > 0
+            out["sum_form"]["parity_vs_exact_update"] = {
+                "keys_equal": bool(np.array_equal(k_ex, k_sf)), "weights_equal": bool(np.array_equal(v_ex[..., 1], v_sf[..., 1])),
+                "max_abs_sdf_diff_over_truncation": float(np.abs(v_ex[..., 0] - v_sf[..., 0])[obs].max() / 0.1),
+                "max_abs_colour_diff": float(np.abs(v_ex[..., 2:] - v_sf[..., 2:])[obs].max()), "blocks": int(len(k_ex)), "bar": 1e-4}
+            del k_sf, v_sf, k_ex, v_ex, obs
+        hv.SetUpdateMode("exact")
         # -- live PMC passes (separate rocprofv3 --pmc runs of the torch-free driver on a dump of this step's frames)
         if world == 1 and not args.no_counters:
             try:
@@ -286,14 +315,28 @@ def main():
                                  "source": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950, calibrated for this kernel's 4 B/lane plane rows: profiles/r03_calib.FETCH_SIZE.pmc.csv) "
                                            "and WRITE_SIZE (exact: profiles/r03_calib.WRITE_SIZE.pmc.csv), separate passes, tools/prof_driver.bin on the first %d frames "
                                            "of this run (32-frame launches; per-launch figures scaled by %.3f to the timed region's %.1f frames per launch)" % (nfc, scale, frames_per_launch)})
-                costs_file = os.path.join(ROOT, "profiles", "r03_issue_costs.json")
+                costs_file = os.path.join(ROOT, "profiles", "r04_issue_costs.json")
+                if not os.path.exists(costs_file):
+                    costs_file = os.path.join(ROOT, "profiles", "r03_issue_costs.json")
                 cj = json.load(open(costs_file))
                 counts = {c: kc[c]["mean_per_launch"] for c in kc if isinstance(kc[c], dict) and "mean_per_launch" in kc[c]}
                 counts["kernel_cycles"] = kc_cycles
                 im = IM.model(cj["costs"], cj["valu_mix_k_integrate_plain"], counts)
-                # the binding resource goes to the top of the object: a fraction <= 1 of the SIMDs' instruction-issue capacity
-                R.update({"bound": "issue", "achieved": im["issue_cycles_per_launch"], "peak": im["simd_cycles_per_launch"],
-                          "unit": "SIMD issue cycles per launch (shader clock)", "frac": im["frac"]})
+                # The binding resource goes to the top of the object: a fraction <= 1 of the SIMDs' instruction-issue capacity.  Which fraction: the
+                # additive model (every class charged into ONE budget per SIMD) when the mixed-class microbenchmark of the costs file says it predicts
+                # such a kernel's time within 10 %; otherwise the VALU share alone (scalar instructions of other waves co-issue), the rest as context.
+                mc = cj.get("mixed_check")
+                additive_ok = bool(mc and mc.get("additive_model_holds"))
+                valu_frac = im["classes"]["valu"]["share_of_capacity"]
+                R.update({"bound": "issue", "achieved": im["issue_cycles_per_launch"] if additive_ok else im["classes"]["valu"]["issue_cycles"],
+                          "peak": im["simd_cycles_per_launch"], "unit": "SIMD issue cycles per launch (shader clock)",
+                          "frac": im["frac"] if additive_ok else valu_frac,
+                          "frac_definition": ("sum over all instruction classes x measured issue cost / SIMD cycles (additive model, validated on a mixed-class "
+                                              "microbenchmark: predicted / measured = %.3f)" % mc["additive_over_measured"]) if additive_ok else
+                                             "VALU wave-instructions x measured issue cost / SIMD cycles (the additive all-class model is NOT validated%s: scalar work co-issues)"
+                                             % ((": it predicts %.2f x the mixed microbenchmark's time" % mc["additive_over_measured"]) if mc else ""),
+                          "valu_frac": valu_frac, "all_classes_additive_frac": im["frac"], "mixed_check": mc, "costs_file": os.path.relpath(costs_file, ROOT)})
+                R["hbm_frac"] = R["hbm"]["frac"]      # measured HBM traffic of the batched launch / launch time / 8 TB/s
                 R["issue"] = {"classes": im["classes"], "valu_cycles_each": im["valu_cycles_each"], "kernel_cycles": im["kernel_cycles"],
                               "insts_per_voxel_frame_wave": {"valu": counts["SQ_INSTS_VALU"] / (stats["blocks_selected"] / max(stats["frames"], 1) * frames_per_launch * 8.0),
                                                              "salu": counts.get("SQ_INSTS_SALU", 0.0) / (stats["blocks_selected"] / max(stats["frames"], 1) * frames_per_launch * 8.0)},
@@ -568,15 +611,22 @@ def main():
         for _ in range(n_tr):
             run()
         tr_s = n_tr / (time.perf_counter() - t)
-        odo.SetSums("reference_f32")       # validation mode: rows of every iteration summed sequentially in float32 on the host
+        odo.SetSums("reference_f32")       # the reference's sums: rows of every iteration summed sequentially in float32 in raster order, by one wave on the device
         for _ in range(2):
             run()
         t = time.perf_counter()
         for _ in range(20):
             run()
         tr_ref_s = 20 / (time.perf_counter() - t)
+        odo.SetSums("reference_f32_host")  # the same sums on one host thread (all rows cross PCIe every iteration): the cross-check variant
+        run()
+        t = time.perf_counter()
+        for _ in range(5):
+            run()
+        tr_ref_host_s = 5 / (time.perf_counter() - t)
         odo.SetSums("fp64")
-        out["tracking"] = {"tracks_per_s": tr_s, "ms_per_track": 1e3 / tr_s, "reference_order_tracks_per_s": tr_ref_s, "from_raw_frames_tracks_per_s": full_s, "levels": 3, "iters_per_level": [4, 8, 16],
+        out["tracking"] = {"tracks_per_s": tr_s, "ms_per_track": 1e3 / tr_s, "reference_order_tracks_per_s": tr_ref_s, "reference_order_host_sums_tracks_per_s": tr_ref_host_s,
+                           "from_raw_frames_tracks_per_s": full_s, "levels": 3, "iters_per_level": [4, 8, 16],
                            "iterations_executed": int(tres.iterations), "term": "hybrid", "resolution": [W, H],
                            "correspondences": int(tres.n_correspondences), "tracking_success": bool(tres.tracking_success),
                            "input": "pyramids resident in HBM (boundary = Odometry::MultiScaleComputing inputs)"}
@@ -648,12 +698,17 @@ def main():
             for mode_name in ("fp64", "reference_f32"):
                 chk = DS.DenseSlam(hv.camera, device=local_rank)
                 chk.rgbd_odometry.SetSums(mode_name)
-                for i in range(n_par):
+                chk.UpdateFrame(rgb[0], depth[0]); chk.UpdateFrame(rgb[1], depth[1])      # (first call: workspace allocation)
+                torch.cuda.synchronize(dev)
+                t_par = time.perf_counter()
+                for i in range(2, n_par):
                     chk.UpdateFrame(rgb[i], depth[i])
+                t_par = time.perf_counter() - t_par
                 pe = [rel(pair(chk.global_poses, i), pair(ref_chain, i)) for i in range(1, n_par)]
                 ce = [rel(chk.global_poses[i], ref_chain[i]) for i in range(n_par)]
                 par[mode_name] = {"pair_rel_err_max": max(pe), "pair_rel_err_median": float(np.median(pe)), "pairs_within_1e-4": int(sum(e <= 1e-4 for e in pe)),
-                                  "pairs": len(pe), "chain_rel_err_max": max(ce), "max_translation_drift_m": max(drift_of(chk.global_poses))}
+                                  "pairs": len(pe), "chain_rel_err_max": max(ce), "max_translation_drift_m": max(drift_of(chk.global_poses)),
+                                  "tracks_per_s": (n_par - 2) / t_par}   # one pair at a time, from raw frames (image preparation included)
             out["dense_fusion_parity"] = par
         g0 = np.linalg.inv(poses[0].astype(np.float64))
         drift = max(float(np.abs(np.asarray(slam.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max())
@@ -693,7 +748,7 @@ def main():
                     out["dense_fusion"].update({"cpp_frames_per_s": rates_cpp[4][0], "cpp_one_pair_at_a_time_frames_per_s": rates_cpp[1][0] if rates_cpp.get(1) else None,
                                                 "cpp_tracked": rates_cpp[4][1], "cpp_frames": rates_cpp[4][2],
                                                 "cpp_driver": "tools/prof_driver.bin <frames> 3 0.005 track=4: the same pipeline over the C-ABI without the interpreter, "
-                                                              "best of 3; GPU_MAX_HW_QUEUES=8 so that every tracker stream has a hardware queue of its own"})
+                                                              "best of 3; every tracker stream has a hardware queue of its own (the library asks for 8 when it is loaded)"})
             except Exception as e:
                 out["dense_fusion"]["cpp_error"] = repr(e)[:200]
 

@@ -84,6 +84,8 @@ int main(int argc, char* argv[]) {
         tool::BilateralFilter(refined_depth, filtered_depth);
         cube_handler.IntegrateImage(filtered_depth, frames[k].rgb, pose);
     };
+    double t_enqueue = 0, t_wait = 0, t_fuse = 0; // where the host thread spends the loop (printed with the result)
+    auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     if (n) {
         if (!load(0)) return 1;
@@ -97,14 +99,19 @@ int main(int argc, char* argv[]) {
         while (next < n && pending.size() < static_cast<size_t>(pipeline)) {
             if (!load(next)) return 1;
             const size_t target = pending.empty() ? last_ok : pending.back().first; // speculation: the previous pair will have tracked
+            const std::chrono::steady_clock::time_point te = std::chrono::steady_clock::now();
             if (!rgbd_odometry.DenseTrackingEnqueue(frames[next], frames[target], geometry::TransformationMatrix::Identity(), 0)) return 1;
+            t_enqueue += secs(te);
             pending.push_back(std::make_pair(next, target));
             ++next;
         }
         const std::pair<size_t, size_t> pair = pending.front();
         pending.pop_front();
+        const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
         std::shared_ptr<odometry::DenseTrackingResult> result = rgbd_odometry.DenseTrackingWait();
+        t_wait += secs(tw);
         ++used;
+        const std::chrono::steady_clock::time_point tf = std::chrono::steady_clock::now();
         if (result->tracking_success) { // DenseSlam.cpp:24-33: source = the new frame, target = the last tracked frame
             last_pose = last_pose * result->T.inverse();
             last_ok = pair.first;
@@ -115,9 +122,14 @@ int main(int argc, char* argv[]) {
             while (!pending.empty()) { rgbd_odometry.DenseTrackingWait(); pending.pop_front(); }
             next = pair.first + 1;
         }
-        if (!preload) { // frames before the last tracked one and before the oldest pair in flight are not read again (the tracker and the volume hold their own references to the device copies they still need)
+        t_fuse += secs(tf);
+        { // frames before the last tracked one and before the oldest pair in flight are not read again: their images are dropped (with --preload only the
+          // device copies, which then go back to the library's buffer cache; the tracker and the volume hold their own references to what they still read)
             const size_t safe = pending.empty() ? last_ok : (pending.front().second < last_ok ? pending.front().second : last_ok);
-            for (; released < safe; ++released) frames[released].Release();
+            for (; released < safe; ++released) {
+                if (preload) frames[released].on_device.reset();
+                else frames[released].Release();
+            }
         }
     }
     cube_handler.Synchronize();
@@ -140,6 +152,6 @@ int main(int argc, char* argv[]) {
     }
     std::cout << "{\"frames\": " << used << ", \"tracked\": " << tracked << ", \"pipeline\": " << pipeline << ", \"preloaded\": " << (preload ? "true" : "false")
               << ", \"decode_seconds\": " << decode_seconds << ", \"seconds\": " << seconds << ", \"frames_per_s\": " << (seconds > 0 ? used / seconds : 0.0)
-              << ", \"blocks\": " << blocks << ", \"triangles\": " << triangles << "}" << std::endl;
+              << ", \"host_seconds\": {\"enqueue\": " << t_enqueue << ", \"wait\": " << t_wait << ", \"fuse\": " << t_fuse << "}, \"blocks\": " << blocks << ", \"triangles\": " << triangles << "}" << std::endl;
     return 0;
 }

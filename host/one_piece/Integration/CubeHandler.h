@@ -19,6 +19,7 @@
 // through it is uploaded before the next member call touches the volume.  Device selection: environment variable
 // ONEPIECE_HIP_DEVICE (default 0).
 #pragma once
+#include <deque>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -163,7 +164,7 @@ class CubeHandler {
     void AddTransformedCubes(const VoxelCube& v_cube, const geometry::TransformationMatrix& trans, bool nearest);
     mutable op_volume* vol = nullptr;
     // device images of frames that were fused in place (RGBDFrame::on_device): held until the volume is known to be done with them
-    mutable std::vector<std::shared_ptr<void> > borrowed_;
+    mutable std::deque<std::pair<unsigned long long, std::shared_ptr<void> > > borrowed_; // (position among the volume's accepted frames, images)
     void ReleaseBorrowed() const { borrowed_.clear(); } // call only right after a synchronising C-ABI call
     explicit CubeHandler(op_volume* adopted, const CubeHandler& like, float resolution);
 };

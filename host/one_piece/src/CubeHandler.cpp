@@ -222,12 +222,13 @@ void CubeHandler::IntegrateImage(const geometry::RGBDFrame& rgbd, const geometry
     float p[16], pi[16];
     bridge::RowMajor(pose, p);
     bridge::RowMajor(pose.inverse(), pi);
-    if (borrowed_.size() >= 512) { // bounded: wait for the queued batches, then let the old frames go
-        if (op_volume_sync(vol) != OP_OK) { Report("IntegrateImage"); return; }
-        ReleaseBorrowed();
-    }
+    // the volume reads the device images when their batch is launched (and again if it is replayed after a pool growth): they are held here
+    // until the volume reports their batch complete (op_volume_progress: no waiting) -- about three batches' worth of frames in steady state
+    uint64_t accepted = 0, done = 0;
+    if (op_volume_progress(vol, &accepted, &done) != OP_OK) { Report("IntegrateImage"); return; }
+    while (!borrowed_.empty() && borrowed_.front().first < done) borrowed_.pop_front();
     if (op_volume_integrate(vol, d->depth, d->depth_fmt, static_cast<const uint8_t*>(d->rgb), OP_MEM_DEVICE, p, pi) != OP_OK) { Report("IntegrateImage"); return; }
-    borrowed_.push_back(rgbd.on_device);
+    borrowed_.push_back(std::make_pair(static_cast<unsigned long long>(accepted), rgbd.on_device)); // this frame is number `accepted` (0-based)
 }
 
 void CubeHandler::Merge(const CubeHandler& another) {

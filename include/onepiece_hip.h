@@ -67,9 +67,15 @@ const char *op_last_error(void);
 int op_runtime_hw_queues(int *requested);
 /* Images that are used more than once -- a frame is tracked against twice and fused once (example/DenseFusion/DenseSlam.cpp:24-33,
  * DenseFusion.cpp:86-96) -- can be brought to the device ONCE and then handed to op_tracker_dense_tracking(_enqueue) /
- * op_volume_integrate with OP_MEM_DEVICE.  op_device_upload copies `bytes` from host memory into a buffer of the library's buffer cache
- * (blocking: complete on return); op_device_release returns the buffer.  The caller keeps it alive until the last consumer has finished
- * (op_tracker_wait; for a volume: its next synchronising call). */
+ * op_volume_integrate with OP_MEM_DEVICE.
+ *   op_device_alloc    a buffer from the library's buffer cache (hipMalloc synchronises the whole device: allocate slabs, not frames)
+ *   op_device_write    one or two host arrays -> the buffer at the given byte offsets: staged through pinned memory by the caller's thread
+ *                      and the library's copy helpers, one DMA; blocking (complete and visible to every stream on return)
+ *   op_device_upload   alloc + write of one array
+ *   op_device_release  returns a buffer of op_device_alloc / op_device_upload
+ * The caller keeps a buffer alive until its last consumer has finished (op_tracker_wait; for a volume: op_volume_progress). */
+int op_device_alloc(size_t bytes, int device, void **device_ptr);
+int op_device_write(void *device_ptr, size_t n_parts, const void *const *parts, const size_t *bytes, const size_t *offsets, int device);
 int op_device_upload(const void *host, size_t bytes, int device, void **device_ptr);
 int op_device_release(void *device_ptr, int device);
 /* Registration objects (op_icp, the contexts behind op_icp_register / op_estimate_normals / op_points_from_depth) are
@@ -141,6 +147,11 @@ int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* Cu
 #define OP_VOLUME_UPDATE_EXACT 0
 #define OP_VOLUME_UPDATE_SUM_FORM 1
 int op_volume_set_option(op_volume *v, int option, int value);
+/* How far the volume has got with the frames handed to op_volume_integrate / _sequence, WITHOUT waiting: frames accepted so far, and how many
+ * of them belong to batches the device has reported complete (frames are queued up to 32 per launch and a launched batch may still be
+ * replayed after a pool growth).  Device images of the first `frames_done` frames (OP_MEM_DEVICE, in call order) are
+ * no longer read and may be released or overwritten; host images are only borrowed for the call anyway. */
+int op_volume_progress(op_volume *v, uint64_t *frames_accepted, uint64_t *frames_done);
 int op_volume_clear(op_volume *v);                            /* CubeHandler.h:133-136 */
 int op_volume_sync(op_volume *v);
 /* Launches the frames op_volume_integrate / op_volume_integrate_sequence have queued (a batch smaller than 32), without
@@ -422,13 +433,18 @@ int op_tracker_create(int device, op_tracker **out);
 int op_tracker_destroy(op_tracker *t);
 /* OP_TRACK_OPT_SUMS: how an iteration's normal equations are summed (DenseOdometryFunction.cpp:297-381).
  *   OP_TRACK_SUMS_FP64 (default): fp64 reduction on the device, the whole coarse-to-fine loop without a host round trip.
- *   OP_TRACK_SUMS_REFERENCE_F32: VALIDATION mode -- association, acceptance and Jacobian rows come from the kernels, but
- *     every iteration's rows go to the host and are summed on one thread in raster order in float32 exactly like the
- *     reference's loop, followed by the LDL^T solve / exp / pose update on the host (slow: a 17 MB transfer per
- *     full-resolution iteration).  With it a run follows the CPU path step for step. */
+ *   OP_TRACK_SUMS_REFERENCE_F32: the reference's own sums -- association, acceptance and Jacobian rows come from the same kernels, and every
+ *     iteration's rows are summed in raster order in float32 exactly like the reference's loop: on the device, by one wave that owns the
+ *     36 + 6 accumulators and walks the compacted rows (k_seq_sums; the other waves of its workgroup prepare the products), then the 42
+ *     sums go to the host for the LDL^T solve / exp / pose update the reference-order mode shares with the CPU path.  A run follows the
+ *     CPU path step for step: identical correspondence counts at every iteration, poses to 1e-6 (north_star's bar is 1e-4), at ~9 ms
+ *     per 640x480 track.  NormalizeIntensity's two means likewise.
+ *   OP_TRACK_SUMS_REFERENCE_F32_HOST: the same sums taken on ONE host thread after a transfer of all rows (17 MB per full-resolution
+ *     iteration; ~30 tracks/s) -- the cross-check of the device sums: both give the same floats. */
 #define OP_TRACK_OPT_SUMS 0
 #define OP_TRACK_SUMS_FP64 0
 #define OP_TRACK_SUMS_REFERENCE_F32 1
+#define OP_TRACK_SUMS_REFERENCE_F32_HOST 2
 int op_tracker_set_option(op_tracker *t, int option, int value);
 /* Odometry::MultiScaleComputing + the result assembly of DenseTracking (Odometry.cpp:621-687,
  * :600-607).  iters_per_level[l] = iter_count_per_level[l] (Odometry.h:170, default {4,8,16});

@@ -52,7 +52,7 @@ class TrackResult(C.Structure):
 
 
 OP_TRACK_HYBRID, OP_TRACK_PHOTO, OP_TRACK_DEPTH = 0, 1, 2
-OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_FP64, OP_TRACK_SUMS_REFERENCE_F32 = 0, 0, 1
+OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_FP64, OP_TRACK_SUMS_REFERENCE_F32, OP_TRACK_SUMS_REFERENCE_F32_HOST = 0, 0, 1, 2
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_EXACT, OP_VOLUME_UPDATE_SUM_FORM = 0, 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
@@ -74,6 +74,8 @@ SIGNATURES = {
     "op_abi_version": (C.c_int, []),
     "op_last_error": (C.c_char_p, []),
     "op_runtime_hw_queues": (C.c_int, [C.POINTER(C.c_int)]),
+    "op_device_alloc": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "op_device_write": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]),
     "op_device_upload": (C.c_int, [_vp, C.c_size_t, C.c_int, C.POINTER(_vp)]),
     "op_device_release": (C.c_int, [_vp, C.c_int]),
     "op_release_cached_memory": (C.c_int, []),
@@ -96,6 +98,7 @@ SIGNATURES = {
     "op_volume_set_camera": (C.c_int, [_vp, C.POINTER(Camera)]),
     "op_volume_set_near_far": (C.c_int, [_vp, C.c_float, C.c_float]),
     "op_volume_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "op_volume_progress": (C.c_int, [_vp, _u64p, _u64p]),
     "op_volume_clear": (C.c_int, [_vp]),
     "op_volume_sync": (C.c_int, [_vp]),
     "op_volume_flush": (C.c_int, [_vp]),

@@ -208,6 +208,167 @@ __global__ __launch_bounds__(kThreads) void k_track_rows(const TrackState* __res
     }
 }
 
+// ---- reference-order sums on the device (OP_TRACK_SUMS_REFERENCE_F32) ---------------------------------------------
+// The reference adds every accepted pixel's J J^T and J r to float32 accumulators one after the other, in raster order
+// (DenseOdometryFunction.cpp:297-381), and NormalizeIntensity does the same with two intensity sums (:131-141).  The rounding of
+// those 10^5..10^6 sequential additions is part of the reference's result (it moves the pose by up to 2e-4), and a sequential float
+// sum cannot be re-associated.  What CAN run side by side are the 36 + 6 accumulators: one wave owns them, a lane each, and walks the
+// accepted rows in order doing nothing but `acc += product` -- one dependent v_add_f32 per row.  Everything else is taken off that
+// chain: k_rows_count / k_emit_scan / k_track_rows_compact put the accepted pixels' rows into raster order without gaps, and inside
+// k_seq_sums the other 15 waves of the workgroup turn the rows of the NEXT tile into the 42 products per row (transposed in LDS so
+// that the summing wave reads four consecutive rows of its accumulator with one ds_read_b128) while the summing wave consumes the
+// current tile.  Same operands in the same order as the host loop of op_host::track_sums_reference_order: bit-identical sums.
+// A full-resolution iteration (~300 k rows) takes ~1 ms instead of a 17 MB transfer + 10 ms on one host core.
+constexpr int kSeqThreads = 1024;      // wave 0 sums, waves 1..15 produce
+constexpr int kSeqRows = 384;          // rows per tile
+constexpr int kSeqStride = kSeqRows + 4; // floats between two accumulators' rows in LDS: 4 (mod 32) spreads the lanes' 16-byte reads over the banks
+constexpr int kSeqProducers = kSeqThreads - 64;
+
+// the accepted pixels of a level per workgroup of kThreads pixels (level < 0: the last executed level, as k_emit_count)
+__global__ __launch_bounds__(kThreads) void k_rows_count(const TrackState* __restrict__ st, int l, const int* __restrict__ pair_t, unsigned* __restrict__ wg_count) {
+    __shared__ unsigned s_c[kThreads / 64];
+    const int npix = st->lv[l].w * st->lv[l].h;
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    const bool a = s < npix && pair_t[s] >= 0;
+    const unsigned long long m = __ballot(a);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+// position of an accepted pixel among the accepted pixels of the level, in raster order (wg_off: exclusive scan of k_rows_count's counts)
+__device__ __forceinline__ unsigned raster_rank(bool a, const unsigned* __restrict__ wg_off, unsigned* s_c) {
+    const unsigned long long m = __ballot(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_c[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned idx = wg_off[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) idx += s_c[w];
+    return idx;
+}
+
+// the Jacobian rows {J[6], r} of every accepted pixel -- two for the hybrid term, one otherwise -- compacted in raster order
+// (k_track_rows writes them per source pixel, with gaps)
+template <int TERM>
+__global__ __launch_bounds__(kThreads) void k_track_rows_compact(const TrackState* __restrict__ st, int l, const int* __restrict__ pair_t,
+                                                                 const unsigned* __restrict__ wg_off, float* __restrict__ rows) {
+    __shared__ float s_T[12];
+    __shared__ unsigned s_c[kThreads / 64];
+    const LevelDev L = st->lv[l];
+    if (threadIdx.x < 12) s_T[threadIdx.x] = st->T[threadIdx.x];
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    const int t = s < L.w * L.h ? pair_t[s] : -1;
+    const unsigned idx = raster_rank(t >= 0, wg_off, s_c); // (its barrier also publishes s_T)
+    if (t < 0) return;
+    float J[2][6], r[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        r[m] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[m][k] = 0.0f;
+    }
+    track_rows_dev<TERM>(L, s_T, s, t, J, r);
+    constexpr int kRows = TERM == 0 ? 2 : 1;
+    float* o = rows + (size_t)idx * (7 * kRows);
+#pragma unroll
+    for (int m = 0; m < kRows; ++m) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[7 * m + k] = J[m][k];
+        o[7 * m + 6] = r[m];
+    }
+}
+
+// NormalizeIntensity's operands (DenseOdometryFunction.cpp:131-141): {source intensity at s, target intensity at p(s)} of every accepted pixel
+__global__ __launch_bounds__(kThreads) void k_norm_pairs_compact(const float* __restrict__ gs, const float* __restrict__ gt, int npix, const int* __restrict__ pair_t,
+                                                                 const unsigned* __restrict__ wg_off, float* __restrict__ out2) {
+    __shared__ unsigned s_c[kThreads / 64];
+    const int s = blockIdx.x * kThreads + threadIdx.x;
+    const int t = s < npix ? pair_t[s] : -1;
+    const unsigned idx = raster_rank(t >= 0, wg_off, s_c);
+    if (t < 0) return;
+    out2[2 * (size_t)idx] = gs[s];
+    out2[2 * (size_t)idx + 1] = gt[t];
+}
+
+// Sequential float32 sums of NACC accumulators over n_pix compacted pixels of NF floats each, RPP rows per pixel.
+//   NACC 42 (NF 7 * RPP): row = {J[6], r}; accumulator a*6+b += J[a]*J[b] (a, b < 6), accumulator 36+a += J[a]*r   -- the order of
+//                    op_host::track_sums_reference_order: per pixel row 0 then row 1, per accumulator one rounded product and one rounded add
+//   NACC 2  (NF 2):  accumulator k += value k of the pixel (NormalizeIntensity's two sums)
+// One workgroup.  out[0 .. NACC-1] = the sums, ((unsigned*)out)[NACC] = n_pix.  Rows beyond the last pixel of the last tile are
+// products of zeros: acc + (+0.0f) == acc for every acc this loop can hold (it starts at +0 and a float sum only yields -0 from -0 + -0).
+template <int NACC, int NF, int RPP>
+__global__ __launch_bounds__(kSeqThreads) void k_seq_sums(const float* __restrict__ rows, const unsigned* __restrict__ n_pix_ptr, float* __restrict__ out) {
+    extern __shared__ float seq_lds[];
+    constexpr int P = kSeqRows / RPP;                        // pixels per tile
+    constexpr int RF = NF / RPP;                             // floats per row
+    float* prod = seq_lds;                                   // [2][NACC][kSeqStride]
+    float* stage = seq_lds + 2 * NACC * kSeqStride;          // [2][P * NF]
+    const unsigned n_pix = *n_pix_ptr;
+    const unsigned n_tiles = (n_pix + (unsigned)P - 1u) / (unsigned)P;
+    const int tid = threadIdx.x;
+    const bool consumer = tid < 64;
+    const int pj = tid - 64;                                 // producer index
+    auto load_tile = [&](unsigned tile, float (&reg)[(P * NF + kSeqProducers - 1) / kSeqProducers]) { // global -> registers (zeros beyond the data)
+        const size_t base = (size_t)tile * P * NF, end = (size_t)n_pix * NF;
+#pragma unroll
+        for (int i = 0; i < (P * NF + kSeqProducers - 1) / kSeqProducers; ++i) {
+            const int e = pj + i * kSeqProducers;
+            reg[i] = (e < P * NF && base + (size_t)e < end) ? rows[base + (size_t)e] : 0.0f;
+        }
+    };
+    auto store_tile = [&](int buf, const float (&reg)[(P * NF + kSeqProducers - 1) / kSeqProducers]) {
+#pragma unroll
+        for (int i = 0; i < (P * NF + kSeqProducers - 1) / kSeqProducers; ++i) {
+            const int e = pj + i * kSeqProducers;
+            if (e < P * NF) stage[buf * (P * NF) + e] = reg[i];
+        }
+    };
+    auto produce = [&](int buf) { // stage[buf] -> prod[buf]: all kSeqRows rows of the tile, one (accumulator, row) entry per step
+        const float* sg = stage + buf * (P * NF);
+        float* pd = prod + buf * (NACC * kSeqStride);
+        for (int e = pj; e < NACC * kSeqRows; e += kSeqProducers) {
+            const int k = e / kSeqRows, row = e - k * kSeqRows;
+            const float* r = sg + row * RF;                  // RPP rows of RF floats per pixel: row * RF == pixel * NF + (row % RPP) * RF
+            float v;
+            if (NACC == 42) v = k < 36 ? r[k / 6] * r[k % 6] : r[k - 36] * r[6];
+            else v = r[k];
+            pd[k * kSeqStride + row] = v;
+        }
+    };
+    float acc = 0.0f;
+    float reg[(P * NF + kSeqProducers - 1) / kSeqProducers];
+    // prologue: tile 0 staged and produced, tile 1 staged
+    if (!consumer && n_tiles) { load_tile(0, reg); store_tile(0, reg); }
+    __syncthreads();
+    if (!consumer && n_tiles) { produce(0); load_tile(1, reg); store_tile(1, reg); }
+    __syncthreads();
+    if (consumer) __builtin_amdgcn_s_setprio(3);
+    for (unsigned t = 0; t < n_tiles; ++t) {
+        const int cur = (int)(t & 1u);
+        if (consumer) {
+            if (tid < NACC) {
+                const unsigned left = n_pix - t * (unsigned)P;
+                const int nrows = (int)((left < (unsigned)P ? left : (unsigned)P) * RPP);
+                const float4* src = reinterpret_cast<const float4*>(prod + cur * (NACC * kSeqStride) + tid * kSeqStride);
+                const int n4 = (nrows + 3) >> 2;
+#pragma unroll 4
+                for (int q = 0; q < n4; ++q) {
+                    const float4 v = src[q];
+                    acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+                }
+            }
+        } else {
+            if (t + 2 < n_tiles) load_tile(t + 2, reg);      // in flight while the products are formed
+            if (t + 1 < n_tiles) produce(cur ^ 1);           // tile t + 1 from stage[cur ^ 1]
+            if (t + 2 < n_tiles) store_tile(cur, reg);       // stage[cur] held tile t: consumed by produce() one iteration ago
+        }
+        __syncthreads();
+    }
+    if (consumer && tid < NACC) out[tid] = acc;
+    if (tid == 0) reinterpret_cast<unsigned*>(out)[NACC] = n_pix;
+}
+constexpr size_t seq_lds_bytes(int nacc, int nf, int rpp) { return sizeof(float) * (2 * (size_t)nacc * kSeqStride + 2 * (size_t)(kSeqRows / rpp) * nf); }
+
 // The bookkeeping of k_track_solve for a pose computed on the host (validation mode).
 struct PoseArg { float m[16]; };
 __global__ void k_track_apply(TrackState* __restrict__ st, int l, int it, PoseArg T, unsigned long long n) {
@@ -539,7 +700,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_count(const TrackState* __res
     if (threadIdx.x == 0) wg_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
 
-__global__ __launch_bounds__(1024) void k_emit_scan(TrackState* __restrict__ st, unsigned* __restrict__ wg_count, int n_wg) {
+__global__ __launch_bounds__(1024) void k_emit_scan(TrackState* __restrict__ st, unsigned* __restrict__ wg_count, int n_wg, unsigned* __restrict__ total_out = nullptr) {
     // exclusive scan of n_wg counts by one workgroup (n_wg <= a few thousand), in place
     __shared__ unsigned s_part[1024];
     const int per = (n_wg + 1023) / 1024;
@@ -556,7 +717,7 @@ __global__ __launch_bounds__(1024) void k_emit_scan(TrackState* __restrict__ st,
     }
     unsigned run = s_part[threadIdx.x] - sum;
     for (int i = lo; i < hi; ++i) { const unsigned c = wg_count[i]; wg_count[i] = run; run += c; }
-    if (threadIdx.x == 1023) st->n_emit = s_part[1023];
+    if (threadIdx.x == 1023) { st->n_emit = s_part[1023]; if (total_out) *total_out = s_part[1023]; }
 }
 
 __global__ __launch_bounds__(kThreads) void k_emit_scatter(const TrackState* __restrict__ st, const int* __restrict__ pair_t,
@@ -638,10 +799,14 @@ struct op_tracker {
     unsigned short* code = nullptr;  // per source pixel: acceptance link code
     int lds_cap = 0;                 // dynamic LDS bytes available to one k_track_iter workgroup
     int sums = OP_TRACK_SUMS_FP64;   // OP_TRACK_OPT_SUMS
+    bool seq_ok = false;             // k_seq_sums may have its LDS (else OP_TRACK_SUMS_REFERENCE_F32 sums on the host like _F32_HOST)
     float* rows_dev = nullptr;       // validation mode: 14 floats per source pixel
     float* rows_host = nullptr;      // pinned
     int* pair_host = nullptr;        // pinned
     size_t rows_cap = 0;             // pixels
+    float* seq_out = nullptr;        // device: the 42 (+ count) results of k_seq_sums
+    float* seq_host = nullptr;       // pinned copy
+    unsigned* seq_total = nullptr;   // device: number of accepted pixels (k_emit_scan)
     int lds_total = 0, lds_static = 0, n_cu = 256;
     double* partials = nullptr;
     unsigned* wg_count = nullptr;
@@ -744,6 +909,12 @@ int op_tracker_create(int device, op_tracker** out) {
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<2>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_track_iter<3>), hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_cap) == hipSuccess;
     if (!attr_ok) { (void)hipGetLastError(); t->lds_total = 65536; t->lds_cap = 65536 - lds_static; }
+    // k_seq_sums (reference-order sums) double-buffers its product tiles in ~150 KB of LDS
+    t->seq_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_sums<42, 14, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(42, 14, 2)) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_sums<42, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(42, 7, 1)) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_sums<2, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(2, 2, 1)) == hipSuccess &&
+                (size_t)lds_max >= seq_lds_bytes(42, 14, 2);
+    if (!t->seq_ok) (void)hipGetLastError();
     if (const char* e = std::getenv("ONEPIECE_TRACKER_GRAPH")) t->graph_ok = std::atoi(e) != 0;
     *out = t;
     return OP_OK;
@@ -751,7 +922,7 @@ int op_tracker_create(int device, op_tracker** out) {
 
 int op_tracker_set_option(op_tracker* t, int option, int value) {
     if (!t) return fail(OP_ERR_INVALID, "null tracker");
-    if (option == OP_TRACK_OPT_SUMS && (value == OP_TRACK_SUMS_FP64 || value == OP_TRACK_SUMS_REFERENCE_F32)) { t->sums = value; return OP_OK; }
+    if (option == OP_TRACK_OPT_SUMS && (value == OP_TRACK_SUMS_FP64 || value == OP_TRACK_SUMS_REFERENCE_F32 || value == OP_TRACK_SUMS_REFERENCE_F32_HOST)) { t->sums = value; return OP_OK; }
     return fail(OP_ERR_INVALID, "op_tracker_set_option: unknown option %d / value %d", option, value);
 }
 
@@ -760,6 +931,8 @@ int op_tracker_destroy(op_tracker* t) {
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->rows_dev);
+    (void)hipFree(t->seq_out); (void)hipFree(t->seq_total);
+    if (t->seq_host) (void)hipHostFree(t->seq_host);
     if (t->rows_host) (void)hipHostFree(t->rows_host);
     if (t->pair_host) (void)hipHostFree(t->pair_host);
     (void)hipFree(t->pair_t); (void)hipFree(t->pair_p); (void)hipFree(t->code); (void)hipFree(t->partials); (void)hipFree(t->wg_count); (void)hipFree(t->pix_out); (void)hipFree(t->pts_out);
@@ -792,7 +965,13 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
     OP_HIP(hipMemcpyAsync(t->st, h, offsetof(TrackState, per_iter_count), hipMemcpyHostToDevice, t->stream));
     size_t max_pix = 0;
     int it = 0;
-    const bool strict = t->sums == OP_TRACK_SUMS_REFERENCE_F32;
+    const bool strict = t->sums != OP_TRACK_SUMS_FP64;
+    const bool on_device = t->sums == OP_TRACK_SUMS_REFERENCE_F32 && t->seq_ok; // the sequential float32 sums in k_seq_sums; else on one host thread
+    if (strict && !t->seq_out) {
+        OP_HIP(hipMalloc(&t->seq_out, 64 * sizeof(float)));
+        OP_HIP(hipHostMalloc(&t->seq_host, 64 * sizeof(float), hipHostMallocDefault));
+        OP_HIP(hipMalloc(&t->seq_total, sizeof(unsigned)));
+    }
     float cur[16];
     std::memcpy(cur, init_T, sizeof(cur));
     for (int l = n_levels - 1; l >= 0; --l) {
@@ -806,8 +985,10 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
             if (t->pair_host) OP_HIP(hipHostFree(t->pair_host));
             t->rows_dev = t->rows_host = nullptr; t->pair_host = nullptr; t->rows_cap = 0;
             OP_HIP(hipMalloc(&t->rows_dev, np * 14 * sizeof(float)));
-            OP_HIP(hipHostMalloc(&t->rows_host, np * 14 * sizeof(float), hipHostMallocDefault));
-            OP_HIP(hipHostMalloc(&t->pair_host, np * sizeof(int), hipHostMallocDefault));
+            if (!on_device) {
+                OP_HIP(hipHostMalloc(&t->rows_host, np * 14 * sizeof(float), hipHostMallocDefault));
+                OP_HIP(hipHostMalloc(&t->pair_host, np * sizeof(int), hipHostMallocDefault));
+            }
             t->rows_cap = np;
         }
         for (int j = 0; j < iters_per_level[l]; ++j, ++it) {
@@ -819,19 +1000,41 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
                 hipLaunchKernelGGL(k_track_solve, dim3(1), dim3(1024), 0, t->stream, t->st, l, it, t->partials, g.n_wg);
                 continue;
             }
-            // Validation mode: association, acceptance and the Jacobian rows come from the kernels; the sums are taken on
-            // ONE host thread in raster order in float32 like the reference's loop, the solve / exp / pose update follow on
-            // the host, and the new pose goes back to the device state for the next iteration.
-            if (term_type == 0) hipLaunchKernelGGL(k_track_rows<0>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
-            else if (term_type == 1) hipLaunchKernelGGL(k_track_rows<1>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
-            else hipLaunchKernelGGL(k_track_rows<2>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
-            OP_HIP(hipGetLastError());
-            OP_HIP(hipMemcpyAsync(t->rows_host, t->rows_dev, np * 14 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
-            OP_HIP(hipMemcpyAsync(t->pair_host, t->pair_t, np * sizeof(int), hipMemcpyDeviceToHost, t->stream));
-            OP_HIP(hipStreamSynchronize(t->stream));
+            // Reference-order sums: association, acceptance and the Jacobian rows come from the kernels; the sums are taken in raster
+            // order in float32 like the reference's loop -- by k_seq_sums on the device (42 numbers come back), or, in the _HOST variant,
+            // on ONE host thread after a transfer of all rows -- then the solve / exp / pose update on the host, and the new pose goes
+            // back into the device state for the next iteration.
             float JTJ[36], JTr[6], x[6], D[16];
             size_t n_pairs = 0;
-            op_host::track_sums_reference_order(t->rows_host, t->pair_host, np, term_type == 0 ? 2 : 1, JTJ, JTr, &n_pairs);
+            if (on_device) {
+                hipLaunchKernelGGL(k_rows_count, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->wg_count);
+                hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg_a, t->seq_total);
+                if (term_type == 0) {
+                    hipLaunchKernelGGL(k_track_rows_compact<0>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, (const unsigned*)t->wg_count, t->rows_dev);
+                    hipLaunchKernelGGL((k_seq_sums<42, 14, 2>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 14, 2), t->stream, (const float*)t->rows_dev, (const unsigned*)t->seq_total, t->seq_out);
+                } else {
+                    if (term_type == 1) hipLaunchKernelGGL(k_track_rows_compact<1>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, (const unsigned*)t->wg_count, t->rows_dev);
+                    else hipLaunchKernelGGL(k_track_rows_compact<2>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, (const unsigned*)t->wg_count, t->rows_dev);
+                    hipLaunchKernelGGL((k_seq_sums<42, 7, 1>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 7, 1), t->stream, (const float*)t->rows_dev, (const unsigned*)t->seq_total, t->seq_out);
+                }
+                OP_HIP(hipGetLastError());
+                OP_HIP(hipMemcpyAsync(t->seq_host, t->seq_out, 43 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+                OP_HIP(hipStreamSynchronize(t->stream));
+                std::memcpy(JTJ, t->seq_host, sizeof(JTJ));
+                std::memcpy(JTr, t->seq_host + 36, sizeof(JTr));
+                unsigned n32;
+                std::memcpy(&n32, t->seq_host + 42, sizeof(n32));
+                n_pairs = n32;
+            } else {
+                if (term_type == 0) hipLaunchKernelGGL(k_track_rows<0>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
+                else if (term_type == 1) hipLaunchKernelGGL(k_track_rows<1>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
+                else hipLaunchKernelGGL(k_track_rows<2>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->rows_dev);
+                OP_HIP(hipGetLastError());
+                OP_HIP(hipMemcpyAsync(t->rows_host, t->rows_dev, np * 14 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+                OP_HIP(hipMemcpyAsync(t->pair_host, t->pair_t, np * sizeof(int), hipMemcpyDeviceToHost, t->stream));
+                OP_HIP(hipStreamSynchronize(t->stream));
+                op_host::track_sums_reference_order(t->rows_host, t->pair_host, np, term_type == 0 ? 2 : 1, JTJ, JTr, &n_pairs);
+            }
             op_host::ldlt_solve6_float_sums(JTJ, JTr, x);          // DenseOdometryFunction.cpp:404
             op_host::se3_exp(x, D);
             op_host::mat4_mul(D, cur, cur);                          // relative_pose = delta_matrix * relative_pose
@@ -1050,19 +1253,39 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
         const IterGeom g = iter_geom(t, np);
         hipLaunchKernelGGL(k_track_assoc, dim3(n_wg0), dim3(kThreads), 0, t->stream, t->st, 0, t->pair_p, t->code);
         launch_iter<3>(t, 0, g);
-        if (t->sums == OP_TRACK_SUMS_REFERENCE_F32) {
-            // validation mode: NormalizeIntensity's two means summed like the reference does (DenseOdometryFunction.cpp:131-141):
-            // sequentially in float32 over the identity-pose pairs in raster order, on one host thread
-            std::vector<int> pt(np);
-            std::vector<float> gs(np), gt(np);
-            OP_HIP(hipMemcpyAsync(pt.data(), t->pair_t, np * sizeof(int), hipMemcpyDeviceToHost, t->stream));
-            OP_HIP(hipMemcpyAsync(gs.data(), pyr_image(t, 0, 0, 0), np * sizeof(float), hipMemcpyDeviceToHost, t->stream));
-            OP_HIP(hipMemcpyAsync(gt.data(), pyr_image(t, 1, 0, 0), np * sizeof(float), hipMemcpyDeviceToHost, t->stream));
-            OP_HIP(hipStreamSynchronize(t->stream));
+        if (t->sums != OP_TRACK_SUMS_FP64) {
+            // reference-order mode: NormalizeIntensity's two means summed like the reference does (DenseOdometryFunction.cpp:131-141):
+            // sequentially in float32 over the identity-pose pairs in raster order -- by k_seq_sums, or (_HOST variant) on one host thread
             float mean_s = 0.0f, mean_t = 0.0f;
             size_t cnt = 0;
-            for (size_t k = 0; k < np; ++k)
-                if (pt[k] >= 0) { mean_s += gs[k]; mean_t += gt[(size_t)pt[k]]; ++cnt; }
+            if (t->sums == OP_TRACK_SUMS_REFERENCE_F32 && t->seq_ok) {
+                if (!t->seq_out) {
+                    OP_HIP(hipMalloc(&t->seq_out, 64 * sizeof(float)));
+                    OP_HIP(hipHostMalloc(&t->seq_host, 64 * sizeof(float), hipHostMallocDefault));
+                    OP_HIP(hipMalloc(&t->seq_total, sizeof(unsigned)));
+                }
+                float* pairs2 = reinterpret_cast<float*>(t->pix_out); // 2 floats per accepted pixel; pix_out (16 B per pixel) is idle until the run's final emit
+                hipLaunchKernelGGL(k_rows_count, dim3(n_wg0), dim3(kThreads), 0, t->stream, t->st, 0, (const int*)t->pair_t, t->wg_count);
+                hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg0, t->seq_total);
+                hipLaunchKernelGGL(k_norm_pairs_compact, dim3(n_wg0), dim3(kThreads), 0, t->stream, (const float*)pyr_image(t, 0, 0, 0), (const float*)pyr_image(t, 1, 0, 0), (int)np,
+                                   (const int*)t->pair_t, (const unsigned*)t->wg_count, pairs2);
+                hipLaunchKernelGGL((k_seq_sums<2, 2, 1>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(2, 2, 1), t->stream, (const float*)pairs2, (const unsigned*)t->seq_total, t->seq_out);
+                OP_HIP(hipGetLastError());
+                OP_HIP(hipMemcpyAsync(t->seq_host, t->seq_out, 3 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+                OP_HIP(hipStreamSynchronize(t->stream));
+                unsigned n32;
+                std::memcpy(&n32, t->seq_host + 2, sizeof(n32));
+                mean_s = t->seq_host[0]; mean_t = t->seq_host[1]; cnt = n32;
+            } else {
+                std::vector<int> pt(np);
+                std::vector<float> gs(np), gt(np);
+                OP_HIP(hipMemcpyAsync(pt.data(), t->pair_t, np * sizeof(int), hipMemcpyDeviceToHost, t->stream));
+                OP_HIP(hipMemcpyAsync(gs.data(), pyr_image(t, 0, 0, 0), np * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+                OP_HIP(hipMemcpyAsync(gt.data(), pyr_image(t, 1, 0, 0), np * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+                OP_HIP(hipStreamSynchronize(t->stream));
+                for (size_t k = 0; k < np; ++k)
+                    if (pt[k] >= 0) { mean_s += gs[k]; mean_t += gt[(size_t)pt[k]]; ++cnt; }
+            }
             mean_s /= (float)cnt; mean_t /= (float)cnt;
             const float sc[2] = {(float)(0.5 / (double)mean_s), (float)(0.5 / (double)mean_t)};
             OP_HIP(hipMemcpyAsync(t->norm_scales, sc, sizeof(sc), hipMemcpyHostToDevice, t->stream));

@@ -1658,6 +1658,7 @@ struct op_volume {
     size_t unpack_n = 0;
     uint64_t generation = 0, unpack_gen = 0; // bumped by whatever moves or drops table slots (growth, clear) or fuses frames; _chunk checks it
     uint64_t n_grows = 0, n_replayed = 0; // pool growths and batches launched again after one (op_volume_growth_stats)
+    uint64_t frames_accepted = 0; // op_volume_progress: frames handed to the integrate calls so far
     bool grow_refused = false;   // an early growth could not get memory: stop asking before every batch (a real overflow still tries)
     // frames accepted by op_volume_integrate but not launched yet: single-frame calls are queued
     // and fused in batches of kMaxBatch (every accessor flushes first, so this is unobservable)
@@ -2098,6 +2099,41 @@ class CopyPool {
     std::atomic<uint64_t> epoch_hint_{0}; // lock-free mirror of epoch_ for the spinning helpers
 };
 
+// op_device_write: pageable host memory -> device memory.  A plain hipMemcpy from pageable memory makes the runtime pin the caller's pages for
+// the transfer (0.5-0.7 ms for a 0.9 MB image); like the volume's staging ring this goes through a pinned buffer instead -- the parts are
+// copied next to each other by the caller's thread and the CopyPool helpers, then ONE DMA moves the span they cover.
+int write_staged(void* dst, size_t n_parts, const void* const* parts, const size_t* bytes, const size_t* offsets, int device) {
+    struct Stage { std::mutex mu; void* pinned = nullptr; size_t cap = 0; hipStream_t stream = nullptr; };
+    static Stage stage[16];
+    Stage& S = stage[device & 15];
+    size_t lo = (size_t)-1, hi = 0;
+    for (size_t i = 0; i < n_parts; ++i) {
+        if (!parts[i] || !bytes[i]) return fail(OP_ERR_INVALID, "op_device_write: empty part");
+        lo = std::min(lo, offsets[i]); hi = std::max(hi, offsets[i] + bytes[i]);
+    }
+    if (n_parts == 0 || n_parts > 2) return fail(OP_ERR_INVALID, "op_device_write: one or two parts per call");
+    const size_t span = hi - lo;
+    std::lock_guard<std::mutex> lock(S.mu);
+    hipError_t e = hipSuccess;
+    if (S.cap < span) {
+        if (S.pinned) (void)hipHostFree(S.pinned);
+        S.pinned = nullptr; S.cap = 0;
+        const size_t want = span < (4u << 20) ? (4u << 20) : span;
+        e = hipHostMalloc(&S.pinned, want, hipHostMallocDefault);
+        if (e == hipSuccess) S.cap = want;
+    }
+    if (e == hipSuccess && !S.stream) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        char* h = (char*)S.pinned;
+        CopyPool::get().copy2(h + (offsets[0] - lo), parts[0], bytes[0], n_parts > 1 ? h + (offsets[1] - lo) : nullptr, n_parts > 1 ? parts[1] : nullptr,
+                              n_parts > 1 ? bytes[1] : 0);
+        e = hipMemcpyAsync((char*)dst + lo, S.pinned, span, hipMemcpyHostToDevice, S.stream); // (a gap between the parts carries staging leftovers: it is the caller's padding)
+        if (e == hipSuccess) e = hipStreamSynchronize(S.stream); // complete on return: the staging buffer is free again, the data is visible to every stream
+    }
+    if (e != hipSuccess) return fail(OP_ERR_HIP, "op_device_write: %s", hipGetErrorString(e));
+    return OP_OK;
+}
+
 int vol_ring_alloc(op_volume* v) {
     const size_t npx = (size_t)v->cam.width * v->cam.height;
     if (v->ring_px >= npx && v->copy_stream) return OP_OK;
@@ -2183,16 +2219,27 @@ extern "C" {
 
 int op_abi_version(void) { return OP_ABI_VERSION; }
 
-int op_device_upload(const void* host, size_t bytes, int device, void** device_ptr) {
-    if (!host || !device_ptr || bytes == 0) return fail(OP_ERR_INVALID, "op_device_upload: null argument");
+int op_device_alloc(size_t bytes, int device, void** device_ptr) {
+    if (!device_ptr || bytes == 0) return fail(OP_ERR_INVALID, "op_device_alloc: null argument");
     *device_ptr = nullptr;
     OP_TRY(op::use_device(device));
-    void* d = nullptr;
-    OP_HIP(op::cached_malloc(&d, bytes));
-    const hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice); // blocking: the caller's buffer is free and the copy is complete on return
-    if (e != hipSuccess) { op::cached_free(d); return fail(OP_ERR_HIP, "op_device_upload: %s", hipGetErrorString(e)); }
-    *device_ptr = d;
+    OP_HIP(op::cached_malloc(device_ptr, bytes));
     return OP_OK;
+}
+
+int op_device_write(void* device_ptr, size_t n_parts, const void* const* parts, const size_t* bytes, const size_t* offsets, int device) {
+    if (!device_ptr || !parts || !bytes || !offsets) return fail(OP_ERR_INVALID, "op_device_write: null argument");
+    OP_TRY(op::use_device(device));
+    return write_staged(device_ptr, n_parts, parts, bytes, offsets, device);
+}
+
+int op_device_upload(const void* host, size_t bytes, int device, void** device_ptr) {
+    if (!host || !device_ptr || bytes == 0) return fail(OP_ERR_INVALID, "op_device_upload: null argument");
+    OP_TRY(op_device_alloc(bytes, device, device_ptr));
+    const size_t zero = 0;
+    const int rc = write_staged(*device_ptr, 1, &host, &bytes, &zero, device);
+    if (rc != OP_OK) { op::cached_free(*device_ptr); *device_ptr = nullptr; }
+    return rc;
 }
 
 int op_device_release(void* device_ptr, int device) {
@@ -2576,6 +2623,7 @@ int op_volume_integrate(op_volume* v, const void* depth, int depth_fmt, const ui
     v->pend_P.depth[slot] = depth;
     v->pend_P.rgb[slot] = c;
     v->pend_fmt = depth_fmt;
+    ++v->frames_accepted;
     if (++v->pend_n == kMaxBatch) return vol_flush(v);
     return OP_OK;
 }
@@ -2624,8 +2672,19 @@ int op_volume_integrate_sequence(op_volume* v, const void* depth, size_t depth_s
         v->pend_P.depth[slot] = (const char*)depth + f * depth_stride_bytes;
         v->pend_P.rgb[slot] = rgb + f * rgb_stride_bytes;
         v->pend_fmt = depth_fmt;
+        ++v->frames_accepted;
         if (++v->pend_n == kMaxBatch) OP_TRY(vol_flush(v));
     }
+    return OP_OK;
+}
+
+int op_volume_progress(op_volume* v, uint64_t* frames_accepted, uint64_t* frames_done) {
+    OP_VOL(v);
+    vol_retire(v); // looks at the device's progress report; never blocks
+    uint64_t open = (uint64_t)v->pend_n;
+    for (const auto& r : v->log) open += (uint64_t)r.nf;
+    if (frames_accepted) *frames_accepted = v->frames_accepted;
+    if (frames_done) *frames_done = v->frames_accepted >= open ? v->frames_accepted - open : 0;
     return OP_OK;
 }
 

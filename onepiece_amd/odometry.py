@@ -101,10 +101,12 @@ class Odometry:
         self.camera = camera
 
     def SetSums(self, sums="fp64"):
-        """op_tracker_set_option(OP_TRACK_OPT_SUMS): "fp64" (default, device reduction) or "reference_f32" -- the validation
-        mode that sums every iteration's Jacobian rows sequentially in float32 on the host, as the reference does."""
+        """op_tracker_set_option(OP_TRACK_OPT_SUMS): "fp64" (default, device reduction, no host round trip), "reference_f32" -- every
+        iteration's Jacobian rows summed sequentially in float32 in raster order as the reference does, by one wave on the device -- or
+        "reference_f32_host", the same sums on one host thread (the slow cross-check of the device sums)."""
         L.check(L.load().op_tracker_set_option(self._h, L.OP_TRACK_OPT_SUMS,
-                                               {"fp64": L.OP_TRACK_SUMS_FP64, "reference_f32": L.OP_TRACK_SUMS_REFERENCE_F32}[sums]))
+                                               {"fp64": L.OP_TRACK_SUMS_FP64, "reference_f32": L.OP_TRACK_SUMS_REFERENCE_F32,
+                                                "reference_f32_host": L.OP_TRACK_SUMS_REFERENCE_F32_HOST}[sums]))
 
     def SetMultiScale(self, layer_count):
         """Odometry.h:100-104: resize(layer_count, 4) keeps existing entries, pads with 4."""

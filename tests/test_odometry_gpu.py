@@ -491,3 +491,34 @@ def test_dense_slam_pose_chain_with_reference_order_sums(oracle):
             ref_poses.append(DS._mat4_mul_f32(ref_poses[-1], oracle.mat4_inverse(r["T"])))
     err = max(rel_err(slam.global_poses[k], ref_poses[k]) for k in range(n))
     assert err <= 1e-5, err
+
+
+def test_device_sequential_sums_equal_the_host_loop_bit_for_bit():
+    """OP_TRACK_SUMS_REFERENCE_F32 sums on the device (k_seq_sums: one wave owns the 36 + 6 float32 accumulators and walks the compacted rows in
+    raster order); OP_TRACK_SUMS_REFERENCE_F32_HOST brings all rows to the host and runs the reference's loop there.  Same operands in the same
+    order: every per-iteration pose is bit-identical, for the hybrid, photometric and geometric terms (2 / 1 / 1 rows per pixel), on levels whose
+    row counts are not multiples of the tile size, and end to end from raw frames (NormalizeIntensity's two sequential means included)."""
+    from onepiece_amd import synthetic as S
+    for (i, j, scale, term) in ((100, 102, 1, 0), (300, 301, 2, 1), (640, 643, 2, 2), (10, 11, 4, 0)):
+        levels, _ = track_levels(i, j, holes=True, scale=scale)
+        out = {}
+        for sums in ("reference_f32", "reference_f32_host"):
+            odo = O.Odometry(I.PinholeCamera("OPEN3D_DATASET"))
+            odo.SetSums(sums)
+            odo.SetMultiScale(3); odo.iter_count_per_level = [4, 8, 16]
+            cam = I.PinholeCamera("OPEN3D_DATASET")
+            cam.width, cam.height = levels[0]["width"], levels[0]["height"]
+            odo.SetCamera(cam)
+            out[sums] = odo.MultiScaleComputing(levels, None, term, want_log=True)
+        a, b = out["reference_f32"], out["reference_f32_host"]
+        assert a.iterations == b.iterations and np.array_equal(a.per_iter_count, b.per_iter_count), (i, j, term)
+        assert np.array_equal(np.asarray(a.per_iter_T).view(np.uint32), np.asarray(b.per_iter_T).view(np.uint32)), (i, j, term)
+        assert np.array_equal(np.asarray(a.T).view(np.uint32), np.asarray(b.T).view(np.uint32))
+    d0, c0, _ = S.room_frame(600); d1, c1, _ = S.room_frame(601)
+    res = {}
+    for sums in ("reference_f32", "reference_f32_host"):
+        odo = O.Odometry(I.PinholeCamera("OPEN3D_DATASET"))
+        odo.SetSums(sums)
+        res[sums] = odo.DenseTracking(c1, c0, d1, d0, None, 0)
+    assert np.array_equal(np.asarray(res["reference_f32"].T).view(np.uint32), np.asarray(res["reference_f32_host"].T).view(np.uint32))
+    assert res["reference_f32"].iterations == res["reference_f32_host"].iterations

@@ -139,10 +139,25 @@ def counters_from_summaries(directory, prefix, kernel="k_integrate"):
     return out
 
 
+def mixed_check(ubench_txt):
+    """the MIXED line of tools/valu_ubench.bin: one loop with k_integrate's instruction-class ratio at 8 waves per SIMD, measured against the additive
+    model's and the VALU-only prediction from the single-class rows of the same run -> {additive_over_measured, valu_only_over_measured, ...} or None"""
+    for line in open(ubench_txt):
+        m = re.search(r"MIXED kernel .*measured ([\d.]+) shader cycles.*additive model ([\d.]+) \(VALU ([\d.]+) \+ SALU/SMEM ([\d.]+) \+ branch ([\d.]+)\) = ([\d.]+) x measured; VALU-only ([\d.]+) = ([\d.]+) x measured", line)
+        if m:
+            g = [float(x) for x in m.groups()]
+            return {"measured_cycles_per_iteration": g[0], "additive_model_cycles": g[1], "valu_cycles": g[2], "salu_smem_cycles": g[3], "branch_cycles": g[4],
+                    "additive_over_measured": g[5], "valu_only_over_measured": g[7],
+                    "additive_model_holds": abs(g[5] - 1.0) <= 0.10,
+                    "note": "96 VALU : 24 SALU : 6 branch : 3 SMEM per iteration at 8 waves per SIMD (tools/valu_ubench.hip OP 40); the additive model is used for "
+                            "roofline.frac only when it predicts this kernel's time within 10 %; otherwise frac is the VALU-only share"}
+    return None
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "calibrate":
         out = {"unit": "shader cycles (s_memtime ticks) per wave64 instruction and SIMD at 8 waves per SIMD, from " + os.path.basename(sys.argv[2]),
-               "costs": calibrate(sys.argv[2]), "valu_mix_k_integrate_plain": static_valu_mix()}
+               "costs": calibrate(sys.argv[2]), "valu_mix_k_integrate_plain": static_valu_mix(), "mixed_check": mixed_check(sys.argv[2])}
         json.dump(out, open(sys.argv[3], "w"), indent=1)
         print(json.dumps(out, indent=1))
     elif sys.argv[1] == "model_pmc":

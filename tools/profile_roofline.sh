@@ -6,7 +6,7 @@
 #   batch1.*  / batch32.*          tools/prof_driver.bin with ONE frame per k_integrate launch / with full batches:
 #                                  --kernel-trace --stats durations, HBM counters, SQ instruction and cycle counters
 # Every --pmc group is its own pass (never combined with other trace domains).
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -59,6 +59,25 @@ __global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* c
         if (OP == 33) { REP16(asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(x0) : "s20"); asm volatile("v_readlane_b32 s21, %0, 3" :: "v"(x1) : "s21"); asm volatile("v_readlane_b32 s22, %0, 3" :: "v"(x2) : "s22"); asm volatile("v_readlane_b32 s23, %0, 3" :: "v"(x3) : "s23");) }
         if (OP == 34) { REP16(asm volatile("ds_read_b32 %0, %1" : "=v"(x4) : "v"(lds_off)); asm volatile("ds_read_b32 %0, %1" : "=v"(x5) : "v"(lds_off)); asm volatile("ds_read_b32 %0, %1" : "=v"(x6) : "v"(lds_off)); asm volatile("ds_read_b32 %0, %1" : "=v"(x7) : "v"(lds_off));) asm volatile("s_waitcnt lgkmcnt(0)"); }
         if (OP == 35) { REP16(asm volatile("s_load_dword s20, %0, 0x0" :: "s"(cyc) : "s20"); asm volatile("s_load_dword s21, %0, 0x0" :: "s"(cyc) : "s21"); asm volatile("s_load_dword s22, %0, 0x0" :: "s"(cyc) : "s22"); asm volatile("s_load_dword s23, %0, 0x0" :: "s"(cyc) : "s23");) asm volatile("s_waitcnt lgkmcnt(0)"); }
+        if (OP == 40) { // k_integrate's instruction-class ratio per voxel-frame wave (~95 VALU : 17 SALU : 6 branches : 3 SMEM), interleaved the way
+                        // the kernel's frame loop is: six groups of 16 vector instructions, each followed by scalar bookkeeping and a not-taken branch
+#define MIX_VALU16 \
+    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x1) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x2) : "v"(b)); \
+    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x3) : "v"(b)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x4) : "v"(b)); asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x5), "v"(b) : "vcc"); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x6) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x7) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(b)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x1) : "v"(b)); asm volatile("v_and_b32 %0, %0, %1" : "+v"(x2) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x3) : "v"(b)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x4) : "v"(b)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x5) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x6) : "v"(b)); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x7) : "v"(b));
+#define MIX_SALU3 asm volatile("s_add_u32 s22, s22, 1" ::: "s22", "scc"); asm volatile("s_and_b64 s[24:25], s[24:25], exec" ::: "s24", "s25", "scc"); asm volatile("s_add_u32 s23, s23, 1" ::: "s23", "scc");
+#define MIX_BRANCH asm volatile("s_cmp_eq_u32 s26, s26" ::: "scc"); asm volatile("s_cbranch_scc0 0" :::);
+            MIX_VALU16 MIX_SALU3 MIX_BRANCH
+            MIX_VALU16 MIX_SALU3 MIX_BRANCH asm volatile("s_load_dword s27, %0, 0x0" :: "s"(cyc) : "s27");
+            MIX_VALU16 MIX_SALU3 MIX_BRANCH
+            MIX_VALU16 MIX_SALU3 MIX_BRANCH asm volatile("s_load_dword s28, %0, 0x0" :: "s"(cyc) : "s28");
+            MIX_VALU16 MIX_SALU3 MIX_BRANCH
+            MIX_VALU16 MIX_SALU3 MIX_BRANCH asm volatile("s_load_dword s29, %0, 0x0" :: "s"(cyc) : "s29");
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        }
         if (OP == 10) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p3) : "v"(pb));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -77,7 +96,7 @@ __global__ void k_clock(unsigned long long* out) {
 }
 
 template <int OP>
-void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, int cus, int iters) {
+double run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, int cus, int iters) {
     const int wgs = cus * waves_per_simd; // 256 threads = 4 waves = one wave per SIMD of a CU (per resident workgroup)
     static hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!e0) { hipEventCreate(&e0); hipEventCreate(&e1); }
@@ -91,9 +110,11 @@ void run(const char* name, int waves_per_simd, float* d_out, unsigned long long*
     hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost);
     double s = 0;
     for (auto v : c) s += (double)v;
+    if (OP == 40) return s / c.size() / iters / waves_per_simd; // shader cycles per loop iteration and SIMD-issue slot
     const double per = s / c.size() / (64.0 * iters); // iters iterations x 64 instructions per wave
     std::printf("%-18s OP %2d waves/SIMD %d iters %d: %.2f s_memtime ticks per wave-instruction -> %.2f per SIMD-issue slot; kernel %.1f us = %.3f ns per instruction and SIMD (%.0f ticks per us while it ran)\n", name, OP, waves_per_simd, iters, per, per / waves_per_simd,
                 ms * 1e3, ms * 1e6 / (64.0 * iters * waves_per_simd), (s / c.size()) / (ms * 1e3));
+    return per / waves_per_simd;
 }
 
 int main(int argc, char** argv) {
@@ -154,6 +175,24 @@ int main(int argc, char** argv) {
         run<33>("v_readlane_b32", w, d_out, d_cyc, cus, iters);
         run<34>("ds_read_b32", w, d_out, d_cyc, cus, iters);
         run<35>("s_load_dword", w, d_out, d_cyc, cus, iters);
+    }
+    {   // Is the ADDITIVE issue model (tools/issue_model.py: every instruction class charged its own back-to-back issue cost, all into ONE budget per
+        // SIMD) right for a kernel that mixes the classes?  One loop with k_integrate's class ratio -- 96 VALU : 18 SALU : 6 + 6 compare-and-branch :
+        // 3 SMEM per iteration, 8 waves per SIMD -- is timed and compared with what the model predicts from the single-class rows measured above in
+        // this very run (same clocks), and with the VALU-only prediction (scalar instructions of other waves co-issue with vector ones).
+        const int w = 8;
+        const double c_mul = run<0>("v_mul_f32", w, d_out, d_cyc, cus, iters), c_fma = run<1>("v_fma_f32", w, d_out, d_cyc, cus, iters),
+                     c_add = run<16>("v_add_f32", w, d_out, d_cyc, cus, iters), c_cmp = run<8>("v_cmp_lt_f32", w, d_out, d_cyc, cus, iters),
+                     c_cnd = run<11>("v_cndmask e64 sgpr", w, d_out, d_cyc, cus, iters), c_and = run<15>("v_and_b32", w, d_out, d_cyc, cus, iters),
+                     c_sadd = run<21>("s_add_u32", w, d_out, d_cyc, cus, iters), c_sand = run<22>("s_and/or_b64", w, d_out, d_cyc, cus, iters),
+                     c_br = run<32>("s_cbranch not taken", w, d_out, d_cyc, cus, iters);
+        const double measured = run<40>("mixed", w, d_out, d_cyc, cus, iters);
+        // per iteration: 6 x (5 mul, 4 fma, 3 add, 1 cmp, 2 cndmask, 1 and) vector; 6 x (2 s_add, 1 s_and) + 6 s_cmp scalar; 6 branches; 3 s_load (priced as a scalar slot, like the model)
+        const double valu = 6 * (5 * c_mul + 4 * c_fma + 3 * c_add + 1 * c_cmp + 2 * c_cnd + 1 * c_and);
+        const double salu = 6 * (2 * c_sadd + 1 * c_sand) + 6 * c_sadd + 3 * c_sadd, branch = 6 * c_br;
+        std::printf("MIXED kernel (96 VALU : 24 SALU : 6 branch : 3 SMEM per iteration, %d waves/SIMD): measured %.1f shader cycles per iteration and SIMD-issue slot; "
+                    "additive model %.1f (VALU %.1f + SALU/SMEM %.1f + branch %.1f) = %.3f x measured; VALU-only %.1f = %.3f x measured\n",
+                    w, measured, valu + salu + branch, valu, salu, branch, (valu + salu + branch) / measured, valu, valu / measured);
     }
     return 0;
 }
