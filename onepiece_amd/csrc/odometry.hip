@@ -804,6 +804,7 @@ struct op_tracker {
     float* rows_host = nullptr;      // pinned
     int* pair_host = nullptr;        // pinned
     size_t rows_cap = 0;             // pixels
+    size_t rows_host_cap = 0;        // pixels (rows_host / pair_host)
     float* seq_out = nullptr;        // device: the 42 (+ count) results of k_seq_sums
     float* seq_host = nullptr;       // pinned copy
     unsigned* seq_total = nullptr;   // device: number of accepted pixels (k_emit_scan)
@@ -981,15 +982,17 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
         const IterGeom g = iter_geom(t, np);
         if (strict && np > t->rows_cap) {
             if (t->rows_dev) OP_HIP(hipFree(t->rows_dev));
+            t->rows_dev = nullptr; t->rows_cap = 0;
+            OP_HIP(hipMalloc(&t->rows_dev, np * 14 * sizeof(float)));
+            t->rows_cap = np;
+        }
+        if (strict && !on_device && np > t->rows_host_cap) { // the host-sum variant's pinned copies (not needed when k_seq_sums does the sums)
             if (t->rows_host) OP_HIP(hipHostFree(t->rows_host));
             if (t->pair_host) OP_HIP(hipHostFree(t->pair_host));
-            t->rows_dev = t->rows_host = nullptr; t->pair_host = nullptr; t->rows_cap = 0;
-            OP_HIP(hipMalloc(&t->rows_dev, np * 14 * sizeof(float)));
-            if (!on_device) {
-                OP_HIP(hipHostMalloc(&t->rows_host, np * 14 * sizeof(float), hipHostMallocDefault));
-                OP_HIP(hipHostMalloc(&t->pair_host, np * sizeof(int), hipHostMallocDefault));
-            }
-            t->rows_cap = np;
+            t->rows_host = nullptr; t->pair_host = nullptr; t->rows_host_cap = 0;
+            OP_HIP(hipHostMalloc(&t->rows_host, np * 14 * sizeof(float), hipHostMallocDefault));
+            OP_HIP(hipHostMalloc(&t->pair_host, np * sizeof(int), hipHostMallocDefault));
+            t->rows_host_cap = np;
         }
         for (int j = 0; j < iters_per_level[l]; ++j, ++it) {
             hipLaunchKernelGGL(k_track_assoc, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, t->pair_p, t->code);

@@ -105,6 +105,15 @@ constexpr int kAccSlots = 16;        // see State::acc
 #define KC_COL_GRID (256 * KC_COL_MIN_WAVES * 4 / (8 / KC_ZT)) // resident workgroups: 256 CUs x 4 SIMDs x waves per SIMD / waves per workgroup
 #endif
 constexpr int kColGrid = KC_COL_GRID;
+// the sum-form variant of k_integrate keeps fewer values per voxel alive and may own more voxels per thread (profiles/r04_ab_sumform_zt.txt)
+#ifndef KC_ZT_SUM
+#define KC_ZT_SUM 2
+#endif
+#ifndef KC_SUM_MIN_WAVES
+#define KC_SUM_MIN_WAVES KC_COL_MIN_WAVES
+#endif
+constexpr int kColGridSum = 256 * KC_SUM_MIN_WAVES * 4 / (8 / KC_ZT_SUM);
+static_assert(kColGridSum % 8 == 0, "one drawing workgroup per XCD slab at least");
 static_assert(kColGrid % 8 == 0, "one drawing workgroup per XCD slab at least");
 constexpr int kPartialGrid = 1024; // slots of the counter arrays k_integrate's workgroups add to (workgroup b -> slot b % 1024).  Not more: the host reads
                                    // them with small pageable copies, and a 16 KB device-to-host copy takes the runtime's pinned-staging path (milliseconds)
@@ -916,7 +925,7 @@ __device__ __forceinline__ void voxel_update(float& s, float& w, float& c0, floa
 // frame-by-frame running mean by float rounding only (a few 1e-7 relative; north_star's bar is 1e-4).  Per voxel and frame the ~35 instructions
 // of the exactly rounded update shrink to 7 (two selects, one float add, two byte-pair adds with their masks).
 template <bool FAST, bool PLAIN, int ZT, bool SUMF = false>
-__global__ __launch_bounds__(512 / ZT, KC_COL_MIN_WAVES) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
+__global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAVES)) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                                             int n_frames, unsigned long long* __restrict__ upd_partial,
                                                                             unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial,
                                                                             unsigned plain_from) {
@@ -1966,7 +1975,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (select_only)
         hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, V, v->state);
     else {
-#define OP_KC(FASTPX, PLAINV, SUMFV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, KC_ZT, SUMFV>), dim3(kColGrid), dim3(512 / KC_ZT), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
+#define OP_KC(FASTPX, PLAINV, SUMFV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, (SUMFV ? KC_ZT_SUM : KC_ZT), SUMFV>), dim3(SUMFV ? kColGridSum : kColGrid), dim3(512 / (SUMFV ? KC_ZT_SUM : KC_ZT)), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
                                                  v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial, v->plain_from)
         if (v->update_mode == OP_VOLUME_UPDATE_SUM_FORM) { if (C.fast_px) OP_KC(true, true, true); else OP_KC(false, true, true); }
         else if (C.fast_px) { if (v->plain) OP_KC(true, true, false); else OP_KC(true, false, false); }

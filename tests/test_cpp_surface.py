@@ -419,7 +419,7 @@ def test_cpp_dense_fusion_driver_pipelined_rate_without_any_environment(hip, tmp
         pf = str(tmp_path / ("poses%d.txt" % k))
         best = None
         for rep in range(2):   # the first run of a process also pays the runtime's start-up; the driver is a fresh process each time: best of 2
-            run = subprocess.run([os.path.join(EX, "DenseFusion.bin"), seq, "--voxel", "0.01", "--pipeline", str(k), "--preload", "--poses", pf],
+            run = subprocess.run([os.path.join(EX, "DenseFusion.bin"), seq, "--voxel", "0.01", "--pipeline", str(k), "--preload", "--repeat", "3", "--poses", pf],
                                  capture_output=True, text=True, env=env, timeout=600)
             assert run.returncode == 0, run.stdout + run.stderr
             r = json.loads(run.stdout.strip().splitlines()[-1])

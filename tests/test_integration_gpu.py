@@ -856,6 +856,6 @@ def test_batch64_build_on_the_largest_image_it_admits(tmp_path):
     a, b = res["b32"], res["b64"]
     assert a["library"] == "libonepiece_hip.so" and b["library"] == "libonepiece_hip_b64.so"
     assert a["frames"] == b["frames"] == 70 and a["launches"] == 3 and b["launches"] == 2, (a, b)      # 32 + 32 + 6 | 64 + 6
-    assert a["blocks"] == b["blocks"] > 200 and a["voxels_updated"] == b["voxels_updated"] > 10 ** 7   # 32 cm blocks: a few hundred hold the room
+    assert a["blocks"] == b["blocks"] > 200 and a["voxels_updated"] == b["voxels_updated"] > 10 ** 6   # 32 cm blocks: a few hundred hold the room
     assert a["keys_sha"] == b["keys_sha"] and a["voxels_sha"] == b["voxels_sha"]
     assert a["probe_admitted"] is True and b["probe_admitted"] is False and "pixels" in b["probe_error"]
