@@ -33,7 +33,7 @@ UBENCH_OPS = {0: "v_mul_f32", 1: "v_fma_f32", 2: "v_pk_mul_f32", 10: "v_pk_fma_f
               20: "vop2_mix", 12: "v_bfi_b32", 13: "v_min_f32", 14: "v_max_u32", 15: "v_and_b32", 16: "v_add_f32", 18: "v_add_u32", 19: "v_cmp_u64",
               21: "s_add_u32", 22: "s_and_b64", 23: "v_mul_s_add_mixed", 24: "s_nop", 25: "v_fmac_f32", 26: "v_trunc_f32", 27: "v_cvt_i32_f32",
               28: "v_max_i32", 29: "v_lshlrev_b32", 30: "s_mul_i32", 31: "s_waitcnt_idle", 32: "s_cbranch_not_taken", 33: "v_readlane_b32",
-              34: "ds_read_b32", 35: "s_load_dword"}
+              34: "ds_read_b32", 35: "s_load_dword", 41: "v_add_f32_dependent_chain"}
 
 
 def calibrate(ubench_txt, waves=8):

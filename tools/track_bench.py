@@ -9,8 +9,10 @@ from onepiece_amd import odometry as O, integration as I, _lib as L
 from onepiece_amd import synthetic as S
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+sums = sys.argv[2] if len(sys.argv) > 2 else "fp64"   # fp64 | reference_f32 | reference_f32_host (OP_TRACK_OPT_SUMS)
 lib = L.load()
 odo = O.Odometry(I.PinholeCamera("OPEN3D_DATASET"))
+odo.SetSums(sums)
 for (i, j, term, name) in [(300, 301, 0, "hybrid 300->301"), (100, 102, 0, "hybrid 100->102"), (300, 301, 2, "depth 300->301")]:
     # pyramids built by the library itself from the two raw frames (DenseTracking), then read back
     di, ci, _ = S.room_frame(i)

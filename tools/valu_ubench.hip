@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_bench(float* out, unsigned long long* c
             MIX_VALU16 MIX_SALU3 MIX_BRANCH asm volatile("s_load_dword s29, %0, 0x0" :: "s"(cyc) : "s29");
             asm volatile("s_waitcnt lgkmcnt(0)");
         }
+        if (OP == 41) { REP64(asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(b));) } // ONE dependent chain: the latency a sequential float sum pays per term
         if (OP == 10) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p0) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p1) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2) : "v"(pb)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p3) : "v"(pb));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -176,6 +177,7 @@ int main(int argc, char** argv) {
         run<34>("ds_read_b32", w, d_out, d_cyc, cus, iters);
         run<35>("s_load_dword", w, d_out, d_cyc, cus, iters);
     }
+    run<41>("v_add_f32 dependent", 1, d_out, d_cyc, cus, iters);
     {   // Is the ADDITIVE issue model (tools/issue_model.py: every instruction class charged its own back-to-back issue cost, all into ONE budget per
         // SIMD) right for a kernel that mixes the classes?  One loop with k_integrate's class ratio -- 96 VALU : 18 SALU : 6 + 6 compare-and-branch :
         // 3 SMEM per iteration, 8 waves per SIMD -- is timed and compared with what the model predicts from the single-class rows measured above in
