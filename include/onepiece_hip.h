@@ -146,6 +146,15 @@ int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* Cu
 #define OP_VOLUME_OPT_UPDATE 0
 #define OP_VOLUME_UPDATE_EXACT 0
 #define OP_VOLUME_UPDATE_SUM_FORM 1
+/* OP_VOLUME_OPT_SELECT: which form of the selection step (CubeHandler::PrepareCubes, CubeHandler.cpp:147-196) a batch of >= 4 frames takes.  The
+ * selected set is the same either way (tests/test_integration_gpu.py); a tuning and test knob, not part of the reference's surface.
+ *   OP_VOLUME_SELECT_AUTO (default): the frames record their selections per super-block (4 x 4 x 4 blocks) and one pass claims every block once;
+ *                                    a frame whose candidate range exceeds 2^18 super-blocks claims its blocks directly;
+ *   OP_VOLUME_SELECT_DIRECT: every frame claims directly (the only form of rounds 1-3);
+ *   n >= 1: as AUTO with n super-blocks as the limit (forces the mixed case on small scenes). */
+#define OP_VOLUME_OPT_SELECT 1
+#define OP_VOLUME_SELECT_AUTO 0
+#define OP_VOLUME_SELECT_DIRECT -1
 int op_volume_set_option(op_volume *v, int option, int value);
 /* How far the volume has got with the frames handed to op_volume_integrate / _sequence, WITHOUT waiting: frames accepted so far, and how many
  * of them belong to batches the device has reported complete (frames are queued up to 32 per launch and a launched batch may still be

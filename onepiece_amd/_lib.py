@@ -55,6 +55,7 @@ OP_TRACK_HYBRID, OP_TRACK_PHOTO, OP_TRACK_DEPTH = 0, 1, 2
 OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_FP64, OP_TRACK_SUMS_REFERENCE_F32, OP_TRACK_SUMS_REFERENCE_F32_HOST = 0, 0, 1, 2
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_EXACT, OP_VOLUME_UPDATE_SUM_FORM = 0, 0, 1
+OP_VOLUME_OPT_SELECT, OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT = 1, 0, -1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
 OP_ICP_OPT_FINISH, OP_ICP_OPT_SUMS = 0, 1

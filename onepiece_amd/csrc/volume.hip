@@ -179,6 +179,7 @@ struct State {
                                             // address serialise at ~100 ns each, 300 of them cost KA 35 us
     unsigned kc_next[kKcShares * 16]; // KC dynamic scheduling: next list position of each share of the batch list (one cache line each)
     unsigned n_list[kBands];          // lengths of the batch's block lists (list b = blist + b * max_blocks); a short batch only fills list 0
+    int sel_rng[kMaxBatch][8];        // k_select_vote -> k_select_merge: first super-block (absolute) and extent in super-blocks of a frame's words ([3..5] = 0: none)
 };
 
 struct StateHead { unsigned n_batch, overflow, n_rec, fail_seq, cur_seq, pad[3]; }; // = the first 32 bytes of State
@@ -584,6 +585,133 @@ constexpr int kSBPerWg = KB_SBPERWG;                    // super-blocks a workgr
 constexpr int kSelTiles = 64;                   // a super-block whose pixel box touches more tiles skips the depth test (it is close to the camera)
 static_assert(kSBVol == 64, "one lane per block of a super-block");
 
+// -- the three steps of the selection, shared by k_select and k_select_vote ---------------------------------------------------------
+// Finish ComputeBounding from the frame's accumulators (k_prepare_frames) and turn it into the candidate range (CubeHandler.cpp:147-163): wave 0 of a
+// workgroup calls this, lane 0 leaves {i0, j0, k0, ni, nj, nk} in range[] (shared memory; all 0: no candidates) and, if `publish`, the frame's statistics in State.
+__device__ __forceinline__ void frame_candidate_range(State* st, const CamParams& C, int f, int lane, bool publish, int* range) {
+    unsigned tot = 0, e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    const unsigned poisoned = lane == 0 ? (st->overflow & 3u) : 0u; // issued together with the accumulator loads: one round trip, not two
+    if (lane < kAccSlots) { // lane k < kAccSlots reads set k (one round trip), then a 16-lane fold
+        const unsigned* a = st->acc[f][lane];
+        tot = a[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) e[c] = a[c];
+    }
+#pragma unroll
+    for (int o = kAccSlots / 2; o > 0; o >>= 1) {
+        tot += __shfl_xor(tot, o, 64);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { const unsigned x = __shfl_xor(e[c], o, 64); e[c] = x > e[c] ? x : e[c]; }
+    }
+    if (lane == 0) {
+        float b[6];
+        for (int c = 0; c < 6; ++c) // nothing in the frustum: the reference's lowest() / max() start values (CubeHandler.cpp:129-130)
+            b[c] = tot ? ord_dec(c < 3 ? e[c] : ~e[c]) : (c < 3 ? -FLT_MAX : FLT_MAX);
+        // A batch that ran out of pool / table space poisons the stream: its KC and every later batch do nothing (an empty
+        // candidate range here), so that the host can grow the volume and REPLAY from the failing batch on -- no frame is
+        // ever partially fused (vol_recover).  Read by one thread per workgroup: a per-thread load of this hot line next to
+        // the candidate loop doubled the kernel's time.
+        if (tot == 0 || poisoned) {
+            for (int c = 0; c < 6; ++c) range[c] = 0;
+        } else {
+            for (int c = 0; c < 3; ++c) {
+                // GetCubeID (VoxelCube.h:63-74): floor(p/res) in float -> int, then
+                // floor((pb + 0.0)/8) in double == arithmetic shift by 3.
+                const int hi = ((int)floorf(b[c] / C.res)) >> 3;
+                const int lo = ((int)floorf(b[3 + c] / C.res)) >> 3;
+                range[c] = lo - 1;
+                range[3 + c] = hi - lo + 3;
+            }
+        }
+        if (publish) {
+            for (int c = 0; c < 6; ++c) st->bbox[f][c] = b[c];
+            st->n_inside[f] = tot;
+        }
+    }
+}
+
+// Coarse test of the blocks [bi0..bi1] x [bj0..bj1] x [bk0..bk1] (part of a super-block) against frame M / tiles: false when the exact test below would
+// reject every one of them (see the comment above k_select).  Called by 8 consecutive lanes, one per corner of the box, with the same arguments otherwise.
+__device__ __forceinline__ bool superblock_survives(const CamParams& C, const float* __restrict__ M, const float2* __restrict__ tiles, int tw, int corner,
+                                                    int bi0, int bi1, int bj0, int bj1, int bk0, int bk1, float cube_res, float o_lo, float o_hi) {
+    const float px = (corner & 1) ? (float)bi1 * cube_res + o_hi : (float)bi0 * cube_res + o_lo;
+    const float py = (corner & 2) ? (float)bj1 * cube_res + o_hi : (float)bj0 * cube_res + o_lo;
+    const float pz = (corner & 4) ? (float)bk1 * cube_res + o_hi : (float)bk0 * cube_res + o_lo;
+    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+    const float qy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+    const float qz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+    float zmin = qz, zmax = qz;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o, 64)); zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64)); }
+    if (!(zmin > 0.05f)) return true; // not all 8 extreme centres well in front of the camera: no shortcut
+    const float uf = C.fx * q0 / qz + C.cx, vf = C.fy * qy / qz + C.cy;
+    float umin = uf, umax = uf, vmin = vf, vmax = vf;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        umin = fminf(umin, __shfl_xor(umin, o, 64)); umax = fmaxf(umax, __shfl_xor(umax, o, 64));
+        vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    }
+    const float mu = 2.0f + 1e-3f * fmaxf(fabsf(umin), fabsf(umax)), mv = 2.0f + 1e-3f * fmaxf(fabsf(vmin), fabsf(vmax));
+    const float u_lo = umin - mu, u_hi = umax + mu, v_lo = vmin - mv, v_hi = vmax + mv;
+    const float wmax = (float)(C.width - 1), hmax = (float)(C.height - 1);
+    if (!(u_hi >= 0.0f && u_lo <= wmax && v_hi >= 0.0f && v_lo <= hmax))
+        return !(u_hi < 0.0f || u_lo > wmax || v_hi < 0.0f || v_lo > hmax); // NaN somewhere: no shortcut
+    const int x0 = (int)fmaxf(u_lo, 0.0f), x1 = (int)fminf(u_hi, wmax), y0 = (int)fmaxf(v_lo, 0.0f), y1 = (int)fminf(v_hi, hmax);
+    const int tx0 = x0 / kTile, tx1 = x1 / kTile, ty0 = y0 / kTile, ty1 = y1 / kTile;
+    const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
+    if (nt > kSelTiles) return true;
+    float dmin = __builtin_inff(), dmax = -__builtin_inff();
+    static_assert(kSelTiles == 64, "8 tiles per lane at most");
+    float2 d[8]; // the lane's tiles t = corner, corner + 8, ...: independent loads, one round trip (a loop with one dependent load per trip was most of this function's time)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int t = corner + 8 * k;
+        const int ty = (int)((float)t * (1.0f / (float)ntx) + 1e-4f); // t / ntx for 0 <= t < 64, 1 <= ntx <= 64 (the quotient's fractional part is 0 or >= 1/64)
+        const int tx = t - ty * ntx;
+        d[k] = t < nt ? tiles[(ty0 + ty) * tw + tx0 + tx] : make_float2(__builtin_inff(), -__builtin_inff());
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dmin = fminf(dmin, d[k].x); dmax = fmaxf(dmax, d[k].y); }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { dmin = fminf(dmin, __shfl_xor(dmin, o, 64)); dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); }
+    const float guard = C.trunc + 1e-3f;
+    // (no valid depth in the tiles: dmin = +inf, dmax = -inf, both differences are +inf)
+    return !(dmin - zmax >= guard || zmin - dmax >= guard);
+}
+
+// Integrator::GetSDF (Integrator.cpp:8-35) probes of the 8 corner voxels {0,7,56,63,448,455,504,511} of the block at (bx, by, bz) for the frame
+// with inverse pose rows M and packed image img: all 8 projections first, then all 8 gathers in flight together, then the min.  True when the
+// block is selected (CubeHandler.cpp:176-190: min |sdf| < truncation).  pmax = the largest pixel index among the corners (-1: none on the image).
+template <bool FAST>
+__device__ __forceinline__ bool block_selected(const CamParams& C, const float* __restrict__ M, const uint2* __restrict__ img, float bx, float by, float bz,
+                                               float o_lo, float o_hi, int& pmax) {
+    int pix[8];
+    float zc[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const float px = bx + ((corner & 1) ? o_hi : o_lo);
+        const float py = by + ((corner & 2) ? o_hi : o_lo);
+        const float pz = bz + ((corner & 4) ? o_hi : o_lo);
+        const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+        const float q1c = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+        const float q2c = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+        zc[corner] = q2c;
+        pix[corner] = project_pixel<FAST>(C, q0, q1c, q2c);
+    }
+    float dd[8];
+    pmax = pix[0];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) { dd[corner] = pix[corner] >= 0 ? __uint_as_float(img[(unsigned)pix[corner]].x) : 0.0f; pmax = max(pmax, pix[corner]); }
+    float min_sdf = FLT_MAX;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const float sdf = dd[corner] <= 0 ? 999.0f : dd[corner] - zc[corner]; // off-image or d <= 0 -> 999
+        const float a = fabsf(sdf);
+        if (min_sdf > a) min_sdf = a;
+    }
+    return min_sdf < C.trunc;
+}
+
 #ifndef KB_MINWAVES
 #define KB_MINWAVES 7
 #endif
@@ -620,47 +748,8 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
     const int tw = tiles_w(C.width), th = tiles_h(C.height);
     const float2* tiles = ptile + (size_t)f * tw * th;
 
-    // -- finish ComputeBounding from the frame's accumulators (k_prepare_frames)
-    unsigned tot = 0, e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-    const unsigned poisoned = tid == 0 ? (st->overflow & 3u) : 0u; // issued together with the accumulator loads: one round trip, not two
-    if (wave == 0) { // lane k < kAccSlots reads set k (one round trip), then a 16-lane fold
-        if (lane < kAccSlots) {
-            const unsigned* a = st->acc[f][lane];
-            tot = a[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) e[c] = a[c];
-        }
-#pragma unroll
-        for (int o = kAccSlots / 2; o > 0; o >>= 1) {
-            tot += __shfl_xor(tot, o, 64);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { const unsigned x = __shfl_xor(e[c], o, 64); e[c] = x > e[c] ? x : e[c]; }
-        }
-    }
+    if (wave == 0) frame_candidate_range(st, C, f, lane, wslot == 0, s_range);
     if (tid == 0) {
-        float b[6];
-        for (int c = 0; c < 6; ++c) // nothing in the frustum: the reference's lowest() / max() start values (CubeHandler.cpp:129-130)
-            b[c] = tot ? ord_dec(c < 3 ? e[c] : ~e[c]) : (c < 3 ? -FLT_MAX : FLT_MAX);
-        // A batch that ran out of pool / table space poisons the stream: its KC and every later batch do nothing (an empty
-        // candidate range here), so that the host can grow the volume and REPLAY from the failing batch on -- no frame is
-        // ever partially fused (vol_recover).  Read by one thread per workgroup: a per-thread load of this hot line next to
-        // the candidate loop doubled the kernel's time.
-        if (tot == 0 || poisoned) {
-            for (int c = 0; c < 6; ++c) s_range[c] = 0;
-        } else {
-            for (int c = 0; c < 3; ++c) {
-                // GetCubeID (VoxelCube.h:63-74): floor(p/res) in float -> int, then
-                // floor((pb + 0.0)/8) in double == arithmetic shift by 3.
-                const int hi = ((int)floorf(b[c] / C.res)) >> 3;
-                const int lo = ((int)floorf(b[3 + c] / C.res)) >> 3;
-                s_range[c] = lo - 1;
-                s_range[3 + c] = hi - lo + 3;
-            }
-        }
-        if (wslot == 0) {
-            for (int c = 0; c < 6; ++c) st->bbox[f][c] = b[c];
-            st->n_inside[f] = tot;
-        }
         s_nsurv = 0u; s_nfirst = 0u; s_nrec = 0u;
     }
     if (tid < kBands) s_bcnt[tid] = 0u;
@@ -697,48 +786,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
                 // first and last block of the super-block inside the range, per axis
                 const int bi0 = i0 + si * kSB, bj0 = j0 + sj * kSB, bk0 = k0 + sk * kSB;
                 const int bi1 = min(bi0 + kSB - 1, i0 + ni - 1), bj1 = min(bj0 + kSB - 1, j0 + nj - 1), bk1 = min(bk0 + kSB - 1, k0 + nk - 1);
-                const float px = (corner & 1) ? (float)bi1 * cube_res + o_hi : (float)bi0 * cube_res + o_lo;
-                const float py = (corner & 2) ? (float)bj1 * cube_res + o_hi : (float)bj0 * cube_res + o_lo;
-                const float pz = (corner & 4) ? (float)bk1 * cube_res + o_hi : (float)bk0 * cube_res + o_lo;
-                const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-                const float qy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-                const float qz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                float zmin = qz, zmax = qz;
-#pragma unroll
-                for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o, 64)); zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64)); }
-                survive = true;
-                if (zmin > 0.05f) { // all 8 extreme centres well in front of the camera (else: no shortcut)
-                    const float uf = C.fx * q0 / qz + C.cx, vf = C.fy * qy / qz + C.cy;
-                    float umin = uf, umax = uf, vmin = vf, vmax = vf;
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) {
-                        umin = fminf(umin, __shfl_xor(umin, o, 64)); umax = fmaxf(umax, __shfl_xor(umax, o, 64));
-                        vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-                    }
-                    const float mu = 2.0f + 1e-3f * fmaxf(fabsf(umin), fabsf(umax)), mv = 2.0f + 1e-3f * fmaxf(fabsf(vmin), fabsf(vmax));
-                    const float u_lo = umin - mu, u_hi = umax + mu, v_lo = vmin - mv, v_hi = vmax + mv;
-                    const float wmax = (float)(C.width - 1), hmax = (float)(C.height - 1);
-                    if (!(u_hi >= 0.0f && u_lo <= wmax && v_hi >= 0.0f && v_lo <= hmax)) {
-                        survive = !(u_hi < 0.0f || u_lo > wmax || v_hi < 0.0f || v_lo > hmax); // NaN somewhere: no shortcut
-                    } else {
-                        const int x0 = (int)fmaxf(u_lo, 0.0f), x1 = (int)fminf(u_hi, wmax), y0 = (int)fmaxf(v_lo, 0.0f), y1 = (int)fminf(v_hi, hmax);
-                        const int tx0 = x0 / kTile, tx1 = x1 / kTile, ty0 = y0 / kTile, ty1 = y1 / kTile;
-                        const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
-                        if (nt <= kSelTiles) {
-                            float dmin = __builtin_inff(), dmax = -__builtin_inff();
-                            for (int t = corner; t < nt; t += 8) {
-                                const int ty = t / ntx, tx = t - ty * ntx;
-                                const float2 d = tiles[(ty0 + ty) * tw + tx0 + tx];
-                                dmin = fminf(dmin, d.x); dmax = fmaxf(dmax, d.y);
-                            }
-#pragma unroll
-                            for (int o = 1; o < 8; o <<= 1) { dmin = fminf(dmin, __shfl_xor(dmin, o, 64)); dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); }
-                            const float guard = C.trunc + 1e-3f;
-                            // (no valid depth in the tiles: dmin = +inf, dmax = -inf, both differences are +inf)
-                            if (dmin - zmax >= guard || zmin - dmax >= guard) survive = false;
-                        }
-                    }
-                }
+                survive = superblock_survives(C, M, tiles, tw, corner, bi0, bi1, bj0, bj1, bk0, bk1, cube_res, o_lo, o_hi);
             }
             if (survive && corner == 0) s_surv[atomicAdd(&s_nsurv, 1u)] = chunk * kSBPerWg + (unsigned)(tid >> 3);
         }
@@ -755,33 +803,8 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
             if (ci < ni && cj < nj && ck < nk) {
                 const int bi = i0 + ci, bj = j0 + cj, bk = k0 + ck;
                 const float bx = (float)bi * cube_res, by = (float)bj * cube_res, bz = (float)bk * cube_res;
-                // Integrator::GetSDF (Integrator.cpp:8-35) for the 8 corner voxels {0,7,56,63,448,455,504,511}:
-                // all 8 projections first, then all 8 gathers in flight together, then the min
-                int pix[8];
-                float zc[8];
-#pragma unroll
-                for (int corner = 0; corner < 8; ++corner) {
-                    const float px = bx + ((corner & 1) ? o_hi : o_lo);
-                    const float py = by + ((corner & 2) ? o_hi : o_lo);
-                    const float pz = bz + ((corner & 4) ? o_hi : o_lo);
-                    const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
-                    const float q1c = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
-                    const float q2c = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
-                    zc[corner] = q2c;
-                    pix[corner] = project_pixel<FAST>(C, q0, q1c, q2c);
-                }
-                float dd[8];
-                int pmax = pix[0]; // the lowest on-image corner (largest pixel index): files the block under an image band below
-#pragma unroll
-                for (int corner = 0; corner < 8; ++corner) { dd[corner] = pix[corner] >= 0 ? __uint_as_float(img[(unsigned)pix[corner]].x) : 0.0f; pmax = max(pmax, pix[corner]); }
-                float min_sdf = FLT_MAX;
-#pragma unroll
-                for (int corner = 0; corner < 8; ++corner) {
-                    const float sdf = dd[corner] <= 0 ? 999.0f : dd[corner] - zc[corner]; // off-image or d <= 0 -> 999
-                    const float a = fabsf(sdf);
-                    if (min_sdf > a) min_sdf = a;
-                }
-                if (min_sdf < C.trunc) {
+                int pmax; // the lowest on-image corner (largest pixel index): files the block under an image band below
+                if (block_selected<FAST>(C, M, img, bx, by, bz, o_lo, o_hi, pmax)) {
                     if (!key_in_range(bi, bj, bk)) {
                         atomicOr(&st->overflow, 8u);
                     } else {
@@ -846,6 +869,287 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
         if (tid == 0) { s_nfirst = 0u; s_nrec = 0u; }
         if (tid < kBands) s_bcnt[tid] = 0u;
         // (the next chunk's coarse test does not touch s_nfirst / s_nrec / s_bcnt; its __syncthreads orders the reset before their next use)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KB for a batch of several frames, in two steps.  Consecutive frames select nearly the same blocks -- a block of the bench scene is selected by ~25 of a
+// batch's 32 frames -- and in k_select every one of those selections is a hash probe + a returning atomicOr on the block's batch mask + a list append by
+// whichever frame came first, ~650 k dependent round trips per batch, with the lists in LDS that force four barriers on every chunk of super-blocks.
+// k_select_vote only RECORDS a frame's selections: one 64-bit word per super-block of its range (bit = lane = block; 0 for a super-block the coarse
+// test dropped), plain stores into sbits[f][super-block].  Nothing is shared between the waves of a workgroup any more, so every wave walks chunks of 8
+// super-blocks on its own -- coarse test (8 lanes per super-block), then the exact test of each survivor (one lane per block) -- without a barrier.
+// The super-blocks are aligned to absolute block coordinates (block >> 2), so that the frames of a batch cut space into the SAME super-blocks: the
+// first and last super-block of an axis may be partly outside the frame's range (bits of blocks outside it stay 0; a block is a candidate of frame f
+// iff it lies in f's range, as in k_select).  k_select_merge then ORs the frames' words per super-block and claims every selected block once.
+// A frame whose range has more super-blocks than a row of sbits holds (kVoteCap) claims directly, like k_select; the two mix freely (both OR into bmask).
+// ---------------------------------------------------------------------------------------------
+#ifndef KB_VOTE
+#define KB_VOTE 1            // 0: every batch goes through k_select
+#endif
+#ifndef KB_VOTE_MIN_FRAMES
+#define KB_VOTE_MIN_FRAMES 4
+#endif
+#ifndef KB_VOTE_WGS
+#define KB_VOTE_WGS 1792     // workgroups of a k_select_vote launch (all resident: 7 per CU), shared out among the frames
+#endif
+constexpr unsigned kVoteCap = 1u << 18; // super-blocks per frame in sbits (2 MB per frame; 16.8 M blocks = 1000 m^3 at 5 mm voxels)
+static_assert(kSB == 4, "k_select_vote / k_select_merge: super-block = block >> 2");
+
+#ifdef KB_TRACE // development aid (make EXTRA=-DKB_TRACE, tools/kb_trace.sh): per-wave phase times of the last k_select_vote launch, dumped by op_volume_destroy
+__device__ unsigned long long g_kb_trace[kSelectGrid * kMaxBatch * 4 * 8];
+#define KB_T(K) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tr_[K] += now_ - tr_last_; tr_last_ = now_; } while (0)
+#define KB_N(K, V) do { tr_[K] += (V); } while (0)
+#else
+#define KB_T(K) do { } while (0)
+#define KB_N(K, V) do { } while (0)
+#endif
+template <bool FAST>
+__global__ __launch_bounds__(256, KB_MINWAVES) void k_select_vote(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, const float2* __restrict__ ptile,
+                                                                  State* st, unsigned long long* __restrict__ sbits, unsigned vote_cap) {
+    __shared__ int s_range[6]; // i0, j0, k0, ni, nj, nk
+    __shared__ unsigned s_vn[3], s_vsb[3][32]; // the survivors of three consecutive rounds (one barrier per round)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) s_vn[tid] = 0u;
+    int f, wslot, wstride; // workgroup -> (frame, slot within the frame): whole frames per XCD, as in k_select
+    {
+        const int nf = (int)gridDim.y, id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        const int per_unit = (int)gridDim.x >> 3;
+        const int x = id & 7, j = id >> 3;
+        const int u = x * nf + j / per_unit;
+        f = u >> 3;
+        wslot = (u & 7) + 8 * (j % per_unit);
+        wstride = (int)gridDim.x;
+    }
+    const float* M = B.f[f].m;
+    const uint2* img = pimg + (size_t)f * C.width * C.height;
+    const int tw = tiles_w(C.width), th = tiles_h(C.height);
+    const float2* tiles = ptile + (size_t)f * tw * th;
+#ifdef KB_TRACE
+    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last_ = __builtin_amdgcn_s_memtime();
+#endif
+    if (wave == 0) frame_candidate_range(st, C, f, lane, wslot == 0, s_range);
+    __syncthreads();
+    KB_T(0);
+    const int i0 = s_range[0], j0 = s_range[1], k0 = s_range[2];
+    int ni = s_range[3], nj = s_range[4], nk = s_range[5];
+    unsigned long long ncand = (unsigned long long)((long long)ni * nj * nk);
+    if (ni > 4096 || nj > 4096 || nk > 4096) { // > 160 m at 5 mm: treat as a bad frame, select nothing
+        if (wslot == 0 && tid == 0) atomicOr(&st->overflow, 4u);
+        ncand = 0; ni = nj = nk = 0;
+    }
+    if (wslot == 0 && tid == 0) st->n_cand[f] = ncand;
+    const float cube_res = C.res * 8.0f; // CubeHandler.cpp:164
+    const float half = C.res / 2;        // VoxelCube.h:47
+    const float o_lo = 0.0f * C.res + half, o_hi = 7.0f * C.res + half; // VoxelCentroidOffSet of x = 0 / 7
+    const bmask_t fbit = (bmask_t)1 << f;
+    const int oi = (i0 >> 2) * kSB, oj = (j0 >> 2) * kSB, ok = (k0 >> 2) * kSB; // first block of super-block 0 (<= the first block of the range)
+    const unsigned nsi = ni > 0 ? (unsigned)(i0 + ni - oi + kSB - 1) / kSB : 0u, nsj = nj > 0 ? (unsigned)(j0 + nj - oj + kSB - 1) / kSB : 0u,
+                   nsk = nk > 0 ? (unsigned)(k0 + nk - ok + kSB - 1) / kSB : 0u;
+    const unsigned n_super = nsi * nsj * nsk; // (<= 1026^3 < 2^32)
+    const bool vote = n_super <= vote_cap; // (vote_cap <= kVoteCap, a row of sbits)
+    unsigned long long* bits = sbits + (size_t)f * kVoteCap;
+    if (wslot == 0 && tid == 0) { // for k_select_merge: the super-blocks this frame's words are laid out over (extent 0: it has none)
+        int* r = st->sel_rng[f];
+        r[0] = oi >> 2; r[1] = oj >> 2; r[2] = ok >> 2;
+        r[3] = vote ? (int)nsi : 0; r[4] = vote ? (int)nsj : 0; r[5] = vote ? (int)nsk : 0;
+        r[6] = !vote && n_super != 0u; // this frame claims directly: the merge step must expect batch masks that are already set
+    }
+    // A round = 32 super-blocks: every wave runs the coarse test of 8 of them (8 lanes per super-block, one per corner), the survivors of the four waves
+    // are pooled in LDS and dealt out again for the exact test (one wave per super-block, one lane per block) -- a wave's own 8 super-blocks hold anything
+    // from 0 to 8 survivors.  The pool of round r + 2 is emptied while round r runs, so one barrier per round is enough.
+    // The 32 super-blocks of a round are spread evenly over the range (slot s of round r = super-block s * n_rounds + r), not adjacent: survivors come in
+    // clusters -- a round of 32 neighbours has anything from 0 to 32 of them, and the busiest workgroup decided the kernel's length.
+    const unsigned n_rounds = (n_super + 31u) / 32u;
+    unsigned vc = 0;
+    for (unsigned round = (unsigned)wslot; round < n_rounds; round += (unsigned)wstride, vc = vc == 2u ? 0u : vc + 1u) {
+        {
+            const unsigned sb = (unsigned)(tid >> 3) * n_rounds + round;
+            const int corner = lane & 7;
+            bool survive = false;
+            if (sb < n_super) {
+                const unsigned q1 = sb / nsk, q2 = q1 / nsj;
+                const int sk = (int)(sb - q1 * nsk), sj = (int)(q1 - q2 * nsj), si = (int)q2;
+                // first and last block of the super-block inside the range, per axis
+                const int bi0 = max(oi + si * kSB, i0), bj0 = max(oj + sj * kSB, j0), bk0 = max(ok + sk * kSB, k0);
+                const int bi1 = min(oi + si * kSB + kSB - 1, i0 + ni - 1), bj1 = min(oj + sj * kSB + kSB - 1, j0 + nj - 1), bk1 = min(ok + sk * kSB + kSB - 1, k0 + nk - 1);
+                survive = superblock_survives(C, M, tiles, tw, corner, bi0, bi1, bj0, bj1, bk0, bk1, cube_res, o_lo, o_hi);
+                if (corner == 0) {
+                    if (survive) s_vsb[vc][atomicAdd(&s_vn[vc], 1u)] = sb;
+                    else if (vote) bits[sb] = 0ull; // dropped as a whole: no block of it is selected
+                }
+            }
+        }
+        KB_T(1); KB_N(4, 1);
+        __syncthreads();
+        const unsigned n_todo = s_vn[vc];
+        if (tid == 0) s_vn[vc == 0u ? 2u : vc - 1u] = 0u; // the pool of the round after the next (its last readers have passed the barrier above)
+        KB_T(3);
+        // ---- exact test: one lane per block of a surviving super-block
+        for (unsigned sv = (unsigned)wave; sv < n_todo; sv += 4u) {
+            KB_N(5, 1);
+            const unsigned sb = s_vsb[vc][sv];
+            const unsigned q1 = sb / nsk, q2 = q1 / nsj;
+            const int sk = (int)(sb - q1 * nsk), sj = (int)(q1 - q2 * nsj), si = (int)q2;
+            const int bi = oi + si * kSB + (lane >> 4), bj = oj + sj * kSB + ((lane >> 2) & 3), bk = ok + sk * kSB + (lane & 3);
+            bool selected = false;
+            if (bi >= i0 && bi < i0 + ni && bj >= j0 && bj < j0 + nj && bk >= k0 && bk < k0 + nk) { // a candidate of this frame
+                int pmax;
+                selected = block_selected<FAST>(C, M, img, (float)bi * cube_res, (float)bj * cube_res, (float)bk * cube_res, o_lo, o_hi, pmax);
+            }
+            if (vote) { // the frame's word for this super-block
+                const unsigned long long word = __ballot(selected);
+                if (lane == 0) bits[sb] = word;
+                KB_T(2);
+                continue;
+            }
+            // (a range too large for sbits: claim directly)
+            int slot = -1;
+            if (selected) {
+                if (!key_in_range(bi, bj, bk)) {
+                    atomicOr(&st->overflow, 8u);
+                } else {
+                    bool created;
+                    const int ts = table_claim(V, st, bi, bj, bk, &created);
+                    if (ts >= 0 && atomicOr(&V.bmask[ts], fbit) == (bmask_t)0) slot = ts;
+                }
+            }
+            const unsigned long long got = __ballot(slot >= 0);
+            unsigned base = 0;
+            if (lane == 0 && got) base = atomicAdd(&st->n_list[0], (unsigned)__popcll(got));
+            base = __shfl(base, 0, 64);
+            if (slot >= 0) {
+                const unsigned pos = base + (unsigned)__popcll(got & ((1ULL << lane) - 1ULL));
+                if (pos < V.max_blocks) V.blist[pos] = slot;
+            }
+        }
+    }
+#ifdef KB_TRACE
+    if (lane == 0) for (int k = 0; k < 8; ++k) g_kb_trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + k] = tr_[k];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// KB, second step of a voting batch.  The frames' words are laid out over their own ranges, but on the same absolute super-block grid, so the words of
+// different frames for one super-block can be put side by side: one wave per super-block S, lane e fetches frame e's word for S (0 where S is outside e's
+// range) -- one round trip for the whole batch.  The 32 x 64 bit matrix is transposed with one ballot per selected block (lane = block gets the mask of the
+// frames that selected it), each block is claimed once, its complete mask ORed into its batch mask, and -- unless a frame on the direct path listed it
+// first -- it joins the batch list.  The walk covers the bounding range of the frames' ranges; if the frames lie so far apart that this has more
+// super-blocks than the frames' words together, the words are walked instead (frame by frame) and the wave of the LOWEST frame whose word for S is not 0
+// deals with S.  A workgroup handles kMergeWords consecutive super-blocks and appends their blocks as ONE segment in super-block / lane order: the batch
+// list comes out in runs of spatially adjacent blocks (super-blocks k fastest), which k_integrate rewards -- its workgroups draw consecutive entries, and
+// neighbours gather from the same image lines at the same time.
+// ---------------------------------------------------------------------------------------------
+#ifndef KB_MERGE_WORDS
+#define KB_MERGE_WORDS 8
+#endif
+constexpr int kMergeWords = KB_MERGE_WORDS; // = waves per workgroup
+#ifndef KB_MERGE_GRID
+#define KB_MERGE_GRID 2048
+#endif
+__global__ __launch_bounds__(64 * kMergeWords) void k_select_merge(VolView V, State* st, const unsigned long long* __restrict__ sbits, int nf) {
+    __shared__ int s_r[kMaxBatch][6];          // first super-block (absolute) and extent in super-blocks of every frame's words
+    __shared__ unsigned s_pre[kMaxBatch + 1];  // words before frame f (only for the walk over the words)
+    __shared__ unsigned s_wc[kMergeWords], s_wp[kMergeWords], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this lane's frame (lane < nf; every wave loads the 32 rows itself: no barrier in the usual case), for the gathers below
+    int e0 = 0, e1 = 0, e2 = 0, en0 = 0, en1 = 0, en2 = 0, direct = 0;
+    if (lane < nf) {
+        const int* r = st->sel_rng[lane];
+        e0 = r[0]; e1 = r[1]; e2 = r[2]; en0 = r[3]; en1 = r[4]; en2 = r[5]; direct = r[6];
+    }
+    const bool any_direct = __ballot(direct != 0) != 0ull;
+    unsigned total = (unsigned)en0 * (unsigned)en1 * (unsigned)en2; // this frame's words (<= kVoteCap), then all frames' (<= 64 x 2^18)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    // the bounding range of the frames' words (every wave computes it: six 64-lane reductions)
+    const bool has_words = en0 > 0 && en1 > 0 && en2 > 0;
+    int lo0 = has_words ? e0 : INT_MAX, lo1 = has_words ? e1 : INT_MAX, lo2 = has_words ? e2 : INT_MAX;
+    int hi0 = has_words ? e0 + en0 : INT_MIN, hi1 = has_words ? e1 + en1 : INT_MIN, hi2 = has_words ? e2 + en2 : INT_MIN;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo0 = min(lo0, __shfl_xor(lo0, o, 64)); lo1 = min(lo1, __shfl_xor(lo1, o, 64)); lo2 = min(lo2, __shfl_xor(lo2, o, 64));
+        hi0 = max(hi0, __shfl_xor(hi0, o, 64)); hi1 = max(hi1, __shfl_xor(hi1, o, 64)); hi2 = max(hi2, __shfl_xor(hi2, o, 64));
+    }
+    const unsigned long long n_union = total ? (unsigned long long)(hi0 - lo0) * (unsigned long long)(hi1 - lo1) * (unsigned long long)(hi2 - lo2) : 0ull;
+    const bool by_union = n_union <= (unsigned long long)total; // (the usual case: consecutive frames of one camera)
+    const unsigned n_units = by_union ? (unsigned)n_union : total;
+    const unsigned un1 = (unsigned)(hi1 - lo1), un2 = (unsigned)(hi2 - lo2);
+    if (!by_union) { // the walk over the words needs to know where a frame's words start
+        if (tid < nf) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s_r[tid][c] = st->sel_rng[tid][c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_pre[0] = 0u;
+            for (int f = 0; f < nf; ++f) s_pre[f + 1] = s_pre[f] + (unsigned)s_r[f][3] * (unsigned)s_r[f][4] * (unsigned)s_r[f][5];
+        }
+        __syncthreads();
+    }
+
+    for (unsigned run = blockIdx.x; (unsigned long long)run * kMergeWords < n_units; run += gridDim.x) {
+        const unsigned g = run * kMergeWords + (unsigned)wave;
+        int slot = -1;
+        if (g < n_units) {
+            int S0, S1, S2, f = -1; // the super-block (absolute); per-word walk: the frame whose word this is
+            if (by_union) {
+                const unsigned q1 = g / un2, q2 = q1 / un1;
+                S0 = lo0 + (int)q2; S1 = lo1 + (int)(q1 - q2 * un1); S2 = lo2 + (int)(g - q1 * un2);
+            } else {
+                f = (int)__popcll(__ballot(lane < nf && s_pre[lane + 1] <= g)); // frames whose words end at or before g (kMaxBatch <= 64 lanes)
+                const unsigned sb = g - s_pre[f];
+                const int* r = s_r[f];
+                const unsigned nsj = (unsigned)r[4], nsk = (unsigned)r[5];
+                const unsigned q1 = sb / nsk, q2 = q1 / nsj;
+                S0 = r[0] + (int)q2; S1 = r[1] + (int)(q1 - q2 * nsj); S2 = r[2] + (int)(sb - q1 * nsk);
+            }
+            // lane e: frame e's word for S
+            unsigned long long w = 0ull;
+            const int d0 = S0 - e0, d1 = S1 - e1, d2 = S2 - e2;
+            if ((unsigned)d0 < (unsigned)en0 && (unsigned)d1 < (unsigned)en1 && (unsigned)d2 < (unsigned)en2)
+                w = sbits[(size_t)lane * kVoteCap + (((unsigned)d0 * (unsigned)en1 + (unsigned)d1) * (unsigned)en2 + (unsigned)d2)];
+            const unsigned long long voters = __ballot(w != 0ull);
+            if (voters != 0ull && (by_union || (int)__builtin_ctzll(voters) == f)) {
+                // transpose: which blocks are selected at all, then one ballot per selected block
+                unsigned long long any = w;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o, 64);
+                bmask_t m = (bmask_t)0;
+                for (unsigned long long rem = any; rem != 0ull; rem &= rem - 1ull) {
+                    const int l = (int)__builtin_ctzll(rem);
+                    const unsigned long long col = __ballot((w >> l) & 1ull);
+                    if (lane == l) m = (bmask_t)col;
+                }
+                if (m != (bmask_t)0) {
+                    const int bi = S0 * kSB + (lane >> 4), bj = S1 * kSB + ((lane >> 2) & 3), bk = S2 * kSB + (lane & 3);
+                    if (!key_in_range(bi, bj, bk)) {
+                        atomicOr(&st->overflow, 8u);
+                    } else {
+                        bool created;
+                        const int ts = table_claim(V, st, bi, bj, bk, &created); // table slot; KC translates it
+                        if (ts >= 0) {
+                            // this wave is the only one that sees this block -- unless a frame claims directly, then the batch mask tells who listed it
+                            if (!any_direct) { V.bmask[ts] = m; slot = ts; }
+                            else if (atomicOr(&V.bmask[ts], m) == (bmask_t)0) slot = ts;
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long got = __ballot(slot >= 0);
+        if (lane == 0) s_wc[wave] = (unsigned)__popcll(got);
+        if (__syncthreads_or(got != 0ull) == 0) continue; // nothing selected in these super-blocks
+        if (tid == 0) {
+            unsigned n = 0;
+            for (int w = 0; w < kMergeWords; ++w) { s_wp[w] = n; n += s_wc[w]; }
+            s_base = atomicAdd(&st->n_list[0], n);
+        }
+        __syncthreads();
+        if (slot >= 0) {
+            const unsigned pos = s_base + s_wp[wave] + (unsigned)__popcll(got & ((1ULL << lane) - 1ULL));
+            if (pos < V.max_blocks) V.blist[pos] = slot;
+        }
     }
 }
 
@@ -1616,6 +1920,7 @@ struct op_volume {
     State* state = nullptr;
     float* partial = nullptr;   // kMaxBatch x ka_grid x 8
     uint2* pimg = nullptr;      // kMaxBatch x W*H packed {depth, rgba}
+    unsigned long long* sbits = nullptr; // kMaxBatch x kVoteCap words: a frame's selections per super-block of its range (k_select_vote -> k_select_merge)
     float2* ptile = nullptr;    // kMaxBatch x tiles: {min, max} valid depth of every 16 x 16 pixel tile (KA -> KB)
     size_t pimg_px = 0;
     int pimg_w = 0, pimg_h = 0;
@@ -1661,6 +1966,7 @@ struct op_volume {
     // true while every voxel was written by k_integrate only since create / clear (see k_integrate<., PLAIN>): any other
     // writer (upload, merge, sum-form unpack, resampling result, file) clears it and fusion takes the general update
     bool plain = true;
+    int select_mode = 0;         // OP_VOLUME_OPT_SELECT: OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT, or the largest range (in super-blocks) a frame may vote with
     int update_mode = 0;         // OP_VOLUME_OPT_UPDATE: OP_VOLUME_UPDATE_EXACT (the reference's frame-by-frame running mean, bit for bit) or _SUM_FORM
     unsigned plain_from = 0;     // with !plain: pool slots below this bound may hold foreign data (general update); later blocks are k_integrate's own
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
@@ -1904,6 +2210,7 @@ void frame_params(const op_volume* v, const float pose[16], const float* pose_in
 }
 
 int vol_ensure_frame_buffers(op_volume* v) {
+    if (!v->sbits) OP_HIP(op::cached_malloc((void**)&v->sbits, (size_t)kMaxBatch * kVoteCap * sizeof(unsigned long long)));
     const size_t npx = (size_t)v->cam.width * v->cam.height;
     if (npx <= v->pimg_px && v->cam.width == v->pimg_w && v->cam.height == v->pimg_h) return OP_OK; // (KA's grid and the tile grid depend on both)
     OP_HIP(hipStreamSynchronize(v->stream)); // released buffers go back to a cache and may be handed out at once
@@ -1965,7 +2272,15 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
     if (cube_keys)
         hipLaunchKernelGGL(k_mark_cubes, dim3((n_cubes + 255u) / 256u), dim3(256), 0, v->stream, V, v->state, cube_keys, n_cubes);
-    else if (C.fast_px)
+    else if (KB_VOTE && KC_BANDS == 0 && !record && nf >= KB_VOTE_MIN_FRAMES && v->select_mode != OP_VOLUME_SELECT_DIRECT) { // several frames: they record their selections, one pass claims every block once
+        const unsigned vote_cap = v->select_mode > 0 ? (unsigned)v->select_mode : kVoteCap;
+        const int per_frame = std::max(8, std::min(kSelectGrid, (KB_VOTE_WGS / nf + 7) / 8 * 8)); // a multiple of 8: whole frames per XCD
+        if (C.fast_px)
+            hipLaunchKernelGGL(k_select_vote<true>, dim3(per_frame, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg, (const float2*)v->ptile, v->state, v->sbits, vote_cap);
+        else
+            hipLaunchKernelGGL(k_select_vote<false>, dim3(per_frame, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg, (const float2*)v->ptile, v->state, v->sbits, vote_cap);
+        hipLaunchKernelGGL(k_select_merge, dim3(KB_MERGE_GRID), dim3(64 * kMergeWords), 0, v->stream, V, v->state, (const unsigned long long*)v->sbits, nf);
+    } else if (C.fast_px)
         hipLaunchKernelGGL(k_select<true>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg, (const float2*)v->ptile,
                            v->state, record ? 1 : 0);
     else
@@ -2412,11 +2727,30 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
 
 int op_volume_destroy(op_volume* v) {
     if (!v) return OP_OK;
+#ifdef KB_TRACE
+    if (hipSetDevice(v->device) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+        const int nw = std::max(8, std::min(kSelectGrid, (KB_VOTE_WGS / kMaxBatch + 7) / 8 * 8)) * kMaxBatch * 4; // waves of a full batch's launch
+        std::vector<unsigned long long> t((size_t)nw * 8);
+        if (hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_kb_trace), t.size() * 8) == hipSuccess) {
+            double sum[8] = {0}, mx[8] = {0}, tot_max = 0, tot_sum = 0;
+            std::vector<double> tots;
+            for (int w = 0; w < nw; ++w) {
+                double tot = 0;
+                for (int k = 0; k < 8; ++k) { const double d = (double)t[(size_t)w * 8 + k]; sum[k] += d; mx[k] = std::max(mx[k], d); if (k < 4) tot += d; }
+                tot_max = std::max(tot_max, tot); tot_sum += tot; tots.push_back(tot);
+            }
+            std::sort(tots.begin(), tots.end());
+            const double n = nw;
+            fprintf(stderr, "kb trace (shader cycles, %d waves; mean/max): total %.0f/%.0f (median %.0f, 90%% %.0f, 99%% %.0f) setup %.0f/%.0f coarse %.0f/%.0f exact %.0f/%.0f barrier %.0f/%.0f | rounds %.2f/%.0f exact tests %.2f/%.0f\n",
+                    nw, tot_sum / n, tot_max, tots[tots.size() / 2], tots[tots.size() * 9 / 10], tots[tots.size() * 99 / 100], sum[0] / n, mx[0], sum[1] / n, mx[1], sum[2] / n, mx[2], sum[3] / n, mx[3], sum[4] / n, mx[4], sum[5] / n, mx[5]);
+        }
+    }
+#endif
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
-                    v->partial, v->pimg, v->ptile, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots};
+                    v->partial, v->pimg, v->ptile, v->sbits, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots};
     for (void* p : ptrs)
         if (p) op::cached_free(p);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
@@ -2474,6 +2808,12 @@ int op_volume_set_near_far(op_volume* v, float near_dist, float far_dist) {
 
 int op_volume_set_option(op_volume* v, int option, int value) {
     OP_VOL(v);
+    if (option == OP_VOLUME_OPT_SELECT) { // which form of the selection step batches take (results are identical; a tuning / test knob)
+        if (value != OP_VOLUME_SELECT_AUTO && value != OP_VOLUME_SELECT_DIRECT && (value < 1 || value > (int)kVoteCap))
+            return fail(OP_ERR_INVALID, "op_volume_set_option: OP_VOLUME_OPT_SELECT takes OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT or 1..%u super-blocks per frame", kVoteCap);
+        v->select_mode = value;
+        return OP_OK;
+    }
     if (option != OP_VOLUME_OPT_UPDATE) return fail(OP_ERR_INVALID, "op_volume_set_option: unknown option %d", option);
     if (value != OP_VOLUME_UPDATE_EXACT && value != OP_VOLUME_UPDATE_SUM_FORM) return fail(OP_ERR_INVALID, "op_volume_set_option: bad value %d", value);
     if (value == v->update_mode) return OP_OK;

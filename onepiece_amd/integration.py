@@ -125,6 +125,13 @@ class CubeHandler:
         value = {"exact": L.OP_VOLUME_UPDATE_EXACT, "sum_form": L.OP_VOLUME_UPDATE_SUM_FORM}[mode]
         L.check(self._lib.op_volume_set_option(self._h, L.OP_VOLUME_OPT_UPDATE, value))
 
+    def SetSelectMode(self, mode):
+        """Extension (op_volume_set_option / OP_VOLUME_OPT_SELECT): which form of the selection step batches of >= 4 frames take -- "auto" (default:
+        frames record their selections, one pass claims every block once), "direct" (every frame claims its blocks itself) or an int n >= 1
+        (as "auto", but frames whose range has more than n super-blocks claim directly).  The selected set is the same in every mode."""
+        value = {"auto": L.OP_VOLUME_SELECT_AUTO, "direct": L.OP_VOLUME_SELECT_DIRECT}.get(mode, mode)
+        L.check(self._lib.op_volume_set_option(self._h, L.OP_VOLUME_OPT_SELECT, int(value)))
+
     # -- the hot path
     def ComputeBounding(self, depth, pose):
         """CubeHandler.cpp:116-145 -> (max_pos, min_pos, n_points_inside_frustum)."""

@@ -315,3 +315,13 @@ def test_new_volume_entry_points_refuse_without_a_volume(hip):
     n = C.c_size_t(0)
     st = hip.MergeStats()
     assert lib.op_volume_merge_rccl_stats(None, None, 0, C.byref(n), C.byref(st)) == hip.OP_ERR_INVALID and st.ranks == 0
+
+
+def test_select_option_constants_match_the_header():
+    """OP_VOLUME_OPT_SELECT and its values: _lib.py mirrors include/onepiece_hip.h."""
+    import re
+    from onepiece_amd import _lib as L
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "onepiece_hip.h")).read()
+    for name in ("OP_VOLUME_OPT_SELECT", "OP_VOLUME_SELECT_AUTO", "OP_VOLUME_SELECT_DIRECT"):
+        m = re.search(r"#define\s+%s\s+(-?\d+)" % name, text)
+        assert m and int(m.group(1)) == getattr(L, name), name

@@ -859,3 +859,64 @@ def test_batch64_build_on_the_largest_image_it_admits(tmp_path):
     assert a["blocks"] == b["blocks"] > 200 and a["voxels_updated"] == b["voxels_updated"] > 10 ** 6   # 32 cm blocks: a few hundred hold the room
     assert a["keys_sha"] == b["keys_sha"] and a["voxels_sha"] == b["voxels_sha"]
     assert a["probe_admitted"] is True and b["probe_admitted"] is False and "pixels" in b["probe_error"]
+
+
+def _fuse(oracle_mod, depth, rgb, poses, mode, res=0.01, chunks=None):
+    """The frames through IntegrateSequence with the given selection mode; `chunks`: the sizes of the calls (default: one call)."""
+    _ov, hv = _mk(oracle_mod, res)
+    hv.SetSelectMode(mode)
+    k = 0
+    for n in (chunks or [len(poses)]):
+        hv.IntegrateSequence(depth[k:k + n], rgb[k:k + n], poses[k:k + n])
+        hv.Stats()   # launches what is queued: the next call starts a new batch
+        k += n
+    assert k == len(poses)
+    return hv
+
+
+def test_selection_forms_select_the_same_blocks(oracle):
+    """Round 4: batches of >= 4 frames record their selections per super-block (k_select_vote) and one pass claims every block once
+    (k_select_merge); frames whose range is too large for that claim directly, as every frame did before.  All forms -- and every mix of them
+    inside one batch (a limit of n super-blocks splits the frames of a batch by the size of their range) -- must give the oracle's volume bit for bit:
+    same keys, same voxels, same counters."""
+    import torch
+    dev = torch.device("cuda:0")
+    depth, rgb, poses = S.room_sequence_torch(300, 37, dev)
+    torch.cuda.synchronize()
+    ov, _ = _mk(oracle, 0.01)
+    dn, cn = depth.cpu().numpy(), rgb.cpu().numpy()
+    sel = upd = 0
+    for k in range(37):
+        n, _vis, nu = ov.integrate(dn[k], cn[k], poses[k])
+        sel += n; upd += nu
+    for mode in ("auto", "direct", 1, 1500, 2200, 3000, 6000):
+        hv = _fuse(oracle, depth, rgb, poses, mode)
+        st = hv.Stats()
+        assert st["frames"] == 37 and st["blocks_selected"] == sel and st["voxels_updated"] == upd, (mode, st)
+        _compare(oracle, ov, hv)
+    # short batches: 4..7 frames vote too, 1..3 take the single-frame form
+    hv = _fuse(oracle, depth, rgb, poses, "auto", chunks=[4, 5, 7, 1, 3, 6, 2, 9])
+    assert hv.Stats()["blocks_selected"] == sel
+    _compare(oracle, ov, hv)
+
+
+def test_selection_with_frames_far_apart(oracle):
+    """One batch whose frames look at places 60 m apart: the bounding range of their candidate ranges is mostly empty, so the merge step walks the
+    frames' words instead of the bounding range (and a block is handled by the lowest frame that selected anything in its super-block).  Also: two
+    frames of the batch see nothing at all."""
+    import torch
+    dev = torch.device("cuda:0")
+    depth, rgb, poses = S.room_sequence_torch(40, 12, dev)
+    poses = poses.copy()
+    for k in range(12):
+        poses[k, :3, 3] += np.float32(60.0 * (k % 3)) * np.array([1.0, -0.5, 0.25], np.float32)   # three sites
+    depth[5] = 0.0
+    depth[9] = 0.0
+    torch.cuda.synchronize()
+    ov, _ = _mk(oracle, 0.01)
+    dn, cn = depth.cpu().numpy(), rgb.cpu().numpy()
+    for k in range(12):
+        ov.integrate(dn[k], cn[k], poses[k])
+    for mode in ("auto", "direct", 2000):
+        hv = _fuse(oracle, depth, rgb, poses, mode)
+        _compare(oracle, ov, hv)
