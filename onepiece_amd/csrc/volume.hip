@@ -644,7 +644,9 @@ __device__ __forceinline__ bool superblock_survives(const CamParams& C, const fl
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) { zmin = fminf(zmin, __shfl_xor(zmin, o, 64)); zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64)); }
     if (!(zmin > 0.05f)) return true; // not all 8 extreme centres well in front of the camera: no shortcut
-    const float uf = C.fx * q0 / qz + C.cx, vf = C.fy * qy / qz + C.cy;
+    // (qz > 0.05 on all 8 lanes.  v_rcp_f32 instead of the exact quotient: 1 ulp against margins of 2 px + 0.1 %, and two divisions were a sixth of this function)
+    const float rz = __builtin_amdgcn_rcpf(qz);
+    const float uf = (C.fx * q0) * rz + C.cx, vf = (C.fy * qy) * rz + C.cy;
     float umin = uf, umax = uf, vmin = vf, vmax = vf;
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
@@ -960,7 +962,16 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select_vote(BatchInv B, Ca
     // from 0 to 8 survivors.  The pool of round r + 2 is emptied while round r runs, so one barrier per round is enough.
     // The 32 super-blocks of a round are spread evenly over the range (slot s of round r = super-block s * n_rounds + r), not adjacent: survivors come in
     // clusters -- a round of 32 neighbours has anything from 0 to 32 of them, and the busiest workgroup decided the kernel's length.
+    // (Rounds drawn from a per-frame counter instead of the fixed stride: measured, no gain -- a workgroup has two rounds, the draw for the second is
+    // made before the first one's weight is known.)
     const unsigned n_rounds = (n_super + 31u) / 32u;
+    const float inv_nsk = 1.0f / (float)nsk, inv_nsj = 1.0f / (float)nsj;
+    auto div_small = [](unsigned a, unsigned d, float inv_d) { // floor(a / d) for a < 2^22: the float quotient is off by one at most
+        unsigned q = (unsigned)((float)a * inv_d);
+        const unsigned r = q * d;
+        if (r > a) --q; else if (a - r >= d) ++q;
+        return q;
+    };
     unsigned vc = 0;
     for (unsigned round = (unsigned)wslot; round < n_rounds; round += (unsigned)wstride, vc = vc == 2u ? 0u : vc + 1u) {
         {
@@ -968,7 +979,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select_vote(BatchInv B, Ca
             const int corner = lane & 7;
             bool survive = false;
             if (sb < n_super) {
-                const unsigned q1 = sb / nsk, q2 = q1 / nsj;
+                const unsigned q1 = vote ? div_small(sb, nsk, inv_nsk) : sb / nsk, q2 = vote ? div_small(q1, nsj, inv_nsj) : q1 / nsj;
                 const int sk = (int)(sb - q1 * nsk), sj = (int)(q1 - q2 * nsj), si = (int)q2;
                 // first and last block of the super-block inside the range, per axis
                 const int bi0 = max(oi + si * kSB, i0), bj0 = max(oj + sj * kSB, j0), bk0 = max(ok + sk * kSB, k0);
@@ -989,7 +1000,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select_vote(BatchInv B, Ca
         for (unsigned sv = (unsigned)wave; sv < n_todo; sv += 4u) {
             KB_N(5, 1);
             const unsigned sb = s_vsb[vc][sv];
-            const unsigned q1 = sb / nsk, q2 = q1 / nsj;
+            const unsigned q1 = vote ? div_small(sb, nsk, inv_nsk) : sb / nsk, q2 = vote ? div_small(q1, nsj, inv_nsj) : q1 / nsj;
             const int sk = (int)(sb - q1 * nsk), sj = (int)(q1 - q2 * nsj), si = (int)q2;
             const int bi = oi + si * kSB + (lane >> 4), bj = oj + sj * kSB + ((lane >> 2) & 3), bk = ok + sk * kSB + (lane & 3);
             bool selected = false;

@@ -39,6 +39,14 @@ def build_driver():
     return DRIVER
 
 
+def _short(k):
+    """Kernel name of a trace row -> the short name results are filed under (k_select = the per-frame step, k_select / k_select_vote)."""
+    for name in ("k_integrate", "k_select_merge", "k_select", "k_prepare_frames"):
+        if name in k:
+            return name
+    return None
+
+
 def _pass(counters, frames_file, reps, voxel, timeout, batch=None):
     """One rocprofv3 pass -> {kernel short name: {counter: (dispatches, sum)}} + kernel durations if traced."""
     td = tempfile.mkdtemp(prefix="opc_", dir="/tmp")
@@ -55,7 +63,7 @@ def _pass(counters, frames_file, reps, voxel, timeout, batch=None):
         for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r.get("Kernel_Name", "?")
-                name = "k_integrate" if "k_integrate" in k else "k_select" if "k_select" in k else "k_prepare_frames" if "k_prepare_frames" in k else None
+                name = _short(k)
                 if name is None:
                     continue
                 d = out.setdefault(name, {}).setdefault(r["Counter_Name"], {})
@@ -65,7 +73,7 @@ def _pass(counters, frames_file, reps, voxel, timeout, batch=None):
         for f in glob.glob(os.path.join(td, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r.get("Kernel_Name", "?")
-                name = "k_integrate" if "k_integrate" in k else "k_select" if "k_select" in k else "k_prepare_frames" if "k_prepare_frames" in k else None
+                name = _short(k)
                 if name:
                     durs.setdefault(name, []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
         return out, durs
