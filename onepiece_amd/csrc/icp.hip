@@ -290,6 +290,10 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             // pattern orders like the value, and "nearer, ties to the smaller original index" is an unsigned minimum --
             // the visiting order does not matter and a candidate costs one 64-bit compare and two selects.
             unsigned long long best_key = kNoKey;
+#ifdef ICP_REPEAT // measurement aid (make EXTRA=-DICP_REPEAT=2): the search runs ICP_REPEAT times in ONE launch, the later passes with this launch's L2 content
+            for (int rep_ = 0; rep_ < ICP_REPEAT; ++rep_) {
+            if (rep_ > 0) { tp0 += best_key == 0x0123456789abcdefull ? 1.0f : 0.0f; best_key = kNoKey; ICP_STAMP(7); } // (depends on the pass before; never true)
+#endif
             if (fabsf(tp0) <= FLT_MAX && fabsf(tp1) <= FLT_MAX && fabsf(tp2) <= FLT_MAX) { // NaN / inf queries match nothing
                 // cell of the query, clamped to two cells outside the grid (beyond that nothing can be within a cell of it;
                 // keeps the int conversion and the +-1 neighbourhood arithmetic in range for far-away points)
@@ -383,6 +387,9 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                     }
                 }
             }
+#ifdef ICP_REPEAT
+            }
+#endif
             ICP_STAMP(3);
             best = best_key != kNoKey ? (int)(unsigned)best_key : -1;
             nn[i] = best;
