@@ -146,12 +146,13 @@ int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* Cu
 #define OP_VOLUME_OPT_UPDATE 0
 #define OP_VOLUME_UPDATE_EXACT 0
 #define OP_VOLUME_UPDATE_SUM_FORM 1
-/* OP_VOLUME_OPT_SELECT: which form of the selection step (CubeHandler::PrepareCubes, CubeHandler.cpp:147-196) a batch of >= 4 frames takes.  The
+/* OP_VOLUME_OPT_SELECT: which form of the selection step (CubeHandler::PrepareCubes, CubeHandler.cpp:147-196) a batch takes.  The
  * selected set is the same either way (tests/test_integration_gpu.py); a tuning and test knob, not part of the reference's surface.
- *   OP_VOLUME_SELECT_AUTO (default): the frames record their selections per super-block (4 x 4 x 4 blocks) and one pass claims every block once;
- *                                    a frame whose candidate range exceeds 2^18 super-blocks claims its blocks directly;
+ *   OP_VOLUME_SELECT_AUTO (default): in batches of >= 20 frames the frames record their selections per super-block (4 x 4 x 4 blocks) and one pass
+ *                                    claims every block once (faster from ~16 frames on); a frame whose candidate range exceeds 2^18 super-blocks,
+ *                                    and every frame of a shorter batch, claims its blocks directly;
  *   OP_VOLUME_SELECT_DIRECT: every frame claims directly (the only form of rounds 1-3);
- *   n >= 1: as AUTO with n super-blocks as the limit (forces the mixed case on small scenes). */
+ *   n >= 1: every batch of >= 2 frames takes the recording form, with n super-blocks as the limit (forces every mix of the two on small scenes). */
 #define OP_VOLUME_OPT_SELECT 1
 #define OP_VOLUME_SELECT_AUTO 0
 #define OP_VOLUME_SELECT_DIRECT -1

@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256, KB_MINWAVES) void k_select(BatchInv B, CamPara
 #define KB_VOTE 1            // 0: every batch goes through k_select
 #endif
 #ifndef KB_VOTE_MIN_FRAMES
-#define KB_VOTE_MIN_FRAMES 4
+#define KB_VOTE_MIN_FRAMES 20 // per batch, k_select against k_select_vote + k_select_merge (profiles/r04_ab_kb_select.txt): 24 / 33 us at 4 frames, 33 / 39 at 8, 51 / 51 at 16, 82 / 75 at 32
 #endif
 #ifndef KB_VOTE_WGS
 #define KB_VOTE_WGS 1792     // workgroups of a k_select_vote launch (all resident: 7 per CU), shared out among the frames
@@ -2283,7 +2283,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
     if (cube_keys)
         hipLaunchKernelGGL(k_mark_cubes, dim3((n_cubes + 255u) / 256u), dim3(256), 0, v->stream, V, v->state, cube_keys, n_cubes);
-    else if (KB_VOTE && KC_BANDS == 0 && !record && nf >= KB_VOTE_MIN_FRAMES && v->select_mode != OP_VOLUME_SELECT_DIRECT) { // several frames: they record their selections, one pass claims every block once
+    else if (KB_VOTE && KC_BANDS == 0 && !record && nf >= (v->select_mode > 0 ? 2 : KB_VOTE_MIN_FRAMES) && v->select_mode != OP_VOLUME_SELECT_DIRECT) { // (an explicit limit: every batch of >= 2 frames) // several frames: they record their selections, one pass claims every block once
         const unsigned vote_cap = v->select_mode > 0 ? (unsigned)v->select_mode : kVoteCap;
         const int per_frame = std::max(8, std::min(kSelectGrid, (KB_VOTE_WGS / nf + 7) / 8 * 8)); // a multiple of 8: whole frames per XCD
         if (C.fast_px)

@@ -126,9 +126,9 @@ class CubeHandler:
         L.check(self._lib.op_volume_set_option(self._h, L.OP_VOLUME_OPT_UPDATE, value))
 
     def SetSelectMode(self, mode):
-        """Extension (op_volume_set_option / OP_VOLUME_OPT_SELECT): which form of the selection step batches of >= 4 frames take -- "auto" (default:
-        frames record their selections, one pass claims every block once), "direct" (every frame claims its blocks itself) or an int n >= 1
-        (as "auto", but frames whose range has more than n super-blocks claim directly).  The selected set is the same in every mode."""
+        """Extension (op_volume_set_option / OP_VOLUME_OPT_SELECT): which form of the selection step batches take -- "auto" (default: in batches of
+        >= 20 frames the frames record their selections and one pass claims every block once), "direct" (every frame claims its blocks itself) or an
+        int n >= 1 (every batch of >= 2 frames records, except frames whose range has more than n super-blocks).  The selected set is the same in every mode."""
         value = {"auto": L.OP_VOLUME_SELECT_AUTO, "direct": L.OP_VOLUME_SELECT_DIRECT}.get(mode, mode)
         L.check(self._lib.op_volume_set_option(self._h, L.OP_VOLUME_OPT_SELECT, int(value)))
 

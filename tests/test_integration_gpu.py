@@ -894,10 +894,11 @@ def test_selection_forms_select_the_same_blocks(oracle):
         st = hv.Stats()
         assert st["frames"] == 37 and st["blocks_selected"] == sel and st["voxels_updated"] == upd, (mode, st)
         _compare(oracle, ov, hv)
-    # short batches: 4..7 frames vote too, 1..3 take the single-frame form
-    hv = _fuse(oracle, depth, rgb, poses, "auto", chunks=[4, 5, 7, 1, 3, 6, 2, 9])
-    assert hv.Stats()["blocks_selected"] == sel
-    _compare(oracle, ov, hv)
+    # short batches: with an explicit limit every batch of >= 2 frames records and merges; "auto" sends them through the direct form
+    for mode in (1 << 18, 2200, "auto"):
+        hv = _fuse(oracle, depth, rgb, poses, mode, chunks=[4, 5, 7, 1, 3, 6, 2, 9])
+        assert hv.Stats()["blocks_selected"] == sel
+        _compare(oracle, ov, hv)
 
 
 def test_selection_with_frames_far_apart(oracle):
