@@ -1,5 +1,6 @@
 """Long fusion fuzz (one-off confidence run, not part of the suites): many seeds of tests/test_integration_gpu.py's
-random-frame fuzz, HIP path vs oracle bit for bit.  usage: fuzz_fusion_long.py [seeds=20]"""
+random-frame fuzz, HIP path vs oracle bit for bit, in every form of the selection step (24 frames per seed = one batch that records and merges
+in "auto"; a limit of n super-blocks splits the batch's frames between the recording and the direct form).  usage: fuzz_fusion_long.py [seeds=20]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -15,8 +16,12 @@ for seed in range(n_seeds):
     hcam = I.PinholeCamera(); hcam.fx, hcam.fy, hcam.cx, hcam.cy, hcam.width, hcam.height, hcam.depth_scale = cam
     res = float(rng.choice([0.02, 0.03, 0.04]))
     ov = oracle.Volume(oracle.make_camera(*cam), voxel_res=res)
-    hv = I.CubeHandler(hcam, max_blocks=1 << 19); hv.SetVoxelResolution(res)
-    for k in range(20):
+    modes = ("auto", "direct", int(rng.integers(50, 4000)))
+    hvs = []
+    for m in modes:
+        hv = I.CubeHandler(hcam, max_blocks=1 << 19); hv.SetVoxelResolution(res); hv.SetSelectMode(m)
+        hvs.append(hv)
+    for k in range(24):
         d = rng.uniform(0.05, 6.0, (120, 160)).astype(np.float32)
         d[rng.random((120, 160)) < 0.1] = 0.0
         d[rng.random((120, 160)) < 0.02] = -1.0
@@ -29,10 +34,15 @@ for seed in range(n_seeds):
         c[rng.random((120, 160)) < 0.2] = 0                         # black pixels: zero numerators in the colour update
         x = np.concatenate([rng.uniform(-0.3, 0.3, 3), rng.uniform(-1.5, 1.5, 3)]).astype(np.float32)
         pose = oracle.se3_exp(x)
-        ov.integrate(d, c, pose); hv.IntegrateImage(d, c, pose)
-    ok, ox = ov.export(); hk, hx = hv.GetCubeMap()
-    same = np.array_equal(ok, hk) and np.array_equal(ox.view(np.uint32), hx.view(np.uint32))
+        ov.integrate(d, c, pose)
+        for hv in hvs:
+            hv.IntegrateImage(d, c, pose)
+    ok, ox = ov.export()
+    same = True
+    for hv in hvs:
+        hk, hx = hv.GetCubeMap()
+        same = same and np.array_equal(ok, hk) and np.array_equal(ox.view(np.uint32), hx.view(np.uint32))
     bad += not same
-    print("seed %d res %.2f: %d blocks %s" % (seed, res, len(ok), "bit-equal" if same else "DIFFERENT"), flush=True)
+    print("seed %d res %.2f, selection %s: %d blocks %s" % (seed, res, modes, len(ok), "bit-equal" if same else "DIFFERENT"), flush=True)
 print("%d of %d seeds differ" % (bad, n_seeds))
 sys.exit(1 if bad else 0)
