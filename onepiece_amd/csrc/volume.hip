@@ -1082,10 +1082,10 @@ __global__ __launch_bounds__(64 * kMergeWords) void k_select_merge(VolView V, St
         lo0 = min(lo0, __shfl_xor(lo0, o, 64)); lo1 = min(lo1, __shfl_xor(lo1, o, 64)); lo2 = min(lo2, __shfl_xor(lo2, o, 64));
         hi0 = max(hi0, __shfl_xor(hi0, o, 64)); hi1 = max(hi1, __shfl_xor(hi1, o, 64)); hi2 = max(hi2, __shfl_xor(hi2, o, 64));
     }
-    const unsigned long long n_union = total ? (unsigned long long)(hi0 - lo0) * (unsigned long long)(hi1 - lo1) * (unsigned long long)(hi2 - lo2) : 0ull;
+    const unsigned un0 = (unsigned)hi0 - (unsigned)lo0, un1 = (unsigned)hi1 - (unsigned)lo1, un2 = (unsigned)hi2 - (unsigned)lo2; // (meaningless without words: total == 0)
+    const unsigned long long n_union = total ? (unsigned long long)un0 * (unsigned long long)un1 * (unsigned long long)un2 : 0ull;
     const bool by_union = n_union <= (unsigned long long)total; // (the usual case: consecutive frames of one camera)
     const unsigned n_units = by_union ? (unsigned)n_union : total;
-    const unsigned un1 = (unsigned)(hi1 - lo1), un2 = (unsigned)(hi2 - lo2);
     if (!by_union) { // the walk over the words needs to know where a frame's words start
         if (tid < nf) {
 #pragma unroll
