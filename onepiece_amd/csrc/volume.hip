@@ -1239,6 +1239,14 @@ __device__ __forceinline__ void voxel_update(float& s, float& w, float& c0, floa
 // (TSDFVoxel.h:24-39) applied n times in exact arithmetic.  Same blocks, same pixels, same weights (integers); sdf and colour differ from the
 // frame-by-frame running mean by float rounding only (a few 1e-7 relative; north_star's bar is 1e-4).  Per voxel and frame the ~35 instructions
 // of the exactly rounded update shrink to 7 (two selects, one float add, two byte-pair adds with their masks).
+#ifdef KC_TRACE // development aid (make EXTRA=-DKC_TRACE): where a workgroup of the last k_integrate launch spent its time, per wave; dumped by op_volume_destroy
+__device__ unsigned long long g_kc_trace[4096 * 4 * 8];
+#define KC_T(K) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); kt_[K] += now_ - kt_last_; kt_last_ = now_; } while (0)
+#define KC_N(K, V) do { kt_[K] += (V); } while (0)
+#else
+#define KC_T(K) do { } while (0)
+#define KC_N(K, V) do { } while (0)
+#endif
 template <bool FAST, bool PLAIN, int ZT, bool SUMF = false>
 __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAVES)) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                                             int n_frames, unsigned long long* __restrict__ upd_partial,
@@ -1249,6 +1257,9 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
     __shared__ float s_c255[256];             // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
     __shared__ unsigned s_next[2];
     const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+#ifdef KC_TRACE
+    unsigned long long kt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt_last_ = t_in;
+#endif
     // KB has consumed the frames' bounding accumulators: back to the identity for the next batch (also when poisoned)
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < (unsigned)(kMaxBatch * kAccSlots * 8); k += gridDim.x * blockDim.x) (&st->acc[0][0][0])[k] = 0u;
     if (st->overflow & 3u) return; // pool / table exhausted in this or an earlier batch: nothing is fused, the host replays
@@ -1301,8 +1312,10 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
     for (unsigned j = s_next[0]; j < per_xcd;) {
         if (tid == 0) s_next[slot ^ 1u] = atomicAdd(ctr, 1u);
         const unsigned b = lists ? j : (eighths ? xcd * per_xcd + j : (((j >> KC_CHUNK_LOG2) * (unsigned)kKcShares + xcd) << KC_CHUNK_LOG2) + (j & (kChunk - 1u)));
+        KC_T(0);
         const int tslot = b < n ? list[b] : -1;
         const int idx = tslot >= 0 ? V.tvals[tslot] : -1; // idx < 0: pool overflow (reported through st->overflow)
+        KC_N(6, 1);
         if (idx >= 0) {
             const bmask_t mask = V.bmask[tslot];
             if (zg == 0) { sel += mask_popc(mask); ++nblk; }
@@ -1371,6 +1384,9 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
             };
             kc_v2u recA[ZT], recB[ZT];
             float zcA[ZT], zcB[ZT];
+#ifdef KC_TRACE
+            { float keep_ = px + py + pz[0]; if (!SUMF) keep_ += s[0]; asm volatile("" :: "v"(keep_)); KC_T(1); } // (the block's metadata and voxels have arrived)
+#endif
             auto frames = [&](auto plain_c) {
                 bmask_t m = mask;                                 // wave-uniform
                 if (!m) return;
@@ -1388,6 +1404,7 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
                 }
             };
             if (SUMF || PLAIN || plain_block) frames(std::true_type{}); else frames(std::false_type{});
+            KC_T(2); KC_N(7, mask_popc(mask));
             if (SUMF) {
 #pragma unroll
                 for (int z = 0; z < ZT; ++z)
@@ -1415,7 +1432,9 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
                 if ((changed >> z) & 1u) { vox[z * 64] = s[z]; vox[kVox + z * 64] = w[z]; vox[2 * kVox + z * 64] = c0[z]; vox[3 * kVox + z * 64] = c1[z]; vox[4 * kVox + z * 64] = c2[z]; }
             chg += (unsigned)__popc(changed);
         }
+        KC_T(3);
         __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
+        KC_T(4);
         if (tslot >= 0 && tid == 0) V.bmask[tslot] = (bmask_t)0; // the owner clears it for the next batch
         slot ^= 1u;
         j = s_next[slot];
@@ -1442,6 +1461,10 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
     xcd = key & 0xffu;
     __syncthreads();                                          // s_next[0] is written again at the top
     }
+#ifdef KC_TRACE
+    KC_T(5);
+    if (lane == 0 && blockIdx.x < 4096) for (int k = 0; k < 8; ++k) g_kc_trace[((size_t)blockIdx.x * 4 + zg) * 8 + k] = kt_[k];
+#endif
     // per-workgroup counters into kPartialGrid slots
     upd = wave_sum(upd); chg = wave_sum(chg);
     if (lane == 0) { s_cnt[zg][0] = upd; s_cnt[zg][1] = chg; }
@@ -2738,6 +2761,20 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
 
 int op_volume_destroy(op_volume* v) {
     if (!v) return OP_OK;
+#ifdef KC_TRACE
+    if (hipSetDevice(v->device) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+        const int nw = kColGrid * (8 / KC_ZT);
+        std::vector<unsigned long long> t((size_t)4096 * 4 * 8);
+        if (hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_kc_trace), t.size() * 8) == hipSuccess) {
+            double sum[8] = {0}, mx[8] = {0};
+            for (int w = 0; w < nw; ++w)
+                for (int k = 0; k < 8; ++k) { const double d = (double)t[(size_t)w * 8 + k]; sum[k] += d; mx[k] = std::max(mx[k], d); }
+            const double n = nw;
+            fprintf(stderr, "kc trace (shader cycles per wave of the last launch, %d waves; mean/max): draw+list %.0f/%.0f metadata+voxels %.0f/%.0f frames %.0f/%.0f stores %.0f/%.0f barrier %.0f/%.0f tail %.0f/%.0f | blocks %.1f/%.0f frames applied %.0f/%.0f\n",
+                    nw, sum[0] / n, mx[0], sum[1] / n, mx[1], sum[2] / n, mx[2], sum[3] / n, mx[3], sum[4] / n, mx[4], sum[5] / n, mx[5], sum[6] / n, mx[6], sum[7] / n, mx[7]);
+        }
+    }
+#endif
 #ifdef KB_TRACE
     if (hipSetDevice(v->device) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
         const int nw = std::max(8, std::min(kSelectGrid, (KB_VOTE_WGS / kMaxBatch + 7) / 8 * 8)) * kMaxBatch * 4; // waves of a full batch's launch
