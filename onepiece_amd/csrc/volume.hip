@@ -1981,6 +1981,8 @@ struct op_volume {
         void* h_depth = nullptr; unsigned char* h_rgb = nullptr;
         hipEvent_t copied = nullptr;
         uint64_t busy_seq = 0; // sequence number of the batch staged here, 0 = free
+        int dma_lo = 0, dma_hi = 0; // positions [dma_lo, dma_hi) are staged in pinned memory and not yet on their way to the device
+        size_t dma_dbytes = 0;      // depth bytes per frame of those positions
     };
     static constexpr int kRing = 3;
     RingSlot ring[kRing];
@@ -2028,6 +2030,7 @@ struct op_volume {
 namespace {
 
 int vol_flush(op_volume* v); // launches the frames queued by op_volume_integrate
+int vol_ring_send(op_volume* v, op_volume::RingSlot& r); // the DMA of the staged host frames that have not been sent yet
 
 // Every block with a pool slot below `bound` may hold data k_integrate did not write (see its PLAIN comment).
 void vol_mark_foreign(op_volume* v, unsigned long long bound) {
@@ -2347,6 +2350,7 @@ int vol_flush(op_volume* v) {
     v->pend_n = 0;
     v->ring_cur = -1;
     if (rs >= 0) { // the batch's kernels start when its host images have arrived
+        OP_TRY(vol_ring_send(v, v->ring[rs]));
         OP_HIP(hipEventRecord(v->ring[rs].copied, v->copy_stream));
         OP_HIP(hipStreamWaitEvent(v->stream, v->ring[rs].copied, 0));
     }
@@ -2514,8 +2518,23 @@ int vol_ring_alloc(op_volume* v) {
     return OP_OK;
 }
 
-// Stages one host frame into position `pos` of the batch being assembled: pageable -> pinned on the host (parallel),
-// then an asynchronous DMA on the copy stream.  The caller's buffers are free again when this returns.
+// The DMA of the staged positions that have not been sent: consecutive frames go as ONE span per image kind -- a copy of ~1 MB runs at 33 GB/s over
+// this PCIe link, one of >= 4 MB at 53 GB/s (tests/tools/pcie_probe.py).
+#ifndef OP_RING_DMA_FRAMES
+#define OP_RING_DMA_FRAMES 8
+#endif
+int vol_ring_send(op_volume* v, op_volume::RingSlot& r) {
+    if (r.dma_hi <= r.dma_lo) return OP_OK;
+    const size_t npx = (size_t)v->cam.width * v->cam.height, cbytes = npx * 3, n = (size_t)(r.dma_hi - r.dma_lo);
+    OP_HIP(hipMemcpyAsync((char*)r.d_depth + (size_t)r.dma_lo * r.dma_dbytes, (const char*)r.h_depth + (size_t)r.dma_lo * r.dma_dbytes, n * r.dma_dbytes, hipMemcpyHostToDevice, v->copy_stream));
+    OP_HIP(hipMemcpyAsync(r.d_rgb + (size_t)r.dma_lo * cbytes, r.h_rgb + (size_t)r.dma_lo * cbytes, n * cbytes, hipMemcpyHostToDevice, v->copy_stream));
+    r.dma_lo = r.dma_hi;
+    return OP_OK;
+}
+
+// Stages one host frame into position `pos` of the batch being assembled: pageable -> pinned on the host (parallel); the
+// asynchronous DMA on the copy stream follows when OP_RING_DMA_FRAMES consecutive frames are waiting, or when the batch is launched.
+// The caller's buffers are free again when this returns.  (A batch has one depth format: frames lie dbytes apart.)
 int vol_ring_stage(op_volume* v, const void** depth, int depth_fmt, const unsigned char** rgb, int pos) {
     OP_TRY(vol_ring_alloc(v));
     if (v->ring_cur < 0) { // first host frame of this batch: take the next slot
@@ -2529,18 +2548,20 @@ int vol_ring_stage(op_volume* v, const void** depth, int depth_fmt, const unsign
             OP_TRY(rc);
         }
         v->ring_cur = rs;
+        v->ring[rs].dma_lo = v->ring[rs].dma_hi = 0;
     }
     op_volume::RingSlot& r = v->ring[v->ring_cur];
     const size_t npx = (size_t)v->cam.width * v->cam.height, dbytes = npx * (depth_fmt == OP_DEPTH_U16 ? 2 : 4), cbytes = npx * 3;
-    char* hd = (char*)r.h_depth + (size_t)pos * npx * 4;
-    unsigned char* hc = r.h_rgb + (size_t)pos * npx * 3;
+    if (r.dma_hi > r.dma_lo && (pos != r.dma_hi || dbytes != r.dma_dbytes)) OP_TRY(vol_ring_send(v, r)); // not adjacent to what is waiting (device frames in between)
+    char* hd = (char*)r.h_depth + (size_t)pos * dbytes;
+    unsigned char* hc = r.h_rgb + (size_t)pos * cbytes;
     CopyPool::get().copy2(hd, *depth, dbytes, hc, *rgb, cbytes);
-    char* dd = (char*)r.d_depth + (size_t)pos * npx * 4;
-    unsigned char* dc = r.d_rgb + (size_t)pos * npx * 3;
-    OP_HIP(hipMemcpyAsync(dd, hd, dbytes, hipMemcpyHostToDevice, v->copy_stream));
-    OP_HIP(hipMemcpyAsync(dc, hc, cbytes, hipMemcpyHostToDevice, v->copy_stream));
-    *depth = dd;
-    *rgb = dc;
+    if (r.dma_hi == r.dma_lo) r.dma_lo = pos;
+    r.dma_hi = pos + 1;
+    r.dma_dbytes = dbytes;
+    if (r.dma_hi - r.dma_lo >= OP_RING_DMA_FRAMES) OP_TRY(vol_ring_send(v, r));
+    *depth = (char*)r.d_depth + (size_t)pos * dbytes;
+    *rgb = r.d_rgb + (size_t)pos * cbytes;
     return OP_OK;
 }
 
