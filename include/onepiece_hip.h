@@ -118,7 +118,7 @@ int op_get_sdf(const op_camera *cam, const float point[3], const float pose[16],
  * (valid when |c| >= 1 or c == 0).  Both return INT_MIN for values no int can hold. */
 int op_debug_project_px(float a, float c, int fast);
 /* Test hook (device): the kernels' projection of n operand triples -- u = (fx*X)/Z + 0.5 + cx, v likewise, the two
- * quotients sharing one refined reciprocal (csrc/volume.hip: project_uv) -- next to the same formula with the plain
+ * quotients sharing one refined reciprocal (csrc/volume_core.hpp: project_pixel) -- next to the same formula with the plain
  * IEEE division.  out: n x {u, v, u_plain, v_plain}; INT_MIN stands for "no int can hold it". */
 int op_debug_project_uv(float fx, float fy, float cx, float cy, const float *X, const float *Y, const float *Z,
                         size_t n, int device, int32_t *out);

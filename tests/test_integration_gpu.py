@@ -483,7 +483,7 @@ def test_random_frames_fuzz(oracle):
 
 
 def test_projection_with_shared_reciprocal_equals_plain_division():
-    """The kernels evaluate (fx*X)/Z and (fy*Y)/Z with one refined reciprocal (csrc/volume.hip: project_uv).  On the device,
+    """The kernels evaluate (fx*X)/Z and (fy*Y)/Z with one refined reciprocal (csrc/volume_core.hpp: project_pixel).  On the device,
     over dense random operands, operands a few ulp around every kind of rounding boundary, and specials (0, inf, NaN,
     denormals, |Z| outside the fast window), the resulting pixel equals the reference formula with the plain IEEE division
     whenever either of them is a pixel an image could contain (except for Z = +-inf, where no sdf can be finite)."""

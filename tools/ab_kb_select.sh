@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/ab_kb_select
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/tools/dump_frames.py /tmp/frames.bin $N 0 > /dev/null
-build() { (cd $R/onepiece_amd/csrc && make -B EXTRA="$1" > /tmp/ab_make.log 2>&1) || { echo "build failed: $1"; tail -5 /tmp/ab_make.log; return 1; }
+build() { (cd $R/onepiece_amd/csrc && make -B -j8 EXTRA="$1" > /tmp/ab_make.log 2>&1) || { echo "build failed: $1"; tail -5 /tmp/ab_make.log; return 1; }
           /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -I $R/include $R/tools/prof_driver.cpp -L $R/onepiece_amd -lonepiece_hip -Wl,-rpath,$R/onepiece_amd -o $R/tools/prof_driver.bin; }
 one() { # tag
   local tag=$1

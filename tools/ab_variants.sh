@@ -5,6 +5,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 N=$1; shift
 cd $R/onepiece_amd/csrc
 for V in "$@"; do
-  make -B EXTRA="$V" > /tmp/ab_make.log 2>&1 || { echo "variant [$V]: build failed"; tail -5 /tmp/ab_make.log; continue; }
+  make -B -j8 EXTRA="$V" > /tmp/ab_make.log 2>&1 || { echo "variant [$V]: build failed"; tail -5 /tmp/ab_make.log; continue; }
   echo "variant [$V]"; python $R/tools/quick_bench.py $N 2>&1 | tail -3 | grep -v algorithmic
 done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static opcode histogram of one kernel of onepiece_amd/csrc/*.hip for gfx950 (MI355X).
 
-    python tools/isa_histogram.py volume.hip k_integrateILb1 [-D...] [--frames 16]
+    python tools/isa_histogram.py integrate.hip k_integrateILb1 [-D...] [--frames 16]
 
 Compiles the file to device assembly (hipcc -S --cuda-device-only, the flags of csrc/Makefile), takes the body of the
 first function whose mangled name contains the given substring, and counts instructions per opcode and per issue class

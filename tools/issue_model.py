@@ -88,7 +88,7 @@ def valu_cost_key(op):
     return "v_and_b32"               # mov / and / or / xor / integer add-sub: plain VOP1 / VOP2
 
 
-def static_valu_mix(kernel_substr="k_integrateILb1ELb1", src="volume.hip"):
+def static_valu_mix(kernel_substr="k_integrateILb1ELb1", src="integrate.hip"):
     """-> {cost row: share of the kernel's static VALU instructions} from tools/isa_histogram.py's per-opcode table"""
     import subprocess
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_histogram.py"), src, kernel_substr], capture_output=True, text=True, check=True).stdout
