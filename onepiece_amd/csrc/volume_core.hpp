@@ -401,6 +401,10 @@ struct op_volume {
     int select_mode = 0;         // OP_VOLUME_OPT_SELECT: OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT, or the largest range (in super-blocks) a frame may vote with
     int update_mode = 0;         // OP_VOLUME_OPT_UPDATE: OP_VOLUME_UPDATE_EXACT (the reference's frame-by-frame running mean, bit for bit) or _SUM_FORM
     unsigned plain_from = 0;     // with !plain: pool slots below this bound may hold foreign data (general update); later blocks are k_integrate's own
+    void* rc_list = nullptr;     // raycast.hip: the visible-block list of the view being cast (one entry per pool block at most), its capacity in blocks
+    unsigned rc_cap = 0;
+    unsigned* rc_count = nullptr; // ... and its length
+    unsigned char* rc_hit = nullptr; // one byte per pool slot: the block holds hit points of the view being cast (zero between calls)
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
     size_t unpack_n = 0;
     uint64_t generation = 0, unpack_gen = 0; // bumped by whatever moves or drops table slots (growth, clear) or fuses frames; _chunk checks it

@@ -718,16 +718,25 @@ int orc_volume_read_file(orc_volume *v, const char *path, int legacy_float) {
 /* north_star names one).  This is the CPU restatement of the definition in include/onepiece_hip.h, */
 /* validated against the analytic synthetic scene, not against OnePiece.                            */
 /* ------------------------------------------------------------------------------------------ */
+/* Definition (include/onepiece_hip.h, onepiece_amd/csrc/raycast.hip):                                                 */
+/*   ray of pixel (u, v): origin = pose translation, direction d = R ((u - cx) / fx, (v - cy) / fy, 1);                */
+/*   lattice t_k = near + k * res (t_k <= far), p_k = origin + t_k d;                                                  */
+/*   s_k = trilinear sdf over the 8 voxel centres around p_k (g = p * (1 / res) - 0.5), valid when all 8 have w > 0;   */
+/*   hit = the smallest k >= 1 with s_(k-1) valid and > 0 and s_k valid and <= 0 (and a positive depth):               */
+/*   depth = t_(k-1) + (t_k - t_(k-1)) * s_(k-1) / (s_(k-1) - s_k); 0 = no hit.                                        */
+/* This walks EVERY lattice point of every ray in order (the HIP path marches block-major and takes a minimum).        */
 /* trilinear sdf / colour at world point p; needs all 8 surrounding voxel centres observed (w > 0) */
-static int sample_trilinear(const orc_volume *v, const float p[3], float *sdf, float col[3]) {
+static int sample_trilinear(const orc_volume *v, float inv_res, const float p[3], float *sdf, float col[3]) {
     float g[3], f[3];
     int i0[3];
     for (int c = 0; c < 3; ++c) {
-        g[c] = p[c] / v->res - 0.5f;
+        g[c] = p[c] * inv_res - 0.5f;
         float fl = floorf(g[c]);
         i0[c] = (int)fl;
         f[c] = g[c] - fl;
     }
+    /* (the base voxel is corner 0: if its block is absent the sample is invalid whatever the other corners hold) */
+    if (vol_find(v, i0[0] >> 3, i0[1] >> 3, i0[2] >> 3) < 0) return 0;
     float acc = 0, ac[3] = {0, 0, 0};
     for (int k = 0; k < 8; ++k) {
         int q[3] = {i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + ((k >> 2) & 1)};
@@ -737,7 +746,7 @@ static int sample_trilinear(const orc_volume *v, const float p[3], float *sdf, f
         float wx = (k & 1) ? f[0] : 1.0f - f[0], wy = (k & 2) ? f[1] : 1.0f - f[1], wz = (k & 4) ? f[2] : 1.0f - f[2];
         float w = (wx * wy) * wz;
         acc += w * t[0];
-        for (int c = 0; c < 3; ++c) ac[c] += w * t[2 + c];
+        if (col) for (int c = 0; c < 3; ++c) ac[c] += w * t[2 + c];
     }
     *sdf = acc;
     if (col) { col[0] = ac[0]; col[1] = ac[1]; col[2] = ac[2]; }
@@ -746,47 +755,39 @@ static int sample_trilinear(const orc_volume *v, const float p[3], float *sdf, f
 
 void orc_volume_raycast(const orc_volume *v, const orc_camera *cam, const float pose[16], float *depth_out, float *normals_out,
                         float *colors_out) {
-    const float fine = v->res, coarse = v->res * CUBE;
+    const float inv_res = 1.0f / v->res;
+#pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < cam->height; ++py)
         for (int px = 0; px < cam->width; ++px) {
             const size_t pix = (size_t)py * cam->width + px;
             const float dcx = ((float)px - cam->cx) / cam->fx, dcy = ((float)py - cam->cy) / cam->fy;
             float dir[3], org[3] = {pose[3], pose[7], pose[11]};
             for (int r = 0; r < 3; ++r) dir[r] = (pose[r * 4] * dcx + pose[r * 4 + 1] * dcy) + pose[r * 4 + 2];
-            float t = v->near_d, t_prev = 0, s_prev = 0, hit = 0;
+            float t_prev = 0, s_prev = 0, hit = 0;
             int have_prev = 0;
-            while (t <= v->far_d) {
+            for (int k = 0;; ++k) {
+                const float t = v->near_d + (float)k * v->res;
+                if (!(t <= v->far_d) || k > (1 << 24)) break;
                 float p[3] = {org[0] + t * dir[0], org[1] + t * dir[1], org[2] + t * dir[2]}, sdf;
-                if (sample_trilinear(v, p, &sdf, NULL)) {
-                    if (have_prev && s_prev > 0 && sdf <= 0) { hit = t_prev + (t - t_prev) * (s_prev / (s_prev - sdf)); break; }
-                    have_prev = 1; s_prev = sdf; t_prev = t;
-                    t += fine;
-                } else {
-                    /* unobserved voxel inside an allocated block: one voxel; absent block: jump to its exit face */
-                    have_prev = 0;
-                    float bf[3], step = fine;
-                    for (int c = 0; c < 3; ++c) bf[c] = floorf(p[c] / coarse);
-                    if (vol_find(v, (int)bf[0], (int)bf[1], (int)bf[2]) < 0) {
-                        float t_exit = FLT_MAX;
-                        for (int c = 0; c < 3; ++c) {
-                            if (dir[c] > 0) t_exit = fminf(t_exit, ((bf[c] + 1.0f) * coarse - p[c]) / dir[c]);
-                            else if (dir[c] < 0) t_exit = fminf(t_exit, (bf[c] * coarse - p[c]) / dir[c]);
-                        }
-                        if (t_exit < FLT_MAX) step = fmaxf(fine, t_exit + 0.01f * v->res);
+                if (sample_trilinear(v, inv_res, p, &sdf, NULL)) {
+                    if (have_prev && s_prev > 0 && sdf <= 0) {
+                        const float depth = t_prev + (t - t_prev) * (s_prev / (s_prev - sdf));
+                        if (depth > 0) { hit = depth; break; }
                     }
-                    t += step;
-                }
+                    have_prev = 1; s_prev = sdf; t_prev = t;
+                } else
+                    have_prev = 0;
             }
             depth_out[pix] = hit;
             float n[3] = {0, 0, 0}, c[3] = {0, 0, 0};
             if (hit > 0) {
                 float p[3] = {org[0] + hit * dir[0], org[1] + hit * dir[1], org[2] + hit * dir[2]}, s0, h = 0.5f * v->res;
-                if (!sample_trilinear(v, p, &s0, c)) { c[0] = c[1] = c[2] = 0; }
+                if (!sample_trilinear(v, inv_res, p, &s0, c)) { c[0] = c[1] = c[2] = 0; }
                 int ok = 1;
                 for (int a = 0; a < 3 && ok; ++a) {
                     float pp[3] = {p[0], p[1], p[2]}, pm[3] = {p[0], p[1], p[2]}, sp = 0, sm = 0;
                     pp[a] += h; pm[a] -= h;
-                    ok = sample_trilinear(v, pp, &sp, NULL) && sample_trilinear(v, pm, &sm, NULL);
+                    ok = sample_trilinear(v, inv_res, pp, &sp, NULL) && sample_trilinear(v, inv_res, pm, &sm, NULL);
                     n[a] = sp - sm;
                 }
                 float l2 = sum3(n[0] * n[0], n[1] * n[1], n[2] * n[2]);

@@ -111,6 +111,23 @@ def test_legacy_float_map_format(oracle, tmp_path):
     assert np.allclose(ox[1, 5], [0.25, 3.0, 1.0, 0.5, 0.25]) and np.allclose(ox[1, 77, :2], [-0.5, 1.0])
 
 
+def _raycast_equal(ov, hv, pose, hcam=None, ocam=None):
+    """HIP raycast == the CPU restatement of its definition: the hit masks and the depths BIT FOR BIT (the block-major march takes a
+    minimum over independent pieces of every ray, so its result may not depend on the order blocks are visited in), colours to 1e-5,
+    normals to 1e-3 (a normalised difference of nearly equal numbers)."""
+    hd, hn, hc = hv.Raycast(pose, hcam)
+    od, on, oc = ov.raycast(pose, ocam)
+    assert np.array_equal(hd > 0, od > 0)
+    assert np.array_equal(hd.view(np.uint32), od.view(np.uint32))
+    hit = od > 0
+    if hit.any():
+        assert np.abs(hn - on)[hit].max() <= 1e-3 and np.abs(hc - oc)[hit].max() <= 1e-5
+        nn = np.linalg.norm(hn[hit], axis=1)
+        assert np.all((np.abs(nn - 1) < 1e-4) | (nn == 0))
+    assert not hn[~hit].any() and not hc[~hit].any()
+    return hd, hit
+
+
 def test_raycast_matches_its_cpu_restatement_and_the_analytic_scene(oracle):
     """north_star names a raycast; the reference has none.  The HIP raycaster must agree
     with the CPU restatement of its own definition, and both with the analytic room it was fused from."""
@@ -119,20 +136,75 @@ def test_raycast_matches_its_cpu_restatement_and_the_analytic_scene(oracle):
     cam = small_camera(4)
     pose = S.room_pose(30)
     truth, _c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
-    hd, hn, hc = hv.Raycast(pose)
-    od, on, oc = ov.raycast(pose)
-    assert np.array_equal(hd > 0, od > 0)
-    hit = od > 0
+    hd, hit = _raycast_equal(ov, hv, pose)
     # free space in front of a surface is UNOBSERVED voxels inside allocated blocks (only |sdf| < truncation is ever
     # written): the march must not leap over the positive band there -- nearly every pixel whose analytic depth lies
     # between the near and far planes is hit (what is missing: grazing views of block borders never observed)
     in_range = (truth > 0.5) & (truth < 5.0)
     assert hit[in_range].mean() > 0.97
-    assert np.abs(hd - od)[hit].max() <= 1e-5 and np.abs(hn - on)[hit].max() <= 1e-3 and np.abs(hc - oc)[hit].max() <= 1e-5
     err = np.abs(hd - truth)[hit]
     assert np.median(err) < 0.001 and np.percentile(err, 95) < 0.005          # 2 cm voxels, sub-voxel surface
-    nn = np.linalg.norm(hn[hit], axis=1)
-    assert np.all((np.abs(nn - 1) < 1e-4) | (nn == 0))
+
+
+def test_raycast_other_cameras_views_and_an_empty_volume(oracle):
+    """The edge cases of the block-major march: a camera that is not the volume's (other size and intrinsics, ragged against the
+    16-pixel tiles), views the volume was never fused from -- from outside the room through its walls, with allocated blocks behind and
+    around the camera, far beyond the far plane, a rolled camera -- a 1 x 1 image, and a volume without any block."""
+    ov, hv = _pair(oracle, 0.02, frames=tuple(range(0, 120, 8)))
+    cam = small_camera(4)
+    # (1) another camera: 211 x 97 pixels, different focal lengths and centre
+    hcam = I.PinholeCamera()
+    hcam.fx, hcam.fy, hcam.cx, hcam.cy, hcam.width, hcam.height, hcam.depth_scale = 170.0, 150.0, 101.3, 50.7, 211, 97, 1000.0
+    ocam = oracle.make_camera(170.0, 150.0, 101.3, 50.7, 211, 97, 1000.0)
+    _raycast_equal(ov, hv, S.room_pose(50), hcam, ocam)
+    # (2) views from elsewhere
+    base = S.room_pose(40).astype(np.float32)
+    views = []
+    out = base.copy(); out[:3, 3] -= 3.5 * base[:3, 2]; views.append(out)           # 3.5 m behind the orbit: outside the room, looking through a wall
+    near_wall = base.copy(); near_wall[:3, 3] += 1.7 * base[:3, 2]; views.append(near_wall)  # so close that the surface band straddles the near plane
+    roll = oracle.se3_exp(np.array([0.1, -0.05, 0.08, 0.3, -0.2, 0.9], np.float32)) @ base; views.append(roll.astype(np.float32))
+    away = base.copy(); away[:3, 3] += 40.0; views.append(away)                     # nothing within the far plane
+    n_hits = []
+    for p in views:
+        _hd, hit = _raycast_equal(ov, hv, p)
+        n_hits.append(int(hit.sum()))
+    assert n_hits[2] > 1000 and n_hits[3] == 0
+    # (3) a single pixel
+    one = I.PinholeCamera()
+    one.fx, one.fy, one.cx, one.cy, one.width, one.height, one.depth_scale = cam[0], cam[1], 0.0, 0.0, 1, 1, 1000.0
+    _raycast_equal(ov, hv, base, one, oracle.make_camera(cam[0], cam[1], 0.0, 0.0, 1, 1, 1000.0))
+    # (4) no blocks at all
+    ev = I.CubeHandler(hv.camera, max_blocks=1 << 10)
+    ev.SetVoxelResolution(0.02)
+    d, n, c = ev.Raycast(base)
+    assert not d.any() and not n.any() and not c.any()
+
+
+def test_raycast_of_uploaded_data_with_unobserved_voxels_nan_and_negative_weights(oracle):
+    """The march keeps unobserved voxels as NaN in its LDS tile: stored NaN / inf sdf values, zero and negative weights and a
+    surface that crosses block borders exactly at a block's last voxel layer must give the restatement's answer too."""
+    rng = np.random.default_rng(5)
+    keys = np.array([[x, y, z] for x in range(-2, 2) for y in range(-2, 2) for z in range(8, 12)], np.int32)
+    vox = np.zeros((len(keys), 512, 5), np.float32)
+    res = 0.02
+    ii = np.arange(512)
+    for b, k in enumerate(keys):
+        zc = (k[2] * 8 + (ii >> 6) + 0.5) * res                       # voxel centre depth
+        xc = (k[0] * 8 + (ii & 7) + 0.5) * res
+        vox[b, :, 0] = (1.6 + 0.05 * np.sin(7 * xc)) - zc             # a wavy wall around z = 1.6 m: sdf = surface - z
+        vox[b, :, 1] = (rng.random(512) > 0.03) * rng.integers(1, 4, 512)  # 3 % of the voxels unobserved (w = 0)
+        vox[b, :, 2:] = rng.random((512, 3))
+    vox[3, 17, 0] = np.nan; vox[5, 100, 0] = np.inf; vox[7, 200, 1] = -2.0; vox[9, :, 1] = 0.0
+    cam = small_camera(4)
+    hcam = I.PinholeCamera()
+    hcam.fx, hcam.fy, hcam.cx, hcam.cy, hcam.width, hcam.height, hcam.depth_scale = cam
+    hv = I.CubeHandler(hcam, max_blocks=1 << 12); hv.SetVoxelResolution(res)
+    ov = oracle.Volume(oracle.make_camera(*cam), voxel_res=res)
+    hv.SetCubeMap(keys, vox)
+    assert ov.load(keys, vox) in (0, None)
+    for T in (np.eye(4, dtype=np.float32), oracle.se3_exp(np.array([0.2, -0.1, 0.0, 0.1, 0.3, 0.05], np.float32))):
+        _hd, hit = _raycast_equal(ov, hv, T)
+    assert hit.sum() > 500
 
 
 def test_merge_with_transform_and_add_cube(oracle):
