@@ -156,6 +156,11 @@ int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* Cu
 #define OP_VOLUME_OPT_SELECT 1
 #define OP_VOLUME_SELECT_AUTO 0
 #define OP_VOLUME_SELECT_DIRECT -1
+/* OP_VOLUME_OPT_RAYCAST_PRUNE (default 1): op_volume_raycast remembers, per block it loaded, whether the block holds an observed sdf <= 0 / > 0,
+ * and later views of the UNCHANGED volume use that to drop blocks in which no zero crossing can end before loading them (anything that can
+ * change a voxel invalidates what was remembered).  0: every view loads every visible block, as the first view after a change does.
+ * The images are identical either way (tests/test_volume_ops_gpu.py); a measurement and test knob. */
+#define OP_VOLUME_OPT_RAYCAST_PRUNE 2
 int op_volume_set_option(op_volume *v, int option, int value);
 /* How far the volume has got with the frames handed to op_volume_integrate / _sequence, WITHOUT waiting: frames accepted so far, and how many
  * of them belong to batches the device has reported complete (frames are queued up to 32 per launch and a launched batch may still be
@@ -268,14 +273,26 @@ int op_volume_write_file(op_volume *v, const char *path);
 int op_volume_read_file(op_volume *v, const char *path, int legacy_float_format);
 
 /* TSDF ray casting (north_star "integrate/raycast").  NO reference counterpart: OnePiece has no
- * raycast, so the definition is this library's own and is validated against the
- * analytic synthetic scene.  For every pixel of `cam` (NULL = the volume's camera) at camera-to-world
- * `pose`: march the viewing ray from the near to the far plane, sample the sdf trilinearly over the
- * 8 surrounding voxel centres (all observed), step one voxel while samples are valid and one block
- * otherwise, report the first + -> - zero crossing as z-depth in metres (0 = no hit).  Optional
- * outputs: world-frame normals (sdf gradient) and trilinear colours, W*H*3 floats each. */
+ * raycast (its closest relative is the trilinear gather of VoxelCube::ReadVoxelInterpolate,
+ * Integration/VoxelCube.cpp:6-50), so the definition is this library's own, restated on the CPU in
+ * oracle/onepiece_oracle.c and validated against the analytic synthetic scene.  For every pixel (u, v) of
+ * `cam` (NULL = the volume's camera) at camera-to-world `pose`:
+ *   ray      origin = the pose's translation, direction d = R ((u - cx) / fx, (v - cy) / fy, 1): the parameter t is the z-depth;
+ *   lattice  t_k = near + k * res for k = 0, 1, ... while t_k <= far;  p_k = origin + t_k d;
+ *   sample   s_k = trilinear sdf over the 8 voxel centres around p_k (g = p * (1 / res) - 0.5, base voxel floor(g)),
+ *            valid when all 8 voxels are observed (weight > 0);
+ *   hit      the smallest k >= 1 with s_(k-1) valid and > 0 and s_k valid and <= 0:
+ *            depth = t_(k-1) + (t_k - t_(k-1)) * s_(k-1) / (s_(k-1) - s_k), in metres (0 = no hit).
+ * Optional outputs (W*H*3 floats each, zero where there is no hit): world-frame normals = the normalised central difference
+ * of the trilinear sdf at +-res/2 around the hit point, and the trilinear colour there -- each zero unless all its samples are valid.
+ * The crossing test is local to a lattice pair, so the result does not depend on the order the volume is traversed in: the kernels
+ * march block by block from an LDS tile per block (csrc/raycast.hip) and agree with the CPU restatement bit for bit (depth). */
 int op_volume_raycast(op_volume *v, const op_camera *cam, const float pose[16], float *depth_out,
                       float *normals_out, float *colors_out, int mem);
+/* Measurement hook: what the LAST op_volume_raycast call on this volume did -- blocks whose sample domain met the view frustum, how many
+ * of those earlier views' summaries dropped before loading (OP_VOLUME_OPT_RAYCAST_PRUNE), how many were loaded into LDS and how many of
+ * the loaded ones were marched (the others held no zero crossing). */
+int op_volume_raycast_stats(op_volume *v, uint64_t *visible_blocks, uint64_t *dropped_unloaded, uint64_t *loaded_blocks, uint64_t *marched_blocks);
 
 /* Frame-sharded multi-GPU merge (the distributed form of CubeHandler::Merge; DESIGN.md "Multi-GPU").
  * All pointers are DEVICE pointers on the volume's device.

@@ -56,6 +56,7 @@ OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_FP64, OP_TRACK_SUMS_REFERENCE_F32, OP_TRACK_SUM
 OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_EXACT, OP_VOLUME_UPDATE_SUM_FORM = 0, 0, 1
 OP_VOLUME_OPT_SELECT, OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT = 1, 0, -1
+OP_VOLUME_OPT_RAYCAST_PRUNE = 2
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
 OP_ICP_OPT_FINISH, OP_ICP_OPT_SUMS = 0, 1
@@ -128,6 +129,7 @@ SIGNATURES = {
     "op_volume_write_file": (C.c_int, [_vp, C.c_char_p]),
     "op_volume_read_file": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "op_volume_raycast": (C.c_int, [_vp, C.POINTER(Camera), _fp, _fp, _fp, _fp, C.c_int]),
+    "op_volume_raycast_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "op_volume_keys_device": (C.c_int, [_vp, _vp, C.c_size_t, _szp]),
     "op_volume_pack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "op_volume_unpack_sum": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),

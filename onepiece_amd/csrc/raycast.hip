@@ -39,6 +39,7 @@
 
 namespace {
 
+constexpr unsigned kRcCountWords = 16 + 16 * 64;
 constexpr unsigned kNoHit = 0x7f800000u; // +inf: the depth image while blocks are marched (positive floats order like their bits)
 constexpr int kTileEdge = 11;            // the block with one voxel in front of it and two behind it on every axis: voxels -1 .. 9
 constexpr int kTileVox = kTileEdge * kTileEdge * kTileEdge;
@@ -161,13 +162,39 @@ __global__ __launch_bounds__(256) void k_rc_visible(VolView V, RcView W, RcBlock
 }
 
 // ---- R0b: one lane per (visible block, neighbour): 26 hash lookups per block, all of them in flight at once ------------------------------------
-__global__ __launch_bounds__(256) void k_rc_neighbours(VolView V, RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis) {
+// The 32 lanes of an entry also look at what EARLIER views of the unchanged volume learnt about the 27 blocks (summary: has an observed
+// sdf <= 0 / > 0 among its own voxels; stamp = the volume's content generation; an absent block has neither) and mark the entry (pad bit 1)
+// when the march would only load the tile to find that no crossing can end in the block:
+//   * a crossing ends at an in-block sample <= 0, which needs an observed sdf <= 0 among tile voxels 0 .. 8 = the block and its 7 upper neighbours;
+//   * its first sample is > 0 and lies in the tile when the rays step <= 1 voxel per axis (pad bit 0), which needs an observed sdf > 0 among the 27.
+// The summaries are supersets of what the tile tests see (whole blocks instead of their border layers), so a marked entry is one the march
+// would have dropped anyway: results cannot change, only the work.
+__global__ __launch_bounds__(256) void k_rc_neighbours(VolView V, RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis, const unsigned* __restrict__ summary,
+                                                       unsigned stamp) {
     const unsigned n = *n_vis, total = n * 32u;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    for (unsigned i0 = blockIdx.x * 256u; i0 < total; i0 += gridDim.x * 256u) { // (uniform per wave: ballots below)
+        const unsigned i = i0 + threadIdx.x;
         const unsigned e = i >> 5, j = i & 31u;
-        if (j >= 27u || j == 13u) continue;
-        RcBlock& B = list[e];
-        B.nb[j] = table_find(V, B.kx + (int)(j % 3u) - 1, B.ky + (int)((j / 3u) % 3u) - 1, B.kz + (int)(j / 9u) - 1);
+        bool known = true, neg = false, pos = false; // (lanes 27 .. 31 and lanes beyond the list: neutral)
+        RcBlock* B = nullptr;
+        if (i < total && j < 27u) {
+            B = list + e;
+            const int slot = j == 13u ? B->nb[13] : table_find(V, B->kx + (int)(j % 3u) - 1, B->ky + (int)((j / 3u) % 3u) - 1, B->kz + (int)(j / 9u) - 1);
+            if (j != 13u) B->nb[j] = slot;
+            if (slot >= 0) {
+                const unsigned sm = summary[slot];
+                known = (sm >> 2) == stamp;
+                neg = (sm & 1u) != 0u; pos = (sm & 2u) != 0u;
+            }
+        }
+        const int half = (threadIdx.x & 32) ? 32 : 0;
+        const unsigned upper = (1u << 13) | (1u << 14) | (1u << 16) | (1u << 17) | (1u << 22) | (1u << 23) | (1u << 25) | (1u << 26); // offsets (0|1, 0|1, 0|1)
+        const unsigned m_unknown = (unsigned)(__ballot(!known) >> half), m_neg = (unsigned)(__ballot(known && neg) >> half), m_pos = (unsigned)(__ballot(known && pos) >> half);
+        if (B && j == 13u) {
+            const bool no_end = !(m_unknown & upper) && !(m_neg & upper);
+            const bool no_start = (B->pad & 1) && !m_unknown && !m_pos;
+            if (no_end || no_start) B->pad |= 2;
+        }
     }
 }
 
@@ -213,9 +240,9 @@ __device__ __forceinline__ void rc_tile_map(unsigned short* s_cell, int tid) {
 }
 // Voxels -1 .. 9 of the block's frame on every axis (own 512 + the shell of its 26 neighbours) -> s_sdf: the observed sdf, or NaN; RC_STAGE_GROUP
 // cells per thread in flight at a time.  Returns bit 0: an observed sdf <= 0 among the voxels an IN-BLOCK sample can touch, bit 1: an observed
-// sdf > 0 anywhere in the tile (this thread's cells).
+// sdf > 0 anywhere in the tile, bits 2 / 3: the same two among the block's OWN 512 voxels (this thread's cells).
 __device__ __forceinline__ unsigned rc_tile_load(const VolView& V, const int* __restrict__ s_nb, const unsigned short* __restrict__ s_cell, float* __restrict__ s_sdf, int tid) {
-    bool neg = false, pos = false;
+    bool neg = false, pos = false, own_neg = false, own_pos = false;
 #pragma unroll
     for (int g = 0; g < kStageIter; g += RC_STAGE_GROUP) {
         float sd[RC_STAGE_GROUP], wt[RC_STAGE_GROUP];
@@ -236,12 +263,15 @@ __device__ __forceinline__ unsigned rc_tile_load(const VolView& V, const int* __
         for (int i = 0; i < RC_STAGE_GROUP; ++i)
             if (cl[i] >> 15) {
                 const bool ok = wt[i] > 0;
+                const bool own = (cl[i] & 31u) == 13u;
                 neg |= ok && sd[i] <= 0 && ((cl[i] >> 14) & 1u);
                 pos |= ok && sd[i] > 0;
+                own_neg |= own && ok && sd[i] <= 0;
+                own_pos |= own && ok && sd[i] > 0;
                 s_sdf[tid + kRcWg * (g + i)] = ok ? sd[i] : __builtin_nanf("");
             }
     }
-    return (neg ? 1u : 0u) | (pos ? 2u : 0u);
+    return (neg ? 1u : 0u) | (pos ? 2u : 0u) | (own_neg ? 4u : 0u) | (own_pos ? 8u : 0u);
 }
 // The visible list is in pool order -- runs of spatially adjacent blocks -- and a block's voxels are read by up to 27 workgroups (its own and
 // its neighbours' shells): XCD x (workgroup b runs on XCD b % 8) takes the x-th contiguous eighth of the list, so that those re-reads
@@ -255,7 +285,8 @@ __device__ __forceinline__ RcSpan rc_span(unsigned n) {
 // hit_blocks: one byte per pool slot, set for the block whose sample domain holds the hit point of a crossing recorded here (k_rc_shade works
 // through exactly those blocks and clears the bytes again); nullptr when neither normals nor colours are asked for.
 __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcView W, const RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis,
-                                                                  unsigned* __restrict__ depth_bits, unsigned char* __restrict__ hit_blocks) {
+                                                                  unsigned* __restrict__ depth_bits, unsigned char* __restrict__ hit_blocks, unsigned* __restrict__ summary,
+                                                                  unsigned stamp, unsigned* __restrict__ counters) {
     __shared__ float s_sdf[kTileVox + 5];
     __shared__ int s_ent[36];
     __shared__ unsigned s_flags;
@@ -264,7 +295,9 @@ __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcV
     const float o0 = W.P[3], o1 = W.P[7], o2 = W.P[11];
     rc_tile_map(s_cell, tid);
     const RcSpan span = rc_span(*n_vis);
+    unsigned n_dropped = 0, n_loaded = 0, n_marched = 0; // (uniform over the workgroup; op_volume_raycast_stats)
     for (unsigned e = span.first; e < span.end; e += span.step) {
+        if (list[e].pad & 2) { ++n_dropped; continue; } // k_rc_neighbours could tell from the summaries of earlier views that no crossing ends here (uniform: no LDS touched yet)
         __syncthreads(); // the previous block's readers are done with the tile and the entry
         if (tid < 36) s_ent[tid] = reinterpret_cast<const int*>(list + e)[tid];
         if (tid == 64) s_flags = 0u;
@@ -273,15 +306,18 @@ __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcV
         const int* s_nb = s_ent + 8;
         {
             const unsigned mine = rc_tile_load(V, s_nb, s_cell, s_sdf, tid);
-            const unsigned f = (__ballot(mine & 1u) ? 1u : 0u) | (__ballot(mine & 2u) ? 2u : 0u);
+            const unsigned f = (__ballot(mine & 1u) ? 1u : 0u) | (__ballot(mine & 2u) ? 2u : 0u) | (__ballot(mine & 4u) ? 4u : 0u) | (__ballot(mine & 8u) ? 8u : 0u);
             if ((tid & 63) == 0 && f) atomicOr(&s_flags, f);
         }
         if (tid == 0) RC_COUNT(0, 1);
+        ++n_loaded;
         __syncthreads(); // the tile and the flags are complete
+        if (tid == 0) summary[s_nb[13]] = (stamp << 2) | ((s_flags >> 2) & 3u); // what this view learnt about the block's own voxels, for the next views of the unchanged volume
         // No observed sdf <= 0 in reach of this block's samples: no crossing can END here.  No observed sdf > 0 in the whole tile: no sample BEFORE
         // one of this block's can be positive either, provided it lies in the tile (s_ent[7]: every ray through the box steps <= 1 voxel per axis)
         const unsigned flags = s_flags;
-        if (!(flags & 1u) || (!(flags & 2u) && s_ent[7])) continue;
+        if (!(flags & 1u) || (!(flags & 2u) && (s_ent[7] & 1))) continue;
+        ++n_marched;
 #ifdef RC_STAGE_ONLY // (timing experiment only)
         const int npix = s_sdf[tid] == 12345.0f ? s_ent[5] * s_ent[6] : 0;
 #else
@@ -357,6 +393,12 @@ __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcV
                 prev_in = true; s_prev = acc; t_prev = t;
             }
         }
+    }
+    if (tid == 0) { // one shard of the call's counters per 64th of the workgroups (atomics on one address serialise)
+        unsigned* c = counters + 16u * (blockIdx.x & 63u);
+        if (n_dropped) atomicAdd(c, n_dropped);
+        if (n_loaded) atomicAdd(c + 1, n_loaded);
+        if (n_marched) atomicAdd(c + 2, n_marched);
     }
 }
 
@@ -446,7 +488,7 @@ __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_shade(VolView V, RcV
 }
 
 #ifndef RC_NB_GRID
-#define RC_NB_GRID 1024
+#define RC_NB_GRID 4096
 #endif
 #ifndef RC_MARCH_GRID
 #define RC_MARCH_GRID 16384 // workgroups of k_rc_march, each taking every RC_MARCH_GRID-th visible block (4 x what is resident: evens out blocks of unequal cost)
@@ -464,17 +506,20 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     OP_TRY(vol_check(v));
     const size_t npx = (size_t)c.width * c.height;
     // the visible-block list (one entry per pool block at most) and the hit-point bytes (one per pool slot; zero between calls)
-    if (v->rc_cap < v->max_blocks || !v->rc_list || !v->rc_hit) {
+    if (v->rc_cap < v->max_blocks || !v->rc_list || !v->rc_hit || !v->rc_sum) {
         if (v->rc_list) op::cached_free(v->rc_list);
         if (v->rc_hit) op::cached_free(v->rc_hit);
-        v->rc_list = nullptr; v->rc_hit = nullptr; v->rc_cap = 0;
+        if (v->rc_sum) op::cached_free(v->rc_sum);
+        v->rc_list = nullptr; v->rc_hit = nullptr; v->rc_sum = nullptr; v->rc_cap = 0;
         OP_HIP(op::cached_malloc(&v->rc_list, sizeof(RcBlock) * (size_t)v->max_blocks));
         OP_HIP(op::cached_malloc((void**)&v->rc_hit, (size_t)v->max_blocks));
         OP_HIP(hipMemsetAsync(v->rc_hit, 0, (size_t)v->max_blocks, v->stream));
+        OP_HIP(op::cached_malloc((void**)&v->rc_sum, sizeof(unsigned) * (size_t)v->max_blocks));
+        OP_HIP(hipMemsetAsync(v->rc_sum, 0, sizeof(unsigned) * (size_t)v->max_blocks, v->stream)); // stamp 0 = nothing known (content_gen starts at 1)
         v->rc_cap = v->max_blocks;
     }
-    if (!v->rc_count) OP_HIP(op::cached_malloc((void**)&v->rc_count, sizeof(unsigned)));
-    OP_HIP(hipMemsetAsync(v->rc_count, 0, sizeof(unsigned), v->stream));
+    if (!v->rc_count) OP_HIP(op::cached_malloc((void**)&v->rc_count, sizeof(unsigned) * kRcCountWords)); // [0] the list's length, [16 + 16 s ...] shard s of the call's counters
+    OP_HIP(hipMemsetAsync(v->rc_count, 0, sizeof(unsigned) * kRcCountWords, v->stream));
     float *d_depth = depth_out, *d_nrm = normals_out, *d_col = colors_out;
     if (mem == OP_MEM_HOST) {
         d_depth = d_nrm = d_col = nullptr;
@@ -502,9 +547,16 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     hipLaunchKernelGGL(k_rc_visible, dim3(std::min(2048u, (work + 255u) / 256u)), dim3(256), 0, v->stream, V, W, (RcBlock*)v->rc_list, v->rc_count,
                        reinterpret_cast<unsigned*>(d_depth), (unsigned)npx);
     const bool shade = d_nrm || d_col;
-    hipLaunchKernelGGL(k_rc_neighbours, dim3(RC_NB_GRID), dim3(256), 0, v->stream, V, (RcBlock*)v->rc_list, (const unsigned*)v->rc_count);
+    // summaries are stamped with the low 30 bits of the content generation; when those wrap, nothing older may survive
+    if ((v->content_gen >> 30) != v->rc_sum_epoch) {
+        OP_HIP(hipMemsetAsync(v->rc_sum, 0, sizeof(unsigned) * (size_t)v->rc_cap, v->stream));
+        v->rc_sum_epoch = v->content_gen >> 30;
+    }
+    const unsigned stamp = (unsigned)(v->content_gen & 0x3fffffffull);
+    const unsigned stamp_read = v->rc_prune ? stamp : 0x7fffffffu; // OP_VOLUME_OPT_RAYCAST_PRUNE = 0: no stored summary ever matches
+    hipLaunchKernelGGL(k_rc_neighbours, dim3(RC_NB_GRID), dim3(256), 0, v->stream, V, (RcBlock*)v->rc_list, (const unsigned*)v->rc_count, (const unsigned*)v->rc_sum, stamp_read);
     hipLaunchKernelGGL(k_rc_march, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count,
-                       reinterpret_cast<unsigned*>(d_depth), shade ? v->rc_hit : nullptr);
+                       reinterpret_cast<unsigned*>(d_depth), shade ? v->rc_hit : nullptr, v->rc_sum, stamp, v->rc_count + 16);
     hipLaunchKernelGGL(k_rc_finish, dim3((unsigned)std::min<size_t>(2048, (npx + 255) / 256)), dim3(256), 0, v->stream, W, d_depth, d_nrm, d_col);
     if (shade)
         hipLaunchKernelGGL(k_rc_shade, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count, v->rc_hit,
@@ -527,6 +579,23 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
         if (d_col) op::cached_free(d_col);
     }
     if (e != hipSuccess) return fail(OP_ERR_HIP, "raycast failed: %s", hipGetErrorString(e));
+    return OP_OK;
+}
+
+int op_volume_raycast_stats(op_volume* v, uint64_t* visible_blocks, uint64_t* dropped_unloaded, uint64_t* loaded_blocks, uint64_t* marched_blocks) {
+    OP_VOL(v);
+    uint64_t out[4] = {0, 0, 0, 0};
+    if (v->rc_count) {
+        std::vector<unsigned> h(kRcCountWords);
+        OP_HIP(hipStreamSynchronize(v->stream));
+        OP_HIP(hipMemcpy(h.data(), v->rc_count, sizeof(unsigned) * kRcCountWords, hipMemcpyDeviceToHost));
+        out[0] = h[0];
+        for (unsigned s = 0; s < 64; ++s) { out[1] += h[16 + 16 * s]; out[2] += h[16 + 16 * s + 1]; out[3] += h[16 + 16 * s + 2]; }
+    }
+    if (visible_blocks) *visible_blocks = out[0];
+    if (dropped_unloaded) *dropped_unloaded = out[1];
+    if (loaded_blocks) *loaded_blocks = out[2];
+    if (marched_blocks) *marched_blocks = out[3];
     return OP_OK;
 }
 

@@ -102,12 +102,13 @@ int vol_ring_send(op_volume* v, op_volume::RingSlot& r); // the DMA of the stage
 // Every block with a pool slot below `bound` may hold data k_integrate did not write (see its PLAIN comment).
 void vol_mark_foreign(op_volume* v, unsigned long long bound) {
     v->plain = false;
+    ++v->content_gen;
     const unsigned b = bound > 0xffffffffull ? 0xffffffffu : (unsigned)bound;
     if (b > v->plain_from) v->plain_from = b;
 }
 
 int vol_reset(op_volume* v) {
-    ++v->generation;
+    ++v->generation; ++v->content_gen;
     hipLaunchKernelGGL(k_clear_table, dim3(1024), dim3(256), 0, v->stream, v->tkeys, v->tvals, (size_t)v->table_size);
     OP_HIP(hipMemsetAsync(v->n_blocks, 0, sizeof(unsigned), v->stream));
     OP_HIP(hipMemsetAsync(v->bmask, 0, sizeof(bmask_t) * (size_t)v->table_size, v->stream));
@@ -166,7 +167,7 @@ int vol_grow(op_volume* v, unsigned long long want, unsigned n_valid) {
     v->pool = pool; v->keys = keys; v->blist = blist; v->sel_list = sel_list; v->sel_cand = sel_cand;
     v->tkeys = tkeys; v->tvals = tvals; v->bmask = bmask;
     v->max_blocks = new_max; v->table_size = new_table;
-    ++v->n_grows; ++v->generation;
+    ++v->n_grows; ++v->generation; ++v->content_gen;
     return OP_OK;
 }
 
@@ -353,7 +354,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         v->hstat[1] = n;
     }
     const unsigned seq = (unsigned)(++v->seq);
-    ++v->generation;
+    ++v->generation; ++v->content_gen;
     if (!select_only && !cube_keys) v->log.push_back(op_volume::BatchRec{v->seq, F, I, Q, nf, depth_fmt, -1});
     const CamParams C = cam_params(v, depth_fmt);
     const bool sample = !select_only && v->prof_every > 0 && (v->prof_batch++ % (uint64_t)v->prof_every) == 0 &&
@@ -807,7 +808,7 @@ int op_volume_destroy(op_volume* v) {
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
-                    v->partial, v->pimg, v->ptile, v->sbits, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots, v->rc_list, v->rc_count, v->rc_hit};
+                    v->partial, v->pimg, v->ptile, v->sbits, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots, v->rc_list, v->rc_count, v->rc_hit, v->rc_sum};
     for (void* p : ptrs)
         if (p) op::cached_free(p);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);
@@ -866,6 +867,11 @@ int op_volume_set_option(op_volume* v, int option, int value) {
         if (value != OP_VOLUME_SELECT_AUTO && value != OP_VOLUME_SELECT_DIRECT && (value < 1 || value > (int)kVoteCap))
             return fail(OP_ERR_INVALID, "op_volume_set_option: OP_VOLUME_OPT_SELECT takes OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT or 1..%u super-blocks per frame", kVoteCap);
         v->select_mode = value;
+        return OP_OK;
+    }
+    if (option == OP_VOLUME_OPT_RAYCAST_PRUNE) { // results are identical either way: a measurement / test knob
+        if (value != 0 && value != 1) return fail(OP_ERR_INVALID, "op_volume_set_option: OP_VOLUME_OPT_RAYCAST_PRUNE takes 0 or 1");
+        v->rc_prune = value;
         return OP_OK;
     }
     if (option != OP_VOLUME_OPT_UPDATE) return fail(OP_ERR_INVALID, "op_volume_set_option: unknown option %d", option);

@@ -404,6 +404,10 @@ struct op_volume {
     void* rc_list = nullptr;     // raycast.hip: the visible-block list of the view being cast (one entry per pool block at most), its capacity in blocks
     unsigned rc_cap = 0;
     unsigned* rc_count = nullptr; // ... and its length
+    unsigned* rc_sum = nullptr;   // per pool slot: what the march learnt about the block's own voxels ((stamp << 2) | has sdf > 0 << 1 | has sdf <= 0), valid while stamp == content_gen
+    uint64_t rc_sum_epoch = 0;    // content_gen >> 30 the summaries were last wiped for
+    int rc_prune = 1;             // OP_VOLUME_OPT_RAYCAST_PRUNE
+    uint64_t content_gen = 1;     // bumped by everything that can change a voxel or a pool slot's meaning (fusion, clear, growth, every foreign writer)
     unsigned char* rc_hit = nullptr; // one byte per pool slot: the block holds hit points of the view being cast (zero between calls)
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
     size_t unpack_n = 0;

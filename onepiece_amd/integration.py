@@ -373,6 +373,25 @@ class CubeHandler:
         L.check(self._lib.op_volume_raycast(self._h, C.byref(cam), _fp(pose), _fp(d), _fp(n), _fp(c), L.OP_MEM_HOST))
         return d, n, c
 
+    def RaycastDevice(self, pose, depth_ptr, normals_ptr=0, colors_ptr=0, camera=None):
+        """The same with outputs that stay in HBM: device addresses (e.g. torch tensor.data_ptr()) of W*H / W*H*3 float32 buffers on the
+        volume's device; 0 = not wanted.  Returns when the images are complete."""
+        cam = camera if camera is not None else self.camera
+        pose = _f32(pose).reshape(16)
+        as_fp = lambda a: C.cast(C.c_void_p(int(a)), L._fp) if a else None
+        L.check(self._lib.op_volume_raycast(self._h, C.byref(cam), _fp(pose), as_fp(depth_ptr), as_fp(normals_ptr), as_fp(colors_ptr), L.OP_MEM_DEVICE))
+
+    def RaycastStats(self):
+        """Measurement hook: what the last Raycast call did (op_volume_raycast_stats)."""
+        v = [C.c_uint64(0) for _ in range(4)]
+        L.check(self._lib.op_volume_raycast_stats(self._h, *[C.byref(x) for x in v]))
+        return {"visible_blocks": v[0].value, "dropped_unloaded": v[1].value, "loaded_blocks": v[2].value, "marched_blocks": v[3].value}
+
+    def SetRaycastPrune(self, on):
+        """Extension (OP_VOLUME_OPT_RAYCAST_PRUNE): whether later views of the unchanged volume may drop blocks by what earlier views learnt
+        about them (default on; the images are identical either way)."""
+        L.check(self._lib.op_volume_set_option(self._h, L.OP_VOLUME_OPT_RAYCAST_PRUNE, 1 if on else 0))
+
     def WriteToFile(self, filename):
         L.check(self._lib.op_volume_write_file(self._h, str(filename).encode()))
         return True

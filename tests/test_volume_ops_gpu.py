@@ -180,6 +180,44 @@ def test_raycast_other_cameras_views_and_an_empty_volume(oracle):
     assert not d.any() and not n.any() and not c.any()
 
 
+def test_raycast_views_of_an_unchanged_volume_prune_by_earlier_views_and_every_change_invalidates_that(oracle):
+    """Later views of an unchanged volume drop blocks by the summaries earlier views left (OP_VOLUME_OPT_RAYCAST_PRUNE): same images, fewer
+    blocks loaded; fusing a frame, uploading, merging or clearing must invalidate what was remembered."""
+    ov, hv = _pair(oracle, 0.008, frames=tuple(range(0, 80, 8)))   # truncation 0.1 m = 12.5 voxels: whole blocks in front of / behind the surface
+    cam = small_camera(4)
+    poses = [S.room_pose(i) for i in (20, 24, 60, 20)]
+    first = []
+    for p in poses:                                  # cold, then warmer and warmer
+        _raycast_equal(ov, hv, p)
+        first.append(hv.RaycastStats())
+    assert first[0]["dropped_unloaded"] == 0 and first[0]["loaded_blocks"] == first[0]["visible_blocks"] > 0
+    assert first[3]["visible_blocks"] == first[0]["visible_blocks"] and first[3]["dropped_unloaded"] > 0
+    assert first[3]["loaded_blocks"] + first[3]["dropped_unloaded"] == first[3]["visible_blocks"]
+    assert first[3]["marched_blocks"] == first[0]["marched_blocks"]           # the dropped ones are blocks the march would have dropped after loading
+    hv.SetRaycastPrune(False)
+    _raycast_equal(ov, hv, poses[3])
+    off = hv.RaycastStats()
+    assert off["dropped_unloaded"] == 0 and off["marched_blocks"] == first[0]["marched_blocks"]
+    hv.SetRaycastPrune(True)
+    # a new frame changes voxels the summaries describe: nothing may be dropped by stale knowledge, and the image follows the volume
+    pose = S.room_pose(22)
+    d, c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+    ov.integrate(d, c, pose); hv.IntegrateImage(d, c, pose)
+    _raycast_equal(ov, hv, poses[3])
+    assert hv.RaycastStats()["dropped_unloaded"] == 0
+    _raycast_equal(ov, hv, poses[3])
+    assert hv.RaycastStats()["dropped_unloaded"] > 0
+    # a foreign writer: SetCubeMap with every sdf negated (fronts become backs)
+    k, v = hv.GetCubeMap()
+    v = v.copy(); obs = v[..., 1] > 0; v[..., 0][obs] = -v[..., 0][obs]
+    hv.SetCubeMap(k, v); ov.clear(); ov.load(k, v)
+    _raycast_equal(ov, hv, poses[3])
+    assert hv.RaycastStats()["dropped_unloaded"] == 0
+    hv.Clear()
+    d0, _n, _c = hv.Raycast(poses[3])
+    assert not d0.any() and hv.RaycastStats()["visible_blocks"] == 0
+
+
 def test_raycast_of_uploaded_data_with_unobserved_voxels_nan_and_negative_weights(oracle):
     """The march keeps unobserved voxels as NaN in its LDS tile: stored NaN / inf sdf values, zero and negative weights and a
     surface that crosses block borders exactly at a block's last voxel layer must give the restatement's answer too."""

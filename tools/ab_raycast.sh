@@ -8,7 +8,7 @@ for V in "$@"; do
   touch $R/onepiece_amd/csrc/raycast.hip
   (cd $R/onepiece_amd/csrc && make -j8 EXTRA="$V" > /tmp/ab_make.log 2>&1) || { echo "variant [$V]: build failed"; tail -5 /tmp/ab_make.log; continue; }
   echo "variant [$V]"
-  $R/tools/ops_driver.bin /tmp/ops_frames.bin 0.005 ${REPS:-5} raycast raycast_nc 2>&1 | grep -v fused | sed 's/ per view (call to completion)//' | awk 'NR<=12'
+  $R/tools/ops_driver.bin /tmp/ops_frames.bin 0.005 ${REPS:-5} raycast raycast_nc 2>&1 | grep -v fused | cut -c1-400
   rm -rf /tmp/abrc; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abrc -o p -- $R/tools/ops_driver.bin /tmp/ops_frames.bin 0.005 3 raycast raycast_nc > /dev/null 2>&1
   python - <<PY
 import csv, glob

@@ -73,21 +73,32 @@ int main(int argc, char** argv) {
         const int views = std::min(n, 8);
         for (int nc = 0; nc < 2; ++nc) {
             if (!want(nc ? "raycast_nc" : "raycast")) continue;
-            double best = 1e9, sum = 0; size_t hits = 0; int cnt = 0;
-            for (int r = 0; r < reps + 1; ++r)              // (the first round warms up)
-                for (int k = 0; k < views; ++k) {
-                    const float* p = &poses[(size_t)(k * n / views) * 16];
-                    t0 = now();
-                    CK(op_volume_raycast(v, &cam, p, d_out, nc ? d_nrm : nullptr, nc ? d_col : nullptr, OP_MEM_DEVICE));
-                    const double dt = now() - t0;
-                    if (r == 0) {
-                        HK(hipMemcpy(hd.data(), d_out, npx * 4, hipMemcpyDeviceToHost));
-                        for (float z : hd) hits += z > 0;
-                    } else { best = std::min(best, dt); sum += dt; ++cnt; }
-                }
-            printf("%s: %d views x %d reps of %zu rays: mean %.3f ms, best %.3f ms per view (call to completion), %.1f M rays/s, hit fraction %.4f\n",
-                   nc ? "raycast_nc (depth + normals + colours)" : "raycast (depth only)", views, reps, npx, sum / cnt * 1e3, best * 1e3, npx / (sum / cnt) / 1e6,
-                   (double)hits / ((double)npx * views));
+            // cold = every view loads every visible block (what the first view after a change of the volume costs: OP_VOLUME_OPT_RAYCAST_PRUNE 0);
+            // warm = later views of the unchanged volume, which drop blocks by what earlier views learnt about them (the default)
+            for (int warm = 0; warm < 2; ++warm) {
+                CK(op_volume_set_option(v, OP_VOLUME_OPT_RAYCAST_PRUNE, warm));
+                double best = 1e9, sum = 0; size_t hits = 0; int cnt = 0;
+                uint64_t st[4] = {0, 0, 0, 0};
+                for (int r = 0; r < reps + 1; ++r)              // (the first round warms up -- and, with pruning on, is the round that learns)
+                    for (int k = 0; k < views; ++k) {
+                        const float* p = &poses[(size_t)(k * n / views) * 16];
+                        t0 = now();
+                        CK(op_volume_raycast(v, &cam, p, d_out, nc ? d_nrm : nullptr, nc ? d_col : nullptr, OP_MEM_DEVICE));
+                        const double dt = now() - t0;
+                        if (r == 0) {
+                            HK(hipMemcpy(hd.data(), d_out, npx * 4, hipMemcpyDeviceToHost));
+                            for (float z : hd) hits += z > 0;
+                        } else {
+                            best = std::min(best, dt); sum += dt; ++cnt;
+                            uint64_t s4[4]; CK(op_volume_raycast_stats(v, &s4[0], &s4[1], &s4[2], &s4[3]));
+                            for (int q = 0; q < 4; ++q) st[q] += s4[q];
+                        }
+                    }
+                printf("%s, %s: %d views x %d reps of %zu rays: mean %.3f ms, best %.3f ms per view (call to completion), %.1f M rays/s, hit fraction %.4f | per view: "
+                       "%.0f visible blocks, %.0f dropped unloaded, %.0f loaded, %.0f marched\n",
+                       nc ? "raycast_nc (depth + normals + colours)" : "raycast (depth only)", warm ? "warm" : "cold", views, reps, npx, sum / cnt * 1e3, best * 1e3,
+                       npx / (sum / cnt) / 1e6, (double)hits / ((double)npx * views), (double)st[0] / cnt, (double)st[1] / cnt, (double)st[2] / cnt, (double)st[3] / cnt);
+            }
         }
         (void)hipFree(d_out); (void)hipFree(d_nrm); (void)hipFree(d_col);
     }
