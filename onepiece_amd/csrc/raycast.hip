@@ -225,18 +225,24 @@ __device__ __forceinline__ float rc_tile_sample(const float* __restrict__ tile, 
 }
 
 // ---- the LDS tile of a block, shared by the march and the shading pass --------------------------------------------------------------------------
-// Which voxel of which neighbour a thread's tile cells come from does not depend on the block: worked out once per workgroup, kept in LDS
+// Which voxel of which neighbour a thread's tile cells come from does not depend on the block: a table, copied into LDS once per workgroup
 // (bits 0-4 neighbour slot, 5-13 voxel id, 14 "an in-block sample can touch it" = tile coordinates 0 .. 8, 15 the cell exists).
 constexpr int kStageIter = (kTileVox + kRcWg - 1) / kRcWg;
-__device__ __forceinline__ void rc_tile_map(unsigned short* s_cell, int tid) {
-#pragma unroll 1
-    for (int i = 0; i < kStageIter; ++i) {
-        const int a = tid + kRcWg * i;
-        const int x = a % kTileEdge - 1, y = (a / kTileEdge) % kTileEdge - 1, z = a / (kTileEdge * kTileEdge) - 1;
-        const unsigned slot = (unsigned)(((x + 8) >> 3) + 3 * ((y + 8) >> 3) + 9 * ((z + 8) >> 3)), vid = (unsigned)((x & 7) + (y & 7) * 8 + (z & 7) * 64);
-        const unsigned reach = (x >= 0 && y >= 0 && z >= 0 && x <= 8 && y <= 8 && z <= 8) ? 1u : 0u;
-        s_cell[a] = (unsigned short)(a < kTileVox ? (slot | (vid << 5) | (reach << 14) | (1u << 15)) : 0u);
+struct RcCellLut {
+    unsigned short v[kStageIter * kRcWg];
+    constexpr RcCellLut() : v{} {
+        for (int a = 0; a < kStageIter * kRcWg; ++a) {
+            const int x = a % kTileEdge - 1, y = (a / kTileEdge) % kTileEdge - 1, z = a / (kTileEdge * kTileEdge) - 1;
+            const unsigned slot = (unsigned)(((x + 8) >> 3) + 3 * ((y + 8) >> 3) + 9 * ((z + 8) >> 3)), vid = (unsigned)((x & 7) + (y & 7) * 8 + (z & 7) * 64);
+            const unsigned reach = (x >= 0 && y >= 0 && z >= 0 && x <= 8 && y <= 8 && z <= 8) ? 1u : 0u;
+            v[a] = (unsigned short)(a < kTileVox ? (slot | (vid << 5) | (reach << 14) | (1u << 15)) : 0u);
+        }
     }
+};
+__device__ const RcCellLut g_rc_cells{}; // (evaluated by the compiler)
+__device__ __forceinline__ void rc_tile_map(unsigned short* s_cell, int tid) {
+#pragma unroll
+    for (int i = 0; i < kStageIter; ++i) s_cell[tid + kRcWg * i] = g_rc_cells.v[tid + kRcWg * i];
 }
 // Voxels -1 .. 9 of the block's frame on every axis (own 512 + the shell of its 26 neighbours) -> s_sdf: the observed sdf, or NaN; RC_STAGE_GROUP
 // cells per thread in flight at a time.  Returns bit 0: an observed sdf <= 0 among the voxels an IN-BLOCK sample can touch, bit 1: an observed

@@ -48,6 +48,12 @@ class DenseSlam:
         self._inflight = []                                            # [(frame_id, source_id, tracker)] in frame order
         self._spec_last = -1                                           # speculative "last tracked frame"
 
+    def SetSums(self, sums):
+        """How every tracker sums an iteration's normal equations (Odometry.SetSums): "fp64" (default) or "reference_f32" -- the reference's own
+        sequential float32 order, the mode whose poses follow the CPU path step for step (north_star's 1e-4 bar)."""
+        for t in self._trackers:
+            t.SetSums(sums)
+
     # -- resolution of one finished pair: DenseSlam.cpp:21-36
     def _resolve(self, frame_id, source_id, res):
         rmse = float(np.float32(res.rmse))                             # `float rmse = tracking_result->rmse`

@@ -1,0 +1,143 @@
+"""BASELINE configs[3]: tracking + fusion.
+
+One section of bench.py's JSON line (bench.py builds the context `c` -- the fused volume, the frames in HBM, the timed region's counters -- and calls run(c, out))."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+# ---- config 4 (BASELINE configs[3]): tracking + fusion, frames resident in HBM; rank 0 reports
+def run(c, out):
+    args, torch, dev, rank, world, local_rank, hv, depth, rgb, poses, K, F, n_local = c.args, c.torch, c.dev, c.rank, c.world, c.local_rank, c.hv, c.depth, c.rgb, c.poses, c.K, c.F, c.n_local
+    I, S, ROOT, W, H, HBM_PEAK_GBS = c.I, c.S, c.ROOT, c.W, c.H, c.HBM_PEAK_GBS
+    from onepiece_amd import dense_slam as DS
+    n_df = min(100, n_local)
+
+    def dense_fusion_pass(pipe, sums="fp64"):
+        vol = I.CubeHandler(hv.camera, device=local_rank)
+        vol.SetVoxelResolution(0.005)
+        slam = DS.DenseSlam(hv.camera, device=local_rank, pipeline=pipe,
+                            on_tracked=lambda fid, c, d, T: vol.IntegrateImage(d, c, T))
+        slam.SetSums(sums)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n_df):
+            slam.UpdateFrame(rgb[i], depth[i])
+        slam.Finish()
+        nb = vol.BlockCount()           # flushes the pending batch and synchronises
+        return slam, nb, time.perf_counter() - t0
+
+    dense_fusion_pass(4)                # warm-up
+    _s1, _nb1, dt_seq = dense_fusion_pass(1)
+    slam, nb, dt = dense_fusion_pass(4)
+    # the same pipeline with every iteration's sums in the reference's own sequential float32 order: the mode that meets north_star's 1e-4 pose bar on every
+    # pair, and therefore the mode config 4's figure is quoted in
+    dense_fusion_pass(4, "reference_f32")
+    _sr1, _nbr1, dt_ref_seq = dense_fusion_pass(1, "reference_f32")
+    slam_ref, nb_ref, dt_ref = dense_fusion_pass(4, "reference_f32")
+    if world == 1 and not args.no_cpu_baseline:
+        # the same pipeline on one host core (the reference's tracker and integrator are serial): 4 frames fused, then tracking alone
+        # over a 24-frame prefix for the pose-chain parity
+        from oracle import oracle as O
+        ocam = O.make_camera()
+        ovol = O.Volume(ocam, voxel_res=0.005)
+        n_par = min(24, n_df)
+        hd, hc = depth[:n_par].cpu().numpy(), rgb[:n_par].cpu().numpy()
+        t0 = time.perf_counter()
+        gp = np.eye(4, dtype=np.float32)
+        ovol.integrate(hd[0], hc[0], gp)
+        ref_chain = [gp]
+        for i in range(1, 4):
+            r = O.dense_tracking(ocam, hc[i - 1], hc[i], hd[i - 1], hd[i], (4, 8, 16), 0)
+            gp = DS._mat4_mul_f32(gp, O.mat4_inverse(r["T"]))
+            ref_chain.append(gp)
+            ovol.integrate(hd[i], hc[i], gp)
+        out["cpu_baseline"]["dense_fusion_frames_per_s"] = 4 / (time.perf_counter() - t0)
+        for i in range(4, n_par):
+            r = O.dense_tracking(ocam, hc[i - 1], hc[i], hd[i - 1], hd[i], (4, 8, 16), 0)
+            ref_chain.append(DS._mat4_mul_f32(ref_chain[-1], O.mat4_inverse(r["T"])))
+        rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+        pair = lambda chain, i: np.linalg.inv(np.asarray(chain[i - 1], np.float64)) @ np.asarray(chain[i], np.float64)
+        g0p = np.linalg.inv(poses[0].astype(np.float64))
+        drift_of = lambda chain: [float(np.abs(np.asarray(chain[i], np.float64) - g0p @ poses[i].astype(np.float64))[:3, 3].max()) for i in range(n_par)]
+        par = {"frames": n_par, "oracle_chain_max_translation_drift_m": max(drift_of(ref_chain))}
+        for mode_name in ("fp64", "reference_f32"):
+            chk = DS.DenseSlam(hv.camera, device=local_rank)
+            chk.rgbd_odometry.SetSums(mode_name)
+            chk.UpdateFrame(rgb[0], depth[0]); chk.UpdateFrame(rgb[1], depth[1])      # (first call: workspace allocation)
+            torch.cuda.synchronize(dev)
+            t_par = time.perf_counter()
+            for i in range(2, n_par):
+                chk.UpdateFrame(rgb[i], depth[i])
+            t_par = time.perf_counter() - t_par
+            pe = [rel(pair(chk.global_poses, i), pair(ref_chain, i)) for i in range(1, n_par)]
+            ce = [rel(chk.global_poses[i], ref_chain[i]) for i in range(n_par)]
+            par[mode_name] = {"pair_rel_err_max": max(pe), "pair_rel_err_median": float(np.median(pe)), "pairs_within_1e-4": int(sum(e <= 1e-4 for e in pe)),
+                              "pairs": len(pe), "chain_rel_err_max": max(ce), "max_translation_drift_m": max(drift_of(chk.global_poses)),
+                              "tracks_per_s": (n_par - 2) / t_par}   # one pair at a time, from raw frames (image preparation included)
+        out["dense_fusion_parity"] = par
+    g0 = np.linalg.inv(poses[0].astype(np.float64))
+    drift = max(float(np.abs(np.asarray(slam.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max())
+                for i in range(n_df))
+    par_summary = None
+    if "dense_fusion_parity" in out:   # the pose error of the mode the rates below are quoted in, next to them (north_star's bar: 1e-4 relative)
+        pf, pr = out["dense_fusion_parity"]["fp64"], out["dense_fusion_parity"]["reference_f32"]
+        par_summary = {"default_mode_fp64": {"pair_rel_err_max_vs_cpu": pf["pair_rel_err_max"], "pairs_within_1e-4": pf["pairs_within_1e-4"], "pairs": pf["pairs"],
+                                             "meets_1e-4_on_every_pair": pf["pairs_within_1e-4"] == pf["pairs"]},
+                       "reference_order_f32": {"pair_rel_err_max_vs_cpu": pr["pair_rel_err_max"], "pairs_within_1e-4": pr["pairs_within_1e-4"], "pairs": pr["pairs"],
+                                               "meets_1e-4_on_every_pair": pr["pairs_within_1e-4"] == pr["pairs"], "tracks_per_s": pr["tracks_per_s"]},
+                       "note": "frames_per_s of this object is the reference_order_f32 mode's (the reference's own float32 summation order, OP_TRACK_SUMS_REFERENCE_F32, sums by one "
+                               "wave on the device): it follows the CPU path step for step; the default fp64 mode's faster rates are under outside_tolerance_fp64_mode"}
+    drift_ref = max(float(np.abs(np.asarray(slam_ref.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max()) for i in range(n_df))
+    out["dense_fusion"] = {"pose_parity": par_summary,
+                           "frames_per_s": n_df / dt_ref,      # config 4's figure: the mode INSIDE north_star's 1e-4 pose tolerance (reference-order float32 sums), four pairs in flight
+                           "frames_per_s_mode": "reference_order_f32 (OP_TRACK_SUMS_REFERENCE_F32): every pair of the parity chain at 0.0 from the CPU path",
+                           "one_pair_at_a_time_frames_per_s": n_df / dt_ref_seq, "pairs_in_flight": 4,
+                           "frames": n_df, "tracked": int(sum(slam_ref.tracking_success)), "blocks": int(nb_ref), "voxel_m": 0.005, "max_translation_drift_m": drift_ref,
+                           "outside_tolerance_fp64_mode": {"frames_per_s": n_df / dt, "one_pair_at_a_time_frames_per_s": n_df / dt_seq, "tracked": int(sum(slam.tracking_success)),
+                                                           "blocks": int(nb), "max_translation_drift_m": drift,
+                                                           "note": "the library's default tracker mode (fp64 device reduction, no sequential sums): 20 of 23 pairs within 1e-4 of the CPU "
+                                                                   "path, worst 4.4e-4 (pose_parity.default_mode_fp64) -- NOT config 4's figure; the rate of callers that accept that"},
+                           "pipeline": "per frame: Odometry::DenseTracking(prev, cur, I) on the GPU (image preparation, 3 levels x "
+                                       "{4,8,16}), pose chaining on the host, CubeHandler::IntegrateImage with the TRACKED pose; "
+                                       "no submap registration / BA (out of scope).  pairs_in_flight independent frame pairs are tracked "
+                                       "concurrently on separate HIP streams (speculating on the success flag, resolved in order): "
+                                       "identical poses, the latency-bound tracker no longer leaves the chip idle"}
+    # the same pipeline from C++ over the C-ABI (tools/prof_driver.bin track=4: op_tracker_dense_tracking_enqueue / op_tracker_wait on four
+    # trackers, op_volume_integrate with the chained pose): the interpreter's ~250 us per frame are what limits the figure above
+    if world == 1:
+        try:
+            import subprocess, tempfile, re as _re
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import counters as CT
+            CT.build_driver()
+            n_cpp = min(200, n_local)
+            with tempfile.NamedTemporaryFile(prefix="opc_track_", suffix=".bin", dir="/tmp", delete=False) as tf:
+                np.array([n_cpp, W, H], np.int32).tofile(tf)
+                dh, ch = depth[:n_cpp].cpu().numpy(), rgb[:n_cpp].cpu().numpy()
+                for i in range(n_cpp):
+                    poses[i].astype(np.float32).tofile(tf); dh[i].tofile(tf); ch[i].tofile(tf)
+                tname = tf.name
+            try:
+                rates_cpp, rates_cpp_ref = {}, {}
+                for sums, dst in (("fp64", rates_cpp), ("reference_f32", rates_cpp_ref)):
+                    for k in (1, 4):
+                        txt = subprocess.run([CT.DRIVER, tname, "3", "0.005", "track=%d" % k], capture_output=True, text=True, timeout=600,
+                                             env=dict(os.environ, PD_TRACK_SUMS=sums)).stdout
+                        m = _re.findall(r"tracked (\d+)/(\d+) frames, ([\d.]+) frames/s", txt)
+                        dst[k] = (max(float(x[2]) for x in m), int(m[-1][0]), int(m[-1][1])) if m else None
+            finally:
+                os.unlink(tname)
+            if rates_cpp_ref.get(4):
+                out["dense_fusion"].update({"cpp_frames_per_s": rates_cpp_ref[4][0], "cpp_one_pair_at_a_time_frames_per_s": rates_cpp_ref[1][0] if rates_cpp_ref.get(1) else None,
+                                            "cpp_tracked": rates_cpp_ref[4][1], "cpp_frames": rates_cpp_ref[4][2]})
+            if rates_cpp.get(4):
+                out["dense_fusion"]["outside_tolerance_fp64_mode"].update({"cpp_frames_per_s": rates_cpp[4][0], "cpp_one_pair_at_a_time_frames_per_s": rates_cpp[1][0] if rates_cpp.get(1) else None,
+                                            "cpp_tracked": rates_cpp[4][1], "cpp_frames": rates_cpp[4][2],
+                                            "cpp_driver": "tools/prof_driver.bin <frames> 3 0.005 track=4: the same pipeline over the C-ABI without the interpreter, "
+                                                          "best of 3; every tracker stream has a hardware queue of its own (the library asks for 8 when it is loaded)"})
+        except Exception as e:
+            out["dense_fusion"]["cpp_error"] = repr(e)[:200]

@@ -1,0 +1,61 @@
+"""Host images: the reference's own call pattern, PCIe included.
+
+One section of bench.py's JSON line (bench.py builds the context `c` -- the fused volume, the frames in HBM, the timed region's counters -- and calls run(c, out))."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+# ---- the reference's own call pattern: one CubeHandler::IntegrateImage(cv::Mat depth, cv::Mat rgb, pose) per frame with
+# PAGEABLE host images (CubeHandler.cpp:197-210).  PCIe-inclusive, never the headline `value`: each call copies its two
+# images into the pinned staging ring (caller thread + 2 helper threads), the DMA runs on a copy stream and overlaps the
+# previous batch's kernels, frames are fused up to 32 per launch group.  (From C++ -- tools/prof_driver.cpp "host" -- the same
+# loop reaches ~13 k frames/s; here the Python interpreter sits in the loop.)
+def run(c, out):
+    args, torch, dev, rank, world, local_rank, hv, depth, rgb, poses, K, F, n_local = c.args, c.torch, c.dev, c.rank, c.world, c.local_rank, c.hv, c.depth, c.rgb, c.poses, c.K, c.F, c.n_local
+    I, S, ROOT, W, H, HBM_PEAK_GBS = c.I, c.S, c.ROOT, c.W, c.H, c.HBM_PEAK_GBS
+    nh = min(300, n_local)
+    dn, cn = depth[:nh].cpu().numpy(), rgb[:nh].cpu().numpy()
+    d16h = np.clip(np.round(dn * 1000.0), 0, 65535).astype(np.uint16)
+    rates = {}
+    for name, dsrc in (("float32_depth", dn), ("uint16_depth", d16h)):
+        best = None
+        for rep in range(3):
+            hv.Clear(); hv.Synchronize()
+            t = time.perf_counter()
+            for k in range(nh):
+                hv.IntegrateImage(dsrc[k], cn[k], poses[k])
+            hv.Synchronize()
+            dth = time.perf_counter() - t
+            best = dth if best is None else min(best, dth)
+        rates[name] = nh / best
+    out["host_images_frames_per_s"] = rates["float32_depth"]
+    out["host_images"] = {"frames": nh, "float32_depth_frames_per_s": rates["float32_depth"], "uint16_depth_frames_per_s": rates["uint16_depth"],
+                          "call_pattern": "one IntegrateImage(depth, rgb, pose) per frame, pageable numpy buffers, Python loop; pinned staging ring + copy stream"}
+    # (a) the same loop from C++ (tools/prof_driver.bin host): no interpreter between the calls -- the reference's actual call pattern
+    try:
+        import subprocess, tempfile, re as _re
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import counters as CT
+        CT.build_driver()
+        with tempfile.NamedTemporaryFile(prefix="opc_host_", suffix=".bin", dir="/tmp", delete=False) as tf:
+            np.array([nh, W, H], np.int32).tofile(tf)
+            for i in range(nh):
+                poses[i].astype(np.float32).tofile(tf); dn[i].tofile(tf); cn[i].tofile(tf)
+            hname = tf.name
+        try:
+            txt = subprocess.run([CT.DRIVER, hname, "3", repr(float(args.voxel)), "host"], capture_output=True, text=True, timeout=300).stdout
+        finally:
+            os.unlink(hname)
+        best_cpp = {}
+        for m in _re.finditer(r"host images, (float32|uint16) depth: \d+ frames, ([\d.]+) frames/s", txt):
+            best_cpp[m.group(1)] = max(best_cpp.get(m.group(1), 0.0), float(m.group(2)))
+        out["host_images"]["cpp_float32_depth_frames_per_s"] = best_cpp.get("float32")
+        out["host_images"]["cpp_uint16_depth_frames_per_s"] = best_cpp.get("uint16")
+        out["host_images"]["cpp_driver"] = "tools/prof_driver.bin <frames> 3 <voxel> host: one op_volume_integrate per frame from C++ with pageable images, best of 3"
+    except Exception as e:
+        out["host_images"]["cpp_error"] = repr(e)[:200]
+    del dn, cn, d16h

@@ -1,0 +1,136 @@
+"""The roofline object's extras: the one-frame-per-launch run (where SURVEY 8(d)'s bytes are a bound), the sum-form update, the live PMC passes.
+
+One section of bench.py's JSON line (bench.py builds the context `c` -- the fused volume, the frames in HBM, the timed region's counters -- and calls run(c, out))."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def run(c, out):
+    args, torch, dev, rank, world, local_rank, hv, depth, rgb, poses, K, F, n_local = c.args, c.torch, c.dev, c.rank, c.world, c.local_rank, c.hv, c.depth, c.rgb, c.poses, c.K, c.F, c.n_local
+    I, S, ROOT, W, H, HBM_PEAK_GBS = c.I, c.S, c.ROOT, c.W, c.H, c.HBM_PEAK_GBS
+    stats, prof, frames_per_launch, k3_s, kc_cycles, batch_bytes = c.stats, c.prof, c.frames_per_launch, c.k3_s, c.kc_cycles, c.batch_bytes
+    # -- the byte model where it is a roofline: one frame per launch (every voxel read + written once per frame)
+    hv.Clear(); hv.ProfileEnable(1)
+    nb1 = min(64, n_local)
+    for k in range(nb1):
+        hv.IntegrateSequence(depth[k:k + 1], rgb[k:k + 1], poses[k:k + 1])
+        hv.Flush()   # one frame per launch
+    hv.Synchronize()
+    st1, p1 = hv.Stats(), hv.ProfileRead()
+    hv.ProfileEnable(0)
+    b1 = 40.0 * st1["voxels_updated"] / max(st1["frames"], 1) + 7.0 * W * H
+    a1 = b1 / (p1["integrate_ms"] * 1e-3) / 1e9
+    m1 = (10240.0 * st1["blocks_read"] + 20.0 * st1["voxels_written"]) / max(st1["launches"], 1) + 8.0 * W * H
+    out["roofline"]["batch1_frac"] = a1 / HBM_PEAK_GBS   # SURVEY 8(d)'s bytes where they ARE a bound (one frame per launch) / time / 8 TB/s: north_star's ">= 50 % of HBM roofline"
+    out["roofline"]["hbm_frac"] = None                    # measured traffic of the batched launch / time / 8 TB/s; filled in by the counter passes below
+    out["roofline"]["batch1"] = {"frames": nb1, "bound": "hbm", "avg_launch_ms": p1["integrate_ms"], "algorithmic_bytes_per_launch": b1, "achieved": a1, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic_model_bytes_per_launch": m1, "traffic_model_frac": m1 / (p1["integrate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "evidence": "profiles/r04_batch1.kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/prof_driver.bin ... batch=1), "
+                                             "profiles/r04_batch1.FETCH_SIZE.pmc.csv / WRITE_SIZE.pmc.csv: 395 MB per launch measured = 0.63 of the 8 TB/s peak, the rate the "
+                                             "read-modify-write calibration kernel of the same shape reaches (profiles/r03_calib.timing.txt: 5.0 TB/s)",
+                                 "note": "k_integrate with ONE frame per launch: SURVEY 8(d)'s algorithmic bytes are then a lower bound of the real traffic, "
+                                         "so this is a true HBM roofline fraction (north_star: >= 50 % of HBM roofline on the integrate kernel)"}
+    # -- the opt-in sum-form update (OP_VOLUME_UPDATE_SUM_FORM): the same frames, one weighted mean per batch instead of one rounded update per frame
+    fuse_all = lambda: [hv.IntegrateSequence(depth[k * F:(k + 1) * F], rgb[k * F:(k + 1) * F], poses[k * F:(k + 1) * F]) for k in range(K)]
+    hv.Clear(); hv.SetUpdateMode("sum_form"); hv.ProfileEnable(args.profile_every)
+    best_sf = 0.0
+    for _rep in range(2):
+        hv.Clear()
+        hv.Synchronize(); torch.cuda.synchronize()
+        t_sf = time.perf_counter()
+        fuse_all()
+        hv.Synchronize()
+        best_sf = max(best_sf, n_local / (time.perf_counter() - t_sf))
+    psf = hv.ProfileRead()
+    hv.ProfileEnable(0)
+    out["sum_form"] = {"frames_per_s": best_sf, "integrate_ms_per_launch": psf["integrate_ms"], "frames_per_launch": psf["frames"] / max(psf["launches"], 1),
+                       "note": "op_volume_set_option(OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_SUM_FORM): opt-in; `value` above is the default exact update"}
+    if True:   # the two volumes side by side over a prefix of the workload (~1 GB of host memory each at 500 frames)
+        n_cmp = min(n_local, 500)
+        hv.Clear()
+        hv.IntegrateSequence(depth[:n_cmp], rgb[:n_cmp], poses[:n_cmp])
+        k_sf, v_sf = hv.GetCubeMap()
+        hv.SetUpdateMode("exact"); hv.Clear()
+        hv.IntegrateSequence(depth[:n_cmp], rgb[:n_cmp], poses[:n_cmp])
+        k_ex, v_ex = hv.GetCubeMap()
+        obs = v_ex[..., 1] > 0
+        out["sum_form"]["parity_vs_exact_update"] = {
+            "keys_equal": bool(np.array_equal(k_ex, k_sf)), "weights_equal": bool(np.array_equal(v_ex[..., 1], v_sf[..., 1])),
+            "max_abs_sdf_diff_over_truncation": float(np.abs(v_ex[..., 0] - v_sf[..., 0])[obs].max() / 0.1),
+            "max_abs_colour_diff": float(np.abs(v_ex[..., 2:] - v_sf[..., 2:])[obs].max()), "blocks": int(len(k_ex)), "frames": int(n_cmp), "bar": 1e-4}
+        del k_sf, v_sf, k_ex, v_ex, obs
+    hv.SetUpdateMode("exact")
+    # -- live PMC passes (separate rocprofv3 --pmc runs of the torch-free driver on a dump of this step's frames)
+    if world == 1 and not args.no_counters:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import counters as CT
+            import issue_model as IM
+            import tempfile
+            nfc = F if F < 32 else F // 32 * 32   # whole 32-frame batches, like the timed region's launches
+            with tempfile.NamedTemporaryFile(prefix="opc_frames_", suffix=".bin", dir="/tmp", delete=False) as tf:
+                np.array([nfc, W, H], np.int32).tofile(tf)
+                dh, ch = depth[:nfc].cpu().numpy(), rgb[:nfc].cpu().numpy()
+                for i in range(nfc):
+                    poses[i].astype(np.float32).tofile(tf); dh[i].tofile(tf); ch[i].tofile(tf)
+                fname = tf.name
+            try:
+                cnt = CT.measure(fname, args.voxel)
+            finally:
+                os.unlink(fname)
+            kc = cnt["k_integrate"]
+            R = out["roofline"]
+            # the driver's launches fuse nfc / ceil(nfc / 32) frames each, the timed region's frames_per_launch (its last launch may be
+            # shorter): per-launch counts are scaled by the ratio (they are proportional to the frames of a launch to within a few %)
+            fpl_driver = nfc / float(-(-nfc // 32))
+            scale = frames_per_launch / fpl_driver
+            for key in ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch"):
+                kc[key] *= scale
+            for c in kc:
+                if isinstance(kc[c], dict) and "mean_per_launch" in kc[c]:
+                    kc[c]["mean_per_launch"] *= scale
+            R["traffic"] = kc["hbm_bytes_per_launch"]
+            R["hbm"].update({"traffic_bytes_per_launch": kc["hbm_bytes_per_launch"], "read_bytes_per_launch": kc["hbm_read_bytes_per_launch"],
+                             "write_bytes_per_launch": kc["hbm_write_bytes_per_launch"], "achieved": kc["hbm_bytes_per_launch"] / k3_s / 1e9, "unit": "GB/s",
+                             "frac": kc["hbm_bytes_per_launch"] / k3_s / 1e9 / HBM_PEAK_GBS, "traffic_over_model": kc["hbm_bytes_per_launch"] / batch_bytes,
+                             "source": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950, calibrated for this kernel's 4 B/lane plane rows: profiles/r03_calib.FETCH_SIZE.pmc.csv) "
+                                       "and WRITE_SIZE (exact: profiles/r03_calib.WRITE_SIZE.pmc.csv), separate passes, tools/prof_driver.bin on the first %d frames "
+                                       "of this run (32-frame launches; per-launch figures scaled by %.3f to the timed region's %.1f frames per launch)" % (nfc, scale, frames_per_launch)})
+            costs_file = os.path.join(ROOT, "profiles", "r04_issue_costs.json")
+            if not os.path.exists(costs_file):
+                costs_file = os.path.join(ROOT, "profiles", "r03_issue_costs.json")
+            cj = json.load(open(costs_file))
+            counts = {c: kc[c]["mean_per_launch"] for c in kc if isinstance(kc[c], dict) and "mean_per_launch" in kc[c]}
+            counts["kernel_cycles"] = kc_cycles
+            im = IM.model(cj["costs"], cj["valu_mix_k_integrate_plain"], counts)
+            # The binding resource goes to the top of the object: a fraction <= 1 of the SIMDs' instruction-issue capacity.  Which fraction: the
+            # additive model (every class charged into ONE budget per SIMD) when the mixed-class microbenchmark of the costs file says it predicts
+            # such a kernel's time within 10 %; otherwise the VALU share alone (scalar instructions of other waves co-issue), the rest as context.
+            mc = cj.get("mixed_check")
+            additive_ok = bool(mc and mc.get("additive_model_holds"))
+            valu_frac = im["classes"]["valu"]["share_of_capacity"]
+            R.update({"bound": "issue", "achieved": im["issue_cycles_per_launch"] if additive_ok else im["classes"]["valu"]["issue_cycles"],
+                      "peak": im["simd_cycles_per_launch"], "unit": "SIMD issue cycles per launch (shader clock)",
+                      "frac": im["frac"] if additive_ok else valu_frac,
+                      "frac_definition": ("sum over all instruction classes x measured issue cost / SIMD cycles (additive model, validated on a mixed-class "
+                                          "microbenchmark: predicted / measured = %.3f)" % mc["additive_over_measured"]) if additive_ok else
+                                         "VALU wave-instructions x measured issue cost / SIMD cycles (the additive all-class model is NOT validated%s: scalar work co-issues)"
+                                         % ((": it predicts %.2f x the mixed microbenchmark's time" % mc["additive_over_measured"]) if mc else ""),
+                      "valu_frac": valu_frac, "all_classes_additive_frac": im["frac"], "mixed_check": mc, "costs_file": os.path.relpath(costs_file, ROOT)})
+            R["hbm_frac"] = R["hbm"]["frac"]      # measured HBM traffic of the batched launch / launch time / 8 TB/s
+            R["issue"] = {"classes": im["classes"], "valu_cycles_each": im["valu_cycles_each"], "kernel_cycles": im["kernel_cycles"],
+                          "insts_per_voxel_frame_wave": {"valu": counts["SQ_INSTS_VALU"] / (stats["blocks_selected"] / max(stats["frames"], 1) * frames_per_launch * 8.0),
+                                                         "salu": counts.get("SQ_INSTS_SALU", 0.0) / (stats["blocks_selected"] / max(stats["frames"], 1) * frames_per_launch * 8.0)},
+                          "costs": os.path.relpath(costs_file, ROOT) + " (tools/valu_ubench.hip at 8 waves per SIMD, shader cycles per wave64 instruction and SIMD; "
+                                   "VALU classes weighted by the kernel's static opcode histogram)",
+                          "note": "frac = sum over classes of wave-instructions (SQ_INSTS_* of this step's launches) x issue cost / (1024 SIMDs x the launch's "
+                                  "shader cycles): the share of the chip's instruction-issue slots the kernel fills.  HBM is far from binding for a batched launch "
+                                  "(roofline.hbm), so the way to make it faster is fewer instructions per voxel and frame"}
+            R["counters"] = {k: {c: v["mean_per_launch"] for c, v in r.items() if isinstance(v, dict) and "mean_per_launch" in v} for k, r in cnt.items()}
+        except Exception as e:  # rocprofv3 missing / failing must not take the bench line down
+            out["roofline"]["traffic_error"] = repr(e)[:300]
+
