@@ -510,7 +510,10 @@ int op_tracker_dense_tracking(op_tracker *t, const op_camera *cam, int n_levels,
  * frame pairs concurrently -- a single 640x480 track is 28 strictly sequential small problems that leave
  * most of the 256 CUs idle.  _enqueue returns as soon as everything is on the tracker's stream (device
  * frames are used in place and must stay valid until the wait); op_tracker_wait synchronises that stream
- * and fills the result.  One enqueue may be outstanding per tracker. */
+ * and fills the result.  One enqueue may be outstanding per tracker.  With the reference-order sums
+ * (OP_TRACK_SUMS_REFERENCE_F32*), which need the host after every iteration, the run proceeds on a host thread of
+ * the tracker's own, so _enqueue still returns at once and trackers still overlap; HOST frames must then stay
+ * valid until the wait as well. */
 int op_tracker_dense_tracking_enqueue(op_tracker *t, const op_camera *cam, int n_levels,
                                       const int32_t *iters_per_level, const uint8_t *source_rgb,
                                       const uint8_t *target_rgb, const void *source_depth,

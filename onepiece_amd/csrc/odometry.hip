@@ -21,8 +21,12 @@
 // NormalizeIntensity) on the device, and splits into _enqueue / op_tracker_wait so that several trackers
 // (one HIP stream each) keep independent frame pairs in flight; one call's ~100 launches are captured
 // into a hipGraph on first use and replayed afterwards.
+#include <array>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -822,6 +826,13 @@ struct op_tracker {
     TrackState* st_back = nullptr;   // pinned: state downloaded after the run
     bool pending = false;            // a run has been enqueued and not yet waited for
     bool pending_logs = false, pending_points = false;
+    // The reference-order modes (OP_TRACK_SUMS_REFERENCE_F32*) need the host after every iteration, so an "enqueued" run of theirs executes on a host
+    // thread of the tracker's own: op_tracker_dense_tracking_enqueue still returns at once and several trackers still run side by side (their
+    // sequential one-wave sums on different CUs).  op_tracker_wait joins it.
+    std::thread worker;
+    bool worker_active = false;
+    int worker_rc = OP_OK;
+    char worker_err[512] = "";
     size_t pix_cap = 0;              // workspace capacity in pixels
     int* pair_p = nullptr;           // per source pixel: candidate target pixel index p(s) or -1
     int* pair_t = nullptr;           // per source pixel: accepted target pixel index or -1
@@ -952,12 +963,14 @@ int op_tracker_create(int device, op_tracker** out) {
 
 int op_tracker_set_option(op_tracker* t, int option, int value) {
     if (!t) return fail(OP_ERR_INVALID, "null tracker");
+    if (t->worker_active) return fail(OP_ERR_INVALID, "op_tracker_set_option: an enqueued run has not been waited for");
     if (option == OP_TRACK_OPT_SUMS && (value == OP_TRACK_SUMS_FP64 || value == OP_TRACK_SUMS_REFERENCE_F32 || value == OP_TRACK_SUMS_REFERENCE_F32_HOST)) { t->sums = value; return OP_OK; }
     return fail(OP_ERR_INVALID, "op_tracker_set_option: unknown option %d / value %d", option, value);
 }
 
 int op_tracker_destroy(op_tracker* t) {
     if (!t) return OP_OK;
+    if (t->worker_active) { t->worker.join(); t->worker_active = false; }
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->rows_dev);
@@ -1156,7 +1169,7 @@ int op_tracker_track(op_tracker* t, const op_track_level* levels, int n_levels, 
         max_pix = np > max_pix ? np : max_pix;
         image_floats += 8 * np;
     }
-    if (t->pending) return fail(OP_ERR_INVALID, "op_tracker_track: an enqueued run has not been waited for");
+    if (t->pending || t->worker_active) return fail(OP_ERR_INVALID, "op_tracker_track: an enqueued run has not been waited for");
     OP_TRY(use_device(t->device));
     OP_TRY(tracker_reserve(t, max_pix, mem == OP_MEM_HOST ? image_floats : 0));
     TrackState* h = t->st_host;
@@ -1192,11 +1205,35 @@ static float* pyr_image(const op_tracker* t, int f, int k, int l) {
     return t->pyr + (size_t)(f * 6 + k) * per_set + off;
 }
 
+static int dense_tracking_enqueue_now(op_tracker* t, const op_camera* cam, int n_levels, const int32_t* iters_per_level,
+                                      const uint8_t* source_rgb, const uint8_t* target_rgb, const void* source_depth, const void* target_depth,
+                                      int depth_fmt, const float init_T[16], int term_type, int mem, int want_point_corr);
+
 int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n_levels, const int32_t* iters_per_level,
                                       const uint8_t* source_rgb, const uint8_t* target_rgb, const void* source_depth, const void* target_depth,
                                       int depth_fmt, const float init_T[16], int term_type, int mem, int want_point_corr) {
     if (!t || !cam || !iters_per_level || !source_rgb || !target_rgb || !source_depth || !target_depth || !init_T)
         return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: NULL argument");
+    if (t->pending || t->worker_active) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: an enqueued run has not been waited for");
+    if (t->sums == OP_TRACK_SUMS_FP64)
+        return dense_tracking_enqueue_now(t, cam, n_levels, iters_per_level, source_rgb, target_rgb, source_depth, target_depth, depth_fmt, init_T, term_type, mem, want_point_corr);
+    // reference-order sums: the run synchronises with the host every iteration -- on the tracker's own host thread (the images must stay valid until op_tracker_wait, as for any enqueue)
+    OP_TRY(check_iters("op_tracker_dense_tracking", n_levels, iters_per_level, term_type));
+    const op_camera cam_copy = *cam;
+    const std::vector<int32_t> iters(iters_per_level, iters_per_level + n_levels);
+    std::array<float, 16> T0;
+    std::memcpy(T0.data(), init_T, sizeof(float) * 16);
+    t->worker_active = true; t->worker_rc = OP_OK; t->worker_err[0] = 0;
+    t->worker = std::thread([=] {
+        t->worker_rc = dense_tracking_enqueue_now(t, &cam_copy, n_levels, iters.data(), source_rgb, target_rgb, source_depth, target_depth, depth_fmt, T0.data(), term_type, mem, want_point_corr);
+        if (t->worker_rc != OP_OK) std::snprintf(t->worker_err, sizeof(t->worker_err), "%s", op::g_last_error); // (the error text is thread-local: hand it over)
+    });
+    return OP_OK;
+}
+
+static int dense_tracking_enqueue_now(op_tracker* t, const op_camera* cam, int n_levels, const int32_t* iters_per_level,
+                                      const uint8_t* source_rgb, const uint8_t* target_rgb, const void* source_depth, const void* target_depth,
+                                      int depth_fmt, const float init_T[16], int term_type, int mem, int want_point_corr) {
     if (t->pending) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: an enqueued run has not been waited for");
     OP_TRY(check_iters("op_tracker_dense_tracking", n_levels, iters_per_level, term_type));
     if (depth_fmt != OP_DEPTH_F32 && depth_fmt != OP_DEPTH_U16) return fail(OP_ERR_INVALID, "op_tracker_dense_tracking: bad depth_fmt %d", depth_fmt);
@@ -1368,6 +1405,11 @@ int op_tracker_dense_tracking_enqueue(op_tracker* t, const op_camera* cam, int n
 int op_tracker_wait(op_tracker* t, op_track_result* result, int32_t* pixel_corr, float* point_corr, size_t corr_cap) {
     if (!t || !result) return fail(OP_ERR_INVALID, "op_tracker_wait: NULL argument");
     OP_TRY(use_device(t->device));
+    if (t->worker_active) { // a reference-order run on the tracker's own host thread
+        t->worker.join();
+        t->worker_active = false;
+        if (t->worker_rc != OP_OK) { t->pending = false; return fail(t->worker_rc, "%s", t->worker_err); }
+    }
     return track_finish(t, result, pixel_corr, point_corr, corr_cap, nullptr, nullptr);
 }
 
@@ -1383,7 +1425,7 @@ int op_tracker_dense_tracking(op_tracker* t, const op_camera* cam, int n_levels,
 
 int op_tracker_read_pyramid(op_tracker* t, int frame, int kind, int level, float* out, size_t cap) {
     if (!t || !out) return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: NULL argument");
-    if (t->pending) return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: an enqueued run has not been waited for");
+    if (t->pending || t->worker_active) return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: an enqueued run has not been waited for");
     if (!t->pyr || frame < 0 || frame > 1 || kind < 0 || kind > 5 || level < 0 || level >= t->pyr_levels || (frame == 0 && kind > 1))
         return fail(OP_ERR_INVALID, "op_tracker_read_pyramid: no such image (frame %d kind %d level %d)", frame, kind, level);
     const size_t n = (size_t)(t->pyr_w >> level) * (t->pyr_h >> level);
