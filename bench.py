@@ -154,6 +154,8 @@ def main():
     total_frames = n_local * world
     # what every rank did, so that a 1 -> 8 GPU curve decomposes into fusion and merge (gathered outside the timed region)
     mine = {"rank": rank, "frames": n_local, "fusion_ms": t_fuse * 1e3, "merge_ms": t_merge * 1e3, "local_blocks": int(local_blocks)}
+    if world > 1 or force_dist:   # what this rank put on the wire (onepiece_amd.distributed.last_stats)
+        mine.update({k: D.last_stats.get(k) for k in ("algorithm", "held_blocks", "owned_blocks", "wire_bytes_sent", "wire_bytes_received")})
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
@@ -193,10 +195,15 @@ def main():
             "merge_union_blocks": n_union,
             "multi_gpu": {"ranks_in_process_group": (dist.get_world_size() if (world > 1 or force_dist) else 1),
                           "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
-                          "merge_bytes_per_rank": (int(n_union) * 10240 if n_union else 0), "merge_slices": (-(-int(n_union) // 32768) if n_union else 0),
+                          "merge_algorithm": per_rank[0].get("algorithm") if (world > 1 or force_dist) else None,
+                          "dense_reduce_bytes_per_rank_for_comparison": (int(n_union) * 10240 if n_union else 0),
+                          "wire_bytes_sent_per_rank": [p.get("wire_bytes_sent") for p in per_rank] if (world > 1 or force_dist) else None,
                           "per_rank": per_rank,
-                          "note": "weak scaling: every rank fuses its own frames without communication (fusion_ms), then ONE merge: all_gather of the block keys, "
-                                  "sum-form pack, sliced reduce(SUM) to rank 0 over RCCL, normalisation (merge_ms, inside the timed region)"},
+                          "note": "weak scaling: every rank fuses its own frames without communication (fusion_ms), then ONE merge (merge_ms, inside the timed region): the "
+                                  "owner-partitioned exchange -- every rank sends the blocks it HOLDS, in sum form, to their owner ranks (all pairs at once over xGMI's "
+                                  "point-to-point links), the owners add them up and send their partitions to rank 0, which normalises the whole map (the reference's Merge "
+                                  "semantics).  wire_bytes_sent = (held blocks of other ranks' partitions + the rank's own summed partition) x 10 248 B; the dense "
+                                  "reduce of rounds 1-4 put union x 10 240 B on every rank's link"},
             "per_frame": {"blocks_selected": stats["blocks_selected"] / max(stats["frames"], 1),
                           "voxels_visited": stats["voxels_visited"] / max(stats["frames"], 1),
                           "voxels_updated": n_upd_frame, "final_blocks_rank0": hv.BlockCount()},
@@ -221,13 +228,17 @@ def main():
                          "shader_cycles_per_launch": kc_cycles, "shader_clock_ghz": kc_cycles / k3_s / 1e9 if k3_s > 0 else None},
         }
     if rank == 0:
-        # ---- everything below is supplementary (rank 0; most of it N = 1 only): one module per section under tools/benchparts/
+        # ---- everything below is supplementary (rank 0; most of it N = 1 only): one module per section under benchparts/
         import types
-        from tools.benchparts import roofline_extras, raycast, volume_ops, host_images, general_update, depth_filter, cpu_baseline, icp, tracking, dense_fusion
+        from benchparts import roofline_extras, raycast, volume_ops, host_images, general_update, depth_filter, cpu_baseline, icp, tracking, dense_fusion
         c = types.SimpleNamespace(args=args, torch=torch, dev=dev, rank=rank, world=world, local_rank=local_rank, hv=hv, depth=depth, rgb=rgb, poses=poses, K=K, F=F,
                                   n_local=n_local, I=I, S=S, ROOT=ROOT, W=W, H=H, HBM_PEAK_GBS=HBM_PEAK_GBS, stats=stats, prof=prof,
                                   frames_per_launch=frames_per_launch, k3_s=k3_s, kc_cycles=kc_cycles, batch_bytes=batch_bytes)
         single = world == 1
+        c.oracle = None
+        if single and not args.no_cpu_baseline:
+            from oracle import oracle as _oracle   # the cpu_baseline leg: the CPU oracle as the timed baseline and the parity checker, never on the measured path
+            c.oracle = _oracle
         if single and not args.timed_only:
             raycast.run(c, out)            # first: the volume still holds the timed region's frames
         if not args.timed_only:

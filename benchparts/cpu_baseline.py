@@ -23,7 +23,7 @@ def _cpu_model():
 def run(c, out):
     args, torch, dev, rank, world, local_rank, hv, depth, rgb, poses, K, F, n_local = c.args, c.torch, c.dev, c.rank, c.world, c.local_rank, c.hv, c.depth, c.rgb, c.poses, c.K, c.F, c.n_local
     I, S, ROOT, W, H, HBM_PEAK_GBS = c.I, c.S, c.ROOT, c.W, c.H, c.HBM_PEAK_GBS
-    from oracle import oracle as O
+    O = c.oracle   # the CPU oracle, imported by bench.py for its cpu_baseline leg (the only place that does)
     ns = min(args.cpu_sample_frames, n_local)
     dn, cn = depth[:ns].cpu().numpy(), rgb[:ns].cpu().numpy()
     ov = O.Volume(voxel_res=args.voxel)

@@ -41,7 +41,7 @@ def run(c, out):
     if world == 1 and not args.no_cpu_baseline:
         # the same pipeline on one host core (the reference's tracker and integrator are serial): 4 frames fused, then tracking alone
         # over a 24-frame prefix for the pose-chain parity
-        from oracle import oracle as O
+        O = c.oracle   # the CPU oracle, imported by bench.py for its cpu_baseline leg (the only place that does)
         ocam = O.make_camera()
         ovol = O.Volume(ocam, voxel_res=0.005)
         n_par = min(24, n_df)

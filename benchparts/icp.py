@@ -71,7 +71,7 @@ def run(c, out):
                   # a latency-bound gather (27-cell scan), so this is far from the HBM roof by construction
                   "algorithmic_gbs": 36.0 * len(src) * gpu_it_s / 1e9}
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
+        O = c.oracle   # the CPU oracle, imported by bench.py for its cpu_baseline leg (the only place that does)
         t = time.perf_counter()
         ref = O.icp(src, tgt, nrm, None, 10, 0.01, True)
         cpu_it_s = 10 / (time.perf_counter() - t)

@@ -67,7 +67,7 @@ def run(c, out):
                        "correspondences": int(tres.n_correspondences), "tracking_success": bool(tres.tracking_success),
                        "input": "pyramids resident in HBM (boundary = Odometry::MultiScaleComputing inputs)"}
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
+        O = c.oracle   # the CPU oracle, imported by bench.py for its cpu_baseline leg (the only place that does)
         O.dense_track(levels, (4, 8, 16), term=0)
         t = time.perf_counter()
         for _ in range(5):

@@ -1,10 +1,11 @@
 // MultiGpuSequenceIntegration.cpp -- BASELINE configs[4] from a C++ host: the frames of a sequence directory are
 // sharded contiguously over N GPUs of one node (one host thread + one CubeHandler-style volume per device, zero
-// communication while fusing), then merged into GPU 0's volume with ONE RCCL reduce (op_volume_merge_rccl).
-// Single process, ncclCommInitAll.  With N = 1 the merge is the identity (or, with ONEPIECE_RCCL_FORCE=1, a
-// one-rank all-gather + reduce that exercises the RCCL path on a single-GPU box).
+// communication while fusing), then merged into GPU 0's volume over RCCL (op_volume_merge_rccl: the owner-partitioned
+// exchange by default, --dense for the one sliced reduce of the whole union).
+// Single process, ncclCommInitAll.  With N = 1 the merge is the identity (or, with --force-exchange, the whole
+// exchange with a one-rank communicator, which exercises the RCCL path on a single-GPU box).
 //
-//   MultiGpuSequenceIntegration <dataset_path> [--gpus N] [--voxel 0.005] [--map out.map]
+//   MultiGpuSequenceIntegration <dataset_path> [--gpus N] [--voxel 0.005] [--map out.map] [--dense] [--slice-blocks n] [--force-exchange]
 #include <rccl/rccl.h>
 
 #include <chrono>
@@ -31,6 +32,9 @@ int main(int argc, char* argv[]) {
         if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--voxel") && i + 1 < argc) voxel = static_cast<float>(std::atof(argv[++i]));
         else if (!std::strcmp(argv[i], "--map") && i + 1 < argc) map_file = argv[++i];
+        else if (!std::strcmp(argv[i], "--dense")) op_runtime_set_option(OP_RUNTIME_OPT_MERGE_ALGORITHM, OP_MERGE_DENSE_REDUCE);
+        else if (!std::strcmp(argv[i], "--slice-blocks") && i + 1 < argc) op_runtime_set_option(OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS, std::atoll(argv[++i]));
+        else if (!std::strcmp(argv[i], "--force-exchange")) op_runtime_set_option(OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK, 1);
     }
     int available = 0;
     op_device_count(&available);
@@ -93,7 +97,9 @@ int main(int argc, char* argv[]) {
     for (int g = 0; g < gpus; ++g)
         std::cout << (g ? ", " : "") << "{\"rank\": " << mstats[g].rank << ", \"rccl_ranks\": " << mstats[g].ranks << ", \"local_blocks\": " << local_blocks[g]
                   << ", \"fusion_ms\": " << fuse_ms[g] << ", \"merge_ms\": " << mstats[g].total_ms << ", \"merge_prepare_ms\": " << mstats[g].prepare_ms
-                  << ", \"merge_transfer_ms\": " << mstats[g].transfer_ms << ", \"merge_bytes\": " << mstats[g].reduce_bytes << ", \"slices\": " << mstats[g].slices << "}";
+                  << ", \"merge_transfer_ms\": " << mstats[g].transfer_ms << ", \"merge_bytes\": " << mstats[g].reduce_bytes << ", \"slices\": " << mstats[g].slices
+                  << ", \"algorithm\": " << mstats[g].algorithm << ", \"held_blocks\": " << mstats[g].held_blocks << ", \"owned_blocks\": " << mstats[g].owned_blocks
+                  << ", \"wire_bytes_sent\": " << mstats[g].wire_bytes_sent << ", \"wire_bytes_received\": " << mstats[g].wire_bytes_received << "}";
     std::cout << "], \"ok\": " << (bad ? "false" : "true") << "}" << std::endl;
     for (int g = 0; g < gpus; ++g) { if (vols[g]) op_volume_destroy(vols[g]); ncclCommDestroy(comms[g]); }
     return bad;

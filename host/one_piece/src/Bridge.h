@@ -21,7 +21,12 @@ inline geometry::Matrix4 FromRowMajor(const float in[16]) {
 }
 // the reference tests `depth.depth() == CV_32FC1` and treats everything else as unsigned short (Integrator.cpp:26-29)
 inline int DepthFormat(const cv::Mat& depth) { return depth.depth() == CV_32F ? OP_DEPTH_F32 : OP_DEPTH_U16; }
+// Every device object of the class surface is created through this call -- which is therefore where the surface makes its one explicit runtime
+// request, before its first object touches HIP: eight hardware queues (op_runtime_configure: the pipelined tracker's streams must not share a
+// queue; a value the application has set is never overwritten).  The C-ABI library itself changes nothing in the process on its own.
 inline int Device() {
+    static const int configured = op_runtime_configure(8);
+    (void)configured;
     const char* e = std::getenv("ONEPIECE_HIP_DEVICE");
     return e ? std::atoi(e) : 0;
 }

@@ -60,11 +60,34 @@ typedef struct op_tracker op_tracker; /* dense RGB-D tracker workspace (stream, 
 /* ---- library ----------------------------------------------------------------------------- */
 int op_abi_version(void);
 const char *op_last_error(void);
-/* Hardware queues the HIP runtime was asked for (GPU_MAX_HW_QUEUES).  Every volume and every tracker owns a stream, and streams that
- * share a hardware queue serialise; the library therefore sets the variable to 8 when it is LOADED unless the caller has set it (the
- * runtime reads it at its first API call: load or link the library before the process touches HIP).  Four tracker streams + one
- * fusing volume need five queues for the pipelined tracking + fusion rate quoted in DESIGN.md. */
+/* ---- process-wide settings.  The library reads nothing from the environment and changes nothing in it on its own (rounds 1-4 set
+ * GPU_MAX_HW_QUEUES from a load-time constructor and took test hooks from ONEPIECE_* variables): a host opts in through these calls.
+ *
+ * op_runtime_configure(hw_queues): every volume and every tracker owns a HIP stream, and streams that share a hardware queue serialise;
+ *   the runtime maps streams onto 4 queues unless GPU_MAX_HW_QUEUES says otherwise, and reads that variable ONCE, at its first API call.
+ *   This call sets it (never overwriting a value the caller has set) -- to be made before the process touches HIP; the C++ class surface
+ *   (host/one_piece) makes it when its first device object is constructed, the Python package before it loads the library.  Four tracker
+ *   streams + one fusing volume need five queues for the pipelined tracking + fusion rate quoted in DESIGN.md.
+ * op_runtime_hw_queues: what is in the variable now (4 = the runtime's default when unset); whether the runtime had already read it cannot be known. */
+int op_runtime_configure(int hw_queues);
 int op_runtime_hw_queues(int *requested);
+/* op_runtime_set_option:
+ *   OP_RUNTIME_OPT_MERGE_ALGORITHM        OP_MERGE_OWNER_EXCHANGE (default) / OP_MERGE_DENSE_REDUCE -- see op_volume_merge_rccl
+ *   OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS     union blocks per reduce slice of the dense merge (0 = the built-in 32 768; tests force several slices)
+ *   OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK  1: run the whole exchange with a one-rank communicator too (how a one-GPU box exercises the RCCL path)
+ *   OP_RUNTIME_OPT_TRACKER_GRAPH          0: trackers created afterwards issue plain launches instead of replaying a captured hipGraph
+ *   OP_RUNTIME_OPT_COPY_THREADS           0 .. 8 helper threads of the pageable -> pinned staging copies (before the first host image)
+ * op_runtime_set_rccl_library(path): the RCCL to bind at the first merge instead of "librccl.so.1" (a site build; the test suite names a
+ *   host-memory double that runs several ranks on one device); NULL = the system's.  Fails once RCCL has been bound. */
+#define OP_RUNTIME_OPT_MERGE_ALGORITHM 0
+#define OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS 1
+#define OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK 2
+#define OP_RUNTIME_OPT_TRACKER_GRAPH 3
+#define OP_RUNTIME_OPT_COPY_THREADS 4
+#define OP_MERGE_OWNER_EXCHANGE 0
+#define OP_MERGE_DENSE_REDUCE 1
+int op_runtime_set_option(int option, long long value);
+int op_runtime_set_rccl_library(const char *path);
 /* Images that are used more than once -- a frame is tracked against twice and fused once (example/DenseFusion/DenseSlam.cpp:24-33,
  * DenseFusion.cpp:86-96) -- can be brought to the device ONCE and then handed to op_tracker_dense_tracking(_enqueue) /
  * op_volume_integrate with OP_MEM_DEVICE.
@@ -275,7 +298,7 @@ int op_volume_read_file(op_volume *v, const char *path, int legacy_float_format)
 /* TSDF ray casting (north_star "integrate/raycast").  NO reference counterpart: OnePiece has no
  * raycast (its closest relative is the trilinear gather of VoxelCube::ReadVoxelInterpolate,
  * Integration/VoxelCube.cpp:6-50), so the definition is this library's own, restated on the CPU in
- * oracle/onepiece_oracle.c and validated against the analytic synthetic scene.  For every pixel (u, v) of
+ * the test suite's CPU checker and validated against the analytic synthetic scene.  For every pixel (u, v) of
  * `cam` (NULL = the volume's camera) at camera-to-world `pose`:
  *   ray      origin = the pose's translation, direction d = R ((u - cx) / fx, (v - cy) / fy, 1): the parameter t is the z-depth;
  *   lattice  t_k = near + k * res for k = 0, 1, ... while t_k <= far;  p_k = origin + t_k d;
@@ -310,20 +333,30 @@ int op_volume_unpack_sum(op_volume *v, const int32_t *d_union_keys, size_t n_uni
  * union blocks [first, first + count) from a buffer holding just those (count x 5 x 512 floats). */
 int op_volume_unpack_sum_begin(op_volume *v, const int32_t *d_union_keys, size_t n_union);
 int op_volume_unpack_sum_chunk(op_volume *v, size_t first, size_t count, const float *d_sum_chunk);
-/* The whole merge as ONE call for a C/C++ host: all-gather of the per-rank block keys over RCCL, the
- * identical sorted union on every rank, sum-form pack, ONE ncclReduce(float32, sum) to `root`, normalisation on the
- * root -- i.e. CubeHandler::Merge (CubeHandler.h:145-167) across the ranks of a communicator.  nccl_comm is an
- * ncclComm_t whose rank owns the volume's device; call from one host thread (or process) per rank.  Non-root volumes
- * are left untouched.  *n_union (may be NULL) = number of blocks in the merged volume.  RCCL is bound at run time
- * (dlopen), so the library does not need it until this entry point is used. */
+/* The whole merge as ONE call for a C/C++ host: CubeHandler::Merge (CubeHandler.h:145-167) across the ranks of a
+ * communicator.  nccl_comm is an ncclComm_t whose rank owns the volume's device; call from one host thread (or process) per rank.
+ * *n_union (may be NULL) = number of blocks in the merged map.  RCCL is bound at run time (dlopen), so the library does not need it
+ * until this entry point is used.  Two algorithms (OP_RUNTIME_OPT_MERGE_ALGORITHM):
+ *   OP_MERGE_OWNER_EXCHANGE (default): every block key has an owner rank (a hash of the key); each rank sends the blocks it HOLDS, in sum
+ *     form, to their owners (one group of ncclSend / ncclRecv over all pairs), the owners add them up in rank order; then
+ *       root >= 0: the owners send their partitions to the root, which normalises the whole map into its volume (the others' volumes
+ *                  are left untouched) -- the reference's Merge semantics;
+ *       root == -1: no gather -- every rank's volume is REPLACED by its owned, merged partition (a distributed map).
+ *   OP_MERGE_DENSE_REDUCE: all-gather of the keys, the same sorted union on every rank, every rank packs the whole union (zeros where it
+ *     holds nothing), ONE sliced ncclReduce(float32, sum) to `root` (>= 0), normalisation on the root. */
 int op_volume_merge_rccl(op_volume *v, void *nccl_comm, int root, size_t *n_union);
-/* The same call, reporting how the time was spent (for the N > 1 bench line): ranks / rank of the communicator, blocks
- * in the union, bytes this rank put into the reduce, the number of reduce slices, host wall time of the preparation
- * (all-gathers, union), of the pack / reduce / normalise pipeline, and of the whole call, in milliseconds. */
+/* The same call, reporting what was moved and how the time was spent (for the N > 1 bench line): ranks / rank of the communicator, blocks
+ * in the union, the number of reduce slices (dense) and the bytes this rank put into the reduce / the exchange, host wall time of the
+ * preparation, of the transfer pipeline, and of the whole call in milliseconds; the algorithm that ran; the blocks this rank HELD, the blocks
+ * it OWNS after the exchange (dense: the union on the root, 0 elsewhere) and the payload bytes it sent / received over the wire (keys included;
+ * the few-word agreements excluded).  Owner exchange: sent = (blocks held of OTHER ranks' partitions) x 10 248 B (+ its summed partition
+ * when a root gathers) -- on average held x 10 248 x (world - 1) / world. */
 typedef struct op_merge_stats {
     int32_t ranks, rank;
     uint64_t union_blocks, reduce_bytes, slices;
     double prepare_ms, transfer_ms, total_ms;
+    int32_t algorithm, pad_;
+    uint64_t held_blocks, owned_blocks, wire_bytes_sent, wire_bytes_received;
 } op_merge_stats;
 int op_volume_merge_rccl_stats(op_volume *v, void *nccl_comm, int root, size_t *n_union, op_merge_stats *stats);
 

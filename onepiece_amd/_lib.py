@@ -30,7 +30,9 @@ class Camera(C.Structure):
 class MergeStats(C.Structure):
     """op_merge_stats of op_volume_merge_rccl_stats."""
     _fields_ = [("ranks", C.c_int32), ("rank", C.c_int32), ("union_blocks", C.c_uint64), ("reduce_bytes", C.c_uint64), ("slices", C.c_uint64),
-                ("prepare_ms", C.c_double), ("transfer_ms", C.c_double), ("total_ms", C.c_double)]
+                ("prepare_ms", C.c_double), ("transfer_ms", C.c_double), ("total_ms", C.c_double),
+                ("algorithm", C.c_int32), ("pad_", C.c_int32), ("held_blocks", C.c_uint64), ("owned_blocks", C.c_uint64),
+                ("wire_bytes_sent", C.c_uint64), ("wire_bytes_received", C.c_uint64)]
 
 
 class IcpResult(C.Structure):
@@ -57,6 +59,8 @@ OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_EXACT, OP_VOLUME_UPDATE_SUM_FORM = 0, 0, 1
 OP_VOLUME_OPT_SELECT, OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT = 1, 0, -1
 OP_VOLUME_OPT_RAYCAST_PRUNE = 2
+OP_RUNTIME_OPT_MERGE_ALGORITHM, OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS, OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK, OP_RUNTIME_OPT_TRACKER_GRAPH, OP_RUNTIME_OPT_COPY_THREADS = 0, 1, 2, 3, 4
+OP_MERGE_OWNER_EXCHANGE, OP_MERGE_DENSE_REDUCE = 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
 OP_ICP_OPT_FINISH, OP_ICP_OPT_SUMS = 0, 1
@@ -76,6 +80,9 @@ SIGNATURES = {
     "op_abi_version": (C.c_int, []),
     "op_last_error": (C.c_char_p, []),
     "op_runtime_hw_queues": (C.c_int, [C.POINTER(C.c_int)]),
+    "op_runtime_configure": (C.c_int, [C.c_int]),
+    "op_runtime_set_option": (C.c_int, [C.c_int, C.c_longlong]),
+    "op_runtime_set_rccl_library": (C.c_int, [C.c_char_p]),
     "op_device_alloc": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(_vp)]),
     "op_device_write": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]),
     "op_device_upload": (C.c_int, [_vp, C.c_size_t, C.c_int, C.POINTER(_vp)]),

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -13,6 +14,18 @@
 namespace op {
 
 extern thread_local char g_last_error[512];
+
+// Process-wide settings (op_runtime_set_option; defined in volume.hip).  The library reads NOTHING from the environment and changes nothing in it:
+// what rounds 1-4 took from ONEPIECE_* variables or set at load time is set through the C-ABI by whoever wants it.
+struct RuntimeOptions {
+    std::atomic<int> merge_algorithm{OP_MERGE_OWNER_EXCHANGE};
+    std::atomic<long long> merge_slice_blocks{0};      // union blocks per reduce slice of the dense merge; 0 = the built-in 32 768
+    std::atomic<int> merge_force_single_rank{0};       // run the whole exchange with one rank too (how a one-GPU box exercises the RCCL path)
+    std::atomic<int> tracker_graph{1};                 // dense tracker: replay the captured hipGraph of a track (0: plain launches)
+    std::atomic<int> copy_threads{2};                  // helper threads of the pageable -> pinned staging copies (read when the first host image arrives)
+    std::atomic<int> hw_queues_requested{0};           // op_runtime_configure
+};
+RuntimeOptions& runtime_options();
 
 inline int fail(int code, const char* fmt, ...) {
     va_list ap;

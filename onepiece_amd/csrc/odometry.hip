@@ -956,7 +956,7 @@ int op_tracker_create(int device, op_tracker** out) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_sums<2, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(2, 2, 1)) == hipSuccess &&
                 (size_t)lds_max >= seq_lds_bytes(42, 14, 2);
     if (!t->seq_ok) (void)hipGetLastError();
-    if (const char* e = std::getenv("ONEPIECE_TRACKER_GRAPH")) t->graph_ok = std::atoi(e) != 0;
+    if (!op::runtime_options().tracker_graph.load()) t->graph_ok = 0; // OP_RUNTIME_OPT_TRACKER_GRAPH
     *out = t;
     return OP_OK;
 }

@@ -39,12 +39,9 @@ namespace op {
 thread_local char g_last_error[512] = "";
 }
 
-// Load-time defaults of the HIP runtime this library relies on.  Every volume and every tracker owns a HIP stream; the runtime maps
-// streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and streams that share a queue serialise: four trackers in
-// flight + the fusing volume reach 2.6 k frames/s on 4 queues and 4.5 k on 8.  The runtime reads the variable when
-// it initialises (its first API call), so setting it when this library is LOADED is early enough for every consumer that links it or
-// dlopens it before touching HIP; a value the caller has set is never overwritten.  op_runtime_hw_queues() reports what is in force.
-__attribute__((constructor)) static void op_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+namespace op {
+RuntimeOptions& runtime_options() { static RuntimeOptions o; return o; }
+}
 
 namespace {
 
@@ -429,7 +426,7 @@ class CopyPool {
     struct Job { char* d; const char* s; size_t n; };
     CopyPool() {
         int n = 2;
-        if (const char* e = std::getenv("ONEPIECE_HIP_COPY_THREADS")) n = std::atoi(e);
+        n = op::runtime_options().copy_threads.load(); // OP_RUNTIME_OPT_COPY_THREADS
         if ((int)std::thread::hardware_concurrency() <= 2) n = 0;
         for (int i = 0; i < n && i < 8; ++i) helpers_.emplace_back([this] { loop(); });
     }
@@ -650,10 +647,39 @@ int op_device_release(void* device_ptr, int device) {
 
 int op_runtime_hw_queues(int* requested) {
     if (!requested) return fail(OP_ERR_INVALID, "null argument");
-    const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+    const char* e = std::getenv("GPU_MAX_HW_QUEUES"); // (reading the runtime's own variable to REPORT it; nothing of the library's behaviour depends on it)
     *requested = e ? std::atoi(e) : 4; // 4 = the runtime's own default
     return OP_OK;
 }
+
+int op_runtime_configure(int hw_queues) {
+    if (hw_queues < 1 || hw_queues > 64) return fail(OP_ERR_INVALID, "op_runtime_configure: %d hardware queues", hw_queues);
+    char buf[16];
+    std::snprintf(buf, sizeof(buf), "%d", hw_queues);
+    if (setenv("GPU_MAX_HW_QUEUES", buf, /*overwrite=*/0) != 0) return fail(OP_ERR_INVALID, "op_runtime_configure: setenv failed");
+    op::runtime_options().hw_queues_requested.store(hw_queues);
+    return OP_OK;
+}
+
+int op_runtime_set_option(int option, long long value) {
+    op::RuntimeOptions& o = op::runtime_options();
+    switch (option) {
+        case OP_RUNTIME_OPT_MERGE_ALGORITHM:
+            if (value != OP_MERGE_OWNER_EXCHANGE && value != OP_MERGE_DENSE_REDUCE) return fail(OP_ERR_INVALID, "op_runtime_set_option: unknown merge algorithm %lld", value);
+            o.merge_algorithm.store((int)value); return OP_OK;
+        case OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS:
+            if (value < 0) return fail(OP_ERR_INVALID, "op_runtime_set_option: slice size %lld", value);
+            o.merge_slice_blocks.store(value); return OP_OK;
+        case OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK: o.merge_force_single_rank.store(value != 0); return OP_OK;
+        case OP_RUNTIME_OPT_TRACKER_GRAPH: o.tracker_graph.store(value != 0); return OP_OK;
+        case OP_RUNTIME_OPT_COPY_THREADS:
+            if (value < 0 || value > 8) return fail(OP_ERR_INVALID, "op_runtime_set_option: %lld copy threads (0 .. 8)", value);
+            o.copy_threads.store((int)value); return OP_OK;
+        default: break;
+    }
+    return fail(OP_ERR_INVALID, "op_runtime_set_option: unknown option %d", option);
+}
+
 const char* op_last_error(void) { return op::g_last_error; }
 
 int op_device_count(int* count) {

@@ -1,18 +1,25 @@
 """Frame-sharded multi-GPU fusion: shard frames across ranks, fuse locally with zero communication,
-merge the per-GPU voxel-block hashes once at the end with a single RCCL reduce.
+merge the per-GPU voxel-block hashes once at the end over RCCL.
 
 This is the distributed form of CubeHandler::Merge (/root/reference/src/Integration/CubeHandler.h:
-145-167): key union + per-voxel weighted mean.  The reference has no communication layer; the
-exchange below is designed for xGMI:
+145-167): key union + per-voxel weighted mean -- and, like the reference's Merge, it only touches blocks
+somebody HOLDS.  The reference has no communication layer; the exchange is designed for xGMI,
+which is point to point (7 links per GPU).  Two algorithms, the same two as op_volume_merge_rccl (csrc/merge_rccl.hip):
 
-  1. all_gather the per-rank block counts and (padded) int32x3 key arrays    -- 12 B / block
-  2. every rank builds the same sorted union of keys (deterministic, no communication)
-  3. each rank packs its blocks into union order in SUM form [w*sdf, w, w*c0, w*c1, w*c2]
-     (HIP kernel k_pack_sum; zeros where the rank has no data)               -- 10 KiB / block
-  4. ONE reduce(SUM, fp32) to the root over RCCL                              -- the only bulk transfer
-  5. the root normalises back to mean form (HIP kernel k_unpack_sum).
+  "owner" (default) -- every block key has an owner rank (a hash of the key mod the number of ranks):
+    1. a rank sorts its keys by owner and packs its blocks in that order in SUM form [w*sdf, w, w*c0, w*c1, w*c2]
+       (HIP kernel k_pack_sum)                                                                    -- 10 KiB / block HELD
+    2. all_gather of the world x world matrix of counts, then one batch of point-to-point sends / receives: each rank
+       sends every other rank the keys and blocks it holds of that rank's partition -- (world - 1) / world of what it
+       holds crosses the wire, over its links to all peers at once
+    3. the owner builds the sorted union of its partition and adds the received blocks into it source by source in
+       rank order (deterministic)
+    4. root given: the owners send their summed partitions to the root, which normalises the whole map into its volume
+       (HIP kernel k_unpack_sum); root None: every rank's volume becomes its owned, merged partition.
+  "dense" (rounds 1-4, the fallback) -- all_gather the padded key arrays, the same sorted union on every rank, every rank
+    packs the WHOLE union (zeros where it holds nothing), ONE sliced reduce(SUM, fp32) to the root, normalise.
 
-With 2 ranks step 3-5 evaluate exactly TSDFVoxel::operator+ ((w1*s1 + w2*s2)/(w1+w2)); with more
+With 2 ranks both evaluate exactly TSDFVoxel::operator+ ((w1*s1 + w2*s2)/(w1+w2)); with more
 ranks the summation order differs from a sequential Merge chain only in fp32 rounding (weights and
 keys stay exact).  ICP does not shard (one pose chain): replicas only.
 
@@ -72,8 +79,135 @@ def _forced():
     return os.environ.get("ONEPIECE_MERGE_FORCE") == "1"
 
 
-def merge_volumes(ops, root=0, group=None, chunk_blocks=32768):
-    """Merge every rank's volume into `root`'s.  Returns the number of union blocks.
+last_stats = {}   # what the last merge_volumes call of this process moved (bench.py's multi_gpu object)
+
+_BLOCK_BYTES = 10240 + 8   # a sum-form block + its packed key
+
+
+def _pack64(keys):
+    """int32 x 3 block ids -> one int64 each (3 x 21 bits: the packing of the device hash table; the packed order is the lexicographic one)."""
+    import torch
+    k = keys.to(torch.int64) + (1 << 20)
+    return (k[:, 0] << 42) | (k[:, 1] << 21) | k[:, 2]
+
+
+def _unpack64(packed):
+    import torch
+    off = 1 << 20
+    return torch.stack([(packed >> 42) - off, ((packed >> 21) & 0x1FFFFF) - off, (packed & 0x1FFFFF) - off], dim=1).to(torch.int32).contiguous()
+
+
+def owner_of(packed, world):
+    """Owner rank of a block: a finalising mix of its packed id, mod the number of ranks (= owner_of of csrc/merge_rccl.hip; int64 arithmetic
+    wraps like uint64's, the shifts are made logical by masking)."""
+    p = packed.clone()
+    p = p ^ ((p >> 33) & 0x7FFFFFFF)
+    p = p * (-49064778989728563)            # 0xff51afd7ed558ccd
+    p = p ^ ((p >> 33) & 0x7FFFFFFF)
+    p = p * (-4265267296055464877)          # 0xc4ceb9fe1a85ec53
+    p = p ^ ((p >> 33) & 0x7FFFFFFF)
+    # unsigned p mod world from the signed representation: p_u = 2 * (p >>> 1) + (p & 1)
+    half = (p >> 1) & 0x7FFFFFFFFFFFFFFF
+    return ((half % world) * 2 + (p & 1)) % world
+
+
+def _merge_owner_exchange(ops, dist, root, group, world, rank):
+    import torch
+    keys = ops.keys().contiguous()
+    dev = keys.device
+    n_local = int(keys.shape[0])
+    packed = _pack64(keys) if n_local else torch.zeros((0,), dtype=torch.int64, device=dev)
+    own = owner_of(packed, world) if n_local else packed
+    order = torch.argsort(own, stable=True)
+    packed = packed[order].contiguous()
+    counts = torch.bincount(own, minlength=world).to(torch.int64) if n_local else torch.zeros((world,), dtype=torch.int64, device=dev)
+    # 1. my blocks in owner order, sum form
+    sync = (lambda: torch.cuda.current_stream(dev).synchronize()) if keys.is_cuda else (lambda: None)
+    skeys = _unpack64(packed) if n_local else keys
+    sync()
+    send = ops.pack_sum(skeys).contiguous() if n_local else torch.zeros((0, 5, 512), dtype=torch.float32, device=dev)
+    # 2. the matrix of counts
+    rows = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(rows, counts, group=group)
+    matrix = torch.stack(rows).cpu().numpy()                 # matrix[s][d]: blocks s holds of d's partition
+    bounds = np.concatenate([[0], np.cumsum(matrix[rank])]).astype(np.int64)
+    roff = np.concatenate([[0], np.cumsum(matrix[:, rank])]).astype(np.int64)
+    n_recv = int(roff[-1])
+    rkeys = torch.empty((n_recv,), dtype=torch.int64, device=dev)
+    rpay = torch.empty((n_recv, 5, 512), dtype=torch.float32, device=dev)
+    # 3. the exchange: one batch of point-to-point operations over all pairs
+    p2p, sent, received = [], 0, 0
+    for p in range(world):
+        lo, hi = int(bounds[p]), int(bounds[p + 1])
+        rlo, rhi = int(roff[p]), int(roff[p + 1])
+        if p == rank:
+            if hi > lo:
+                rkeys[rlo:rhi] = packed[lo:hi]; rpay[rlo:rhi] = send[lo:hi]
+            continue
+        if hi > lo:
+            p2p += [dist.P2POp(dist.isend, packed[lo:hi], p, group), dist.P2POp(dist.isend, send[lo:hi], p, group)]
+            sent += (hi - lo) * _BLOCK_BYTES
+        if rhi > rlo:
+            p2p += [dist.P2POp(dist.irecv, rkeys[rlo:rhi], p, group), dist.P2POp(dist.irecv, rpay[rlo:rhi], p, group)]
+            received += (rhi - rlo) * _BLOCK_BYTES
+    sync()   # the pack kernel ran on the volume's stream; torch's collectives are ordered on torch's
+    if p2p:
+        for w in dist.batch_isend_irecv(p2p):
+            w.wait()
+    # 4. the partition's sorted union, and the sum over the sources in rank order
+    uni, inv = torch.unique(rkeys, sorted=True, return_inverse=True) if n_recv else (rkeys, rkeys)
+    n_own = int(uni.shape[0])
+    acc = torch.zeros((n_own, 5, 512), dtype=torch.float32, device=dev)
+    for s_ in range(world):
+        lo, hi = int(roff[s_]), int(roff[s_ + 1])
+        if hi > lo:
+            acc.index_add_(0, inv[lo:hi], rpay[lo:hi])       # a source holds a key once: no two rows of one call meet
+    del rpay, send
+    # 5. sizes of the partitions
+    mine = torch.tensor([n_own], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    owned = [int(x.item()) for x in sizes]
+    n_union = sum(owned)
+    if root is None:
+        sync()
+        ops.unpack_sum(_unpack64(uni) if n_own else keys[:0], acc)      # my volume = my owned, merged partition
+    else:
+        goff = np.concatenate([[0], np.cumsum(owned)]).astype(np.int64)
+        p2p = []
+        if rank == root:
+            gk = torch.empty((n_union,), dtype=torch.int64, device=dev)
+            gp = torch.empty((n_union, 5, 512), dtype=torch.float32, device=dev)
+            for r_ in range(world):
+                lo, hi = int(goff[r_]), int(goff[r_ + 1])
+                if hi == lo:
+                    continue
+                if r_ == rank:
+                    gk[lo:hi] = uni; gp[lo:hi] = acc
+                else:
+                    p2p += [dist.P2POp(dist.irecv, gk[lo:hi], r_, group), dist.P2POp(dist.irecv, gp[lo:hi], r_, group)]
+                    received += (hi - lo) * _BLOCK_BYTES
+        elif n_own:
+            p2p += [dist.P2POp(dist.isend, uni.contiguous(), root, group), dist.P2POp(dist.isend, acc, root, group)]
+            sent += n_own * _BLOCK_BYTES
+        if p2p:
+            for w in dist.batch_isend_irecv(p2p):
+                w.wait()
+        if rank == root:
+            allk = _unpack64(gk) if n_union else keys[:0]
+            sync()
+            ops.unpack_sum(allk, gp)
+    last_stats.clear()
+    last_stats.update({"algorithm": "owner", "ranks": world, "rank": rank, "held_blocks": n_local, "owned_blocks": n_own, "union_blocks": n_union,
+                       "wire_bytes_sent": int(sent), "wire_bytes_received": int(received)})
+    return n_union
+
+
+def merge_volumes(ops, root=0, group=None, chunk_blocks=32768, algorithm="owner"):
+    """Merge every rank's volume into `root`'s (algorithm "owner" with root=None: into a distributed map, every rank keeping its owned
+    partition).  Returns the number of union blocks; `last_stats` says what crossed the wire.
+
+    "owner": the owner-partitioned exchange of the module docstring.  "dense": the one reduce of the whole union, below.
 
     The one reduce is issued in slices of `chunk_blocks` union blocks (320 MB each): while slice i is on the wire (RCCL's
     own stream), slice i+1 is packed on the volume's stream and slice i-1 is normalised on the root -- the device steps
@@ -88,6 +222,10 @@ def merge_volumes(ops, root=0, group=None, chunk_blocks=32768):
         return int(ops.keys().shape[0])
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if algorithm == "owner":
+        return _merge_owner_exchange(ops, dist, root, group, world, rank)
+    if root is None:
+        raise ValueError("the dense reduce needs a root")
     keys = ops.keys().contiguous()
     dev = keys.device
     # 1. counts, then padded keys
@@ -113,6 +251,10 @@ def merge_volumes(ops, root=0, group=None, chunk_blocks=32768):
     else:
         union = allk
     n_union = int(union.shape[0])
+    last_stats.clear()
+    last_stats.update({"algorithm": "dense", "ranks": world, "rank": rank, "held_blocks": int(keys.shape[0]), "owned_blocks": n_union if rank == root else 0,
+                       "union_blocks": n_union, "wire_bytes_sent": (n_union * 10240 if rank != root else 0) + (world - 1) * mx * 12,
+                       "wire_bytes_received": n_union * 10240 + (world - 1) * mx * 12})
     if n_union == 0:
         return 0
     # `union` was produced by torch ops queued on torch's stream, the pack / unpack kernels run on the volume's own

@@ -2,11 +2,13 @@
 //
 // N host threads = N ranks, every rank with its own volume on device 0, fuse their shards of a frame file (the format of
 // tools/dump_frames.py) through op_volume_integrate (host images) and then call op_volume_merge_rccl_stats on communicators
-// created with ncclCommInitAll of the library ONEPIECE_RCCL_LIBRARY names -- tests/cpp/librccl_double.so on a one-GPU box
-// (the real RCCL refuses two ranks on one device), the real librccl on a multi-GPU node (then rank r runs on device r).
-// The root writes its merged volume as a .map file; the caller compares it with a sequential CubeHandler::Merge chain.
+// created with ncclCommInitAll of the library --rccl-library names (handed to the product with op_runtime_set_rccl_library) --
+// tests/cpp/librccl_double.so on a one-GPU box (the real RCCL refuses two ranks on one device), the real librccl on a multi-GPU
+// node (then rank r runs on device r).  The root writes its merged volume as a .map file; with --root -1 (owner exchange without a
+// gather) every rank writes its owned partition as <out.map>.rank<r>.  The caller compares with a sequential CubeHandler::Merge chain.
 //
 //   merge_world <frames.bin> <out.map> --shards "0-10,10-13,13-13,13-40" [--voxel 0.02] [--root 0] [--fail-rank r] [--devices N]
+//               [--rccl-library path] [--algorithm owner|dense] [--slice-blocks n]
 //
 // --shards: one "first-last" (last exclusive) per rank; an empty range = a rank with nothing to contribute.
 // --fail-rank r: rank r fuses a frame no volume can hold (a bounding box of 10 km), so that it ENTERS the merge with a failed volume:
@@ -30,12 +32,17 @@ int main(int argc, char** argv) {
     std::string shards_arg;
     float voxel = 0.02f;
     int root = 0, fail_rank = -1, devices = 1;
+    std::string rccl_library, algorithm = "owner";
+    long long slice_blocks = 0;
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--shards") && i + 1 < argc) shards_arg = argv[++i];
         else if (!strcmp(argv[i], "--voxel") && i + 1 < argc) voxel = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--root") && i + 1 < argc) root = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fail-rank") && i + 1 < argc) fail_rank = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--rccl-library") && i + 1 < argc) rccl_library = argv[++i];
+        else if (!strcmp(argv[i], "--algorithm") && i + 1 < argc) algorithm = argv[++i];
+        else if (!strcmp(argv[i], "--slice-blocks") && i + 1 < argc) slice_blocks = atoll(argv[++i]);
     }
     std::vector<std::pair<int, int>> shards;
     for (size_t p = 0; p < shards_arg.size();) {
@@ -47,7 +54,10 @@ int main(int argc, char** argv) {
         p = q + 1;
     }
     const int world = (int)shards.size();
-    if (world < 1 || root < 0 || root >= world) { fprintf(stderr, "bad world / root\n"); return 2; }
+    if (world < 1 || root < -1 || root >= world) { fprintf(stderr, "bad world / root\n"); return 2; }
+    if (op_runtime_set_option(OP_RUNTIME_OPT_MERGE_ALGORITHM, algorithm == "dense" ? OP_MERGE_DENSE_REDUCE : OP_MERGE_OWNER_EXCHANGE) != OP_OK ||
+        op_runtime_set_option(OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS, slice_blocks) != OP_OK ||
+        op_runtime_set_rccl_library(rccl_library.empty() ? nullptr : rccl_library.c_str()) != OP_OK) { fprintf(stderr, "%s\n", op_last_error()); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     int hdr[3];
@@ -61,8 +71,7 @@ int main(int argc, char** argv) {
     }
     fclose(f);
     // the communicators come from the same library op_volume_merge_rccl will bind (dlopen returns the same handle)
-    const char* libname = getenv("ONEPIECE_RCCL_LIBRARY");
-    void* lib = dlopen(libname ? libname : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    void* lib = dlopen(rccl_library.empty() ? "librccl.so.1" : rccl_library.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
     auto init_all = (ncclResult_t(*)(ncclComm_t*, int, const int*))dlsym(lib, "ncclCommInitAll");
     auto destroy = (ncclResult_t(*)(ncclComm_t))dlsym(lib, "ncclCommDestroy");
@@ -102,14 +111,23 @@ int main(int argc, char** argv) {
     int bad = 0;
     for (int r = 0; r < world; ++r) bad |= status[(size_t)r] != OP_OK;
     size_t root_blocks = 0;
-    if (!bad) { op_volume_block_count(vols[(size_t)root], &root_blocks); if (op_volume_write_file(vols[(size_t)root], argv[2]) != OP_OK) bad = 1; }
+    if (!bad && root >= 0) { op_volume_block_count(vols[(size_t)root], &root_blocks); if (op_volume_write_file(vols[(size_t)root], argv[2]) != OP_OK) bad = 1; }
+    if (!bad && root < 0)
+        for (int r = 0; r < world; ++r) {
+            size_t nb = 0;
+            op_volume_block_count(vols[(size_t)r], &nb);
+            root_blocks += nb;
+            if (op_volume_write_file(vols[(size_t)r], (std::string(argv[2]) + ".rank" + std::to_string(r)).c_str()) != OP_OK) bad = 1;
+        }
     printf("{\"world\": %d, \"root\": %d, \"ok\": %s, \"root_blocks\": %zu, \"per_rank\": [", world, root, bad ? "false" : "true", root_blocks);
     for (int r = 0; r < world; ++r) {
         std::string e = errors[(size_t)r];
         for (auto& ch : e) if (ch == '"' || ch == '\\') ch = '\'';
-        printf("%s{\"rank\": %d, \"status\": %d, \"error\": \"%s\", \"local_blocks\": %zu, \"union_blocks\": %zu, \"rccl_ranks\": %d, \"rccl_rank\": %d, \"slices\": %llu, \"bytes\": %llu}",
+        printf("%s{\"rank\": %d, \"status\": %d, \"error\": \"%s\", \"local_blocks\": %zu, \"union_blocks\": %zu, \"rccl_ranks\": %d, \"rccl_rank\": %d, \"slices\": %llu, \"bytes\": %llu, "
+               "\"algorithm\": %d, \"held_blocks\": %llu, \"owned_blocks\": %llu, \"wire_bytes_sent\": %llu, \"wire_bytes_received\": %llu}",
                r ? ", " : "", r, status[(size_t)r], e.c_str(), local_blocks[(size_t)r], merged[(size_t)r], ms[(size_t)r].ranks, ms[(size_t)r].rank,
-               (unsigned long long)ms[(size_t)r].slices, (unsigned long long)ms[(size_t)r].reduce_bytes);
+               (unsigned long long)ms[(size_t)r].slices, (unsigned long long)ms[(size_t)r].reduce_bytes, ms[(size_t)r].algorithm, (unsigned long long)ms[(size_t)r].held_blocks,
+               (unsigned long long)ms[(size_t)r].owned_blocks, (unsigned long long)ms[(size_t)r].wire_bytes_sent, (unsigned long long)ms[(size_t)r].wire_bytes_received);
     }
     printf("]}\n");
     for (int r = 0; r < world; ++r) { if (vols[(size_t)r]) op_volume_destroy(vols[(size_t)r]); destroy(comms[(size_t)r]); }

@@ -1,11 +1,11 @@
 // rccl_double.cpp -- TEST INFRASTRUCTURE: a stand-in for the few RCCL entry points op_volume_merge_rccl binds at run time
-// (onepiece_amd/csrc/merge_rccl.hip: ncclCommCount, ncclCommUserRank, ncclAllGather, ncclAllReduce, ncclReduce,
-// ncclGetErrorString) plus ncclCommInitAll / ncclCommDestroy for the driver that creates the communicators.
+// (onepiece_amd/csrc/merge_rccl.hip: ncclCommCount, ncclCommUserRank, ncclAllGather, ncclAllReduce, ncclReduce, ncclSend, ncclRecv,
+// ncclGroupStart, ncclGroupEnd, ncclGetErrorString) plus ncclCommInitAll / ncclCommDestroy for the driver that creates the communicators.
 //
 // Why it exists: the real RCCL refuses two ranks on one device, and the boxes the GPU tests run on have ONE MI355X -- so the
 // multi-rank control flow of op_volume_merge_rccl (padded key all-gather, the ~0 sentinel of the union, the three agreement
 // points, the sliced reduce, root-only unpack) would otherwise only ever execute on an 8-GPU node.  With this library
-// (selected through ONEPIECE_RCCL_LIBRARY, which merge_rccl.hip's dlopen list tries first) N ranks = N host threads of one
+// (named to the library with op_runtime_set_rccl_library before the first merge) N ranks = N host threads of one
 // process, all on device 0, exchange their buffers through host memory.  The product never loads it unless that variable
 // says so; nothing here is a model of RCCL's performance.
 //
@@ -13,6 +13,9 @@
 // result is in recvbuff when the call returns (the double synchronises the stream it is given, copies through the host,
 // and meets the other ranks at a barrier -- a legal, if slow, implementation of stream-ordered completion).  In-place
 // operation (sendbuff inside recvbuff) works as in NCCL.  Sums are formed in rank order, so results are deterministic.
+// Point-to-point: ncclSend / ncclRecv are only supported INSIDE ncclGroupStart / ncclGroupEnd, and every rank of the communicator
+// must close a group (possibly an empty one) for each group any rank closes -- which is how op_volume_merge_rccl uses them: the
+// group's sends go to per-pair host mailboxes, all ranks meet, the receives are served in posting order, all ranks meet again.
 //
 // Build: hipcc -O2 -fPIC -shared tests/cpp/rccl_double.cpp -o tests/cpp/librccl_double.so
 #include <hip/hip_runtime.h>
@@ -34,6 +37,7 @@ struct Group {
     uint64_t generation = 0;
     std::vector<std::vector<char>> stage; // one host buffer per rank
     std::vector<size_t> bytes;            // what each rank staged in the current collective
+    std::vector<std::vector<std::vector<char>>> mail; // [src * n + dst]: the messages src sent dst in the current group, in posting order
     int live = 0;                         // communicators not destroyed yet
     void barrier() {
         std::unique_lock<std::mutex> lk(mu);
@@ -44,6 +48,10 @@ struct Group {
 };
 
 struct Comm { Group* g; int rank; };
+
+struct P2P { bool send; void* buf; size_t bytes; int peer; Comm* c; hipStream_t stream; };
+thread_local int tl_depth = 0;           // (a rank is a host thread)
+thread_local std::vector<P2P> tl_ops;
 
 size_t type_size(ncclDataType_t t) {
     switch (t) {
@@ -76,7 +84,9 @@ bool fold_any(void* acc, const void* x, size_t n, ncclDataType_t t, ncclRedOp_t 
 }
 
 // every rank: wait for the stream, copy `bytes` of sendbuff to its host slot, meet the others
+Comm*& last_comm();
 ncclResult_t stage_in(Comm* c, const void* sendbuff, size_t bytes, hipStream_t stream) {
+    last_comm() = c;
     Group* g = c->g;
     ncclResult_t rc = ncclSuccess;
     if (hipStreamSynchronize(stream) != hipSuccess) rc = ncclUnhandledCudaError;
@@ -88,6 +98,8 @@ ncclResult_t stage_in(Comm* c, const void* sendbuff, size_t bytes, hipStream_t s
     return rc;
 }
 
+Comm*& last_comm() { static thread_local Comm* c = nullptr; return c; } // the communicator of an EMPTY group is not known from its operations: the last one this rank's thread used
+
 } // namespace
 
 extern "C" {
@@ -98,6 +110,7 @@ ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
     Group* g = new Group();
     g->n = ndev; g->live = ndev;
     g->stage.resize((size_t)ndev); g->bytes.assign((size_t)ndev, 0);
+    g->mail.resize((size_t)ndev * ndev);
     for (int r = 0; r < ndev; ++r) comms[r] = (ncclComm_t) new Comm{g, r};
     return ncclSuccess;
 }
@@ -170,6 +183,58 @@ ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, nccl
 
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) {
     return reduce_impl(sendbuff, recvbuff, count, datatype, op, -1, comm, stream);
+}
+
+ncclResult_t ncclGroupStart(void) { ++tl_depth; return ncclSuccess; }
+
+static ncclResult_t post(bool send, void* buf, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    Comm* c = (Comm*)comm;
+    const size_t ts = type_size(datatype);
+    if (!c || !ts || peer < 0 || peer >= c->g->n || peer == c->rank) return ncclInvalidArgument;
+    if (tl_depth <= 0) return ncclInvalidUsage; // the double serves point-to-point calls at ncclGroupEnd, where all ranks meet
+    tl_ops.push_back(P2P{send, buf, count * ts, peer, c, stream});
+    return ncclSuccess;
+}
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    return post(true, const_cast<void*>(sendbuff), count, datatype, peer, comm, stream);
+}
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    return post(false, recvbuff, count, datatype, peer, comm, stream);
+}
+
+// The communicator of an EMPTY group is not known from its operations: the double remembers the last communicator a rank's thread used.
+ncclResult_t ncclGroupEnd(void) {
+    if (tl_depth <= 0) return ncclInvalidUsage;
+    if (--tl_depth > 0) return ncclSuccess;
+    std::vector<P2P> ops;
+    ops.swap(tl_ops);
+    Comm* c = ops.empty() ? last_comm() : ops[0].c;
+    if (!c) return ncclInvalidUsage;
+    Group* g = c->g;
+    ncclResult_t rc = ncclSuccess;
+    const size_t n = (size_t)g->n, me = (size_t)c->rank;
+    for (const P2P& o : ops) {
+        if (o.c != c) { rc = ncclInvalidArgument; continue; }
+        if (hipStreamSynchronize(o.stream) != hipSuccess) rc = ncclUnhandledCudaError;
+        if (!o.send) continue;
+        std::vector<char> m(o.bytes);
+        if (o.bytes && hipMemcpy(m.data(), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = ncclUnhandledCudaError;
+        g->mail[me * n + (size_t)o.peer].push_back(std::move(m));
+    }
+    g->barrier(); // every send of the group is in its mailbox
+    std::vector<size_t> next(n, 0);
+    for (const P2P& o : ops) {
+        if (o.send || o.c != c) continue;
+        std::vector<std::vector<char>>& box = g->mail[(size_t)o.peer * n + me];
+        const size_t k = next[(size_t)o.peer]++;
+        if (k >= box.size() || box[k].size() != o.bytes) { rc = ncclInvalidArgument; continue; } // unmatched receive / mismatched count: a protocol error of the caller
+        if (o.bytes && hipMemcpy(o.buf, box[k].data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+    }
+    for (size_t p = 0; p < n; ++p)
+        if (next[p] != g->mail[p * n + me].size()) rc = ncclInvalidArgument; // something was sent to this rank that it did not receive
+    g->barrier(); // every receive is served: the senders may drop their messages
+    for (size_t p = 0; p < n; ++p) g->mail[me * n + p].clear();
+    return rc;
 }
 
 } // extern "C"

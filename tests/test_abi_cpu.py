@@ -325,3 +325,41 @@ def test_select_option_constants_match_the_header():
     for name in ("OP_VOLUME_OPT_SELECT", "OP_VOLUME_SELECT_AUTO", "OP_VOLUME_SELECT_DIRECT"):
         m = re.search(r"#define\s+%s\s+(-?\d+)" % name, text)
         assert m and int(m.group(1)) == getattr(L, name), name
+
+
+def test_loading_the_library_changes_nothing_in_the_process_environment():
+    """A drop-in libone_piece replacement must not edit its host's environment or bind libraries by environment variable: rounds 1-4 set
+    GPU_MAX_HW_QUEUES from a load-time constructor.  Now that is op_runtime_configure's job -- an explicit call -- and op_runtime_set_option /
+    op_runtime_set_rccl_library replace the ONEPIECE_* variables the library used to read."""
+    import subprocess, sys
+    lib = os.path.join(ROOT, "onepiece_amd", "libonepiece_hip.so")
+    code = (
+        "import ctypes, os\n"
+        "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+        "assert libc.getenv(b'GPU_MAX_HW_QUEUES') is None\n"
+        "env_before = dict(os.environ)\n"
+        "L = ctypes.CDLL(%r)\n"
+        "assert libc.getenv(b'GPU_MAX_HW_QUEUES') is None, 'loading the library set GPU_MAX_HW_QUEUES'\n"
+        "q = ctypes.c_int(0); assert L.op_runtime_hw_queues(ctypes.byref(q)) == 0 and q.value == 4\n"
+        "assert L.op_runtime_configure(8) == 0 and libc.getenv(b'GPU_MAX_HW_QUEUES') == b'8'\n"
+        "assert L.op_runtime_hw_queues(ctypes.byref(q)) == 0 and q.value == 8\n"
+        "L.op_runtime_set_option.argtypes = [ctypes.c_int, ctypes.c_longlong]\n"
+        "assert L.op_runtime_set_option(0, 1) == 0 and L.op_runtime_set_option(0, 7) != 0 and L.op_runtime_set_option(99, 0) != 0\n"
+        "assert L.op_runtime_set_rccl_library(b'/nonexistent/librccl.so') == 0 and L.op_runtime_set_rccl_library(None) == 0\n"
+        "print('ok')\n" % lib)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES" and not k.startswith("ONEPIECE_")}
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout + run.stderr
+    # and no source of the product reads an ONEPIECE_* variable or calls setenv outside op_runtime_configure
+    import re
+    hits = []
+    for d in ("onepiece_amd/csrc",):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            if not f.endswith((".hip", ".hpp")):
+                continue
+            text = open(os.path.join(ROOT, d, f)).read()
+            code_only = re.sub(r"//[^\n]*", "", text)
+            hits += ["%s: %s" % (f, m) for m in re.findall(r'getenv\("ONEPIECE_[A-Z_]*"\)|__attribute__\(\(constructor\)\)', code_only)]
+            if f != "volume.hip":
+                hits += ["%s: setenv" % f for _ in re.findall(r"\bsetenv\(", code_only)]
+    assert not hits, hits

@@ -5,8 +5,8 @@ MI355X can run it.
    GPU, then merged through exactly the device steps the multi-GPU merge wraps around its one reduce (op_volume_keys_device ->
    sorted union -> k_pack_sum -> sum over "ranks" -> k_unpack_sum) and compared with the reference semantics, a sequential
    CubeHandler::Merge chain (/root/reference/src/Integration/CubeHandler.h:145-167; op_volume_merge).
-2. op_volume_merge_rccl ITSELF with 2 ... 8 ranks: the real RCCL refuses two ranks on one device, so the library's run-time binding
-   (ONEPIECE_RCCL_LIBRARY) is pointed at tests/cpp/librccl_double.so -- ranks = host threads of tests/cpp/merge_world.bin, all on
+2. op_volume_merge_rccl ITSELF with 2 ... 8 ranks, both algorithms (the owner-partitioned exchange and the dense reduce): the real RCCL refuses
+   two ranks on one device, so the library's run-time binding (op_runtime_set_rccl_library) is pointed at tests/cpp/librccl_double.so -- ranks = host threads of tests/cpp/merge_world.bin, all on
    device 0, collectives through host memory.  What executes is the product's merge: padded key all-gather, the ~0 sentinel of the
    union, the three agreement points, the sliced reduce, root-only unpack -- with uneven shards, an empty rank, a root that is not
    rank 0, several reduce slices, and a rank that enters with a failed volume (every rank must return an error, nobody may hang).
@@ -133,35 +133,45 @@ def _expected(frames, shards, cam, voxel, root):
     return _sorted_map(vols[root]), hcam, [v.BlockCount() for v in vols[:root]] + [None] + [v.BlockCount() for v in vols[root + 1:]]
 
 
-def _run_world(tmp_path, shards, voxel, root=0, fail_rank=None, slice_blocks=None, timeout=300):
+def _run_world(tmp_path, shards, voxel, root=0, fail_rank=None, slice_blocks=None, algorithm="owner", timeout=300):
     build_double_and_driver()
     mp = str(tmp_path / "merged.map")
-    env = dict(os.environ, ONEPIECE_RCCL_LIBRARY=DOUBLE)
-    env.pop("ONEPIECE_RCCL_FORCE", None)
+    cmd = [WORLD, str(tmp_path / "frames.bin"), mp, "--shards", ",".join("%d-%d" % s for s in shards), "--voxel", str(voxel), "--root", str(root),
+           "--rccl-library", DOUBLE, "--algorithm", algorithm]
     if slice_blocks:
-        env["ONEPIECE_MERGE_SLICE_BLOCKS"] = str(slice_blocks)
-    cmd = [WORLD, str(tmp_path / "frames.bin"), mp, "--shards", ",".join("%d-%d" % s for s in shards), "--voxel", str(voxel), "--root", str(root)]
+        cmd += ["--slice-blocks", str(slice_blocks)]
     if fail_rank is not None:
         cmd += ["--fail-rank", str(fail_rank)]
-    run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)   # a rank left waiting in a collective = a timeout here
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)   # a rank left waiting in a collective = a timeout here
     assert run.stdout.strip(), run.stderr
     return run, json.loads(run.stdout.strip().splitlines()[-1]), mp
 
 
-@pytest.mark.parametrize("shards,root,slice_blocks", [
+SHARD_CASES = [
     ([(0, 6), (6, 12)], 0, None),                                           # two equal ranks, one slice
     ([(0, 5), (5, 6), (6, 6), (6, 14)], 2, 700),                            # uneven, an EMPTY rank that is also the root, several slices
     ([(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 14), (14, 16)], 5, 500),   # eight ranks as in configs[4], root 5
-])
-def test_merge_rccl_with_several_ranks_on_one_gpu(hip, tmp_path, shards, root, slice_blocks):
+]
+
+
+def _read_map(hcam, voxel, path):
+    hv = I.CubeHandler(hcam)
+    hv.SetVoxelResolution(voxel)
+    hv.ReadFromFile(path)
+    return hv
+
+
+@pytest.mark.parametrize("shards,root,slice_blocks", SHARD_CASES)
+def test_merge_rccl_dense_reduce_with_several_ranks_on_one_gpu(hip, tmp_path, shards, root, slice_blocks):
+    """OP_MERGE_DENSE_REDUCE (the fallback): key all-gather, the union everywhere, one sliced ncclReduce of the whole union."""
     cam = small_camera(4)
     voxel = 0.02
     frames = _write_frames(str(tmp_path / "frames.bin"), [100 + 7 * i for i in range(shards[-1][1])], cam)
     want, hcam, _ = _expected(frames, shards, cam, voxel, root)
-    run, r, mp = _run_world(tmp_path, shards, voxel, root=root, slice_blocks=slice_blocks)
+    run, r, mp = _run_world(tmp_path, shards, voxel, root=root, slice_blocks=slice_blocks, algorithm="dense")
     assert run.returncode == 0 and r["ok"] is True, run.stdout + run.stderr
     world = len(shards)
-    assert [p["rccl_rank"] for p in r["per_rank"]] == list(range(world)) and all(p["rccl_ranks"] == world and p["status"] == 0 for p in r["per_rank"])
+    assert [p["rccl_rank"] for p in r["per_rank"]] == list(range(world)) and all(p["rccl_ranks"] == world and p["status"] == 0 and p["algorithm"] == 1 for p in r["per_rank"])
     n_union = len(want[0])
     assert r["root_blocks"] == n_union and r["per_rank"][root]["union_blocks"] == n_union
     assert all(p["bytes"] == n_union * 10240 for p in r["per_rank"])
@@ -169,17 +179,65 @@ def test_merge_rccl_with_several_ranks_on_one_gpu(hip, tmp_path, shards, root, s
         assert all(p["slices"] == -(-n_union // slice_blocks) >= 2 for p in r["per_rank"])
     for p, (lo, hi) in zip(r["per_rank"], shards):
         assert (p["local_blocks"] == 0) == (lo == hi)
-    hv = I.CubeHandler(hcam)
-    hv.SetVoxelResolution(voxel)
-    hv.ReadFromFile(mp)
-    _assert_merged(_sorted_map(hv), want)
+    _assert_merged(_sorted_map(_read_map(hcam, voxel, mp)), want)
 
 
-def test_merge_rccl_rank_with_a_failed_volume_fails_everywhere_without_hanging(hip, tmp_path):
+@pytest.mark.parametrize("shards,root,slice_blocks", SHARD_CASES)
+def test_merge_rccl_owner_exchange_with_several_ranks_on_one_gpu(hip, tmp_path, shards, root, slice_blocks):
+    """OP_MERGE_OWNER_EXCHANGE (the default): every rank sends only the blocks it HOLDS, to their owners; the owners' partitions are
+    gathered on the root.  (a) the merged volume = the sequential Merge chain; (b) the bytes on the wire are what the blocks held say:
+    per rank, sent = (blocks held of other ranks' partitions) x 10 248 B + its summed partition (unless it is the root); summed over the
+    ranks, the exchange moves held x 10 248 x (world - 1) / world on average -- never the union's zeros."""
+    del slice_blocks
+    cam = small_camera(4)
+    voxel = 0.02
+    frames = _write_frames(str(tmp_path / "frames.bin"), [100 + 7 * i for i in range(shards[-1][1])], cam)
+    want, hcam, _ = _expected(frames, shards, cam, voxel, root)
+    run, r, mp = _run_world(tmp_path, shards, voxel, root=root)
+    assert run.returncode == 0 and r["ok"] is True, run.stdout + run.stderr
+    world = len(shards)
+    P = r["per_rank"]
+    assert [p["rccl_rank"] for p in P] == list(range(world)) and all(p["rccl_ranks"] == world and p["status"] == 0 and p["algorithm"] == 0 for p in P)
+    n_union = len(want[0])
+    assert r["root_blocks"] == n_union and all(p["union_blocks"] == n_union for p in P)
+    assert sum(p["owned_blocks"] for p in P) == n_union                      # the partitions are disjoint and cover the union
+    assert all(p["held_blocks"] == p["local_blocks"] for p in P)
+    B = 10240 + 8
+    held = sum(p["held_blocks"] for p in P)
+    exchange_sent = sum(p["wire_bytes_sent"] for p in P) - sum(p["owned_blocks"] * B for k, p in enumerate(P) if k != root)   # minus the gather
+    assert sum(p["wire_bytes_sent"] for p in P) == sum(p["wire_bytes_received"] for p in P)
+    assert 0 <= exchange_sent <= held * B and exchange_sent % B == 0
+    # the owner hash spreads the keys evenly: the exchange moves (world - 1) / world of what is held, within a few per cent on these ~1e3-block volumes
+    assert abs(exchange_sent / (held * B) - (world - 1) / world) < 0.08
+    # and far less than the dense reduce puts on the wire (every rank but the root sends the whole union)
+    assert sum(p["wire_bytes_sent"] for p in P) < (world - 1) * n_union * 10240 or world == 2
+    _assert_merged(_sorted_map(_read_map(hcam, voxel, mp)), want)
+
+
+def test_merge_rccl_owner_exchange_without_a_gather_leaves_every_rank_its_partition(hip, tmp_path):
+    """root = -1: a distributed map -- every rank's volume is replaced by its owned, merged partition; their disjoint union is the Merge chain's result."""
+    shards = [(0, 4), (4, 5), (5, 5), (5, 12)]
+    cam = small_camera(4)
+    voxel = 0.02
+    frames = _write_frames(str(tmp_path / "frames.bin"), [100 + 7 * i for i in range(shards[-1][1])], cam)
+    want, hcam, _ = _expected(frames, shards, cam, voxel, 0)
+    run, r, mp = _run_world(tmp_path, shards, voxel, root=-1)
+    assert run.returncode == 0 and r["ok"] is True, run.stdout + run.stderr
+    parts = [_sorted_map(_read_map(hcam, voxel, "%s.rank%d" % (mp, k))) for k in range(len(shards))]
+    assert [len(p[0]) for p in parts] == [p["owned_blocks"] for p in r["per_rank"]]
+    keys = np.concatenate([p[0] for p in parts]); vox = np.concatenate([p[1] for p in parts])
+    assert len(np.unique(keys, axis=0)) == len(keys) == len(want[0])       # disjoint, complete
+    o = np.lexsort(keys.T[::-1])
+    _assert_merged((keys[o], vox[o]), want)
+    assert sum(p["wire_bytes_sent"] for p in r["per_rank"]) == sum(p["wire_bytes_received"] for p in r["per_rank"])
+
+
+@pytest.mark.parametrize("algorithm", ["owner", "dense"])
+def test_merge_rccl_rank_with_a_failed_volume_fails_everywhere_without_hanging(hip, tmp_path, algorithm):
     cam = small_camera(4)
     frames = _write_frames(str(tmp_path / "frames.bin"), [100 + 7 * i for i in range(9)], cam)
     del frames
-    run, r, _ = _run_world(tmp_path, [(0, 3), (3, 6), (6, 9)], 0.02, root=0, fail_rank=1, timeout=120)
+    run, r, _ = _run_world(tmp_path, [(0, 3), (3, 6), (6, 9)], 0.02, root=0, fail_rank=1, algorithm=algorithm, timeout=120)
     assert run.returncode != 0 and r["ok"] is False
     assert all(p["status"] != 0 for p in r["per_rank"]), r          # nobody "succeeds" with a partial merge
     assert "bounding box" in r["per_rank"][1]["error"]               # the failing rank reports ITS failure ...

@@ -327,11 +327,12 @@ def test_cpp_icp_driver_matches_oracle(hip, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_multi_gpu_driver_runs_the_rccl_merge(hip, oracle, tmp_path):
+@pytest.mark.parametrize("algorithm", ["owner", "dense"])
+def test_cpp_multi_gpu_driver_runs_the_rccl_merge(hip, oracle, tmp_path, algorithm):
     """examples/cpp/MultiGpuSequenceIntegration.cpp on the GPUs this box has.  With one GPU the exchange is forced through
-    RCCL anyway (ONEPIECE_RCCL_FORCE=1: one-rank all-gather + reduce + the sum-form round trip), so op_volume_merge_rccl --
-    dlopen'ed librccl, rocPRIM union, pack, ncclReduce, unpack -- executes on hardware: keys and weights exact, sdf / colour
-    within one rounding of the oracle."""
+    RCCL anyway (--force-exchange: a one-rank communicator), so op_volume_merge_rccl -- dlopen'ed librccl, rocPRIM sorts, pack,
+    ncclSend / ncclRecv groups or ncclReduce, unpack -- executes on hardware with both algorithms: keys and weights exact,
+    sdf / colour within one rounding of the oracle."""
     _build_host(); _make(cwd=EX)
     import torch
     gpus = min(torch.cuda.device_count(), 2)
@@ -339,15 +340,22 @@ def test_cpp_multi_gpu_driver_runs_the_rccl_merge(hip, oracle, tmp_path):
     seq = str(tmp_path / "seq")
     decoded, poses = _write_sequence(seq, 6, cam, first=100, step=3)
     mp = str(tmp_path / "merged.map")
-    env = dict(os.environ, ONEPIECE_RCCL_FORCE="1", ONEPIECE_MERGE_SLICE_BLOCKS="1500")   # several reduce slices on this small volume
-    run = subprocess.run([os.path.join(EX, "MultiGpuSequenceIntegration.bin"), seq, "--gpus", str(gpus), "--voxel", "0.01", "--map", mp],
-                         capture_output=True, text=True, env=env)
+    extra = ["--dense", "--slice-blocks", "1500"] if algorithm == "dense" else []   # several reduce slices on this small volume
+    run = subprocess.run([os.path.join(EX, "MultiGpuSequenceIntegration.bin"), seq, "--gpus", str(gpus), "--voxel", "0.01", "--map", mp, "--force-exchange"] + extra,
+                         capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
     r = json.loads(run.stdout.strip().splitlines()[-1])
     assert r["ok"] is True and r["gpus"] == gpus
-    # what the call reports per rank: the communicator's size, the sliced reduce, where the time went
+    # what the call reports per rank: the communicator's size, what crossed the wire, where the time went
     assert [p["rank"] for p in r["per_rank"]] == list(range(gpus)) and all(p["rccl_ranks"] == gpus for p in r["per_rank"])
-    assert all(p["slices"] == -(-r["union_blocks"] // 1500) >= 2 and p["merge_bytes"] == r["union_blocks"] * 10240 for p in r["per_rank"])
+    if algorithm == "dense":
+        assert all(p["algorithm"] == 1 and p["slices"] == -(-r["union_blocks"] // 1500) >= 2 and p["merge_bytes"] == r["union_blocks"] * 10240 for p in r["per_rank"])
+    else:
+        assert all(p["algorithm"] == 0 and p["held_blocks"] == p["local_blocks"] for p in r["per_rank"])
+        assert sum(p["owned_blocks"] for p in r["per_rank"]) == r["union_blocks"]
+        assert sum(p["wire_bytes_sent"] for p in r["per_rank"]) == sum(p["wire_bytes_received"] for p in r["per_rank"])
+        if gpus == 1:
+            assert r["per_rank"][0]["wire_bytes_sent"] == 0                       # one rank owns everything it holds: nothing leaves the device
     assert all(0 < p["merge_prepare_ms"] < p["merge_ms"] and 0 < p["merge_transfer_ms"] < p["merge_ms"] for p in r["per_rank"])
     # the oracle: per-shard volumes merged sequentially into shard 0's (CubeHandler::Merge)
     ocam = oracle.make_camera()
@@ -406,8 +414,8 @@ def test_cpp_dense_fusion_driver_tracks_and_fuses(hip, oracle, tmp_path):
 @pytest.mark.gpu
 def test_cpp_dense_fusion_driver_pipelined_rate_without_any_environment(hip, tmp_path):
     """Tracking + fusion from the C++ class surface at the rate the C-ABI pipeline reaches: frames uploaded once (RGBDFrame::on_device), four
-    pairs in flight (Odometry::DenseTrackingEnqueue / Wait), fusion in place.  GPU_MAX_HW_QUEUES is NOT in the environment: the library asks
-    for its hardware queues when it is loaded.  The pipelined run and the one-pair-at-a-time run of the same driver print the same poses (the
+    pairs in flight (Odometry::DenseTrackingEnqueue / Wait), fusion in place.  GPU_MAX_HW_QUEUES is NOT in the environment: the class surface
+    asks for its hardware queues (op_runtime_configure) when its first device object is created.  The pipelined run and the one-pair-at-a-time run of the same driver print the same poses (the
     pipeline only changes WHEN a pair is tracked) and fuse the same volume."""
     _build_host(); _make(cwd=EX)
     seq = str(tmp_path / "seq")

@@ -96,7 +96,7 @@ class _Appender:
         self._vol.load(keys, vox)
 
 
-def _worker(rank, world, port, outdir, chunk_blocks=32768):
+def _worker(rank, world, port, outdir, chunk_blocks=32768, algorithm="dense", root=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -116,8 +116,13 @@ def _worker(rank, world, port, outdir, chunk_blocks=32768):
         vol.integrate(d, c, pose)
     k, v = vol.export()
     np.savez(os.path.join(outdir, "shard%d.npz" % rank), k=k, v=v)
-    n_union = D.merge_volumes(OracleVolumeOps(vol), root=0, chunk_blocks=chunk_blocks)
-    if rank == 0:
+    n_union = D.merge_volumes(OracleVolumeOps(vol), root=root, chunk_blocks=chunk_blocks, algorithm=algorithm)
+    import json
+    json.dump(dict(D.last_stats), open(os.path.join(outdir, "stats%d.json" % rank), "w"))
+    if root is None:                                          # a distributed map: every rank keeps its owned partition
+        k, v = vol.export()
+        np.savez(os.path.join(outdir, "part%d.npz" % rank), k=k, v=v, n_union=n_union)
+    elif rank == root:
         k, v = vol.export()
         np.savez(os.path.join(outdir, "merged.npz"), k=k, v=v, n_union=n_union)
     dist.barrier()
@@ -182,6 +187,68 @@ def test_four_rank_gloo_sliced_merge_equals_sequential_merge_chain(oracle, tmp_p
     seen = rv[:, :, 1] > 0
     assert np.abs(m["v"][:, :, 0] - rv[:, :, 0])[seen].max() <= 1e-4 * 0.1 and np.abs(m["v"][:, :, 2:] - rv[:, :, 2:])[seen].max() <= 1e-4
     assert np.array_equal(m["v"][~seen], rv[~seen])
+
+
+def _chain(oracle, tmp_path, world):
+    from helpers import small_camera
+    cam = oracle.make_camera(*small_camera(4))
+    vols, shards = [], []
+    for r in range(world):
+        sh = np.load(tmp_path / ("shard%d.npz" % r))
+        v = oracle.Volume(cam, voxel_res=0.02)
+        if len(sh["k"]):
+            v.load(sh["k"], sh["v"])
+        vols.append(v); shards.append(sh)
+    for v in vols[1:]:
+        assert vols[0].merge(v) == 0
+    return vols[0].export(), shards
+
+
+def _same_as_chain(k, v, rk, rv):
+    assert np.array_equal(k, rk) and np.array_equal(v[:, :, 1], rv[:, :, 1])
+    seen = rv[:, :, 1] > 0
+    assert np.abs(v[:, :, 0] - rv[:, :, 0])[seen].max() <= 1e-4 * 0.1 and np.abs(v[:, :, 2:] - rv[:, :, 2:])[seen].max() <= 1e-4
+    assert np.array_equal(v[~seen], rv[~seen])
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (4, 2)])
+def test_gloo_owner_exchange_equals_sequential_merge_chain_and_moves_only_held_blocks(oracle, tmp_path, world, root):
+    """The default algorithm, the owner-partitioned exchange, over gloo: every rank sends the blocks it HOLDS to their owners (point to
+    point, all pairs in one batch), the owners' summed partitions are gathered on the root.  The root's volume = the sequential Merge
+    chain (keys and weights exactly); the bytes on the wire are what the held blocks say."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), 32768, "owner", root), nprocs=world, join=True)
+    (rk, rv), _sh = _chain(oracle, tmp_path, world)
+    m = np.load(tmp_path / "merged.npz")
+    assert int(m["n_union"]) == len(rk)
+    _same_as_chain(m["k"], m["v"], rk, rv)
+    st = [json.load(open(tmp_path / ("stats%d.json" % r))) for r in range(world)]
+    assert all(s["algorithm"] == "owner" and s["union_blocks"] == len(rk) for s in st) and sum(s["owned_blocks"] for s in st) == len(rk)
+    B = 10240 + 8
+    held = sum(s["held_blocks"] for s in st)
+    total_sent = sum(s["wire_bytes_sent"] for s in st)
+    assert total_sent == sum(s["wire_bytes_received"] for s in st)
+    exchange = total_sent - sum(s["owned_blocks"] * B for r, s in enumerate(st) if r != root)     # minus the gather to the root
+    assert 0 < exchange <= held * B and abs(exchange / (held * B) - (world - 1) / world) < 0.1
+    assert st[root]["wire_bytes_sent"] == exchange - sum(s["wire_bytes_sent"] - s["owned_blocks"] * B for r, s in enumerate(st) if r != root)
+
+
+def test_gloo_owner_exchange_without_a_root_leaves_a_distributed_map(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), 32768, "owner", None), nprocs=world, join=True)
+    (rk, rv), _sh = _chain(oracle, tmp_path, world)
+    parts = [np.load(tmp_path / ("part%d.npz" % r)) for r in range(world)]
+    keys = np.concatenate([p["k"] for p in parts]); vox = np.concatenate([p["v"] for p in parts])
+    assert len(np.unique(keys, axis=0)) == len(keys) == len(rk) and all(int(p["n_union"]) == len(rk) for p in parts)
+    o = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+    _same_as_chain(keys[o], vox[o], rk, rv)
+    from onepiece_amd import distributed as D
+    import torch
+    for r, p in enumerate(parts):                            # every block sits on its owner
+        if len(p["k"]):
+            assert (D.owner_of(D._pack64(torch.from_numpy(p["k"])), world) == r).all()
 
 
 def test_frame_prefetcher_yields_in_order(tmp_path):

@@ -98,7 +98,7 @@ def test_config4_tracked_pose_chain_60_frames(oracle, torch_dev):
     # north_star's bar for this row is 1e-4 relative on the pose.  This mode is documented NOT to meet it on every pair; the assertion below states
     # that in executable form (should it ever hold, the documentation and bench.py's choice of config 4's mode are out of date and must be revisited)
     meets_north_star_bar = bool(pair_err.max() <= 1e-4)
-    assert not meets_north_star_bar, "the fp64 mode now meets 1e-4 on every pair: update DESIGN.md section 7 and tools/benchparts/dense_fusion.py"
+    assert not meets_north_star_bar, "the fp64 mode now meets 1e-4 on every pair: update DESIGN.md section 7 and benchparts/dense_fusion.py"
     assert pair_err.max() <= 5e-4
     assert (pair_err <= 1e-4).mean() >= 0.90
     assert chain_err.max() <= 3e-3
