@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every rank fuses K x F frames; strong: the K x F frames are split over the ranks (BASELINE configs[4] as "
                          "written: `--scaling strong --steps 80` = 8000 frames in total at any N)")
+    ap.add_argument("--merge-algorithm", choices=["owner", "dense"], default="owner",
+                    help="the N > 1 merge: the owner-partitioned exchange (default) or the dense reduce of the whole union (rounds 1-4)")
     ap.add_argument("--timed-only", action="store_true", help="only the warm-up and the timed region (for rocprofv3 --kernel-trace --stats runs: "
                     "every k_integrate launch in the trace then has the timed region's batch shape)")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic / roofline.valu (~30 s)")
@@ -121,7 +123,7 @@ def main():
         hv.IntegrateSequence(depth[s:s + F], rgb[s:s + F], poses[s:s + F])
     hv.Synchronize()
     if world > 1 or force_dist:
-        D.merge_volumes(ops, root=0)
+        D.merge_volumes(ops, root=0, algorithm=args.merge_algorithm)
     hv.Clear()
     hv.ProfileEnable(args.profile_every)
 
@@ -139,7 +141,7 @@ def main():
     local_blocks = hv.BlockCount()
     t_m0 = time.perf_counter()
     if world > 1 or force_dist:
-        n_union = D.merge_volumes(ops, root=0)
+        n_union = D.merge_volumes(ops, root=0, algorithm=args.merge_algorithm)
         hv.Synchronize(); torch.cuda.synchronize()
     t_merge = time.perf_counter() - t_m0
     barrier()

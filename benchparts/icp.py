@@ -70,6 +70,61 @@ def run(c, out):
                   # 36 B per source point per iteration (source + matched target + normal); the kernel is
                   # a latency-bound gather (27-cell scan), so this is far from the HBM roof by construction
                   "algorithmic_gbs": 36.0 * len(src) * gpu_it_s / 1e9}
+    # -- replicas in flight (ICP's only parallel axis): K contexts, each on its own stream and host thread (op_icp_run_enqueue / op_icp_wait),
+    #    registering K DIFFERENT consecutive frame pairs of the sequence at once
+    try:
+        Kmax = 8
+        ctxs, srcs, tgts, nrms = [], [], [], []
+        for k in range(Kmax):
+            dk0, dk1 = depth[2 * k].cpu().numpy(), depth[2 * k + 1].cpu().numpy()
+            tp = R.PointCloud.LoadFromDepth(dk0, cam, device=local_rank)
+            tp.EstimateNormals(0.1, 30, device=local_rank)
+            sp = R.PointCloud.LoadFromDepth(dk1, cam, device=local_rank).points
+            hk = C.c_void_p()
+            L.check(lib.op_icp_create(C.c_void_p(tp.points.ctypes.data), C.c_void_p(tp.normals.ctypes.data), len(tp.points), 0.01, L.OP_MEM_HOST, local_rank, C.byref(hk)))
+            L.check(lib.op_icp_set_source(hk, C.c_void_p(sp.ctypes.data), len(sp), L.OP_MEM_HOST))
+            ctxs.append(hk); srcs.append(sp); tgts.append(tp.points); nrms.append(tp.normals)
+        agg, results = {}, {}
+        for Kc in (1, 2, 4, 8):
+            res_k = [L.IcpResult() for _ in range(Kc)]
+            best = None
+            for rep in range(3):
+                t = time.perf_counter()
+                for k in range(Kc):
+                    L.check(lib.op_icp_run_enqueue(ctxs[k], 1, fp(T0), iters, C.byref(res_k[k]), None, 0))
+                for k in range(Kc):
+                    L.check(lib.op_icp_wait(ctxs[k]))
+                dtk = time.perf_counter() - t
+                best = dtk if best is None else min(best, dtk)
+            agg[Kc] = Kc * iters / best
+            results[Kc] = res_k
+        # a context's result does not depend on what runs next to it: the 8-in-flight results against the same contexts run alone
+        alone = []
+        for k in range(Kmax):
+            r1 = L.IcpResult()
+            L.check(lib.op_icp_run(ctxs[k], 1, fp(T0), iters, C.byref(r1), None, 0, None, None))
+            alone.append(r1)
+        same = all(bytes(results[8][k].T) == bytes(alone[k].T) and results[8][k].n_inliers == alone[k].n_inliers for k in range(Kmax))
+        out["icp"]["replicas"] = {"aggregate_iters_per_s": {str(k): v for k, v in agg.items()}, "best_aggregate_iters_per_s": max(agg.values()),
+                                  "speedup_over_one_context": max(agg.values()) / agg[1], "iterations_per_run": iters,
+                                  "in_flight_results_identical_to_sequential": bool(same),
+                                  "points": [int(len(x)) for x in srcs],
+                                  "note": "K contexts x %d point-to-plane iterations on K different frame pairs, enqueued together (op_icp_run_enqueue: each on its own "
+                                          "stream and host thread) and waited for; aggregate = K x iterations / wall time, best of 3" % iters}
+        if c.oracle is not None:   # per-context parity against the CPU path (10 iterations, four of the pairs)
+            par = []
+            for k in range(4):
+                rk = L.IcpResult()
+                L.check(lib.op_icp_run(ctxs[k], 1, fp(T0), 10, C.byref(rk), None, 0, None, None))
+                ref_k = c.oracle.icp(srcs[k], tgts[k], nrms[k], None, 10, 0.01, True)
+                gT = np.array(rk.T, np.float64).reshape(4, 4)
+                par.append({"pair": [2 * k, 2 * k + 1], "returned_T_rel_err_vs_cpu": float(np.linalg.norm(gT - ref_k["T"].astype(np.float64)) / np.linalg.norm(ref_k["T"].astype(np.float64))),
+                            "inliers": {"gpu": int(rk.n_inliers), "cpu": int(len(ref_k["pairs"]))}})
+            out["icp"]["replicas"]["parity_10_iterations"] = par
+        for hk in ctxs:
+            lib.op_icp_destroy(hk)
+    except Exception as e:
+        out["icp"]["replicas"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_cpu_baseline:
         O = c.oracle   # the CPU oracle, imported by bench.py for its cpu_baseline leg (the only place that does)
         t = time.perf_counter()

@@ -404,6 +404,14 @@ int op_icp_iterate(op_icp *icp, const float T[16], int mode, double sums[42], ui
 int op_icp_run(op_icp *icp, int mode, const float init_T[16], int max_iteration,
                op_icp_result *result, int32_t *pairs, size_t pairs_cap, int32_t *per_iter_inliers,
                float *per_iter_T);
+/* The same run split in two, so that several contexts work on independent frame pairs at once -- ICP shards only as REPLICAS,
+ * and one 307 200-point problem cannot fill the chip (28 k iterations/s = 4 % of the HBM rate its 11 MB would allow).  The loop needs
+ * the host after every iteration (the 6x6 solve), so an enqueued run proceeds on a host thread of the context's own; `result` and `pairs`
+ * (may be NULL) must stay valid until op_icp_wait, which returns the run's status.  One run may be outstanding per context; results are
+ * those of op_icp_run (each context is independent of the others). */
+int op_icp_run_enqueue(op_icp *icp, int mode, const float init_T[16], int max_iteration, op_icp_result *result, int32_t *pairs, size_t pairs_cap);
+int op_icp_wait(op_icp *icp);
+
 /* Convenience: create + set_source + run + destroy with host buffers. */
 int op_icp_register(int mode, const float *src_xyz, size_t n, const float *tgt_xyz,
                     const float *tgt_normals, size_t m, const float init_T[16], int max_iteration,

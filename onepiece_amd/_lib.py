@@ -150,6 +150,8 @@ SIGNATURES = {
     "op_icp_set_source": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "op_icp_iterate": (C.c_int, [_vp, _fp, C.c_int, C.POINTER(C.c_double), _u64p,
                                  C.POINTER(C.c_double)]),
+    "op_icp_run_enqueue": (C.c_int, [_vp, C.c_int, _fp, C.c_int, C.POINTER(IcpResult), _ip, C.c_size_t]),
+    "op_icp_wait": (C.c_int, [_vp]),
     "op_icp_run": (C.c_int, [_vp, C.c_int, _fp, C.c_int, C.POINTER(IcpResult), _ip, C.c_size_t, _ip,
                              _fp]),
     "op_icp_register": (C.c_int, [C.c_int, _fp, C.c_size_t, _fp, _fp, C.c_size_t, _fp, C.c_int,

@@ -22,9 +22,13 @@
 #include <cfloat>
 #include <climits>
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -837,6 +841,12 @@ struct op_icp {
     unsigned *flag = nullptr, *start = nullptr, *scan_tot = nullptr;
     float *rows_dev = nullptr, *rows_host = nullptr; // src_cap x 9 floats each; rows_host is pinned
     size_t rows_cap = 0;
+    // op_icp_run_enqueue / op_icp_wait: the loop needs the host after every iteration (the 6x6 solve), so an enqueued run proceeds on a host
+    // thread of the context's own -- K contexts (each with its stream) register K frame pairs side by side: ICP's only parallel axis (replicas)
+    std::thread worker;
+    bool worker_active = false;
+    int worker_rc = OP_OK;
+    char worker_err[512] = "";
 };
 
 namespace {
@@ -1051,6 +1061,7 @@ int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, doub
 }
 
 int op_icp_destroy(op_icp* c) {
+    if (c && c->worker_active) { c->worker.join(); c->worker_active = false; }
     if (!c) return OP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1291,6 +1302,28 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         for (size_t i = 0; i < c->n && k < pairs_cap; ++i)
             if (inl[i] >= 0) { pairs[2 * k] = (int32_t)i; pairs[2 * k + 1] = inl[i]; ++k; }
     }
+    return OP_OK;
+}
+
+int op_icp_run_enqueue(op_icp* c, int mode, const float init_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap) {
+    if (!c || !init_T || !result) return fail(OP_ERR_INVALID, "null argument");
+    if (c->worker_active) return fail(OP_ERR_INVALID, "op_icp_run_enqueue: an enqueued run has not been waited for");
+    std::array<float, 16> T0;
+    std::memcpy(T0.data(), init_T, sizeof(float) * 16);
+    c->worker_active = true; c->worker_rc = OP_OK; c->worker_err[0] = 0;
+    c->worker = std::thread([=] {
+        c->worker_rc = op_icp_run(c, mode, T0.data(), max_iteration, result, pairs, pairs_cap, nullptr, nullptr);
+        if (c->worker_rc != OP_OK) std::snprintf(c->worker_err, sizeof(c->worker_err), "%s", op::g_last_error); // (the error text is thread-local: hand it over)
+    });
+    return OP_OK;
+}
+
+int op_icp_wait(op_icp* c) {
+    if (!c) return fail(OP_ERR_INVALID, "null argument");
+    if (!c->worker_active) return fail(OP_ERR_INVALID, "op_icp_wait: nothing has been enqueued");
+    c->worker.join();
+    c->worker_active = false;
+    if (c->worker_rc != OP_OK) return fail(c->worker_rc, "%s", c->worker_err);
     return OP_OK;
 }
 

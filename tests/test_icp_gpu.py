@@ -324,3 +324,48 @@ def test_contexts_reuse_cached_buffers_without_seeing_each_others_data(oracle):
     ref = oracle.icp(src_a, tgt_a, nrm_a, None, 8, 0.02, point_to_plane=True)
     got = R.PointToPlane(R.PointCloud(src_a), R.PointCloud(tgt_a, nrm_a), None, par)
     assert np.array_equal(got.per_iter_inliers, ref["per_iter_inliers"]) and rel_err(got.T, ref["T"]) <= POSE_TOL
+
+
+def test_replicas_in_flight_give_each_context_its_sequential_result(oracle):
+    """ICP shards only as replicas: op_icp_run_enqueue / op_icp_wait run K contexts -- each with its own stream and host
+    thread -- on K different frame pairs at once.  Every context's result (returned T, accumulated pose, rmse, inlier count, pairs) is
+    bit-identical to the same context run alone, and matches the CPU path like any single registration (pose 1e-4, first-iteration
+    inliers exact)."""
+    import ctypes as C
+    from onepiece_amd import _lib as L
+    lib = L.load()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    T0 = np.eye(4, dtype=np.float32).reshape(16)
+    K, iters = 4, 8
+    ctxs, clouds = [], []
+    for k in range(K):
+        _, src, _ = room_cloud(401 + 10 * k, scale=2)
+        _, tgt, nrm = room_cloud(400 + 10 * k, scale=2)
+        h = C.c_void_p()
+        L.check(lib.op_icp_create(C.c_void_p(tgt.ctypes.data), C.c_void_p(nrm.ctypes.data), len(tgt), 0.02, L.OP_MEM_HOST, 0, C.byref(h)))
+        L.check(lib.op_icp_set_source(h, C.c_void_p(src.ctypes.data), len(src), L.OP_MEM_HOST))
+        ctxs.append(h); clouds.append((src, tgt, nrm))
+    alone, pairs_alone = [], []
+    for k in range(K):
+        r = L.IcpResult(); p = np.full((len(clouds[k][0]), 2), -1, np.int32)
+        L.check(lib.op_icp_run(ctxs[k], 1, fp(T0), iters, C.byref(r), p.ctypes.data_as(L._ip), len(p), None, None))
+        alone.append(r); pairs_alone.append(p)
+    for _round in range(3):
+        res = [L.IcpResult() for _ in range(K)]
+        prs = [np.full((len(clouds[k][0]), 2), -1, np.int32) for k in range(K)]
+        for k in range(K):
+            L.check(lib.op_icp_run_enqueue(ctxs[k], 1, fp(T0), iters, C.byref(res[k]), prs[k].ctypes.data_as(L._ip), len(prs[k])))
+        assert lib.op_icp_run_enqueue(ctxs[0], 1, fp(T0), iters, C.byref(res[0]), None, 0) != 0      # one run per context at a time
+        for k in reversed(range(K)):                                                                  # (waited for in another order than enqueued)
+            L.check(lib.op_icp_wait(ctxs[k]))
+        assert lib.op_icp_wait(ctxs[0]) != 0                                                           # nothing left to wait for
+        for k in range(K):
+            assert bytes(res[k].T) == bytes(alone[k].T) and bytes(res[k].last_T) == bytes(alone[k].last_T)
+            assert res[k].n_inliers == alone[k].n_inliers and res[k].rmse == alone[k].rmse and res[k].iterations == alone[k].iterations
+            assert np.array_equal(prs[k], pairs_alone[k])
+    for k in range(K):
+        src, tgt, nrm = clouds[k]
+        ref = oracle.icp(src, tgt, nrm, None, iters, 0.02, point_to_plane=True)
+        assert rel_err(np.array(alone[k].T).reshape(4, 4), ref["T"]) <= POSE_TOL and rel_err(np.array(alone[k].last_T).reshape(4, 4), ref["last_T"]) <= POSE_TOL
+        assert abs(int(alone[k].n_inliers) - len(ref["pairs"])) <= 1e-4 * len(src)
+        lib.op_icp_destroy(ctxs[k])

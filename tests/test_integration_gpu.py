@@ -292,24 +292,29 @@ def test_bench_multi_rank_flow_on_one_gpu(oracle, tmp_path):
     assert r["per_frame"]["final_blocks_rank0"] == r["merge_union_blocks"]
 
 
-def test_bench_distributed_path_over_rccl_with_one_rank(tmp_path):
-    """The WHOLE distributed path of bench.py on real RCCL (backend "nccl"): process group, all_gather of counts and keys,
-    the reduce issued in slices, normalisation on the root -- with the one rank a single-GPU box can host
-    (ONEPIECE_BENCH_FORCE_DIST=1; two ranks on one device are refused by RCCL).  The merged volume keeps every block."""
+@pytest.mark.parametrize("algorithm", ["owner", "dense"])
+def test_bench_distributed_path_over_rccl_with_one_rank(tmp_path, algorithm):
+    """The WHOLE distributed path of bench.py on real RCCL (backend "nccl"): process group, the collectives of either merge algorithm
+    (owner: count matrix all_gather, partition sums, gather; dense: all_gather of counts and keys, the reduce issued in slices),
+    normalisation on the root -- with the one rank a single-GPU box can host (ONEPIECE_BENCH_FORCE_DIST=1; two ranks on one device
+    are refused by RCCL).  The merged volume keeps every block."""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, ONEPIECE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--frames-per-step", "40", "--no-icp", "--no-tracking", "--no-cpu-baseline", "--no-counters"]
+           "--frames-per-step", "40", "--no-icp", "--no-tracking", "--no-cpu-baseline", "--no-counters", "--merge-algorithm", algorithm]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 1 and r["value"] > 0
     assert r["merge_union_blocks"] == r["per_frame"]["final_blocks_rank0"] > 32768     # more than one slice went through the reduce
     mg = r["multi_gpu"]
-    assert mg["backend"] == "nccl" and mg["ranks_in_process_group"] == 1 and mg["merge_slices"] >= 2 and mg["merge_bytes_per_rank"] == r["merge_union_blocks"] * 10240
+    assert mg["backend"] == "nccl" and mg["ranks_in_process_group"] == 1 and mg["merge_algorithm"] == algorithm
+    pr = mg["per_rank"][0]
+    assert pr["held_blocks"] == r["merge_union_blocks"] and pr["owned_blocks"] == r["merge_union_blocks"]
+    assert pr["wire_bytes_sent"] == 0        # one rank owns (owner) / is the root of (dense) everything it holds: nothing leaves the device
     assert len(mg["per_rank"]) == 1 and mg["per_rank"][0]["frames"] == 80 and mg["per_rank"][0]["merge_ms"] > 0 and mg["per_rank"][0]["fusion_ms"] > 0
 
 
