@@ -179,6 +179,36 @@ int main(int argc, char** argv) {
         op_volume_destroy(v);
         return 0;
     }
+    if (argc > 4 && std::string(argv[4]).rfind("icpk=", 0) == 0) {
+        // "icpk=K": K registration contexts, each with its own consecutive frame pair (2k -> 2k + 1... wrapped), 60 point-to-plane iterations each, enqueued together
+        // (op_icp_run_enqueue: own stream + host thread per context) -- ICP's replica axis.  Prints the aggregate iteration rate.
+        const int K = std::max(1, atoi(argv[4] + 5));
+        if (n < 2) return 1;
+        std::vector<op_icp*> ctx((size_t)K, nullptr);
+        std::vector<float> tgt(npx * 3), src(npx * 3), nrm(npx * 3);
+        for (int k = 0; k < K; ++k) {
+            const int a = (2 * k) % (n - 1);
+            size_t nt = 0, ns = 0;
+            CK(op_points_from_depth(&cam, depth.data() + npx * a, OP_DEPTH_F32, OP_MEM_HOST, 0, tgt.data(), &nt));
+            CK(op_points_from_depth(&cam, depth.data() + npx * (a + 1), OP_DEPTH_F32, OP_MEM_HOST, 0, src.data(), &ns));
+            CK(op_estimate_normals(tgt.data(), nt, 0.1f, 30, OP_MEM_HOST, 0, nrm.data()));
+            CK(op_icp_create(tgt.data(), nrm.data(), nt, 0.01, OP_MEM_HOST, 0, &ctx[(size_t)k]));
+            CK(op_icp_set_source(ctx[(size_t)k], src.data(), ns, OP_MEM_HOST));
+        }
+        const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        std::vector<op_icp_result> res((size_t)K);
+        for (int r = 0; r < reps + 1; ++r) {
+            auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < K; ++k) CK(op_icp_run_enqueue(ctx[(size_t)k], 1, I4, 60, &res[(size_t)k], nullptr, 0));
+            for (int k = 0; k < K; ++k) CK(op_icp_wait(ctx[(size_t)k]));
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (r) printf("rep %d: %d contexts in flight x 60 iterations in %.3f ms: aggregate %.0f it/s (%.2f us per iteration chip-wide), inliers of context 0: %llu\n", r, K, dt * 1e3,
+                          K * 60 / dt, dt / (K * 60) * 1e6, (unsigned long long)res[0].n_inliers);
+        }
+        for (auto c : ctx) op_icp_destroy(c);
+        op_volume_destroy(v);
+        return 0;
+    }
     if (argc > 4 && std::string(argv[4]) == "host") {
         // the reference's own call pattern: one CubeHandler::IntegrateImage(cv::Mat depth, cv::Mat rgb, pose) per frame with
         // PAGEABLE host images (std::vector storage here, like cv::Mat's), float32 depth and raw uint16 depth
