@@ -191,7 +191,9 @@ def main():
             "config": {"workload": "ImageSequenceIntegration: %d-frame synthetic 640x480 room sequence per GPU, %.4g m voxel, "
                                    "trunc 0.1 m, frames resident in HBM" % (n_local, args.voxel),
                        "frames_per_step": F, "frames_per_gpu": n_local, "sharding": "contiguous frames per GPU, one RCCL reduce at end",
-                       "voxel_m": args.voxel},
+                       "voxel_m": args.voxel,
+                       "update_mode": "exact: `value` is measured with the default update, whose voxels are bit-identical to the reference's CPU path; the opt-in sum form "
+                                      "(within 2e-6 of it, two decades inside north_star's 1e-4) is faster and reported under sum_form -- both answer north_star, only this one bit for bit"},
             "fusion_only_frames_per_s": total_frames / t_fuse_max,
             "pool": growth,   # the pool starts at 2^18 blocks and grows on demand INSIDE the timed region (grows / replayed batches since create)
             "merge_union_blocks": n_union,

@@ -80,7 +80,7 @@ CubeHandler& CubeHandler::operator=(const CubeHandler& other) {
     other.Pending();
     cube_map.edited = false; // whatever was pending here is overwritten
     Touch();
-    if (vol) { op_volume_destroy(vol); vol = nullptr; }
+    if (vol) { op_volume_destroy(vol); vol = nullptr; borrowed_.clear(); } // (the destroy synchronised: nothing reads the borrowed device frames any more)
     camera = other.camera; integrator = other.integrator; c_para = other.c_para; far = other.far; near = other.near;
     if (other.vol && Ensure() && op_volume_merge(vol, other.vol) != OP_OK) Report("assign");
     return *this;
@@ -219,6 +219,16 @@ void CubeHandler::IntegrateImage(const geometry::RGBDFrame& rgbd, const geometry
     if (!Ensure()) return;
     Touch();
     std::shared_ptr<bridge::DeviceImages> d = std::static_pointer_cast<bridge::DeviceImages>(rgbd.on_device);
+    // the device copy was made for the tracker's camera: it is fused in place only if it is what THIS volume reads -- its camera's size, its device
+    if (d->width != camera.GetWidth() || d->height != camera.GetHeight() || d->device != bridge::Device()) {
+        if (rgbd.depth.empty() || rgbd.rgb.empty()) {
+            std::cout << RED << "[ERROR]::[IntegrateImage]::the frame's device copy (" << d->width << " x " << d->height << ", device " << d->device
+                      << ") does not match the volume's camera (" << camera.GetWidth() << " x " << camera.GetHeight() << ") and the frame has no host images" << RESET << std::endl;
+            return;
+        }
+        IntegrateImage(rgbd.depth, rgbd.rgb, pose);
+        return;
+    }
     float p[16], pi[16];
     bridge::RowMajor(pose, p);
     bridge::RowMajor(pose.inverse(), pi);

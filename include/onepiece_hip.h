@@ -164,7 +164,9 @@ int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* Cu
  *   OP_VOLUME_UPDATE_SUM_FORM: the observations a batch of frames (<= 32) makes of a voxel are summed and the weighted mean with the stored
  *     voxel is formed once per batch.  Same blocks, same pixels, same weights; sdf and colour agree with the reference to float rounding
  *     (<= 1e-6 of the truncation distance / of 1 in practice; the path's bar is 1e-4 relative).  The integrate kernel executes a third
- *     fewer instructions per voxel and frame.
+ *     fewer instructions per voxel and frame.  Precondition: truncation < 1 -- the reference re-tests IsValid (sdf < 1) before every frame,
+ *     the sum form once per batch (on the stored voxel), and the two only agree while no observation can itself be "invalid"; with
+ *     truncation >= 1 the exact update runs whatever this option says.
  * Changing the option waits for the frames accepted so far (they are fused under the old setting). */
 #define OP_VOLUME_OPT_UPDATE 0
 #define OP_VOLUME_UPDATE_EXACT 0

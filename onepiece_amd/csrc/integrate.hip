@@ -334,7 +334,11 @@ void launch_integrate(op_volume* v, const BatchInv& I, const CamParams& C, int n
     const VolView V = v->view();
 #define OP_KC(FASTPX, PLAINV, SUMFV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, (SUMFV ? KC_ZT_SUM : KC_ZT), SUMFV>), dim3(SUMFV ? kColGridSum : kColGrid), dim3(512 / (SUMFV ? KC_ZT_SUM : KC_ZT)), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
                                                  v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial, v->plain_from)
-    if (v->update_mode == OP_VOLUME_UPDATE_SUM_FORM) { if (C.fast_px) OP_KC(true, true, true); else OP_KC(false, true, true); }
+    // The sum form tests TSDFVoxel::IsValid on the STORED voxel once per batch where the reference re-tests it before every frame (Integrator.cpp:74-87,
+    // TSDFVoxel.h:75-78): the two agree to rounding only while no OBSERVATION can itself be invalid, i.e. truncation < 1 (an observed sdf is < truncation;
+    // a stored voxel of any origin gets the test).  With truncation >= 1 the exact update runs, whatever the option says.
+    const bool sum_form = v->update_mode == OP_VOLUME_UPDATE_SUM_FORM && v->trunc < 1.0f;
+    if (sum_form) { if (C.fast_px) OP_KC(true, true, true); else OP_KC(false, true, true); }
     else if (C.fast_px) { if (v->plain) OP_KC(true, true, false); else OP_KC(true, false, false); }
     else { if (v->plain) OP_KC(false, true, false); else OP_KC(false, false, false); }
 #undef OP_KC

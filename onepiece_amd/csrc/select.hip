@@ -815,11 +815,14 @@ void launch_prepare_frames(op_volume* v, const BatchFwd& F, int nf, const CamPar
     }
 }
 
-void launch_select(op_volume* v, const BatchInv& I, const CamParams& C, int nf, bool record, const int* cube_keys, unsigned n_cubes) {
+int launch_select(op_volume* v, const BatchInv& I, const CamParams& C, int nf, bool record, const int* cube_keys, unsigned n_cubes) {
     const VolView V = v->view();
     if (cube_keys)
         hipLaunchKernelGGL(k_mark_cubes, dim3((n_cubes + 255u) / 256u), dim3(256), 0, v->stream, V, v->state, cube_keys, n_cubes);
     else if (KB_VOTE && KC_BANDS == 0 && !record && nf >= (v->select_mode > 0 ? 2 : KB_VOTE_MIN_FRAMES) && v->select_mode != OP_VOLUME_SELECT_DIRECT) { // (an explicit limit: every batch of >= 2 frames) // several frames: they record their selections, one pass claims every block once
+        // the frames' voting words (64 MB): only a volume that takes this path ever has them (PrepareCubes / ComputeBounding volumes, short batches, the
+        // many small sub-map volumes of a DenseSlam run do not)
+        if (!v->sbits) OP_HIP(op::cached_malloc((void**)&v->sbits, (size_t)kMaxBatch * kVoteCap * sizeof(unsigned long long)));
         const unsigned vote_cap = v->select_mode > 0 ? (unsigned)v->select_mode : kVoteCap;
         const int per_frame = std::max(8, std::min(kSelectGrid, (KB_VOTE_WGS / nf + 7) / 8 * 8)); // a multiple of 8: whole frames per XCD
         if (C.fast_px)
@@ -833,6 +836,7 @@ void launch_select(op_volume* v, const BatchInv& I, const CamParams& C, int nf, 
     else
         hipLaunchKernelGGL(k_select<false>, dim3(kSelectGrid, nf), dim3(256), 0, v->stream, I, C, V, (const uint2*)v->pimg, (const float2*)v->ptile,
                            v->state, record ? 1 : 0);
+    return OP_OK;
 }
 
 void launch_finish_select(op_volume* v) { hipLaunchKernelGGL(k_finish_select, dim3(256), dim3(256), 0, v->stream, v->view(), v->state); }

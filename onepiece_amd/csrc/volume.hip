@@ -311,7 +311,6 @@ void frame_params(const op_volume* v, const float pose[16], const float* pose_in
 }
 
 int vol_ensure_frame_buffers(op_volume* v) {
-    if (!v->sbits) OP_HIP(op::cached_malloc((void**)&v->sbits, (size_t)kMaxBatch * kVoteCap * sizeof(unsigned long long)));
     const size_t npx = (size_t)v->cam.width * v->cam.height;
     if (npx <= v->pimg_px && v->cam.width == v->pimg_w && v->cam.height == v->pimg_h) return OP_OK; // (KA's grid and the tile grid depend on both)
     OP_HIP(hipStreamSynchronize(v->stream)); // released buffers go back to a cache and may be handed out at once
@@ -363,7 +362,7 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
     }
     launch_prepare_frames(v, F, nf, C, Q, seq);
     if (sample) OP_HIP(hipEventRecord(ev[1], v->stream));
-    launch_select(v, I, C, nf, record, cube_keys, n_cubes);
+    OP_TRY(launch_select(v, I, C, nf, record, cube_keys, n_cubes));
     if (sample) OP_HIP(hipEventRecord(ev[2], v->stream));
     if (select_only) launch_finish_select(v);
     else launch_integrate(v, I, C, nf);
@@ -499,11 +498,14 @@ class CopyPool {
 // copied next to each other by the caller's thread and the CopyPool helpers, then ONE DMA moves the span they cover.
 int write_staged(void* dst, size_t n_parts, const void* const* parts, const size_t* bytes, const size_t* offsets, int device) {
     struct Stage { std::mutex mu; void* pinned = nullptr; size_t cap = 0; hipStream_t stream = nullptr; };
-    static Stage stage[16];
-    Stage& S = stage[device & 15];
+    constexpr int kStageDevices = 64;
+    static Stage stage[kStageDevices]; // one staging buffer and stream per device, keyed by the device's own number
+    if (device < 0 || device >= kStageDevices) return fail(OP_ERR_INVALID, "op_device_write: device %d (0 .. %d)", device, kStageDevices - 1);
+    Stage& S = stage[device];
     size_t lo = (size_t)-1, hi = 0;
     for (size_t i = 0; i < n_parts; ++i) {
         if (!parts[i] || !bytes[i]) return fail(OP_ERR_INVALID, "op_device_write: empty part");
+        if (offsets[i] + bytes[i] < offsets[i]) return fail(OP_ERR_INVALID, "op_device_write: offset + size overflows");
         lo = std::min(lo, offsets[i]); hi = std::max(hi, offsets[i] + bytes[i]);
     }
     if (n_parts == 0 || n_parts > 2) return fail(OP_ERR_INVALID, "op_device_write: one or two parts per call");

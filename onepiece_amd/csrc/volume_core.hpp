@@ -447,7 +447,7 @@ int check_cam(const op_camera* cam);
 // ---- kernel launchers (a kernel is launched from the translation unit that defines it)
 // select.hip: KA over the batch's frames (kKaFrames per launch); KB in the form the batch takes (cube_keys: k_mark_cubes instead); k_finish_select
 void launch_prepare_frames(op_volume* v, const BatchFwd& F, int nf, const CamParams& C, const BatchPtrs& Q, unsigned seq);
-void launch_select(op_volume* v, const BatchInv& I, const CamParams& C, int nf, bool record, const int* cube_keys, unsigned n_cubes);
+int launch_select(op_volume* v, const BatchInv& I, const CamParams& C, int nf, bool record, const int* cube_keys, unsigned n_cubes); // (may allocate the voting words: can fail)
 void launch_finish_select(op_volume* v);
 void kb_trace_dump(op_volume* v);            // -DKB_TRACE builds only
 // integrate.hip: KC

@@ -838,6 +838,36 @@ def test_sum_form_update_after_upload_and_on_the_wall_scene(oracle):
     _compare(oracle, ov2, hv2, exact=False)
 
 
+def test_sum_form_with_a_truncation_of_one_or_more_takes_the_exact_update(oracle):
+    """TSDFVoxel::IsValid is sdf < 1 (TSDFVoxel.h:75-78) and the reference re-tests it before EVERY frame: with truncation >= 1 an observation can itself
+    be "invalid" and is then REPLACED by the next one (weight 1 again) -- which a once-per-batch mean cannot reproduce.  The sum-form option therefore
+    only applies below 1; above, the volume is the exact one bit for bit, option or not."""
+    cam = small_camera(4)
+    frames = []
+    for i in range(6):
+        pose = S.room_pose(40 + i)
+        d, c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+        frames.append((d, c, pose))
+    vols = {}
+    for mode in ("exact", "sum_form"):
+        hcam = I.PinholeCamera()
+        hcam.fx, hcam.fy, hcam.cx, hcam.cy, hcam.width, hcam.height, hcam.depth_scale = cam
+        hv = I.CubeHandler(hcam, max_blocks=1 << 16)
+        hv.SetVoxelResolution(0.08); hv.SetTruncation(1.5)
+        hv.SetUpdateMode(mode)
+        for d, c, p in frames:
+            hv.IntegrateImage(d, c, p)
+        vols[mode] = hv.GetCubeMap()
+    ov = oracle.Volume(oracle.make_camera(*cam), voxel_res=0.08, trunc=1.5)
+    for d, c, p in frames:
+        ov.integrate(d, c, p)
+    ok, ox = ov.export()
+    for mode in vols:
+        k, v = vols[mode]
+        assert np.array_equal(k, ok) and np.array_equal(v.view(np.uint32), ox.view(np.uint32)), mode
+    assert (ox[..., 0][ox[..., 1] > 0] >= 1).any()        # the case exists in this volume: stored observations that IsValid rejects
+
+
 def test_batch64_build_on_the_largest_image_it_admits(tmp_path):
     """The documented build option -DOP_MAX_BATCH=64 (64-bit batch masks).  k_integrate addresses a batch's packed frames with 32-bit byte offsets,
     so the 64-frame build admits images of up to 2^23 pixels (the default: 2^24).  On a 4096 x 2048 image -- its limit -- 70 frames fused in
