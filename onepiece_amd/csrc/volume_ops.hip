@@ -146,11 +146,30 @@ __device__ __forceinline__ Vox5 interp_stage(const Vox5& a, const Vox5& b, float
     return vox_scale(sum, 1 / d); // operator/(w) = operator*(1 / w) (TSDFVoxel.h:68-71)
 }
 
+// workgroup-wide minimum / maximum of an int (512 threads = 8 waves), result in every thread
+__device__ __forceinline__ void wg_min_max(int v_lo, int v_hi, int* s_red, int* out_lo, int* out_hi) {
+    for (int o = 32; o > 0; o >>= 1) { v_lo = min(v_lo, __shfl_xor(v_lo, o, 64)); v_hi = max(v_hi, __shfl_xor(v_hi, o, 64)); }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads(); // (s_red may still be read from a previous call)
+    if ((threadIdx.x & 63) == 0) { s_red[wave] = v_lo; s_red[8 + wave] = v_hi; }
+    __syncthreads();
+    int lo = s_red[0], hi = s_red[8];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { lo = min(lo, s_red[k]); hi = max(hi, s_red[8 + k]); }
+    *out_lo = lo; *out_hi = hi;
+}
+
 // pass 1: AddTransformedCube / AddTransformedCubeNearest (CubeHandler.h:199-241), executed with the
-// RESULT's CubePara (alloc_res).  One workgroup per source block.
+// RESULT's CubePara (alloc_res).  One workgroup per source block.  A block's 512 voxels land in a handful of result blocks: the
+// workgroup gathers the distinct ids in a small LDS set and claims each ONCE in the result's hash table (a voxel-by-voxel claim
+// was ~2 000 hash probes per source block, most of them for ids another voxel had just entered).
+constexpr int kClaimSet = 128; // slots of the set (a power of two); a workgroup whose voxels reach more distinct blocks claims the overflow directly
 template <bool NEAREST>
 __global__ __launch_bounds__(512) void k_transform_alloc(VolView S, VolView D, State* dst_state, Mat4 T, float alloc_res) {
+    __shared__ unsigned long long s_set[kClaimSet];
     const int b = blockIdx.x, vid = threadIdx.x;
+    if (vid < kClaimSet) s_set[vid] = kEmptyKey;
+    __syncthreads();
     const int kx = S.keys[3 * b], ky = S.keys[3 * b + 1], kz = S.keys[3 * b + 2];
     const float half = alloc_res / 2;
     const float px = ((float)kx * 8.0f) * alloc_res + ((float)(vid & 7) * alloc_res + half);
@@ -171,16 +190,44 @@ __global__ __launch_bounds__(512) void k_transform_alloc(VolView S, VolView D, S
         if (cx == lx && cy == ly && cz == lz) continue;
         lx = cx; ly = cy; lz = cz;
         if (!key_in_range(cx, cy, cz)) { atomicOr(&dst_state->overflow, 8u); continue; }
+        // enter the id into the workgroup's set; a full set (never, for a rigid motion) falls back to the direct claim
+        const unsigned long long key = pack_key(cx, cy, cz);
+        unsigned sl = (unsigned)(hash_key_dev(cx, cy, cz) * 0x9E3779B97F4A7C15ULL >> 57) & (kClaimSet - 1);
+        bool placed = false;
+        for (int probe = 0; probe < kClaimSet; ++probe, sl = (sl + 1) & (kClaimSet - 1)) {
+            const unsigned long long cur = s_set[sl];
+            if (cur == key) { placed = true; break; }
+            if (cur == kEmptyKey) {
+                const unsigned long long old = atomicCAS(&s_set[sl], kEmptyKey, key);
+                if (old == kEmptyKey || old == key) { placed = true; break; }
+            }
+        }
+        if (!placed) { bool created; table_claim(D, dst_state, cx, cy, cz, &created); }
+    }
+    __syncthreads();
+    if (vid < kClaimSet && s_set[vid] != kEmptyKey) {
+        const unsigned long long key = s_set[vid];
         bool created;
-        table_claim(D, dst_state, cx, cy, cz, &created); // AddCube
+        table_claim(D, dst_state, (int)(key >> 42) - kCoordLimit, (int)((key >> 21) & 0x1FFFFFull) - kCoordLimit, (int)(key & 0x1FFFFFull) - kCoordLimit, &created); // AddCube
     }
 }
 
 // pass 2: every voxel of the result reads the source through trans^-1 (CubeHandler.h:257-294 /
 // :312-334) with the SOURCE's CubePara (this->c_para).  One workgroup per result block; result
 // voxels are still default, so `voxels[voxel_id] += result` stores `result` (weight == 0 -> other).
+// The taps of a block's 512 voxels fall into a few source blocks (a rotated 8^3 cube spans at most three per axis): the workgroup
+// takes the bounding box of its taps in block coordinates, looks every block of the box up ONCE (up to kSrcBox of them) and the taps
+// index that LDS table -- eight hash probes per voxel become none.  A box beyond kSrcBox blocks (a projective `trans`, NaN) probes per tap.
+constexpr int kSrcBox = 64;
+__device__ __forceinline__ Vox5 load_voxel(const VolView& S, int idx, int px, int py, int pz) {
+    if (idx < 0) return default_voxel();
+    const float* t = S.pool + (size_t)idx * kBlockFloats + ((px & 7) + (py & 7) * 8 + (pz & 7) * 64);
+    return Vox5{t[0], t[kVox], t[2 * kVox], t[3 * kVox], t[4 * kVox]};
+}
 template <bool NEAREST>
 __global__ __launch_bounds__(512) void k_transform_fill(VolView S, VolView D, Mat4 Tinv, float src_res) {
+    __shared__ int s_red[16];
+    __shared__ int s_slot[kSrcBox];
     const int b = blockIdx.x, vid = threadIdx.x;
     const int kx = D.keys[3 * b], ky = D.keys[3 * b + 1], kz = D.keys[3 * b + 2];
     const float half = src_res / 2;
@@ -195,19 +242,37 @@ __global__ __launch_bounds__(512) void k_transform_fill(VolView S, VolView D, Ma
     const float n0 = NEAREST ? q0 / q3 : q0 / q3 - half, n1 = NEAREST ? q1 / q3 : q1 / q3 - half,
                 n2 = NEAREST ? q2 / q3 : q2 / q3 - half;
     const int p0 = (int)floorf(n0 / src_res), p1 = (int)floorf(n1 / src_res), p2 = (int)floorf(n2 / src_res);
+    // the source blocks this workgroup's taps touch (taps at p and p + 1; the nearest form has ONE tap per voxel and probes directly: measured, the
+    // box costs it more than it saves).  An int overflow of p + 1 only ever widens the box: fallback.
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
+    if (!NEAREST) {
+        wg_min_max(p0 >> 3, (int)(((long long)p0 + 1) >> 3), s_red, &x0, &x1);
+        wg_min_max(p1 >> 3, (int)(((long long)p1 + 1) >> 3), s_red, &y0, &y1);
+        wg_min_max(p2 >> 3, (int)(((long long)p2 + 1) >> 3), s_red, &z0, &z1);
+    }
+    const long long ex = (long long)x1 - x0 + 1, ey = (long long)y1 - y0 + 1, ez = (long long)z1 - z0 + 1;
+    const bool boxed = !NEAREST && ex * ey <= kSrcBox && ex * ey * ez <= kSrcBox; // (uniform)
+    if (boxed) {
+        if (vid < (int)(ex * ey * ez)) s_slot[vid] = table_find(S, x0 + vid % (int)ex, y0 + (vid / (int)ex) % (int)ey, z0 + vid / (int)(ex * ey));
+        __syncthreads();
+    }
+    auto fetch = [&](int tx, int ty, int tz) -> Vox5 { // cube_map.find(GetCubeID(p)) + GetVoxel(GetVoxelID(p)); default voxel if absent
+        if (!boxed) return fetch_voxel(S, tx, ty, tz);
+        return load_voxel(S, s_slot[((tx >> 3) - x0) + (int)ex * (((ty >> 3) - y0) + (int)ey * ((tz >> 3) - z0))], tx, ty, tz);
+    };
     Vox5 r;
     if (NEAREST) {
-        r = fetch_voxel(S, p0, p1, p2);
+        r = fetch(p0, p1, p2);
     } else {
         Vox5 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = fetch_voxel(S, p0 + (k & 1), p1 + ((k >> 1) & 1), p2 + ((k >> 2) & 1));
+        for (int k = 0; k < 8; ++k) v[k] = fetch(p0 + (k & 1), p1 + ((k >> 1) & 1), p2 + ((k >> 2) & 1));
         // ReadVoxelInterpolate (VoxelCube.cpp:6-50)
         const float xw = (n0 - (float)p0 * src_res) / src_res, yw = (n1 - (float)p1 * src_res) / src_res,
                     zw = (n2 - (float)p2 * src_res) / src_res;
-        const Vox5 z1 = interp_stage(interp_stage(v[0], v[1], xw), interp_stage(v[2], v[3], xw), yw);
-        const Vox5 z2 = interp_stage(interp_stage(v[4], v[5], xw), interp_stage(v[6], v[7], xw), yw);
-        r = interp_stage(z1, z2, zw);
+        const Vox5 z1v = interp_stage(interp_stage(v[0], v[1], xw), interp_stage(v[2], v[3], xw), yw);
+        const Vox5 z2v = interp_stage(interp_stage(v[4], v[5], xw), interp_stage(v[6], v[7], xw), yw);
+        r = interp_stage(z1v, z2v, zw);
     }
     float* t = D.pool + (size_t)b * kBlockFloats + vid;
     t[0] = r.s; t[kVox] = r.w; t[2 * kVox] = r.c0; t[3 * kVox] = r.c1; t[4 * kVox] = r.c2;
