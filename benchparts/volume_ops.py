@@ -71,11 +71,15 @@ def run(c, out):
            "driver_wall_clock": [l for l in txt.splitlines() if l and not l.startswith("fused")]}
     if blocks:
         res["point_cloud"] = entry("k_point_cloud", 4096.0 * blocks + 12.0 * (points or 0), "per pass (count, then emit): the sdf + weight planes of every block (4 KB) [+ 24 B per point written by the emit pass, halved over the two passes]")
-        res["mesh"] = entry("k_mesh", 10240.0 * blocks + 36.0 * (tris or 0), "per pass (count, then emit): all five planes of every block (10 KB) [+ 72 B per triangle written by the emit pass, halved]",
-                            "the 7 neighbour blocks a block's +x/+y/+z faces need are re-reads that mostly hit in L2")
+        res["mesh"] = entry("k_mesh", 4096.0 * blocks + (36.0 + 36.0) * (tris or 0), "per pass (count, then emit): the sdf + weight planes of every block (4 KB), staged once in LDS "
+                            "[+ per triangle, in the emit pass: 72 B of colour gathers and 72 B written, halved over the two passes]",
+                            "the +x/+y/+z layers of the 7 neighbour blocks are re-reads that mostly hit in L2; 3.3 ms per pass before round 5 (every voxel loaded 8 corners x 5 planes)")
         if t_out:
             res["transform"] = entry("k_transform_fill<false>", 10240.0 * (t_out + blocks), "10 KB written per result block + every source block read at least once",
-                                     "eight trilinear taps per voxel, each through the hash: a gather kernel, not a streaming one")
+                                     "eight trilinear taps x five planes per voxel: a gather kernel (40 scattered 4-byte loads per voxel), not a streaming one; the source "
+                                     "blocks of a result block are looked up once per workgroup since round 5 (4.8 -> 2.9 ms on the 164 k-block volume)")
+            res["transform_alloc"] = entry("k_transform_alloc<false>", 512.0 * 4.0 * blocks, "nominal: one 4-byte key component per source voxel -- the kernel is hash-table work (claims), not traffic",
+                                           "the result blocks a source block's voxels land in are gathered in an LDS set and claimed once per workgroup since round 5 (3.4 -> 1.5 ms)")
         if tn_out:
             res["transform_nearest"] = entry("k_transform_fill<true>", 10240.0 * (tn_out + blocks), "10 KB written per result block + every source block read at least once")
     if n_pts:

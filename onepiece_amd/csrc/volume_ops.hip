@@ -316,51 +316,72 @@ __global__ __launch_bounds__(512) void k_point_cloud(VolView V, float res, float
 // MarchingCube (MarchingCube.cpp:8-74).  One workgroup per block, one thread per voxel in the reference's
 // x, y, z loop order; the 7 neighbour blocks a voxel on the +x/+y/+z faces needs are looked up once per
 // workgroup.  The 256 x 16 triangle table and the 12 x 2 edge table are the CALLER'S data (the reference
-// keeps them in MarchingCubePredefined.h; its shim passes them through the C-ABI), staged in LDS.
+// keeps them in MarchingCubePredefined.h; its shim passes them through the C-ABI); the triangle table arrives
+// packed to one signed byte per entry (4 KB: it stays in the L1 / L2 of every CU instead of being copied into
+// 16 KB of LDS by each of the volume's workgroups).
 // Two passes with the same kernel: counts (triangles per block) and, after a scan, the ordered emit of
 // three unshared vertices per triangle, exactly as MarchingCube() pushes them.
+// The block's sdf values and IsValid flags (and the +x/+y/+z layer of its neighbours) are staged ONCE in a 9^3 LDS
+// tile: the case of a voxel comes from 8 LDS reads; positions are arithmetic; colours -- needed only by the few
+// voxels that emit triangles, and only in the emit pass -- are gathered per emitted vertex.  (Rounds 1-4 loaded
+// 8 corners x 5 planes from global memory for every voxel in both passes: 3.3 ms per pass on the 164 k-block
+// room volume, profiles/r05_volume_ops.kernel_stats.csv.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const int* __restrict__ tri_table, const int* __restrict__ edge_pairs,
+constexpr int kMeshEdge = 9, kMeshTile = kMeshEdge * kMeshEdge * kMeshEdge;
+__global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const signed char* __restrict__ tri8, const int* __restrict__ edge_pairs,
                                               const unsigned* __restrict__ blocks, unsigned* __restrict__ counts,
                                               const unsigned* __restrict__ offsets, float* __restrict__ pts, float* __restrict__ col) {
-    __shared__ int s_tri[256 * 16];
+    __shared__ float s_sdf[kMeshTile];
+    __shared__ unsigned char s_ok[kMeshTile + 3]; // 1: the voxel exists and IsValid (sdf < 1, weight > 0: TSDFVoxel.h:75-78)
     __shared__ int s_edge[24];
     __shared__ int s_nb[8];
     __shared__ unsigned s_w[8];
     const int b = (int)blocks[blockIdx.x], o = threadIdx.x;
-    for (int k = o; k < 256 * 16; k += 512) s_tri[k] = tri_table[k];
     if (o < 24) s_edge[o] = edge_pairs[o];
     const int kx = V.keys[3 * b], ky = V.keys[3 * b + 1], kz = V.keys[3 * b + 2];
     if (o < 8) s_nb[o] = o == 0 ? b : table_find(V, kx + (o & 1), ky + ((o >> 1) & 1), kz + ((o >> 2) & 1)); // HasCube(neighbor_cube_id)
     __syncthreads();
+    {   // the tile: own 512 voxels (thread = voxel id, coalesced plane rows), then the 217 voxels of the +x / +y / +z layer
+        const float* own = V.pool + (size_t)b * kBlockFloats;
+        const float sd = own[o], w = own[kVox + o];
+        const int ti = (o & 7) + kMeshEdge * ((o >> 3) & 7) + kMeshEdge * kMeshEdge * (o >> 6);
+        s_sdf[ti] = sd; s_ok[ti] = (sd >= 1 || w <= 0) ? 0 : 1;
+        if (o < 217) {
+            int x, y, z;
+            if (o < 81) { x = o % 9; y = o / 9; z = 8; }
+            else if (o < 153) { const int j = o - 81; x = j % 9; y = 8; z = j / 9; }
+            else { const int j = o - 153; x = 8; y = j & 7; z = j >> 3; }
+            const int nb = s_nb[(x >> 3) | ((y >> 3) << 1) | ((z >> 3) << 2)];
+            float sd2 = 0.0f;
+            unsigned char ok2 = 0;
+            if (nb >= 0) {
+                const float* t = V.pool + (size_t)nb * kBlockFloats + ((x & 7) + (y & 7) * 8 + (z & 7) * 64);
+                sd2 = t[0];
+                ok2 = (sd2 >= 1 || t[kVox] <= 0) ? 0 : 1;
+            }
+            const int tj = x + kMeshEdge * y + kMeshEdge * kMeshEdge * z;
+            s_sdf[tj] = sd2; s_ok[tj] = ok2;
+        }
+    }
+    __syncthreads();
     const int x = o >> 6, y = (o >> 3) & 7, z = o & 7;    // loop nest: x outer, y, z inner
-    const int ox = x == 7, oy = y == 7, oz = z == 7;      // NeighborCubeIDOffset[index]
-    const float cube_res = 8.0f * res, half = res / 2;    // VoxelCube.h:149-153, :48-61
-    float cp[8][3], cs[8], cc[8][3];
+    float cs[8];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int xo = (i == 1 || i == 2 || i == 5 || i == 6), yo = (i == 2 || i == 3 || i == 6 || i == 7), zo = i >= 4; // CornerXYZOffset, VoxelCube.h:45-47
-        const int sel = (xo & ox) | ((yo & oy) << 1) | ((zo & oz) << 2);
-        const int nb = s_nb[sel];
-        const int vx = (x + xo) & 7, vy = (y + yo) & 7, vz = (z + zo) & 7;
-        if (ok && nb < 0) ok = false;
-        if (ok) {
-            const float* t = V.pool + (size_t)nb * kBlockFloats + (vx + vy * 8 + vz * 64);
-            const float sdf = t[0], w = t[kVox];
-            cs[i] = sdf; cc[i][0] = t[2 * kVox]; cc[i][1] = t[3 * kVox]; cc[i][2] = t[4 * kVox];
-            cp[i][0] = (float)(kx + (xo & ox)) * cube_res + ((float)vx * res + half);
-            cp[i][1] = (float)(ky + (yo & oy)) * cube_res + ((float)vy * res + half);
-            cp[i][2] = (float)(kz + (zo & oz)) * cube_res + ((float)vz * res + half);
-            if (sdf >= 1 || w <= 0) ok = false;            // !IsValid (TSDFVoxel.h:75-78)
-        }
+        const int tq = (x + xo) + kMeshEdge * (y + yo) + kMeshEdge * kMeshEdge * (z + zo);
+        cs[i] = s_sdf[tq];
+        ok = ok && s_ok[tq] != 0;
     }
     int ci = 0;
     unsigned ntri = 0;
+    const signed char* row = tri8;
     if (ok) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) ci |= cs[i] > 0 ? 1 << i : 0;  // DetermineCase
-        for (int i = 0; i < 16 && s_tri[16 * ci + i] != -1; i += 3) ++ntri;
+        row = tri8 + 16 * ci;
+        for (int i = 0; i < 16 && row[i] != -1; i += 3) ++ntri;
     }
     // exclusive scan of ntri over the workgroup in thread (= reference loop) order
     unsigned incl = ntri;
@@ -376,22 +397,31 @@ __global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const int* _
     unsigned first = incl - ntri;
     for (int k = 0; k < wave; ++k) first += s_w[k];
     size_t vtx = ((size_t)offsets[blockIdx.x] + first) * 3;
-    for (int i = 0; i < 16 && s_tri[16 * ci + i] != -1; i += 3)
+    const float cube_res = 8.0f * res, half = res / 2;    // VoxelCube.h:149-153, :48-61
+    for (int i = 0; i < 16 && row[i] != -1; i += 3)
         for (int j = 0; j < 3; ++j, ++vtx) {
-            const int e = s_tri[16 * ci + i + j], a = s_edge[2 * e], c = s_edge[2 * e + 1];
-            // InterpolateEdgeVetex (MarchingCube.cpp:8-16); corners picked by dynamic index -> select chains
-            float pa[3] = {0, 0, 0}, pc[3] = {0, 0, 0}, ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0}, sa = 0, sc = 0;
+            const int e = row[i + j];
+            // InterpolateEdgeVetex (MarchingCube.cpp:8-16) between corners s_edge[2e] and s_edge[2e + 1]
+            float sv[2], pv[2][3], cv[2][3];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (q == a) { sa = cs[q]; pa[0] = cp[q][0]; pa[1] = cp[q][1]; pa[2] = cp[q][2]; ca[0] = cc[q][0]; ca[1] = cc[q][1]; ca[2] = cc[q][2]; }
-                if (q == c) { sc = cs[q]; pc[0] = cp[q][0]; pc[1] = cp[q][1]; pc[2] = cp[q][2]; cb[0] = cc[q][0]; cb[1] = cc[q][1]; cb[2] = cc[q][2]; }
+            for (int q = 0; q < 2; ++q) {
+                const int cn = s_edge[2 * e + q];
+                const int xo = (cn == 1 || cn == 2 || cn == 5 || cn == 6), yo = (cn == 2 || cn == 3 || cn == 6 || cn == 7), zo = cn >= 4;
+                const int gx = x + xo, gy = y + yo, gz = z + zo;                     // 0 .. 8
+                const int vx = gx & 7, vy = gy & 7, vz = gz & 7, bxo = gx >> 3, byo = gy >> 3, bzo = gz >> 3;
+                sv[q] = s_sdf[gx + kMeshEdge * gy + kMeshEdge * kMeshEdge * gz];
+                pv[q][0] = (float)(kx + bxo) * cube_res + ((float)vx * res + half);
+                pv[q][1] = (float)(ky + byo) * cube_res + ((float)vy * res + half);
+                pv[q][2] = (float)(kz + bzo) * cube_res + ((float)vz * res + half);
+                const float* t = V.pool + (size_t)s_nb[bxo | (byo << 1) | (bzo << 2)] * kBlockFloats + (vx + vy * 8 + vz * 64);
+                cv[q][0] = t[2 * kVox]; cv[q][1] = t[3 * kVox]; cv[q][2] = t[4 * kVox];
             }
-            const float sdf_diff = sc - sa;
-            const float t = sa / sdf_diff;
+            const float sdf_diff = sv[1] - sv[0];
+            const float t = sv[0] / sdf_diff;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                pts[3 * vtx + k] = pa[k] - t * (pc[k] - pa[k]);
-                col[3 * vtx + k] = (ca[k] + cb[k]) / 2.0f;  // (c1 + c2) / 2
+                pts[3 * vtx + k] = pv[0][k] - t * (pv[1][k] - pv[0][k]);
+                col[3 * vtx + k] = (cv[0][k] + cv[1][k]) / 2.0f;  // (c1 + c2) / 2
             }
         }
 }
@@ -685,21 +715,24 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
     }
     const unsigned nl = (unsigned)list.size();
     unsigned *d_list = nullptr, *d_counts = nullptr, *d_offsets = nullptr;
-    int *d_tri = nullptr, *d_edge = nullptr;
+    signed char* d_tri = nullptr;
+    int* d_edge = nullptr;
     float *d_pts = nullptr, *d_col = nullptr;
     int rc = OP_OK;
+    signed char tri8[256 * 16];
+    for (int i = 0; i < 256 * 16; ++i) tri8[i] = (signed char)tri_table[i]; // (validated above: -1 .. 11)
     hipError_t e = op::cached_malloc((void**)&d_list, nl * sizeof(unsigned));
     if (e == hipSuccess) e = op::cached_malloc((void**)&d_counts, nl * sizeof(unsigned));
     if (e == hipSuccess) e = op::cached_malloc((void**)&d_offsets, nl * sizeof(unsigned));
-    if (e == hipSuccess) e = op::cached_malloc((void**)&d_tri, 256 * 16 * sizeof(int));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_tri, 256 * 16);
     if (e == hipSuccess) e = op::cached_malloc((void**)&d_edge, 24 * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_list, list.data(), nl * sizeof(unsigned), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_tri, tri_table, 256 * 16 * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_tri, tri8, 256 * 16, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_edge, edge_pairs, 24 * sizeof(int), hipMemcpyHostToDevice);
     std::vector<unsigned> cnt(nl), off(nl);
     size_t total_tri = 0;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const int*)d_tri, (const int*)d_edge, (const unsigned*)d_list,
+        hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const signed char*)d_tri, (const int*)d_edge, (const unsigned*)d_list,
                            d_counts, (const unsigned*)nullptr, (float*)nullptr, (float*)nullptr);
         e = hipStreamSynchronize(v->stream);
         if (e == hipSuccess) e = hipMemcpy(cnt.data(), d_counts, nl * sizeof(unsigned), hipMemcpyDeviceToHost);
@@ -715,7 +748,7 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
             if (e == hipSuccess) e = op::cached_malloc((void**)&d_pts, total * 12);
             if (e == hipSuccess) e = op::cached_malloc((void**)&d_col, total * 12);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const int*)d_tri, (const int*)d_edge,
+                hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const signed char*)d_tri, (const int*)d_edge,
                                    (const unsigned*)d_list, (unsigned*)nullptr, (const unsigned*)d_offsets, d_pts, d_col);
                 e = hipStreamSynchronize(v->stream);
             }
