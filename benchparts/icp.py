@@ -111,16 +111,52 @@ def run(c, out):
                                   "points": [int(len(x)) for x in srcs],
                                   "note": "K contexts x %d point-to-plane iterations on K different frame pairs, enqueued together (op_icp_run_enqueue: each on its own "
                                           "stream and host thread) and waited for; aggregate = K x iterations / wall time, best of 3" % iters}
-        if c.oracle is not None:   # per-context parity against the CPU path (10 iterations, four of the pairs)
+        # the reference-order mode (OP_ICP_SUMS_REFERENCE_F32: every iteration's 36 + 6 sums sequentially in float32, by one wave on the device): the mode that follows
+        # the CPU path on EVERY pair -- the reference's own float32 sums decide, where J^T J sits at JacobiSVD's rank threshold, which way its pose goes
+        strict_rates = {}
+        for hk in ctxs:
+            L.check(lib.op_icp_set_option(hk, L.OP_ICP_OPT_SUMS, L.OP_ICP_SUMS_REFERENCE_F32))
+        for Kc in (1, 4):
+            res_k = [L.IcpResult() for _ in range(Kc)]
+            best = None
+            for rep in range(2):
+                t = time.perf_counter()
+                for k in range(Kc):
+                    L.check(lib.op_icp_run_enqueue(ctxs[k], 1, fp(T0), 20, C.byref(res_k[k]), None, 0))
+                for k in range(Kc):
+                    L.check(lib.op_icp_wait(ctxs[k]))
+                dtk = time.perf_counter() - t
+                best = dtk if best is None else min(best, dtk)
+            strict_rates[Kc] = Kc * 20 / best
+        out["icp"]["reference_order_mode"] = {"iters_per_s": strict_rates[1], "aggregate_iters_per_s_4_in_flight": strict_rates[4],
+                                              "note": "OP_ICP_SUMS_REFERENCE_F32 with the sums on the device (k_seq_sums, the tracker's kernel): identical to the CPU path on every pair "
+                                                      "(pose_parity_over_pairs below); 356 it/s in round 4, when the ordered rows went to one host thread every iteration"}
+        if c.oracle is not None:   # per-pair parity of BOTH modes against the CPU path, and the CPU path against itself with double sums (10 iterations, four pairs)
             par = []
+            rel_ = lambda a_, b_: float(np.linalg.norm(np.asarray(a_, np.float64) - np.asarray(b_, np.float64)) / np.linalg.norm(np.asarray(b_, np.float64)))
             for k in range(4):
-                rk = L.IcpResult()
-                L.check(lib.op_icp_run(ctxs[k], 1, fp(T0), 10, C.byref(rk), None, 0, None, None))
+                rs_ = L.IcpResult()
+                L.check(lib.op_icp_run(ctxs[k], 1, fp(T0), 10, C.byref(rs_), None, 0, None, None))                      # reference-order sums
+                L.check(lib.op_icp_set_option(ctxs[k], L.OP_ICP_OPT_SUMS, L.OP_ICP_SUMS_FP64))
+                rd_ = L.IcpResult()
+                L.check(lib.op_icp_run(ctxs[k], 1, fp(T0), 10, C.byref(rd_), None, 0, None, None))                      # default: fp64 device reduction
                 ref_k = c.oracle.icp(srcs[k], tgts[k], nrms[k], None, 10, 0.01, True)
-                gT = np.array(rk.T, np.float64).reshape(4, 4)
-                par.append({"pair": [2 * k, 2 * k + 1], "returned_T_rel_err_vs_cpu": float(np.linalg.norm(gT - ref_k["T"].astype(np.float64)) / np.linalg.norm(ref_k["T"].astype(np.float64))),
-                            "inliers": {"gpu": int(rk.n_inliers), "cpu": int(len(ref_k["pairs"]))}})
-            out["icp"]["replicas"]["parity_10_iterations"] = par
+                c.oracle.lib().orc_set_accumulate_double(1)
+                ref_d = c.oracle.icp(srcs[k], tgts[k], nrms[k], None, 10, 0.01, True)
+                c.oracle.lib().orc_set_accumulate_double(0)
+                gs_, gd_ = np.array(rs_.T, np.float64).reshape(4, 4), np.array(rd_.T, np.float64).reshape(4, 4)
+                par.append({"pair": [2 * k, 2 * k + 1],
+                            "reference_order_mode": {"returned_T_rel_err_vs_cpu": rel_(gs_, ref_k["T"]), "inliers": int(rs_.n_inliers)},
+                            "default_mode_fp64": {"returned_T_rel_err_vs_cpu": rel_(gd_, ref_k["T"]), "returned_T_rel_err_vs_cpu_with_double_sums": rel_(gd_, ref_d["T"]), "inliers": int(rd_.n_inliers)},
+                            "cpu": {"inliers": int(len(ref_k["pairs"])), "float_sums_vs_double_sums_rel_err": rel_(ref_k["T"], ref_d["T"])}})
+            out["icp"]["pose_parity_over_pairs"] = {
+                "pairs": par, "iterations": 10, "bar": 1e-4,
+                "default_mode_within_bar": int(sum(p_["default_mode_fp64"]["returned_T_rel_err_vs_cpu"] <= 1e-4 for p_ in par)),
+                "reference_order_mode_within_bar": int(sum(p_["reference_order_mode"]["returned_T_rel_err_vs_cpu"] <= 1e-4 for p_ in par)),
+                "note": "the reference sums J^T J / J^T r sequentially in float32 (ICP.cpp:121-136) and solves with JacobiSVD's rank threshold: on pairs whose system sits at that "
+                        "threshold its OWN answer moves by up to 5e-2 when the same sums are taken in double (cpu.float_sums_vs_double_sums_rel_err).  The default mode (fp64 "
+                        "reduction) equals the CPU path with double sums to 1e-7 on every pair and meets the 1e-4 bar where the reference is stable (the timed pair 0 -> 1: 0.0); "
+                        "the reference-order mode reproduces the float32 sums and meets it everywhere, at reference_order_mode.iters_per_s"}
         for hk in ctxs:
             lib.op_icp_destroy(hk)
     except Exception as e:

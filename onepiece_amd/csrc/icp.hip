@@ -33,6 +33,7 @@
 
 #include "common.hpp"
 #include "host_math.hpp"
+#include "seq_sums.hpp"
 
 namespace {
 
@@ -587,6 +588,16 @@ __global__ __launch_bounds__(256) void k_emit_rows(const float* __restrict__ T, 
         const float q3 = ((M[12] * s0 + M[13] * s1) + M[14] * s2) + M[15] * 1.0f;
         s0 = q0 / q3; s1 = q1 / q3; s2 = q2 / q3;
     }
+    if (KIND == 3) { // the Jacobian row and residual of the pair as ICP.cpp:121-136 forms them (op_host::plane_sums_reference_order): {n, s x n, n.s - n.t}
+        const float t0 = tgt_orig[3 * (size_t)b], t1 = tgt_orig[3 * (size_t)b + 1], t2 = tgt_orig[3 * (size_t)b + 2];
+        const float n0 = nrm_orig[3 * (size_t)b], n1 = nrm_orig[3 * (size_t)b + 1], n2 = nrm_orig[3 * (size_t)b + 2];
+        const float ns = n0 * s0 + (n1 * s1 + n2 * s2), nt = n0 * t0 + (n1 * t1 + n2 * t2); // dot3 = Eigen's a0 + (a1 + a2)
+        float* o7 = rows + (size_t)start[i] * 7;
+        o7[0] = n0; o7[1] = n1; o7[2] = n2;
+        o7[3] = s1 * n2 - s2 * n1; o7[4] = s2 * n0 - s0 * n2; o7[5] = s0 * n1 - s1 * n0;
+        o7[6] = ns - nt;
+        return;
+    }
     constexpr int W = KIND == 1 ? 9 : 6;
     float* o = rows + (size_t)start[i] * W;
     o[0] = s0; o[1] = s1; o[2] = s2;
@@ -841,6 +852,11 @@ struct op_icp {
     unsigned *flag = nullptr, *start = nullptr, *scan_tot = nullptr;
     float *rows_dev = nullptr, *rows_host = nullptr; // src_cap x 9 floats each; rows_host is pinned
     size_t rows_cap = 0;
+    // reference-order point-to-plane sums on the device (k_seq_sums, seq_sums.hpp): the 42 results + the row count, and whether the kernel may have its LDS
+    float* seq_out = nullptr;
+    float* seq_host = nullptr;       // pinned
+    unsigned* seq_total = nullptr;
+    int seq_ok = -1;                 // -1: not asked yet
     // op_icp_run_enqueue / op_icp_wait: the loop needs the host after every iteration (the 6x6 solve), so an enqueued run proceeds on a host
     // thread of the context's own -- K contexts (each with its stream) register K frame pairs side by side: ICP's only parallel axis (replicas)
     std::thread worker;
@@ -910,6 +926,20 @@ void expand_plane_sums(const double in[kNSums], double JTJ[36], double JTr[6]) {
 
 // Compacts the rows of the current inlier set (c->inl, written by a pass with write_inl) in ascending source
 // index, copies the first n_rows of them to pinned host memory and waits.  The transform is read from c->T_dev.
+// k_seq_sums needs ~150 KB of dynamic LDS (opt-in attribute) and three small buffers; false = sum on the host as before
+bool seq_device_ok(op_icp* c) {
+    if (c->seq_ok < 0) {
+        int lds_max = 0;
+        bool ok = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) == hipSuccess && (size_t)lds_max >= seq_lds_bytes(42, 7, 1) &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_sums<42, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(42, 7, 1)) == hipSuccess;
+        if (ok) ok = op::cached_malloc((void**)&c->seq_out, 64 * sizeof(float)) == hipSuccess && op::cached_malloc((void**)&c->seq_total, sizeof(unsigned)) == hipSuccess &&
+                     op::cached_host_malloc((void**)&c->seq_host, 64 * sizeof(float)) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        c->seq_ok = ok ? 1 : 0;
+    }
+    return c->seq_ok == 1;
+}
+
 int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
     if (rows) *rows = nullptr;
     if (!c->n || !n_rows) return OP_OK;
@@ -935,7 +965,7 @@ int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nwg), dim3(256), 0, c->stream, (const unsigned*)c->flag, n, (const unsigned*)c->scan_tot, c->start);
 #define OP_EMIT(K) hipLaunchKernelGGL(k_emit_rows<K>, dim3(g256), dim3(256), 0, c->stream, (const float*)c->T_dev, (const float*)c->src, \
                                       (const float*)c->tgt_orig, (const float*)c->nrm_orig, (const int*)c->inl, (const unsigned*)c->start, n, c->rows_dev)
-    if (kind == 1) OP_EMIT(1); else if (kind == 2) OP_EMIT(2); else OP_EMIT(0);
+    if (kind == 1) OP_EMIT(1); else if (kind == 2) OP_EMIT(2); else if (kind == 3) OP_EMIT(3); else OP_EMIT(0);
 #undef OP_EMIT
     OP_HIP(hipGetLastError());
     if (!rows) return OP_OK; // enqueue only: the caller copies c->rows_dev itself
@@ -1087,6 +1117,9 @@ int op_icp_destroy(op_icp* c) {
     for (hipEvent_t ev : c->chunk_ev)
         op::release_event(ev, c->device);
     if (c->rows_host) op::cached_free(c->rows_host);
+    if (c->seq_out) op::cached_free(c->seq_out);
+    if (c->seq_total) op::cached_free(c->seq_total);
+    if (c->seq_host) op::cached_free(c->seq_host);
     op::release_stream(c->stream, c->device);
     delete c;
     return OP_OK;
@@ -1181,6 +1214,26 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             OP_TRY(run_pass(c, pass_mode, cur, true, r)); // leaves `cur` in c->T_dev
             const size_t n_it = (size_t)(r[28] + 0.5);
             const float* rows = nullptr;
+            if (pass_mode == 1 && seq_device_ok(c) && n_it) {
+                // the 36 + 6 sequential float32 sums by one wave on the device (k_seq_sums: the tracker's kernel, same row layout {J[6], r}): the ordered rows never
+                // leave HBM, 42 numbers come back -- ~0.8 ms for 3e5 inliers instead of an 11 MB transfer and a pass on one host core
+                OP_TRY(emit_rows(c, 3, n_it, nullptr));
+                const unsigned n_rows_u = (unsigned)n_it;
+                OP_HIP(hipMemcpyAsync(c->seq_total, &n_rows_u, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL((k_seq_sums<42, 7, 1>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 7, 1), c->stream, (const float*)c->rows_dev, (const unsigned*)c->seq_total, c->seq_out);
+                OP_HIP(hipMemcpyAsync(c->seq_host, c->seq_out, 43 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                OP_HIP(hipStreamSynchronize(c->stream));
+                double JTJ[36], JTr[6];
+                float x[6];
+                for (int k = 0; k < 36; ++k) JTJ[k] = c->seq_host[k];
+                for (int k = 0; k < 6; ++k) JTr[k] = c->seq_host[36 + k];
+                op_host::solve6_psd<true>(JTJ, JTr, x);
+                op_host::se3_exp(x, tmp_T);
+                op_host::mat4_mul(tmp_T, cur, cur);
+                if (per_iter_inliers) per_iter_inliers[it] = (int32_t)n_it;
+                if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
+                continue;
+            }
             OP_TRY(emit_rows(c, pass_mode == 1 ? 1 : 2, n_it, &rows));
             if (pass_mode == 1) {
                 double JTJ[36], JTr[6];

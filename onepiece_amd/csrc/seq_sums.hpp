@@ -1,0 +1,125 @@
+// seq_sums.hpp -- sequential float32 sums on the device: the reference adds long runs of products to float32 accumulators ONE AFTER THE OTHER
+// (the dense tracker's J J^T / J r over the accepted pixels, DenseOdometryFunction.cpp:297-381; point-to-plane ICP's over the inliers, ICP.cpp:121-136),
+// and the rounding of those 10^5..10^6 dependent additions is part of its result -- it moves a pose by up to 2e-4 in the tracker and, where the 6x6
+// system sits at JacobiSVD's rank threshold, by up to 5e-2 in ICP (DESIGN.md sections 5, 7).  A sequential float sum cannot be re-associated; what CAN
+// run side by side are its accumulators.  Included by odometry.hip and icp.hip (each translation unit gets its own copy of the kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace {
+
+constexpr int kSeqRows = 384;          // rows per tile
+constexpr int kSeqStride = kSeqRows + 4; // floats between two accumulators' rows in LDS: 4 (mod 32) spreads the lanes' 16-byte reads over the banks
+constexpr int kSeqProducers = 2 * kSeqRows; // 12 producer waves: producer p owns row p % kSeqRows and every second accumulator
+constexpr int kSeqThreads = 1024;      // wave 0 sums; waves 4, 8 and 12 -- the ones that share its SIMD -- only keep the barriers company, the other 12 produce
+
+// products of one row for the accumulators k = H, H + 2, ...: everything but the row's address is a compile-time constant
+template <int NACC, int H>
+__device__ __forceinline__ void seq_produce_row(const float* __restrict__ r, float* __restrict__ pd_row) {
+    if (NACC == 42) {
+        float J[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) J[i] = r[i];
+#pragma unroll
+        for (int k = H; k < 42; k += 2) pd_row[k * kSeqStride] = k < 36 ? J[k / 6] * J[k % 6] : J[k - 36] * J[6];
+    } else {
+        if (H < NACC) pd_row[H * kSeqStride] = r[H];
+    }
+}
+
+// Sequential float32 sums of NACC accumulators over n_pix compacted pixels of NF floats each, RPP rows per pixel.
+//   NACC 42 (NF 7 * RPP): row = {J[6], r}; accumulator a*6+b += J[a]*J[b] (a, b < 6), accumulator 36+a += J[a]*r   -- the order of
+//                    op_host::track_sums_reference_order: per pixel row 0 then row 1, per accumulator one rounded product and one rounded add
+//   NACC 2  (NF 2):  accumulator k += value k of the pixel (NormalizeIntensity's two sums)
+// One workgroup.  Wave 0 sums: lane k owns accumulator k and reads four consecutive rows of it per ds_read_b128, the next 32
+// rows always in flight (two register sets) so that its only cost per row is the dependent add -- 8.25 shader cycles on this chip
+// (tools/valu_ubench.hip OP 41), the floor of any sequential float32 sum; measured here: ~10 per row.  Twelve waves on the other SIMDs produce: thread p owns row
+// p % 384 of the NEXT tile and every second accumulator -- 7 LDS reads, 21 multiplies, 21 LDS writes at constant offsets -- and stages
+// the rows of the tile after that (global loads in flight while it multiplies).  out[0 .. NACC-1] = the sums, ((unsigned*)out)[NACC] = n_pix.
+// Rows beyond the last pixel are products of zeros: acc + (+0.0f) == acc for every acc this loop can hold (it starts at +0 and a float
+// sum only yields -0 from -0 + -0), so every tile is summed over all of its 384 rows.
+template <int NACC, int NF, int RPP>
+__global__ __launch_bounds__(kSeqThreads) void k_seq_sums(const float* __restrict__ rows, const unsigned* __restrict__ n_pix_ptr, float* __restrict__ out) {
+    extern __shared__ float seq_lds[];
+    constexpr int P = kSeqRows / RPP;                        // pixels per tile
+    constexpr int RF = NF / RPP;                             // floats per row
+    constexpr int kStage = P * NF;                           // floats of one staged tile
+    constexpr int kLoads = (kStage + kSeqProducers - 1) / kSeqProducers;
+    float* prod = seq_lds;                                   // [2][NACC][kSeqStride]
+    float* stage = seq_lds + 2 * NACC * kSeqStride;          // [2][kStage]
+    const unsigned n_pix = *n_pix_ptr;
+    const unsigned n_tiles = (n_pix + (unsigned)P - 1u) / (unsigned)P;
+    const int tid = threadIdx.x;
+    const bool consumer = tid < 64;
+    const int wave = tid >> 6;
+    const bool idle = wave != 0 && (wave & 3) == 0;          // same SIMD as the summing wave (waves go to the SIMDs round-robin): nothing may delay its adds
+    const int pj = (wave - 1 - (wave >> 2)) * 64 + (tid & 63); // producer index 0 .. 767 (meaningless for wave 0 and the idle waves)
+    const int prow = pj >= kSeqRows ? pj - kSeqRows : pj;    // its row of the tile
+    auto load_tile = [&](unsigned tile, float (&reg)[kLoads]) { // global -> registers (zeros beyond the data)
+        const size_t base = (size_t)tile * kStage, end = (size_t)n_pix * NF;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int e = pj + i * kSeqProducers;
+            reg[i] = (e < kStage && base + (size_t)e < end) ? rows[base + (size_t)e] : 0.0f;
+        }
+    };
+    auto store_tile = [&](int buf, const float (&reg)[kLoads]) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int e = pj + i * kSeqProducers;
+            if (e < kStage) stage[buf * kStage + e] = reg[i];
+        }
+    };
+    auto produce = [&](int buf) { // stage[buf] -> prod[buf]: RPP rows of RF floats per pixel, row * RF == pixel * NF + (row % RPP) * RF
+        const float* r = stage + buf * kStage + prow * RF;
+        float* pd_row = prod + buf * (NACC * kSeqStride) + prow;
+        if (pj < kSeqRows) seq_produce_row<NACC, 0>(r, pd_row); // (wave-uniform: 6 waves per half)
+        else seq_produce_row<NACC, 1>(r, pd_row);
+    };
+    float acc = 0.0f;
+    float reg[kLoads];
+    // prologue: tile 0 staged and produced, tile 1 staged
+    const bool producer = !consumer && !idle;
+    if (producer && n_tiles) { load_tile(0, reg); store_tile(0, reg); }
+    __syncthreads();
+    if (producer && n_tiles) { produce(0); load_tile(1, reg); store_tile(1, reg); }
+    __syncthreads();
+    if (consumer) __builtin_amdgcn_s_setprio(3);
+    for (unsigned t = 0; t < n_tiles; ++t) {
+        const int cur = (int)(t & 1u);
+        if (consumer) {
+            if (tid < NACC) {
+                const float4* src = reinterpret_cast<const float4*>(prod + cur * (NACC * kSeqStride) + tid * kSeqStride);
+                constexpr int kChunk = 8, kChunks = kSeqRows / 4 / kChunk; // 8 x 16 bytes = 32 rows per register set, 12 sets per tile
+                static_assert(kChunks % 2 == 0, "two register sets alternate");
+                float4 A[kChunk], B[kChunk];
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) A[i] = src[i];
+#pragma unroll 1
+                for (int c = 0; c < kChunks; c += 2) {
+#pragma unroll
+                    for (int i = 0; i < kChunk; ++i) B[i] = src[(c + 1) * kChunk + i];
+#pragma unroll
+                    for (int i = 0; i < kChunk; ++i) { acc += A[i].x; acc += A[i].y; acc += A[i].z; acc += A[i].w; }
+                    if (c + 2 < kChunks) {
+#pragma unroll
+                        for (int i = 0; i < kChunk; ++i) A[i] = src[(c + 2) * kChunk + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < kChunk; ++i) { acc += B[i].x; acc += B[i].y; acc += B[i].z; acc += B[i].w; }
+                }
+            }
+        } else if (producer) {
+            if (t + 2 < n_tiles) load_tile(t + 2, reg);      // in flight while the products are formed
+            if (t + 1 < n_tiles) produce(cur ^ 1);           // tile t + 1 from stage[cur ^ 1]
+            if (t + 2 < n_tiles) store_tile(cur, reg);       // stage[cur] held tile t: consumed by produce() one iteration ago
+        }
+        __syncthreads();
+    }
+    if (consumer && tid < NACC) out[tid] = acc;
+    if (tid == 0) reinterpret_cast<unsigned*>(out)[NACC] = n_pix;
+}
+constexpr size_t seq_lds_bytes(int nacc, int nf, int rpp) { return sizeof(float) * (2 * (size_t)nacc * kSeqStride + 2 * (size_t)(kSeqRows / rpp) * nf); }
+
+
+} // namespace

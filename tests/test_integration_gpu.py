@@ -13,6 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from onepiece_amd import integration as I, synthetic as S
+from helpers import small_camera
 
 TOL = 1e-4  # north_star: "TSDF ... within 1e-4 relative" (relative to the truncation distance / to 1 for colour)
 
