@@ -322,16 +322,26 @@ __global__ __launch_bounds__(512) void k_point_cloud(VolView V, float res, float
 // Two passes with the same kernel: counts (triangles per block) and, after a scan, the ordered emit of
 // three unshared vertices per triangle, exactly as MarchingCube() pushes them.
 // The block's sdf values and IsValid flags (and the +x/+y/+z layer of its neighbours) are staged ONCE in a 9^3 LDS
-// tile: the case of a voxel comes from 8 LDS reads; positions are arithmetic; colours -- needed only by the few
-// voxels that emit triangles, and only in the emit pass -- are gathered per emitted vertex.  (Rounds 1-4 loaded
+// tile: the case of a voxel comes from 8 LDS reads; positions are arithmetic; colours -- needed only by the
+// emit pass, and there only by blocks that hold triangles -- are staged the same way when they are.  (Rounds 1-4 loaded
 // 8 corners x 5 planes from global memory for every voxel in both passes: 3.3 ms per pass on the 164 k-block
 // room volume, profiles/r05_volume_ops.kernel_stats.csv.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kMeshEdge = 9, kMeshTile = kMeshEdge * kMeshEdge * kMeshEdge;
+// the pool slots of a listed block and of its 7 upper neighbours (HasCube(neighbor_cube_id); -1: absent), one lane per lookup: both passes of k_mesh then
+// start on their voxels one load after reading them (the dependent chain keys -> hash probe -> voxels was what a 512-thread workgroup waited for)
+__global__ __launch_bounds__(256) void k_mesh_neighbours(VolView V, const unsigned* __restrict__ blocks, unsigned n, int* __restrict__ nbs) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n * 8u) return;
+    const unsigned e = i >> 3, j = i & 7u;
+    const int b = (int)blocks[e];
+    nbs[i] = j == 0 ? b : table_find(V, V.keys[3 * b] + (int)(j & 1u), V.keys[3 * b + 1] + (int)((j >> 1) & 1u), V.keys[3 * b + 2] + (int)((j >> 2) & 1u));
+}
 __global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const signed char* __restrict__ tri8, const int* __restrict__ edge_pairs,
-                                              const unsigned* __restrict__ blocks, unsigned* __restrict__ counts,
+                                              const unsigned* __restrict__ blocks, const int* __restrict__ nbs, unsigned* __restrict__ counts,
                                               const unsigned* __restrict__ offsets, float* __restrict__ pts, float* __restrict__ col) {
     __shared__ float s_sdf[kMeshTile];
+    __shared__ float s_col[3][kMeshTile];         // emit pass, blocks with triangles: the colour planes of the same 9^3 voxels
     __shared__ unsigned char s_ok[kMeshTile + 3]; // 1: the voxel exists and IsValid (sdf < 1, weight > 0: TSDFVoxel.h:75-78)
     __shared__ int s_edge[24];
     __shared__ int s_nb[8];
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const signed
     const int b = (int)blocks[blockIdx.x], o = threadIdx.x;
     if (o < 24) s_edge[o] = edge_pairs[o];
     const int kx = V.keys[3 * b], ky = V.keys[3 * b + 1], kz = V.keys[3 * b + 2];
-    if (o < 8) s_nb[o] = o == 0 ? b : table_find(V, kx + (o & 1), ky + ((o >> 1) & 1), kz + ((o >> 2) & 1)); // HasCube(neighbor_cube_id)
+    if (o < 8) s_nb[o] = nbs[8 * (size_t)blockIdx.x + o];
     __syncthreads();
     {   // the tile: own 512 voxels (thread = voxel id, coalesced plane rows), then the 217 voxels of the +x / +y / +z layer
         const float* own = V.pool + (size_t)b * kBlockFloats;
@@ -376,12 +386,14 @@ __global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const signed
     }
     int ci = 0;
     unsigned ntri = 0;
-    const signed char* row = tri8;
+    uint4 rw = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu); // the case's table row: sixteen signed bytes, -1 terminated
+    auto entry = [&](int i) -> int { const unsigned wd = i < 4 ? rw.x : (i < 8 ? rw.y : (i < 12 ? rw.z : rw.w)); return (int)(signed char)((wd >> (8 * (i & 3))) & 0xffu); };
     if (ok) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) ci |= cs[i] > 0 ? 1 << i : 0;  // DetermineCase
-        row = tri8 + 16 * ci;
-        for (int i = 0; i < 16 && row[i] != -1; i += 3) ++ntri;
+        rw = *reinterpret_cast<const uint4*>(tri8 + 16 * ci);
+#pragma unroll
+        for (int i = 0; i < 16; i += 3) ntri += entry(i) != -1 ? 1u : 0u; // rows are well formed: whole triangles, then -1s (validated by the caller side: i == 15 is -1)
     }
     // exclusive scan of ntri over the workgroup in thread (= reference loop) order
     unsigned incl = ntri;
@@ -393,14 +405,38 @@ __global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const signed
         if (o == 0) { unsigned tot = 0; for (int k = 0; k < 8; ++k) tot += s_w[k]; counts[blockIdx.x] = tot; }
         return;
     }
+    {   // emit pass: a block without triangles is done; otherwise its colour planes are staged like the sdf tile (coalesced plane rows + the
+        // neighbours' layer) -- a gather per emitted vertex fetched a 32-byte sector for every 4 bytes it used (2.3 GB per pass on the 164 k-block volume)
+        unsigned tot = 0;
+        for (int k = 0; k < 8; ++k) tot += s_w[k];
+        if (tot == 0) return;                      // (uniform over the workgroup)
+        const float* own = V.pool + (size_t)b * kBlockFloats;
+        const int ti = (o & 7) + kMeshEdge * ((o >> 3) & 7) + kMeshEdge * kMeshEdge * (o >> 6);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) s_col[c3][ti] = own[(2 + c3) * kVox + o];
+        if (o < 217) {
+            int x2, y2, z2;
+            if (o < 81) { x2 = o % 9; y2 = o / 9; z2 = 8; }
+            else if (o < 153) { const int j = o - 81; x2 = j % 9; y2 = 8; z2 = j / 9; }
+            else { const int j = o - 153; x2 = 8; y2 = j & 7; z2 = j >> 3; }
+            const int nb = s_nb[(x2 >> 3) | ((y2 >> 3) << 1) | ((z2 >> 3) << 2)];
+            const int tj = x2 + kMeshEdge * y2 + kMeshEdge * kMeshEdge * z2;
+            if (nb >= 0) {
+                const float* t = V.pool + (size_t)nb * kBlockFloats + ((x2 & 7) + (y2 & 7) * 8 + (z2 & 7) * 64);
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) s_col[c3][tj] = t[(2 + c3) * kVox];
+            }
+        }
+        __syncthreads();
+    }
     if (!ntri) return;
     unsigned first = incl - ntri;
     for (int k = 0; k < wave; ++k) first += s_w[k];
     size_t vtx = ((size_t)offsets[blockIdx.x] + first) * 3;
     const float cube_res = 8.0f * res, half = res / 2;    // VoxelCube.h:149-153, :48-61
-    for (int i = 0; i < 16 && row[i] != -1; i += 3)
+    for (int i = 0; i < 16 && entry(i) != -1; i += 3)
         for (int j = 0; j < 3; ++j, ++vtx) {
-            const int e = row[i + j];
+            const int e = entry(i + j);
             // InterpolateEdgeVetex (MarchingCube.cpp:8-16) between corners s_edge[2e] and s_edge[2e + 1]
             float sv[2], pv[2][3], cv[2][3];
 #pragma unroll
@@ -409,12 +445,12 @@ __global__ __launch_bounds__(512) void k_mesh(VolView V, float res, const signed
                 const int xo = (cn == 1 || cn == 2 || cn == 5 || cn == 6), yo = (cn == 2 || cn == 3 || cn == 6 || cn == 7), zo = cn >= 4;
                 const int gx = x + xo, gy = y + yo, gz = z + zo;                     // 0 .. 8
                 const int vx = gx & 7, vy = gy & 7, vz = gz & 7, bxo = gx >> 3, byo = gy >> 3, bzo = gz >> 3;
-                sv[q] = s_sdf[gx + kMeshEdge * gy + kMeshEdge * kMeshEdge * gz];
+                const int tq = gx + kMeshEdge * gy + kMeshEdge * kMeshEdge * gz;
+                sv[q] = s_sdf[tq];
                 pv[q][0] = (float)(kx + bxo) * cube_res + ((float)vx * res + half);
                 pv[q][1] = (float)(ky + byo) * cube_res + ((float)vy * res + half);
                 pv[q][2] = (float)(kz + bzo) * cube_res + ((float)vz * res + half);
-                const float* t = V.pool + (size_t)s_nb[bxo | (byo << 1) | (bzo << 2)] * kBlockFloats + (vx + vy * 8 + vz * 64);
-                cv[q][0] = t[2 * kVox]; cv[q][1] = t[3 * kVox]; cv[q][2] = t[4 * kVox];
+                cv[q][0] = s_col[0][tq]; cv[q][1] = s_col[1][tq]; cv[q][2] = s_col[2][tq];
             }
             const float sdf_diff = sv[1] - sv[0];
             const float t = sv[0] / sdf_diff;
@@ -716,7 +752,7 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
     const unsigned nl = (unsigned)list.size();
     unsigned *d_list = nullptr, *d_counts = nullptr, *d_offsets = nullptr;
     signed char* d_tri = nullptr;
-    int* d_edge = nullptr;
+    int *d_edge = nullptr, *d_nbs = nullptr;
     float *d_pts = nullptr, *d_col = nullptr;
     int rc = OP_OK;
     signed char tri8[256 * 16];
@@ -726,14 +762,16 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
     if (e == hipSuccess) e = op::cached_malloc((void**)&d_offsets, nl * sizeof(unsigned));
     if (e == hipSuccess) e = op::cached_malloc((void**)&d_tri, 256 * 16);
     if (e == hipSuccess) e = op::cached_malloc((void**)&d_edge, 24 * sizeof(int));
+    if (e == hipSuccess) e = op::cached_malloc((void**)&d_nbs, (size_t)nl * 8 * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(d_list, list.data(), nl * sizeof(unsigned), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_tri, tri8, 256 * 16, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_edge, edge_pairs, 24 * sizeof(int), hipMemcpyHostToDevice);
     std::vector<unsigned> cnt(nl), off(nl);
     size_t total_tri = 0;
     if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_mesh_neighbours, dim3((nl * 8u + 255u) / 256u), dim3(256), 0, v->stream, v->view(), (const unsigned*)d_list, nl, d_nbs);
         hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const signed char*)d_tri, (const int*)d_edge, (const unsigned*)d_list,
-                           d_counts, (const unsigned*)nullptr, (float*)nullptr, (float*)nullptr);
+                           (const int*)d_nbs, d_counts, (const unsigned*)nullptr, (float*)nullptr, (float*)nullptr);
         e = hipStreamSynchronize(v->stream);
         if (e == hipSuccess) e = hipMemcpy(cnt.data(), d_counts, nl * sizeof(unsigned), hipMemcpyDeviceToHost);
         for (unsigned b = 0; b < nl; ++b) { off[b] = (unsigned)total_tri; total_tri += cnt[b]; }
@@ -749,14 +787,14 @@ int op_volume_extract_mesh(op_volume* v, const int32_t* tri_table, const int32_t
             if (e == hipSuccess) e = op::cached_malloc((void**)&d_col, total * 12);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_mesh, dim3(nl), dim3(512), 0, v->stream, v->view(), v->res, (const signed char*)d_tri, (const int*)d_edge,
-                                   (const unsigned*)d_list, (unsigned*)nullptr, (const unsigned*)d_offsets, d_pts, d_col);
+                                   (const unsigned*)d_list, (const int*)d_nbs, (unsigned*)nullptr, (const unsigned*)d_offsets, d_pts, d_col);
                 e = hipStreamSynchronize(v->stream);
             }
             if (e == hipSuccess) e = hipMemcpy(points, d_pts, total * 12, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(colors, d_col, total * 12, hipMemcpyDeviceToHost);
         }
     }
-    void* ptrs[] = {d_list, d_counts, d_offsets, d_tri, d_edge, d_pts, d_col};
+    void* ptrs[] = {d_list, d_counts, d_offsets, d_tri, d_edge, d_nbs, d_pts, d_col};
     for (void* p : ptrs)
         if (p) op::cached_free(p);
     if (e != hipSuccess) return fail(OP_ERR_HIP, "mesh extraction failed: %s", hipGetErrorString(e));
