@@ -338,6 +338,13 @@ def test_bench_strong_scaling_four_ranks_on_one_gpu(tmp_path):
     assert mg["backend"] == "gloo" and mg["ranks_in_process_group"] == 4 and [p["rank"] for p in mg["per_rank"]] == [0, 1, 2, 3]
     assert all(p["frames"] == 20 and p["local_blocks"] > 0 for p in mg["per_rank"]) and r["merge_union_blocks"] >= max(p["local_blocks"] for p in mg["per_rank"])
     assert r["per_frame"]["final_blocks_rank0"] == r["merge_union_blocks"]
+    # the merge is the owner-partitioned exchange: the partitions cover the union, what was sent was received, and the exchange moved about 3/4 of what the ranks held
+    P = mg["per_rank"]
+    assert mg["merge_algorithm"] == "owner" and sum(p["owned_blocks"] for p in P) == r["merge_union_blocks"]
+    assert sum(p["wire_bytes_sent"] for p in P) == sum(p["wire_bytes_received"] for p in P)
+    B = 10248
+    exchange = sum(p["wire_bytes_sent"] for p in P) - sum(p["owned_blocks"] * B for p in P[1:])
+    assert abs(exchange / (sum(p["held_blocks"] for p in P) * B) - 0.75) < 0.05
 
 
 def test_survey_reference_run_anchor_on_the_gpu():
