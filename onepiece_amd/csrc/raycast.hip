@@ -200,14 +200,14 @@ __global__ __launch_bounds__(256) void k_rc_neighbours(VolView V, RcBlock* __res
 
 // ---- R1 ------------------------------------------------------------------------------------------------------------------------
 #ifndef RC_MIN_WAVES
-#define RC_MIN_WAVES 8
+#define RC_MIN_WAVES 6 // waves per SIMD the march and shading kernels are compiled for: at 8 (64 VGPRs) the shading pass spills and takes 58 instead of 38 us
 #endif
 #ifndef RC_WG
 #define RC_WG 128      // threads per workgroup = per visible block in flight (profiles/r05_ab_raycast.txt: 64 / 128 / 256)
 #endif
 constexpr int kRcWg = RC_WG;
 #ifndef RC_STAGE_GROUP
-#define RC_STAGE_GROUP 4
+#define RC_STAGE_GROUP 11 // tile cells per thread whose loads are in flight together (all of them: one round trip)
 #endif
 #ifdef RC_STATS // development aid (make EXTRA=-DRC_STATS): what the last views marched; printed by op_volume_raycast
 __device__ unsigned long long g_rc_stats[8]; // visible blocks, blocks marched, pixels in boxes, pixels past the slab + depth tests, samples in block, hash lookups of a previous sample, crossings
@@ -247,6 +247,10 @@ __device__ __forceinline__ void rc_tile_map(unsigned short* s_cell, int tid) {
 // Voxels -1 .. 9 of the block's frame on every axis (own 512 + the shell of its 26 neighbours) -> s_sdf: the observed sdf, or NaN; RC_STAGE_GROUP
 // cells per thread in flight at a time.  Returns bit 0: an observed sdf <= 0 among the voxels an IN-BLOCK sample can touch, bit 1: an observed
 // sdf > 0 anywhere in the tile, bits 2 / 3: the same two among the block's OWN 512 voxels (this thread's cells).
+// PLAIN: every voxel of the volume was written by the fusion kernel alone since create / clear (op_volume::plain): a voxel is then either the default
+// {sdf 999, weight 0} or a running mean of in-band observations (|sdf| < truncation < 999, weight >= 1), so "observed" is `sdf != 999` and the weight plane
+// need not be read at all -- half the loads of the tile.  Any other writer (upload, merge, resampling, file) clears the flag and both planes are read.
+template <bool PLAIN>
 __device__ __forceinline__ unsigned rc_tile_load(const VolView& V, const int* __restrict__ s_nb, const unsigned short* __restrict__ s_cell, float* __restrict__ s_sdf, int tid) {
     bool neg = false, pos = false, own_neg = false, own_pos = false;
 #pragma unroll
@@ -255,20 +259,21 @@ __device__ __forceinline__ unsigned rc_tile_load(const VolView& V, const int* __
         unsigned cl[RC_STAGE_GROUP];
 #pragma unroll
         for (int i = 0; i < RC_STAGE_GROUP; ++i) {
-            sd[i] = 0.0f; wt[i] = 0.0f;
+            sd[i] = PLAIN ? 999.0f : 0.0f; wt[i] = 0.0f;
             cl[i] = g + i < kStageIter ? (unsigned)s_cell[tid + (g + i) * kRcWg] : 0u;
             if (cl[i] >> 15) {
                 const int nbk = s_nb[cl[i] & 31u];
                 if (nbk >= 0) {
                     const float* t = V.pool + (size_t)nbk * kBlockFloats + ((cl[i] >> 5) & 511u);
-                    sd[i] = t[0]; wt[i] = t[kVox];
+                    sd[i] = t[0];
+                    if (!PLAIN) wt[i] = t[kVox];
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < RC_STAGE_GROUP; ++i)
             if (cl[i] >> 15) {
-                const bool ok = wt[i] > 0;
+                const bool ok = PLAIN ? sd[i] != 999.0f : wt[i] > 0;
                 const bool own = (cl[i] & 31u) == 13u;
                 neg |= ok && sd[i] <= 0 && ((cl[i] >> 14) & 1u);
                 pos |= ok && sd[i] > 0;
@@ -290,6 +295,7 @@ __device__ __forceinline__ RcSpan rc_span(unsigned n) {
 
 // hit_blocks: one byte per pool slot, set for the block whose sample domain holds the hit point of a crossing recorded here (k_rc_shade works
 // through exactly those blocks and clears the bytes again); nullptr when neither normals nor colours are asked for.
+template <bool PLAIN>
 __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcView W, const RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis,
                                                                   unsigned* __restrict__ depth_bits, unsigned char* __restrict__ hit_blocks, unsigned* __restrict__ summary,
                                                                   unsigned stamp, unsigned* __restrict__ counters) {
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcV
         const int kx = s_ent[0], ky = s_ent[1], kz = s_ent[2];
         const int* s_nb = s_ent + 8;
         {
-            const unsigned mine = rc_tile_load(V, s_nb, s_cell, s_sdf, tid);
+            const unsigned mine = rc_tile_load<PLAIN>(V, s_nb, s_cell, s_sdf, tid);
             const unsigned f = (__ballot(mine & 1u) ? 1u : 0u) | (__ballot(mine & 2u) ? 2u : 0u) | (__ballot(mine & 4u) ? 4u : 0u) | (__ballot(mine & 8u) ? 8u : 0u);
             if ((tid & 63) == 0 && f) atomicOr(&s_flags, f);
         }
@@ -426,7 +432,11 @@ __global__ __launch_bounds__(256) void k_rc_finish(RcView W, float* __restrict__
 //   normal = normalised (s(p + h e_a) - s(p - h e_a))_a, h = res / 2 -- six trilinear samples, all inside the tile (base voxels -1 .. 8),
 //   colour = trilinear colour at p -- 24 gathers from the colour planes through the entry's neighbour slots (no hash probe),
 // both zero unless every sample is valid (the definition's rule).  Every hit point lies in the sample domain of exactly one block.
-__global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_shade(VolView V, RcView W, const RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis,
+#ifndef RC_SHADE_MIN_WAVES
+#define RC_SHADE_MIN_WAVES RC_MIN_WAVES
+#endif
+template <bool PLAIN>
+__global__ __launch_bounds__(RC_WG, RC_SHADE_MIN_WAVES) void k_rc_shade(VolView V, RcView W, const RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis,
                                                                   unsigned char* __restrict__ hit_blocks, const float* __restrict__ depth, float* __restrict__ normals_out,
                                                                   float* __restrict__ colors_out) {
     __shared__ float s_sdf[kTileVox + 5];
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_shade(VolView V, RcV
         if (tid == 64) hit_blocks[self] = 0; // consumed (every block is visited by exactly one workgroup)
         __syncthreads();
         const int* s_nb = s_ent + 8;
-        (void)rc_tile_load(V, s_nb, s_cell, s_sdf, tid);
+        (void)rc_tile_load<PLAIN>(V, s_nb, s_cell, s_sdf, tid);
         __syncthreads();
         const int bx8 = 8 * s_ent[0], by8 = 8 * s_ent[1], bz8 = 8 * s_ent[2], bu0 = s_ent[3], bv0 = s_ent[4], bw = s_ent[5], npix = s_ent[5] * s_ent[6];
         const float h = 0.5f * W.res;
@@ -561,12 +571,16 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     const unsigned stamp = (unsigned)(v->content_gen & 0x3fffffffull);
     const unsigned stamp_read = v->rc_prune ? stamp : 0x7fffffffu; // OP_VOLUME_OPT_RAYCAST_PRUNE = 0: no stored summary ever matches
     hipLaunchKernelGGL(k_rc_neighbours, dim3(RC_NB_GRID), dim3(256), 0, v->stream, V, (RcBlock*)v->rc_list, (const unsigned*)v->rc_count, (const unsigned*)v->rc_sum, stamp_read);
-    hipLaunchKernelGGL(k_rc_march, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count,
-                       reinterpret_cast<unsigned*>(d_depth), shade ? v->rc_hit : nullptr, v->rc_sum, stamp, v->rc_count + 16);
+    const bool plain = v->plain && v->trunc < 900.0f; // (see rc_tile_load: the weight plane is not needed to tell observed voxels)
+#define OP_RC_MARCH(P) hipLaunchKernelGGL(k_rc_march<P>, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count, \
+                                          reinterpret_cast<unsigned*>(d_depth), shade ? v->rc_hit : nullptr, v->rc_sum, stamp, v->rc_count + 16)
+    if (plain) OP_RC_MARCH(true); else OP_RC_MARCH(false);
+#undef OP_RC_MARCH
     hipLaunchKernelGGL(k_rc_finish, dim3((unsigned)std::min<size_t>(2048, (npx + 255) / 256)), dim3(256), 0, v->stream, W, d_depth, d_nrm, d_col);
-    if (shade)
-        hipLaunchKernelGGL(k_rc_shade, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count, v->rc_hit,
-                           (const float*)d_depth, d_nrm, d_col);
+#define OP_RC_SHADE(P) hipLaunchKernelGGL(k_rc_shade<P>, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count, v->rc_hit, \
+                                          (const float*)d_depth, d_nrm, d_col)
+    if (shade) { if (plain) OP_RC_SHADE(true); else OP_RC_SHADE(false); }
+#undef OP_RC_SHADE
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(v->stream);
 #ifdef RC_STATS
