@@ -138,6 +138,6 @@ def run(c, out):
                 out["dense_fusion"]["outside_tolerance_fp64_mode"].update({"cpp_frames_per_s": rates_cpp[4][0], "cpp_one_pair_at_a_time_frames_per_s": rates_cpp[1][0] if rates_cpp.get(1) else None,
                                             "cpp_tracked": rates_cpp[4][1], "cpp_frames": rates_cpp[4][2],
                                             "cpp_driver": "tools/prof_driver.bin <frames> 3 0.005 track=4: the same pipeline over the C-ABI without the interpreter, "
-                                                          "best of 3; every tracker stream has a hardware queue of its own (the library asks for 8 when it is loaded)"})
+                                                          "best of 3; every tracker stream has a hardware queue of its own (the driver calls op_runtime_configure(8) before its first HIP call)"})
         except Exception as e:
             out["dense_fusion"]["cpp_error"] = repr(e)[:200]
