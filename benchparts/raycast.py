@@ -50,8 +50,8 @@ def run(c, out):
     hv.SetRaycastPrune(True)
     res["before_round_5"] = {"ms_per_view_depth_only": 1.121, "ms_per_view_depth_normals_colours": 1.239, "volume": "the same scene from 250 frames (164 k blocks)",
                              "evidence": "profiles/r05_raycast_before.driver.txt / .kernel_stats.csv (one thread per ray, one-voxel steps through the hash)"}
-    res["bound"] = ("tile loading: k_rc_march's waves wait on memory for 54 % of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES), VALU issue is ~25 % of the launch; "
-                    "297 MB per launch over the fabric = 2.9 TB/s for 236 MB of tile bytes (cold), L2 hit rate 52 %: profiles/r05_raycast.*.pmc.csv, DESIGN.md section 3")
+    res["bound"] = ("k_rc_march (89 us): ~60 % pixel march = VALU issue (33.7 M wave-instructions, ~85 per sample, 45-50 % lane utilisation), ~40 % tile loading = latency (waves wait on "
+                    "memory 47 % of their cycles; 135 MB per launch over the fabric = 1.5 TB/s, 0.19 of the HBM peak; L2 hit rate 52 %): profiles/r05_raycast.*.pmc.csv, DESIGN.md section 3.5")
     res["evidence"] = "profiles/r05_raycast.driver.txt, .kernel_stats.csv, .FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum_TCC_MISS_sum / SQ_* .pmc.csv (tools/profile_volume_ops.sh), profiles/r05_ab_raycast.txt"
     out["raycast"] = res
     del d, nr, cl
