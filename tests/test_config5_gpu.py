@@ -151,6 +151,7 @@ SHARD_CASES = [
     ([(0, 6), (6, 12)], 0, None),                                           # two equal ranks, one slice
     ([(0, 5), (5, 6), (6, 6), (6, 14)], 2, 700),                            # uneven, an EMPTY rank that is also the root, several slices
     ([(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 14), (14, 16)], 5, 500),   # eight ranks as in configs[4], root 5
+    ([(0, 4), (4, 9), (9, 13)], 1, 900),                                    # three ranks: the owner hash must spread keys for a rank count that is no power of two
 ]
 
 
@@ -209,8 +210,9 @@ def test_merge_rccl_owner_exchange_with_several_ranks_on_one_gpu(hip, tmp_path, 
     assert 0 <= exchange_sent <= held * B and exchange_sent % B == 0
     # the owner hash spreads the keys evenly: the exchange moves (world - 1) / world of what is held, within a few per cent on these ~1e3-block volumes
     assert abs(exchange_sent / (held * B) - (world - 1) / world) < 0.08
-    # and far less than the dense reduce puts on the wire (every rank but the root sends the whole union)
-    assert sum(p["wire_bytes_sent"] for p in P) < (world - 1) * n_union * 10240 or world == 2
+    # a rank never sends more than what it holds plus its summed partition (the dense reduce sends the whole union from every rank but the root, through one link;
+    # with shards that overlap almost completely -- these -- the totals are close, what differs is that the exchange uses every link at once)
+    assert all(p["wire_bytes_sent"] <= (p["held_blocks"] + p["owned_blocks"]) * B for p in P)
     _assert_merged(_sorted_map(_read_map(hcam, voxel, mp)), want)
 
 

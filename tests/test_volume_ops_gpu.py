@@ -173,6 +173,15 @@ def test_raycast_other_cameras_views_and_an_empty_volume(oracle):
     one = I.PinholeCamera()
     one.fx, one.fy, one.cx, one.cy, one.width, one.height, one.depth_scale = cam[0], cam[1], 0.0, 0.0, 1, 1, 1000.0
     _raycast_equal(ov, hv, base, one, oracle.make_camera(cam[0], cam[1], 0.0, 0.0, 1, 1, 1000.0))
+    # (3b) other lattices: empty (near plane beyond the far plane), a single point (nothing can cross), and one that starts inside the room and ends before its far walls
+    k, v = hv.GetCubeMap()
+    for near, far in ((6.0, 5.0), (2.0, 2.0), (1.0, 2.5)):
+        hv.SetNearPlane(near); hv.SetFarPlane(far)
+        ov2 = oracle.Volume(oracle.make_camera(*cam), voxel_res=0.02, far=far, near=near)
+        ov2.load(k, v)
+        _hd, hit = _raycast_equal(ov2, hv, base)
+        assert hit.any() == (near < far)
+    hv.SetNearPlane(0.5); hv.SetFarPlane(5.0)
     # (4) no blocks at all
     ev = I.CubeHandler(hv.camera, max_blocks=1 << 10)
     ev.SetVoxelResolution(0.02)
