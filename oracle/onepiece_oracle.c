@@ -1,7 +1,7 @@
 /*
  * onepiece_oracle.c -- CPU restatement (plain C99) of the OnePiece TSDF-fusion + ICP hot path.
  * TEST INFRASTRUCTURE ONLY; see onepiece_oracle.h for the rules and the parity status
- * ("parity unpinned" against the compiled reference; pinned against Eigen/Sophus golden vectors
+ * ("parity unpinned" against the compiled reference; pinned against Eigen/Sophus and nanoflann golden vectors
  * and the SURVEY.md reference-run statistics).
  *
  * Build: gcc -O3 -msse4.2 -ffp-contract=off -fopenmp (the reference's flags, CMakeLists.txt:149-150,
@@ -1121,6 +1121,34 @@ void orc_estimate_normals(const float *pts, size_t n, float radius, int knn, flo
         int used = 0;
         while (used < s.n && !(s.d[used] > radius)) ++used;
         fit_plane_normal(pts, s.i, used, normals + 3 * i);
+    }
+    free(t.idx); free(t.nodes);
+}
+
+/* The searches above, exposed for tests/test_oracle_golden.py's comparison with the real nanoflann (tests/golden/nanoflann_golden.json):
+ * k == 1 is ICP's search (kd_query, ties to the smaller index), k > 1 is EstimateNormals' (kd_knn, sorted by (distance, index)).
+ * idx / d2 hold k entries per query (-1 / -1.0f beyond `found`). */
+void orc_knn_search(const float *tgt, size_t n_tgt, const float *queries, size_t n_q, int k, int32_t *idx, float *d2, int32_t *found) {
+    if (k > 64) k = 64;
+    kdtree t;
+    t.pts = tgt; t.idx = (int *)malloc((n_tgt + 1) * sizeof(int));
+    t.nodes = (kdnode *)malloc((2 * n_tgt + 2) * sizeof(kdnode)); t.n_nodes = 0;
+    for (size_t i = 0; i < n_tgt; ++i) t.idx[i] = (int)i;
+    if (n_tgt) kd_build(&t, 0, (int)n_tgt);
+    for (size_t i = 0; i < n_q; ++i) {
+        for (int j = 0; j < k; ++j) { idx[i * k + j] = -1; d2[i * k + j] = -1.0f; }
+        found[i] = 0;
+        if (!n_tgt) continue;
+        if (k == 1) {
+            float bd = FLT_MAX; int bi = -1;
+            kd_query(&t, 0, queries + 3 * i, &bd, &bi);
+            if (bi >= 0) { idx[i] = bi; d2[i] = bd; found[i] = 1; }
+        } else {
+            knn_set s; s.n = 0; s.k = k;
+            kd_knn(&t, 0, queries + 3 * i, &s);
+            for (int j = 0; j < s.n; ++j) { idx[i * k + j] = s.i[j]; d2[i * k + j] = s.d[j]; }
+            found[i] = s.n;
+        }
     }
     free(t.idx); free(t.nodes);
 }

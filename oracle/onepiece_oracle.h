@@ -14,6 +14,10 @@
  *     product / dot evaluation order, JacobiSVD solve, Sophus SE3::exp), through golden vectors
  *     generated in the build container by oracle/tools/gen_eigen_golden.cpp and committed under
  *     tests/golden/;
+ *   - the reference's vendored nanoflann 1.3.2, driven as geometry::KDTree drives it (KDTree.h:62-98,171-190): the 1-NN and k-NN
+ *     searches return its indices and squared distances bit for bit on tie-free clouds (tests/golden/nanoflann_golden.json from
+ *     oracle/tools/gen_nanoflann_golden.cpp); among exactly equidistant candidates nanoflann keeps the first its traversal met,
+ *     this file the smallest index -- the fixture's lattice cases record that difference;
  *   - the VoxelGridHasher known answers in SURVEY.md A.8;
  *   - the reference-run statistics recorded in SURVEY.md Appendix B / section 6 (block count,
  *     observed-voxel count, weight sum, XOR of key hashes for the 5-frame "wall" scene).
@@ -114,6 +118,8 @@ void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
 
 /* Geometry/PointCloud.cpp:102-144 (normals up to sign; < 3 neighbours -> (0,0,0)). */
 void orc_estimate_normals(const float *pts, size_t n, float radius, int knn, float *normals);
+/* the kd-tree searches behind orc_icp (k = 1) and orc_estimate_normals (k > 1); checked against nanoflann's answers in tests/golden */
+void orc_knn_search(const float *tgt, size_t n_tgt, const float *queries, size_t n_q, int k, int32_t *idx, float *d2, int32_t *found);
 
 /* Diagnostic only: 1 = accumulate the normal equations in double (the reference uses float). */
 void orc_set_accumulate_double(int on);

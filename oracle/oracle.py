@@ -99,6 +99,8 @@ def lib():
         L.orc_load_from_depth.restype = C.c_size_t
         L.orc_load_from_depth.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, _fp]
         L.orc_estimate_normals.argtypes = [_fp, C.c_size_t, C.c_float, C.c_int, _fp]
+        L.orc_knn_search.argtypes = [_fp, C.c_size_t, _fp, C.c_size_t, C.c_int, _ip, _fp, _ip]
+        L.orc_knn_search.restype = None
         L.orc_se3_exp.argtypes = [_fp, _fp]
         L.orc_kabsch.argtypes = [_fp, C.c_size_t, _fp]
         L.orc_solve6.argtypes = [_fp, _fp, _fp]
@@ -228,6 +230,16 @@ def estimate_normals(points, radius=0.1, knn=30):
     out = np.zeros_like(pts)
     lib().orc_estimate_normals(_p(pts), len(pts), radius, knn, _p(out))
     return out
+
+
+def knn_search(target, queries, k=1):
+    """The oracle's own kd-tree searches (k = 1: ICP.cpp:69,189; k > 1: PointCloud.cpp:120) -> (index [nq, k], squared distance [nq, k], found [nq])."""
+    t, q = _f32(target).reshape(-1, 3), _f32(queries).reshape(-1, 3)
+    idx = np.empty((len(q), k), np.int32)
+    d2 = np.empty((len(q), k), np.float32)
+    found = np.empty(len(q), np.int32)
+    lib().orc_knn_search(_p(t), len(t), _p(q), len(q), k, _p(idx, _ip), _p(d2), _p(found, _ip))
+    return idx, d2, found
 
 
 class Volume:

@@ -11,3 +11,6 @@ echo "wrote tests/golden/eigen_golden.json"
 g++ -std=c++11 -O3 -msse4.2 -w -I$R/Eigen -I$R/Sophus "$HERE/gen_odometry_golden.cpp" -o "$HERE/../_ref/gen_odometry_golden"
 "$HERE/../_ref/gen_odometry_golden" "$HERE/../../tests/golden/odometry_golden.json"
 echo "wrote tests/golden/odometry_golden.json"
+g++ -std=c++11 -O3 -msse4.2 -w -I$R/nanoflann/include "$HERE/gen_nanoflann_golden.cpp" -o "$HERE/../_ref/gen_nanoflann_golden"
+"$HERE/../_ref/gen_nanoflann_golden" "$HERE/../../tests/golden/nanoflann_golden.json"
+echo "wrote tests/golden/nanoflann_golden.json"

@@ -1,0 +1,128 @@
+// gen_nanoflann_golden.cpp -- generates tests/golden/nanoflann_golden.json.
+//
+// Runs ONLY in the build container: it includes the reference's vendored third-party header
+// /root/reference/3rdparty/nanoflann/include/nanoflann.hpp (nanoflann 1.3.2) where it lies and drives it the way the reference's
+// geometry::KDTree does (KDTree.h:62-98,171-190,230-255: KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<float, cloud>, cloud, 3>,
+// max leaf 10, buildIndex(), knnSearch(query, k, indices, squared distances) with the default SearchParams, i.e. eps = 0, sorted).
+// KDTree.h itself cannot be compiled here (it includes <opencv2/core/eigen.hpp>), so the adaptor below is this file's own: a plain
+// array of float triples with the three members nanoflann asks a dataset for.  The JSON holds inputs and outputs only (float32
+// arrays as base64 of their little-endian bytes, indices as integers); it contains no OnePiece source.
+//
+// What the fixture pins: the 1-NN of registration::PointToPoint / PointToPlane (ICP.cpp:69,189: k = 1) and the k-NN of
+// PointCloud::EstimateNormals (PointCloud.cpp:120: k = knn) -- indices AND squared distances, bit for bit -- on inputs without
+// exact-distance ties, and nanoflann's choice among exactly equidistant points (lattice cases), which follows its traversal order.
+//
+// Build + run: see oracle/tools/gen_golden.sh
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include "nanoflann.hpp"
+
+struct Cloud {
+    std::vector<float> xyz;
+    inline size_t kdtree_get_point_count() const { return xyz.size() / 3; }
+    inline float kdtree_get_pt(const size_t idx, const size_t dim) const { return xyz[3 * idx + dim]; }
+    template <class BBOX> bool kdtree_get_bbox(BBOX&) const { return false; }
+};
+typedef nanoflann::KDTreeSingleIndexAdaptor<nanoflann::L2_Simple_Adaptor<float, Cloud>, Cloud, 3> Tree;
+
+static FILE* out;
+static void b64(const char* name, const void* data, size_t bytes, bool comma = true) {
+    static const char* A = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    const unsigned char* p = (const unsigned char*)data;
+    fprintf(out, "\"%s\": \"", name);
+    for (size_t i = 0; i < bytes; i += 3) {
+        const unsigned v = (p[i] << 16) | ((i + 1 < bytes ? p[i + 1] : 0) << 8) | (i + 2 < bytes ? p[i + 2] : 0);
+        fputc(A[(v >> 18) & 63], out); fputc(A[(v >> 12) & 63], out);
+        fputc(i + 1 < bytes ? A[(v >> 6) & 63] : '=', out); fputc(i + 2 < bytes ? A[v & 63] : '=', out);
+    }
+    fprintf(out, "\"%s", comma ? ", " : "");
+}
+
+// one case: k nearest of every query, in nanoflann's output order
+static void run_case(const char* name, const char* what, const Cloud& tgt, const std::vector<float>& q, int k, bool last = false) {
+    Tree tree(3, tgt, nanoflann::KDTreeSingleIndexAdaptorParams(10));
+    tree.buildIndex();
+    const size_t nq = q.size() / 3;
+    std::vector<int32_t> idx(nq * k, -1);
+    std::vector<float> d2(nq * k, -1.0f);
+    std::vector<int32_t> cnt(nq);
+    for (size_t i = 0; i < nq; ++i) {
+        std::vector<size_t> id(k);
+        std::vector<float> dd(k);
+        const size_t found = tree.knnSearch(&q[3 * i], k, &id[0], &dd[0]);
+        cnt[i] = (int32_t)found;
+        for (size_t j = 0; j < found; ++j) { idx[i * k + j] = (int32_t)id[j]; d2[i * k + j] = dd[j]; }
+    }
+    fprintf(out, "\"%s\": {\"what\": \"%s\", \"k\": %d, \"n_target\": %zu, \"n_query\": %zu, ", name, what, k, tgt.xyz.size() / 3, nq);
+    b64("target_f32", tgt.xyz.data(), tgt.xyz.size() * 4);
+    b64("query_f32", q.data(), q.size() * 4);
+    b64("found_i32", cnt.data(), cnt.size() * 4);
+    b64("index_i32", idx.data(), idx.size() * 4);
+    b64("dist2_f32", d2.data(), d2.size() * 4, false);
+    fprintf(out, "}%s\n", last ? "" : ",");
+}
+
+int main(int argc, char** argv) {
+    out = fopen(argc > 1 ? argv[1] : "nanoflann_golden.json", "w");
+    if (!out) return 1;
+    std::mt19937 g(20260929);
+    std::uniform_real_distribution<float> u(-1.f, 1.f);
+    fprintf(out, "{\n\"generator\": \"oracle/tools/gen_nanoflann_golden.cpp against /root/reference/3rdparty/nanoflann/include/nanoflann.hpp (version 0x%x), g++ -O3 -msse4.2; "
+                 "adaptor = KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<float, cloud>, cloud, 3>, leaf 10, knnSearch with default SearchParams\",\n", NANOFLANN_VERSION);
+
+    { // 1. uniform cloud, independent queries: 1-NN
+        Cloud t; std::vector<float> q;
+        for (int i = 0; i < 3000 * 3; ++i) t.xyz.push_back(u(g));
+        for (int i = 0; i < 1000 * 3; ++i) q.push_back(1.1f * u(g));   // (some queries lie outside the target's box)
+        run_case("uniform_1nn", "3000 uniform targets in [-1,1]^3, 1000 queries in [-1.1,1.1]^3, k = 1 (ICP.cpp:69,189)", t, q, 1);
+    }
+    { // 2. a depth-image-like surface and the same surface after a small rigid motion: the shape of ICP's own inputs
+        Cloud t; std::vector<float> q;
+        const float c = std::cos(0.03f), s = std::sin(0.03f);
+        for (int v = 0; v < 48; ++v)
+            for (int x = 0; x < 64; ++x) {
+                const float z = 1.5f + 0.2f * std::sin(0.11f * x) * std::cos(0.07f * v) + 0.002f * u(g);
+                const float X = (x * 10 + 5 - 318.771f) / 514.817f * z, Y = (v * 10 + 5 - 238.447f) / 515.375f * z;
+                t.xyz.push_back(X); t.xyz.push_back(Y); t.xyz.push_back(z);
+                const float z2 = z + 0.001f * u(g);
+                q.push_back(c * X + s * z2 + 0.01f); q.push_back(Y - 0.015f); q.push_back(-s * X + c * z2 + 0.02f);
+            }
+        run_case("surface_1nn", "64 x 48 back-projected wavy sheet; queries = the sheet moved by 0.03 rad about y and (0.01,-0.015,0.02) m, k = 1", t, q, 1);
+    }
+    { // 3. exact-distance ties: a lattice with exactly representable coordinates plus duplicated points
+        Cloud t; std::vector<float> q;
+        for (int z = 0; z < 10; ++z) for (int y = 0; y < 10; ++y) for (int x = 0; x < 10; ++x) { t.xyz.push_back(0.125f * x); t.xyz.push_back(0.125f * y); t.xyz.push_back(0.125f * z); }
+        std::uniform_int_distribution<int> pick(0, 999), cell(0, 8);
+        for (int i = 0; i < 60; ++i) { const int j = pick(g); for (int c = 0; c < 3; ++c) t.xyz.push_back(t.xyz[3 * j + c]); }         // duplicates: distance-0 ties
+        for (int i = 0; i < 300; ++i) { q.push_back(0.125f * cell(g) + 0.0625f); q.push_back(0.125f * cell(g) + 0.0625f); q.push_back(0.125f * cell(g) + 0.0625f); } // cell centres: 8-way
+        for (int i = 0; i < 300; ++i) { q.push_back(0.125f * cell(g) + 0.0625f); q.push_back(0.125f * cell(g)); q.push_back(0.125f * cell(g)); }                     // edge midpoints: 2-way
+        for (int i = 0; i < 200; ++i) { const int j = 1000 + pick(g) % 60; for (int c = 0; c < 3; ++c) q.push_back(t.xyz[3 * j + c]); }                                // on a duplicated lattice point
+        run_case("lattice_ties_1nn", "10^3 lattice of spacing 1/8 + 60 duplicated points; queries at cell centres, edge midpoints, lattice points: every query has exactly equidistant candidates, k = 1", t, q, 1);
+    }
+    { // 4. k = 30 with the query a member of the cloud: PointCloud::EstimateNormals' search
+        Cloud t; std::vector<float> q;
+        for (int i = 0; i < 3000 * 3; ++i) t.xyz.push_back(0.5f * u(g));
+        for (int i = 0; i < 250 * 3; ++i) q.push_back(t.xyz[i]);
+        run_case("uniform_knn30", "3000 uniform points in [-0.5,0.5]^3, queries = its first 250 points, k = 30 (PointCloud.cpp:120)", t, q, 30);
+    }
+    { // 5. fewer points than k
+        Cloud t; std::vector<float> q;
+        for (int i = 0; i < 7 * 3; ++i) t.xyz.push_back(u(g));
+        for (int i = 0; i < 5 * 3; ++i) q.push_back(u(g));
+        run_case("tiny_knn30", "7 points, k = 30: knnSearch returns 7", t, q, 30);
+    }
+    { // 6. k = 30 on the lattice: ties inside the result list
+        Cloud t; std::vector<float> q;
+        for (int z = 0; z < 8; ++z) for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) { t.xyz.push_back(0.25f * x); t.xyz.push_back(0.25f * y); t.xyz.push_back(0.25f * z); }
+        for (int i = 0; i < 100 * 3; ++i) q.push_back(t.xyz[3 * 73 + i]);
+        run_case("lattice_knn30", "8^3 lattice of spacing 1/4, queries = 100 of its points, k = 30: the sorted distance list is unique, the indices within a distance shell are not", t, q, 30, true);
+    }
+    fprintf(out, "}\n");
+    fclose(out);
+    return 0;
+}

@@ -91,3 +91,20 @@ def triangle_soup(points, colors):
     """Order-independent form of an unshared-vertex mesh: rows = triangles (18 floats), sorted lexicographically."""
     t = np.concatenate([points.reshape(-1, 9), colors.reshape(-1, 9)], 1)
     return t[np.lexsort(t.T[::-1])]
+
+
+def nanoflann_case(name):
+    """One case of the fixture oracle/tools/gen_nanoflann_golden.cpp wrote: inputs and the real nanoflann's answers."""
+    import base64
+    import json, os
+    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nanoflann_golden.json")))[name]
+    a = lambda key, dt: np.frombuffer(base64.b64decode(c[key]), dtype=dt)
+    k = c["k"]
+    return {"k": k, "target": a("target_f32", np.float32).reshape(-1, 3), "query": a("query_f32", np.float32).reshape(-1, 3), "found": a("found_i32", np.int32),
+            "index": a("index_i32", np.int32).reshape(-1, k), "dist2": a("dist2_f32", np.float32).reshape(-1, k)}
+
+
+def squared_distances(target, q):
+    """nanoflann's L2_Simple_Adaptor: ((0 + dx*dx) + dy*dy) + dz*dz in float32."""
+    d = q[None, :] - target
+    return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]

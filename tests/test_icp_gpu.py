@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from onepiece_amd import registration as R, integration as I
-from helpers import room_cloud, rel_err, small_camera
+from helpers import room_cloud, rel_err, small_camera, nanoflann_case, squared_distances
 
 POSE_TOL = 1e-4  # north_star: "ICP pose within 1e-4 relative" (Frobenius, relative)
 
@@ -369,3 +369,82 @@ def test_replicas_in_flight_give_each_context_its_sequential_result(oracle):
         assert rel_err(np.array(alone[k].T).reshape(4, 4), ref["T"]) <= POSE_TOL and rel_err(np.array(alone[k].last_T).reshape(4, 4), ref["last_T"]) <= POSE_TOL
         assert abs(int(alone[k].n_inliers) - len(ref["pairs"])) <= 1e-4 * len(src)
         lib.op_icp_destroy(ctxs[k])
+
+
+@pytest.mark.parametrize("name,thr", [("uniform_1nn", 0.1), ("surface_1nn", 0.08), ("lattice_ties_1nn", 0.2)])
+def test_grid_search_equals_the_real_nanoflann(name, thr):
+    """The HIP search (uniform grid, 64-bit distance/index keys) against the answers of the reference's vendored nanoflann 1.3.2
+    (tests/golden/nanoflann_golden.json, no oracle in between): one iteration from the identity returns the inlier pairs of the raw
+    source (ICP.cpp:189-191), which must be nanoflann's nearest neighbour of every query closer than the threshold.  With exactly
+    equidistant candidates nanoflann keeps the one its traversal met first; the HIP search returns the smallest index among them."""
+    import ctypes as C
+    from onepiece_amd import _lib as L
+    c = nanoflann_case(name)
+    d2 = c["dist2"][:, 0].astype(np.float64)
+    assert np.all(np.abs(d2 - thr * thr) > 1e-6 * thr * thr)      # no query sits on the threshold
+    inl = np.flatnonzero(d2 < thr * thr)
+    assert len(inl) > 0.5 * len(d2)
+    # (1) the search + CountInliers at the identity: the count is exact, the sums are those over nanoflann's neighbours
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.op_icp_create(C.c_void_p(c["target"].ctypes.data), None, len(c["target"]), C.c_double(thr), L.OP_MEM_HOST, 0, C.byref(h)))
+    try:
+        L.check(lib.op_icp_set_source(h, C.c_void_p(c["query"].ctypes.data), len(c["query"]), L.OP_MEM_HOST))
+        out = np.zeros(42, np.float64); cnt = C.c_uint64(); err = C.c_double()
+        T = np.eye(4, dtype=np.float32)
+        L.check(lib.op_icp_iterate(h, T.ctypes.data_as(C.POINTER(C.c_float)), 0, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(err)))
+    finally:
+        lib.op_icp_destroy(h)
+    assert cnt.value == len(inl)
+    assert abs(err.value - d2[inl].sum()) <= 1e-6 * d2[inl].sum()
+    assert np.allclose(out[0:3], c["query"][inl].astype(np.float64).sum(0), rtol=0, atol=1e-9 * len(inl))
+    if name != "lattice_ties_1nn":
+        assert np.allclose(out[3:6], c["target"][c["index"][inl, 0]].astype(np.float64).sum(0), rtol=0, atol=1e-9 * len(inl))
+    # (2) the pair list of a one-iteration run: the inlier test of the returned list uses the pose AFTER the update with the
+    # correspondences found BEFORE it (ICP.cpp:96), so membership near the threshold moves -- the partner of a source does not
+    got = R.PointToPoint(R.PointCloud(c["query"]), R.PointCloud(c["target"]), None, R.ICPParameter(1, thr))
+    pairs = got.correspondence_set_index
+    assert len(pairs) > 0.5 * len(d2) and np.all(np.diff(pairs[:, 0]) > 0)
+    if name != "lattice_ties_1nn":
+        assert np.array_equal(pairs[:, 1], c["index"][pairs[:, 0], 0])
+    else:
+        differ = 0
+        for s_id, t_id in pairs:
+            d = squared_distances(c["target"], c["query"][s_id])
+            tied = np.flatnonzero(d == d.min())
+            assert t_id == tied[0] and c["index"][s_id, 0] in tied
+            differ += int(t_id != c["index"][s_id, 0])
+        assert differ > 0
+
+
+def test_normals_from_the_real_nanoflann_neighbour_lists():
+    """EstimateNormals' neighbourhoods against nanoflann's own k = 30 lists (tests/golden/nanoflann_golden.json, no oracle in between):
+    the plane fitted (in float64) to the neighbours nanoflann returned for a point is the plane the HIP kernel found for it.  The
+    radius test keeps every one of the 30 here (KDTree.h:248-252 compares the SQUARED distance with the radius)."""
+    c = nanoflann_case("uniform_knn30")
+    assert np.all(c["found"] == 30) and c["dist2"].max() <= 0.1
+    pc = R.PointCloud(c["target"]); pc.EstimateNormals(0.1, 30)
+    nq = len(c["query"])
+    assert np.array_equal(c["query"], c["target"][:nq])
+    dots, gaps = [], []
+    for i in range(nq):
+        nb = c["target"][c["index"][i]].astype(np.float64)
+        w, v = np.linalg.eigh(np.cov(nb.T, bias=True))
+        dots.append(abs(float(v[:, 0] @ pc.normals[i].astype(np.float64)))); gaps.append((w[1] - w[0]) / w[2])
+    dots, gaps = np.array(dots), np.array(gaps)
+    # a different neighbour set would turn the plane by degrees; float32 summation turns it by ~1e-6 / gap
+    assert np.all(dots[gaps > 0.05] > 1 - 1e-6) and np.all(dots > 1 - 1e-3) and np.mean(gaps > 0.05) > 0.5
+    # shrinking the radius below the 30th neighbour uses nanoflann's prefix: squared distance <= radius
+    r_small = float(np.median(c["dist2"][:, 15]))
+    pc2 = R.PointCloud(c["target"]); pc2.EstimateNormals(r_small, 30)
+    checked = 0
+    for i in range(nq):
+        used = int(np.sum(c["dist2"][i] <= np.float32(r_small)))
+        if used < 5:
+            continue
+        nb = c["target"][c["index"][i, :used]].astype(np.float64)
+        w, v = np.linalg.eigh(np.cov(nb.T, bias=True))
+        if (w[1] - w[0]) / w[2] > 0.05:
+            assert abs(float(v[:, 0] @ pc2.normals[i].astype(np.float64))) > 1 - 1e-6
+            checked += 1
+    assert checked > nq // 3
