@@ -77,6 +77,9 @@ int op_runtime_hw_queues(int *requested);
  *   OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK  1: run the whole exchange with a one-rank communicator too (how a one-GPU box exercises the RCCL path)
  *   OP_RUNTIME_OPT_TRACKER_GRAPH          0: trackers created afterwards issue plain launches instead of replaying a captured hipGraph
  *   OP_RUNTIME_OPT_COPY_THREADS           0 .. 8 helper threads of the pageable -> pinned staging copies (before the first host image)
+ *   OP_RUNTIME_OPT_CACHE_DEVICE_BYTES     bytes of RELEASED device buffers (block pools, cell tables, images) the library keeps per device for the next
+ *                                         request of a similar size instead of returning them to the driver (default 32 GB; 0 = keep none; buffers
+ *                                         already kept stay until op_release_cached_memory)
  * op_runtime_set_rccl_library(path): the RCCL to bind at the first merge instead of "librccl.so.1" (a site build; the test suite names a
  *   host-memory double that runs several ranks on one device); NULL = the system's.  Fails once RCCL has been bound. */
 #define OP_RUNTIME_OPT_MERGE_ALGORITHM 0
@@ -84,6 +87,7 @@ int op_runtime_hw_queues(int *requested);
 #define OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK 2
 #define OP_RUNTIME_OPT_TRACKER_GRAPH 3
 #define OP_RUNTIME_OPT_COPY_THREADS 4
+#define OP_RUNTIME_OPT_CACHE_DEVICE_BYTES 5
 #define OP_MERGE_OWNER_EXCHANGE 0
 #define OP_MERGE_DENSE_REDUCE 1
 int op_runtime_set_option(int option, long long value);

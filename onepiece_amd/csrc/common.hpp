@@ -24,6 +24,7 @@ struct RuntimeOptions {
     std::atomic<int> tracker_graph{1};                 // dense tracker: replay the captured hipGraph of a track (0: plain launches)
     std::atomic<int> copy_threads{2};                  // helper threads of the pageable -> pinned staging copies (read when the first host image arrives)
     std::atomic<int> hw_queues_requested{0};           // op_runtime_configure
+    std::atomic<long long> cache_device_bytes{32ll << 30}; // released device buffers kept for reuse, per device (buffer cache below); 0 = keep none
 };
 RuntimeOptions& runtime_options();
 
@@ -66,10 +67,14 @@ inline int use_device(int device) {
 // call); the GPU equivalents -- a 216 MB cell table, an 11 MB pinned row buffer, a stream, events -- cost milliseconds
 // to allocate and free (hipFree synchronises the device), several times the 1-2 ms such a call computes for.  Released
 // buffers therefore go to a per-process cache and are handed out again to the next request of a similar size (best fit,
-// at most 25 % larger), so a steady stream of calls allocates nothing.  The cache holds at most kCacheDeviceBytes per
-// device and kCacheHostBytes of pinned memory per device, nothing above kCacheLargest (beyond that a released buffer is really freed); op_release_cached_memory()
-// empties it.  Owners synchronise their stream before releasing, so a cached buffer is idle.  Contents are NOT cleared.
-constexpr size_t kCacheDeviceBytes = 8ull << 30, kCacheHostBytes = 1ull << 30, kCacheLargest = 1ull << 30;
+// at most 25 % larger), so a steady stream of calls allocates nothing.  That includes a volume's block pool (2.7 GB at the default
+// capacity): the reference's drivers make a CubeHandler per submap and a new one per Transform, and a hipMalloc of gigabytes
+// is not only milliseconds -- every few calls the driver takes 1.2-1.5 s over one (measured: tools/ops_driver.bin transform,
+// profiles/r05_transform_pool.txt).  The cache holds at most RuntimeOptions::cache_device_bytes per device (32 GB of the
+// 288 GB; OP_RUNTIME_OPT_CACHE_DEVICE_BYTES) and kCacheHostBytes of pinned memory per device, no single buffer above half the
+// device limit (beyond that a released buffer is really freed); op_release_cached_memory() empties it.  Owners synchronise their
+// stream before releasing, so a cached buffer is idle.  Contents are NOT cleared.
+constexpr size_t kCacheHostBytes = 1ull << 30;
 struct BufferCache {
     struct Slot { void* p; size_t bytes; int device; bool host; };
     std::mutex mu;
@@ -136,8 +141,8 @@ inline void cached_free(void* p) {
         std::lock_guard<std::mutex> lock(c.mu);
         for (size_t i = 0; i < c.live_slots.size(); ++i)
             if (c.live_slots[i].p == p) { s = c.live_slots[i]; c.live_slots.erase(c.live_slots.begin() + (long)i); break; }
-        // buffers above 1 GB (a volume's block pool) are not kept: they are long-lived and would crowd everything else out
-        if (s.p && s.bytes <= kCacheLargest && c.cached(s.device, s.host) + s.bytes <= (s.host ? kCacheHostBytes : kCacheDeviceBytes)) {
+        const size_t limit = s.host ? kCacheHostBytes : (size_t)runtime_options().cache_device_bytes.load();
+        if (s.p && s.bytes <= limit / 2 && c.cached(s.device, s.host) + s.bytes <= limit) {
             c.free_slots.push_back(s);
             return;
         }

@@ -535,7 +535,7 @@ int vol_ring_alloc(op_volume* v) {
     const size_t npx = (size_t)v->cam.width * v->cam.height;
     if (v->ring_px >= npx && v->copy_stream) return OP_OK;
     OP_TRY(vol_check(v)); // nothing in flight may still read the old slots
-    if (!v->copy_stream) OP_HIP(hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking));
+    if (!v->copy_stream) OP_HIP(op::cached_stream(&v->copy_stream));
     for (auto& r : v->ring) {
         if (r.d_depth) op::cached_free(r.d_depth);
         if (r.d_rgb) op::cached_free(r.d_rgb);
@@ -677,6 +677,9 @@ int op_runtime_set_option(int option, long long value) {
         case OP_RUNTIME_OPT_COPY_THREADS:
             if (value < 0 || value > 8) return fail(OP_ERR_INVALID, "op_runtime_set_option: %lld copy threads (0 .. 8)", value);
             o.copy_threads.store((int)value); return OP_OK;
+        case OP_RUNTIME_OPT_CACHE_DEVICE_BYTES:
+            if (value < 0) return fail(OP_ERR_INVALID, "op_runtime_set_option: cache limit %lld", value);
+            o.cache_device_bytes.store(value); return OP_OK;
         default: break;
     }
     return fail(OP_ERR_INVALID, "op_runtime_set_option: unknown option %d", option);
@@ -802,7 +805,7 @@ int op_volume_create(const op_camera* cam, float voxel_res, float truncation, fl
     v->table_size = next_pow2(2ull * max_blocks);
     auto cleanup = [&](int rc) { op_volume_destroy(v); return rc; };
 #define OP_HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(OP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
-    OP_HIP_C(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    OP_HIP_C(op::cached_stream(&v->stream)); // creating and destroying a stream costs 1.5-2 ms each: kept like the buffers
     OP_HIP_C(op::cached_malloc((void**)&v->tkeys, sizeof(unsigned long long) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->tvals, sizeof(int) * (size_t)v->table_size));
     OP_HIP_C(op::cached_malloc((void**)&v->bmask, sizeof(bmask_t) * (size_t)v->table_size));
@@ -848,8 +851,8 @@ int op_volume_destroy(op_volume* v) {
         if (r.copied) (void)hipEventDestroy(r.copied);
     }
     if (v->hstat) op::cached_free(v->hstat);
-    if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
-    if (v->stream) (void)hipStreamDestroy(v->stream);
+    op::release_stream(v->copy_stream, v->device); // both were synchronised above
+    op::release_stream(v->stream, v->device);
     delete v;
     return OP_OK;
 }

@@ -639,7 +639,9 @@ int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, i
     // Transform copies c_para into the result (CubeHandler.h:249); TransformNearest does not
     // (CubeHandler.h:301-305), so its result keeps the default resolution 0.01 (VoxelCube.h:27)
     const float dst_res = nearest ? 0.01f : src->res;
-    if (max_blocks == 0) max_blocks = std::max<uint64_t>(8ull * ns + 4096ull, 1ull << 14);
+    // a rigid motion turns ns blocks into ~1.25 ns (164 k -> 205 k on the room volume); the pool starts at twice the source and the
+    // idempotent allocation pass below runs again after a growth if a thin, badly aligned shell needs more (8 ns was 13 GB for that volume)
+    if (max_blocks == 0) max_blocks = std::max<uint64_t>(2ull * ns + 4096ull, 1ull << 14);
     op_volume* dst = nullptr;
     OP_TRY(op_volume_create(&src->cam, dst_res, src->trunc, src->far_d, src->near_d, src->device, max_blocks, &dst));
     vol_mark_foreign(dst, max_blocks); // resampled values (the reference's own divisions may even leave NaN / inf in them); the bound is tightened below

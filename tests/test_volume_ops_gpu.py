@@ -59,6 +59,19 @@ def test_transform_trilinear(oracle):
     _same(oi, hi)
 
 
+@pytest.mark.parametrize("nearest", [False, True])
+def test_transform_result_outgrows_its_pool(oracle, nearest):
+    """The result's pool starts at twice the source's block count and grows when the resampled surface needs more: started far too
+    small (a quarter of the source), the allocation pass is repeated after every growth and the result is the same volume."""
+    ov, hv = _pair(oracle, 0.01)
+    T = oracle.se3_exp(T_SMALL)
+    ot = ov.transform(T, nearest=nearest)
+    small = max(hv.BlockCount() // 4, 16)
+    ht = hv.TransformNearest(T, max_blocks=small) if nearest else hv.Transform(T, max_blocks=small)
+    assert ht.BlockCount() == ot.block_count() > small
+    _same(ot, ht)
+
+
 def test_get_point_cloud(oracle):
     ov, hv = _pair(oracle, 0.01)
     op, oc = ov.point_cloud()

@@ -9,6 +9,7 @@
 //   transform_nn  op_volume_transform, nearest     (CubeHandler::TransformNearest)
 //   normals       op_points_from_depth + op_estimate_normals(0.1, 30) of frame 0 (PointCloud::EstimateNormals)
 //   bilateral     op_bilateral_filter_depth(d = 7, 0.03, 4.5) of every frame (tool::BilateralFilter)
+//   create        op_volume_create + op_volume_destroy of an empty volume of the default capacity (a CubeHandler per submap / per Transform)
 //   all           every one of the above
 // Usage: ops_driver.bin frames.bin voxel reps op [op ...]
 // Build: hipcc --offload-arch=gfx950 -O2 -I include tools/ops_driver.cpp -L onepiece_amd -lonepiece_hip -L host/one_piece -lone_piece_hip_host -o tools/ops_driver.bin
@@ -135,6 +136,18 @@ int main(int argc, char** argv) {
             CK(op_volume_destroy(o));
         }
         printf("%s: %zu -> %zu blocks, %.3f ms per call (new volume included)\n", nearest ? "transform_nn" : "transform", nb, nout, sum / reps * 1e3);
+    }
+    if (want("create")) {
+        double sum = 0, worst = 0;
+        for (int r = 0; r < reps + 1; ++r) {
+            op_volume* o = nullptr;
+            t0 = now();
+            CK(op_volume_create(&cam, voxel, 0.1f, 5.0f, 0.5f, 0, 0, &o));
+            CK(op_volume_destroy(o));
+            const double dt = now() - t0;
+            if (r) { sum += dt; worst = std::max(worst, dt); }
+        }
+        printf("create: empty volume of the default capacity (2^18 blocks, 2.7 GB) created and destroyed in %.3f ms (worst of %d: %.3f ms)\n", sum / reps * 1e3, reps, worst * 1e3);
     }
     if (want("normals")) {
         std::vector<float> xyz(npx * 3), nrm(npx * 3);
