@@ -345,6 +345,7 @@ def test_loading_the_library_changes_nothing_in_the_process_environment():
         "assert L.op_runtime_hw_queues(ctypes.byref(q)) == 0 and q.value == 8\n"
         "L.op_runtime_set_option.argtypes = [ctypes.c_int, ctypes.c_longlong]\n"
         "assert L.op_runtime_set_option(0, 1) == 0 and L.op_runtime_set_option(0, 7) != 0 and L.op_runtime_set_option(99, 0) != 0\n"
+        "assert L.op_runtime_set_option(5, 0) == 0 and L.op_runtime_set_option(5, 64 << 30) == 0 and L.op_runtime_set_option(5, -1) != 0\n"
         "assert L.op_runtime_set_rccl_library(b'/nonexistent/librccl.so') == 0 and L.op_runtime_set_rccl_library(None) == 0\n"
         "print('ok')\n" % lib)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES" and not k.startswith("ONEPIECE_")}

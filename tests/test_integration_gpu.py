@@ -964,3 +964,31 @@ def test_selection_with_frames_far_apart(oracle):
     for mode in ("auto", "direct", 2000):
         hv = _fuse(oracle, depth, rgb, poses, mode)
         _compare(oracle, ov, hv)
+
+
+def test_released_pools_are_kept_for_reuse_up_to_the_configured_limit():
+    """A destroyed volume's block pool (2.7 GB at the default capacity) stays with the library for the next volume -- the reference's
+    drivers make a CubeHandler per submap and per Transform -- until op_release_cached_memory, or not at all with the limit at 0
+    (OP_RUNTIME_OPT_CACHE_DEVICE_BYTES)."""
+    import torch
+    from onepiece_amd import _lib as L
+    lib = L.load()
+    pool = (1 << 18) * 10240
+    L.check(lib.op_release_cached_memory())
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    hv = I.CubeHandler(); del hv
+    import gc; gc.collect()
+    kept = free0 - torch.cuda.mem_get_info(0)[0]
+    assert kept >= pool                                   # the pool (and the small tables) are still allocated
+    hv = I.CubeHandler(); del hv; gc.collect()
+    assert free0 - torch.cuda.mem_get_info(0)[0] <= kept + (64 << 20)   # the second volume took the first one's buffers
+    L.check(lib.op_release_cached_memory())
+    assert free0 - torch.cuda.mem_get_info(0)[0] < pool // 2
+    try:
+        L.check(lib.op_runtime_set_option(L.OP_RUNTIME_OPT_CACHE_DEVICE_BYTES, 0))
+        hv = I.CubeHandler(); del hv; gc.collect()
+        assert free0 - torch.cuda.mem_get_info(0)[0] < pool // 2
+    finally:
+        L.check(lib.op_runtime_set_option(L.OP_RUNTIME_OPT_CACHE_DEVICE_BYTES, 32 << 30))
+        L.check(lib.op_release_cached_memory())
