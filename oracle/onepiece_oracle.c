@@ -1004,79 +1004,164 @@ void orc_p2plane_step(const float *src, const float *tgt, const float *tgt_n,
     if (JTr) memcpy(JTr, jtr, sizeof(jtr));
 }
 
-/* ---- exact 1-NN: kd-tree (the reference uses nanoflann 1.3.2, exact, eps = 0) -------------- */
-typedef struct { int left, right, axis, lo, hi; float split; } kdnode;
-typedef struct { const float *pts; int *idx; kdnode *nodes; int n_nodes; } kdtree;
+/* ---- nearest neighbours: a restatement of nanoflann 1.3.2 as geometry::KDTree drives it ------------------------------
+ * (third-party dependency of the reference, vendored under 3rdparty/nanoflann/include/nanoflann.hpp; KDTree.h:62-98 builds a
+ * KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<float, cloud>, cloud, 3> with leaf size 10, KDTree.h:171-190 / :230-255 call
+ * knnSearch with the default SearchParams, i.e. eps = 0).  The restatement follows the published algorithm step for step --
+ * bounding boxes, middle split with its spread test, the three-way plane split and its permutation of the index array,
+ * near-child-first descent with the per-dimension lower bound, and the result set that keeps the FIRST of equally distant
+ * candidates -- because the answer on exactly equidistant candidates (duplicated points, lattices) is decided by nothing else:
+ * tests/golden/nanoflann_golden.json (generated with the real header) holds such cases, and the indices must agree there too.
+ * All arithmetic is float, as in the instantiation above (ElementType = DistanceType = float). */
+typedef struct { int child1, child2; size_t left, right; int divfeat; float divlow, divhigh; } nf_node;
+typedef struct { const float *pts; size_t *vind; nf_node *nodes; int n_nodes; size_t n; float root_lo[3], root_hi[3]; } nf_tree;
 
-static int kd_build(kdtree *t, int lo, int hi) {
-    int id = t->n_nodes++;
-    kdnode *nd = &t->nodes[id];
-    nd->lo = lo; nd->hi = hi; nd->left = nd->right = -1; nd->axis = -1;
-    if (hi - lo <= 10) return id; /* leaf size 10 as nanoflann's default in KDTree.h:86-92 */
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = lo; i < hi; ++i)
-        for (int c = 0; c < 3; ++c) {
-            float v = t->pts[3 * t->idx[i] + c];
-            if (v < mn[c]) mn[c] = v;
-            if (v > mx[c]) mx[c] = v;
-        }
-    int ax = 0;
-    if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
-    if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
-    float split = 0.5f * (mn[ax] + mx[ax]);
-    int i = lo, j = hi - 1;
-    while (i <= j) {
-        if (t->pts[3 * t->idx[i] + ax] < split) ++i;
-        else { int tmp = t->idx[i]; t->idx[i] = t->idx[j]; t->idx[j] = tmp; --j; }
+static void nf_min_max(const nf_tree *t, const size_t *ind, size_t count, int element, float *mn, float *mx) { /* computeMinMax */
+    *mn = *mx = t->pts[3 * ind[0] + element];
+    for (size_t i = 1; i < count; ++i) {
+        float v = t->pts[3 * ind[i] + element];
+        if (v < *mn) *mn = v;
+        if (v > *mx) *mx = v;
     }
-    if (i == lo || i == hi) return id; /* degenerate: keep as a (large) leaf */
-    t->nodes[id].axis = ax; t->nodes[id].split = split;
-    int l = kd_build(t, lo, i);
-    int r = kd_build(t, i, hi);
-    t->nodes[id].left = l; t->nodes[id].right = r;
+}
+static void nf_plane_split(const nf_tree *t, size_t *ind, size_t count, int cutfeat, float cutval, size_t *lim1, size_t *lim2) { /* planeSplit */
+    size_t left = 0, right = count - 1;
+    for (;;) {
+        while (left <= right && t->pts[3 * ind[left] + cutfeat] < cutval) ++left;
+        while (right && left <= right && t->pts[3 * ind[right] + cutfeat] >= cutval) --right;
+        if (left > right || !right) break;
+        size_t tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim1 = left;
+    right = count - 1;
+    for (;;) {
+        while (left <= right && t->pts[3 * ind[left] + cutfeat] <= cutval) ++left;
+        while (right && left <= right && t->pts[3 * ind[right] + cutfeat] > cutval) --right;
+        if (left > right || !right) break;
+        size_t tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim2 = left;
+}
+static void nf_middle_split(const nf_tree *t, size_t *ind, size_t count, size_t *index, int *cutfeat, float *cutval, const float lo[3], const float hi[3]) { /* middleSplit_ */
+    const float eps = 0.00001f;
+    float max_span = hi[0] - lo[0];
+    for (int i = 1; i < 3; ++i) { float span = hi[i] - lo[i]; if (span > max_span) max_span = span; }
+    float max_spread = -1;
+    *cutfeat = 0;
+    for (int i = 0; i < 3; ++i) {
+        float span = hi[i] - lo[i];
+        if (span > (1 - eps) * max_span) {
+            float mn, mx;
+            nf_min_max(t, ind, count, i, &mn, &mx);
+            float spread = mx - mn;
+            if (spread > max_spread) { *cutfeat = i; max_spread = spread; }
+        }
+    }
+    float split_val = (lo[*cutfeat] + hi[*cutfeat]) / 2;
+    float mn, mx;
+    nf_min_max(t, ind, count, *cutfeat, &mn, &mx);
+    if (split_val < mn) *cutval = mn;
+    else if (split_val > mx) *cutval = mx;
+    else *cutval = split_val;
+    size_t lim1, lim2;
+    nf_plane_split(t, ind, count, *cutfeat, *cutval, &lim1, &lim2);
+    if (lim1 > count / 2) *index = lim1;
+    else if (lim2 < count / 2) *index = lim2;
+    else *index = count / 2;
+}
+static int nf_divide(nf_tree *t, size_t left, size_t right, float lo[3], float hi[3]) { /* divideTree; lo/hi in: the cell, out: the box of the points */
+    int id = t->n_nodes++;
+    if (right - left <= 10) { /* leaf_max_size: KDTree(int _max_leaf = 10) */
+        t->nodes[id].child1 = t->nodes[id].child2 = -1;
+        t->nodes[id].left = left; t->nodes[id].right = right;
+        for (int i = 0; i < 3; ++i) lo[i] = hi[i] = t->pts[3 * t->vind[left] + i];
+        for (size_t k = left + 1; k < right; ++k)
+            for (int i = 0; i < 3; ++i) {
+                float v = t->pts[3 * t->vind[k] + i];
+                if (lo[i] > v) lo[i] = v;
+                if (hi[i] < v) hi[i] = v;
+            }
+        return id;
+    }
+    size_t idx; int cutfeat; float cutval;
+    nf_middle_split(t, t->vind + left, right - left, &idx, &cutfeat, &cutval, lo, hi);
+    float llo[3], lhi[3], rlo[3], rhi[3];
+    memcpy(llo, lo, sizeof(llo)); memcpy(lhi, hi, sizeof(lhi)); memcpy(rlo, lo, sizeof(rlo)); memcpy(rhi, hi, sizeof(rhi));
+    lhi[cutfeat] = cutval;
+    int c1 = nf_divide(t, left, left + idx, llo, lhi);
+    rlo[cutfeat] = cutval;
+    int c2 = nf_divide(t, left + idx, right, rlo, rhi);
+    nf_node *nd = &t->nodes[id]; /* (the array does not move: allocated for 2 n nodes up front) */
+    nd->child1 = c1; nd->child2 = c2; nd->divfeat = cutfeat; nd->left = left; nd->right = right;
+    nd->divlow = lhi[cutfeat]; nd->divhigh = rlo[cutfeat];
+    for (int i = 0; i < 3; ++i) { lo[i] = llo[i] < rlo[i] ? llo[i] : rlo[i]; hi[i] = lhi[i] > rhi[i] ? lhi[i] : rhi[i]; }
     return id;
 }
-static void kd_query(const kdtree *t, int id, const float *q, float *best_d, int *best_i) {
-    const kdnode *nd = &t->nodes[id];
-    if (nd->axis < 0) {
-        for (int i = nd->lo; i < nd->hi; ++i) {
-            const float *p = t->pts + 3 * t->idx[i];
-            float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
-            float d = dx * dx + dy * dy + dz * dz;
-            if (d < *best_d || (d == *best_d && t->idx[i] < *best_i)) { *best_d = d; *best_i = t->idx[i]; }
+static void nf_build(nf_tree *t, const float *pts, size_t n) { /* buildIndex */
+    t->pts = pts; t->n = n; t->n_nodes = 0;
+    t->vind = (size_t *)malloc((n + 1) * sizeof(size_t));
+    t->nodes = (nf_node *)malloc((2 * n + 2) * sizeof(nf_node));
+    for (size_t i = 0; i < n; ++i) t->vind[i] = i;
+    if (!n) return;
+    for (int i = 0; i < 3; ++i) t->root_lo[i] = t->root_hi[i] = pts[i];   /* computeBoundingBox */
+    for (size_t k = 1; k < n; ++k)
+        for (int i = 0; i < 3; ++i) {
+            if (pts[3 * k + i] < t->root_lo[i]) t->root_lo[i] = pts[3 * k + i];
+            if (pts[3 * k + i] > t->root_hi[i]) t->root_hi[i] = pts[3 * k + i];
         }
-        return;
-    }
-    float diff = q[nd->axis] - nd->split;
-    int first = diff < 0 ? nd->left : nd->right, second = diff < 0 ? nd->right : nd->left;
-    kd_query(t, first, q, best_d, best_i);
-    if (diff * diff <= *best_d) kd_query(t, second, q, best_d, best_i);
+    nf_divide(t, 0, n, t->root_lo, t->root_hi);
 }
+static void nf_free(nf_tree *t) { free(t->vind); free(t->nodes); }
 
-/* k nearest neighbours, sorted ascending by (squared distance, index) -- nanoflann knnSearch */
+/* KNNResultSet: ascending distances; an equally distant newcomer goes BEHIND the entries already there (and is dropped when the set is full) */
 typedef struct { float d[64]; int i[64]; int n, k; } knn_set;
-static void knn_push(knn_set *s, float d, int idx) {
-    if (s->n == s->k && !(d < s->d[s->n - 1] || (d == s->d[s->n - 1] && idx < s->i[s->n - 1]))) return;
-    int pos = s->n < s->k ? s->n++ : s->n - 1;
-    while (pos > 0 && (d < s->d[pos - 1] || (d == s->d[pos - 1] && idx < s->i[pos - 1]))) {
-        s->d[pos] = s->d[pos - 1]; s->i[pos] = s->i[pos - 1]; --pos;
+static void knn_init(knn_set *s, int k) { s->n = 0; s->k = k; s->d[k - 1] = FLT_MAX; }
+static void knn_add(knn_set *s, float dist, int index) { /* addPoint */
+    int i;
+    for (i = s->n; i > 0; --i) {
+        if (s->d[i - 1] > dist) { if (i < s->k) { s->d[i] = s->d[i - 1]; s->i[i] = s->i[i - 1]; } }
+        else break;
     }
-    s->d[pos] = d; s->i[pos] = idx;
+    if (i < s->k) { s->d[i] = dist; s->i[i] = index; }
+    if (s->n < s->k) s->n++;
 }
-static void kd_knn(const kdtree *t, int id, const float *q, knn_set *s) {
-    const kdnode *nd = &t->nodes[id];
-    if (nd->axis < 0) {
-        for (int i = nd->lo; i < nd->hi; ++i) {
-            const float *p = t->pts + 3 * t->idx[i];
-            float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
-            knn_push(s, dx * dx + dy * dy + dz * dz, t->idx[i]);
+static void nf_search_level(const nf_tree *t, int id, const float *q, float mindistsq, float dists[3], knn_set *s) { /* searchLevel, epsError = 1 */
+    const nf_node *nd = &t->nodes[id];
+    if (nd->child1 < 0) {
+        float worst = s->d[s->k - 1]; /* read once per leaf, as nanoflann does */
+        for (size_t i = nd->left; i < nd->right; ++i) {
+            const float *p = t->pts + 3 * t->vind[i];
+            float dist = 0; /* L2_Simple_Adaptor::evalMetric: result += diff * diff over the dimensions */
+            for (int c = 0; c < 3; ++c) { float diff = q[c] - p[c]; dist += diff * diff; }
+            if (dist < worst) knn_add(s, dist, (int)t->vind[i]);
         }
         return;
     }
-    float diff = q[nd->axis] - nd->split;
-    int first = diff < 0 ? nd->left : nd->right, second = diff < 0 ? nd->right : nd->left;
-    kd_knn(t, first, q, s);
-    if (s->n < s->k || diff * diff <= s->d[s->n - 1]) kd_knn(t, second, q, s);
+    int idx = nd->divfeat;
+    float val = q[idx], diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+    int best, other; float cut;
+    if ((diff1 + diff2) < 0) { best = nd->child1; other = nd->child2; cut = (val - nd->divhigh) * (val - nd->divhigh); }
+    else { best = nd->child2; other = nd->child1; cut = (val - nd->divlow) * (val - nd->divlow); }
+    nf_search_level(t, best, q, mindistsq, dists, s);
+    float dst = dists[idx];
+    mindistsq = mindistsq + cut - dst;
+    dists[idx] = cut;
+    if (mindistsq * 1.0f <= s->d[s->k - 1]) nf_search_level(t, other, q, mindistsq, dists, s);
+    dists[idx] = dst;
+}
+/* knnSearch -> number found; s holds them in nanoflann's order */
+static int nf_knn(const nf_tree *t, const float *q, int k, knn_set *s) { /* findNeighbors */
+    knn_init(s, k);
+    if (!t->n) return 0;
+    float dists[3] = {0, 0, 0}, distsq = 0;
+    for (int i = 0; i < 3; ++i) { /* computeInitialDistances */
+        if (q[i] < t->root_lo[i]) { dists[i] = (q[i] - t->root_lo[i]) * (q[i] - t->root_lo[i]); distsq += dists[i]; }
+        if (q[i] > t->root_hi[i]) { dists[i] = (q[i] - t->root_hi[i]) * (q[i] - t->root_hi[i]); distsq += dists[i]; }
+    }
+    nf_search_level(t, 0, q, distsq, dists, s);
+    return s->n;
 }
 
 /* geometry::FitPlane (Geometry.cpp:172-218): float sums in neighbour order, W / n, normal = the
@@ -1109,48 +1194,34 @@ static void fit_plane_normal(const float *pts, const int *idx, int n, float norm
  * k nearest, then the prefix whose SQUARED distance is <= radius). */
 void orc_estimate_normals(const float *pts, size_t n, float radius, int knn, float *normals) {
     if (knn > 64) knn = 64;
-    kdtree t;
-    t.pts = pts; t.idx = (int *)malloc((n + 1) * sizeof(int));
-    t.nodes = (kdnode *)malloc((2 * n + 2) * sizeof(kdnode)); t.n_nodes = 0;
-    for (size_t i = 0; i < n; ++i) t.idx[i] = (int)i;
-    if (n) kd_build(&t, 0, (int)n);
+    if (knn < 1) { memset(normals, 0, n * 3 * sizeof(float)); return; }
+    nf_tree t;
+    nf_build(&t, pts, n);
 #pragma omp parallel for schedule(dynamic, 256)
     for (long i = 0; i < (long)n; ++i) {
-        knn_set s; s.n = 0; s.k = knn;
-        kd_knn(&t, 0, pts + 3 * i, &s);
+        knn_set s;
+        nf_knn(&t, pts + 3 * i, knn, &s);
         int used = 0;
         while (used < s.n && !(s.d[used] > radius)) ++used;
         fit_plane_normal(pts, s.i, used, normals + 3 * i);
     }
-    free(t.idx); free(t.nodes);
+    nf_free(&t);
 }
 
-/* The searches above, exposed for tests/test_oracle_golden.py's comparison with the real nanoflann (tests/golden/nanoflann_golden.json):
- * k == 1 is ICP's search (kd_query, ties to the smaller index), k > 1 is EstimateNormals' (kd_knn, sorted by (distance, index)).
- * idx / d2 hold k entries per query (-1 / -1.0f beyond `found`). */
+/* The search above, exposed for tests/test_oracle_golden.py's comparison with the real nanoflann (tests/golden/nanoflann_golden.json):
+ * k == 1 is ICP's search, k > 1 EstimateNormals'.  idx / d2 hold k entries per query (-1 / -1.0f beyond `found`). */
 void orc_knn_search(const float *tgt, size_t n_tgt, const float *queries, size_t n_q, int k, int32_t *idx, float *d2, int32_t *found) {
     if (k > 64) k = 64;
-    kdtree t;
-    t.pts = tgt; t.idx = (int *)malloc((n_tgt + 1) * sizeof(int));
-    t.nodes = (kdnode *)malloc((2 * n_tgt + 2) * sizeof(kdnode)); t.n_nodes = 0;
-    for (size_t i = 0; i < n_tgt; ++i) t.idx[i] = (int)i;
-    if (n_tgt) kd_build(&t, 0, (int)n_tgt);
+    if (k < 1) k = 1;
+    nf_tree t;
+    nf_build(&t, tgt, n_tgt);
     for (size_t i = 0; i < n_q; ++i) {
         for (int j = 0; j < k; ++j) { idx[i * k + j] = -1; d2[i * k + j] = -1.0f; }
-        found[i] = 0;
-        if (!n_tgt) continue;
-        if (k == 1) {
-            float bd = FLT_MAX; int bi = -1;
-            kd_query(&t, 0, queries + 3 * i, &bd, &bi);
-            if (bi >= 0) { idx[i] = bi; d2[i] = bd; found[i] = 1; }
-        } else {
-            knn_set s; s.n = 0; s.k = k;
-            kd_knn(&t, 0, queries + 3 * i, &s);
-            for (int j = 0; j < s.n; ++j) { idx[i * k + j] = s.i[j]; d2[i * k + j] = s.d[j]; }
-            found[i] = s.n;
-        }
+        knn_set s;
+        found[i] = nf_knn(&t, queries + 3 * i, k, &s);
+        for (int j = 0; j < s.n; ++j) { idx[i * k + j] = s.i[j]; d2[i * k + j] = s.d[j]; }
     }
-    free(t.idx); free(t.nodes);
+    nf_free(&t);
 }
 
 /* ICP.cpp:9-30 */
@@ -1188,11 +1259,8 @@ int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt
             orc_icp_result *res, int32_t *inlier_pairs, int32_t *per_iter_inliers,
             float *per_iter_T) {
     if (point_to_plane && !tgt_normals) return 1; /* ICP.cpp:159-163 */
-    kdtree t;
-    t.pts = tgt; t.idx = (int *)malloc(n_tgt * sizeof(int));
-    t.nodes = (kdnode *)malloc((2 * n_tgt + 2) * sizeof(kdnode)); t.n_nodes = 0;
-    for (size_t i = 0; i < n_tgt; ++i) t.idx[i] = (int)i;
-    if (n_tgt) kd_build(&t, 0, (int)n_tgt);
+    nf_tree t;
+    nf_build(&t, tgt, n_tgt);
     float start_T[16];
     memcpy(start_T, init_T, sizeof(start_T));
     int *corr = (int *)malloc(n_src * sizeof(int));
@@ -1208,9 +1276,8 @@ int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt
         }
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)n_src; ++i) { /* ICP.cpp:184-192 */
-            float bd = FLT_MAX; int bi = -1;
-            if (n_tgt) kd_query(&t, 0, tp + 3 * i, &bd, &bi);
-            corr[i] = bi;
+            knn_set s1; /* indices.size() > 0 ? indices[0] : -1 (ICP.cpp:69-72, :189-192) */
+            corr[i] = nf_knn(&t, tp + 3 * i, 1, &s1) > 0 ? s1.i[0] : -1;
         }
         count_inliers(src, tgt, corr, n_src, start_T, threshold, inl, &n_inl); /* ICP.cpp:193 */
         float tmp_T[16];
@@ -1238,7 +1305,7 @@ int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt
     }
     orc_kabsch(pairs, n_inl, res->T);
     if (inlier_pairs) memcpy(inlier_pairs, inl, n_inl * 2 * sizeof(int32_t));
-    free(corr); free(tp); free(inl); free(pairs); free(t.idx); free(t.nodes);
+    free(corr); free(tp); free(inl); free(pairs); nf_free(&t);
     return 0;
 }
 

@@ -44,7 +44,7 @@ static void b64(const char* name, const void* data, size_t bytes, bool comma = t
 }
 
 // one case: k nearest of every query, in nanoflann's output order
-static void run_case(const char* name, const char* what, const Cloud& tgt, const std::vector<float>& q, int k, bool last = false) {
+static void run_case(const char* name, const char* what, const Cloud& tgt, const std::vector<float>& q, int k, bool last = false, const char* target_of = nullptr) {
     Tree tree(3, tgt, nanoflann::KDTreeSingleIndexAdaptorParams(10));
     tree.buildIndex();
     const size_t nq = q.size() / 3;
@@ -59,7 +59,8 @@ static void run_case(const char* name, const char* what, const Cloud& tgt, const
         for (size_t j = 0; j < found; ++j) { idx[i * k + j] = (int32_t)id[j]; d2[i * k + j] = dd[j]; }
     }
     fprintf(out, "\"%s\": {\"what\": \"%s\", \"k\": %d, \"n_target\": %zu, \"n_query\": %zu, ", name, what, k, tgt.xyz.size() / 3, nq);
-    b64("target_f32", tgt.xyz.data(), tgt.xyz.size() * 4);
+    if (target_of) fprintf(out, "\"target_of\": \"%s\", ", target_of);   // the same cloud as that case: not stored twice
+    else b64("target_f32", tgt.xyz.data(), tgt.xyz.size() * 4);
     b64("query_f32", q.data(), q.size() * 4);
     b64("found_i32", cnt.data(), cnt.size() * 4);
     b64("index_i32", idx.data(), idx.size() * 4);
@@ -77,22 +78,22 @@ int main(int argc, char** argv) {
 
     { // 1. uniform cloud, independent queries: 1-NN
         Cloud t; std::vector<float> q;
-        for (int i = 0; i < 3000 * 3; ++i) t.xyz.push_back(u(g));
-        for (int i = 0; i < 1000 * 3; ++i) q.push_back(1.1f * u(g));   // (some queries lie outside the target's box)
-        run_case("uniform_1nn", "3000 uniform targets in [-1,1]^3, 1000 queries in [-1.1,1.1]^3, k = 1 (ICP.cpp:69,189)", t, q, 1);
+        for (int i = 0; i < 2000 * 3; ++i) t.xyz.push_back(u(g));
+        for (int i = 0; i < 700 * 3; ++i) q.push_back(1.1f * u(g));   // (some queries lie outside the target's box)
+        run_case("uniform_1nn", "2000 uniform targets in [-1,1]^3, 700 queries in [-1.1,1.1]^3, k = 1 (ICP.cpp:69,189)", t, q, 1);
     }
     { // 2. a depth-image-like surface and the same surface after a small rigid motion: the shape of ICP's own inputs
         Cloud t; std::vector<float> q;
         const float c = std::cos(0.03f), s = std::sin(0.03f);
-        for (int v = 0; v < 48; ++v)
-            for (int x = 0; x < 64; ++x) {
+        for (int v = 0; v < 40; ++v)
+            for (int x = 0; x < 52; ++x) {
                 const float z = 1.5f + 0.2f * std::sin(0.11f * x) * std::cos(0.07f * v) + 0.002f * u(g);
-                const float X = (x * 10 + 5 - 318.771f) / 514.817f * z, Y = (v * 10 + 5 - 238.447f) / 515.375f * z;
+                const float X = (x * 12 + 6 - 318.771f) / 514.817f * z, Y = (v * 12 + 6 - 238.447f) / 515.375f * z;
                 t.xyz.push_back(X); t.xyz.push_back(Y); t.xyz.push_back(z);
                 const float z2 = z + 0.001f * u(g);
                 q.push_back(c * X + s * z2 + 0.01f); q.push_back(Y - 0.015f); q.push_back(-s * X + c * z2 + 0.02f);
             }
-        run_case("surface_1nn", "64 x 48 back-projected wavy sheet; queries = the sheet moved by 0.03 rad about y and (0.01,-0.015,0.02) m, k = 1", t, q, 1);
+        run_case("surface_1nn", "52 x 40 back-projected wavy sheet; queries = the sheet moved by 0.03 rad about y and (0.01,-0.015,0.02) m, k = 1", t, q, 1);
     }
     { // 3. exact-distance ties: a lattice with exactly representable coordinates plus duplicated points
         Cloud t; std::vector<float> q;
@@ -115,6 +116,15 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 7 * 3; ++i) t.xyz.push_back(u(g));
         for (int i = 0; i < 5 * 3; ++i) q.push_back(u(g));
         run_case("tiny_knn30", "7 points, k = 30: knnSearch returns 7", t, q, 30);
+    }
+    { // 5b. a noisy surface whose coordinates are quantised to 1/128: duplicated points and equidistant pairs all over a deep tree
+        Cloud t; std::vector<float> q;
+        auto qz = [](float v) { return std::floor(v * 128.0f + 0.5f) / 128.0f; };
+        for (int i = 0; i < 4000; ++i) { const float x = u(g), y = u(g); t.xyz.push_back(qz(x)); t.xyz.push_back(qz(y)); t.xyz.push_back(qz(0.3f * std::sin(3.0f * x) * std::cos(2.0f * y) + 0.01f * u(g))); }
+        for (int i = 0; i < 1000; ++i) { const float x = u(g), y = u(g); q.push_back(qz(x)); q.push_back(qz(y)); q.push_back(qz(0.3f * std::sin(3.0f * x) * std::cos(2.0f * y) + 0.02f * u(g))); }
+        run_case("quantised_1nn", "4000 points of a wavy sheet with coordinates rounded to 1/128 (duplicates, equidistant pairs), 1000 queries rounded alike, k = 1", t, q, 1);
+        std::vector<float> q2(q.begin(), q.begin() + 3 * 200);
+        run_case("quantised_knn30", "the same cloud, 200 of the queries, k = 30", t, q2, 30, false, "quantised_1nn");
     }
     { // 6. k = 30 on the lattice: ties inside the result list
         Cloud t; std::vector<float> q;

@@ -97,10 +97,11 @@ def nanoflann_case(name):
     """One case of the fixture oracle/tools/gen_nanoflann_golden.cpp wrote: inputs and the real nanoflann's answers."""
     import base64
     import json, os
-    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nanoflann_golden.json")))[name]
-    a = lambda key, dt: np.frombuffer(base64.b64decode(c[key]), dtype=dt)
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nanoflann_golden.json")))
+    c = cases[name]
+    a = lambda key, dt, case=c: np.frombuffer(base64.b64decode(case[key]), dtype=dt)
     k = c["k"]
-    return {"k": k, "target": a("target_f32", np.float32).reshape(-1, 3), "query": a("query_f32", np.float32).reshape(-1, 3), "found": a("found_i32", np.int32),
+    return {"k": k, "target": a("target_f32", np.float32, cases[c.get("target_of", name)]).reshape(-1, 3), "query": a("query_f32", np.float32).reshape(-1, 3), "found": a("found_i32", np.int32),
             "index": a("index_i32", np.int32).reshape(-1, k), "dist2": a("dist2_f32", np.float32).reshape(-1, k)}
 
 
