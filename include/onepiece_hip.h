@@ -394,15 +394,29 @@ int op_icp_destroy(op_icp *icp);
  *       per-iteration inlier counts and the poses then equal the CPU path's at any size and on every frame pair: where
  *       J^T J sits at JacobiSVD's rank threshold the reference's own float32 rounding decides which way its step goes
  *       (its pose moves by up to 5e-2 when the same sums are taken in double), and only this mode follows it there.
- *       ~600 iterations/s at 307 200 points against ~25 000 in the default mode. */
+ *       ~600 iterations/s at 307 200 points against ~25 000 in the default mode.
+ *   OP_ICP_OPT_TIES: which target a source point is paired with when its nearest candidates are EXACTLY equidistant (duplicated
+ *     target points, clouds on a lattice, quantised coordinates; on depth-derived clouds a chance event of ~1e-7 per query).
+ *     OP_ICP_TIES_REFERENCE (default): the target the reference's kd-tree (nanoflann 1.3.2 as Geometry/KDTree.h:62-98,171-190 drives it)
+ *       returns: the candidate its depth-first traversal meets first.  The search marks the tied queries (one compare and one select per
+ *       candidate: +2 % on the point-to-plane loop, +11 % on the point-to-point loop at 307 200 points) and their number comes back with
+ *       the sums; only when a pass has some does the host repeat THEIR search in the tree nanoflann would build (csrc/nn_tree.hpp, ~1 us
+ *       per tied query after a one-off build) and are the sums taken again over the corrected correspondences.  op_icp_tie_stats counts them.
+ *     OP_ICP_TIES_LOWEST_INDEX: the smallest target index among the equidistant ones -- what the grid search yields without the marking. */
 #define OP_ICP_OPT_FINISH 0
 #define OP_ICP_OPT_SUMS 1
+#define OP_ICP_OPT_TIES 2
 #define OP_ICP_FINISH_REFERENCE 0
 #define OP_ICP_FINISH_FP64 1
 #define OP_ICP_SUMS_FP64 0
 #define OP_ICP_SUMS_REFERENCE_F32 1
+#define OP_ICP_TIES_LOWEST_INDEX 0
+#define OP_ICP_TIES_REFERENCE 1
 int op_icp_set_option(op_icp *icp, int option, int value);
 int op_icp_set_source(op_icp *icp, const float *src_xyz, size_t n, int mem);
+/* OP_ICP_TIES_REFERENCE: queries with exactly equidistant nearest candidates seen since op_icp_create (summed over passes), and how many of
+ * them the reference pairs with another target than the smallest index. */
+int op_icp_tie_stats(op_icp *icp, uint64_t *tied_queries, uint64_t *changed);
 /* One loop body of ICP.cpp:177-199 without the solve: transform by T, 1-NN, CountInliers and the
  * normal-equation sums.  mode PLANE: sums[0..35] = JTJ (row-major 6x6), sums[36..41] = JTr.
  * mode POINT: sums[0..2] = sum s', [3..5] = sum t, [6..14] = sum s' t^T (row-major), s' = T*s. */

@@ -63,7 +63,8 @@ OP_RUNTIME_OPT_MERGE_ALGORITHM, OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS, OP_RUNTIME_OP
 OP_MERGE_OWNER_EXCHANGE, OP_MERGE_DENSE_REDUCE = 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1
-OP_ICP_OPT_FINISH, OP_ICP_OPT_SUMS = 0, 1
+OP_ICP_OPT_FINISH, OP_ICP_OPT_SUMS, OP_ICP_OPT_TIES = 0, 1, 2
+OP_ICP_TIES_LOWEST_INDEX, OP_ICP_TIES_REFERENCE = 0, 1
 OP_ICP_FINISH_REFERENCE, OP_ICP_FINISH_FP64 = 0, 1
 OP_ICP_SUMS_FP64, OP_ICP_SUMS_REFERENCE_F32 = 0, 1
 OP_OK, OP_ERR_INVALID = 0, 1
@@ -147,6 +148,7 @@ SIGNATURES = {
     "op_icp_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]),
     "op_icp_destroy": (C.c_int, [_vp]),
     "op_icp_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "op_icp_tie_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "op_icp_set_source": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "op_icp_iterate": (C.c_int, [_vp, _fp, C.c_int, C.POINTER(C.c_double), _u64p,
                                  C.POINTER(C.c_double)]),

@@ -33,6 +33,7 @@
 
 #include "common.hpp"
 #include "host_math.hpp"
+#include "nn_tree.hpp"
 #include "seq_sums.hpp"
 
 namespace {
@@ -203,6 +204,10 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, size_t m, Grid g,
 // MODE 1 (plane): sums[0..20] = upper triangle of JTJ (row-major), [21..26] = JTr.
 // MODE 0 (point): sums[0..2] = sum s', [3..5] = sum t, [6..14] = sum s' t^T.
 // MODE 2 (final): like MODE 0 but over the ORIGINAL source points and the stored nn[] (no search).
+// MODE 3 / 4: MODE 0 / 1 with the stored nn[] instead of the search -- the second pass of an iteration whose exactly equidistant
+//   candidates were re-decided on the host (OP_ICP_TIES_REFERENCE, below).
+// DETECT: the search also reports the queries whose nearest distance is shared by more than one target (tie_list: transformed query +
+//   its index; sums[29] = how many): an extra compare and select per candidate.
 //
 // The kernel also finishes the reduction itself (no second-pass kernels on the per-iteration critical path): every
 // workgroup writes its row of partial sums, the LAST workgroup of each group of `per_group` rows to arrive folds that
@@ -250,13 +255,16 @@ __device__ unsigned long long g_icp_trace[8 * 8192];
 #define ICP_STAMP(K) do { } while (0)
 #endif
 
-template <int MODE>
+template <int MODE, bool DETECT = false>
 __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restrict__ T, Mat4 T_arg, const float* __restrict__ src, unsigned n, Grid g,
                                                            const unsigned* __restrict__ cell_start, const float4* __restrict__ tgt, unsigned dummy,
                                                            const float* __restrict__ tgt_orig, const float* __restrict__ nrm_orig, double thr2,
                                                            int* __restrict__ nn, int* __restrict__ inl, double* __restrict__ partials,
                                                            double* __restrict__ stage, unsigned* __restrict__ sync, unsigned per_group,
-                                                           double* __restrict__ out, double* __restrict__ host_out, double seq) {
+                                                           double* __restrict__ out, double* __restrict__ host_out, double seq,
+                                                           unsigned* __restrict__ tie_count, unsigned tie_base, float4* __restrict__ tie_list) {
+    constexpr bool kPlane = MODE == 1 || MODE == 4;
+    bool tied = false; // DETECT: more than one target at this point's nearest distance
     __shared__ double s_red[kIterThreads / 64][kNSums];
     __shared__ double s_fin[kIterThreads / 32][kNSums];
     __shared__ uint2 s_runs[8][kIterThreads]; // per lane: the [begin, end) runs of the rows it still has to scan
@@ -290,11 +298,15 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             const float q2 = ((M[8] * s0 + M[9] * s1) + M[10] * s2) + M[11] * 1.0f;
             const float q3 = ((M[12] * s0 + M[13] * s1) + M[14] * s2) + M[15] * 1.0f;
             tp0 = q0 / q3; tp1 = q1 / q3; tp2 = q2 / q3;
+          if (MODE >= 3) {
+            best = nn[i]; // decided by an earlier pass (and, for tied queries, by the host)
+          } else {
             // exact 1-NN restricted to the 27 cells around the query (see header comment).  The running best is ONE
             // 64-bit key (bits of the squared distance, original index): the distance is never negative, so its bit
             // pattern orders like the value, and "nearer, ties to the smaller original index" is an unsigned minimum --
             // the visiting order does not matter and a candidate costs one 64-bit compare and two selects.
             unsigned long long best_key = kNoKey;
+            unsigned tie_d = 0xffffffffu; // DETECT: bits of the distance at which a second candidate last equalled the running best
 #ifdef ICP_REPEAT // measurement aid (make EXTRA=-DICP_REPEAT=2): the search runs ICP_REPEAT times in ONE launch, the later passes with this launch's L2 content
             for (int rep_ = 0; rep_ < ICP_REPEAT; ++rep_) {
             if (rep_ > 0) { tp0 += best_key == 0x0123456789abcdefull ? 1.0f : 0.0f; best_key = kNoKey; ICP_STAMP(7); } // (depends on the pass before; never true)
@@ -345,6 +357,10 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                         const float d = dx * dx + dyy * dyy + dzz * dzz;
                         const unsigned kd = __float_as_uint(d), ki = __float_as_uint(c.w);
                         const unsigned long long key = ((unsigned long long)kd << 32) | (unsigned long long)ki;
+                        if (DETECT) // every target is visited once, so an equal distance is another target's (the running best only falls: the last such event is the one
+                            tie_d = select_lanes(__builtin_amdgcn_ballot_w64(kd == (unsigned)(best_key >> 32)), tie_d, kd); // at the final distance, if there is one).
+                        // (Measured and not kept: the mark as one bit per lane in a scalar register pair -- one VALU compare, scalar bookkeeping: +6 % instead of
+                        //  +2 %; the mark in bit 31 of the running best's index -- no register of its own, three VALU: +6 %.)
                         const unsigned long long nearer = __builtin_amdgcn_ballot_w64(key < best_key);
                         best_key = ((unsigned long long)select_lanes(nearer, (unsigned)(best_key >> 32), kd) << 32) |
                                    (unsigned long long)select_lanes(nearer, (unsigned)best_key, ki);
@@ -398,13 +414,19 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             ICP_STAMP(3);
             best = best_key != kNoKey ? (int)(unsigned)best_key : -1;
             nn[i] = best;
+            if (DETECT && best >= 0 && tie_d == (unsigned)(best_key >> 32)) {
+                // tie_count only ever grows (no reset between launches: the host keeps the running total, which it learns from sums[29])
+                tied = true;
+                tie_list[atomicAdd(tie_count, 1u) - tie_base] = make_float4(tp0, tp1, tp2, __int_as_float((int)i)); // at most n entries per launch
+            }
+          }
         } else {
             best = nn[i];
         }
         if (best >= 0) {
             const F3 tv = ld_off<F3>(tgt_orig, 12u * (unsigned)best);
             t0 = tv.x; t1 = tv.y; t2 = tv.z;
-            if (MODE == 1) { const F3 nv = ld_off<F3>(nrm_orig, 12u * (unsigned)best); n0 = nv.x; n1 = nv.y; n2 = nv.z; }
+            if (kPlane) { const F3 nv = ld_off<F3>(nrm_orig, 12u * (unsigned)best); n0 = nv.x; n1 = nv.y; n2 = nv.z; }
             // CountInliers (ICP.cpp:15-23): ||(R s + t) - target||^2 in float, compared in double
             const float d0 = (sum3(M[0] * s0, M[1] * s1, M[2] * s2) + M[3]) - t0;
             const float d1 = (sum3(M[4] * s0, M[5] * s1, M[6] * s2) + M[7]) - t1;
@@ -420,10 +442,11 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
     double acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if (DETECT && tied) acc[29] = 1.0; // the number of reported queries travels with the sums
     if (inlier) {
         acc[27] = e;
         acc[28] = 1.0;
-        if (MODE == 1) {
+        if (kPlane) {
             // ICP.cpp:121-136: row = [n ; s' x n], r = n.s' - n.t
             const float r = sum3(n0 * a0, n1 * a1, n2 * a2) - sum3(n0 * t0, n1 * t1, n2 * t2);
             const float row[6] = {n0, n1, n2, a1 * n2 - a2 * n1, a2 * n0 - a0 * n2, a0 * n1 - a1 * n0};
@@ -822,6 +845,12 @@ int device_exclusive_scan(const unsigned* d_count, size_t n, unsigned* d_start, 
     return OP_OK;
 }
 
+// nn[source] = target for the queries the host re-decided
+__global__ __launch_bounds__(256) void k_patch_nn(const int2* __restrict__ patch, unsigned n, int* __restrict__ nn) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k < n) nn[patch[k].x] = patch[k].y;
+}
+
 } // namespace
 
 struct op_icp {
@@ -859,6 +888,16 @@ struct op_icp {
     int seq_ok = -1;                 // -1: not asked yet
     // op_icp_run_enqueue / op_icp_wait: the loop needs the host after every iteration (the 6x6 solve), so an enqueued run proceeds on a host
     // thread of the context's own -- K contexts (each with its stream) register K frame pairs side by side: ICP's only parallel axis (replicas)
+    // OP_ICP_TIES_REFERENCE (default): queries whose nearest candidates are exactly equidistant are re-decided on the host in the tree the reference would build
+    int ties = OP_ICP_TIES_REFERENCE;
+    unsigned* tie_count = nullptr;      // device: grows by one per reported query, never reset between launches
+    unsigned tie_total = 0;             // its value once the launches issued so far have run (the host adds sums[29] of every pass)
+    float4* tie_list = nullptr;         // device, src_cap entries: transformed query, source index
+    int2* tie_patch = nullptr;          // device, src_cap entries: (source index, target index)
+    size_t tie_cap = 0;
+    std::vector<float> tgt_host;        // the target in original order (downloaded when the first tie shows up)
+    op_host::NanoTree tie_tree;
+    uint64_t tie_queries = 0, tie_changed = 0; // since the context was created
     std::thread worker;
     bool worker_active = false;
     int worker_rc = OP_OK;
@@ -868,15 +907,15 @@ struct op_icp {
 namespace {
 
 // one fused pass (transform + NN + inliers + sums + reduction); start_T is read from c->T_dev unless host_T is given.
-template <int MODE>
+template <int MODE, bool DETECT = false>
 void launch_pass(op_icp* c, bool write_inl, const float* host_T = nullptr, double seq = 0.0) {
     Mat4 Tv;
     if (host_T) std::memcpy(Tv.m, host_T, sizeof(Tv.m)); else std::memset(Tv.m, 0, sizeof(Tv.m));
     const unsigned per_group = (unsigned)((c->n_wg + kGroups - 1) / kGroups);
-    hipLaunchKernelGGL(k_icp_iter<MODE>, dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
+    hipLaunchKernelGGL((k_icp_iter<MODE, DETECT>), dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
                        (const float*)c->src, (unsigned)c->n, c->grid, (const unsigned*)c->cell_start, (const float4*)c->tgt, (unsigned)c->m,
                        (const float*)c->tgt_orig, (const float*)c->nrm_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials,
-                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq);
+                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq, c->tie_count, c->tie_total, c->tie_list);
 }
 
 // Waits for the rows of sums the launch with sequence number c->seq publishes (one per group of workgroups, in
@@ -901,19 +940,92 @@ int wait_rows(op_icp* c, double r[kNSums]) {
 }
 
 int enqueue_pass(op_icp* c, int mode, bool write_inl) {
-    if (mode == 1) launch_pass<1>(c, write_inl);
-    else if (mode == 0) launch_pass<0>(c, write_inl);
+    const bool detect = c->ties == OP_ICP_TIES_REFERENCE;
+    if (mode == 1) { if (detect) launch_pass<1, true>(c, write_inl); else launch_pass<1>(c, write_inl); }
+    else if (mode == 0) { if (detect) launch_pass<0, true>(c, write_inl); else launch_pass<0>(c, write_inl); }
     else launch_pass<2>(c, write_inl);
     OP_HIP(hipGetLastError());
     return OP_OK;
 }
 
 // host-synchronous single pass with an explicit T (op_icp_iterate)
+int ensure_tie_buffers(op_icp* c);
+int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]);
 int run_pass(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]) {
+    const bool detect = c->ties == OP_ICP_TIES_REFERENCE && mode < 2;
+    if (detect) OP_TRY(ensure_tie_buffers(c));
     OP_HIP(hipMemcpyAsync(c->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     OP_TRY(enqueue_pass(c, mode, write_inl));
     OP_HIP(hipMemcpyAsync(out, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     OP_HIP(hipStreamSynchronize(c->stream));
+    if (detect) OP_TRY(resolve_ties(c, mode, T, write_inl, out));
+    return OP_OK;
+}
+
+// OP_ICP_TIES_REFERENCE.  The search kernels (DETECT) report the queries whose nearest distance more than one target has; there are
+// none on depth-derived clouds, and then this costs the extra compare per candidate and nothing else -- the count comes back with the
+// sums.  When a pass reports some, resolve_ties repeats THEIR search on the host in the tree nanoflann would build (nn_tree.hpp: the
+// first candidate its traversal meets wins), writes the partners back and takes the sums again over the stored correspondences
+// (MODE 3 / 4).  T = the pose of the pass; `out` = the sums of the pass on entry, of the corrected correspondences on return.
+int ensure_tie_buffers(op_icp* c) {
+    if (c->tie_cap >= c->src_cap && c->tie_count) return OP_OK;
+    if (c->tie_list) op::cached_free(c->tie_list);
+    if (c->tie_patch) op::cached_free(c->tie_patch);
+    c->tie_list = nullptr; c->tie_patch = nullptr; c->tie_cap = 0;
+    if (!c->tie_count) {
+        OP_HIP(op::cached_malloc((void**)&c->tie_count, sizeof(unsigned)));
+        OP_HIP(hipMemsetAsync(c->tie_count, 0, sizeof(unsigned), c->stream));
+        c->tie_total = 0;
+    }
+    OP_HIP(op::cached_malloc((void**)&c->tie_list, std::max<size_t>(c->src_cap, 1) * sizeof(float4)));
+    OP_HIP(op::cached_malloc((void**)&c->tie_patch, std::max<size_t>(c->src_cap, 1) * sizeof(int2)));
+    c->tie_cap = c->src_cap;
+    return OP_OK;
+}
+
+int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]) {
+    const unsigned n_tied = (unsigned)(out[29] + 0.5);
+    c->tie_total += n_tied; // what the device counter now reads
+    if (!n_tied) return OP_OK;
+    OP_HIP(hipStreamSynchronize(c->stream)); // the sums were read from published rows: let the launch retire before its list is copied
+    if (!c->tie_tree.built()) {
+        c->tgt_host.resize(c->m * 3);
+        OP_HIP(hipMemcpy(c->tgt_host.data(), c->tgt_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        c->tie_tree.build(c->tgt_host.data(), c->m);
+    }
+    std::vector<float4> tied(n_tied);
+    std::vector<int> nn_dev(c->n);
+    OP_HIP(hipMemcpy(tied.data(), c->tie_list, (size_t)n_tied * sizeof(float4), hipMemcpyDeviceToHost));
+    OP_HIP(hipMemcpy(nn_dev.data(), c->nn, c->n * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int2> patch(n_tied);
+    auto decide = [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) {
+            const float q[3] = {tied[k].x, tied[k].y, tied[k].z};
+            int src_id;
+            std::memcpy(&src_id, &tied[k].w, sizeof(int));
+            patch[k] = make_int2(src_id, c->tie_tree.nearest(q));
+        }
+    };
+    const unsigned n_threads = n_tied >= 8192 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (n_threads > 1) { // a lattice ties every query: a few host threads share the searches (the tree is read-only)
+        std::vector<std::thread> pool;
+        const size_t per = ((size_t)n_tied + n_threads - 1) / n_threads;
+        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(decide, std::min<size_t>(t * per, n_tied), std::min<size_t>((t + 1) * per, n_tied));
+        for (std::thread& th : pool) th.join();
+    } else {
+        decide(0, n_tied);
+    }
+    size_t changed = 0;
+    for (const int2& pr : patch) changed += nn_dev[(size_t)pr.x] != pr.y;
+    c->tie_queries += n_tied; c->tie_changed += changed;
+    if (!changed) return OP_OK; // the smallest index happened to be the first the tree meets: the sums stand
+    OP_HIP(hipMemcpyAsync(c->tie_patch, patch.data(), (size_t)n_tied * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    OP_HIP(hipMemcpyAsync(c->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_patch_nn, dim3((n_tied + 255u) / 256u), dim3(256), 0, c->stream, (const int2*)c->tie_patch, n_tied, c->nn);
+    if (mode == 1) launch_pass<4>(c, write_inl); else launch_pass<3>(c, write_inl);
+    OP_HIP(hipGetLastError());
+    OP_HIP(hipMemcpyAsync(out, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OP_HIP(hipStreamSynchronize(c->stream)); // (also: `patch` is pageable host memory the copy above read from)
     return OP_OK;
 }
 
@@ -1120,6 +1232,9 @@ int op_icp_destroy(op_icp* c) {
     if (c->seq_out) op::cached_free(c->seq_out);
     if (c->seq_total) op::cached_free(c->seq_total);
     if (c->seq_host) op::cached_free(c->seq_host);
+    if (c->tie_count) op::cached_free(c->tie_count);
+    if (c->tie_list) op::cached_free(c->tie_list);
+    if (c->tie_patch) op::cached_free(c->tie_patch);
     op::release_stream(c->stream, c->device);
     delete c;
     return OP_OK;
@@ -1134,7 +1249,15 @@ int op_icp_set_option(op_icp* c, int option, int value) {
     if (!c) return fail(OP_ERR_INVALID, "null icp");
     if (option == OP_ICP_OPT_FINISH && (value == OP_ICP_FINISH_REFERENCE || value == OP_ICP_FINISH_FP64)) { c->finish = value; return OP_OK; }
     if (option == OP_ICP_OPT_SUMS && (value == OP_ICP_SUMS_FP64 || value == OP_ICP_SUMS_REFERENCE_F32)) { c->sums = value; return OP_OK; }
+    if (option == OP_ICP_OPT_TIES && (value == OP_ICP_TIES_LOWEST_INDEX || value == OP_ICP_TIES_REFERENCE)) { c->ties = value; return OP_OK; }
     return fail(OP_ERR_INVALID, "op_icp_set_option: unknown option %d / value %d", option, value);
+}
+
+int op_icp_tie_stats(op_icp* c, uint64_t* tied_queries, uint64_t* changed) {
+    if (!c) return fail(OP_ERR_INVALID, "null icp");
+    if (tied_queries) *tied_queries = c->tie_queries;
+    if (changed) *changed = c->tie_changed;
+    return OP_OK;
 }
 
 int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
@@ -1196,6 +1319,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     double r[kNSums];
     if (max_iteration <= 0 && c->n) OP_HIP(hipMemsetAsync(c->nn, 0xff, c->n * sizeof(int), c->stream)); // corresponding_index stays -1
     OP_HIP(hipMemsetAsync(c->sync, 0, (kGroups + 1) * sizeof(unsigned), c->stream)); // the counters reset themselves; this covers an aborted launch
+    if (c->tie_count) { OP_HIP(hipMemsetAsync(c->tie_count, 0, sizeof(unsigned), c->stream)); c->tie_total = 0; } // likewise
     // ICP.cpp:177-199.  The reduced sums of every iteration come back to the host, which does the 6x6 solve (JacobiSVD
     // semantics incl. its rank threshold -- the synthetic room's JTJ has cond 1.5e8, so the threshold matters) and the SE3
     // exp, or the Kabsch step of PointToPoint, as north_star prescribes.  The round trip is kept short: the pose goes
@@ -1211,7 +1335,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         float cur[16], tmp_T[16];
         std::memcpy(cur, init_T, sizeof(cur));
         for (int it = 0; it < max_iteration; ++it) {
-            OP_TRY(run_pass(c, pass_mode, cur, true, r)); // leaves `cur` in c->T_dev
+            OP_TRY(run_pass(c, pass_mode, cur, true, r)); // leaves `cur` in c->T_dev; with OP_ICP_TIES_REFERENCE, tied queries are re-decided inside
             const size_t n_it = (size_t)(r[28] + 0.5);
             const float* rows = nullptr;
             if (pass_mode == 1 && seq_device_ok(c) && n_it) {
@@ -1252,6 +1376,8 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     } else {
         float cur[16], tmp_T[16];
         std::memcpy(cur, init_T, sizeof(cur));
+        const bool detect = c->ties == OP_ICP_TIES_REFERENCE;
+        if (detect) OP_TRY(ensure_tie_buffers(c));
 #ifdef ICP_TRACE
         double tr_launch = 0, tr_wait = 0, tr_solve = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1261,13 +1387,15 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
 #ifdef ICP_TRACE
             const double ta = now();
 #endif
-            if (pass_mode == 1) launch_pass<1>(c, false, cur, c->seq);
+            if (detect) { if (pass_mode == 1) launch_pass<1, true>(c, false, cur, c->seq); else launch_pass<0, true>(c, false, cur, c->seq); }
+            else if (pass_mode == 1) launch_pass<1>(c, false, cur, c->seq);
             else launch_pass<0>(c, false, cur, c->seq);
             OP_HIP(hipGetLastError());
 #ifdef ICP_TRACE
             const double tb = now();
 #endif
             OP_TRY(wait_rows(c, r));
+            if (detect) OP_TRY(resolve_ties(c, pass_mode, cur, false, r)); // nothing to do unless the pass reported tied queries (r[29])
 #ifdef ICP_TRACE
             const double tc = now();
 #endif

@@ -82,7 +82,7 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def _run(mode, source, target, init_T, icp_para, device, finish="reference", sums="fp64"):
+def _run(mode, source, target, init_T, icp_para, device, finish="reference", sums="fp64", ties="reference"):
     lib = L.load()
     res = RegistrationResult()
     # ICP.cpp:150-163: scaling != 1 or missing normals -> error line, default result
@@ -102,6 +102,7 @@ def _run(mode, source, target, init_T, icp_para, device, finish="reference", sum
     try:
         L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_FINISH, {"reference": L.OP_ICP_FINISH_REFERENCE, "fp64": L.OP_ICP_FINISH_FP64}[finish]))
         L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_SUMS, {"fp64": L.OP_ICP_SUMS_FP64, "reference_f32": L.OP_ICP_SUMS_REFERENCE_F32}[sums]))
+        L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_TIES, {"lowest_index": L.OP_ICP_TIES_LOWEST_INDEX, "reference": L.OP_ICP_TIES_REFERENCE}[ties]))
         L.check(lib.op_icp_set_source(h, C.c_void_p(src.ctypes.data), len(src), L.OP_MEM_HOST))
         out = L.IcpResult()
         iters = max(int(icp_para.max_iteration), 0)
@@ -110,6 +111,9 @@ def _run(mode, source, target, init_T, icp_para, device, finish="reference", sum
         per_T = np.zeros((max(iters, 1), 16), np.float32)
         L.check(lib.op_icp_run(h, mode, _fp(T0), iters, C.byref(out), pairs.ctypes.data_as(C.POINTER(C.c_int32)),
                                len(pairs), per_n.ctypes.data_as(C.POINTER(C.c_int32)), _fp(per_T)))
+        tied, changed = C.c_uint64(0), C.c_uint64(0)
+        L.check(lib.op_icp_tie_stats(h, C.byref(tied), C.byref(changed)))
+        res.tie_stats = (int(tied.value), int(changed.value))   # ties="reference": tied queries over all passes, and how many got another partner
     finally:
         lib.op_icp_destroy(h)
     n = int(out.n_inliers)
@@ -127,16 +131,18 @@ def _run(mode, source, target, init_T, icp_para, device, finish="reference", sum
     return res
 
 
-def PointToPlane(source, target, init_T=None, icp_para=None, device=0, finish="reference", sums="fp64"):
-    """registration::PointToPlane (ICP.cpp:146-224).  finish / sums: op_icp_set_option (include/onepiece_hip.h) --
+def PointToPlane(source, target, init_T=None, icp_para=None, device=0, finish="reference", sums="fp64", ties="reference"):
+    """registration::PointToPlane (ICP.cpp:146-224).  finish / sums / ties: op_icp_set_option (include/onepiece_hip.h) --
     "reference" finish (default) forms RegistrationResult::T with the reference's sequential float32 sums;
-    sums="reference_f32" is the validation mode that also sums every iteration's JTJ/JTr that way."""
-    return _run(L.OP_ICP_POINT_TO_PLANE, source, target, init_T, icp_para or ICPParameter(), device, finish, sums)
+    sums="reference_f32" is the validation mode that also sums every iteration's JTJ/JTr that way;
+    ties="reference" (default) pairs a source point whose nearest targets are exactly equidistant with the one the reference's kd-tree
+    returns, ties="lowest_index" with the smallest index (no marking in the search: 2 % faster)."""
+    return _run(L.OP_ICP_POINT_TO_PLANE, source, target, init_T, icp_para or ICPParameter(), device, finish, sums, ties)
 
 
-def PointToPoint(source, target, init_T=None, icp_para=None, device=0, finish="reference", sums="fp64"):
+def PointToPoint(source, target, init_T=None, icp_para=None, device=0, finish="reference", sums="fp64", ties="reference"):
     """registration::PointToPoint (ICP.cpp:31-107)."""
-    return _run(L.OP_ICP_POINT_TO_POINT, source, target, init_T, icp_para or ICPParameter(), device, finish, sums)
+    return _run(L.OP_ICP_POINT_TO_POINT, source, target, init_T, icp_para or ICPParameter(), device, finish, sums, ties)
 
 
 def Se3ToSE3(x):

@@ -364,3 +364,23 @@ def test_loading_the_library_changes_nothing_in_the_process_environment():
             if f != "volume.hip":
                 hits += ["%s: setenv" % f for _ in re.findall(r"\bsetenv\(", code_only)]
     assert not hits, hits
+
+
+@pytest.mark.parametrize("name", ["uniform_1nn", "surface_1nn", "lattice_ties_1nn", "quantised_1nn"])
+def test_host_tie_tree_equals_the_real_nanoflann(name, tmp_path):
+    """onepiece_amd/csrc/nn_tree.hpp -- the host-side search the ICP path falls back to for queries with exactly equidistant nearest
+    candidates (OP_ICP_TIES_REFERENCE) -- returns the real nanoflann's index for every query of the fixture, ties included."""
+    import subprocess
+    from helpers import nanoflann_case
+    c = nanoflann_case(name)
+    exe = tmp_path / "nn_tree_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-msse4.2", "-ffp-contract=off", "-I", os.path.join(ROOT, "onepiece_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "nn_tree_check.cpp"), "-o", str(exe)])
+    blob = tmp_path / "case.bin"
+    with open(blob, "wb") as f:
+        f.write(np.array([len(c["target"]), len(c["query"])], np.int32).tobytes())
+        f.write(np.ascontiguousarray(c["target"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(c["query"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(c["index"][:, 0], np.int32).tobytes())
+    run = subprocess.run([str(exe), str(blob)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr

@@ -222,7 +222,7 @@ def test_unstructured_clouds_fuzz(oracle, seed, thr):
     rng = np.random.default_rng(seed)
     m, n = 6000, 4500
     tgt = rng.uniform(-1.0, 1.0, (m, 3)).astype(np.float32) * np.array([1.0, 0.6, 0.3], np.float32)
-    tgt[100:130] = tgt[200:230]                                  # exact duplicates: ties resolved by the lower index
+    tgt[100:130] = tgt[200:230]                                  # exact duplicates: ties go to the point the reference's tree meets first
     nrm = rng.normal(size=(m, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     x = np.array([0.004, -0.003, 0.002, 0.01, -0.008, 0.006], np.float32)
     Tx = oracle.se3_exp(x).astype(np.float64)
@@ -376,7 +376,8 @@ def test_grid_search_equals_the_real_nanoflann(name, thr):
     """The HIP search (uniform grid, 64-bit distance/index keys) against the answers of the reference's vendored nanoflann 1.3.2
     (tests/golden/nanoflann_golden.json, no oracle in between): one iteration from the identity returns the inlier pairs of the raw
     source (ICP.cpp:189-191), which must be nanoflann's nearest neighbour of every query closer than the threshold.  With exactly
-    equidistant candidates nanoflann keeps the one its traversal met first; the HIP search returns the smallest index among them."""
+    equidistant candidates nanoflann keeps the one its traversal met first; so does the default tie rule (the sums below), while
+    ties="lowest_index" returns the smallest index among them (the pair list below)."""
     import ctypes as C
     from onepiece_amd import _lib as L
     c = nanoflann_case(name)
@@ -398,11 +399,10 @@ def test_grid_search_equals_the_real_nanoflann(name, thr):
     assert cnt.value == len(inl)
     assert abs(err.value - d2[inl].sum()) <= 1e-6 * d2[inl].sum()
     assert np.allclose(out[0:3], c["query"][inl].astype(np.float64).sum(0), rtol=0, atol=1e-9 * len(inl))
-    if name != "lattice_ties_1nn":
-        assert np.allclose(out[3:6], c["target"][c["index"][inl, 0]].astype(np.float64).sum(0), rtol=0, atol=1e-9 * len(inl))
-    # (2) the pair list of a one-iteration run: the inlier test of the returned list uses the pose AFTER the update with the
+    assert np.allclose(out[3:6], c["target"][c["index"][inl, 0]].astype(np.float64).sum(0), rtol=0, atol=1e-9 * len(inl))   # (ties: the default rule is the reference's)
+    # (2) the pair list of a one-iteration run with ties="lowest_index" (the search without the tie marking): the inlier test of the returned list uses the pose AFTER the update with the
     # correspondences found BEFORE it (ICP.cpp:96), so membership near the threshold moves -- the partner of a source does not
-    got = R.PointToPoint(R.PointCloud(c["query"]), R.PointCloud(c["target"]), None, R.ICPParameter(1, thr))
+    got = R.PointToPoint(R.PointCloud(c["query"]), R.PointCloud(c["target"]), None, R.ICPParameter(1, thr), ties="lowest_index")
     pairs = got.correspondence_set_index
     assert len(pairs) > 0.5 * len(d2) and np.all(np.diff(pairs[:, 0]) > 0)
     if name != "lattice_ties_1nn":
@@ -448,3 +448,79 @@ def test_normals_from_the_real_nanoflann_neighbour_lists():
             assert abs(float(v[:, 0] @ pc2.normals[i].astype(np.float64))) > 1 - 1e-6
             checked += 1
     assert checked > nq // 3
+
+
+@pytest.mark.parametrize("name,thr", [("lattice_ties_1nn", 0.2), ("quantised_1nn", 0.05), ("uniform_1nn", 0.1)])
+def test_ties_option_pairs_every_query_with_nanoflanns_choice(name, thr):
+    """OP_ICP_TIES_REFERENCE: the search reports the queries whose nearest candidates are exactly equidistant, the host re-decides them in the
+    tree nanoflann would build (csrc/nn_tree.hpp) and the sums are taken again -- the pair list and the sums are then those of the real
+    nanoflann's answers (tests/golden/nanoflann_golden.json), index for index, on the lattice (every query tied), on the quantised
+    sheet (dozens tied) and on a tie-free cloud (nothing reported, nothing changed)."""
+    import ctypes as C
+    from onepiece_amd import _lib as L
+    c = nanoflann_case(name)
+    d2 = c["dist2"][:, 0].astype(np.float64)
+    inl = np.flatnonzero(d2 < thr * thr)
+    assert len(inl) > 0.5 * len(d2) and np.all(np.abs(d2 - thr * thr) > 1e-6 * thr * thr)
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.op_icp_create(C.c_void_p(c["target"].ctypes.data), None, len(c["target"]), C.c_double(thr), L.OP_MEM_HOST, 0, C.byref(h)))
+    try:
+        L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_TIES, L.OP_ICP_TIES_REFERENCE))
+        L.check(lib.op_icp_set_source(h, C.c_void_p(c["query"].ctypes.data), len(c["query"]), L.OP_MEM_HOST))
+        out = np.zeros(42, np.float64); cnt = C.c_uint64(); err = C.c_double()
+        T = np.eye(4, dtype=np.float32)
+        L.check(lib.op_icp_iterate(h, T.ctypes.data_as(C.POINTER(C.c_float)), 0, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(err)))
+        tied, changed = C.c_uint64(), C.c_uint64()
+        L.check(lib.op_icp_tie_stats(h, C.byref(tied), C.byref(changed)))
+    finally:
+        lib.op_icp_destroy(h)
+    assert cnt.value == len(inl)
+    assert np.allclose(out[3:6], c["target"][c["index"][inl, 0]].astype(np.float64).sum(0), rtol=0, atol=1e-9 * len(inl))
+    # how many queries have several targets at the nearest distance, counted independently
+    n_tied = 0
+    for i in range(len(c["query"])):
+        d = squared_distances(c["target"], c["query"][i])
+        n_tied += int(np.sum(d == d.min()) > 1)
+    assert tied.value == n_tied
+    if name == "uniform_1nn":
+        assert tied.value == 0 and changed.value == 0
+    else:
+        assert 0 < changed.value <= tied.value
+    got = R.PointToPoint(R.PointCloud(c["query"]), R.PointCloud(c["target"]), None, R.ICPParameter(1, thr), ties="reference")
+    pairs = got.correspondence_set_index
+    assert len(pairs) > 0.5 * len(d2) and np.array_equal(pairs[:, 1], c["index"][pairs[:, 0], 0])
+    assert got.tie_stats[0] == n_tied
+
+
+@pytest.mark.parametrize("plane", [False, True])
+@pytest.mark.parametrize("sums", ["reference_f32", "fp64"])
+def test_icp_on_a_target_with_duplicated_points_follows_the_reference(oracle, plane, sums):
+    """A target cloud that holds points twice (merged scans) ties every query that lands on such a point, in EVERY iteration.  With
+    ties="reference" the HIP loop follows the oracle (whose search is the nanoflann restatement pinned by the fixture): identical
+    per-iteration inlier counts and pair lists with the reference-order sums, poses within north_star's 1e-4 with the fp64 sums;
+    with the default rule the pair lists differ (which is what the option is for)."""
+    _, src, _ = room_cloud(101, scale=4)
+    _, tgt, nrm = room_cloud(100, scale=4)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(len(tgt), len(tgt) // 3, replace=False)
+    order = rng.permutation(len(tgt) + len(dup))                      # the copies are scattered through the array, not appended
+    tgt2 = np.concatenate([tgt, tgt[dup]])[order].copy()
+    nrm2 = np.concatenate([nrm, nrm[dup]])[order].copy()
+    iters, thr = 8, 0.05
+    ref = oracle.icp(src, tgt2, nrm2 if plane else None, None, iters, thr, point_to_plane=plane)
+    run = R.PointToPlane if plane else R.PointToPoint
+    tp = R.PointCloud(tgt2, nrm2 if plane else None)
+    got = run(R.PointCloud(src), tp, None, R.ICPParameter(iters, thr), sums=sums, ties="reference")
+    assert got.tie_stats[0] > 1000 and got.tie_stats[1] > 100
+    if sums == "reference_f32":
+        assert np.array_equal(got.per_iter_inliers, ref["per_iter_inliers"])
+        assert np.array_equal(got.correspondence_set_index, ref["pairs"])
+        assert rel_err(got.T, ref["T"]) <= 1e-6 and rel_err(got.last_T, ref["last_T"]) <= 1e-6
+    else:
+        assert rel_err(got.last_T, ref["last_T"]) <= POSE_TOL and rel_err(got.T, ref["T"]) <= POSE_TOL
+        assert np.max(np.abs(got.per_iter_inliers.astype(np.int64) - ref["per_iter_inliers"])) <= 1e-4 * len(src)
+    plain = run(R.PointCloud(src), tp, None, R.ICPParameter(iters, thr), sums=sums, ties="lowest_index")
+    assert plain.tie_stats == (0, 0)
+    same = plain.correspondence_set_index.shape == ref["pairs"].shape and np.array_equal(plain.correspondence_set_index, ref["pairs"])
+    assert not same

@@ -147,6 +147,7 @@ int main(int argc, char** argv) {
             const double tn = secs(t0); t0 = std::chrono::steady_clock::now();
             CK(op_icp_create(tgt.data(), nrm.data(), nt, 0.01, OP_MEM_HOST, 0, &icp));
             const double tc = secs(t0); t0 = std::chrono::steady_clock::now();
+            if (const char* e = getenv("PD_ICP_TIES")) CK(op_icp_set_option(icp, OP_ICP_OPT_TIES, atoi(e))); // 1 = OP_ICP_TIES_REFERENCE
             CK(op_icp_set_source(icp, src.data(), ns, OP_MEM_HOST));
             printf("op_estimate_normals %.3f ms, op_icp_create %.3f ms, op_icp_set_source %.3f ms (host arrays, %zu / %zu points)\n", tn * 1e3, tc * 1e3, secs(t0) * 1e3, nt, ns);
         }
