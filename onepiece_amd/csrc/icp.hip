@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                                                            int* __restrict__ nn, int* __restrict__ inl, double* __restrict__ partials,
                                                            double* __restrict__ stage, unsigned* __restrict__ sync, unsigned per_group,
                                                            double* __restrict__ out, double* __restrict__ host_out, double seq,
-                                                           unsigned* __restrict__ tie_count, unsigned tie_base, float4* __restrict__ tie_list) {
+                                                           unsigned* __restrict__ tie_count, unsigned tie_base, float4* __restrict__ tie_list, int* __restrict__ tie_best) {
     constexpr bool kPlane = MODE == 1 || MODE == 4;
     bool tied = false; // DETECT: more than one target at this point's nearest distance
     __shared__ double s_red[kIterThreads / 64][kNSums];
@@ -417,7 +417,9 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             if (DETECT && best >= 0 && tie_d == (unsigned)(best_key >> 32)) {
                 // tie_count only ever grows (no reset between launches: the host keeps the running total, which it learns from sums[29])
                 tied = true;
-                tie_list[atomicAdd(tie_count, 1u) - tie_base] = make_float4(tp0, tp1, tp2, __int_as_float((int)i)); // at most n entries per launch
+                const unsigned slot = atomicAdd(tie_count, 1u) - tie_base; // at most n entries per launch
+                tie_list[slot] = make_float4(tp0, tp1, tp2, __int_as_float((int)i));
+                tie_best[slot] = best;
             }
           }
         } else {
@@ -893,6 +895,7 @@ struct op_icp {
     unsigned* tie_count = nullptr;      // device: grows by one per reported query, never reset between launches
     unsigned tie_total = 0;             // its value once the launches issued so far have run (the host adds sums[29] of every pass)
     float4* tie_list = nullptr;         // device, src_cap entries: transformed query, source index
+    int* tie_best = nullptr;            // device, src_cap entries: the target the search itself picked (smallest index)
     int2* tie_patch = nullptr;          // device, src_cap entries: (source index, target index)
     size_t tie_cap = 0;
     std::vector<float> tgt_host;        // the target in original order (downloaded when the first tie shows up)
@@ -915,7 +918,7 @@ void launch_pass(op_icp* c, bool write_inl, const float* host_T = nullptr, doubl
     hipLaunchKernelGGL((k_icp_iter<MODE, DETECT>), dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
                        (const float*)c->src, (unsigned)c->n, c->grid, (const unsigned*)c->cell_start, (const float4*)c->tgt, (unsigned)c->m,
                        (const float*)c->tgt_orig, (const float*)c->nrm_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials,
-                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq, c->tie_count, c->tie_total, c->tie_list);
+                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq, c->tie_count, c->tie_total, c->tie_list, c->tie_best);
 }
 
 // Waits for the rows of sums the launch with sequence number c->seq publishes (one per group of workgroups, in
@@ -971,7 +974,8 @@ int ensure_tie_buffers(op_icp* c) {
     if (c->tie_cap >= c->src_cap && c->tie_count) return OP_OK;
     if (c->tie_list) op::cached_free(c->tie_list);
     if (c->tie_patch) op::cached_free(c->tie_patch);
-    c->tie_list = nullptr; c->tie_patch = nullptr; c->tie_cap = 0;
+    if (c->tie_best) op::cached_free(c->tie_best);
+    c->tie_list = nullptr; c->tie_patch = nullptr; c->tie_best = nullptr; c->tie_cap = 0;
     if (!c->tie_count) {
         OP_HIP(op::cached_malloc((void**)&c->tie_count, sizeof(unsigned)));
         OP_HIP(hipMemsetAsync(c->tie_count, 0, sizeof(unsigned), c->stream));
@@ -979,6 +983,7 @@ int ensure_tie_buffers(op_icp* c) {
     }
     OP_HIP(op::cached_malloc((void**)&c->tie_list, std::max<size_t>(c->src_cap, 1) * sizeof(float4)));
     OP_HIP(op::cached_malloc((void**)&c->tie_patch, std::max<size_t>(c->src_cap, 1) * sizeof(int2)));
+    OP_HIP(op::cached_malloc((void**)&c->tie_best, std::max<size_t>(c->src_cap, 1) * sizeof(int)));
     c->tie_cap = c->src_cap;
     return OP_OK;
 }
@@ -994,9 +999,9 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
         c->tie_tree.build(c->tgt_host.data(), c->m);
     }
     std::vector<float4> tied(n_tied);
-    std::vector<int> nn_dev(c->n);
+    std::vector<int> picked(n_tied);
     OP_HIP(hipMemcpy(tied.data(), c->tie_list, (size_t)n_tied * sizeof(float4), hipMemcpyDeviceToHost));
-    OP_HIP(hipMemcpy(nn_dev.data(), c->nn, c->n * sizeof(int), hipMemcpyDeviceToHost));
+    OP_HIP(hipMemcpy(picked.data(), c->tie_best, (size_t)n_tied * sizeof(int), hipMemcpyDeviceToHost));
     std::vector<int2> patch(n_tied);
     auto decide = [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; ++k) {
@@ -1016,7 +1021,7 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
         decide(0, n_tied);
     }
     size_t changed = 0;
-    for (const int2& pr : patch) changed += nn_dev[(size_t)pr.x] != pr.y;
+    for (size_t k = 0; k < patch.size(); ++k) changed += picked[k] != patch[k].y;
     c->tie_queries += n_tied; c->tie_changed += changed;
     if (!changed) return OP_OK; // the smallest index happened to be the first the tree meets: the sums stand
     OP_HIP(hipMemcpyAsync(c->tie_patch, patch.data(), (size_t)n_tied * sizeof(int2), hipMemcpyHostToDevice, c->stream));
@@ -1235,6 +1240,7 @@ int op_icp_destroy(op_icp* c) {
     if (c->tie_count) op::cached_free(c->tie_count);
     if (c->tie_list) op::cached_free(c->tie_list);
     if (c->tie_patch) op::cached_free(c->tie_patch);
+    if (c->tie_best) op::cached_free(c->tie_best);
     op::release_stream(c->stream, c->device);
     delete c;
     return OP_OK;
