@@ -74,6 +74,18 @@ typedef compat::Mat<unsigned int, 3, 1> Point3ui;
 #define ONEPIECE_ALIGNED_VECTOR(T) std::vector<T>
 #endif
 
+// Geometry.h:55-57,74-76: fixed-size column vector of any length and a list of them
+#ifdef ONEPIECE_HAVE_EIGEN
+template <int T>
+using Vector = Eigen::Matrix<scalar, T, 1>;
+template <int T>
+using PointList = std::vector<Eigen::Matrix<scalar, T, 1>, Eigen::aligned_allocator<Eigen::Matrix<scalar, T, 1> > >;
+#else
+template <int T>
+using Vector = compat::Mat<scalar, T, 1>;
+template <int T>
+using PointList = std::vector<compat::Mat<scalar, T, 1> >;
+#endif
 typedef Matrix4 TransformationMatrix;
 typedef Vector3 Point3;
 typedef Vector2 Point2;

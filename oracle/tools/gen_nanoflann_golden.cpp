@@ -30,6 +30,15 @@ struct Cloud {
 };
 typedef nanoflann::KDTreeSingleIndexAdaptor<nanoflann::L2_Simple_Adaptor<float, Cloud>, Cloud, 3> Tree;
 
+// any dimension (Registration/3DFeature.cpp searches 33-bin histograms with KDTree<33>), and the radius search as KDTree.h:131-146 calls it
+template <int D>
+struct CloudD {
+    std::vector<float> v;
+    inline size_t kdtree_get_point_count() const { return v.size() / D; }
+    inline float kdtree_get_pt(const size_t idx, const size_t dim) const { return v[D * idx + dim]; }
+    template <class BBOX> bool kdtree_get_bbox(BBOX&) const { return false; }
+};
+
 static FILE* out;
 static void b64(const char* name, const void* data, size_t bytes, bool comma = true) {
     static const char* A = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
@@ -66,6 +75,53 @@ static void run_case(const char* name, const char* what, const Cloud& tgt, const
     b64("index_i32", idx.data(), idx.size() * 4);
     b64("dist2_f32", d2.data(), d2.size() * 4, false);
     fprintf(out, "}%s\n", last ? "" : ",");
+}
+
+template <int D>
+static void run_case_d(const char* name, const char* what, const CloudD<D>& tgt, const std::vector<float>& q, int k) {
+    typedef nanoflann::KDTreeSingleIndexAdaptor<nanoflann::L2_Simple_Adaptor<float, CloudD<D> >, CloudD<D>, D> TreeD;
+    TreeD tree(D, tgt, nanoflann::KDTreeSingleIndexAdaptorParams(10));
+    tree.buildIndex();
+    const size_t nq = q.size() / D;
+    std::vector<int32_t> idx(nq * k, -1), cnt(nq);
+    std::vector<float> d2(nq * k, -1.0f);
+    for (size_t i = 0; i < nq; ++i) {
+        std::vector<size_t> id(k);
+        std::vector<float> dd(k);
+        const size_t found = tree.knnSearch(&q[D * i], k, &id[0], &dd[0]);
+        cnt[i] = (int32_t)found;
+        for (size_t j = 0; j < found; ++j) { idx[i * k + j] = (int32_t)id[j]; d2[i * k + j] = dd[j]; }
+    }
+    fprintf(out, "\"%s\": {\"what\": \"%s\", \"dim\": %d, \"k\": %d, \"n_target\": %zu, \"n_query\": %zu, ", name, what, D, k, tgt.v.size() / D, nq);
+    b64("target_f32", tgt.v.data(), tgt.v.size() * 4);
+    b64("query_f32", q.data(), q.size() * 4);
+    b64("found_i32", cnt.data(), cnt.size() * 4);
+    b64("index_i32", idx.data(), idx.size() * 4);
+    b64("dist2_f32", d2.data(), d2.size() * 4, false);
+    fprintf(out, "},\n");
+}
+
+// KDTree::RadiusSearch (KDTree.h:131-146): radiusSearch(point, radius, matches, max_result * 2.5, SearchParams(checks, eps, sorted)), first max_result kept
+static void run_radius(const char* name, const char* what, const Cloud& tgt, const std::vector<float>& q, float radius, size_t max_result, bool sorted, const char* target_of) {
+    Tree tree(3, tgt, nanoflann::KDTreeSingleIndexAdaptorParams(10));
+    tree.buildIndex();
+    const size_t nq = q.size() / 3;
+    std::vector<int32_t> idx(nq * max_result, -1), cnt(nq);
+    std::vector<float> d2(nq * max_result, -1.0f);
+    for (size_t i = 0; i < nq; ++i) {
+        std::vector<std::pair<size_t, float> > ret;
+        size_t n = tree.radiusSearch(&q[3 * i], radius, ret, max_result * 2.5, nanoflann::SearchParams(128, 1e-8f, sorted));
+        if (n > max_result) n = max_result;
+        cnt[i] = (int32_t)n;
+        for (size_t j = 0; j < n; ++j) { idx[i * max_result + j] = (int32_t)ret[j].first; d2[i * max_result + j] = ret[j].second; }
+    }
+    fprintf(out, "\"%s\": {\"what\": \"%s\", \"dim\": 3, \"k\": %zu, \"radius\": %.9g, \"sorted\": %d, \"n_target\": %zu, \"n_query\": %zu, \"target_of\": \"%s\", ", name, what, max_result, radius, (int)sorted,
+            tgt.xyz.size() / 3, nq, target_of);
+    b64("query_f32", q.data(), q.size() * 4);
+    b64("found_i32", cnt.data(), cnt.size() * 4);
+    b64("index_i32", idx.data(), idx.size() * 4);
+    b64("dist2_f32", d2.data(), d2.size() * 4, false);
+    fprintf(out, "},\n");
 }
 
 int main(int argc, char** argv) {
@@ -108,8 +164,8 @@ int main(int argc, char** argv) {
     { // 4. k = 30 with the query a member of the cloud: PointCloud::EstimateNormals' search
         Cloud t; std::vector<float> q;
         for (int i = 0; i < 3000 * 3; ++i) t.xyz.push_back(0.5f * u(g));
-        for (int i = 0; i < 250 * 3; ++i) q.push_back(t.xyz[i]);
-        run_case("uniform_knn30", "3000 uniform points in [-0.5,0.5]^3, queries = its first 250 points, k = 30 (PointCloud.cpp:120)", t, q, 30);
+        for (int i = 0; i < 150 * 3; ++i) q.push_back(t.xyz[i]);
+        run_case("uniform_knn30", "3000 uniform points in [-0.5,0.5]^3, queries = its first 150 points, k = 30 (PointCloud.cpp:120)", t, q, 30);
     }
     { // 5. fewer points than k
         Cloud t; std::vector<float> q;
@@ -125,6 +181,26 @@ int main(int argc, char** argv) {
         run_case("quantised_1nn", "4000 points of a wavy sheet with coordinates rounded to 1/128 (duplicates, equidistant pairs), 1000 queries rounded alike, k = 1", t, q, 1);
         std::vector<float> q2(q.begin(), q.begin() + 3 * 200);
         run_case("quantised_knn30", "the same cloud, 200 of the queries, k = 30", t, q2, 30, false, "quantised_1nn");
+    }
+    { // 5c. the capped radius search of KDTree::RadiusSearch on the quantised sheet (its squared-distance radius, 2.5 x cap, then cut): sorted and in traversal order
+        Cloud t; std::vector<float> q;
+        std::mt19937 g2(20260929 + 7);
+        std::uniform_real_distribution<float> u2(-1.f, 1.f);
+        auto qz = [](float v) { return std::floor(v * 128.0f + 0.5f) / 128.0f; };
+        // (the same generator state as case 5b is not available here: the cloud is regenerated and stored under its own name)
+        for (int i = 0; i < 1500; ++i) { const float x = u2(g2), y = u2(g2); t.xyz.push_back(qz(x)); t.xyz.push_back(qz(y)); t.xyz.push_back(qz(0.3f * std::sin(3.0f * x) * std::cos(2.0f * y))); }
+        for (int i = 0; i < 150; ++i) { const float x = u2(g2), y = u2(g2); q.push_back(qz(x)); q.push_back(qz(y)); q.push_back(qz(0.3f * std::sin(3.0f * x) * std::cos(2.0f * y))); }
+        run_case("radius_cloud_1nn", "1500 points of the wavy sheet rounded to 1/128, 150 queries, k = 1 (holds the cloud of the radius cases)", t, q, 1);
+        run_radius("radius_sorted", "RadiusSearch(radius 0.01 (squared), max_result 20): sorted by distance, at most 50 collected before the cut", t, q, 0.01f, 20, true, "radius_cloud_1nn");
+        run_radius("radius_unsorted", "the same, SearchParameter::sorted = false: traversal order", t, q, 0.01f, 20, false, "radius_cloud_1nn");
+        run_radius("radius_capped", "radius 0.05 (squared), max_result 8: the cap of 20 collected neighbours stops the traversal early", t, q, 0.05f, 8, true, "radius_cloud_1nn");
+    }
+    { // 5d. 33 dimensions with small integer coordinates (FPFH histograms are sums of integer quotients: equal distances are common)
+        CloudD<33> t; std::vector<float> q;
+        std::uniform_int_distribution<int> bin(0, 4);
+        for (int i = 0; i < 250 * 33; ++i) t.v.push_back((float)bin(g));
+        for (int i = 0; i < 60 * 33; ++i) q.push_back((float)bin(g));
+        run_case_d<33>("hist33_knn5", "250 points in 33 dimensions with coordinates in {0..4}, 60 queries, k = 5", t, q, 5);
     }
     { // 6. k = 30 on the lattice: ties inside the result list
         Cloud t; std::vector<float> q;

@@ -100,9 +100,10 @@ def nanoflann_case(name):
     cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nanoflann_golden.json")))
     c = cases[name]
     a = lambda key, dt, case=c: np.frombuffer(base64.b64decode(case[key]), dtype=dt)
-    k = c["k"]
-    return {"k": k, "target": a("target_f32", np.float32, cases[c.get("target_of", name)]).reshape(-1, 3), "query": a("query_f32", np.float32).reshape(-1, 3), "found": a("found_i32", np.int32),
-            "index": a("index_i32", np.int32).reshape(-1, k), "dist2": a("dist2_f32", np.float32).reshape(-1, k)}
+    k, dim = c["k"], c.get("dim", 3)
+    return {"k": k, "dim": dim, "radius": c.get("radius"), "sorted": c.get("sorted", 1),
+            "target": a("target_f32", np.float32, cases[c.get("target_of", name)]).reshape(-1, dim), "query": a("query_f32", np.float32).reshape(-1, dim),
+            "found": a("found_i32", np.int32), "index": a("index_i32", np.int32).reshape(-1, k), "dist2": a("dist2_f32", np.float32).reshape(-1, k)}
 
 
 def squared_distances(target, q):

@@ -384,3 +384,34 @@ def test_host_tie_tree_equals_the_real_nanoflann(name, tmp_path):
         f.write(np.ascontiguousarray(c["index"][:, 0], np.int32).tobytes())
     run = subprocess.run([str(exe), str(blob)], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
+
+
+KD_CASES = ["uniform_1nn", "lattice_ties_1nn", "quantised_1nn", "quantised_knn30", "uniform_knn30", "tiny_knn30", "lattice_knn30", "hist33_knn5",
+            "radius_sorted", "radius_unsorted", "radius_capped"]
+
+
+@pytest.mark.parametrize("eigen", [False, True])
+def test_class_surface_kdtree_equals_the_reference_wrapper_over_nanoflann(eigen, tmp_path):
+    """geometry::KDTree<T> (host/one_piece/Geometry/KDTree.h; reference: src/Geometry/KDTree.h:62-259) -- KnnSearch and RadiusSearch return what
+    the reference's wrapper over the real nanoflann returned for the fixture: indices and squared distances bit for bit, in its order, with
+    exactly equidistant points (lattice, duplicates, quantised coordinates, integer histograms in 33 dimensions), sorted / unsorted and
+    capped radius searches.  With the look-alike matrix types and, where the reference tree is present, with the real Eigen."""
+    import subprocess
+    from helpers import nanoflann_case
+    eig = "/root/reference/3rdparty/Eigen"
+    if eigen and not os.path.isdir(eig):
+        pytest.skip("the reference's vendored Eigen is not on this machine")
+    exe = tmp_path / "kdtree_check"
+    flags = ["-DONEPIECE_HAVE_EIGEN", "-I", eig, "-w"] if eigen else ["-Wall"]
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-msse4.2", "-ffp-contract=off"] + flags + ["-I", os.path.join(ROOT, "host", "one_piece"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "kdtree_check.cpp"), "-o", str(exe)])
+    for name in KD_CASES:
+        c = nanoflann_case(name)
+        blob = tmp_path / (name + ".bin")
+        with open(blob, "wb") as f:
+            f.write(np.array([c["dim"], len(c["target"]), len(c["query"]), c["k"], 0 if c["radius"] is None else 1, c["sorted"]], np.int32).tobytes())
+            f.write(np.array([c["radius"] or 0.0], np.float32).tobytes())
+            for key, dt in (("target", np.float32), ("query", np.float32), ("found", np.int32), ("index", np.int32), ("dist2", np.float32)):
+                f.write(np.ascontiguousarray(c[key], dt).tobytes())
+        run = subprocess.run([str(exe), str(blob)], capture_output=True, text=True)
+        assert run.returncode == 0, name + ": " + run.stdout + run.stderr

@@ -143,7 +143,8 @@ for _name in ("CreateImagePyramid", "CreateImageXYZPyramid", "MultiScaleComputin
 SURFACE = [("Integration/CubeHandler.h", "CubeHandler"), ("Integration/Frustum.h", "Frustum"), ("Integration/Integrator.h", "Integrator"),
            ("Integration/VoxelCube.h", "VoxelCube"), ("Integration/VoxelCube.h", "CubePara"), ("Integration/TSDFVoxel.h", "TSDFVoxel"),
            ("Geometry/PointCloud.h", "PointCloud"), ("Geometry/TriangleMesh.h", "TriangleMesh"), ("Geometry/RGBDFrame.h", "RGBDFrame"),
-           ("Camera/Camera.h", "PinholeCamera"), ("Registration/RegistrationResult.h", "RegistrationResult"), ("Odometry/Odometry.h", "Odometry")]
+           ("Camera/Camera.h", "PinholeCamera"), ("Registration/RegistrationResult.h", "RegistrationResult"), ("Odometry/Odometry.h", "Odometry"),
+           ("Geometry/KDTree.h", "KDTree"), ("Geometry/KDTree.h", "SearchParameter")]
 
 
 @have_ref
