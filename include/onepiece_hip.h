@@ -399,9 +399,12 @@ int op_icp_destroy(op_icp *icp);
  *     target points, clouds on a lattice, quantised coordinates; on depth-derived clouds a chance event of ~1e-7 per query).
  *     OP_ICP_TIES_REFERENCE (default): the target the reference's kd-tree (nanoflann 1.3.2 as Geometry/KDTree.h:62-98,171-190 drives it)
  *       returns: the candidate its depth-first traversal meets first.  The search marks the tied queries (one compare and one select per
- *       candidate: +2 % on the point-to-plane loop, +11 % on the point-to-point loop at 307 200 points) and their number comes back with
- *       the sums; only when a pass has some does the host repeat THEIR search in the tree nanoflann would build (csrc/nn_tree.hpp, ~1 us
- *       per tied query after a one-off build) and are the sums taken again over the corrected correspondences.  op_icp_tie_stats counts them.
+ *       candidate: +2-4 % on the iteration kernel); their number comes back with the sums and their records through host-mapped memory.
+ *       Only for them does the host repeat the search, in the tree nanoflann would build (onepiece_nanotree.hpp; built on the first tie,
+ *       ~1 us per query afterwards), and where the partner changes it exchanges the pair's contribution to the sums (same float
+ *       expressions as the kernel's) and patches the stored correspondence; floods of ties (lattices) and the reference-order summation
+ *       mode take the sums again on the device instead.  Measured at 307 200 points: a depth-derived pair has 0-3 tied queries per
+ *       pass (two float32 squared distances equal in every bit); 60 iterations 2.32 ms against 2.25 ms.  op_icp_tie_stats counts them.
  *     OP_ICP_TIES_LOWEST_INDEX: the smallest target index among the equidistant ones -- what the grid search yields without the marking. */
 #define OP_ICP_OPT_FINISH 0
 #define OP_ICP_OPT_SUMS 1

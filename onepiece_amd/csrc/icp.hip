@@ -23,6 +23,7 @@
 #include <climits>
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -206,7 +207,7 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, size_t m, Grid g,
 // MODE 2 (final): like MODE 0 but over the ORIGINAL source points and the stored nn[] (no search).
 // MODE 3 / 4: MODE 0 / 1 with the stored nn[] instead of the search -- the second pass of an iteration whose exactly equidistant
 //   candidates were re-decided on the host (OP_ICP_TIES_REFERENCE, below).
-// DETECT: the search also reports the queries whose nearest distance is shared by more than one target (tie_list: transformed query +
+// DETECT: the search also reports the queries whose nearest distance is shared by more than one target (TieRec records in host-mapped memory: transformed query, source point,
 //   its index; sums[29] = how many): an extra compare and select per candidate.
 //
 // The kernel also finishes the reduction itself (no second-pass kernels on the per-iteration critical path): every
@@ -217,6 +218,16 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, size_t m, Grid g,
 // order -- three device-memory round trips less on the critical path of every iteration.  Who does the folding depends on timing, what is added in which order does not, so the sums are
 // reproducible bit for bit.  sync[0..kGroups-1] count the arrivals per group, sync[kGroups] the finished groups; the
 // workgroup that completes a count resets it for the next launch.
+// What the search reports about a query whose nearest distance more than one target has (OP_ICP_TIES_REFERENCE).  The records live in
+// host-mapped pinned memory: a pass has a handful at most on depth-derived clouds, and the host needs them right after the sums.
+struct TieRec {
+    float tp[3];        // the transformed query (what the reference hands to its kd-tree)
+    int src;            // source index
+    float s[3];         // the source point itself (CountInliers transforms it again, in its own operand order)
+    int best;           // the target the search picked: the smallest index among the equidistant ones
+    unsigned stamp;     // the launch's tie stamp, stored after everything else has been acknowledged
+    unsigned pad[3];
+};
 constexpr int kGroups = 32;
 constexpr unsigned long long kNoKey = 0x7f7fffff00000000ull; // (FLT_MAX, index 0): no candidate compares below it
 
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                                                            int* __restrict__ nn, int* __restrict__ inl, double* __restrict__ partials,
                                                            double* __restrict__ stage, unsigned* __restrict__ sync, unsigned per_group,
                                                            double* __restrict__ out, double* __restrict__ host_out, double seq,
-                                                           unsigned* __restrict__ tie_count, unsigned tie_base, float4* __restrict__ tie_list, int* __restrict__ tie_best) {
+                                                           unsigned* __restrict__ tie_count, unsigned tie_base, TieRec* __restrict__ tie_rec, unsigned tie_stamp) {
     constexpr bool kPlane = MODE == 1 || MODE == 4;
     bool tied = false; // DETECT: more than one target at this point's nearest distance
     __shared__ double s_red[kIterThreads / 64][kNSums];
@@ -417,9 +428,12 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
             if (DETECT && best >= 0 && tie_d == (unsigned)(best_key >> 32)) {
                 // tie_count only ever grows (no reset between launches: the host keeps the running total, which it learns from sums[29])
                 tied = true;
-                const unsigned slot = atomicAdd(tie_count, 1u) - tie_base; // at most n entries per launch
-                tie_list[slot] = make_float4(tp0, tp1, tp2, __int_as_float((int)i));
-                tie_best[slot] = best;
+                TieRec* rec = tie_rec + (atomicAdd(tie_count, 1u) - tie_base); // at most n records per launch
+                auto put = [](void* p, unsigned v) { __hip_atomic_store(static_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+                put(&rec->tp[0], __float_as_uint(tp0)); put(&rec->tp[1], __float_as_uint(tp1)); put(&rec->tp[2], __float_as_uint(tp2)); put(&rec->src, i);
+                put(&rec->s[0], __float_as_uint(s0)); put(&rec->s[1], __float_as_uint(s1)); put(&rec->s[2], __float_as_uint(s2)); put(&rec->best, (unsigned)best);
+                __builtin_amdgcn_s_waitcnt(0); // the record has arrived before its stamp says so (no fence: that would write the whole L2 back)
+                put(&rec->stamp, tie_stamp);
             }
           }
         } else {
@@ -894,11 +908,13 @@ struct op_icp {
     int ties = OP_ICP_TIES_REFERENCE;
     unsigned* tie_count = nullptr;      // device: grows by one per reported query, never reset between launches
     unsigned tie_total = 0;             // its value once the launches issued so far have run (the host adds sums[29] of every pass)
-    float4* tie_list = nullptr;         // device, src_cap entries: transformed query, source index
-    int* tie_best = nullptr;            // device, src_cap entries: the target the search itself picked (smallest index)
-    int2* tie_patch = nullptr;          // device, src_cap entries: (source index, target index)
+    unsigned tie_stamp = 0;             // stamp of the last search launch (its records carry it)
+    TieRec* tie_rec = nullptr;          // pinned + mapped, src_cap records
+    TieRec* tie_rec_dev = nullptr;      // its device-side address
+    int2* tie_patch = nullptr;          // pinned + mapped, src_cap entries: (source index, target index) for k_patch_nn
+    int2* tie_patch_dev = nullptr;
     size_t tie_cap = 0;
-    std::vector<float> tgt_host;        // the target in original order (downloaded when the first tie shows up)
+    std::vector<float> tgt_host, nrm_host; // the target (and its normals) in original order, downloaded when the first tie shows up
     op_host::NanoTree tie_tree;
     uint64_t tie_queries = 0, tie_changed = 0; // since the context was created
     std::thread worker;
@@ -915,10 +931,11 @@ void launch_pass(op_icp* c, bool write_inl, const float* host_T = nullptr, doubl
     Mat4 Tv;
     if (host_T) std::memcpy(Tv.m, host_T, sizeof(Tv.m)); else std::memset(Tv.m, 0, sizeof(Tv.m));
     const unsigned per_group = (unsigned)((c->n_wg + kGroups - 1) / kGroups);
+    if (DETECT) ++c->tie_stamp;
     hipLaunchKernelGGL((k_icp_iter<MODE, DETECT>), dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
                        (const float*)c->src, (unsigned)c->n, c->grid, (const unsigned*)c->cell_start, (const float4*)c->tgt, (unsigned)c->m,
                        (const float*)c->tgt_orig, (const float*)c->nrm_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials,
-                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq, c->tie_count, c->tie_total, c->tie_list, c->tie_best);
+                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq, c->tie_count, c->tie_total, c->tie_rec_dev, c->tie_stamp);
 }
 
 // Waits for the rows of sums the launch with sequence number c->seq publishes (one per group of workgroups, in
@@ -953,7 +970,7 @@ int enqueue_pass(op_icp* c, int mode, bool write_inl) {
 
 // host-synchronous single pass with an explicit T (op_icp_iterate)
 int ensure_tie_buffers(op_icp* c);
-int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]);
+int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums], bool launch_retired);
 int run_pass(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]) {
     const bool detect = c->ties == OP_ICP_TIES_REFERENCE && mode < 2;
     if (detect) OP_TRY(ensure_tie_buffers(c));
@@ -961,56 +978,89 @@ int run_pass(op_icp* c, int mode, const float T[16], bool write_inl, double out[
     OP_TRY(enqueue_pass(c, mode, write_inl));
     OP_HIP(hipMemcpyAsync(out, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     OP_HIP(hipStreamSynchronize(c->stream));
-    if (detect) OP_TRY(resolve_ties(c, mode, T, write_inl, out));
+    if (detect) OP_TRY(resolve_ties(c, mode, T, write_inl, out, true));
     return OP_OK;
 }
 
-// OP_ICP_TIES_REFERENCE.  The search kernels (DETECT) report the queries whose nearest distance more than one target has; there are
-// none on depth-derived clouds, and then this costs the extra compare per candidate and nothing else -- the count comes back with the
-// sums.  When a pass reports some, resolve_ties repeats THEIR search on the host in the tree nanoflann would build (nn_tree.hpp: the
-// first candidate its traversal meets wins), writes the partners back and takes the sums again over the stored correspondences
-// (MODE 3 / 4).  T = the pose of the pass; `out` = the sums of the pass on entry, of the corrected correspondences on return.
+// OP_ICP_TIES_REFERENCE.  The search kernels (DETECT) report the queries whose nearest distance more than one target has -- a handful per
+// pass on depth-derived clouds (two float32 squared distances that agree in every bit), every query on a lattice.  Their number comes
+// back with the sums (sums[29]), the records through host-mapped memory, so a pass without them costs the marking in the scan and nothing
+// else.  For the reported queries resolve_ties repeats the search on the host in the tree nanoflann would build (nn_tree.hpp: the first
+// candidate its traversal meets wins).  Where the partner changes, the pair's contribution to the sums is exchanged on the host -- the
+// same float expressions as the kernel's, accumulated in fp64 like its sums -- and nn[] is patched by a small kernel behind the pass
+// (only the final pass and the pair list read it).  The reference-order modes (write_inl) and floods of ties take the sums again on the
+// device instead (MODE 3 / 4 over the stored correspondences).  T = the pose of the pass; `out` = its sums, corrected on return.
 int ensure_tie_buffers(op_icp* c) {
     if (c->tie_cap >= c->src_cap && c->tie_count) return OP_OK;
-    if (c->tie_list) op::cached_free(c->tie_list);
+    if (c->tie_rec) op::cached_free(c->tie_rec);
     if (c->tie_patch) op::cached_free(c->tie_patch);
-    if (c->tie_best) op::cached_free(c->tie_best);
-    c->tie_list = nullptr; c->tie_patch = nullptr; c->tie_best = nullptr; c->tie_cap = 0;
+    c->tie_rec = nullptr; c->tie_patch = nullptr; c->tie_cap = 0;
     if (!c->tie_count) {
         OP_HIP(op::cached_malloc((void**)&c->tie_count, sizeof(unsigned)));
         OP_HIP(hipMemsetAsync(c->tie_count, 0, sizeof(unsigned), c->stream));
         c->tie_total = 0;
     }
-    OP_HIP(op::cached_malloc((void**)&c->tie_list, std::max<size_t>(c->src_cap, 1) * sizeof(float4)));
-    OP_HIP(op::cached_malloc((void**)&c->tie_patch, std::max<size_t>(c->src_cap, 1) * sizeof(int2)));
-    OP_HIP(op::cached_malloc((void**)&c->tie_best, std::max<size_t>(c->src_cap, 1) * sizeof(int)));
+    const size_t cap = std::max<size_t>(c->src_cap, 1);
+    OP_HIP(op::cached_host_malloc((void**)&c->tie_rec, cap * sizeof(TieRec)));
+    OP_HIP(op::cached_host_malloc((void**)&c->tie_patch, cap * sizeof(int2)));
+    OP_HIP(hipHostGetDevicePointer((void**)&c->tie_rec_dev, c->tie_rec, 0));
+    OP_HIP(hipHostGetDevicePointer((void**)&c->tie_patch_dev, c->tie_patch, 0));
+    for (size_t k = 0; k < cap; ++k) c->tie_rec[k].stamp = 0xffffffffu; // (a recycled buffer may hold any stamp)
     c->tie_cap = c->src_cap;
     return OP_OK;
 }
 
-int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]) {
+// what the pair (source point s with transformed position a, target t with normal n) adds to the sums of k_icp_iter<0 / 1>: the kernel's expressions
+inline float h_sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+void pair_contribution(int mode, const float M[16], const float s[3], const float a[3], const float t[3], const float* n, double thr2, double acc[kNSums]) {
+    for (int k = 0; k < kNSums; ++k) acc[k] = 0.0;
+    const float d0 = (h_sum3(M[0] * s[0], M[1] * s[1], M[2] * s[2]) + M[3]) - t[0];
+    const float d1 = (h_sum3(M[4] * s[0], M[5] * s[1], M[6] * s[2]) + M[7]) - t[1];
+    const float d2 = (h_sum3(M[8] * s[0], M[9] * s[1], M[10] * s[2]) + M[11]) - t[2];
+    const double e = (double)h_sum3(d0 * d0, d1 * d1, d2 * d2);
+    if (!(e < thr2)) return;
+    acc[27] = e; acc[28] = 1.0;
+    if (mode == 1) {
+        const float r = h_sum3(n[0] * a[0], n[1] * a[1], n[2] * a[2]) - h_sum3(n[0] * t[0], n[1] * t[1], n[2] * t[2]);
+        const float row[6] = {n[0], n[1], n[2], a[1] * n[2] - a[2] * n[1], a[2] * n[0] - a[0] * n[2], a[0] * n[1] - a[1] * n[0]};
+        int k = 0;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p; q < 6; ++q) acc[k++] = (double)(row[p] * row[q]);
+        for (int p = 0; p < 6; ++p) acc[21 + p] = (double)(r * row[p]);
+    } else {
+        for (int p = 0; p < 3; ++p) { acc[p] = a[p]; acc[3 + p] = t[p]; }
+        for (int p = 0; p < 3; ++p)
+            for (int q = 0; q < 3; ++q) acc[6 + 3 * p + q] = (double)a[p] * t[q];
+    }
+}
+
+int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums], bool launch_retired) {
     const unsigned n_tied = (unsigned)(out[29] + 0.5);
     c->tie_total += n_tied; // what the device counter now reads
     if (!n_tied) return OP_OK;
-    OP_HIP(hipStreamSynchronize(c->stream)); // the sums were read from published rows: let the launch retire before its list is copied
+    if (n_tied > c->tie_cap) return fail(OP_ERR_HIP, "icp: the search reported %u tied queries for %zu source points", n_tied, c->n);
+    if (!launch_retired) { // the sums were read from published rows: every record carries the launch's stamp once it has arrived
+        volatile TieRec* rec = c->tie_rec;
+        bool synced = false;
+        for (unsigned k = 0; k < n_tied && !synced; ++k)
+            for (unsigned spin = 0; rec[k].stamp != c->tie_stamp; ++spin) {
+                if ((spin & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) { OP_HIP(hipStreamSynchronize(c->stream)); synced = true; break; }
+                __builtin_ia32_pause();
+            }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     if (!c->tie_tree.built()) {
         c->tgt_host.resize(c->m * 3);
         OP_HIP(hipMemcpy(c->tgt_host.data(), c->tgt_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
         c->tie_tree.build(c->tgt_host.data(), c->m);
     }
-    std::vector<float4> tied(n_tied);
-    std::vector<int> picked(n_tied);
-    OP_HIP(hipMemcpy(tied.data(), c->tie_list, (size_t)n_tied * sizeof(float4), hipMemcpyDeviceToHost));
-    OP_HIP(hipMemcpy(picked.data(), c->tie_best, (size_t)n_tied * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<int2> patch(n_tied);
-    auto decide = [&](size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; ++k) {
-            const float q[3] = {tied[k].x, tied[k].y, tied[k].z};
-            int src_id;
-            std::memcpy(&src_id, &tied[k].w, sizeof(int));
-            patch[k] = make_int2(src_id, c->tie_tree.nearest(q));
-        }
-    };
+    if (mode == 1 && c->nrm_host.empty() && c->m) {
+        c->nrm_host.resize(c->m * 3);
+        OP_HIP(hipMemcpy(c->nrm_host.data(), c->nrm_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    const TieRec* rec = c->tie_rec;
+    std::vector<int> partner(n_tied);
+    auto decide = [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) partner[k] = c->tie_tree.nearest(rec[k].tp); };
     const unsigned n_threads = n_tied >= 8192 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
     if (n_threads > 1) { // a lattice ties every query: a few host threads share the searches (the tree is read-only)
         std::vector<std::thread> pool;
@@ -1021,16 +1071,31 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
         decide(0, n_tied);
     }
     size_t changed = 0;
-    for (size_t k = 0; k < patch.size(); ++k) changed += picked[k] != patch[k].y;
+    for (unsigned k = 0; k < n_tied; ++k)
+        if (partner[k] != rec[k].best) c->tie_patch[changed++] = make_int2(rec[k].src, partner[k]);
     c->tie_queries += n_tied; c->tie_changed += changed;
     if (!changed) return OP_OK; // the smallest index happened to be the first the tree meets: the sums stand
-    OP_HIP(hipMemcpyAsync(c->tie_patch, patch.data(), (size_t)n_tied * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    // nn[] follows in stream order (tie_patch is not written again before the next pass's sums have come back, i.e. after this kernel ran)
+    hipLaunchKernelGGL(k_patch_nn, dim3(((unsigned)changed + 255u) / 256u), dim3(256), 0, c->stream, (const int2*)c->tie_patch_dev, (unsigned)changed, c->nn);
+    OP_HIP(hipGetLastError());
+    if (!write_inl && changed <= 4096) {
+        const double thr2 = c->threshold * c->threshold;
+        double was[kNSums], is[kNSums];
+        for (unsigned k = 0; k < n_tied; ++k) {
+            if (partner[k] == rec[k].best) continue;
+            const float* n_old = mode == 1 ? &c->nrm_host[3 * (size_t)rec[k].best] : nullptr;
+            const float* n_new = mode == 1 ? &c->nrm_host[3 * (size_t)partner[k]] : nullptr;
+            pair_contribution(mode, T, rec[k].s, rec[k].tp, &c->tgt_host[3 * (size_t)rec[k].best], n_old, thr2, was);
+            pair_contribution(mode, T, rec[k].s, rec[k].tp, &c->tgt_host[3 * (size_t)partner[k]], n_new, thr2, is);
+            for (int q = 0; q < 29; ++q) out[q] += is[q] - was[q];
+        }
+        return OP_OK;
+    }
     OP_HIP(hipMemcpyAsync(c->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_patch_nn, dim3((n_tied + 255u) / 256u), dim3(256), 0, c->stream, (const int2*)c->tie_patch, n_tied, c->nn);
     if (mode == 1) launch_pass<4>(c, write_inl); else launch_pass<3>(c, write_inl);
     OP_HIP(hipGetLastError());
     OP_HIP(hipMemcpyAsync(out, c->result, kNSums * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    OP_HIP(hipStreamSynchronize(c->stream)); // (also: `patch` is pageable host memory the copy above read from)
+    OP_HIP(hipStreamSynchronize(c->stream));
     return OP_OK;
 }
 
@@ -1238,9 +1303,8 @@ int op_icp_destroy(op_icp* c) {
     if (c->seq_total) op::cached_free(c->seq_total);
     if (c->seq_host) op::cached_free(c->seq_host);
     if (c->tie_count) op::cached_free(c->tie_count);
-    if (c->tie_list) op::cached_free(c->tie_list);
+    if (c->tie_rec) op::cached_free(c->tie_rec);
     if (c->tie_patch) op::cached_free(c->tie_patch);
-    if (c->tie_best) op::cached_free(c->tie_best);
     op::release_stream(c->stream, c->device);
     delete c;
     return OP_OK;
@@ -1401,7 +1465,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             const double tb = now();
 #endif
             OP_TRY(wait_rows(c, r));
-            if (detect) OP_TRY(resolve_ties(c, pass_mode, cur, false, r)); // nothing to do unless the pass reported tied queries (r[29])
+            if (detect) OP_TRY(resolve_ties(c, pass_mode, cur, false, r, false)); // nothing to do unless the pass reported tied queries (r[29])
 #ifdef ICP_TRACE
             const double tc = now();
 #endif
