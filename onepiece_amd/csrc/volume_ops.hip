@@ -226,7 +226,7 @@ __device__ __forceinline__ Vox5 load_voxel(const VolView& S, int idx, int px, in
 }
 template <bool NEAREST>
 __global__ __launch_bounds__(512) void k_transform_fill(VolView S, VolView D, Mat4 Tinv, float src_res) {
-    __shared__ int s_red[16];
+    __shared__ int s_red3[3][16];
     __shared__ int s_slot[kSrcBox];
     const int b = blockIdx.x, vid = threadIdx.x;
     const int kx = D.keys[3 * b], ky = D.keys[3 * b + 1], kz = D.keys[3 * b + 2];
@@ -245,10 +245,26 @@ __global__ __launch_bounds__(512) void k_transform_fill(VolView S, VolView D, Ma
     // the source blocks this workgroup's taps touch (taps at p and p + 1; the nearest form has ONE tap per voxel and probes directly: measured, the
     // box costs it more than it saves).  An int overflow of p + 1 only ever widens the box: fallback.
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
-    if (!NEAREST) {
-        wg_min_max(p0 >> 3, (int)(((long long)p0 + 1) >> 3), s_red, &x0, &x1);
-        wg_min_max(p1 >> 3, (int)(((long long)p1 + 1) >> 3), s_red, &y0, &y1);
-        wg_min_max(p2 >> 3, (int)(((long long)p2 + 1) >> 3), s_red, &z0, &z1);
+    if (!NEAREST) { // the three axes in ONE pass over the workgroup (two barriers instead of six)
+        int lo[3] = {p0 >> 3, p1 >> 3, p2 >> 3};
+        int hi[3] = {(int)(((long long)p0 + 1) >> 3), (int)(((long long)p1 + 1) >> 3), (int)(((long long)p2 + 1) >> 3)};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = max(hi[a], __shfl_xor(hi[a], o, 64)); }
+        const int wave = vid >> 6;
+        if ((vid & 63) == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { s_red3[a][wave] = lo[a]; s_red3[a][8 + wave] = hi[a]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int l = s_red3[a][0], h = s_red3[a][8];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { l = min(l, s_red3[a][k]); h = max(h, s_red3[a][8 + k]); }
+            lo[a] = l; hi[a] = h;
+        }
+        x0 = lo[0]; x1 = hi[0]; y0 = lo[1]; y1 = hi[1]; z0 = lo[2]; z1 = hi[2];
     }
     const long long ex = (long long)x1 - x0 + 1, ey = (long long)y1 - y0 + 1, ez = (long long)z1 - z0 + 1;
     const bool boxed = !NEAREST && ex * ey <= kSrcBox && ex * ey * ez <= kSrcBox; // (uniform)
