@@ -294,6 +294,68 @@ __global__ __launch_bounds__(512) void k_transform_fill(VolView S, VolView D, Ma
     t[0] = r.s; t[kVox] = r.w; t[2 * kVox] = r.c0; t[3 * kVox] = r.c1; t[4 * kVox] = r.c2;
 }
 
+// The trilinear form as ONE WAVE per result block (eight z-slices of 64 voxels in turn).  The 512-thread form above is a chain of dependent
+// phases -- key, positions, box reduction, hash probes, taps, stores -- with workgroup barriers between them and only four workgroups per CU to
+// overlap one block's waiting with another's work (measured: neither staging the tap box in LDS nor halving the number of tap loads moved it).
+// A wave needs no barriers: the box is a shuffle reduction, the probed slots sit in the wave's own 64 LDS words, and 32 independent blocks are in
+// flight per CU.  Same positions, same taps, same arithmetic as the form above.  2.82 -> 2.61 ms on the 164 k-block room volume.
+// (Also measured, on top of this form, and not kept: the result blocks in Morton order of their keys with one compact region per XCD -- the kernel
+// fetches 5.8 GB for a 1.7 GB source at 40 % L2 hits, so locality looked like the lever -- 2.69 ms, and 1.39 against 1.20 ms for the nearest form.)
+__global__ __launch_bounds__(64) void k_transform_fill_wave(VolView S, VolView D, Mat4 Tinv, float src_res) {
+    __shared__ int s_slot[kSrcBox];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int kx = D.keys[3 * b], ky = D.keys[3 * b + 1], kz = D.keys[3 * b + 2];
+    const float half = src_res / 2;
+    const float* M = Tinv.m;
+    float n0[8], n1[8], n2[8];
+    int p0[8], p1[8], p2[8];
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll
+    for (int zs = 0; zs < 8; ++zs) {
+        const int vid = lane + 64 * zs;
+        const float px = ((float)kx * 8.0f) * src_res + ((float)(vid & 7) * src_res + half);
+        const float py = ((float)ky * 8.0f) * src_res + ((float)((vid >> 3) & 7) * src_res + half);
+        const float pz = ((float)kz * 8.0f) * src_res + ((float)(vid >> 6) * src_res + half);
+        const float q0 = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3] * 1.0f;
+        const float q1 = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7] * 1.0f;
+        const float q2 = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11] * 1.0f;
+        const float q3 = ((M[12] * px + M[13] * py) + M[14] * pz) + M[15] * 1.0f;
+        n0[zs] = q0 / q3 - half; n1[zs] = q1 / q3 - half; n2[zs] = q2 / q3 - half;
+        p0[zs] = (int)floorf(n0[zs] / src_res); p1[zs] = (int)floorf(n1[zs] / src_res); p2[zs] = (int)floorf(n2[zs] / src_res);
+        lo[0] = min(lo[0], p0[zs] >> 3); hi[0] = max(hi[0], (int)(((long long)p0[zs] + 1) >> 3));
+        lo[1] = min(lo[1], p1[zs] >> 3); hi[1] = max(hi[1], (int)(((long long)p1[zs] + 1) >> 3));
+        lo[2] = min(lo[2], p2[zs] >> 3); hi[2] = max(hi[2], (int)(((long long)p2[zs] + 1) >> 3));
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = max(hi[a], __shfl_xor(hi[a], o, 64)); }
+    const int x0 = lo[0], y0 = lo[1], z0 = lo[2];
+    const long long ex = (long long)hi[0] - x0 + 1, ey = (long long)hi[1] - y0 + 1, ez = (long long)hi[2] - z0 + 1;
+    const bool boxed = ex * ey <= kSrcBox && ex * ey * ez <= kSrcBox; // (uniform)
+    if (boxed) {
+        if (lane < (int)(ex * ey * ez)) s_slot[lane] = table_find(S, x0 + lane % (int)ex, y0 + (lane / (int)ex) % (int)ey, z0 + lane / (int)(ex * ey));
+        __syncthreads(); // (one wave: orders the LDS writes before the reads below)
+    }
+    auto fetch = [&](int tx, int ty, int tz) -> Vox5 {
+        if (!boxed) return fetch_voxel(S, tx, ty, tz);
+        return load_voxel(S, s_slot[((tx >> 3) - x0) + (int)ex * (((ty >> 3) - y0) + (int)ey * ((tz >> 3) - z0))], tx, ty, tz);
+    };
+#pragma unroll 2
+    for (int zs = 0; zs < 8; ++zs) {
+        Vox5 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fetch(p0[zs] + (k & 1), p1[zs] + ((k >> 1) & 1), p2[zs] + ((k >> 2) & 1));
+        // ReadVoxelInterpolate (VoxelCube.cpp:6-50)
+        const float xw = (n0[zs] - (float)p0[zs] * src_res) / src_res, yw = (n1[zs] - (float)p1[zs] * src_res) / src_res,
+                    zw = (n2[zs] - (float)p2[zs] * src_res) / src_res;
+        const Vox5 z1v = interp_stage(interp_stage(v[0], v[1], xw), interp_stage(v[2], v[3], xw), yw);
+        const Vox5 z2v = interp_stage(interp_stage(v[4], v[5], xw), interp_stage(v[6], v[7], xw), yw);
+        const Vox5 r = interp_stage(z1v, z2v, zw);
+        float* t = D.pool + (size_t)b * kBlockFloats + (lane + 64 * zs);
+        t[0] = r.s; t[kVox] = r.w; t[2 * kVox] = r.c0; t[3 * kVox] = r.c1; t[4 * kVox] = r.c2;
+    }
+}
+
 // GetPointCloud: voxels with weight != 0 and |sdf| < truncation, in the reference's x,y,z loop order
 // inside a block.  counts == nullptr: emit using offsets; else count only.
 __global__ __launch_bounds__(512) void k_point_cloud(VolView V, float res, float trunc, unsigned* __restrict__ counts,
@@ -677,7 +739,7 @@ int op_volume_transform(op_volume* src, const float T[16], const float* T_inv, i
         }
         if (rc == OP_OK && nd) {
             if (nearest) hipLaunchKernelGGL(k_transform_fill<true>, dim3(nd), dim3(512), 0, dst->stream, src->view(), dst->view(), Mi, src->res);
-            else hipLaunchKernelGGL(k_transform_fill<false>, dim3(nd), dim3(512), 0, dst->stream, src->view(), dst->view(), Mi, src->res);
+            else hipLaunchKernelGGL(k_transform_fill_wave, dim3(nd), dim3(64), 0, dst->stream, src->view(), dst->view(), Mi, src->res);
             rc = vol_check(dst);
         }
     }
