@@ -75,9 +75,10 @@ def run(c, out):
                             "[+ per triangle, in the emit pass: 72 B of colour gathers and 72 B written, halved over the two passes]",
                             "the +x/+y/+z layers of the 7 neighbour blocks are re-reads that mostly hit in L2; 3.3 ms per pass before round 5 (every voxel loaded 8 corners x 5 planes)")
         if t_out:
-            res["transform"] = entry("k_transform_fill<false>", 10240.0 * (t_out + blocks), "10 KB written per result block + every source block read at least once",
-                                     "eight trilinear taps x five planes per voxel: a gather kernel (40 scattered 4-byte loads per voxel), not a streaming one; the source "
-                                     "blocks of a result block are looked up once per workgroup since round 5 (4.8 -> 2.9 ms on the 164 k-block volume)")
+            res["transform"] = entry("k_transform_fill_wave", 10240.0 * (t_out + blocks), "10 KB written per result block + every source block read at least once",
+                                     "eight trilinear taps x five planes per voxel: a gather kernel (40 scattered 4-byte loads per voxel), not a streaming one; round 5: the source "
+                                     "blocks of a result block are looked up once per block, and one wave fills a block (no barriers, more blocks in flight): 4.8 -> 2.6 ms on the "
+                                     "164 k-block volume; what was measured and did not move it (LDS staging, 8-byte tap pairs, Morton order): DESIGN.md section 8")
             res["transform_alloc"] = entry("k_transform_alloc<false>", 512.0 * 4.0 * blocks, "nominal: one 4-byte key component per source voxel -- the kernel is hash-table work (claims), not traffic",
                                            "the result blocks a source block's voxels land in are gathered in an LDS set and claimed once per workgroup since round 5 (3.4 -> 1.5 ms)")
         if tn_out:
