@@ -970,7 +970,7 @@ int enqueue_pass(op_icp* c, int mode, bool write_inl) {
 
 // host-synchronous single pass with an explicit T (op_icp_iterate)
 int ensure_tie_buffers(op_icp* c);
-int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums], bool launch_retired);
+int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums], bool launch_retired, bool nn_is_read = true);
 int run_pass(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums]) {
     const bool detect = c->ties == OP_ICP_TIES_REFERENCE && mode < 2;
     if (detect) OP_TRY(ensure_tie_buffers(c));
@@ -1034,7 +1034,7 @@ void pair_contribution(int mode, const float M[16], const float s[3], const floa
     }
 }
 
-int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums], bool launch_retired) {
+int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums], bool launch_retired, bool nn_is_read) {
     const unsigned n_tied = (unsigned)(out[29] + 0.5);
     c->tie_total += n_tied; // what the device counter now reads
     if (!n_tied) return OP_OK;
@@ -1075,10 +1075,13 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
         if (partner[k] != rec[k].best) c->tie_patch[changed++] = make_int2(rec[k].src, partner[k]);
     c->tie_queries += n_tied; c->tie_changed += changed;
     if (!changed) return OP_OK; // the smallest index happened to be the first the tree meets: the sums stand
-    // nn[] follows in stream order (tie_patch is not written again before the next pass's sums have come back, i.e. after this kernel ran)
-    hipLaunchKernelGGL(k_patch_nn, dim3(((unsigned)changed + 255u) / 256u), dim3(256), 0, c->stream, (const int2*)c->tie_patch_dev, (unsigned)changed, c->nn);
-    OP_HIP(hipGetLastError());
-    if (!write_inl && changed <= 4096) {
+    const bool on_host = !write_inl && changed <= 4096;
+    if (nn_is_read || !on_host) { // nn[] follows in stream order (tie_patch is not written again before the next pass's sums have come back, i.e. after this kernel ran);
+        // every search pass rewrites all of nn[], so inside a loop only the last iteration's partners are ever read (final pass, pair list)
+        hipLaunchKernelGGL(k_patch_nn, dim3(((unsigned)changed + 255u) / 256u), dim3(256), 0, c->stream, (const int2*)c->tie_patch_dev, (unsigned)changed, c->nn);
+        OP_HIP(hipGetLastError());
+    }
+    if (on_host) {
         const double thr2 = c->threshold * c->threshold;
         double was[kNSums], is[kNSums];
         for (unsigned k = 0; k < n_tied; ++k) {
@@ -1465,7 +1468,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
             const double tb = now();
 #endif
             OP_TRY(wait_rows(c, r));
-            if (detect) OP_TRY(resolve_ties(c, pass_mode, cur, false, r, false)); // nothing to do unless the pass reported tied queries (r[29])
+            if (detect) OP_TRY(resolve_ties(c, pass_mode, cur, false, r, false, it == max_iteration - 1)); // nothing to do unless the pass reported tied queries (r[29])
 #ifdef ICP_TRACE
             const double tc = now();
 #endif
