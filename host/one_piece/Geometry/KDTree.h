@@ -8,6 +8,7 @@
 // parameters (eps = 0) whatever `sp` says, RadiusSearch passes sp.eps and sp.sorted on and collects at most 2.5 x max_result neighbours
 // before keeping the first max_result of them.
 #pragma once
+#include <algorithm>
 #include <iostream>
 #include <utility>
 #include <vector>
@@ -55,114 +56,84 @@ public:
         tree.build(flat.data(), points.size(), (size_t)max_leaf);
     }
 
+    // The reference spells every search out four times (dynamic / fixed-size query x int / size_t indices); here the twelve public overloads
+    // forward to three private templates.
     // ---- RadiusSearch (KDTree.h:99-146)
     void RadiusSearch(const geometry::VectorX& point, std::vector<int>& indices, std::vector<float>& dists, double radius, size_t max_result,
-                      const SearchParameter& sp = SearchParameter()) {
-        std::vector<size_t> _indices;
-        RadiusSearch(point, _indices, dists, radius, max_result, sp);
-        Narrow(_indices, indices);
-    }
+                      const SearchParameter& sp = SearchParameter()) { WithinRadius(point, indices, dists, radius, max_result, sp, "[ERROR]::[RadiusSearch]::Wrong dimension!"); }
     void RadiusSearch(const geometry::VectorX& point, std::vector<size_t>& indices, std::vector<float>& dists, double radius, size_t max_result,
-                      const SearchParameter& sp = SearchParameter()) {
-        if (point.rows() != T) {
-            std::cout << RED << "[ERROR]::[RadiusSearch]::Wrong dimension!" << RESET << std::endl;
-            return;
-        }
-        geometry::Vector<T> _point;
-        for (int d = 0; d < T; ++d) _point(d) = point(d);
-        RadiusSearch(_point, indices, dists, radius, max_result, sp);
-    }
+                      const SearchParameter& sp = SearchParameter()) { WithinRadius(point, indices, dists, radius, max_result, sp, "[ERROR]::[RadiusSearch]::Wrong dimension!"); }
     void RadiusSearch(const geometry::Vector<T>& point, std::vector<int>& indices, std::vector<float>& dists, double radius, size_t max_result,
-                      const SearchParameter sp = SearchParameter()) {
-        std::vector<size_t> _indices;
-        RadiusSearch(point, _indices, dists, radius, max_result, sp);
-        Narrow(_indices, indices);
-    }
+                      const SearchParameter sp = SearchParameter()) { WithinRadius(point, indices, dists, radius, max_result, sp, nullptr); }
     void RadiusSearch(const geometry::Vector<T>& point, std::vector<size_t>& indices, std::vector<float>& dists, double radius, size_t max_result,
-                      const SearchParameter sp = SearchParameter()) {
-        float q[T];
-        for (int d = 0; d < T; ++d) q[d] = point(d);
-        std::vector<std::pair<size_t, float> > ret_matches;
-        size_t search_num = tree.radius(q, static_cast<float>(radius), ret_matches, static_cast<size_t>(max_result * 2.5), sp.eps, sp.sorted);
-        if (search_num > max_result) search_num = max_result;
-        indices.resize(search_num);
-        dists.resize(search_num);
-        for (size_t i = 0; i < search_num; ++i) {
-            indices[i] = ret_matches[i].first;
-            dists[i] = ret_matches[i].second;
-        }
-    }
+                      const SearchParameter sp = SearchParameter()) { WithinRadius(point, indices, dists, radius, max_result, sp, nullptr); }
 
-    // ---- KnnSearch (KDTree.h:147-196)
+    // ---- KnnSearch (KDTree.h:147-196); the reference calls knnSearch with nanoflann's default parameters whatever `sp` says
     void KnnSearch(const geometry::VectorX& point, std::vector<int>& indices, std::vector<float>& dists, int k, const SearchParameter& sp = SearchParameter()) {
-        std::vector<size_t> _indices;
-        KnnSearch(point, _indices, dists, k, sp);
-        Narrow(_indices, indices);
+        (void)sp; Nearest(point, indices, dists, k, "[ERROR]::[KnnSearch]::Wrong dimension!");
     }
     void KnnSearch(const geometry::VectorX& point, std::vector<size_t>& indices, std::vector<float>& dists, int k, const SearchParameter& sp = SearchParameter()) {
-        if (point.rows() != T) {
-            std::cout << RED << "[ERROR]::[KnnSearch]::Wrong dimension!" << RESET << std::endl;
-            return;
-        }
-        geometry::Vector<T> _point;
-        for (int d = 0; d < T; ++d) _point(d) = point(d);
-        KnnSearch(_point, indices, dists, k, sp);
+        (void)sp; Nearest(point, indices, dists, k, "[ERROR]::[KnnSearch]::Wrong dimension!");
     }
     void KnnSearch(const geometry::Vector<T>& point, std::vector<int>& indices, std::vector<float>& dists, int k, const SearchParameter& sp = SearchParameter()) {
-        std::vector<size_t> _indices;
-        KnnSearch(point, _indices, dists, k, sp);
-        Narrow(_indices, indices);
+        (void)sp; Nearest(point, indices, dists, k, nullptr);
     }
     void KnnSearch(const geometry::Vector<T>& point, std::vector<size_t>& indices, std::vector<float>& dists, int k, const SearchParameter& sp = SearchParameter()) {
-        (void)sp; // the reference calls knnSearch with nanoflann's default parameters whatever sp says
-        float q[T];
-        for (int d = 0; d < T; ++d) q[d] = point(d);
-        const size_t kk = k > 0 ? (size_t)k : 0;
-        indices.resize(kk);
-        std::vector<float> out_dist_sqr(kk);
-        const size_t search_num = kk ? tree.knn(q, kk, &indices[0], &out_dist_sqr[0]) : 0;
-        indices.resize(search_num);
-        dists.resize(search_num);
-        for (size_t i = 0; i < search_num; ++i) dists[i] = out_dist_sqr[i];
+        (void)sp; Nearest(point, indices, dists, k, nullptr);
     }
 
     // ---- KnnRadiusSearch (KDTree.h:197-255): the k nearest, then the prefix whose squared distance does not exceed `radius`
     void KnnRadiusSearch(const geometry::VectorX& point, std::vector<int>& indices, std::vector<float>& dists, int k, float radius,
-                         const SearchParameter& sp = SearchParameter()) {
-        std::vector<size_t> _indices;
-        KnnRadiusSearch(point, _indices, dists, k, radius, sp);
-        Narrow(_indices, indices);
-    }
+                         const SearchParameter& sp = SearchParameter()) { (void)sp; if (Nearest(point, indices, dists, k, "[ERROR]::[KnnSearch]::Wrong dimension!")) CutAt(radius, indices, dists); }
     void KnnRadiusSearch(const geometry::VectorX& point, std::vector<size_t>& indices, std::vector<float>& dists, int k, float radius,
-                         const SearchParameter& sp = SearchParameter()) {
-        if (point.rows() != T) {
-            std::cout << RED << "[ERROR]::[KnnSearch]::Wrong dimension!" << RESET << std::endl;
-            return;
-        }
-        geometry::Vector<T> _point;
-        for (int d = 0; d < T; ++d) _point(d) = point(d);
-        KnnRadiusSearch(_point, indices, dists, k, radius, sp);
-    }
+                         const SearchParameter& sp = SearchParameter()) { (void)sp; if (Nearest(point, indices, dists, k, "[ERROR]::[KnnSearch]::Wrong dimension!")) CutAt(radius, indices, dists); }
     void KnnRadiusSearch(const geometry::Vector<T>& point, std::vector<int>& indices, std::vector<float>& dists, int k, float radius,
-                         const SearchParameter& sp = SearchParameter()) {
-        std::vector<size_t> _indices;
-        KnnRadiusSearch(point, _indices, dists, k, radius, sp);
-        Narrow(_indices, indices);
-    }
+                         const SearchParameter& sp = SearchParameter()) { (void)sp; if (Nearest(point, indices, dists, k, nullptr)) CutAt(radius, indices, dists); }
     void KnnRadiusSearch(const geometry::Vector<T>& point, std::vector<size_t>& indices, std::vector<float>& dists, int k, float radius,
-                         const SearchParameter& sp = SearchParameter()) {
-        KnnSearch(point, indices, dists, k, sp);
-        size_t in_radius = 0;
-        for (; in_radius != indices.size(); ++in_radius)
-            if (dists[in_radius] > radius) break;
-        indices.resize(in_radius);
-        dists.resize(in_radius);
-    }
+                         const SearchParameter& sp = SearchParameter()) { (void)sp; if (Nearest(point, indices, dists, k, nullptr)) CutAt(radius, indices, dists); }
 
 protected:
-    static void Narrow(const std::vector<size_t>& from, std::vector<int>& to) {
-        to.resize(from.size());
-        for (size_t i = 0; i != from.size(); ++i) to[i] = static_cast<int>(from[i]);
+    // the query as T floats; a dynamic vector of another length is refused with the reference's message (and the outputs are left alone, as there)
+    template <class Query>
+    bool Coordinates(const Query& point, float* q, const char* complaint) const {
+        if (complaint && (int)point.rows() != T) {
+            std::cout << RED << complaint << RESET << std::endl;
+            return false;
+        }
+        for (int d = 0; d < T; ++d) q[d] = point(d);
+        return true;
+    }
+    template <class Query, class Index>
+    bool Nearest(const Query& point, std::vector<Index>& indices, std::vector<float>& dists, int k, const char* complaint) const {
+        float q[T];
+        if (!Coordinates(point, q, complaint)) return false;
+        const size_t want = k > 0 ? (size_t)k : 0;
+        std::vector<size_t> found(want);
+        std::vector<float> d2(want);
+        const size_t n = want ? tree.knn(q, want, found.data(), d2.data()) : 0;
+        indices.resize(n);
+        dists.resize(n);
+        for (size_t i = 0; i < n; ++i) { indices[i] = static_cast<Index>(found[i]); dists[i] = d2[i]; }
+        return true;
+    }
+    // at most 2.5 x max_result neighbours are collected (in traversal order, then sorted if asked), the first max_result of them kept
+    template <class Query, class Index>
+    void WithinRadius(const Query& point, std::vector<Index>& indices, std::vector<float>& dists, double radius, size_t max_result, const SearchParameter& sp,
+                      const char* complaint) const {
+        float q[T];
+        if (!Coordinates(point, q, complaint)) return;
+        std::vector<std::pair<size_t, float> > matches;
+        const size_t n = std::min(tree.radius(q, static_cast<float>(radius), matches, static_cast<size_t>(max_result * 2.5), sp.eps, sp.sorted), max_result);
+        indices.resize(n);
+        dists.resize(n);
+        for (size_t i = 0; i < n; ++i) { indices[i] = static_cast<Index>(matches[i].first); dists[i] = matches[i].second; }
+    }
+    template <class Index>
+    static void CutAt(float radius, std::vector<Index>& indices, std::vector<float>& dists) {
+        size_t keep = 0;
+        while (keep != dists.size() && !(dists[keep] > radius)) ++keep;
+        indices.resize(keep);
+        dists.resize(keep);
     }
 
     op_host::NanoTreeT<T> tree;
