@@ -10,6 +10,9 @@
 //
 // Users: the ICP path (onepiece_amd/csrc/icp.hip re-decides tied queries with nearest()), and the class surface's geometry::KDTree<D>
 // (host/one_piece/Geometry/KDTree.h).  Checked against the real library's answers: tests/golden/nanoflann_golden.json.
+// Nodes are split on first visit (build() only lays down the root): a handful of queries -- the ICP path's tied ones -- then cost the few
+// root-to-leaf paths they walk, ~2 passes over the points, instead of the whole O(n log n) construction; finish() completes the tree (what
+// geometry::KDTree does, and what concurrent queries need: splitting is not thread-safe, searching a finished tree is).
 // Header-only, C++11, no dependencies.
 #pragma once
 #include <algorithm>
@@ -27,24 +30,33 @@ public:
     bool built() const { return ready_; }
     size_t size() const { return n_; }
 
-    // points: n x D floats, kept by reference (the caller owns them for the life of the tree)
-    void build(const float* points, size_t n, size_t leaf_size = 10) {
-        pts_ = points; n_ = n; leaf_ = leaf_size; ready_ = true;
+    // points: n x D floats, kept by reference (the caller owns them for the life of the tree).  complete = false leaves every node to be
+    // split when a search first reaches it.
+    void build(const float* points, size_t n, size_t leaf_size = 10, bool complete = true) {
+        pts_ = points; n_ = n; leaf_ = leaf_size; ready_ = true; finished_ = false;
         order_.resize(n);
         for (size_t i = 0; i < n; ++i) order_[i] = i;
         nodes_.clear();
-        if (!n) return;
-        nodes_.reserve(n / 4 + 16);
-        Box root;
-        for (int d = 0; d < D; ++d) root.lo[d] = root.hi[d] = points[d];
+        if (!n) { finished_ = true; return; }
+        nodes_.reserve(complete ? n / 4 + 16 : 256);
+        Node root;
+        for (int d = 0; d < D; ++d) root.cell.lo[d] = root.cell.hi[d] = points[d];
         for (size_t k = 1; k < n; ++k)
             for (int d = 0; d < D; ++d) {
                 const float v = points[(size_t)D * k + d];
-                if (v < root.lo[d]) root.lo[d] = v;
-                if (v > root.hi[d]) root.hi[d] = v;
+                if (v < root.cell.lo[d]) root.cell.lo[d] = v;
+                if (v > root.cell.hi[d]) root.cell.hi[d] = v;
             }
-        split(0, n, root);
-        root_ = root;
+        root.begin = 0; root.end = n;
+        root_ = root.cell;
+        nodes_.push_back(root);
+        if (complete) finish();
+    }
+    // splits every node that has not been visited yet; afterwards searches do not modify the tree (and may run concurrently)
+    void finish() {
+        if (finished_) return;
+        for (size_t id = 0; id < nodes_.size(); ++id) split((int32_t)id); // (children are appended behind their parent: one sweep reaches them all)
+        finished_ = true;
     }
 
     // knnSearch(query, k, indices, squared distances): the k nearest in ascending distance, equally distant ones in the order the
@@ -78,7 +90,8 @@ public:
 
 private:
     struct Box { float lo[D], hi[D]; };
-    struct Node { int32_t low_part = -1, high_part = -1; size_t begin = 0, end = 0; int axis = 0; float below = 0, above = 0; }; // children: the points below / above the cut (-1 = leaf)
+    // a node covers order_[begin, end) and remembers the cell it was handed; `state`: 0 = not looked at yet, 1 = leaf, 2 = split into low_part / high_part
+    struct Node { Box cell; size_t begin = 0, end = 0; int32_t low_part = -1, high_part = -1; int axis = 0, state = 0; float below = 0, above = 0; };
 
     // nanoflann's KNNResultSet: an equally distant newcomer goes BEHIND the entries already there, and is dropped when the set is full
     struct KnnSet {
@@ -109,8 +122,9 @@ private:
     const float* pts_ = nullptr;
     size_t n_ = 0, leaf_ = 10;
     bool ready_ = false;
-    std::vector<size_t> order_;   // nanoflann's vind: a leaf covers order_[begin .. end)
-    std::vector<Node> nodes_;
+    mutable bool finished_ = false;
+    mutable std::vector<size_t> order_;   // nanoflann's vind: a leaf covers order_[begin .. end)
+    mutable std::vector<Node> nodes_;     // (searches split the nodes they are the first to reach)
     Box root_;
 
     float coord(size_t slot, int d) const { return pts_[(size_t)D * order_[slot] + d]; }
@@ -125,7 +139,7 @@ private:
     }
 
     // three-way partition of order_[begin, begin + count) about `cut` along d: [< cut | == cut | > cut); returns the two boundaries
-    std::pair<size_t, size_t> partition(size_t begin, size_t count, int d, float cut) {
+    std::pair<size_t, size_t> partition(size_t begin, size_t count, int d, float cut) const {
         size_t* ind = order_.data() + begin;
         const float* p = pts_;
         size_t l = 0, r = count - 1;
@@ -148,55 +162,57 @@ private:
         return std::make_pair(first, l);
     }
 
-    // builds the subtree over order_[begin, end); `box` comes in as the cell and goes out as the bounding box of the points
-    int32_t split(size_t begin, size_t end, Box& box) {
-        const int32_t id = (int32_t)nodes_.size();
-        nodes_.push_back(Node());
-        const size_t count = end - begin;
-        if (count <= leaf_) {
-            nodes_[id].begin = begin; nodes_[id].end = end;
-            for (int d = 0; d < D; ++d) box.lo[d] = box.hi[d] = coord(begin, d);
-            for (size_t k = begin + 1; k < end; ++k)
-                for (int d = 0; d < D; ++d) {
-                    const float v = coord(k, d);
-                    if (box.lo[d] > v) box.lo[d] = v;
-                    if (box.hi[d] < v) box.hi[d] = v;
-                }
-            return id;
-        }
+    // decides what node `id` is: a leaf, or two children about a cut (nanoflann's divideTree + middleSplit_ for this one node).  The distances a
+    // search needs at the node -- the largest coordinate below the cut, the smallest above it, which nanoflann takes from the children's bounding
+    // boxes on its way back up -- are read off the two parts directly.
+    void split(int32_t id) const {
+        if (nodes_[id].state) return;
+        const size_t begin = nodes_[id].begin, end = nodes_[id].end, count = end - begin;
+        if (count <= leaf_) { nodes_[id].state = 1; return; }
+        const Box box = nodes_[id].cell;
         // the dimension: among those whose cell span is within 1e-5 of the widest, the one over which the points spread most
         const float eps = 0.00001f;
         float widest = box.hi[0] - box.lo[0];
         for (int d = 1; d < D; ++d) { const float span = box.hi[d] - box.lo[d]; if (span > widest) widest = span; }
         float best_spread = -1;
         int axis = 0;
+        float lo_of[D], hi_of[D]; // the points' range along the candidate dimensions -- all of them in ONE pass when there are few (the big nodes near the root are
+        bool have[D];             // what a handful of queries on an unfinished tree pay for)
+        for (int d = 0; d < D; ++d) have[d] = false;
+        if (D <= 4) {
+            for (int d = 0; d < D; ++d) { lo_of[d] = hi_of[d] = coord(begin, d); have[d] = true; }
+            for (size_t i = 1; i < count; ++i) {
+                const float* p = pts_ + (size_t)D * order_[begin + i];
+                for (int d = 0; d < D; ++d) { if (p[d] < lo_of[d]) lo_of[d] = p[d]; if (p[d] > hi_of[d]) hi_of[d] = p[d]; }
+            }
+        }
         for (int d = 0; d < D; ++d) {
             const float span = box.hi[d] - box.lo[d];
             if (span > (1 - eps) * widest) {
-                float mn, mx;
-                range(begin, count, d, mn, mx);
-                const float spread = mx - mn;
+                if (!have[d]) { range(begin, count, d, lo_of[d], hi_of[d]); have[d] = true; }
+                const float spread = hi_of[d] - lo_of[d];
                 if (spread > best_spread) { axis = d; best_spread = spread; }
             }
         }
         // the cut: the middle of the cell, pulled into the range of the points
         const float middle = (box.lo[axis] + box.hi[axis]) / 2;
-        float mn, mx;
-        range(begin, count, axis, mn, mx);
+        if (!have[axis]) range(begin, count, axis, lo_of[axis], hi_of[axis]);
+        const float mn = lo_of[axis], mx = hi_of[axis];
         const float cut = middle < mn ? mn : (middle > mx ? mx : middle);
         const std::pair<size_t, size_t> lim = partition(begin, count, axis, cut);
         const size_t half = count / 2;
         const size_t take = lim.first > half ? lim.first : (lim.second < half ? lim.second : half);
-        Box low = box, high = box;
-        low.hi[axis] = cut;
-        const int32_t a = split(begin, begin + take, low);
-        high.lo[axis] = cut;
-        const int32_t b = split(begin + take, end, high);
-        Node& nd = nodes_[id]; // (taken after the recursion: the vector may have moved)
-        nd.low_part = a; nd.high_part = b; nd.axis = axis; nd.begin = begin; nd.end = end;
-        nd.below = low.hi[axis]; nd.above = high.lo[axis];
-        for (int d = 0; d < D; ++d) { box.lo[d] = low.lo[d] < high.lo[d] ? low.lo[d] : high.lo[d]; box.hi[d] = low.hi[d] > high.hi[d] ? low.hi[d] : high.hi[d]; }
-        return id;
+        Node low, high;
+        low.cell = box; low.cell.hi[axis] = cut; low.begin = begin; low.end = begin + take;
+        high.cell = box; high.cell.lo[axis] = cut; high.begin = begin + take; high.end = end;
+        float unused, below, above;
+        range(low.begin, take, axis, unused, below);
+        range(high.begin, count - take, axis, above, unused);
+        const int32_t a = (int32_t)nodes_.size();
+        nodes_.push_back(low);
+        nodes_.push_back(high);
+        Node& nd = nodes_[id]; // (taken after the push_backs: the vector may have moved)
+        nd.low_part = a; nd.high_part = a + 1; nd.axis = axis; nd.below = below; nd.above = above; nd.state = 2;
     }
 
     template <class Set>
@@ -213,8 +229,9 @@ private:
     // false = the result set wants no more points
     template <class Set>
     bool descend(int32_t id, const float* q, float bound, float* per_dim, Set& set, float eps_error) const {
-        const Node& nd = nodes_[id];
-        if (nd.low_part < 0) {
+        split(id);
+        const Node nd = nodes_[id]; // (a copy: splitting further down may move the vector)
+        if (nd.state == 1) {
             const float worst = set.worst(); // nanoflann reads the result set's worst distance once per leaf
             for (size_t s = nd.begin; s < nd.end; ++s) {
                 const float* p = pts_ + (size_t)D * order_[s];

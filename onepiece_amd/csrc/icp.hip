@@ -990,6 +990,7 @@ int run_pass(op_icp* c, int mode, const float T[16], bool write_inl, double out[
 // same float expressions as the kernel's, accumulated in fp64 like its sums -- and nn[] is patched by a small kernel behind the pass
 // (only the final pass and the pair list read it).  The reference-order modes (write_inl) and floods of ties take the sums again on the
 // device instead (MODE 3 / 4 over the stored correspondences).  T = the pose of the pass; `out` = its sums, corrected on return.
+constexpr size_t kTieStampChecked = 4096; // records whose arrival the host checks by their stamp (initialised when the buffer is taken)
 int ensure_tie_buffers(op_icp* c) {
     if (c->tie_cap >= c->src_cap && c->tie_count) return OP_OK;
     if (c->tie_rec) op::cached_free(c->tie_rec);
@@ -1005,7 +1006,7 @@ int ensure_tie_buffers(op_icp* c) {
     OP_HIP(op::cached_host_malloc((void**)&c->tie_patch, cap * sizeof(int2)));
     OP_HIP(hipHostGetDevicePointer((void**)&c->tie_rec_dev, c->tie_rec, 0));
     OP_HIP(hipHostGetDevicePointer((void**)&c->tie_patch_dev, c->tie_patch, 0));
-    for (size_t k = 0; k < cap; ++k) c->tie_rec[k].stamp = 0xffffffffu; // (a recycled buffer may hold any stamp)
+    for (size_t k = 0; k < std::min(cap, kTieStampChecked); ++k) c->tie_rec[k].stamp = 0xffffffffu; // (a recycled buffer may hold any stamp; beyond these the host synchronises instead)
     c->tie_cap = c->src_cap;
     return OP_OK;
 }
@@ -1039,6 +1040,7 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
     c->tie_total += n_tied; // what the device counter now reads
     if (!n_tied) return OP_OK;
     if (n_tied > c->tie_cap) return fail(OP_ERR_HIP, "icp: the search reported %u tied queries for %zu source points", n_tied, c->n);
+    if (!launch_retired && n_tied > kTieStampChecked) { OP_HIP(hipStreamSynchronize(c->stream)); launch_retired = true; } // a flood: let the launch retire
     if (!launch_retired) { // the sums were read from published rows: every record carries the launch's stamp once it has arrived
         volatile TieRec* rec = c->tie_rec;
         bool synced = false;
@@ -1052,7 +1054,7 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
     if (!c->tie_tree.built()) {
         c->tgt_host.resize(c->m * 3);
         OP_HIP(hipMemcpy(c->tgt_host.data(), c->tgt_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        c->tie_tree.build(c->tgt_host.data(), c->m);
+        c->tie_tree.build(c->tgt_host.data(), c->m, 10, false); // nodes are split as searches reach them: a few tied queries cost ~2 passes over the target, not the whole construction
     }
     if (mode == 1 && c->nrm_host.empty() && c->m) {
         c->nrm_host.resize(c->m * 3);
@@ -1062,7 +1064,8 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
     std::vector<int> partner(n_tied);
     auto decide = [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) partner[k] = c->tie_tree.nearest(rec[k].tp); };
     const unsigned n_threads = n_tied >= 8192 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-    if (n_threads > 1) { // a lattice ties every query: a few host threads share the searches (the tree is read-only)
+    if (n_threads > 1) { // a lattice ties every query: a few host threads share the searches (over the finished tree, which is read-only)
+        c->tie_tree.finish();
         std::vector<std::thread> pool;
         const size_t per = ((size_t)n_tied + n_threads - 1) / n_threads;
         for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(decide, std::min<size_t>(t * per, n_tied), std::min<size_t>((t + 1) * per, n_tied));

@@ -16,10 +16,16 @@ int main(int argc, char** argv) {
     std::vector<int32_t> want(nq);
     if (fread(t.data(), 4, t.size(), f) != t.size() || fread(q.data(), 4, q.size(), f) != q.size() || fread(want.data(), 4, want.size(), f) != want.size()) return 2;
     fclose(f);
-    op_host::NanoTree tree;
-    tree.build(t.data(), (size_t)n);
     int bad = 0;
-    for (int i = 0; i < nq; ++i) bad += tree.nearest(&q[3 * (size_t)i]) != want[i];
+    for (int lazy = 0; lazy < 2; ++lazy) { // the finished tree, and the tree whose nodes are split as the searches reach them (what the ICP path uses)
+        op_host::NanoTree tree;
+        tree.build(t.data(), (size_t)n, 10, lazy == 0);
+        for (int i = 0; i < nq; ++i) bad += tree.nearest(&q[3 * (size_t)i]) != want[i];
+        if (lazy) { // ... and finished afterwards, it still answers the same
+            tree.finish();
+            for (int i = 0; i < nq; ++i) bad += tree.nearest(&q[3 * (size_t)i]) != want[i];
+        }
+    }
     printf("%d queries, %d mismatches\n", nq, bad);
     return bad ? 1 : 0;
 }
