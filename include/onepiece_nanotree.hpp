@@ -36,6 +36,7 @@ public:
         pts_ = points; n_ = n; leaf_ = leaf_size; ready_ = true; finished_ = false;
         order_.resize(n);
         for (size_t i = 0; i < n; ++i) order_[i] = i;
+        xyz_.assign(points, points + n * (size_t)D); // the coordinates in the order of `order_`: splits and leaves scan them front to back
         nodes_.clear();
         if (!n) { finished_ = true; return; }
         nodes_.reserve(complete ? n / 4 + 16 : 256);
@@ -124,10 +125,11 @@ private:
     bool ready_ = false;
     mutable bool finished_ = false;
     mutable std::vector<size_t> order_;   // nanoflann's vind: a leaf covers order_[begin .. end)
+    mutable std::vector<float> xyz_;      // xyz_[D * slot ..] = the point order_[slot] (kept in step with every swap of order_)
     mutable std::vector<Node> nodes_;     // (searches split the nodes they are the first to reach)
     Box root_;
 
-    float coord(size_t slot, int d) const { return pts_[(size_t)D * order_[slot] + d]; }
+    float coord(size_t slot, int d) const { return xyz_[(size_t)D * slot + d]; }
 
     void range(size_t begin, size_t count, int d, float& mn, float& mx) const {
         mn = mx = coord(begin, d);
@@ -141,22 +143,26 @@ private:
     // three-way partition of order_[begin, begin + count) about `cut` along d: [< cut | == cut | > cut); returns the two boundaries
     std::pair<size_t, size_t> partition(size_t begin, size_t count, int d, float cut) const {
         size_t* ind = order_.data() + begin;
-        const float* p = pts_;
+        float* c = xyz_.data() + (size_t)D * begin;
+        auto exchange = [&](size_t i, size_t j) {
+            std::swap(ind[i], ind[j]);
+            for (int k = 0; k < D; ++k) std::swap(c[(size_t)D * i + k], c[(size_t)D * j + k]);
+        };
         size_t l = 0, r = count - 1;
         for (;;) {
-            while (l <= r && p[(size_t)D * ind[l] + d] < cut) ++l;
-            while (r && l <= r && p[(size_t)D * ind[r] + d] >= cut) --r;
+            while (l <= r && c[(size_t)D * l + d] < cut) ++l;
+            while (r && l <= r && c[(size_t)D * r + d] >= cut) --r;
             if (l > r || !r) break;
-            std::swap(ind[l], ind[r]);
+            exchange(l, r);
             ++l; --r;
         }
         const size_t first = l;
         r = count - 1;
         for (;;) {
-            while (l <= r && p[(size_t)D * ind[l] + d] <= cut) ++l;
-            while (r && l <= r && p[(size_t)D * ind[r] + d] > cut) --r;
+            while (l <= r && c[(size_t)D * l + d] <= cut) ++l;
+            while (r && l <= r && c[(size_t)D * r + d] > cut) --r;
             if (l > r || !r) break;
-            std::swap(ind[l], ind[r]);
+            exchange(l, r);
             ++l; --r;
         }
         return std::make_pair(first, l);
@@ -181,8 +187,9 @@ private:
         for (int d = 0; d < D; ++d) have[d] = false;
         if (D <= 4) {
             for (int d = 0; d < D; ++d) { lo_of[d] = hi_of[d] = coord(begin, d); have[d] = true; }
+            const float* p = xyz_.data() + (size_t)D * begin;
             for (size_t i = 1; i < count; ++i) {
-                const float* p = pts_ + (size_t)D * order_[begin + i];
+                p += D;
                 for (int d = 0; d < D; ++d) { if (p[d] < lo_of[d]) lo_of[d] = p[d]; if (p[d] > hi_of[d]) hi_of[d] = p[d]; }
             }
         }
@@ -234,7 +241,7 @@ private:
         if (nd.state == 1) {
             const float worst = set.worst(); // nanoflann reads the result set's worst distance once per leaf
             for (size_t s = nd.begin; s < nd.end; ++s) {
-                const float* p = pts_ + (size_t)D * order_[s];
+                const float* p = xyz_.data() + (size_t)D * s;
                 float dist = 0;
                 for (int d = 0; d < D; ++d) { const float diff = q[d] - p[d]; dist += diff * diff; }
                 if (dist < worst && !set.add(dist, order_[s])) return false;

@@ -914,7 +914,8 @@ struct op_icp {
     int2* tie_patch = nullptr;          // pinned + mapped, src_cap entries: (source index, target index) for k_patch_nn
     int2* tie_patch_dev = nullptr;
     size_t tie_cap = 0;
-    std::vector<float> tgt_host, nrm_host; // the target (and its normals) in original order, downloaded when the first tie shows up
+    float* tgt_host = nullptr;          // pinned: the target in original order, downloaded when the first tie shows up (the tie tree searches it)
+    float* nrm_host = nullptr;          // pinned: the target's normals, downloaded when a point-to-plane pass first changes a partner
     op_host::NanoTree tie_tree;
     uint64_t tie_queries = 0, tie_changed = 0; // since the context was created
     std::thread worker;
@@ -1052,13 +1053,9 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!c->tie_tree.built()) {
-        c->tgt_host.resize(c->m * 3);
-        OP_HIP(hipMemcpy(c->tgt_host.data(), c->tgt_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        c->tie_tree.build(c->tgt_host.data(), c->m, 10, false); // nodes are split as searches reach them: a few tied queries cost ~2 passes over the target, not the whole construction
-    }
-    if (mode == 1 && c->nrm_host.empty() && c->m) {
-        c->nrm_host.resize(c->m * 3);
-        OP_HIP(hipMemcpy(c->nrm_host.data(), c->nrm_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        OP_HIP(op::cached_host_malloc((void**)&c->tgt_host, std::max<size_t>(c->m, 1) * 3 * sizeof(float))); // (pinned: the 3.7 MB come down at the link's rate)
+        OP_HIP(hipMemcpy(c->tgt_host, c->tgt_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        c->tie_tree.build(c->tgt_host, c->m, 10, false); // nodes are split as searches reach them: a few tied queries cost ~2 passes over the target, not the whole construction
     }
     const TieRec* rec = c->tie_rec;
     std::vector<int> partner(n_tied);
@@ -1087,6 +1084,10 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
     if (on_host) {
         const double thr2 = c->threshold * c->threshold;
         double was[kNSums], is[kNSums];
+        if (mode == 1 && !c->nrm_host) {
+            OP_HIP(op::cached_host_malloc((void**)&c->nrm_host, std::max<size_t>(c->m, 1) * 3 * sizeof(float)));
+            OP_HIP(hipMemcpy(c->nrm_host, c->nrm_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        }
         for (unsigned k = 0; k < n_tied; ++k) {
             if (partner[k] == rec[k].best) continue;
             const float* n_old = mode == 1 ? &c->nrm_host[3 * (size_t)rec[k].best] : nullptr;
@@ -1308,6 +1309,8 @@ int op_icp_destroy(op_icp* c) {
     if (c->seq_out) op::cached_free(c->seq_out);
     if (c->seq_total) op::cached_free(c->seq_total);
     if (c->seq_host) op::cached_free(c->seq_host);
+    if (c->tgt_host) op::cached_free(c->tgt_host);
+    if (c->nrm_host) op::cached_free(c->nrm_host);
     if (c->tie_count) op::cached_free(c->tie_count);
     if (c->tie_rec) op::cached_free(c->tie_rec);
     if (c->tie_patch) op::cached_free(c->tie_patch);
