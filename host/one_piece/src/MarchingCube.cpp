@@ -22,6 +22,27 @@ const int kEdge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}
 // the six faces as corner cycles (either orientation: loop orientation is fixed afterwards from the geometry)
 const int kFace[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}};
 
+// both cube edges lie on one face of the cube
+bool OnOneFace(int ea, int eb) {
+    for (int axis = 0; axis < 3; ++axis)
+        for (int side = 0; side < 2; ++side)
+            if (kCorner[kEdge[ea][0]][axis] == side && kCorner[kEdge[ea][1]][axis] == side && kCorner[kEdge[eb][0]][axis] == side && kCorner[kEdge[eb][1]][axis] == side) return true;
+    return false;
+}
+// triangles of the sub-polygon loop[i .. j] (its closing edge i-j is given) without an in-face diagonal; appends to out, false = none exists
+bool TriangulateAvoidingFaces(const std::vector<int>& loop, int i, int j, std::vector<int>& out) {
+    if (j - i < 2) return true;
+    for (int k = i + 1; k < j; ++k) {
+        if (k - i > 1 && OnOneFace(loop[i], loop[k])) continue;
+        if (j - k > 1 && OnOneFace(loop[k], loop[j])) continue;
+        const size_t mark = out.size();
+        out.push_back(loop[i]); out.push_back(loop[k]); out.push_back(loop[j]);
+        if (TriangulateAvoidingFaces(loop, i, k, out) && TriangulateAvoidingFaces(loop, k, j, out)) return true;
+        out.resize(mark);
+    }
+    return false;
+}
+
 int EdgeBetween(int a, int b) {
     for (int e = 0; e < 12; ++e)
         if ((kEdge[e][0] == a && kEdge[e][1] == b) || (kEdge[e][0] == b && kEdge[e][1] == a)) return e;
@@ -36,8 +57,11 @@ void GenerateMarchingCubeTables(int* tri_table, int* edge_pairs) {
         for (int k = 0; k < 16; ++k) row[k] = -1;
         // bit i of the case = corner i has sdf > 0 (outside), the convention of DetermineCase (MarchingCube.cpp:17-24);
         // "inside" below = bit clear
-        // 1. per face, join the crossing edges pairwise: a segment cuts off each INSIDE corner whose two face edges both
-        //    cross (ambiguous faces thereby keep inside corners apart); what is left is a single pair
+        // 1. per face, join the crossing edges pairwise.  A face with four crossings is ambiguous: a segment cuts off each corner whose
+        //    case bit is SET (the two such corners are kept apart, the other two joined) -- the resolution of the reference's table
+        //    (MarchingCubePredefined.h:17-274) in every one of its rows: tests/golden/mc_table_golden.json holds the polygons of that table,
+        //    and the rows generated here cut all 256 cases along the same ones (same loops, same facing, same triangle counts).  What still
+        //    differs is which diagonals triangulate a polygon (a fan from the loop's first edge here).
         int link[12][2], nlink[12];
         for (int e = 0; e < 12; ++e) { nlink[e] = 0; link[e][0] = link[e][1] = -1; }
         auto join = [&](int a, int b) { link[a][nlink[a]++] = b; link[b][nlink[b]++] = a; };
@@ -55,7 +79,7 @@ void GenerateMarchingCubeTables(int* tri_table, int* edge_pairs) {
                     if (crossing[k]) { if (first < 0) first = k; else join(fe[first], fe[k]); }
             } else if (ncross == 4) {
                 for (int k = 0; k < 4; ++k) // corner kFace[f][k] sits between face edges k-1 and k
-                    if (!((c >> kFace[f][k]) & 1)) join(fe[(k + 3) & 3], fe[k]);
+                    if ((c >> kFace[f][k]) & 1) join(fe[(k + 3) & 3], fe[k]);
             }
         }
         // 2. walk the closed loops, fan-triangulate each, orient every triangle so that its normal points from the inside
@@ -90,7 +114,23 @@ void GenerateMarchingCubeTables(int* tri_table, int* edge_pairs) {
             }
             const double side = normal[0] * (centre[0] - inside[0]) + normal[1] * (centre[1] - inside[1]) + normal[2] * (centre[2] - inside[2]);
             if (side < 0) for (size_t a = 0, b = loop.size() - 1; a < b; ++a, --b) { const int t = loop[a]; loop[a] = loop[b]; loop[b] = t; }
-            for (size_t k = 1; k + 1 < loop.size() && out + 3 <= 15; ++k) { row[out++] = loop[0]; row[out++] = loop[k]; row[out++] = loop[k + 1]; }
+            // 3. triangulate the polygon without a diagonal that lies IN a face of the cube (both of its end points on edges of one face): there the
+            //    neighbouring cell runs its own segments, and a triangle edge on top of them leaves the surface open along it.  The reference's
+            //    table has no such diagonal in any row (mc_table_golden.json: in_face_diagonals).  Fans first, from each vertex in loop order; then
+            //    (never needed for the 256 cases, kept for completeness) any triangulation, by recursion over the apex of the edge (first, last).
+            const int n = (int)loop.size();
+            std::vector<int> tris;
+            bool done = false;
+            for (int s = 0; s < n && !done; ++s) {
+                bool ok = true;
+                for (int k = 2; k + 1 < n && ok; ++k) ok = !OnOneFace(loop[s], loop[(s + k) % n]);
+                if (!ok) continue;
+                for (int k = 1; k + 1 < n; ++k) { tris.push_back(loop[s]); tris.push_back(loop[(s + k) % n]); tris.push_back(loop[(s + k + 1) % n]); }
+                done = true;
+            }
+            if (!done) done = TriangulateAvoidingFaces(loop, 0, n - 1, tris);
+            if (!done) for (int k = 1; k + 1 < n; ++k) { tris.push_back(loop[0]); tris.push_back(loop[k]); tris.push_back(loop[k + 1]); }
+            for (size_t k = 0; k + 2 < tris.size() && out + 3 <= 15; k += 3) { row[out++] = tris[k]; row[out++] = tris[k + 1]; row[out++] = tris[k + 2]; }
         }
     }
 }

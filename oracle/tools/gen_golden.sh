@@ -14,3 +14,6 @@ echo "wrote tests/golden/odometry_golden.json"
 g++ -std=c++11 -O3 -msse4.2 -w -I$R/nanoflann/include "$HERE/gen_nanoflann_golden.cpp" -o "$HERE/../_ref/gen_nanoflann_golden"
 "$HERE/../_ref/gen_nanoflann_golden" "$HERE/../../tests/golden/nanoflann_golden.json"
 echo "wrote tests/golden/nanoflann_golden.json"
+g++ -std=c++11 -O2 -w -I/root/reference/src "$HERE/gen_mc_golden.cpp" -o "$HERE/../_ref/gen_mc_golden"
+"$HERE/../_ref/gen_mc_golden" "$HERE/../../tests/golden/mc_table_golden.json"
+echo "wrote tests/golden/mc_table_golden.json"
