@@ -420,6 +420,12 @@ int op_icp_set_source(op_icp *icp, const float *src_xyz, size_t n, int mem);
 /* OP_ICP_TIES_REFERENCE: queries with exactly equidistant nearest candidates seen since op_icp_create (summed over passes), and how many of
  * them the reference pairs with another target than the smallest index. */
 int op_icp_tie_stats(op_icp *icp, uint64_t *tied_queries, uint64_t *changed);
+/* The final CountInliers of a registration (ICP.cpp:206) measures the LAST search's correspondences with the pose the last solve produced.  The
+ * grid search vouches for a correspondence only within one cell edge (a little over the threshold) of its query -- all that matters while search
+ * and count share a pose -- so op_icp_run's final pass singles out the source points whose stored partner lies beyond that under the search's pose
+ * AND that the last step moved far enough to bridge the gap, and re-decides exactly those in the tree the reference would search (none in a
+ * converged registration; many when the loop is stopped after one or two large steps).  redecided: how many since op_icp_create. */
+int op_icp_final_stats(op_icp *icp, uint64_t *redecided);
 /* One loop body of ICP.cpp:177-199 without the solve: transform by T, 1-NN, CountInliers and the
  * normal-equation sums.  mode PLANE: sums[0..35] = JTJ (row-major 6x6), sums[36..41] = JTr.
  * mode POINT: sums[0..2] = sum s', [3..5] = sum t, [6..14] = sum s' t^T (row-major), s' = T*s. */

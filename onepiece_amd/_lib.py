@@ -149,6 +149,7 @@ SIGNATURES = {
     "op_icp_destroy": (C.c_int, [_vp]),
     "op_icp_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "op_icp_tie_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "op_icp_final_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "op_icp_set_source": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "op_icp_iterate": (C.c_int, [_vp, _fp, C.c_int, C.POINTER(C.c_double), _u64p,
                                  C.POINTER(C.c_double)]),

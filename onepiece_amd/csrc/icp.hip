@@ -228,6 +228,20 @@ struct TieRec {
     unsigned stamp;     // the launch's tie stamp, stored after everything else has been acknowledged
     unsigned pad[3];
 };
+// What the FINAL pass (MODE 2) needs to tell which stored correspondences it may not trust.  The 27-cell search returns the true nearest target of
+// every query that has one within `reach` (< one cell edge) -- all CountInliers ever looks at while search and count share one pose.  The final
+// CountInliers (ICP.cpp:206) does not: it measures the LAST search's pairs with the pose the last solve produced, so a point whose nearest target lay
+// beyond `reach` under the old pose (nn = the nearest the 27 cells happened to hold, or none) can come within the threshold under the new one once the
+// last step moved it by more than reach - threshold -- never in a converged registration (the margin is 0.05 % of the threshold and the last step is
+// orders below it), routinely when the loop is stopped early.  The final pass therefore recomputes the old query of every point, and reports (sums[30],
+// list) those whose stored partner lies beyond `reach` there AND whose displacement could bridge the gap; the host re-decides exactly these in the
+// tree the reference would search (nn_tree.hpp), patches nn[] and repeats the pass.  Handed to the kernel through the tie_rec argument (unused in MODE 2).
+struct FinalAux {
+    float T_old[16];    // the pose of the last search
+    float reach, reach2, thr;
+    unsigned count;     // entries of list (grows by atomicAdd)
+    unsigned* list;     // source indices to re-decide, n entries
+};
 constexpr int kGroups = 32;
 constexpr unsigned long long kNoKey = 0x7f7fffff00000000ull; // (FLT_MAX, index 0): no candidate compares below it
 
@@ -276,6 +290,7 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
                                                            unsigned* __restrict__ tie_count, unsigned tie_base, TieRec* __restrict__ tie_rec, unsigned tie_stamp) {
     constexpr bool kPlane = MODE == 1 || MODE == 4;
     bool tied = false; // DETECT: more than one target at this point's nearest distance
+    bool unsure = false; // MODE 2 with a FinalAux: the stored partner of this point may not be its nearest target (see FinalAux)
     __shared__ double s_red[kIterThreads / 64][kNSums];
     __shared__ double s_fin[kIterThreads / 32][kNSums];
     __shared__ uint2 s_runs[8][kIterThreads]; // per lane: the [begin, end) runs of the rows it still has to scan
@@ -453,12 +468,31 @@ __global__ __launch_bounds__(kIterThreads) void k_icp_iter(const float* __restri
         // the point the sums are taken over: the transformed point, except for the final pass of PointToPoint (MODE 2)
         a0 = MODE == 2 ? s0 : tp0; a1 = MODE == 2 ? s1 : tp1; a2 = MODE == 2 ? s2 : tp2;
         if (inl) inl[i] = inlier ? best : -1;
+        if (MODE == 2 && tie_rec) { // (FinalAux: see there)
+            FinalAux* ax = reinterpret_cast<FinalAux*>(tie_rec);
+            const float* O = ax->T_old;
+            const float o0 = ((O[0] * s0 + O[1] * s1) + O[2] * s2) + O[3] * 1.0f, o1 = ((O[4] * s0 + O[5] * s1) + O[6] * s2) + O[7] * 1.0f;
+            const float o2 = ((O[8] * s0 + O[9] * s1) + O[10] * s2) + O[11] * 1.0f, o3 = ((O[12] * s0 + O[13] * s1) + O[14] * s2) + O[15] * 1.0f;
+            const float p0 = o0 / o3, p1 = o1 / o3, p2 = o2 / o3; // the query the last search ran
+            bool beyond = best < 0;
+            if (!beyond) { const float dx = p0 - t0, dy = p1 - t1, dz = p2 - t2; beyond = !(dx * dx + dy * dy + dz * dz <= ax->reach2); }
+            const float n3 = ((M[12] * s0 + M[13] * s1) + M[14] * s2) + M[15] * 1.0f;
+            const float m0 = (((M[0] * s0 + M[1] * s1) + M[2] * s2) + M[3] * 1.0f) / n3 - p0, m1 = (((M[4] * s0 + M[5] * s1) + M[6] * s2) + M[7] * 1.0f) / n3 - p1,
+                        m2 = (((M[8] * s0 + M[9] * s1) + M[10] * s2) + M[11] * 1.0f) / n3 - p2;
+            const float moved = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+            // (NaN anywhere: the comparisons are false -- such a point is no inlier in the reference either)
+            if (beyond && (moved + ax->thr) * 1.0001f >= ax->reach) {
+                unsure = true;
+                ax->list[atomicAdd(&ax->count, 1u)] = i;
+            }
+        }
     }
     ICP_STAMP(4);
     double acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
     if (DETECT && tied) acc[29] = 1.0; // the number of reported queries travels with the sums
+    if (MODE == 2 && unsure) acc[30] = 1.0; // likewise the final pass's points to re-decide
     if (inlier) {
         acc[27] = e;
         acc[28] = 1.0;
@@ -918,6 +952,10 @@ struct op_icp {
     float* nrm_host = nullptr;          // pinned: the target's normals, downloaded when a point-to-plane pass first changes a partner
     op_host::NanoTree tie_tree;
     uint64_t tie_queries = 0, tie_changed = 0; // since the context was created
+    FinalAux* fin_aux = nullptr;        // device: what the final pass of op_icp_run reports about correspondences it cannot trust (FinalAux)
+    unsigned* fin_list = nullptr;       // device, src_cap entries
+    size_t fin_cap = 0;
+    uint64_t fin_redecided = 0;         // since the context was created
     std::thread worker;
     bool worker_active = false;
     int worker_rc = OP_OK;
@@ -928,7 +966,7 @@ namespace {
 
 // one fused pass (transform + NN + inliers + sums + reduction); start_T is read from c->T_dev unless host_T is given.
 template <int MODE, bool DETECT = false>
-void launch_pass(op_icp* c, bool write_inl, const float* host_T = nullptr, double seq = 0.0) {
+void launch_pass(op_icp* c, bool write_inl, const float* host_T = nullptr, double seq = 0.0, FinalAux* final_aux = nullptr) {
     Mat4 Tv;
     if (host_T) std::memcpy(Tv.m, host_T, sizeof(Tv.m)); else std::memset(Tv.m, 0, sizeof(Tv.m));
     const unsigned per_group = (unsigned)((c->n_wg + kGroups - 1) / kGroups);
@@ -936,7 +974,8 @@ void launch_pass(op_icp* c, bool write_inl, const float* host_T = nullptr, doubl
     hipLaunchKernelGGL((k_icp_iter<MODE, DETECT>), dim3(c->n_wg), dim3(kIterThreads), 0, c->stream, host_T ? (const float*)nullptr : (const float*)c->T_dev, Tv,
                        (const float*)c->src, (unsigned)c->n, c->grid, (const unsigned*)c->cell_start, (const float4*)c->tgt, (unsigned)c->m,
                        (const float*)c->tgt_orig, (const float*)c->nrm_orig, c->threshold * c->threshold, c->nn, write_inl ? c->inl : nullptr, c->partials,
-                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq, c->tie_count, c->tie_total, c->tie_rec_dev, c->tie_stamp);
+                       c->stage, c->sync, per_group, c->result, host_T ? c->result_host_dev : nullptr, seq, c->tie_count, c->tie_total,
+                       MODE == 2 ? reinterpret_cast<TieRec*>(final_aux) : c->tie_rec_dev, c->tie_stamp);
 }
 
 // Waits for the rows of sums the launch with sequence number c->seq publishes (one per group of workgroups, in
@@ -1036,6 +1075,60 @@ void pair_contribution(int mode, const float M[16], const float s[3], const floa
     }
 }
 
+// the target on the host and the (lazily split) tree the reference's nanoflann would build over it
+int ensure_tie_tree(op_icp* c) {
+    if (c->tie_tree.built()) return OP_OK;
+    OP_HIP(op::cached_host_malloc((void**)&c->tgt_host, std::max<size_t>(c->m, 1) * 3 * sizeof(float))); // (pinned: the 3.7 MB come down at the link's rate)
+    OP_HIP(hipMemcpy(c->tgt_host, c->tgt_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    c->tie_tree.build(c->tgt_host, c->m, 10, false); // nodes are split as searches reach them: a few tied queries cost ~2 passes over the target, not the whole construction
+    return OP_OK;
+}
+
+// searches [lo, hi) of `queries` (3 floats each) in the tie tree, a few host threads sharing a large batch (over the finished tree, which is read-only)
+void tree_nearest(op_icp* c, const float* queries, size_t n, int* partner) {
+    auto decide = [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) partner[k] = c->tie_tree.nearest(queries + 3 * k); };
+    const unsigned n_threads = n >= 8192 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (n_threads > 1) {
+        c->tie_tree.finish();
+        std::vector<std::thread> pool;
+        const size_t per = (n + n_threads - 1) / n_threads;
+        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(decide, std::min<size_t>(t * per, n), std::min<size_t>((t + 1) * per, n));
+        for (std::thread& th : pool) th.join();
+    } else {
+        decide(0, n);
+    }
+}
+
+// The final pass reported `n_unsure` source points whose stored partner may not be their nearest target under the pose of the last search
+// (FinalAux): each is searched again, with that pose, in the tree the reference would search; nn[] is patched behind the pass.
+int redecide_final(op_icp* c, const float T_old[16], size_t n_unsure) {
+    OP_HIP(hipStreamSynchronize(c->stream));
+    unsigned count = 0;
+    OP_HIP(hipMemcpy(&count, reinterpret_cast<const char*>(c->fin_aux) + offsetof(FinalAux, count), sizeof(unsigned), hipMemcpyDeviceToHost));
+    if ((size_t)count != n_unsure || count > c->n) return fail(OP_ERR_HIP, "icp: the final pass listed %u points to re-decide and counted %zu", count, n_unsure);
+    OP_TRY(ensure_tie_buffers(c)); // (tie_patch)
+    OP_TRY(ensure_tie_tree(c));
+    std::vector<unsigned> idx(count);
+    OP_HIP(hipMemcpy(idx.data(), c->fin_list, count * sizeof(unsigned), hipMemcpyDeviceToHost));
+    std::sort(idx.begin(), idx.end()); // (the order the kernel appended them in is arbitrary; tree splits happen in a fixed order this way)
+    std::vector<float> src(3 * c->n), q(3 * (size_t)count);
+    OP_HIP(hipMemcpy(src.data(), c->src, src.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < count; ++k) { // TransformPoints (Geometry.cpp:19-27), the search kernel's expression
+        const float* s3 = &src[3 * (size_t)idx[k]];
+        const float* M = T_old;
+        const float q0 = ((M[0] * s3[0] + M[1] * s3[1]) + M[2] * s3[2]) + M[3] * 1.0f, q1 = ((M[4] * s3[0] + M[5] * s3[1]) + M[6] * s3[2]) + M[7] * 1.0f;
+        const float q2 = ((M[8] * s3[0] + M[9] * s3[1]) + M[10] * s3[2]) + M[11] * 1.0f, q3 = ((M[12] * s3[0] + M[13] * s3[1]) + M[14] * s3[2]) + M[15] * 1.0f;
+        q[3 * k] = q0 / q3; q[3 * k + 1] = q1 / q3; q[3 * k + 2] = q2 / q3;
+    }
+    std::vector<int> partner(count);
+    tree_nearest(c, q.data(), count, partner.data());
+    for (size_t k = 0; k < count; ++k) c->tie_patch[k] = make_int2((int)idx[k], partner[k]);
+    hipLaunchKernelGGL(k_patch_nn, dim3((count + 255u) / 256u), dim3(256), 0, c->stream, (const int2*)c->tie_patch_dev, count, c->nn);
+    OP_HIP(hipGetLastError());
+    c->fin_redecided += count;
+    return OP_OK;
+}
+
 int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double out[kNSums], bool launch_retired, bool nn_is_read) {
     const unsigned n_tied = (unsigned)(out[29] + 0.5);
     c->tie_total += n_tied; // what the device counter now reads
@@ -1052,23 +1145,13 @@ int resolve_ties(op_icp* c, int mode, const float T[16], bool write_inl, double 
             }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    if (!c->tie_tree.built()) {
-        OP_HIP(op::cached_host_malloc((void**)&c->tgt_host, std::max<size_t>(c->m, 1) * 3 * sizeof(float))); // (pinned: the 3.7 MB come down at the link's rate)
-        OP_HIP(hipMemcpy(c->tgt_host, c->tgt_orig, c->m * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        c->tie_tree.build(c->tgt_host, c->m, 10, false); // nodes are split as searches reach them: a few tied queries cost ~2 passes over the target, not the whole construction
-    }
+    OP_TRY(ensure_tie_tree(c));
     const TieRec* rec = c->tie_rec;
     std::vector<int> partner(n_tied);
-    auto decide = [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) partner[k] = c->tie_tree.nearest(rec[k].tp); };
-    const unsigned n_threads = n_tied >= 8192 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-    if (n_threads > 1) { // a lattice ties every query: a few host threads share the searches (over the finished tree, which is read-only)
-        c->tie_tree.finish();
-        std::vector<std::thread> pool;
-        const size_t per = ((size_t)n_tied + n_threads - 1) / n_threads;
-        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(decide, std::min<size_t>(t * per, n_tied), std::min<size_t>((t + 1) * per, n_tied));
-        for (std::thread& th : pool) th.join();
-    } else {
-        decide(0, n_tied);
+    {   // (a lattice ties every query)
+        std::vector<float> q(3 * (size_t)n_tied);
+        for (unsigned k = 0; k < n_tied; ++k) { q[3 * k] = rec[k].tp[0]; q[3 * k + 1] = rec[k].tp[1]; q[3 * k + 2] = rec[k].tp[2]; }
+        tree_nearest(c, q.data(), n_tied, partner.data());
     }
     size_t changed = 0;
     for (unsigned k = 0; k < n_tied; ++k)
@@ -1309,6 +1392,8 @@ int op_icp_destroy(op_icp* c) {
     if (c->seq_out) op::cached_free(c->seq_out);
     if (c->seq_total) op::cached_free(c->seq_total);
     if (c->seq_host) op::cached_free(c->seq_host);
+    if (c->fin_aux) op::cached_free(c->fin_aux);
+    if (c->fin_list) op::cached_free(c->fin_list);
     if (c->tgt_host) op::cached_free(c->tgt_host);
     if (c->nrm_host) op::cached_free(c->nrm_host);
     if (c->tie_count) op::cached_free(c->tie_count);
@@ -1336,6 +1421,12 @@ int op_icp_tie_stats(op_icp* c, uint64_t* tied_queries, uint64_t* changed) {
     if (!c) return fail(OP_ERR_INVALID, "null icp");
     if (tied_queries) *tied_queries = c->tie_queries;
     if (changed) *changed = c->tie_changed;
+    return OP_OK;
+}
+
+int op_icp_final_stats(op_icp* c, uint64_t* redecided) {
+    if (!c) return fail(OP_ERR_INVALID, "null icp");
+    if (redecided) *redecided = c->fin_redecided;
     return OP_OK;
 }
 
@@ -1394,7 +1485,8 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     if (mode == OP_ICP_POINT_TO_PLANE && !c->has_normals) // ICP.cpp:159-163: error line + default result
         return fail(OP_ERR_NO_NORMALS, "[ERROR]::[ICPPointToPlane]::target point cloud need to have normals.");
     if (!c->src && c->n) return fail(OP_ERR_INVALID, "op_icp_set_source has not been called");
-    float start_T[16];
+    float start_T[16], last_search_T[16];
+    std::memcpy(last_search_T, init_T, sizeof(last_search_T));
     double r[kNSums];
     if (max_iteration <= 0 && c->n) OP_HIP(hipMemsetAsync(c->nn, 0xff, c->n * sizeof(int), c->stream)); // corresponding_index stays -1
     OP_HIP(hipMemsetAsync(c->sync, 0, (kGroups + 1) * sizeof(unsigned), c->stream)); // the counters reset themselves; this covers an aborted launch
@@ -1414,6 +1506,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         float cur[16], tmp_T[16];
         std::memcpy(cur, init_T, sizeof(cur));
         for (int it = 0; it < max_iteration; ++it) {
+            std::memcpy(last_search_T, cur, sizeof(cur));
             OP_TRY(run_pass(c, pass_mode, cur, true, r)); // leaves `cur` in c->T_dev; with OP_ICP_TIES_REFERENCE, tied queries are re-decided inside
             const size_t n_it = (size_t)(r[28] + 0.5);
             const float* rows = nullptr;
@@ -1462,6 +1555,7 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 #endif
         for (int it = 0; it < max_iteration; ++it) {
+            std::memcpy(last_search_T, cur, sizeof(cur));
             c->seq += 1.0;
 #ifdef ICP_TRACE
             const double ta = now();
@@ -1505,10 +1599,37 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     // (original source, target) pairs
     // The sums of the final pass come back like the loop's (rows in host-mapped memory, no copy, no stream sync).
     // (c->T_dev is not brought up to date: the row emission of the finish works on the ORIGINAL source points.)
+    FinalAux* aux = nullptr;
+    FinalAux h; // (lives until the pass that reads its device copy has been waited for)
+    if (max_iteration > 0 && c->n) { // (without an iteration there was no search: every correspondence is "none", as in the reference)
+        if (c->fin_cap < c->n) {
+            if (c->fin_aux) op::cached_free(c->fin_aux);
+            if (c->fin_list) op::cached_free(c->fin_list);
+            c->fin_aux = nullptr; c->fin_list = nullptr; c->fin_cap = 0;
+            OP_HIP(op::cached_malloc((void**)&c->fin_aux, sizeof(FinalAux)));
+            OP_HIP(op::cached_malloc((void**)&c->fin_list, c->src_cap * sizeof(unsigned)));
+            c->fin_cap = c->src_cap;
+        }
+        std::memcpy(h.T_old, last_search_T, sizeof(h.T_old));
+        h.reach = 0.9995f / c->grid.inv_cell; // every target within one cell edge of a query lies in the 27 cells the search scans (0.05 % for the rounding of the cell assignment)
+        h.reach2 = h.reach * h.reach;
+        h.thr = (float)c->threshold;
+        h.count = 0u;
+        h.list = c->fin_list;
+        OP_HIP(hipMemcpyAsync(c->fin_aux, &h, sizeof(h), hipMemcpyHostToDevice, c->stream)); // (pageable source: the runtime stages it before the call returns)
+        aux = c->fin_aux;
+    }
     c->seq += 1.0;
-    launch_pass<2>(c, true, start_T, c->seq);
+    launch_pass<2>(c, true, start_T, c->seq, aux);
     OP_HIP(hipGetLastError());
     OP_TRY(wait_rows(c, r));
+    if (r[30] > 0.5) { // correspondences the 27-cell search cannot vouch for under the pose they are now measured with (FinalAux): re-decided on the host, pass repeated
+        OP_TRY(redecide_final(c, last_search_T, (size_t)(r[30] + 0.5)));
+        c->seq += 1.0;
+        launch_pass<2>(c, true, start_T, c->seq);
+        OP_HIP(hipGetLastError());
+        OP_TRY(wait_rows(c, r));
+    }
     const double n_inl = r[28];
     result->n_inliers = (uint64_t)(n_inl + 0.5);
     result->rmse = std::sqrt(r[27] / n_inl);

@@ -114,6 +114,9 @@ def _run(mode, source, target, init_T, icp_para, device, finish="reference", sum
         tied, changed = C.c_uint64(0), C.c_uint64(0)
         L.check(lib.op_icp_tie_stats(h, C.byref(tied), C.byref(changed)))
         res.tie_stats = (int(tied.value), int(changed.value))   # ties="reference": tied queries over all passes, and how many got another partner
+        redone = C.c_uint64(0)
+        L.check(lib.op_icp_final_stats(h, C.byref(redone)))
+        res.final_redecided = int(redone.value)                 # correspondences the final CountInliers had re-decided in the reference's tree (op_icp_final_stats)
     finally:
         lib.op_icp_destroy(h)
     n = int(out.n_inliers)

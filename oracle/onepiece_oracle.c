@@ -1268,6 +1268,7 @@ int orc_icp(int point_to_plane, const float *src, size_t n_src, const float *tgt
     int32_t *inl = (int32_t *)malloc(n_src * 2 * sizeof(int32_t));
     float *pairs = (float *)malloc(n_src * 6 * sizeof(float));
     size_t n_inl = 0;
+    for (size_t i = 0; i < n_src; ++i) corr[i] = -1; /* ICP.cpp:177: what the final CountInliers sees when max_iteration is 0 */
     for (int it = 0; it < max_iter; ++it) {
         for (size_t i = 0; i < n_src; ++i) { /* ICP.cpp:182-183, Geometry.cpp:19-27 */
             float q[4];

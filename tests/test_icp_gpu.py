@@ -527,3 +527,34 @@ def test_icp_on_a_target_with_duplicated_points_follows_the_reference(oracle, pl
     assert plain.tie_stats == (0, 0)
     same = plain.correspondence_set_index.shape == ref["pairs"].shape and np.array_equal(plain.correspondence_set_index, ref["pairs"])
     assert not same
+
+
+@pytest.mark.parametrize("plane", [True, False])
+@pytest.mark.parametrize("iters,thr", [(1, 0.05), (2, 0.03), (3, 0.02)])
+def test_a_loop_stopped_after_large_steps_counts_the_final_inliers_over_the_true_nearest_targets(oracle, plane, iters, thr):
+    """ICP.cpp:206 measures the LAST search's correspondences with the pose the last solve produced.  The grid search vouches only for partners
+    within one cell edge (a little over the threshold) of their query, which is all that matters while search and count share a pose; after a
+    large last step a point whose true nearest target lay beyond that can become an inlier.  op_icp_run re-decides exactly those points in the
+    tree the reference would search (op_icp_final_stats): with a 4 cm / 2 degree initial misalignment and one to three iterations the final
+    correspondence set, rmse and T must still be the oracle's -- identical in the reference-order mode -- and the slow path must have run.
+    (Found by tests/tools/fuzz_icp_wide.py; a converged registration never takes it: see the next test.)"""
+    _, src, _ = room_cloud(101, scale=4)
+    _, tgt, nrm = room_cloud(100, scale=4)
+    x = np.array([0.012, -0.02, 0.015, 0.04, -0.03, 0.02], np.float32)  # (rotation, translation) of the initial guess
+    T0 = oracle.se3_exp(x).astype(np.float32)
+    ref = oracle.icp(src, tgt, nrm if plane else None, T0, iters, thr, point_to_plane=plane)
+    fn = R.PointToPlane if plane else R.PointToPoint
+    got = fn(R.PointCloud(src), R.PointCloud(tgt, nrm if plane else None), T0, R.ICPParameter(iters, thr), sums="reference_f32")
+    assert got.final_redecided > 0
+    assert np.array_equal(got.per_iter_inliers, ref["per_iter_inliers"])
+    assert np.array_equal(got.correspondence_set_index, ref["pairs"])
+    assert np.array_equal(got.T.view(np.uint32), ref["T"].view(np.uint32)) and abs(got.rmse - ref["rmse"]) <= 1e-12 * ref["rmse"]
+    dflt = fn(R.PointCloud(src), R.PointCloud(tgt, nrm if plane else None), T0, R.ICPParameter(iters, thr))
+    assert dflt.final_redecided > 0 and len(dflt.correspondence_set_index) > 0
+
+
+def test_a_converged_registration_re_decides_nothing_in_its_final_count(oracle):
+    _, src, _ = room_cloud(101, scale=4)
+    _, tgt, nrm = room_cloud(100, scale=4)
+    got = R.PointToPlane(R.PointCloud(src), R.PointCloud(tgt, nrm), None, R.ICPParameter(30, 0.01))
+    assert got.final_redecided == 0
