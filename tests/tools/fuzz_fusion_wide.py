@@ -1,7 +1,7 @@
 """Wide fusion fuzz (one-off confidence run, not part of the suites): where fuzz_fusion_long.py varies the frames, this one varies the
 CONFIGURATION -- image sizes that are not multiples of 4 / 16 / 64 (narrow loads, partial tiles), intrinsics, uint16 and float32 depth,
 resolution, truncation, near / far planes, a starting pool of a few hundred blocks (growth + replay in the middle of a batch), frame counts
-that end batches at every fill level -- and interleaves the other writers of a volume between fusions (Merge of a second volume, upload through
+that end batches at every fill level -- changes the parameters of a volume in use (truncation, planes, camera incl. its image size, resolution) and interleaves the other writers of a volume between fusions (Merge of a second volume, upload through
 SetCubeMap, Clear, AddCube), which switch the update between its plain and general forms.  HIP path vs oracle, keys and voxels bit for bit
 after every phase.  usage: fuzz_fusion_wide.py [seeds=20] [first_seed=0]"""
 import os, sys
@@ -76,7 +76,23 @@ for seed in range(first, first + n_seeds):
             hv.IntegrateImage(d, c, pose)
         log.append("fuse %d" % n)
         good = good and same(ov, hv, " / ".join(log), seed)
-        op = rng.choice(["none", "merge", "upload", "clear", "addcube"], p=[0.3, 0.3, 0.2, 0.1, 0.1])
+        op = rng.choice(["none", "merge", "upload", "clear", "addcube", "reconfigure"], p=[0.2, 0.25, 0.15, 0.1, 0.1, 0.2])
+        if op == "reconfigure":  # the setters of a volume in use (CubeHandler.h:36-39,137-144,339-346): parameters change, the content stays
+            what = rng.choice(["truncation", "planes", "camera", "resolution"])
+            if what == "truncation": trunc = float(rng.choice([0.06, 0.1, 0.2, 1.5])); hv.SetTruncation(trunc)
+            elif what == "planes": near, far = float(rng.choice([0.1, 0.5, 0.9])), float(rng.choice([2.5, 5.0, 8.0])); hv.SetNearPlane(near); hv.SetFarPlane(far)
+            elif what == "resolution": res = float(rng.choice([0.015, 0.02, 0.03, 0.05])); hv.SetVoxelResolution(res)
+            else:
+                w = int(rng.choice([37, 63, 64, 65, 101, 127, 130, 160, 161, 200])); h = int(rng.choice([29, 31, 48, 50, 97, 120]))
+                f = float(rng.uniform(0.6, 1.3)) * w
+                cam = (f, f * float(rng.uniform(0.97, 1.03)), w / 2 + float(rng.uniform(-3, 3)), h / 2 + float(rng.uniform(-3, 3)), w, h, scale)
+                hcam = I.PinholeCamera(); hcam.fx, hcam.fy, hcam.cx, hcam.cy, hcam.width, hcam.height, hcam.depth_scale = cam
+                ocam = oracle.make_camera(*cam)
+                hv.SetCamera(hcam)
+            keys, vox = ov.export(sort=False)
+            ov = oracle.Volume(ocam, voxel_res=res, trunc=trunc, far=far, near=near)
+            ov.load(keys, vox)
+            op = "set " + str(what)
         if op == "merge":
             ov2 = oracle.Volume(ocam, voxel_res=res, trunc=trunc, far=far, near=near)
             hv2 = I.CubeHandler(hcam, max_blocks=pool); hv2.SetVoxelResolution(res); hv2.SetTruncation(trunc); hv2.SetNearPlane(near); hv2.SetFarPlane(far)
