@@ -161,10 +161,11 @@ int main(int argc, char** argv) {
                 printf("rep %d %s: %zu x %zu points, 30 iterations in %.3f ms (%.0f it/s), inliers %llu, rmse %.6g\n", r, mode ? "point-to-plane" : "point-to-point",
                        ns, nt, dt * 1e3, 30 / dt, (unsigned long long)res.n_inliers, res.rmse);
             }
-        // the loop alone: the difference of a 70- and a 10-iteration call (the final pass and the finish cancel)
+        // the loop alone: the difference of a 100- and a 40-iteration call (the final pass and the finish cancel; both calls end on converged
+        // steps -- a loop stopped after LARGE steps has its final correspondences re-decided in the host tree, which a 10-iteration call would add)
         for (int mode = 1; mode >= 0; --mode) {
             double best[2] = {1e9, 1e9};
-            const int its[2] = {10, 70};
+            const int its[2] = {40, 100};
             for (int r = 0; r < 5; ++r)
                 for (int k = 0; k < 2; ++k) {
                     op_icp_result res;
@@ -174,7 +175,7 @@ int main(int argc, char** argv) {
                     if (dt < best[k]) best[k] = dt;
                 }
             printf("%s loop only: %.2f us/iteration (%.0f it/s); final pass + finish %.3f ms\n", mode ? "point-to-plane" : "point-to-point",
-                   (best[1] - best[0]) / 60 * 1e6, 60 / (best[1] - best[0]), (best[0] - 10 * (best[1] - best[0]) / 60) * 1e3);
+                   (best[1] - best[0]) / (its[1] - its[0]) * 1e6, (its[1] - its[0]) / (best[1] - best[0]), (best[0] - its[0] * (best[1] - best[0]) / (its[1] - its[0])) * 1e3);
         }
         op_icp_destroy(icp);
         op_volume_destroy(v);
