@@ -57,6 +57,8 @@ def main():
                     help="the N > 1 merge: the owner-partitioned exchange (default) or the dense reduce of the whole union (rounds 1-4)")
     ap.add_argument("--timed-only", action="store_true", help="only the warm-up and the timed region (for rocprofv3 --kernel-trace --stats runs: "
                     "every k_integrate launch in the trace then has the timed region's batch shape)")
+    ap.add_argument("--summaries", action="store_true", help="A/B aid: raycast the empty volume once before the warm-up, so that the raycaster's block summaries exist and k_integrate "
+                                                              "keeps them current inside the timed region (what a tracking-against-the-model pipeline does)")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic / roofline.valu (~30 s)")
     ap.add_argument("--profile-every", type=int, default=1, help="HIP-event sample rate for the roofline (every k-th launch group)")
     args = ap.parse_args()
@@ -117,6 +119,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.summaries:
+        hv.Raycast(poses[0])
     # ---- warmup: W untimed steps (+ one merge so RCCL is initialised), then start from empty
     for w in range(Wm):
         s = (w % K) * F

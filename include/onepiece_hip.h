@@ -186,8 +186,10 @@ int op_volume_set_near_far(op_volume *v, float near_dist, float far_dist); /* Cu
 #define OP_VOLUME_SELECT_AUTO 0
 #define OP_VOLUME_SELECT_DIRECT -1
 /* OP_VOLUME_OPT_RAYCAST_PRUNE (default 1): op_volume_raycast remembers, per block it loaded, whether the block holds an observed sdf <= 0 / > 0,
- * and later views of the UNCHANGED volume use that to drop blocks in which no zero crossing can end before loading them (anything that can
- * change a voxel invalidates what was remembered).  0: every view loads every visible block, as the first view after a change does.
+ * and later views use that to drop blocks in which no zero crossing can end before loading them.  Fusion with the default (exact) update keeps
+ * the knowledge current -- the kernel that changes a block restates its summary -- so a view that follows a fused frame still prunes; every other
+ * writer (sum-form fusion, upload, merge, resampling, clear, pool growth) invalidates what was remembered.  0: every view loads every visible block,
+ * as the first view after such a change does.
  * The images are identical either way (tests/test_volume_ops_gpu.py); a measurement and test knob. */
 #define OP_VOLUME_OPT_RAYCAST_PRUNE 2
 int op_volume_set_option(op_volume *v, int option, int value);

@@ -91,9 +91,15 @@ template <bool FAST, bool PLAIN, int ZT, bool SUMF = false>
 __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAVES)) void k_integrate(BatchInv B, CamParams C, VolView V, const uint2* __restrict__ pimg, State* st,
                                                                             int n_frames, unsigned long long* __restrict__ upd_partial,
                                                                             unsigned long long* __restrict__ sel_partial, unsigned long long* __restrict__ chg_partial,
-                                                                            unsigned plain_from) {
+                                                                            unsigned plain_from, unsigned* __restrict__ rc_sum, unsigned rc_stamp) {
     constexpr int kWaves = 8 / ZT;            // waves per workgroup = z-groups per block
+#ifdef KC_NO_SUMMARY // (A/B aid: the kernel without the raycaster's summaries)
+    constexpr bool kSummaries = false;
+#else
+    constexpr bool kSummaries = !SUMF;
+#endif
     __shared__ unsigned s_cnt[kWaves][2];
+    __shared__ unsigned s_sign[2][kWaves];    // rc_sum: per wave, does its part of the block hold an observed sdf <= 0 (bit 0) / > 0 (bit 1) after the batch
     __shared__ float s_c255[256];             // (float)b / 255.0f for every byte (Integrator.cpp:78), correctly rounded once
     __shared__ unsigned s_next[2];
     const unsigned long long t_in = __builtin_amdgcn_s_memtime();
@@ -271,11 +277,27 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
             for (int z = 0; z < ZT; ++z)
                 if ((changed >> z) & 1u) { vox[z * 64] = s[z]; vox[kVox + z * 64] = w[z]; vox[2 * kVox + z * 64] = c0[z]; vox[3 * kVox + z * 64] = c1[z]; vox[4 * kVox + z * 64] = c2[z]; }
             chg += (unsigned)__popc(changed);
+            // The raycaster's block summaries (raycast.hip: k_rc_neighbours drops blocks by them before loading a voxel) describe exactly what is in
+            // registers here -- the block's 512 voxels after the batch: the kernel that changes a block restates its summary, so views between fusions
+            // find every block they meet described instead of starting from nothing (the host does not invalidate the summaries for such a batch).
+            if (kSummaries && rc_sum) {                    // (uniform)
+                bool neg = false, pos = false;
+#pragma unroll
+                for (int z = 0; z < ZT; ++z) { const bool obs = w[z] > 0; neg |= obs && s[z] <= 0; pos |= obs && s[z] > 0; }
+                const unsigned f = (__builtin_amdgcn_ballot_w64(neg) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(pos) ? 2u : 0u);
+                if (lane == 0) s_sign[slot][zg] = f;
+            }
         }
         KC_T(3);
         __syncthreads();                                   // every wave has read the mask; s_next[slot ^ 1] is visible
         KC_T(4);
         if (tslot >= 0 && tid == 0) V.bmask[tslot] = (bmask_t)0; // the owner clears it for the next batch
+        if (kSummaries && rc_sum && idx >= 0 && tid == 0) {     // (s_sign[slot] is written again two blocks on, behind the next barrier)
+            unsigned f = 0u;
+#pragma unroll
+            for (int k = 0; k < kWaves; ++k) f |= s_sign[slot][k];
+            rc_sum[idx] = (rc_stamp << 2) | f;
+        }
         slot ^= 1u;
         j = s_next[slot];
     }
@@ -330,14 +352,24 @@ __global__ __launch_bounds__(512 / ZT, (SUMF ? KC_SUM_MIN_WAVES : KC_COL_MIN_WAV
 
 namespace opv {
 
+// A batch of the exact update leaves the summaries of the blocks it touches exact (k_integrate restates them) and touches nothing else: views of the
+// volume after it may go on using what is known.  Needs the summary array (a raycast has run on this volume) in the pool's current size and epoch.
+bool vol_fusion_keeps_summaries(const op_volume* v) {
+    const bool sum_form = v->update_mode == OP_VOLUME_UPDATE_SUM_FORM && v->trunc < 1.0f;
+    return !sum_form && v->rc_sum != nullptr && v->rc_cap >= v->max_blocks && (v->content_gen >> 30) == v->rc_sum_epoch;
+}
+
 void launch_integrate(op_volume* v, const BatchInv& I, const CamParams& C, int nf) {
     const VolView V = v->view();
 #define OP_KC(FASTPX, PLAINV, SUMFV) hipLaunchKernelGGL((k_integrate<FASTPX, PLAINV, (SUMFV ? KC_ZT_SUM : KC_ZT), SUMFV>), dim3(SUMFV ? kColGridSum : kColGrid), dim3(512 / (SUMFV ? KC_ZT_SUM : KC_ZT)), 0, v->stream, I, C, V, (const uint2*)v->pimg, \
-                                                 v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial, v->plain_from)
+                                                 v->state, nf, v->upd_partial, v->sel_partial, v->chg_partial, v->plain_from, rc_sum, rc_stamp)
     // The sum form tests TSDFVoxel::IsValid on the STORED voxel once per batch where the reference re-tests it before every frame (Integrator.cpp:74-87,
     // TSDFVoxel.h:75-78): the two agree to rounding only while no OBSERVATION can itself be invalid, i.e. truncation < 1 (an observed sdf is < truncation;
     // a stored voxel of any origin gets the test).  With truncation >= 1 the exact update runs, whatever the option says.
     const bool sum_form = v->update_mode == OP_VOLUME_UPDATE_SUM_FORM && v->trunc < 1.0f;
+    // the raycaster's summaries are kept current by this launch (vol_fusion_keeps_summaries: the host has then NOT advanced the content generation)
+    unsigned* rc_sum = vol_fusion_keeps_summaries(v) ? v->rc_sum : nullptr;
+    const unsigned rc_stamp = (unsigned)(v->content_gen & 0x3fffffffull);
     if (sum_form) { if (C.fast_px) OP_KC(true, true, true); else OP_KC(false, true, true); }
     else if (C.fast_px) { if (v->plain) OP_KC(true, true, false); else OP_KC(true, false, false); }
     else { if (v->plain) OP_KC(false, true, false); else OP_KC(false, false, false); }

@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256) void k_rc_visible(VolView V, RcView W, RcBlock
 }
 
 // ---- R0b: one lane per (visible block, neighbour): 26 hash lookups per block, all of them in flight at once ------------------------------------
-// The 32 lanes of an entry also look at what EARLIER views of the unchanged volume learnt about the 27 blocks (summary: has an observed
-// sdf <= 0 / > 0 among its own voxels; stamp = the volume's content generation; an absent block has neither) and mark the entry (pad bit 1)
+// The 32 lanes of an entry also look at what is KNOWN about the 27 blocks (summary: has an observed sdf <= 0 / > 0 among its own voxels; stamp =
+// the volume's content generation; an absent block has neither; written by earlier views' marches from their tiles and by k_integrate for every
+// block a batch of the exact update changes, which is why such a batch does not advance the generation) and mark the entry (pad bit 1)
 // when the march would only load the tile to find that no crossing can end in the block:
 //   * a crossing ends at an in-block sample <= 0, which needs an observed sdf <= 0 among tile voxels 0 .. 8 = the block and its 7 upper neighbours;
 //   * its first sample is > 0 and lies in the tile when the rays step <= 1 voxel per axis (pad bit 0), which needs an observed sdf > 0 among the 27.

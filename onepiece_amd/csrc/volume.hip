@@ -350,7 +350,8 @@ int vol_enqueue_batch(op_volume* v, const BatchFwd& F, const BatchInv& I, const 
         v->hstat[1] = n;
     }
     const unsigned seq = (unsigned)(++v->seq);
-    ++v->generation; ++v->content_gen;
+    ++v->generation;
+    if (select_only || !vol_fusion_keeps_summaries(v)) ++v->content_gen; // (otherwise k_integrate restates the raycaster's summaries of what it changes)
     if (!select_only && !cube_keys) v->log.push_back(op_volume::BatchRec{v->seq, F, I, Q, nf, depth_fmt, -1});
     const CamParams C = cam_params(v, depth_fmt);
     const bool sample = !select_only && v->prof_every > 0 && (v->prof_batch++ % (uint64_t)v->prof_every) == 0 &&

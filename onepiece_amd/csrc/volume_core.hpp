@@ -404,10 +404,10 @@ struct op_volume {
     void* rc_list = nullptr;     // raycast.hip: the visible-block list of the view being cast (one entry per pool block at most), its capacity in blocks
     unsigned rc_cap = 0;
     unsigned* rc_count = nullptr; // ... and its length
-    unsigned* rc_sum = nullptr;   // per pool slot: what the march learnt about the block's own voxels ((stamp << 2) | has sdf > 0 << 1 | has sdf <= 0), valid while stamp == content_gen
+    unsigned* rc_sum = nullptr;   // per pool slot: what the march learnt about the block's own voxels ((stamp << 2) | has sdf > 0 << 1 | has sdf <= 0), valid while stamp == content_gen (written by k_rc_march from its tile and by k_integrate from the block it has just updated)
     uint64_t rc_sum_epoch = 0;    // content_gen >> 30 the summaries were last wiped for
     int rc_prune = 1;             // OP_VOLUME_OPT_RAYCAST_PRUNE
-    uint64_t content_gen = 1;     // bumped by everything that can change a voxel or a pool slot's meaning (fusion, clear, growth, every foreign writer)
+    uint64_t content_gen = 1;     // bumped by everything that can change a voxel or a pool slot's meaning without restating the summaries (clear, growth, every foreign writer, sum-form fusion; exact fusion only while no summaries exist)
     unsigned char* rc_hit = nullptr; // one byte per pool slot: the block holds hit points of the view being cast (zero between calls)
     int* unpack_slots = nullptr; // table slots of the union keys between op_volume_unpack_sum_begin and its chunks
     size_t unpack_n = 0;
@@ -452,5 +452,6 @@ void launch_finish_select(op_volume* v);
 void kb_trace_dump(op_volume* v);            // -DKB_TRACE builds only
 // integrate.hip: KC
 void launch_integrate(op_volume* v, const BatchInv& I, const CamParams& C, int nf);
+bool vol_fusion_keeps_summaries(const op_volume* v); // integrate.hip: this batch's k_integrate restates the raycaster's summaries of the blocks it changes
 void kc_trace_dump(op_volume* v);            // -DKC_TRACE builds only
 } // namespace opv

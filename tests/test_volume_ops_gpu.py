@@ -204,7 +204,7 @@ def test_raycast_other_cameras_views_and_an_empty_volume(oracle):
 
 def test_raycast_views_of_an_unchanged_volume_prune_by_earlier_views_and_every_change_invalidates_that(oracle):
     """Later views of an unchanged volume drop blocks by the summaries earlier views left (OP_VOLUME_OPT_RAYCAST_PRUNE): same images, fewer
-    blocks loaded; fusing a frame, uploading, merging or clearing must invalidate what was remembered."""
+    blocks loaded; fusion with the exact update keeps the summaries current itself (k_integrate restates them for the blocks it changes); the sum-form update, uploading, merging or clearing must invalidate what was remembered."""
     ov, hv = _pair(oracle, 0.008, frames=tuple(range(0, 80, 8)))   # truncation 0.1 m = 12.5 voxels: whole blocks in front of / behind the surface
     cam = small_camera(4)
     poses = [S.room_pose(i) for i in (20, 24, 60, 20)]
@@ -221,11 +221,29 @@ def test_raycast_views_of_an_unchanged_volume_prune_by_earlier_views_and_every_c
     off = hv.RaycastStats()
     assert off["dropped_unloaded"] == 0 and off["marched_blocks"] == first[0]["marched_blocks"]
     hv.SetRaycastPrune(True)
-    # a new frame changes voxels the summaries describe: nothing may be dropped by stale knowledge, and the image follows the volume
-    pose = S.room_pose(22)
+    # a new frame changes voxels the summaries describe.  The exact update restates the summaries of the blocks it changes (k_integrate) and touches no
+    # other block, so the knowledge SURVIVES fusion: the image follows the volume, blocks are still dropped unloaded, and exactly the blocks a view
+    # without any stored knowledge marches are marched
+    for fno in (22, 23, 61):
+        pose = S.room_pose(fno)
+        d, c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+        ov.integrate(d, c, pose); hv.IntegrateImage(d, c, pose)
+        _raycast_equal(ov, hv, poses[3])
+        kept = hv.RaycastStats()
+        assert kept["dropped_unloaded"] > 0 and kept["loaded_blocks"] + kept["dropped_unloaded"] == kept["visible_blocks"]
+        hv.SetRaycastPrune(False)
+        _raycast_equal(ov, hv, poses[3])
+        assert hv.RaycastStats()["dropped_unloaded"] == 0 and hv.RaycastStats()["marched_blocks"] == kept["marched_blocks"]
+        hv.SetRaycastPrune(True)
+    # ... while the sum-form update (which does not load the voxels it leaves alone) invalidates what was remembered, as every other writer does
+    hv.SetUpdateMode("sum_form")
+    pose = S.room_pose(25)
     d, c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
-    ov.integrate(d, c, pose); hv.IntegrateImage(d, c, pose)
-    _raycast_equal(ov, hv, poses[3])
+    hv.IntegrateImage(d, c, pose); hv.Synchronize()
+    hv.SetUpdateMode("exact")
+    k, v = hv.GetCubeMap()
+    ov.clear(); ov.load(k, v)                         # (the oracle has no sum form: it takes the volume as it is now)
+    hv.Raycast(poses[3])
     assert hv.RaycastStats()["dropped_unloaded"] == 0
     _raycast_equal(ov, hv, poses[3])
     assert hv.RaycastStats()["dropped_unloaded"] > 0
@@ -238,6 +256,40 @@ def test_raycast_views_of_an_unchanged_volume_prune_by_earlier_views_and_every_c
     hv.Clear()
     d0, _n, _c = hv.Raycast(poses[3])
     assert not d0.any() and hv.RaycastStats()["visible_blocks"] == 0
+
+
+def test_raycast_between_fusions_follows_the_volume_through_growth_upload_and_added_cubes(oracle):
+    """A tracking-against-the-model pipeline views the volume after every fusion.  Fusion keeps the raycaster's block summaries current itself
+    (k_integrate), so these views prune by stored knowledge; the images must be the restatement's bit for bit after every step: batches of several
+    frames, a pool that grows in the middle (64 blocks to begin with), an upload that switches the update to its general form, AddCube."""
+    cam = small_camera(4)
+    hcam = I.PinholeCamera()
+    hcam.fx, hcam.fy, hcam.cx, hcam.cy, hcam.width, hcam.height, hcam.depth_scale = cam
+    res = 0.01
+    ov = oracle.Volume(oracle.make_camera(*cam), voxel_res=res)
+    hv = I.CubeHandler(hcam, max_blocks=64)
+    hv.SetVoxelResolution(res)
+    views = [S.room_pose(i) for i in (5, 40)]
+    pruned = 0
+    fno = 0
+    for step, nf in enumerate((1, 3, 1, 5, 2, 1, 4, 1)):
+        for _ in range(nf):
+            pose = S.room_pose(fno); fno += 7
+            d, c = S.room_render(pose, width=cam[4], height=cam[5], fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3])
+            ov.integrate(d, c, pose); hv.IntegrateImage(d, c, pose)
+        if step == 4:                                 # a foreign writer in the middle: every voxel's sdf nudged, one block emptied
+            k, v = hv.GetCubeMap()
+            v = v.copy(); v[..., 0] *= np.float32(0.75); v[len(k) // 2, :, 1] = 0
+            hv.SetCubeMap(k, v); ov.clear(); ov.load(k, v)
+        if step == 6:
+            k1 = np.array([[3, -2, 40]], np.int32)   # CubeHandler::AddCube: a default block far from everything (an upload: invalidates, like step 4)
+            v1 = np.empty((1, 512, 5), np.float32); v1[..., 0], v1[..., 1], v1[..., 2:] = 999.0, 0.0, -1.0
+            hv.AddCubes(k1, v1); ov.load(k1, v1)
+        for p in views:
+            _raycast_equal(ov, hv, p)
+            pruned += hv.RaycastStats()["dropped_unloaded"]
+    assert pruned > 0                                 # (stored knowledge was in use)
+    _same(ov, hv)
 
 
 def test_raycast_of_uploaded_data_with_unobserved_voxels_nan_and_negative_weights(oracle):
