@@ -3,7 +3,8 @@ CONFIGURATION -- image sizes that are not multiples of 4 / 16 / 64 (narrow loads
 resolution, truncation, near / far planes, a starting pool of a few hundred blocks (growth + replay in the middle of a batch), frame counts
 that end batches at every fill level -- changes the parameters of a volume in use (truncation, planes, camera incl. its image size, resolution) and interleaves the other writers of a volume between fusions (Merge of a second volume, upload through
 SetCubeMap, Clear, AddCube), which switch the update between its plain and general forms.  HIP path vs oracle, keys and voxels bit for bit
-after every phase.  usage: fuzz_fusion_wide.py [seeds=20] [first_seed=0]"""
+after every phase.  With FUZZ_VIEWS=1 every phase and every operation is also followed by a raycast of the volume from the last frame's pose (depth bit for bit against
+the restatement): views BETWEEN fusions prune by the block summaries k_integrate keeps current.  usage: fuzz_fusion_wide.py [seeds=20] [first_seed=0]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -46,6 +47,22 @@ def same(ov, hv, what, seed):
     return good
 
 
+VIEWS = os.environ.get("FUZZ_VIEWS") == "1"
+pruned_total = 0
+
+
+def view(ov, hv, pose, hcam, ocam, what, seed):
+    """depth images of the volume as it is now, HIP raycaster vs the CPU restatement"""
+    global pruned_total
+    hd, _hn, _hc = hv.Raycast(pose, hcam)
+    od, _on, _oc = ov.raycast(pose, ocam)
+    pruned_total += hv.RaycastStats()["dropped_unloaded"]
+    good = np.array_equal(hd.view(np.uint32), od.view(np.uint32))
+    if not good:
+        print("seed %d: VIEW DIFFERENT after %s: %d pixels" % (seed, what, int((hd.view(np.uint32) != od.view(np.uint32)).sum())), flush=True)
+    return good
+
+
 bad = 0
 for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(77000 + seed)
@@ -76,6 +93,7 @@ for seed in range(first, first + n_seeds):
             hv.IntegrateImage(d, c, pose)
         log.append("fuse %d" % n)
         good = good and same(ov, hv, " / ".join(log), seed)
+        if VIEWS: good = view(ov, hv, pose, hcam, ocam, " / ".join(log), seed) and good
         op = rng.choice(["none", "merge", "upload", "clear", "addcube", "reconfigure"], p=[0.2, 0.25, 0.15, 0.1, 0.1, 0.2])
         if op == "reconfigure":  # the setters of a volume in use (CubeHandler.h:36-39,137-144,339-346): parameters change, the content stays
             what = rng.choice(["truncation", "planes", "camera", "resolution"])
@@ -116,8 +134,9 @@ for seed in range(first, first + n_seeds):
         log.append(op)
         if op != "none":
             good = good and same(ov, hv, " / ".join(log), seed)
+            if VIEWS: good = view(ov, hv, pose, hcam, ocam, " / ".join(log), seed) and good
     bad += not good
     print("seed %d: %dx%d %s res %.3f trunc %.2f near %.1f far %.1f pool %d: %s -> %d blocks %s" % (seed, w, h, "u16" if u16 else "f32", res, trunc, near, far, pool, ", ".join(log), ov.block_count(),
                                                                                               "bit-equal" if good else "DIFFERENT"), flush=True)
-print("%d of %d seeds differ" % (bad, n_seeds))
+print("%d of %d seeds differ" % (bad, n_seeds) + ("; views between the phases dropped %d blocks unloaded in total" % pruned_total if VIEWS else ""))
 sys.exit(1 if bad else 0)
