@@ -13,10 +13,17 @@ fuses global frames [r*K*F, (r+1)*K*F)), there is no communication during fusion
 region ends with the single RCCL reduce that merges the per-GPU block hashes (weak scaling).
 value = frames fused by all ranks / max-over-ranks wall time.
 
-Extra objects on the JSON line: roofline (integrate kernel, HIP-event timed on the volume's own
-stream, against 8 TB/s HBM), cpu_baseline (the CPU oracle = port of the reference path, timed on
-this box's host cores on a bounded sample of the same frames; N=1, rank 0 only), parity (the GPU
-volume for that sample compared bit-for-bit with the oracle's), icp (iterations/s at 307 200 points).
+The LAST stdout line is a compact JSON object (< 8 KB, tests/test_bench_line_cpu.py): the contract's keys plus roofline (the integrate
+kernel, HIP-event timed on the volume's own stream; frac = HBM bytes per launch / launch time / 8 TB/s), cpu_baseline (the CPU oracle =
+port of the reference path, timed on this box's host cores on a bounded sample of the same frames; N=1, rank 0 only), parity (the GPU
+volume for that sample compared bit-for-bit with the oracle's), icp (iterations/s at 307 200 points, the figure of the in-tolerance
+mode next to the default's), tracking, multi_gpu.  Everything else the sections measure goes to bench_detail.json next to this file
+(and to gpurun_out/ when that directory exists); `--full` adds the supplementary sections (raycast, volume ops, host images, sum form,
+depth filter), `--counters` re-measures the HBM counters with rocprofv3 instead of taking the committed ones (profiles/).
+
+N > 1: the merge inside the timed region is the PRODUCT's -- op_volume_merge_rccl (csrc/merge_rccl.hip) on an ncclComm_t this script
+makes (ncclGetUniqueId on rank 0, carried over the process group, ncclCommInitRank); `--merge-impl torch` selects the torch.distributed
+mirror of the same algorithm instead (onepiece_amd/distributed.py; what the gloo test hooks use).
 """
 import argparse
 import json
@@ -59,11 +66,21 @@ def main():
                     "every k_integrate launch in the trace then has the timed region's batch shape)")
     ap.add_argument("--summaries", action="store_true", help="A/B aid: raycast the empty volume once before the warm-up, so that the raycaster's block summaries exist and k_integrate "
                                                               "keeps them current inside the timed region (what a tracking-against-the-model pipeline does)")
-    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic / roofline.valu (~30 s)")
+    ap.add_argument("--merge-impl", choices=["auto", "cabi", "torch"], default="auto",
+                    help="the N > 1 merge: cabi = op_volume_merge_rccl on a communicator made here (the product's path; auto picks it on RCCL), "
+                         "torch = the torch.distributed mirror of the same algorithm (auto picks it on the gloo test hook)")
+    ap.add_argument("--full", action="store_true", help="also run the supplementary sections (raycast, volume ops, host images, general update, depth filter, sum form): "
+                                                         "they go to bench_detail.json, never to the result line")
+    ap.add_argument("--counters", action="store_true", help="re-measure roofline.traffic with rocprofv3 PMC passes (~30 s) instead of scaling the committed measurement "
+                                                             "(profiles/r06_integrate_counters.json) to this run's launch shape")
+    ap.add_argument("--save-counters", action="store_true", help="with --counters: rewrite profiles/r06_integrate_counters.json from this run")
+    ap.add_argument("--no-counters", action="store_true", help=argparse.SUPPRESS)   # rounds 3-5: the passes used to be on by default
+    ap.add_argument("--detail-file", default=None, help="where the full (uncompacted) object goes (default: bench_detail.json next to bench.py)")
     ap.add_argument("--profile-every", type=int, default=1, help="HIP-event sample rate for the roofline (every k-th launch group)")
     args = ap.parse_args()
     if args.timed_only:
-        args.no_cpu_baseline = args.no_icp = args.no_tracking = args.no_counters = True
+        args.no_cpu_baseline = args.no_icp = args.no_tracking = True
+        args.counters = args.full = False
 
     import torch
     import torch.distributed as dist
@@ -119,6 +136,20 @@ def main():
         if world > 1:
             dist.barrier()
 
+    distributed = world > 1 or force_dist
+    merge_impl, merge_fallback, comm = None, None, None
+    if distributed:
+        merge_impl = args.merge_impl if args.merge_impl != "auto" else ("cabi" if dist.get_backend() == "nccl" else "torch")
+    if merge_impl == "cabi":
+        # the product's communicator: ncclGetUniqueId on rank 0 -> the process group carries the 128 bytes -> ncclCommInitRank (torch's own RCCL, the one the merge binds)
+        comm = D.RcclCommunicator(rank, world, D.torch_exchange(dist))
+        assert comm.count() == world
+
+    def merge():
+        if merge_impl == "cabi":
+            return D.merge_volumes_rccl(hv, comm, root=0, algorithm=args.merge_algorithm, force_single_rank=force_dist)
+        return D.merge_volumes(ops, root=0, algorithm=args.merge_algorithm)
+
     if args.summaries:
         hv.Raycast(poses[0])
     # ---- warmup: W untimed steps (+ one merge so RCCL is initialised), then start from empty
@@ -126,8 +157,23 @@ def main():
         s = (w % K) * F
         hv.IntegrateSequence(depth[s:s + F], rgb[s:s + F], poses[s:s + F])
     hv.Synchronize()
-    if world > 1 or force_dist:
-        D.merge_volumes(ops, root=0, algorithm=args.merge_algorithm)
+    if distributed:
+        err = None
+        try:
+            merge()
+        except Exception as e:   # the library's merge returns its error on EVERY rank (agreement points): all ranks land here together
+            if merge_impl != "cabi":
+                raise
+            err = repr(e)[:300]
+        if merge_impl == "cabi":
+            # one agreement over the process group: if the C-ABI merge failed anywhere, every rank takes the mirror -- loudly (multi_gpu.merge_fallback)
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                merge_fallback = err or "op_volume_merge_rccl failed on another rank"
+                print("bench.py: op_volume_merge_rccl failed in the warm-up (%s): falling back to the torch.distributed mirror" % merge_fallback, file=sys.stderr, flush=True)
+                merge_impl = "torch"
+                hv.Clear()
     hv.Clear()
     hv.ProfileEnable(args.profile_every)
 
@@ -144,8 +190,8 @@ def main():
     n_union = None
     local_blocks = hv.BlockCount()
     t_m0 = time.perf_counter()
-    if world > 1 or force_dist:
-        n_union = D.merge_volumes(ops, root=0, algorithm=args.merge_algorithm)
+    if distributed:
+        n_union = merge()
         hv.Synchronize(); torch.cuda.synchronize()
     t_merge = time.perf_counter() - t_m0
     barrier()
@@ -160,8 +206,9 @@ def main():
     total_frames = n_local * world
     # what every rank did, so that a 1 -> 8 GPU curve decomposes into fusion and merge (gathered outside the timed region)
     mine = {"rank": rank, "frames": n_local, "fusion_ms": t_fuse * 1e3, "merge_ms": t_merge * 1e3, "local_blocks": int(local_blocks)}
-    if world > 1 or force_dist:   # what this rank put on the wire (onepiece_amd.distributed.last_stats)
-        mine.update({k: D.last_stats.get(k) for k in ("algorithm", "held_blocks", "owned_blocks", "wire_bytes_sent", "wire_bytes_received")})
+    if distributed:   # what this rank put on the wire (onepiece_amd.distributed.last_stats: op_merge_stats of the library call, or the mirror's own count)
+        mine.update({k: D.last_stats.get(k) for k in ("algorithm", "held_blocks", "owned_blocks", "wire_bytes_sent", "wire_bytes_received", "prepare_ms", "transfer_ms")})
+        mine["rccl_ranks"] = comm.count() if comm is not None else None
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
@@ -194,47 +241,39 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ImageSequenceIntegration: %d-frame synthetic 640x480 room sequence per GPU, %.4g m voxel, "
                                    "trunc 0.1 m, frames resident in HBM" % (n_local, args.voxel),
-                       "frames_per_step": F, "frames_per_gpu": n_local, "sharding": "contiguous frames per GPU, one RCCL reduce at end",
-                       "voxel_m": args.voxel,
-                       "update_mode": "exact: `value` is measured with the default update, whose voxels are bit-identical to the reference's CPU path; the opt-in sum form "
-                                      "(within 2e-6 of it, two decades inside north_star's 1e-4) is faster and reported under sum_form -- both answer north_star, only this one bit for bit"},
+                       "frames_per_step": F, "frames_per_gpu": n_local, "sharding": "contiguous frames per GPU, one RCCL merge at end",
+                       "voxel_m": args.voxel, "update_mode": "exact (voxels bit-identical to the reference's CPU path)"},
             "fusion_only_frames_per_s": total_frames / t_fuse_max,
             "pool": growth,   # the pool starts at 2^18 blocks and grows on demand INSIDE the timed region (grows / replayed batches since create)
             "merge_union_blocks": n_union,
-            "multi_gpu": {"ranks_in_process_group": (dist.get_world_size() if (world > 1 or force_dist) else 1),
-                          "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
-                          "merge_algorithm": per_rank[0].get("algorithm") if (world > 1 or force_dist) else None,
+            "multi_gpu": {"ranks": world, "ranks_in_process_group": (dist.get_world_size() if distributed else 1),
+                          "backend": (dist.get_backend() if distributed else None),
+                          # which code merged: "cabi" = op_volume_merge_rccl (csrc/merge_rccl.hip) on this script's own ncclComm_t, "torch" = the torch.distributed mirror
+                          "merge_impl": merge_impl, "merge_fallback": merge_fallback,
+                          "rccl_ranks": per_rank[0].get("rccl_ranks") if distributed else None,    # ncclCommCount of the communicator the library call ran on
+                          "merge_algorithm": per_rank[0].get("algorithm") if distributed else None,
                           "dense_reduce_bytes_per_rank_for_comparison": (int(n_union) * 10240 if n_union else 0),
-                          "wire_bytes_sent_per_rank": [p.get("wire_bytes_sent") for p in per_rank] if (world > 1 or force_dist) else None,
-                          "per_rank": per_rank,
-                          "note": "weak scaling: every rank fuses its own frames without communication (fusion_ms), then ONE merge (merge_ms, inside the timed region): the "
-                                  "owner-partitioned exchange -- every rank sends the blocks it HOLDS, in sum form, to their owner ranks (all pairs at once over xGMI's "
-                                  "point-to-point links), the owners add them up and send their partitions to rank 0, which normalises the whole map (the reference's Merge "
-                                  "semantics).  wire_bytes_sent = (held blocks of other ranks' partitions + the rank's own summed partition) x 10 248 B; the dense "
-                                  "reduce of rounds 1-4 put union x 10 240 B on every rank's link"},
+                          "wire_bytes_sent_per_rank": [p.get("wire_bytes_sent") for p in per_rank] if distributed else None,
+                          "per_rank": per_rank},
             "per_frame": {"blocks_selected": stats["blocks_selected"] / max(stats["frames"], 1),
                           "voxels_visited": stats["voxels_visited"] / max(stats["frames"], 1),
                           "voxels_updated": n_upd_frame, "final_blocks_rank0": hv.BlockCount()},
             "kernels_ms_per_launch": {"prepare_frames": prof["prepare_ms"], "select": prof["select_ms"], "integrate": prof["integrate_ms"],
                                       "event_sampled_launches": prof["launches"], "frames_per_launch": frames_per_launch},
-            # The integrate kernel with full batches is bound by instruction ISSUE: `frac` is filled in below from the SQ counters of this
-            # very step (tools/issue_model.py).  Until then (--no-counters, N > 1) the object carries the HBM view, which is a true
-            # fraction too: the bytes a batched launch must move / launch time / 8 TB/s.
-            "roofline": {"kernel": "k_integrate (Integrator::IntegrateImage, %.1f frames per launch)" % frames_per_launch,
+            # SURVEY 8(d) + the round-5 review: `frac` = the launch's HBM bytes / launch time / 8 TB/s.  `traffic` = the PMC counters' bytes per launch
+            # (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes: live with --counters, else the committed measurement scaled by this run's
+            # own byte model, see benchparts/roofline_extras.py); until it is filled in, the model (a lower bound of the traffic) stands in.
+            "roofline": {"kernel": "k_integrate<FAST,PLAIN,ZT=2> (Integrator::IntegrateImage), %.1f frames per launch" % frames_per_launch,
                          "bound": "hbm", "achieved": batch_bytes / k3_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": batch_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
-                         "avg_launch_ms": prof["integrate_ms"], "traffic": None,
-                         "hbm": {"bound": "hbm", "model_bytes_per_launch": batch_bytes, "model_gbs": batch_bytes / k3_s / 1e9, "peak": HBM_PEAK_GBS,
-                                 "model_frac": batch_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
-                                 "blocks_read_per_launch": stats["blocks_read"] / n_launch, "voxels_written_per_launch": stats["voxels_written"] / n_launch,
-                                 "note": "model = 10 240 B x blocks read + 20 B x voxels written + 8 B x W*H x frames per launch (counted on the device, "
-                                         "op_volume_stats_launches): a LOWER bound of the launch's HBM traffic"},
-                         "algorithmic_model": {"bytes_per_frame": alg_bytes_frame, "bytes_per_launch": alg_bytes, "gbs": alg_bytes / k3_s / 1e9,
-                                               "ratio_to_hbm_peak": alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
-                                               "note": "SURVEY 8(d): 40 B per updated voxel per FRAME + images, / launch time.  NOT a bound for a batched launch "
-                                                       "(it touches each voxel once per batch of up to 32 frames, so this ratio may exceed 1); it is one for "
-                                                       "a one-frame launch: see batch1"},
+                         "avg_launch_ms": prof["integrate_ms"], "frames_per_launch": frames_per_launch, "traffic": None, "traffic_source": "none: byte model (lower bound) used for achieved / frac",
+                         "model_bytes_per_launch": batch_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_frame": alg_bytes_frame,
+                         # 8(d)'s per-frame bytes x frames per launch / time / peak: NOT a bound for a batched launch (each voxel is loaded once, <= 32 frames are
+                         # applied in registers, stored once), hence > 1; it is a bound with one frame per launch: batch1_frac
+                         "algorithmic_ratio_to_peak": alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS,
                          "shader_cycles_per_launch": kc_cycles, "shader_clock_ghz": kc_cycles / k3_s / 1e9 if k3_s > 0 else None},
         }
+    sections = {}
     if rank == 0:
         # ---- everything below is supplementary (rank 0; most of it N = 1 only): one module per section under benchparts/
         import types
@@ -247,29 +286,106 @@ def main():
         if single and not args.no_cpu_baseline:
             from oracle import oracle as _oracle   # the cpu_baseline leg: the CPU oracle as the timed baseline and the parity checker, never on the measured path
             c.oracle = _oracle
-        if single and not args.timed_only:
-            raycast.run(c, out)            # first: the volume still holds the timed region's frames
-        if not args.timed_only:
-            roofline_extras.run(c, out)
-        if single and not args.timed_only:
-            volume_ops.run(c, out)
-            host_images.run(c, out)
-            general_update.run(c, out)
-            depth_filter.run(c, out)
-        if single and not args.no_cpu_baseline:
-            cpu_baseline.run(c, out)
-        if not args.no_icp:
-            icp.run(c, out)
-        if not args.no_tracking:
-            tracking.run(c, out)
-            dense_fusion.run(c, out)
 
+        def section(name, fn):
+            t_s = time.perf_counter()
+            fn(c, out)
+            sections[name] = round(time.perf_counter() - t_s, 2)
+
+        if single and args.full:
+            section("raycast", raycast.run)            # first: the volume still holds the timed region's frames
+        if not args.timed_only:
+            section("roofline_extras", roofline_extras.run)
+        if single and args.full:
+            section("volume_ops", volume_ops.run)
+            section("host_images", host_images.run)
+            section("general_update", general_update.run)
+            section("depth_filter", depth_filter.run)
+        if single and not args.no_cpu_baseline:
+            section("cpu_baseline", cpu_baseline.run)
+        if not args.no_icp:
+            section("icp", icp.run)
+        if not args.no_tracking:
+            section("tracking", tracking.run)
+            section("dense_fusion", dense_fusion.run)
+        out["section_seconds"] = sections
 
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1 or force_dist:
+        # the whole object goes to a file; the LAST stdout line is its compact form (the driver parses that line: round 5's 28 KB line was not parseable)
+        detail = args.detail_file or os.path.join(ROOT, "bench_detail.json")
+        wrote = []
+        for path in [detail] + ([os.path.join(ROOT, "gpurun_out", "bench_detail.json")] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and not args.detail_file else []):
+            try:
+                with open(path, "w") as f:
+                    json.dump(out, f, indent=1)
+                wrote.append(os.path.relpath(path, ROOT))
+            except OSError:
+                pass
+        line = json.dumps(compact(out, wrote), separators=(",", ":"))
+        assert len(line) < 8192, "the result line must stay under 8 KB (it is %d bytes)" % len(line)
+        sys.stdout.flush()
+        print(line, flush=True)
+    if comm is not None:
+        comm.destroy()
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _r(x, nd=4):
+    """Numbers to `nd` significant digits (the detail file keeps them whole)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def compact(full, detail_files=()):
+    """The result line: the contract's keys + roofline + cpu_baseline + parity + icp + tracking + multi_gpu, numbers only (prose lives in DESIGN.md and the detail file)."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: full["config"].get(k) for k in ("workload", "frames_per_step", "frames_per_gpu", "voxel_m", "update_mode")}
+    out["fusion_only_frames_per_s"] = full.get("fusion_only_frames_per_s")
+    R = full["roofline"]
+    out["roofline"] = {k: R.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms", "frames_per_launch",
+                                              "model_bytes_per_launch", "algorithmic_bytes_per_launch", "algorithmic_ratio_to_peak", "batch1_frac", "batch1_avg_launch_ms",
+                                              "issue_frac", "issue_source", "shader_clock_ghz") if k in R}
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = {k: full["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "host_cores", "cpu_model", "icp_iters_per_s", "icp_threads",
+                                                                        "tracks_per_s", "dense_fusion_frames_per_s") if k in full["cpu_baseline"]}
+    if "parity" in full:
+        out["parity"] = full["parity"]
+    if "icp" in full:
+        ic = full["icp"]
+        out["icp"] = {k: ic.get(k) for k in ("iters_per_s", "mode", "in_tolerance_iters_per_s", "in_tolerance_mode", "fp64_mode_iters_per_s", "points", "register_call_ms", "algorithmic_gbs") if k in ic}
+        if "replicas" in ic and "aggregate_iters_per_s" in ic["replicas"]:
+            out["icp"]["replicas"] = {k: ic["replicas"].get(k) for k in ("aggregate_iters_per_s", "speedup_over_one_context", "fp64_mode_aggregate_iters_per_s", "fp64_mode_speedup_over_one_context", "submitter", "in_flight_results_identical_to_sequential")}
+        pp = ic.get("pose_parity_over_pairs")
+        if pp:
+            out["icp"]["pose_parity"] = {k: pp.get(k) for k in ("pairs_checked", "bar", "default_mode_within_bar", "default_mode_max_rel_err", "fp64_mode_within_bar", "fp64_mode_max_rel_err", "fp64_mode_max_rel_err_vs_cpu_double_sums") if k in pp}
+    if "tracking" in full:
+        tr = full["tracking"]
+        out["tracking"] = {k: tr.get(k) for k in ("tracks_per_s", "reference_order_tracks_per_s", "from_raw_frames_tracks_per_s") if k in tr}
+    if "dense_fusion" in full:
+        df = full["dense_fusion"]
+        out["dense_fusion"] = {k: df.get(k) for k in ("frames_per_s", "frames_per_s_mode", "pairs_in_flight", "one_pair_at_a_time_frames_per_s", "frames") if k in df}
+        if isinstance(df.get("outside_tolerance_fp64_mode"), dict):
+            out["dense_fusion"]["fp64_mode_frames_per_s"] = df["outside_tolerance_fp64_mode"].get("frames_per_s")
+        pz = df.get("pose_parity")
+        if pz:
+            out["dense_fusion"]["pose_parity"] = {m: {k: v.get(k) for k in ("pair_rel_err_max_vs_cpu", "pairs_within_1e-4", "pairs")} for m, v in pz.items() if isinstance(v, dict)}
+    mg = full["multi_gpu"]
+    out["multi_gpu"] = {k: mg.get(k) for k in ("ranks", "backend", "merge_impl", "merge_fallback", "rccl_ranks", "merge_algorithm", "wire_bytes_sent_per_rank")}
+    out["multi_gpu"]["union_blocks"] = full.get("merge_union_blocks")
+    out["multi_gpu"]["per_rank"] = [{k: p.get(k) for k in ("rank", "frames", "fusion_ms", "merge_ms", "local_blocks", "owned_blocks")} for p in mg.get("per_rank", [])][:8]
+    out["per_frame"] = full.get("per_frame")
+    out["section_seconds"] = full.get("section_seconds")
+    out["detail"] = list(detail_files)
+    return _r(out)
 
 
 if __name__ == "__main__":

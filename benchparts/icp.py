@@ -29,6 +29,8 @@ def run(c, out):
     h = C.c_void_p()
     L.check(lib.op_icp_create(C.c_void_p(tgt.ctypes.data), C.c_void_p(nrm.ctypes.data), len(tgt), 0.01, L.OP_MEM_HOST, local_rank, C.byref(h)))
     L.check(lib.op_icp_set_source(h, C.c_void_p(src.ctypes.data), len(src), L.OP_MEM_HOST))
+    # a new context starts in the reference-order mode (OP_RUNTIME_OPT_ICP_DEFAULT_SUMS); the fp64 reduction -- the fast, order-free mode -- is measured first
+    L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_SUMS, L.OP_ICP_SUMS_FP64))
     res = L.IcpResult()
     T0 = np.eye(4, dtype=np.float32).reshape(16)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
@@ -63,13 +65,17 @@ def run(c, out):
         L.check(lib.op_icp_register(1, fp(src.reshape(-1)), len(src), fp(tgt.reshape(-1)), fp(nrm.reshape(-1)), len(tgt), fp(T0), 30, 0.01, local_rank,
                                     C.byref(r1), None, 0))
         reg_ms.append((time.perf_counter() - t) * 1e3)
-    out["icp"] = {"iters_per_s": gpu_it_s, "loop_only_iters_per_s": loop_it_s, "reference_order_sums_iters_per_s": ref_it_s, "iterations_per_call": iters, "points": int(len(src)),
-                  "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31)",
+    # The headline figure is the mode whose pose is within north_star's 1e-4 of the CPU path on EVERY pair: the reference-order float32 sums (the default of new
+    # contexts and of registration::PointToPlane).  tests/tools/icp_sigma_probe.py: no test on the fp64 sums can tell which iterations need that order.
+    out["icp"] = {"iters_per_s": ref_it_s, "mode": "point-to-plane, threshold 0.01 (ICPTest.cpp:31), reference-order float32 sums (OP_ICP_SUMS_REFERENCE_F32, the default): within 1e-4 of the CPU path on every pair",
+                  "in_tolerance_iters_per_s": ref_it_s, "in_tolerance_mode": "OP_ICP_SUMS_REFERENCE_F32",
+                  "fp64_mode_iters_per_s": gpu_it_s, "fp64_mode_loop_only_iters_per_s": loop_it_s, "reference_order_iters_per_s": ref_it_s,
+                  "iterations_per_call": iters, "points": int(len(src)),
                   "final_inliers": int(res.n_inliers), "estimate_normals_s": normals_s,
                   "register_call_ms": float(np.median(reg_ms[1:])), "register_call_iterations": 30,
                   # 36 B per source point per iteration (source + matched target + normal); the kernel is
                   # a latency-bound gather (27-cell scan), so this is far from the HBM roof by construction
-                  "algorithmic_gbs": 36.0 * len(src) * gpu_it_s / 1e9}
+                  "algorithmic_gbs": 36.0 * len(src) * ref_it_s / 1e9, "fp64_mode_algorithmic_gbs": 36.0 * len(src) * gpu_it_s / 1e9}
     # -- replicas in flight (ICP's only parallel axis): K contexts, each on its own stream and host thread (op_icp_run_enqueue / op_icp_wait),
     #    registering K DIFFERENT consecutive frame pairs of the sequence at once
     try:
@@ -83,12 +89,13 @@ def run(c, out):
             hk = C.c_void_p()
             L.check(lib.op_icp_create(C.c_void_p(tp.points.ctypes.data), C.c_void_p(tp.normals.ctypes.data), len(tp.points), 0.01, L.OP_MEM_HOST, local_rank, C.byref(hk)))
             L.check(lib.op_icp_set_source(hk, C.c_void_p(sp.ctypes.data), len(sp), L.OP_MEM_HOST))
+            L.check(lib.op_icp_set_option(hk, L.OP_ICP_OPT_SUMS, L.OP_ICP_SUMS_FP64))
             ctxs.append(hk); srcs.append(sp); tgts.append(tp.points); nrms.append(tp.normals)
         agg, results = {}, {}
         for Kc in (1, 2, 4, 8):
             res_k = [L.IcpResult() for _ in range(Kc)]
             best = None
-            for rep in range(3):
+            for rep in range(5):
                 t = time.perf_counter()
                 for k in range(Kc):
                     L.check(lib.op_icp_run_enqueue(ctxs[k], 1, fp(T0), iters, C.byref(res_k[k]), None, 0))
@@ -110,16 +117,16 @@ def run(c, out):
                                   "in_flight_results_identical_to_sequential": bool(same),
                                   "points": [int(len(x)) for x in srcs],
                                   "note": "K contexts x %d point-to-plane iterations on K different frame pairs, enqueued together (op_icp_run_enqueue: each on its own "
-                                          "stream and host thread) and waited for; aggregate = K x iterations / wall time, best of 3" % iters}
+                                          "stream and host thread) and waited for; aggregate = K x iterations / wall time, best of 5; fp64-reduction mode" % iters}
         # the reference-order mode (OP_ICP_SUMS_REFERENCE_F32: every iteration's 36 + 6 sums sequentially in float32, by one wave on the device): the mode that follows
         # the CPU path on EVERY pair -- the reference's own float32 sums decide, where J^T J sits at JacobiSVD's rank threshold, which way its pose goes
         strict_rates = {}
         for hk in ctxs:
             L.check(lib.op_icp_set_option(hk, L.OP_ICP_OPT_SUMS, L.OP_ICP_SUMS_REFERENCE_F32))
-        for Kc in (1, 4):
+        for Kc in (1, 4, 8):
             res_k = [L.IcpResult() for _ in range(Kc)]
             best = None
-            for rep in range(2):
+            for rep in range(3):
                 t = time.perf_counter()
                 for k in range(Kc):
                     L.check(lib.op_icp_run_enqueue(ctxs[k], 1, fp(T0), 20, C.byref(res_k[k]), None, 0))
@@ -128,7 +135,11 @@ def run(c, out):
                 dtk = time.perf_counter() - t
                 best = dtk if best is None else min(best, dtk)
             strict_rates[Kc] = Kc * 20 / best
-        out["icp"]["reference_order_mode"] = {"iters_per_s": strict_rates[1], "aggregate_iters_per_s_4_in_flight": strict_rates[4],
+        # the headline mode's replicas (ICP does not shard -- replicas only)
+        out["icp"]["replicas"].update({"aggregate_iters_per_s": {str(k): v for k, v in strict_rates.items()}, "speedup_over_one_context": max(strict_rates.values()) / strict_rates[1],
+                                       "fp64_mode_aggregate_iters_per_s": {str(k): v for k, v in agg.items()}, "fp64_mode_speedup_over_one_context": max(agg.values()) / agg[1],
+                                       "submitter": "one host thread per context (op_icp_run_enqueue / op_icp_wait)"})
+        out["icp"]["reference_order_mode"] = {"iters_per_s": strict_rates[1], "aggregate_iters_per_s_4_in_flight": strict_rates[4], "aggregate_iters_per_s_8_in_flight": strict_rates[8],
                                               "note": "OP_ICP_SUMS_REFERENCE_F32 with the sums on the device (k_seq_sums, the tracker's kernel): identical to the CPU path on every pair "
                                                       "(pose_parity_over_pairs below); 356 it/s in round 4, when the ordered rows went to one host thread every iteration"}
         if c.oracle is not None:   # per-pair parity of BOTH modes against the CPU path, and the CPU path against itself with double sums (10 iterations, four pairs)
@@ -151,7 +162,12 @@ def run(c, out):
                             "cpu": {"inliers": int(len(ref_k["pairs"])), "float_sums_vs_double_sums_rel_err": rel_(ref_k["T"], ref_d["T"])}})
             out["icp"]["pose_parity_over_pairs"] = {
                 "pairs": par, "iterations": 10, "bar": 1e-4,
-                "default_mode_within_bar": int(sum(p_["default_mode_fp64"]["returned_T_rel_err_vs_cpu"] <= 1e-4 for p_ in par)),
+                "pairs_checked": len(par),
+                "default_mode_within_bar": int(sum(p_["reference_order_mode"]["returned_T_rel_err_vs_cpu"] <= 1e-4 for p_ in par)),
+                "default_mode_max_rel_err": max(p_["reference_order_mode"]["returned_T_rel_err_vs_cpu"] for p_ in par),
+                "fp64_mode_within_bar": int(sum(p_["default_mode_fp64"]["returned_T_rel_err_vs_cpu"] <= 1e-4 for p_ in par)),
+                "fp64_mode_max_rel_err": max(p_["default_mode_fp64"]["returned_T_rel_err_vs_cpu"] for p_ in par),
+                "fp64_mode_max_rel_err_vs_cpu_double_sums": max(p_["default_mode_fp64"]["returned_T_rel_err_vs_cpu_with_double_sums"] for p_ in par),
                 "reference_order_mode_within_bar": int(sum(p_["reference_order_mode"]["returned_T_rel_err_vs_cpu"] <= 1e-4 for p_ in par)),
                 "note": "the reference sums J^T J / J^T r sequentially in float32 (ICP.cpp:121-136) and solves with JacobiSVD's rank threshold: on pairs whose system sits at that "
                         "threshold its OWN answer moves by up to 5e-2 when the same sums are taken in double (cpu.float_sums_vs_double_sums_rel_err).  The default mode (fp64 "

@@ -1,4 +1,5 @@
-"""The roofline object's extras: the one-frame-per-launch run (where SURVEY 8(d)'s bytes are a bound), the sum-form update, the live PMC passes.
+"""The roofline object's extras: the one-frame-per-launch run (where SURVEY 8(d)'s bytes are a bound), the HBM traffic of the batched launch
+(rocprofv3 PMC: live with --counters, else the committed measurement scaled to this run), and with --full the sum-form update.
 
 One section of bench.py's JSON line (bench.py builds the context `c` -- the fused volume, the frames in HBM, the timed region's counters -- and calls run(c, out))."""
 import json
@@ -26,14 +27,15 @@ def run(c, out):
     a1 = b1 / (p1["integrate_ms"] * 1e-3) / 1e9
     m1 = (10240.0 * st1["blocks_read"] + 20.0 * st1["voxels_written"]) / max(st1["launches"], 1) + 8.0 * W * H
     out["roofline"]["batch1_frac"] = a1 / HBM_PEAK_GBS   # SURVEY 8(d)'s bytes where they ARE a bound (one frame per launch) / time / 8 TB/s: north_star's ">= 50 % of HBM roofline"
-    out["roofline"]["hbm_frac"] = None                    # measured traffic of the batched launch / time / 8 TB/s; filled in by the counter passes below
+    out["roofline"]["batch1_avg_launch_ms"] = p1["integrate_ms"]
     out["roofline"]["batch1"] = {"frames": nb1, "bound": "hbm", "avg_launch_ms": p1["integrate_ms"], "algorithmic_bytes_per_launch": b1, "achieved": a1, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic_model_bytes_per_launch": m1, "traffic_model_frac": m1 / (p1["integrate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "evidence": "profiles/r04_batch1.kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/prof_driver.bin ... batch=1), "
-                                             "profiles/r04_batch1.FETCH_SIZE.pmc.csv / WRITE_SIZE.pmc.csv: 395 MB per launch measured = 0.63 of the 8 TB/s peak, the rate the "
-                                             "read-modify-write calibration kernel of the same shape reaches (profiles/r03_calib.timing.txt: 5.0 TB/s)",
+                                 "evidence": "profiles/r06_batch1.* (tools/profile_roofline.sh ... batch=1: rocprofv3 --kernel-trace --stats and the FETCH_SIZE / WRITE_SIZE passes of the final tree)",
                                  "note": "k_integrate with ONE frame per launch: SURVEY 8(d)'s algorithmic bytes are then a lower bound of the real traffic, "
                                          "so this is a true HBM roofline fraction (north_star: >= 50 % of HBM roofline on the integrate kernel)"}
+    _traffic(c, out)
+    if not args.full:
+        return
     # -- the opt-in sum-form update (OP_VOLUME_UPDATE_SUM_FORM): the same frames, one weighted mean per batch instead of one rounded update per frame
     fuse_all = lambda: [hv.IntegrateSequence(depth[k * F:(k + 1) * F], rgb[k * F:(k + 1) * F], poses[k * F:(k + 1) * F]) for k in range(K)]
     hv.Clear(); hv.SetUpdateMode("sum_form"); hv.ProfileEnable(args.profile_every)
@@ -66,8 +68,44 @@ def run(c, out):
             "max_abs_colour_diff": float(np.abs(v_ex[..., 2:] - v_sf[..., 2:])[obs].max()), "blocks": int(len(k_ex)), "frames": int(n_cmp), "bar": 1e-4}
         del k_sf, v_sf, k_ex, v_ex, obs
     hv.SetUpdateMode("exact")
+
+
+CACHE = os.path.join("profiles", "r06_integrate_counters.json")
+
+
+def _traffic(c, out):
+    """roofline.traffic / achieved / frac of the batched launch: rocprofv3 PMC bytes per launch.  Live (--counters: ~30 s of extra passes on a dump of this
+    step's frames), else the committed measurement of the same kernel on the same workload (profiles/r06_integrate_counters.json), carried over to this
+    run's launch shape through its ratio to the device-counted byte model -- which this run measures itself (blocks read, voxels written, frames per launch)."""
+    args, R = c.args, out["roofline"]
+    if c.world == 1 and args.counters:
+        _live_counters(c, out)
+        if R.get("traffic"):
+            R["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes, this run"
+            if args.save_counters:
+                json.dump({"traffic_bytes_per_launch": R["traffic"], "model_bytes_per_launch": c.batch_bytes, "traffic_over_model": R["traffic"] / c.batch_bytes,
+                           "frames_per_launch": c.frames_per_launch, "avg_launch_ms": c.prof["integrate_ms"], "valu_issue_frac": R.get("issue_frac"),
+                           "hbm": R.get("hbm"), "workload": out["config"]["workload"],
+                           "how": "python bench.py --counters --save-counters (tools/counters.py: rocprofv3 --kernel-trace --pmc, one group per pass, on tools/prof_driver.bin)"},
+                          open(os.path.join(c.ROOT, CACHE), "w"), indent=1)
+            return
+    try:
+        cj = json.load(open(os.path.join(c.ROOT, CACHE)))
+    except (OSError, ValueError):
+        return
+    tr = cj["traffic_over_model"] * c.batch_bytes
+    R.update({"traffic": tr, "achieved": tr / c.k3_s / 1e9, "frac": tr / c.k3_s / 1e9 / c.HBM_PEAK_GBS,
+              "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE at %.1f frames per launch: %.3g B) x this run's byte model / that run's (ratio %.3f); "
+                                "--counters measures live" % (CACHE, cj["frames_per_launch"], cj["traffic_bytes_per_launch"], cj["traffic_over_model"]),
+              "issue_frac": cj.get("valu_issue_frac"), "issue_source": CACHE + ": VALU wave-instructions x measured issue cost / SIMD cycles (what binds the batched launch)"})
+
+
+def _live_counters(c, out):
+    args, torch, dev, rank, world, local_rank, hv, depth, rgb, poses, K, F, n_local = c.args, c.torch, c.dev, c.rank, c.world, c.local_rank, c.hv, c.depth, c.rgb, c.poses, c.K, c.F, c.n_local
+    I, S, ROOT, W, H, HBM_PEAK_GBS = c.I, c.S, c.ROOT, c.W, c.H, c.HBM_PEAK_GBS
+    stats, prof, frames_per_launch, k3_s, kc_cycles, batch_bytes = c.stats, c.prof, c.frames_per_launch, c.k3_s, c.kc_cycles, c.batch_bytes
     # -- live PMC passes (separate rocprofv3 --pmc runs of the torch-free driver on a dump of this step's frames)
-    if world == 1 and not args.no_counters:
+    if True:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import counters as CT
@@ -96,6 +134,7 @@ def run(c, out):
                 if isinstance(kc[c], dict) and "mean_per_launch" in kc[c]:
                     kc[c]["mean_per_launch"] *= scale
             R["traffic"] = kc["hbm_bytes_per_launch"]
+            R["hbm"] = {"model_bytes_per_launch": batch_bytes}
             R["hbm"].update({"traffic_bytes_per_launch": kc["hbm_bytes_per_launch"], "read_bytes_per_launch": kc["hbm_read_bytes_per_launch"],
                              "write_bytes_per_launch": kc["hbm_write_bytes_per_launch"], "achieved": kc["hbm_bytes_per_launch"] / k3_s / 1e9, "unit": "GB/s",
                              "frac": kc["hbm_bytes_per_launch"] / k3_s / 1e9 / HBM_PEAK_GBS, "traffic_over_model": kc["hbm_bytes_per_launch"] / batch_bytes,
@@ -117,13 +156,10 @@ def run(c, out):
             mc = cj.get("mixed_check")
             additive_ok = bool(mc and mc.get("additive_model_holds"))
             valu_frac = im["classes"]["valu"]["share_of_capacity"]
-            R.update({"bound": "issue", "achieved": im["issue_cycles_per_launch"] if additive_ok else im["classes"]["valu"]["issue_cycles"],
-                      "peak": im["simd_cycles_per_launch"], "unit": "SIMD issue cycles per launch (shader clock)",
-                      "frac": im["frac"] if additive_ok else valu_frac,
-                      "frac_definition": ("sum over all instruction classes x measured issue cost / SIMD cycles (additive model, validated on a mixed-class "
-                                          "microbenchmark: predicted / measured = %.3f)" % mc["additive_over_measured"]) if additive_ok else
-                                         "VALU wave-instructions x measured issue cost / SIMD cycles (the additive all-class model is NOT validated%s: scalar work co-issues)"
-                                         % ((": it predicts %.2f x the mixed microbenchmark's time" % mc["additive_over_measured"]) if mc else ""),
+            # `frac` stays SURVEY 8(d)'s quantity (HBM bytes / time / peak); what actually binds the batched launch -- instruction issue -- goes under its own keys
+            R.update({"achieved": R["hbm"]["achieved"], "frac": R["hbm"]["frac"],
+                      "issue_frac": im["frac"] if additive_ok else valu_frac,
+                      "issue_source": "live SQ_INSTS_* x measured issue costs (%s) / SIMD cycles: %s" % (os.path.relpath(costs_file, ROOT), "all classes, additive model validated" if additive_ok else "VALU share (scalar work co-issues)"),
                       "valu_frac": valu_frac, "all_classes_additive_frac": im["frac"], "mixed_check": mc, "costs_file": os.path.relpath(costs_file, ROOT)})
             R["hbm_frac"] = R["hbm"]["frac"]      # measured HBM traffic of the batched launch / launch time / 8 TB/s
             R["issue"] = {"classes": im["classes"], "valu_cycles_each": im["valu_cycles_each"], "kernel_cycles": im["kernel_cycles"],

@@ -80,6 +80,14 @@ int op_runtime_hw_queues(int *requested);
  *   OP_RUNTIME_OPT_CACHE_DEVICE_BYTES     bytes of RELEASED device buffers (block pools, cell tables, images) the library keeps per device for the next
  *                                         request of a similar size instead of returning them to the driver (default 32 GB; 0 = keep none; buffers
  *                                         already kept stay until op_release_cached_memory)
+ *   OP_RUNTIME_OPT_MERGE_FAULT            TEST HOOK: stage * 1024 + rank + 1 makes that rank's allocation of that stage of the owner-exchange merge fail
+ *                                         (stage 1: the partition's sums after the exchange; stage 2: the root's gather buffers) -- every rank must then
+ *                                         return an error, nobody may wait inside RCCL (tests/test_config5_gpu.py); 0 = off (default)
+ *   OP_RUNTIME_OPT_ICP_DEFAULT_SUMS       the OP_ICP_OPT_SUMS mode of ICP contexts created afterwards (op_icp_create, op_icp_register, hence
+ *                                         registration::PointToPlane / PointToPoint of the class surface).  Default OP_ICP_SUMS_REFERENCE_F32: the reference's own
+ *                                         sequential float32 sums, the mode whose pose is within 1e-4 of the CPU path's on EVERY pair (~0.6 k iterations/s at
+ *                                         307 200 points); OP_ICP_SUMS_FP64 opts into the order-free fp64 reduction (~24 k iterations/s; equal to the CPU path
+ *                                         with double sums, but up to 1e-2 from its float32 answer where J^T J is rank-deficient -- DESIGN.md section 5)
  * op_runtime_set_rccl_library(path): the RCCL to bind at the first merge instead of "librccl.so.1" (a site build; the test suite names a
  *   host-memory double that runs several ranks on one device); NULL = the system's.  Fails once RCCL has been bound. */
 #define OP_RUNTIME_OPT_MERGE_ALGORITHM 0
@@ -88,6 +96,8 @@ int op_runtime_hw_queues(int *requested);
 #define OP_RUNTIME_OPT_TRACKER_GRAPH 3
 #define OP_RUNTIME_OPT_COPY_THREADS 4
 #define OP_RUNTIME_OPT_CACHE_DEVICE_BYTES 5
+#define OP_RUNTIME_OPT_MERGE_FAULT 6
+#define OP_RUNTIME_OPT_ICP_DEFAULT_SUMS 7
 #define OP_MERGE_OWNER_EXCHANGE 0
 #define OP_MERGE_DENSE_REDUCE 1
 int op_runtime_set_option(int option, long long value);
@@ -389,14 +399,18 @@ int op_icp_destroy(op_icp *icp);
  *       over 3e5 near-planar pairs their rounding is ~1e-3 of T, i.e. it is part of the reference's result.
  *     OP_ICP_FINISH_FP64: order-free fp64 reduction on the device (closer to the exact Kabsch of the pairs).
  *   OP_ICP_OPT_SUMS: the per-iteration sums (JTJ/JTr, ICP.cpp:121-136; the point-to-point Kabsch, :76-79).
- *     OP_ICP_SUMS_FP64 (default): fp64 reduction on the device, no host round trip in the point-to-point loop.
- *     OP_ICP_SUMS_REFERENCE_F32: every iteration's inlier rows are put in inlier order on the device and summed
+ *     (a new context starts in the process-wide OP_RUNTIME_OPT_ICP_DEFAULT_SUMS mode: OP_ICP_SUMS_REFERENCE_F32 unless the host opted into the fp64 reduction)
+ *     OP_ICP_SUMS_FP64: fp64 reduction on the device, no host round trip in the point-to-point loop: ~24 000 iterations/s at 307 200 points.  Equal to the
+ *       CPU path WITH DOUBLE SUMS to 1e-7; within 1e-4 of the reference's float32 answer only where that answer is stable (2 of the bench's 4 pairs).
+ *     OP_ICP_SUMS_REFERENCE_F32 (default): every iteration's inlier rows are put in inlier order on the device and summed
  *       sequentially in float32 as the reference does -- point-to-plane by one wave on the device (36 + 6 accumulators,
  *       one lane each; 42 numbers come back), point-to-point on one host thread after a transfer of the rows.  The
  *       per-iteration inlier counts and the poses then equal the CPU path's at any size and on every frame pair: where
  *       J^T J sits at JacobiSVD's rank threshold the reference's own float32 rounding decides which way its step goes
  *       (its pose moves by up to 5e-2 when the same sums are taken in double), and only this mode follows it there.
- *       ~600 iterations/s at 307 200 points against ~25 000 in the default mode.
+ *       ~600 iterations/s at 307 200 points against ~24 000 with the fp64 reduction.  No middle way exists: tests/tools/icp_sigma_probe.py
+ *       (profiles/r06_icp_sigma_probe.txt) shows the smallest eigenvalue of the float32 J^T J is summation noise in EVERY iteration, so no test on the fp64
+ *       sums can tell which iterations need the reference's order.
  *   OP_ICP_OPT_TIES: which target a source point is paired with when its nearest candidates are EXACTLY equidistant (duplicated
  *     target points, clouds on a lattice, quantised coordinates; on depth-derived clouds a chance event of ~1e-7 per query).
  *     OP_ICP_TIES_REFERENCE (default): the target the reference's kd-tree (nanoflann 1.3.2 as Geometry/KDTree.h:62-98,171-190 drives it)

@@ -1359,7 +1359,11 @@ static int icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, 
 
 int op_icp_create(const float* tgt_xyz, const float* tgt_normals, size_t m, double threshold, int mem, int device, op_icp** out) {
     if (!(threshold > 0)) return fail(OP_ERR_INVALID, "threshold must be > 0");
-    return icp_create(tgt_xyz, tgt_normals, m, threshold, 0.0, mem, device, out);
+    OP_TRY(icp_create(tgt_xyz, tgt_normals, m, threshold, 0.0, mem, device, out));
+    // OP_RUNTIME_OPT_ICP_DEFAULT_SUMS: the reference's own sequential float32 sums unless the process opted into the fp64 reduction (the mode that is
+    // within north_star's 1e-4 of the CPU path on every pair is the default of the drop-in surface)
+    (*out)->sums = op::runtime_options().icp_default_sums.load();
+    return OP_OK;
 }
 
 int op_icp_destroy(op_icp* c) {

@@ -20,7 +20,7 @@
 //   every rank packs the WHOLE union (zeros where it holds nothing), one sliced ncclReduce(sum) to the root, normalise.
 //
 // Temporaries come from the library's buffer cache (a steady stream of merges allocates nothing); rank-local failures are
-// agreed on over the communicator before the bulk transfer, so no rank is left waiting inside RCCL.
+// agreed on over the communicator before EVERY bulk transfer (the exchange and the gather), so no rank is left waiting inside RCCL.
 // Keys and weights are exact for any rank count; sdf / colour differ from a sequential Merge chain only in fp32
 // summation order (<= 1e-6 relative).  RCCL is bound at run time (dlopen "librccl.so.1", or the library
 // op_runtime_set_rccl_library named before the first merge): a host that never merges -- or a Python process whose torch
@@ -404,6 +404,8 @@ static int merge_owner_exchange(op_volume* v, void* nccl_comm, int root, size_t*
     const auto t_begin = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     auto t_xfer = t_begin;
+    // OP_RUNTIME_OPT_MERGE_FAULT (test hook): does `stage`'s allocation of THIS rank "fail"?
+    auto injected = [&](int stage) { return op::runtime_options().merge_fault.load() == (long long)stage * 1024 + rank + 1; };
 
     // 1. this rank's keys, sorted by owner; its blocks packed in that order
     if (op::cached_malloc((void**)&d_small, ((size_t)world + (size_t)world * world + 4) * sizeof(int)) != hipSuccess) d_small = nullptr;
@@ -499,39 +501,46 @@ static int merge_owner_exchange(op_volume* v, void* nccl_comm, int root, size_t*
             }
         }
     }
-    // 5. the owner's sorted union, and the sum over the sources in rank order.  (From here on a local failure cannot be agreed on before the gather's
-    //    group without another round trip; the buffers are allocated, what can still fail is the device itself: fatal.)
+    // 5. the owner's sorted union, and the sum over the sources in rank order.  A failure here (the sort, the sort's scratch, the partition's
+    //    sums -- n_own x 10 KiB, only known now) is rank-LOCAL: it is announced in step 6's all-gather (-1), so that all ranks leave together.
     if (n_recv) {
-        if (rocprim::radix_sort_keys(nullptr, tmp_b, d_rkeys, d_uni_sorted, n_recv, 0, 64, stream) != hipSuccess ||
-            rocprim::unique(nullptr, tmp_c, d_uni_sorted, d_own, d_nuniq, n_recv, rocprim::equal_to<unsigned long long>(), stream) != hipSuccess) { rc = fail(OP_ERR_HIP, "sort setup failed"); fatal = true; goto done; }
-        if (d_tmp && (tmp_b > tmp_a || tmp_c > tmp_a)) { (void)hipStreamSynchronize(stream); op::cached_free(d_tmp); d_tmp = nullptr; }
-        if (!d_tmp && op::cached_malloc(&d_tmp, std::max(tmp_a, std::max(tmp_b, tmp_c))) != hipSuccess) { rc = fail(OP_ERR_HIP, "no memory for the union sort"); fatal = true; goto done; }
-        if (rocprim::radix_sort_keys(d_tmp, tmp_b, d_rkeys, d_uni_sorted, n_recv, 0, 64, stream) != hipSuccess ||
-            rocprim::unique(d_tmp, tmp_c, d_uni_sorted, d_own, d_nuniq, n_recv, rocprim::equal_to<unsigned long long>(), stream) != hipSuccess ||
-            hipMemcpyAsync(&nuniq, d_nuniq, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
-            rc = fail(OP_ERR_HIP, "building the partition's union failed"); fatal = true; goto done;
+        OP_LOCAL(rocprim::radix_sort_keys(nullptr, tmp_b, d_rkeys, d_uni_sorted, n_recv, 0, 64, stream));
+        OP_LOCAL(rocprim::unique(nullptr, tmp_c, d_uni_sorted, d_own, d_nuniq, n_recv, rocprim::equal_to<unsigned long long>(), stream));
+        if (rc == OP_OK && d_tmp && (tmp_b > tmp_a || tmp_c > tmp_a)) { (void)hipStreamSynchronize(stream); op::cached_free(d_tmp); d_tmp = nullptr; }
+        if (rc == OP_OK && !d_tmp) OP_LOCAL(op::cached_malloc(&d_tmp, std::max(tmp_a, std::max(tmp_b, tmp_c))));
+        OP_LOCAL(rocprim::radix_sort_keys(d_tmp, tmp_b, d_rkeys, d_uni_sorted, n_recv, 0, 64, stream));
+        OP_LOCAL(rocprim::unique(d_tmp, tmp_c, d_uni_sorted, d_own, d_nuniq, n_recv, rocprim::equal_to<unsigned long long>(), stream));
+        OP_LOCAL(hipMemcpyAsync(&nuniq, d_nuniq, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        OP_LOCAL(hipStreamSynchronize(stream));
+        if (rc == OP_OK) {
+            n_own = nuniq;
+            if (injected(1)) rc = fail(OP_ERR_HIP, "no memory for the partition's sums (injected)");
+            OP_LOCAL(op::cached_malloc((void**)&d_acc, n_own * kBlk * sizeof(float)));
+            OP_LOCAL(hipMemsetAsync(d_acc, 0, n_own * kBlk * sizeof(float), stream));
         }
-        n_own = nuniq;
-        if (op::cached_malloc((void**)&d_acc, n_own * kBlk * sizeof(float)) != hipSuccess) { rc = fail(OP_ERR_HIP, "no memory for the partition's sums"); fatal = true; goto done; }
-        if (hipMemsetAsync(d_acc, 0, n_own * kBlk * sizeof(float), stream) != hipSuccess) { rc = fail(OP_ERR_HIP, "memset failed"); fatal = true; goto done; }
-        hipLaunchKernelGGL(k_find_in_union, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, stream, (const unsigned long long*)d_rkeys, n_recv, (const unsigned long long*)d_own, n_own, d_idx);
-        for (int s = 0; s < world; ++s) {
-            const size_t ns = roff[(size_t)s + 1] - roff[(size_t)s];
-            if (ns) hipLaunchKernelGGL(k_accumulate_blocks, dim3((unsigned)ns), dim3(512), 0, stream, d_acc, (const float*)(d_recv + roff[(size_t)s] * kBlk), (const unsigned*)(d_idx + roff[(size_t)s]));
+        if (rc == OP_OK) {
+            hipLaunchKernelGGL(k_find_in_union, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, stream, (const unsigned long long*)d_rkeys, n_recv, (const unsigned long long*)d_own, n_own, d_idx);
+            for (int s = 0; s < world; ++s) {
+                const size_t ns = roff[(size_t)s + 1] - roff[(size_t)s];
+                if (ns) hipLaunchKernelGGL(k_accumulate_blocks, dim3((unsigned)ns), dim3(512), 0, stream, d_acc, (const float*)(d_recv + roff[(size_t)s] * kBlk), (const unsigned*)(d_idx + roff[(size_t)s]));
+            }
         }
     }
-    // 6. sizes of the partitions
+    // 6. sizes of the partitions (a rank whose step 5 failed announces -1: every rank sees it and leaves -- a common exit, like step 2's)
     {
-        const int mine = (int)n_own;
-        if (hipMemcpyAsync(d_small, &mine, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { rc = fail(OP_ERR_HIP, "count upload failed"); fatal = true; goto done; }
+        const int mine = rc == OP_OK ? (int)n_own : -1;
+        if (hipMemcpyAsync(d_small, &mine, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { if (rc == OP_OK) rc = fail(OP_ERR_HIP, "count upload failed"); fatal = true; goto done; }
         OP_NCCL(rccl().AllGather(d_small, d_small + world, 1, ncclInt32, comm, stream));
         if (hipMemcpyAsync(owned.data(), d_small + world, (size_t)world * sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
             rc = fail(OP_ERR_HIP, "reading the partition sizes failed"); fatal = true; goto done;
         }
-        for (int r = 0; r < world; ++r) n_union += (size_t)owned[(size_t)r];
+        for (int r = 0; r < world; ++r) {
+            if (owned[(size_t)r] < 0) { if (rc == OP_OK) rc = fail(OP_ERR_HIP, "rank %d could not sum its partition of the merge", r); goto done; }
+            n_union += (size_t)owned[(size_t)r];
+        }
     }
     if (root < 0) {
-        // 7a. no gather: this rank's volume becomes its owned, merged partition
+        // 7a. no gather: this rank's volume becomes its owned, merged partition (no collective follows: what fails from here on is this rank's own error)
         if (n_own) {
             if (op::cached_malloc((void**)&d_allkeys, n_own * 3 * sizeof(int)) != hipSuccess) { rc = fail(OP_ERR_HIP, "no memory for the partition's keys"); goto done; }
             hipLaunchKernelGGL(k_unpack_keys, dim3((unsigned)((n_own + 255) / 256)), dim3(256), 0, stream, (const unsigned long long*)d_own, n_own, d_allkeys);
@@ -540,12 +549,27 @@ static int merge_owner_exchange(op_volume* v, void* nccl_comm, int root, size_t*
         } else
             rc = op_volume_clear(v);
     } else {
-        // 7b. the owners send their summed partitions to the root, which normalises the whole map into its volume
+        // 7b. the owners send their summed partitions to the root, which normalises the whole map into its volume.  The root's gather buffers
+        //     (n_union x 10 KiB: the largest allocation of the merge) come first, and ONE more agreement: if the root has no room for them,
+        //     no owner enters the group -- everybody returns the error instead of waiting in ncclSend.
         std::vector<size_t> goff((size_t)world + 1, 0);
         for (int r = 0; r < world; ++r) goff[(size_t)r + 1] = goff[(size_t)r] + (size_t)owned[(size_t)r];
         if (rank == root && n_union) {
-            if (op::cached_malloc((void**)&d_gkeys, n_union * 8) != hipSuccess || op::cached_malloc((void**)&d_gather, n_union * kBlk * sizeof(float)) != hipSuccess ||
-                op::cached_malloc((void**)&d_allkeys, n_union * 3 * sizeof(int)) != hipSuccess) { rc = fail(OP_ERR_HIP, "no memory for the gathered map"); fatal = true; goto done; } // (the others are about to send: fatal)
+            if (injected(2)) rc = fail(OP_ERR_HIP, "no memory for the gathered map (injected)");
+            OP_LOCAL(op::cached_malloc((void**)&d_gkeys, n_union * 8));
+            OP_LOCAL(op::cached_malloc((void**)&d_gather, n_union * kBlk * sizeof(float)));
+            OP_LOCAL(op::cached_malloc((void**)&d_allkeys, n_union * 3 * sizeof(int)));
+        }
+        {
+            int* d_flag = d_small + world + world * world + 1;
+            const int bad = rc != OP_OK;
+            if (hipMemcpyAsync(d_flag, &bad, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) { rc = fail(OP_ERR_HIP, "status upload failed"); fatal = true; goto done; }
+            OP_NCCL(rccl().AllReduce(d_flag, d_flag, 1, ncclInt32, ncclMax, comm, stream));
+            int any = 0;
+            if (hipMemcpyAsync(&any, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+                rc = fail(OP_ERR_HIP, "status download failed"); fatal = true; goto done;
+            }
+            if (any) { if (rc == OP_OK) rc = fail(OP_ERR_HIP, "the root could not allocate the gathered map"); goto done; }
         }
         OP_NCCL(rccl().GroupStart());
         if (rank == root) {

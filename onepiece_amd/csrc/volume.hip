@@ -678,6 +678,12 @@ int op_runtime_set_option(int option, long long value) {
         case OP_RUNTIME_OPT_COPY_THREADS:
             if (value < 0 || value > 8) return fail(OP_ERR_INVALID, "op_runtime_set_option: %lld copy threads (0 .. 8)", value);
             o.copy_threads.store((int)value); return OP_OK;
+        case OP_RUNTIME_OPT_ICP_DEFAULT_SUMS:
+            if (value != OP_ICP_SUMS_FP64 && value != OP_ICP_SUMS_REFERENCE_F32) return fail(OP_ERR_INVALID, "op_runtime_set_option: unknown ICP sums mode %lld", value);
+            o.icp_default_sums.store((int)value); return OP_OK;
+        case OP_RUNTIME_OPT_MERGE_FAULT:
+            if (value < 0) return fail(OP_ERR_INVALID, "op_runtime_set_option: merge fault %lld", value);
+            o.merge_fault.store(value); return OP_OK;
         case OP_RUNTIME_OPT_CACHE_DEVICE_BYTES:
             if (value < 0) return fail(OP_ERR_INVALID, "op_runtime_set_option: cache limit %lld", value);
             o.cache_device_bytes.store(value); return OP_OK;

@@ -219,7 +219,10 @@ def merge_volumes(ops, root=0, group=None, chunk_blocks=32768, algorithm="owner"
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _forced()):
-        return int(ops.keys().shape[0])
+        n = int(ops.keys().shape[0])   # one rank: it holds and owns the whole map, nothing crosses a wire
+        last_stats.clear()
+        last_stats.update({"algorithm": "none", "ranks": 1, "rank": 0, "held_blocks": n, "owned_blocks": n, "union_blocks": n, "wire_bytes_sent": 0, "wire_bytes_received": 0})
+        return n
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if algorithm == "owner":
@@ -253,8 +256,9 @@ def merge_volumes(ops, root=0, group=None, chunk_blocks=32768, algorithm="owner"
     n_union = int(union.shape[0])
     last_stats.clear()
     last_stats.update({"algorithm": "dense", "ranks": world, "rank": rank, "held_blocks": int(keys.shape[0]), "owned_blocks": n_union if rank == root else 0,
-                       "union_blocks": n_union, "wire_bytes_sent": (n_union * 10240 if rank != root else 0) + (world - 1) * mx * 12,
-                       "wire_bytes_received": n_union * 10240 + (world - 1) * mx * 12})
+                       "union_blocks": n_union, "wire_bytes_sent": (n_union * 10240 if rank != root and world > 1 else 0) + (world - 1) * mx * 12,
+                       # the reduced payload ends on the root only (what a ring's inner ranks forward is RCCL's business); everybody receives the gathered keys
+                       "wire_bytes_received": (n_union * 10240 if rank == root and world > 1 else 0) + (world - 1) * mx * 12})
     if n_union == 0:
         return 0
     # `union` was produced by torch ops queued on torch's stream, the pack / unpack kernels run on the volume's own
@@ -299,3 +303,101 @@ def _merge_pipelined(ops, dist, union, spans, root, group, is_root, sync):
             ops.unpack_chunk(lo, bufs[i])
         bufs[i] = None
     return n_union
+
+
+# ---- the product path: op_volume_merge_rccl on a communicator of the caller's own ------------------------------------------------------
+class RcclCommunicator:
+    """An ncclComm_t for op_volume_merge_rccl (csrc/merge_rccl.hip), made the way any RCCL host program makes one: rank 0 draws a unique id,
+    the caller carries its 128 bytes to the other ranks (`exchange`: bytes-or-None -> bytes; over torch.distributed's store, MPI, a file ...),
+    every rank calls ncclCommInitRank on the device that is current.  The library named here is also the one the merge binds
+    (op_runtime_set_rccl_library), so that communicator and collectives come from ONE RCCL -- in a torch process, torch's own copy.
+    """
+
+    def __init__(self, rank, world, exchange, library=None):
+        if library is None:
+            library = default_rccl_library()
+        self.library = library
+        self._rccl = C.CDLL(library, mode=C.RTLD_GLOBAL)
+
+        class _UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_ubyte * 128)]   # ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+
+        uid = _UniqueId()
+        self._rccl.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        self._rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        self._rccl.ncclGetErrorString.restype = C.c_char_p
+        if rank == 0:
+            self._check(self._rccl.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        raw = exchange(bytes(uid.internal) if rank == 0 else None)
+        if len(raw) != 128:
+            raise ValueError("the exchanged ncclUniqueId has %d bytes, not 128" % len(raw))
+        C.memmove(C.byref(uid), raw, 128)
+        rc = L.load().op_runtime_set_rccl_library(library.encode())
+        if rc != L.OP_OK and not getattr(RcclCommunicator, "_bound", None) == library:   # already bound by an earlier merge of this process: fine if it is the same library
+            L.check(rc)
+        RcclCommunicator._bound = library
+        self.comm = C.c_void_p()
+        self._check(self._rccl.ncclCommInitRank(C.byref(self.comm), int(world), uid, int(rank)), "ncclCommInitRank")
+        self.rank, self.world = int(rank), int(world)
+
+    def _check(self, r, what):
+        if r != 0:
+            raise RuntimeError("%s failed: %s" % (what, self._rccl.ncclGetErrorString(r).decode()))
+
+    def count(self):
+        """ncclCommCount: the ranks RCCL itself says this communicator has."""
+        n = C.c_int(0)
+        self._check(self._rccl.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
+        return n.value
+
+    def destroy(self):
+        if self.comm:
+            self._rccl.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+def default_rccl_library():
+    """torch's own librccl.so when torch is importable (a second copy of RCCL in one process is asking for trouble), else the system's."""
+    import os
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            return cand
+    except ImportError:
+        pass
+    return "librccl.so.1"
+
+
+def torch_exchange(dist, group=None):
+    """`exchange` for RcclCommunicator over an initialised torch.distributed process group (any backend)."""
+    def ex(raw):
+        box = [raw]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+    return ex
+
+
+_ALGORITHMS = {"owner": L.OP_MERGE_OWNER_EXCHANGE, "dense": L.OP_MERGE_DENSE_REDUCE}
+
+
+def merge_volumes_rccl(handler, comm, root=0, algorithm="owner", force_single_rank=False):
+    """CubeHandler::MergeAcrossRanks: ONE library call, op_volume_merge_rccl_stats, on `comm` (an RcclCommunicator or a raw ncclComm_t
+    address) -- the C++ class surface's path (host/one_piece/src/CubeHandler.cpp) and what bench.py --gpus N times.  root=None: no
+    gather, every rank keeps its owned partition.  Returns the union's block count; `last_stats` says what crossed the wire."""
+    lib = L.load()
+    L.check(lib.op_runtime_set_option(L.OP_RUNTIME_OPT_MERGE_ALGORITHM, _ALGORITHMS[algorithm]))
+    L.check(lib.op_runtime_set_option(L.OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK, 1 if force_single_rank else 0))
+    st = L.MergeStats()
+    n = C.c_size_t(0)
+    raw = comm.comm if isinstance(comm, RcclCommunicator) else C.c_void_p(comm)
+    rc = lib.op_volume_merge_rccl_stats(handler._h, raw, -1 if root is None else int(root), C.byref(n), C.byref(st))
+    last_stats.clear()
+    last_stats.update({"algorithm": "owner" if st.algorithm == L.OP_MERGE_OWNER_EXCHANGE else "dense", "impl": "op_volume_merge_rccl", "ranks": st.ranks, "rank": st.rank,
+                       "held_blocks": int(st.held_blocks), "owned_blocks": int(st.owned_blocks), "union_blocks": int(st.union_blocks),
+                       "wire_bytes_sent": int(st.wire_bytes_sent), "wire_bytes_received": int(st.wire_bytes_received),
+                       "prepare_ms": st.prepare_ms, "transfer_ms": st.transfer_ms, "total_ms": st.total_ms, "slices": int(st.slices)})
+    L.check(rc)
+    return int(n.value)

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     float voxel = 0.02f;
     int root = 0, fail_rank = -1, devices = 1;
     std::string rccl_library, algorithm = "owner";
-    long long slice_blocks = 0;
+    long long slice_blocks = 0, fault = 0;
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--shards") && i + 1 < argc) shards_arg = argv[++i];
         else if (!strcmp(argv[i], "--voxel") && i + 1 < argc) voxel = (float)atof(argv[++i]);
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--rccl-library") && i + 1 < argc) rccl_library = argv[++i];
         else if (!strcmp(argv[i], "--algorithm") && i + 1 < argc) algorithm = argv[++i];
         else if (!strcmp(argv[i], "--slice-blocks") && i + 1 < argc) slice_blocks = atoll(argv[++i]);
+        else if (!strcmp(argv[i], "--fault") && i + 1 < argc) fault = atoll(argv[++i]);   // OP_RUNTIME_OPT_MERGE_FAULT: stage * 1024 + rank + 1
     }
     std::vector<std::pair<int, int>> shards;
     for (size_t p = 0; p < shards_arg.size();) {
@@ -57,6 +58,7 @@ int main(int argc, char** argv) {
     if (world < 1 || root < -1 || root >= world) { fprintf(stderr, "bad world / root\n"); return 2; }
     if (op_runtime_set_option(OP_RUNTIME_OPT_MERGE_ALGORITHM, algorithm == "dense" ? OP_MERGE_DENSE_REDUCE : OP_MERGE_OWNER_EXCHANGE) != OP_OK ||
         op_runtime_set_option(OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS, slice_blocks) != OP_OK ||
+        op_runtime_set_option(OP_RUNTIME_OPT_MERGE_FAULT, fault) != OP_OK ||
         op_runtime_set_rccl_library(rccl_library.empty() ? nullptr : rccl_library.c_str()) != OP_OK) { fprintf(stderr, "%s\n", op_last_error()); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }

@@ -133,7 +133,7 @@ def _expected(frames, shards, cam, voxel, root):
     return _sorted_map(vols[root]), hcam, [v.BlockCount() for v in vols[:root]] + [None] + [v.BlockCount() for v in vols[root + 1:]]
 
 
-def _run_world(tmp_path, shards, voxel, root=0, fail_rank=None, slice_blocks=None, algorithm="owner", timeout=300):
+def _run_world(tmp_path, shards, voxel, root=0, fail_rank=None, slice_blocks=None, algorithm="owner", timeout=300, fault=None):
     build_double_and_driver()
     mp = str(tmp_path / "merged.map")
     cmd = [WORLD, str(tmp_path / "frames.bin"), mp, "--shards", ",".join("%d-%d" % s for s in shards), "--voxel", str(voxel), "--root", str(root),
@@ -142,6 +142,8 @@ def _run_world(tmp_path, shards, voxel, root=0, fail_rank=None, slice_blocks=Non
         cmd += ["--slice-blocks", str(slice_blocks)]
     if fail_rank is not None:
         cmd += ["--fail-rank", str(fail_rank)]
+    if fault:
+        cmd += ["--fault", str(fault)]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)   # a rank left waiting in a collective = a timeout here
     assert run.stdout.strip(), run.stderr
     return run, json.loads(run.stdout.strip().splitlines()[-1]), mp
@@ -244,3 +246,18 @@ def test_merge_rccl_rank_with_a_failed_volume_fails_everywhere_without_hanging(h
     assert all(p["status"] != 0 for p in r["per_rank"]), r          # nobody "succeeds" with a partial merge
     assert "bounding box" in r["per_rank"][1]["error"]               # the failing rank reports ITS failure ...
     assert all("rank 1 entered the merge with a failed volume" in r["per_rank"][k]["error"] for k in (0, 2))   # ... the others whose it was
+
+
+@pytest.mark.parametrize("stage,rank,root,whose", [(1, 2, 0, "rank 2 could not sum its partition"), (2, 1, 1, "the root could not allocate the gathered map")])
+def test_merge_rccl_allocation_failure_after_the_exchange_fails_everywhere_without_hanging(hip, tmp_path, stage, rank, root, whose):
+    """The two allocations whose size is only known AFTER the exchange -- an owner's partition sums (n_own x 10 KiB) and the root's gather
+    buffers (n_union x 10 KiB, the largest of the merge) -- are agreed on before the next transfer: a rank that cannot get them (injected:
+    OP_RUNTIME_OPT_MERGE_FAULT) makes EVERY rank return an error instead of leaving its peers inside ncclSend / the all-gather."""
+    cam = small_camera(4)
+    frames = _write_frames(str(tmp_path / "frames.bin"), [100 + 7 * i for i in range(9)], cam)
+    del frames
+    run, r, _ = _run_world(tmp_path, [(0, 3), (3, 6), (6, 9)], 0.02, root=root, timeout=120, fault=stage * 1024 + rank + 1)
+    assert run.returncode != 0 and r["ok"] is False
+    assert all(p["status"] != 0 for p in r["per_rank"]), r
+    assert "(injected)" in r["per_rank"][rank]["error"]
+    assert all(whose in r["per_rank"][k]["error"] for k in range(3) if k != rank), r
