@@ -369,7 +369,7 @@ def compact(full, detail_files=()):
             out["icp"]["pose_parity"] = {k: pp.get(k) for k in ("pairs_checked", "bar", "default_mode_within_bar", "default_mode_max_rel_err", "fp64_mode_within_bar", "fp64_mode_max_rel_err", "fp64_mode_max_rel_err_vs_cpu_double_sums") if k in pp}
     if "tracking" in full:
         tr = full["tracking"]
-        out["tracking"] = {k: tr.get(k) for k in ("tracks_per_s", "reference_order_tracks_per_s", "from_raw_frames_tracks_per_s") if k in tr}
+        out["tracking"] = {k: tr.get(k) for k in ("tracks_per_s", "mode", "fp64_mode_tracks_per_s", "from_raw_frames_tracks_per_s") if k in tr}
     if "dense_fusion" in full:
         df = full["dense_fusion"]
         out["dense_fusion"] = {k: df.get(k) for k in ("frames_per_s", "frames_per_s_mode", "pairs_in_flight", "one_pair_at_a_time_frames_per_s", "frames") if k in df}

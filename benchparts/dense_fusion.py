@@ -90,7 +90,7 @@ def run(c, out):
                        "reference_order_f32": {"pair_rel_err_max_vs_cpu": pr["pair_rel_err_max"], "pairs_within_1e-4": pr["pairs_within_1e-4"], "pairs": pr["pairs"],
                                                "meets_1e-4_on_every_pair": pr["pairs_within_1e-4"] == pr["pairs"], "tracks_per_s": pr["tracks_per_s"]},
                        "note": "frames_per_s of this object is the reference_order_f32 mode's (the reference's own float32 summation order, OP_TRACK_SUMS_REFERENCE_F32, sums by one "
-                               "wave on the device): it follows the CPU path step for step; the default fp64 mode's faster rates are under outside_tolerance_fp64_mode"}
+                               "wave on the device): it follows the CPU path step for step and is the default of new trackers; the opt-in fp64 mode's faster rates are under outside_tolerance_fp64_mode (pose_parity key default_mode_fp64 keeps its round-5 name)"}
     drift_ref = max(float(np.abs(np.asarray(slam_ref.global_poses[i], np.float64) - g0 @ poses[i].astype(np.float64))[:3, 3].max()) for i in range(n_df))
     out["dense_fusion"] = {"pose_parity": par_summary,
                            "frames_per_s": n_df / dt_ref,      # config 4's figure: the mode INSIDE north_star's 1e-4 pose tolerance (reference-order float32 sums), four pairs in flight
@@ -99,7 +99,7 @@ def run(c, out):
                            "frames": n_df, "tracked": int(sum(slam_ref.tracking_success)), "blocks": int(nb_ref), "voxel_m": 0.005, "max_translation_drift_m": drift_ref,
                            "outside_tolerance_fp64_mode": {"frames_per_s": n_df / dt, "one_pair_at_a_time_frames_per_s": n_df / dt_seq, "tracked": int(sum(slam.tracking_success)),
                                                            "blocks": int(nb), "max_translation_drift_m": drift,
-                                                           "note": "the library's default tracker mode (fp64 device reduction, no sequential sums): 20 of 23 pairs within 1e-4 of the CPU "
+                                                           "note": "the opt-in fp64 mode (OP_TRACK_SUMS_FP64: device reduction, no sequential sums): 20 of 23 pairs within 1e-4 of the CPU "
                                                                    "path, worst 4.4e-4 (pose_parity.default_mode_fp64) -- NOT config 4's figure; the rate of callers that accept that"},
                            "pipeline": "per frame: Odometry::DenseTracking(prev, cur, I) on the GPU (image preparation, 3 levels x "
                                        "{4,8,16}), pose chaining on the host, CubeHandler::IntegrateImage with the TRACKED pose; "
@@ -108,7 +108,7 @@ def run(c, out):
                                        "identical poses, the latency-bound tracker no longer leaves the chip idle"}
     # the same pipeline from C++ over the C-ABI (tools/prof_driver.bin track=4: op_tracker_dense_tracking_enqueue / op_tracker_wait on four
     # trackers, op_volume_integrate with the chained pose): the interpreter's ~250 us per frame are what limits the figure above
-    if world == 1:
+    if world == 1 and args.full:   # (~15 s of driver runs: with --full only)
         try:
             import subprocess, tempfile, re as _re
             sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -17,6 +17,7 @@ def run(c, out):
     from onepiece_amd import odometry as OD, _lib as L
     lib = L.load()
     odo = OD.Odometry(hv.camera, device=local_rank)
+    odo.SetSums("fp64")   # (a new tracker starts in the reference-order mode, OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS: the order-free fp64 reduction is measured first)
     # frame 1 -> frame 0 of this rank's shard.  (a) from the raw frames, end to end (op_tracker_dense_tracking);
     # (b) the loop alone on the pyramids (a) built, resident in HBM (boundary = MultiScaleComputing's inputs)
     full = lambda: odo.DenseTracking(rgb[1], rgb[0], depth[1], depth[0], None, 0, want_correspondences=False)
@@ -61,7 +62,8 @@ def run(c, out):
         run()
     tr_ref_host_s = 5 / (time.perf_counter() - t)
     odo.SetSums("fp64")
-    out["tracking"] = {"tracks_per_s": tr_s, "ms_per_track": 1e3 / tr_s, "reference_order_tracks_per_s": tr_ref_s, "reference_order_host_sums_tracks_per_s": tr_ref_host_s,
+    # headline = the default mode (reference-order float32 sums: every pair within 1e-4 of the CPU path); the fp64 reduction is the opt-in fast mode
+    out["tracking"] = {"tracks_per_s": tr_ref_s, "mode": "OP_TRACK_SUMS_REFERENCE_F32 (default)", "fp64_mode_tracks_per_s": tr_s, "fp64_mode_ms_per_track": 1e3 / tr_s, "reference_order_tracks_per_s": tr_ref_s, "reference_order_host_sums_tracks_per_s": tr_ref_host_s,
                        "from_raw_frames_tracks_per_s": full_s, "levels": 3, "iters_per_level": [4, 8, 16],
                        "iterations_executed": int(tres.iterations), "term": "hybrid", "resolution": [W, H],
                        "correspondences": int(tres.n_correspondences), "tracking_success": bool(tres.tracking_success),

@@ -8,7 +8,9 @@
 // The reference's own example/DenseFusion -- with submap registration and pose-graph optimisation -- compiles and runs unedited against the
 // same surface (tests/test_reference_examples.py); this driver is the throughput-oriented form of its tracking + fusion part.
 //
-//   DenseFusion <dataset_path> [--voxel 0.01] [--stride 1] [--pipeline 4] [--preload] [--repeat 1] [--filter] [--ply out.ply] [--poses out.txt]
+//   DenseFusion <dataset_path> [--voxel 0.01] [--stride 1] [--pipeline 4] [--preload] [--repeat 1] [--filter] [--sums reference|fp64] [--ply out.ply] [--poses out.txt]
+//   --sums: how the trackers sum an iteration's normal equations: reference (the library's default: the reference's own sequential float32 order, every pose within 1e-4
+//           of the CPU path) or fp64 (the order-free device reduction, ~15 x the frame rate; op_runtime_set_option(OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS, ...))
 //   --preload: decode all PNGs before the clock starts (the rate then measures tracking + fusion, not the PNG decoder)
 //   --repeat n: run the whole sequence n times into a cleared volume and report the LAST pass (with --preload): the first pass also creates the
 //               volume (a 2.7 GB pool), the trackers, their streams and graphs -- ~0.1 s of one-time work that a 160-frame run would mostly measure
@@ -37,7 +39,7 @@ int main(int argc, char* argv[]) {
     int pipeline = 4;
     bool filter = false, preload = false;
     int repeat = 1;
-    std::string ply_file, pose_file;
+    std::string ply_file, pose_file, sums;
     for (int i = 2; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--voxel") && i + 1 < argc) voxel = static_cast<float>(std::atof(argv[++i]));
         else if (!std::strcmp(argv[i], "--stride") && i + 1 < argc) stride = static_cast<size_t>(std::atoi(argv[++i]));
@@ -45,12 +47,17 @@ int main(int argc, char* argv[]) {
         else if (!std::strcmp(argv[i], "--filter")) filter = true;
         else if (!std::strcmp(argv[i], "--preload")) preload = true;
         else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--sums") && i + 1 < argc) sums = argv[++i];
         else if (!std::strcmp(argv[i], "--ply") && i + 1 < argc) ply_file = argv[++i];
         else if (!std::strcmp(argv[i], "--poses") && i + 1 < argc) pose_file = argv[++i];
     }
     if (stride < 1) stride = 1;
     if (pipeline < 1) pipeline = 1;
     if (repeat < 1 || !preload) repeat = 1;
+    if (!sums.empty()) { // before the first tracker exists: the mode new trackers start in
+        if (sums != "fp64" && sums != "reference") { std::cout << RED << "[ERROR]::--sums takes reference or fp64" << RESET << std::endl; return 1; }
+        op_runtime_set_option(OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS, sums == "fp64" ? OP_TRACK_SUMS_FP64 : OP_TRACK_SUMS_REFERENCE_F32);
+    }
     camera::PinholeCamera camera;
     camera.SetCameraType(camera::CameraType::OPEN3D_DATASET);
     odometry::Odometry rgbd_odometry(camera);

@@ -88,6 +88,9 @@ int op_runtime_hw_queues(int *requested);
  *                                         sequential float32 sums, the mode whose pose is within 1e-4 of the CPU path's on EVERY pair (~0.6 k iterations/s at
  *                                         307 200 points); OP_ICP_SUMS_FP64 opts into the order-free fp64 reduction (~24 k iterations/s; equal to the CPU path
  *                                         with double sums, but up to 1e-2 from its float32 answer where J^T J is rank-deficient -- DESIGN.md section 5)
+ *   OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS   likewise the OP_TRACK_OPT_SUMS mode of trackers created afterwards (Odometry::DenseTracking of the class surface): default
+ *                                         OP_TRACK_SUMS_REFERENCE_F32 (every pair within 1e-4 of the CPU path: ~75 tracks/s alone, ~230 frames/s with four pairs in flight);
+ *                                         OP_TRACK_SUMS_FP64 opts into the fp64 reduction (~2.2 k tracks/s; 20 of 23 pairs of the bench's chain within 1e-4, worst 4.4e-4)
  * op_runtime_set_rccl_library(path): the RCCL to bind at the first merge instead of "librccl.so.1" (a site build; the test suite names a
  *   host-memory double that runs several ranks on one device); NULL = the system's.  Fails once RCCL has been bound. */
 #define OP_RUNTIME_OPT_MERGE_ALGORITHM 0
@@ -98,6 +101,7 @@ int op_runtime_hw_queues(int *requested);
 #define OP_RUNTIME_OPT_CACHE_DEVICE_BYTES 5
 #define OP_RUNTIME_OPT_MERGE_FAULT 6
 #define OP_RUNTIME_OPT_ICP_DEFAULT_SUMS 7
+#define OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS 8
 #define OP_MERGE_OWNER_EXCHANGE 0
 #define OP_MERGE_DENSE_REDUCE 1
 int op_runtime_set_option(int option, long long value);
@@ -549,7 +553,8 @@ typedef struct {
 int op_tracker_create(int device, op_tracker **out);
 int op_tracker_destroy(op_tracker *t);
 /* OP_TRACK_OPT_SUMS: how an iteration's normal equations are summed (DenseOdometryFunction.cpp:297-381).
- *   OP_TRACK_SUMS_FP64 (default): fp64 reduction on the device, the whole coarse-to-fine loop without a host round trip.
+ *   (a new tracker starts in the process-wide OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS mode: OP_TRACK_SUMS_REFERENCE_F32 unless the host opted into the fp64 reduction)
+ *   OP_TRACK_SUMS_FP64: fp64 reduction on the device, the whole coarse-to-fine loop without a host round trip.
  *   OP_TRACK_SUMS_REFERENCE_F32: the reference's own sums -- association, acceptance and Jacobian rows come from the same kernels, and every
  *     iteration's rows are summed in raster order in float32 exactly like the reference's loop: on the device, by one wave that owns the
  *     36 + 6 accumulators and walks the compacted rows (k_seq_sums; the other waves of its workgroup prepare the products), then the 42

@@ -1250,6 +1250,10 @@ int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
 
 } // namespace
 
+// While a run enqueued with op_icp_run_enqueue is in flight its worker thread owns the context (nn, tie buffers, fin_aux, seq, the stream): every other
+// entry point refuses instead of racing with it.
+#define OP_ICP_NOT_BUSY(c, what) do { if ((c)->worker_active) return fail(OP_ERR_INVALID, what ": a run enqueued with op_icp_run_enqueue has not been waited for (op_icp_wait)"); } while (0)
+
 extern "C" {
 
 // extent_divisor > 0: the cell is the largest extent of the bounding box / extent_divisor instead of the threshold
@@ -1415,6 +1419,7 @@ int op_release_cached_memory(void) {
 
 int op_icp_set_option(op_icp* c, int option, int value) {
     if (!c) return fail(OP_ERR_INVALID, "null icp");
+    OP_ICP_NOT_BUSY(c, "op_icp_set_option");
     if (option == OP_ICP_OPT_FINISH && (value == OP_ICP_FINISH_REFERENCE || value == OP_ICP_FINISH_FP64)) { c->finish = value; return OP_OK; }
     if (option == OP_ICP_OPT_SUMS && (value == OP_ICP_SUMS_FP64 || value == OP_ICP_SUMS_REFERENCE_F32)) { c->sums = value; return OP_OK; }
     if (option == OP_ICP_OPT_TIES && (value == OP_ICP_TIES_LOWEST_INDEX || value == OP_ICP_TIES_REFERENCE)) { c->ties = value; return OP_OK; }
@@ -1423,6 +1428,7 @@ int op_icp_set_option(op_icp* c, int option, int value) {
 
 int op_icp_tie_stats(op_icp* c, uint64_t* tied_queries, uint64_t* changed) {
     if (!c) return fail(OP_ERR_INVALID, "null icp");
+    OP_ICP_NOT_BUSY(c, "op_icp_tie_stats");
     if (tied_queries) *tied_queries = c->tie_queries;
     if (changed) *changed = c->tie_changed;
     return OP_OK;
@@ -1430,12 +1436,14 @@ int op_icp_tie_stats(op_icp* c, uint64_t* tied_queries, uint64_t* changed) {
 
 int op_icp_final_stats(op_icp* c, uint64_t* redecided) {
     if (!c) return fail(OP_ERR_INVALID, "null icp");
+    OP_ICP_NOT_BUSY(c, "op_icp_final_stats");
     if (redecided) *redecided = c->fin_redecided;
     return OP_OK;
 }
 
 int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
     if (!c) return fail(OP_ERR_INVALID, "null icp");
+    OP_ICP_NOT_BUSY(c, "op_icp_set_source");
     OP_HIP(hipSetDevice(c->device));
     if (!src_xyz && n) return fail(OP_ERR_INVALID, "null source");
     if (n >= kMaxPoints) return fail(OP_ERR_INVALID, "source too large (at most %zu points)", kMaxPoints - 1);
@@ -1468,6 +1476,7 @@ int op_icp_set_source(op_icp* c, const float* src_xyz, size_t n, int mem) {
 
 int op_icp_iterate(op_icp* c, const float T[16], int mode, double sums[42], uint64_t* n_inliers, double* sum_sq_err) {
     if (!c || !T || !sums) return fail(OP_ERR_INVALID, "null argument");
+    OP_ICP_NOT_BUSY(c, "op_icp_iterate");
     OP_HIP(hipSetDevice(c->device));
     if (!c->src && c->n) return fail(OP_ERR_INVALID, "op_icp_set_source has not been called");
     if (mode == OP_ICP_POINT_TO_PLANE && !c->has_normals)
@@ -1482,9 +1491,18 @@ int op_icp_iterate(op_icp* c, const float T[16], int mode, double sums[42], uint
     return OP_OK;
 }
 
+static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap,
+                        int32_t* per_iter_inliers, float* per_iter_T);
+
 int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap,
                int32_t* per_iter_inliers, float* per_iter_T) {
     if (!c || !init_T || !result) return fail(OP_ERR_INVALID, "null argument");
+    OP_ICP_NOT_BUSY(c, "op_icp_run");
+    return icp_run_impl(c, mode, init_T, max_iteration, result, pairs, pairs_cap, per_iter_inliers, per_iter_T);
+}
+
+static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap,
+                        int32_t* per_iter_inliers, float* per_iter_T) {
     OP_HIP(hipSetDevice(c->device));
     if (mode == OP_ICP_POINT_TO_PLANE && !c->has_normals) // ICP.cpp:159-163: error line + default result
         return fail(OP_ERR_NO_NORMALS, "[ERROR]::[ICPPointToPlane]::target point cloud need to have normals.");
@@ -1696,10 +1714,15 @@ int op_icp_run_enqueue(op_icp* c, int mode, const float init_T[16], int max_iter
     std::array<float, 16> T0;
     std::memcpy(T0.data(), init_T, sizeof(float) * 16);
     c->worker_active = true; c->worker_rc = OP_OK; c->worker_err[0] = 0;
-    c->worker = std::thread([=] {
-        c->worker_rc = op_icp_run(c, mode, T0.data(), max_iteration, result, pairs, pairs_cap, nullptr, nullptr);
-        if (c->worker_rc != OP_OK) std::snprintf(c->worker_err, sizeof(c->worker_err), "%s", op::g_last_error); // (the error text is thread-local: hand it over)
-    });
+    try {
+        c->worker = std::thread([=] {
+            c->worker_rc = icp_run_impl(c, mode, T0.data(), max_iteration, result, pairs, pairs_cap, nullptr, nullptr);
+            if (c->worker_rc != OP_OK) std::snprintf(c->worker_err, sizeof(c->worker_err), "%s", op::g_last_error); // (the error text is thread-local: hand it over)
+        });
+    } catch (const std::exception& e) { // std::system_error (no thread to be had) must not cross the extern "C" boundary
+        c->worker_active = false;
+        return fail(OP_ERR_INVALID, "op_icp_run_enqueue: could not start the submitter thread: %s", e.what());
+    }
     return OP_OK;
 }
 

@@ -845,6 +845,7 @@ int op_tracker_create(int device, op_tracker** out) {
                 (size_t)lds_max >= seq_lds_bytes(42, 14, 2);
     if (!t->seq_ok) (void)hipGetLastError();
     if (!op::runtime_options().tracker_graph.load()) t->graph_ok = 0; // OP_RUNTIME_OPT_TRACKER_GRAPH
+    t->sums = op::runtime_options().tracker_default_sums.load();       // OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS: the reference's own sums unless the process opted out
     *out = t;
     return OP_OK;
 }

@@ -538,11 +538,20 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     if (!v->rc_count) OP_HIP(op::cached_malloc((void**)&v->rc_count, sizeof(unsigned) * kRcCountWords)); // [0] the list's length, [16 + 16 s ...] shard s of the call's counters
     OP_HIP(hipMemsetAsync(v->rc_count, 0, sizeof(unsigned) * kRcCountWords, v->stream));
     float *d_depth = depth_out, *d_nrm = normals_out, *d_col = colors_out;
+    // OP_MEM_HOST: device temporaries from the buffer cache; released on EVERY exit (a failed allocation or launch must not leave them in the cache's live set)
+    auto release_tmp = [&] {
+        if (mem != OP_MEM_HOST) return;
+        if (d_depth) op::cached_free(d_depth);
+        if (d_nrm) op::cached_free(d_nrm);
+        if (d_col) op::cached_free(d_col);
+        d_depth = d_nrm = d_col = nullptr;
+    };
     if (mem == OP_MEM_HOST) {
         d_depth = d_nrm = d_col = nullptr;
-        OP_HIP(op::cached_malloc((void**)&d_depth, npx * 4));
-        if (normals_out) OP_HIP(op::cached_malloc((void**)&d_nrm, npx * 12));
-        if (colors_out) OP_HIP(op::cached_malloc((void**)&d_col, npx * 12));
+        hipError_t ea = op::cached_malloc((void**)&d_depth, npx * 4);
+        if (ea == hipSuccess && normals_out) ea = op::cached_malloc((void**)&d_nrm, npx * 12);
+        if (ea == hipSuccess && colors_out) ea = op::cached_malloc((void**)&d_col, npx * 12);
+        if (ea != hipSuccess) { release_tmp(); return fail(OP_ERR_HIP, "raycast: no device memory for the output images: %s", hipGetErrorString(ea)); }
     }
     RcView W;
     float inv[16];
@@ -566,11 +575,15 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     const bool shade = d_nrm || d_col;
     // summaries are stamped with the low 30 bits of the content generation; when those wrap, nothing older may survive
     if ((v->content_gen >> 30) != v->rc_sum_epoch) {
-        OP_HIP(hipMemsetAsync(v->rc_sum, 0, sizeof(unsigned) * (size_t)v->rc_cap, v->stream));
+        const hipError_t ew = hipMemsetAsync(v->rc_sum, 0, sizeof(unsigned) * (size_t)v->rc_cap, v->stream);
+        if (ew != hipSuccess) { release_tmp(); return fail(OP_ERR_HIP, "raycast: wiping the block summaries failed: %s", hipGetErrorString(ew)); }
         v->rc_sum_epoch = v->content_gen >> 30;
     }
     const unsigned stamp = (unsigned)(v->content_gen & 0x3fffffffull);
-    const unsigned stamp_read = v->rc_prune ? stamp : 0x7fffffffu; // OP_VOLUME_OPT_RAYCAST_PRUNE = 0: no stored summary ever matches
+    // Stamp 0 is also what the wipe leaves behind ("nothing known"): in the one generation per 2^30 whose low bits are 0 no stored summary may match -- that view
+    // marches every visible block (summaries written with stamp 0, by this view or by k_integrate, match no later generation either).
+    // OP_VOLUME_OPT_RAYCAST_PRUNE = 0: likewise, no stored summary ever matches (a stored stamp has 30 bits).
+    const unsigned stamp_read = (v->rc_prune && stamp != 0u) ? stamp : 0x7fffffffu;
     hipLaunchKernelGGL(k_rc_neighbours, dim3(RC_NB_GRID), dim3(256), 0, v->stream, V, (RcBlock*)v->rc_list, (const unsigned*)v->rc_count, (const unsigned*)v->rc_sum, stamp_read);
     const bool plain = v->plain && v->trunc < 900.0f; // (see rc_tile_load: the weight plane is not needed to tell observed voxels)
 #define OP_RC_MARCH(P) hipLaunchKernelGGL(k_rc_march<P>, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count, \
@@ -595,11 +608,18 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
         if (e == hipSuccess) e = hipMemcpy(depth_out, d_depth, npx * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess && normals_out) e = hipMemcpy(normals_out, d_nrm, npx * 12, hipMemcpyDeviceToHost);
         if (e == hipSuccess && colors_out) e = hipMemcpy(colors_out, d_col, npx * 12, hipMemcpyDeviceToHost);
-        op::cached_free(d_depth);
-        if (d_nrm) op::cached_free(d_nrm);
-        if (d_col) op::cached_free(d_col);
     }
-    if (e != hipSuccess) return fail(OP_ERR_HIP, "raycast failed: %s", hipGetErrorString(e));
+    release_tmp();
+    if (e != hipSuccess) {
+        // k_rc_shade clears the hit bytes it consumes; a launch that failed may have left some set, and the next shading call assumes they are zero between calls:
+        // drop the raycast buffers, the next call re-creates (and zeroes) them
+        (void)hipStreamSynchronize(v->stream);
+        if (v->rc_list) op::cached_free(v->rc_list);
+        if (v->rc_hit) op::cached_free(v->rc_hit);
+        if (v->rc_sum) op::cached_free(v->rc_sum);
+        v->rc_list = nullptr; v->rc_hit = nullptr; v->rc_sum = nullptr; v->rc_cap = 0;
+        return fail(OP_ERR_HIP, "raycast failed: %s", hipGetErrorString(e));
+    }
     return OP_OK;
 }
 

@@ -49,8 +49,8 @@ class DenseSlam:
         self._spec_last = -1                                           # speculative "last tracked frame"
 
     def SetSums(self, sums):
-        """How every tracker sums an iteration's normal equations (Odometry.SetSums): "fp64" (default) or "reference_f32" -- the reference's own
-        sequential float32 order, the mode whose poses follow the CPU path step for step (north_star's 1e-4 bar)."""
+        """How every tracker sums an iteration's normal equations (Odometry.SetSums): "reference_f32" (default) -- the reference's own sequential float32
+        order, the mode whose poses follow the CPU path step for step (north_star's 1e-4 bar) -- or "fp64", the fast order-free reduction."""
         for t in self._trackers:
             t.SetSums(sums)
 

@@ -100,9 +100,10 @@ class Odometry:
     def SetCamera(self, camera):
         self.camera = camera
 
-    def SetSums(self, sums="fp64"):
-        """op_tracker_set_option(OP_TRACK_OPT_SUMS): "fp64" (default, device reduction, no host round trip), "reference_f32" -- every
-        iteration's Jacobian rows summed sequentially in float32 in raster order as the reference does, by one wave on the device -- or
+    def SetSums(self, sums="reference_f32"):
+        """op_tracker_set_option(OP_TRACK_OPT_SUMS): "reference_f32" (the default of new trackers since round 6) -- every iteration's
+        Jacobian rows summed sequentially in float32 in raster order as the reference does, by one wave on the device: every pair within 1e-4 of the CPU
+        path --, "fp64" (device reduction, no host round trip: ~30 x faster, 20 of 23 pairs of the bench's chain within 1e-4) or
         "reference_f32_host", the same sums on one host thread (the slow cross-check of the device sums)."""
         L.check(L.load().op_tracker_set_option(self._h, L.OP_TRACK_OPT_SUMS,
                                                {"fp64": L.OP_TRACK_SUMS_FP64, "reference_f32": L.OP_TRACK_SUMS_REFERENCE_F32,

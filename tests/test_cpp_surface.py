@@ -471,7 +471,8 @@ def test_cpp_dense_fusion_driver_pipelined_rate_without_any_environment(hip, tmp
     """Tracking + fusion from the C++ class surface at the rate the C-ABI pipeline reaches: frames uploaded once (RGBDFrame::on_device), four
     pairs in flight (Odometry::DenseTrackingEnqueue / Wait), fusion in place.  GPU_MAX_HW_QUEUES is NOT in the environment: the class surface
     asks for its hardware queues (op_runtime_configure) when its first device object is created.  The pipelined run and the one-pair-at-a-time run of the same driver print the same poses (the
-    pipeline only changes WHEN a pair is tracked) and fuse the same volume."""
+    pipeline only changes WHEN a pair is tracked) and fuse the same volume.  Run in the opt-in fp64-reduction mode (--sums fp64: op_runtime_set_option(
+    OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS)); the library's default, the reference-order sums, pipelines the same way at ~240 frames/s (bench.py: dense_fusion)."""
     _build_host(); _make(cwd=EX)
     seq = str(tmp_path / "seq")
     n = 160
@@ -482,7 +483,7 @@ def test_cpp_dense_fusion_driver_pipelined_rate_without_any_environment(hip, tmp
         pf = str(tmp_path / ("poses%d.txt" % k))
         best = None
         for rep in range(2):   # the first run of a process also pays the runtime's start-up; the driver is a fresh process each time: best of 2
-            run = subprocess.run([os.path.join(EX, "DenseFusion.bin"), seq, "--voxel", "0.01", "--pipeline", str(k), "--preload", "--repeat", "3", "--poses", pf],
+            run = subprocess.run([os.path.join(EX, "DenseFusion.bin"), seq, "--voxel", "0.01", "--pipeline", str(k), "--preload", "--repeat", "3", "--poses", pf, "--sums", "fp64"],
                                  capture_output=True, text=True, env=env, timeout=600)
             assert run.returncode == 0, run.stdout + run.stderr
             r = json.loads(run.stdout.strip().splitlines()[-1])

@@ -59,8 +59,12 @@ int main(int argc, char** argv) {
         const int K = std::max(1, atoi(argv[4] + 6));
         std::vector<op_tracker*> trk((size_t)K);
         for (auto& t : trk) CK(op_tracker_create(0, &t));
-        if (const char* e = getenv("PD_TRACK_SUMS")) // PD_TRACK_SUMS=reference_f32: every iteration's sums in the reference's sequential float32 order (OP_TRACK_SUMS_REFERENCE_F32)
-            if (std::string(e) == "reference_f32") for (auto t : trk) CK(op_tracker_set_option(t, OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_REFERENCE_F32));
+        {   // this driver profiles the fp64-reduction mode unless PD_TRACK_SUMS=reference_f32 asks for the library's default (every iteration's sums in the
+            // reference's sequential float32 order, OP_TRACK_SUMS_REFERENCE_F32)
+            const char* e = getenv("PD_TRACK_SUMS");
+            const int sums = e && std::string(e) == "reference_f32" ? OP_TRACK_SUMS_REFERENCE_F32 : OP_TRACK_SUMS_FP64;
+            for (auto t : trk) CK(op_tracker_set_option(t, OP_TRACK_OPT_SUMS, sums));
+        }
         const int32_t iters[3] = {4, 8, 16};
         const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         for (int r = 0; r < reps; ++r) {
@@ -98,6 +102,7 @@ int main(int argc, char** argv) {
     const bool track = argc > 4 && std::string(argv[4]) == "track";
     if (track) {
         op_tracker* trk; CK(op_tracker_create(0, &trk));
+        CK(op_tracker_set_option(trk, OP_TRACK_OPT_SUMS, OP_TRACK_SUMS_FP64)); // (the profiled mode; the library's default is the reference-order one)
         const int32_t iters[3] = {4, 8, 16};
         const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         for (int r = 0; r < reps; ++r) {
