@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void k_rc_visible(VolView V, RcView W, RcBlock
                         for (int a = 0; a < 3; ++a) dmax = fmaxf(dmax, fabsf((W.P[4 * a] * dcx + W.P[4 * a + 1] * dcy) + W.P[4 * a + 2]));
                     }
                     e.pad = dmax <= 0.9999f ? 1 : 0;
+                    // bits 8 .. 13: which 64th of [near, far] the block's nearest corner lies in (k_rc_order takes the list front to back)
+                    e.pad |= (int)fminf(fmaxf((fmaxf(zmin, W.near_d) - W.near_d) / fmaxf(W.far_d - W.near_d, 1e-6f) * 64.0f, 0.0f), 63.0f) << 8;
                 }
             }
         }
@@ -197,6 +199,30 @@ __global__ __launch_bounds__(256) void k_rc_neighbours(VolView V, RcBlock* __res
             if (no_end || no_start) B->pad |= 2;
         }
     }
+}
+
+// ---- R0c: front to back ---------------------------------------------------------------------------------------------------------
+// A pixel skips a block when a hit in front of it is already recorded (k_rc_march), so the order blocks are taken in decides how much is marched behind the
+// surface: every XCD's contiguous eighth of the list (rc_span: the L2 locality of the tile re-reads) is counting-sorted by the depth bucket k_rc_visible left in
+// the entry (64 buckets over [near, far]).  One workgroup per eighth; the order inside a bucket is whatever the atomics give -- the result does not depend on it.
+#ifndef RC_ORDER
+#define RC_ORDER 1
+#endif
+__global__ __launch_bounds__(1024) void k_rc_order(const RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis, unsigned* __restrict__ order) {
+    __shared__ unsigned s_hist[64], s_cur[64];
+    const unsigned n = *n_vis, per = (n + 7u) / 8u, lo = blockIdx.x * per, end = lo + per < n ? lo + per : n;
+    if (threadIdx.x < 64) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    for (unsigned e = lo + threadIdx.x; e < end; e += 1024u) atomicAdd(&s_hist[((unsigned)list[e].pad >> 8) & 63u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) { // exclusive scan of 64 counters by one wave
+        unsigned v = s_hist[threadIdx.x], x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned y = __shfl_up(x, d, 64); if ((int)threadIdx.x >= d) x += y; }
+        s_cur[threadIdx.x] = lo + x - v;
+    }
+    __syncthreads();
+    for (unsigned e = lo + threadIdx.x; e < end; e += 1024u) order[atomicAdd(&s_cur[((unsigned)list[e].pad >> 8) & 63u], 1u)] = e;
 }
 
 // ---- R1 ------------------------------------------------------------------------------------------------------------------------
@@ -299,7 +325,7 @@ __device__ __forceinline__ RcSpan rc_span(unsigned n) {
 template <bool PLAIN>
 __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcView W, const RcBlock* __restrict__ list, const unsigned* __restrict__ n_vis,
                                                                   unsigned* __restrict__ depth_bits, unsigned char* __restrict__ hit_blocks, unsigned* __restrict__ summary,
-                                                                  unsigned stamp, unsigned* __restrict__ counters) {
+                                                                  unsigned stamp, unsigned* __restrict__ counters, const unsigned* __restrict__ order) {
     __shared__ float s_sdf[kTileVox + 5];
     __shared__ int s_ent[36];
     __shared__ unsigned s_flags;
@@ -309,7 +335,8 @@ __global__ __launch_bounds__(RC_WG, RC_MIN_WAVES) void k_rc_march(VolView V, RcV
     rc_tile_map(s_cell, tid);
     const RcSpan span = rc_span(*n_vis);
     unsigned n_dropped = 0, n_loaded = 0, n_marched = 0; // (uniform over the workgroup; op_volume_raycast_stats)
-    for (unsigned e = span.first; e < span.end; e += span.step) {
+    for (unsigned i = span.first; i < span.end; i += span.step) {
+        const unsigned e = RC_ORDER ? order[i] : i; // front to back within the XCD's eighth (k_rc_order)
         if (list[e].pad & 2) { ++n_dropped; continue; } // k_rc_neighbours could tell from the summaries of earlier views that no crossing ends here (uniform: no LDS touched yet)
         __syncthreads(); // the previous block's readers are done with the tile and the entry
         if (tid < 36) s_ent[tid] = reinterpret_cast<const int*>(list + e)[tid];
@@ -523,12 +550,14 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     OP_TRY(vol_check(v));
     const size_t npx = (size_t)c.width * c.height;
     // the visible-block list (one entry per pool block at most) and the hit-point bytes (one per pool slot; zero between calls)
-    if (v->rc_cap < v->max_blocks || !v->rc_list || !v->rc_hit || !v->rc_sum) {
+    if (v->rc_cap < v->max_blocks || !v->rc_list || !v->rc_hit || !v->rc_sum || !v->rc_order) {
         if (v->rc_list) op::cached_free(v->rc_list);
         if (v->rc_hit) op::cached_free(v->rc_hit);
         if (v->rc_sum) op::cached_free(v->rc_sum);
-        v->rc_list = nullptr; v->rc_hit = nullptr; v->rc_sum = nullptr; v->rc_cap = 0;
+        if (v->rc_order) op::cached_free(v->rc_order);
+        v->rc_list = nullptr; v->rc_hit = nullptr; v->rc_sum = nullptr; v->rc_order = nullptr; v->rc_cap = 0;
         OP_HIP(op::cached_malloc(&v->rc_list, sizeof(RcBlock) * (size_t)v->max_blocks));
+        OP_HIP(op::cached_malloc((void**)&v->rc_order, sizeof(unsigned) * (size_t)v->max_blocks));
         OP_HIP(op::cached_malloc((void**)&v->rc_hit, (size_t)v->max_blocks));
         OP_HIP(hipMemsetAsync(v->rc_hit, 0, (size_t)v->max_blocks, v->stream));
         OP_HIP(op::cached_malloc((void**)&v->rc_sum, sizeof(unsigned) * (size_t)v->max_blocks));
@@ -585,9 +614,10 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
     // OP_VOLUME_OPT_RAYCAST_PRUNE = 0: likewise, no stored summary ever matches (a stored stamp has 30 bits).
     const unsigned stamp_read = (v->rc_prune && stamp != 0u) ? stamp : 0x7fffffffu;
     hipLaunchKernelGGL(k_rc_neighbours, dim3(RC_NB_GRID), dim3(256), 0, v->stream, V, (RcBlock*)v->rc_list, (const unsigned*)v->rc_count, (const unsigned*)v->rc_sum, stamp_read);
+    if (RC_ORDER) hipLaunchKernelGGL(k_rc_order, dim3(8), dim3(1024), 0, v->stream, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count, v->rc_order);
     const bool plain = v->plain && v->trunc < 900.0f; // (see rc_tile_load: the weight plane is not needed to tell observed voxels)
 #define OP_RC_MARCH(P) hipLaunchKernelGGL(k_rc_march<P>, dim3(RC_MARCH_GRID), dim3(kRcWg), 0, v->stream, V, W, (const RcBlock*)v->rc_list, (const unsigned*)v->rc_count, \
-                                          reinterpret_cast<unsigned*>(d_depth), shade ? v->rc_hit : nullptr, v->rc_sum, stamp, v->rc_count + 16)
+                                          reinterpret_cast<unsigned*>(d_depth), shade ? v->rc_hit : nullptr, v->rc_sum, stamp, v->rc_count + 16, (const unsigned*)v->rc_order)
     if (plain) OP_RC_MARCH(true); else OP_RC_MARCH(false);
 #undef OP_RC_MARCH
     hipLaunchKernelGGL(k_rc_finish, dim3((unsigned)std::min<size_t>(2048, (npx + 255) / 256)), dim3(256), 0, v->stream, W, d_depth, d_nrm, d_col);
@@ -617,7 +647,8 @@ int op_volume_raycast(op_volume* v, const op_camera* cam, const float pose[16], 
         if (v->rc_list) op::cached_free(v->rc_list);
         if (v->rc_hit) op::cached_free(v->rc_hit);
         if (v->rc_sum) op::cached_free(v->rc_sum);
-        v->rc_list = nullptr; v->rc_hit = nullptr; v->rc_sum = nullptr; v->rc_cap = 0;
+        if (v->rc_order) op::cached_free(v->rc_order);
+        v->rc_list = nullptr; v->rc_hit = nullptr; v->rc_sum = nullptr; v->rc_order = nullptr; v->rc_cap = 0;
         return fail(OP_ERR_HIP, "raycast failed: %s", hipGetErrorString(e));
     }
     return OP_OK;

@@ -849,7 +849,7 @@ int op_volume_destroy(op_volume* v) {
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     for (auto e : v->prof_events) (void)hipEventDestroy(e);
     void* ptrs[] = {v->tkeys, v->tvals, v->keys, v->pool, v->n_blocks, v->bmask, v->blist, v->sel_list, v->sel_cand, v->state,
-                    v->partial, v->pimg, v->ptile, v->sbits, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots, v->rc_list, v->rc_count, v->rc_hit, v->rc_sum};
+                    v->partial, v->pimg, v->ptile, v->sbits, v->upd_partial, v->sel_partial, v->chg_partial, v->img_depth, v->img_rgb, v->unpack_slots, v->rc_list, v->rc_count, v->rc_hit, v->rc_sum, v->rc_order};
     for (void* p : ptrs)
         if (p) op::cached_free(p);
     if (v->copy_stream) (void)hipStreamSynchronize(v->copy_stream);

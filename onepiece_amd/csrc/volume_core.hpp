@@ -404,6 +404,7 @@ struct op_volume {
     void* rc_list = nullptr;     // raycast.hip: the visible-block list of the view being cast (one entry per pool block at most), its capacity in blocks
     unsigned rc_cap = 0;
     unsigned* rc_count = nullptr; // ... and its length
+    unsigned* rc_order = nullptr; // the order k_rc_march takes the list in: every XCD's contiguous eighth sorted front to back (k_rc_order)
     unsigned* rc_sum = nullptr;   // per pool slot: what the march learnt about the block's own voxels ((stamp << 2) | has sdf > 0 << 1 | has sdf <= 0), valid while stamp == content_gen (written by k_rc_march from its tile and by k_integrate from the block it has just updated)
     uint64_t rc_sum_epoch = 0;    // content_gen >> 30 the summaries were last wiped for
     int rc_prune = 1;             // OP_VOLUME_OPT_RAYCAST_PRUNE
