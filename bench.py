@@ -372,7 +372,7 @@ def compact(full, detail_files=()):
         out["tracking"] = {k: tr.get(k) for k in ("tracks_per_s", "mode", "fp64_mode_tracks_per_s", "from_raw_frames_tracks_per_s") if k in tr}
     if "dense_fusion" in full:
         df = full["dense_fusion"]
-        out["dense_fusion"] = {k: df.get(k) for k in ("frames_per_s", "frames_per_s_mode", "pairs_in_flight", "one_pair_at_a_time_frames_per_s", "frames") if k in df}
+        out["dense_fusion"] = {k: df.get(k) for k in ("frames_per_s", "frames_per_s_mode", "pairs_in_flight", "frames_per_s_by_pairs_in_flight", "one_pair_at_a_time_frames_per_s", "frames") if k in df}
         if isinstance(df.get("outside_tolerance_fp64_mode"), dict):
             out["dense_fusion"]["fp64_mode_frames_per_s"] = df["outside_tolerance_fp64_mode"].get("frames_per_s")
         pz = df.get("pose_parity")

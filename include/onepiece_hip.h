@@ -91,6 +91,11 @@ int op_runtime_hw_queues(int *requested);
  *   OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS   likewise the OP_TRACK_OPT_SUMS mode of trackers created afterwards (Odometry::DenseTracking of the class surface): default
  *                                         OP_TRACK_SUMS_REFERENCE_F32 (every pair within 1e-4 of the CPU path: ~75 tracks/s alone, ~230 frames/s with four pairs in flight);
  *                                         OP_TRACK_SUMS_FP64 opts into the fp64 reduction (~2.2 k tracks/s; 20 of 23 pairs of the bench's chain within 1e-4, worst 4.4e-4)
+ *   OP_RUNTIME_OPT_TRACKER_BATCH_SUMS     0 (default): every tracker launches its own one-workgroup sum kernel.  1: twelve or more trackers in the reference-order mode that
+ *                                         run at the same time (pairs in flight of a pipeline) meet once per iteration and take their sequential sums in ONE launch, a
+ *                                         workgroup per tracker -- what lifts ICP's reference-order replicas from 2.2 k to 5.7 k iterations/s (op_icp_run_many), measured
+ *                                         WITHOUT gain for the tracker (profiles/r06_track_depth_probe.txt: 254-326 frames/s against 289-302 at 16-24 pairs in flight: its
+ *                                         rounds mix pyramid levels, and the pipeline is bound by the submission of its many small kernels).  Results do not depend on it.
  * op_runtime_set_rccl_library(path): the RCCL to bind at the first merge instead of "librccl.so.1" (a site build; the test suite names a
  *   host-memory double that runs several ranks on one device); NULL = the system's.  Fails once RCCL has been bound. */
 #define OP_RUNTIME_OPT_MERGE_ALGORITHM 0
@@ -102,6 +107,7 @@ int op_runtime_hw_queues(int *requested);
 #define OP_RUNTIME_OPT_MERGE_FAULT 6
 #define OP_RUNTIME_OPT_ICP_DEFAULT_SUMS 7
 #define OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS 8
+#define OP_RUNTIME_OPT_TRACKER_BATCH_SUMS 9
 #define OP_MERGE_OWNER_EXCHANGE 0
 #define OP_MERGE_DENSE_REDUCE 1
 int op_runtime_set_option(int option, long long value);
@@ -464,6 +470,11 @@ int op_icp_run(op_icp *icp, int mode, const float init_T[16], int max_iteration,
  * those of op_icp_run (each context is independent of the others). */
 int op_icp_run_enqueue(op_icp *icp, int mode, const float init_T[16], int max_iteration, op_icp_result *result, int32_t *pairs, size_t pairs_cap);
 int op_icp_wait(op_icp *icp);
+/* K registrations on K contexts from ONE host thread (ICP does not shard -- replicas only).  Contexts in the fp64-reduction mode are pipelined by the
+ * caller's thread: every context has one iteration in flight, the thread goes round waiting for a context's sums (host-mapped memory), solving, enqueueing its next
+ * iteration; the finishes run side by side on helper threads.  Contexts in the reference-order mode get a submitter thread each (they synchronise every iteration).
+ * init_T: K x 16 floats, or NULL for the identity everywhere; results: K entries; every context's result equals what op_icp_run gives it alone. */
+int op_icp_run_many(op_icp *const *icps, int k, int mode, const float *init_T, int max_iteration, op_icp_result *results);
 
 /* Convenience: create + set_source + run + destroy with host buffers. */
 int op_icp_register(int mode, const float *src_xyz, size_t n, const float *tgt_xyz,

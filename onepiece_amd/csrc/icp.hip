@@ -28,7 +28,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -903,6 +906,7 @@ __global__ __launch_bounds__(256) void k_patch_nn(const int2* __restrict__ patch
 
 } // namespace
 
+namespace { template <int, int, int, int> struct SeqRendezvous; } // seq_sums.hpp: where reference-order contexts that run at the same time take their sequential sums
 struct op_icp {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -956,6 +960,8 @@ struct op_icp {
     unsigned* fin_list = nullptr;       // device, src_cap entries
     size_t fin_cap = 0;
     uint64_t fin_redecided = 0;         // since the context was created
+    SeqRendezvous<42, 7, 1, 5>* seq_batch = nullptr; // set for the duration of an op_icp_run_many call: this context's sequential sums are taken in one launch with the other contexts'
+    hipEvent_t seq_ev = nullptr;        // "my ordered rows are in place" (recorded on the context's stream for the batch's stream to wait on)
     std::thread worker;
     bool worker_active = false;
     int worker_rc = OP_OK;
@@ -1212,6 +1218,15 @@ bool seq_device_ok(op_icp* c) {
     return c->seq_ok == 1;
 }
 
+// The reference-order contexts of one op_icp_run_many call take their sequential sums TOGETHER when there are five or more of them (seq_sums.hpp: SeqRendezvous): every such context has a submitter
+// thread (its iterations synchronise the stream anyway) and each iteration ends in k_seq_sums -- ONE workgroup, ~0.8 ms for 3e5 rows; K independent runs scale to
+// 4 x and no further (round 5: 2.3 k iterations/s at K = 4 and at K = 8), K workgroups of one launch do not have that limit.  One batcher per device.
+using IcpSeqBatch = SeqRendezvous<42, 7, 1, 5>;
+IcpSeqBatch* icp_seq_batch(int device) {
+    static IcpSeqBatch pool[16];
+    return device >= 0 && device < 16 ? &pool[device] : nullptr;
+}
+
 int emit_rows(op_icp* c, int kind, size_t n_rows, const float** rows) {
     if (rows) *rows = nullptr;
     if (!c->n || !n_rows) return OP_OK;
@@ -1397,6 +1412,7 @@ int op_icp_destroy(op_icp* c) {
     for (hipEvent_t ev : c->chunk_ev)
         op::release_event(ev, c->device);
     if (c->rows_host) op::cached_free(c->rows_host);
+    if (c->seq_ev) op::release_event(c->seq_ev, c->device);
     if (c->seq_out) op::cached_free(c->seq_out);
     if (c->seq_total) op::cached_free(c->seq_total);
     if (c->seq_host) op::cached_free(c->seq_host);
@@ -1501,24 +1517,82 @@ int op_icp_run(op_icp* c, int mode, const float init_T[16], int max_iteration, o
     return icp_run_impl(c, mode, init_T, max_iteration, result, pairs, pairs_cap, per_iter_inliers, per_iter_T);
 }
 
-static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap,
-                        int32_t* per_iter_inliers, float* per_iter_T) {
+// ---- one registration = head (checks, resets) -> the iteration loop -> finish (final CountInliers, RegistrationResult).  The fp64-mode loop is a small state
+// machine (IcpLoop: launch an iteration / complete it) so that ONE host thread can keep several contexts' iterations in flight (op_icp_run_many).
+static int icp_run_head(op_icp* c, int mode, int max_iteration) {
     OP_HIP(hipSetDevice(c->device));
     if (mode == OP_ICP_POINT_TO_PLANE && !c->has_normals) // ICP.cpp:159-163: error line + default result
         return fail(OP_ERR_NO_NORMALS, "[ERROR]::[ICPPointToPlane]::target point cloud need to have normals.");
     if (!c->src && c->n) return fail(OP_ERR_INVALID, "op_icp_set_source has not been called");
-    float start_T[16], last_search_T[16];
-    std::memcpy(last_search_T, init_T, sizeof(last_search_T));
-    double r[kNSums];
     if (max_iteration <= 0 && c->n) OP_HIP(hipMemsetAsync(c->nn, 0xff, c->n * sizeof(int), c->stream)); // corresponding_index stays -1
     OP_HIP(hipMemsetAsync(c->sync, 0, (kGroups + 1) * sizeof(unsigned), c->stream)); // the counters reset themselves; this covers an aborted launch
     if (c->tie_count) { OP_HIP(hipMemsetAsync(c->tie_count, 0, sizeof(unsigned), c->stream)); c->tie_total = 0; } // likewise
-    // ICP.cpp:177-199.  The reduced sums of every iteration come back to the host, which does the 6x6 solve (JacobiSVD
-    // semantics incl. its rank threshold -- the synthetic room's JTJ has cond 1.5e8, so the threshold matters) and the SE3
-    // exp, or the Kabsch step of PointToPoint, as north_star prescribes.  The round trip is kept short: the pose goes
-    // down as a by-value kernel argument and the sums come up through host-mapped pinned memory that the iteration
-    // kernel publishes with a sequence number the host spins on (no memcpy, no stream sync).  (PointToPoint's step used to
-    // run in a one-thread kernel after every iteration: 6 us of single-lane fp64 against 1 us of the same code on the host.)
+    return OP_OK;
+}
+
+// ICP.cpp:177-199, fp64-reduction mode.  The reduced sums of every iteration come back to the host, which does the 6x6 solve (JacobiSVD
+// semantics incl. its rank threshold -- the synthetic room's JTJ is rank-deficient, so the threshold matters) and the SE3
+// exp, or the Kabsch step of PointToPoint, as north_star prescribes.  The round trip is kept short: the pose goes
+// down as a by-value kernel argument and the sums come up through host-mapped pinned memory that the iteration
+// kernel publishes with a sequence number the host spins on (no memcpy, no stream sync).  (PointToPoint's step used to
+// run in a one-thread kernel after every iteration: 6 us of single-lane fp64 against 1 us of the same code on the host.)
+struct IcpLoop {
+    op_icp* c = nullptr;
+    int pass_mode = 1, max_iteration = 0, it = 0;
+    bool detect = false;
+    float cur[16], last_search_T[16];
+    int32_t* per_iter_inliers = nullptr;
+    float* per_iter_T = nullptr;
+};
+static int icp_loop_begin(IcpLoop& L, op_icp* c, int mode, const float init_T[16], int max_iteration, int32_t* per_iter_inliers, float* per_iter_T) {
+    L.c = c; L.pass_mode = mode == OP_ICP_POINT_TO_PLANE ? 1 : 0; L.max_iteration = max_iteration; L.it = 0;
+    L.per_iter_inliers = per_iter_inliers; L.per_iter_T = per_iter_T;
+    std::memcpy(L.cur, init_T, sizeof(L.cur));
+    std::memcpy(L.last_search_T, init_T, sizeof(L.last_search_T));
+    L.detect = c->ties == OP_ICP_TIES_REFERENCE;
+    if (L.detect) OP_TRY(ensure_tie_buffers(c));
+    return OP_OK;
+}
+static int icp_loop_launch(IcpLoop& L) { // enqueue iteration L.it (does not wait)
+    op_icp* c = L.c;
+    std::memcpy(L.last_search_T, L.cur, sizeof(L.cur));
+    c->seq += 1.0;
+    if (L.detect) { if (L.pass_mode == 1) launch_pass<1, true>(c, false, L.cur, c->seq); else launch_pass<0, true>(c, false, L.cur, c->seq); }
+    else if (L.pass_mode == 1) launch_pass<1>(c, false, L.cur, c->seq);
+    else launch_pass<0>(c, false, L.cur, c->seq);
+    OP_HIP(hipGetLastError());
+    return OP_OK;
+}
+static int icp_loop_complete(IcpLoop& L) { // wait for the sums of iteration L.it, solve, chain the pose
+    op_icp* c = L.c;
+    double r[kNSums];
+    float tmp_T[16];
+    OP_TRY(wait_rows(c, r));
+    if (L.detect) OP_TRY(resolve_ties(c, L.pass_mode, L.cur, false, r, false, L.it == L.max_iteration - 1)); // nothing to do unless the pass reported tied queries (r[29])
+    if (L.pass_mode == 1) {
+        double JTJ[36], JTr[6];
+        float x[6];
+        expand_plane_sums(r, JTJ, JTr);
+        op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
+        op_host::se3_exp(x, tmp_T);        // ICP.cpp:143
+    } else {
+        op_host::kabsch_from_sums(r[28], r, r + 3, r + 6, tmp_T); // ICP.cpp:79
+    }
+    op_host::mat4_mul(tmp_T, L.cur, L.cur); // ICP.cpp:198
+    if (L.per_iter_inliers) L.per_iter_inliers[L.it] = (int32_t)(r[28] + 0.5);
+    if (L.per_iter_T) std::memcpy(L.per_iter_T + 16 * L.it, L.cur, sizeof(L.cur));
+    ++L.it;
+    return OP_OK;
+}
+
+static int icp_run_finish(op_icp* c, const float start_T[16], const float last_search_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap);
+
+static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap,
+                        int32_t* per_iter_inliers, float* per_iter_T) {
+    OP_TRY(icp_run_head(c, mode, max_iteration));
+    float start_T[16], last_search_T[16];
+    std::memcpy(last_search_T, init_T, sizeof(last_search_T));
+    double r[kNSums];
     const int pass_mode = mode == OP_ICP_POINT_TO_PLANE ? 1 : 0;
     const bool strict = c->sums == OP_ICP_SUMS_REFERENCE_F32;
     if (strict) {
@@ -1538,9 +1612,15 @@ static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_ite
                 OP_TRY(emit_rows(c, 3, n_it, nullptr));
                 const unsigned n_rows_u = (unsigned)n_it;
                 OP_HIP(hipMemcpyAsync(c->seq_total, &n_rows_u, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-                hipLaunchKernelGGL((k_seq_sums<42, 7, 1>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 7, 1), c->stream, (const float*)c->rows_dev, (const unsigned*)c->seq_total, c->seq_out);
-                OP_HIP(hipMemcpyAsync(c->seq_host, c->seq_out, 43 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-                OP_HIP(hipStreamSynchronize(c->stream));
+                hipError_t eb = hipErrorNotReady;
+                if (c->seq_batch) // with the other contexts of the op_icp_run_many call: one launch, a workgroup each (hipErrorNotReady: too few of them -- alone, below)
+                    eb = c->seq_batch->submit(c->rows_dev, c->seq_total, c->seq_out, c->seq_host, c->seq_ev, c->stream);
+                if (eb != hipSuccess && eb != hipErrorNotReady) return fail(OP_ERR_HIP, "icp: the batched sequential sums failed: %s", hipGetErrorString(eb));
+                if (eb == hipErrorNotReady) {
+                    hipLaunchKernelGGL((k_seq_sums<42, 7, 1>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 7, 1), c->stream, (const float*)c->rows_dev, (const unsigned*)c->seq_total, c->seq_out);
+                    OP_HIP(hipMemcpyAsync(c->seq_host, c->seq_out, 43 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                    OP_HIP(hipStreamSynchronize(c->stream));
+                }
                 double JTJ[36], JTr[6];
                 float x[6];
                 for (int k = 0; k < 36; ++k) JTJ[k] = c->seq_host[k];
@@ -1552,6 +1632,7 @@ static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_ite
                 if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
                 continue;
             }
+            if (c->seq_batch) c->seq_batch->pass(); // nothing for the batched launch from this context in this iteration
             OP_TRY(emit_rows(c, pass_mode == 1 ? 1 : 2, n_it, &rows));
             if (pass_mode == 1) {
                 double JTJ[36], JTr[6];
@@ -1568,55 +1649,18 @@ static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_ite
         }
         std::memcpy(start_T, cur, sizeof(cur));
     } else {
-        float cur[16], tmp_T[16];
-        std::memcpy(cur, init_T, sizeof(cur));
-        const bool detect = c->ties == OP_ICP_TIES_REFERENCE;
-        if (detect) OP_TRY(ensure_tie_buffers(c));
-#ifdef ICP_TRACE
-        double tr_launch = 0, tr_wait = 0, tr_solve = 0;
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-#endif
-        for (int it = 0; it < max_iteration; ++it) {
-            std::memcpy(last_search_T, cur, sizeof(cur));
-            c->seq += 1.0;
-#ifdef ICP_TRACE
-            const double ta = now();
-#endif
-            if (detect) { if (pass_mode == 1) launch_pass<1, true>(c, false, cur, c->seq); else launch_pass<0, true>(c, false, cur, c->seq); }
-            else if (pass_mode == 1) launch_pass<1>(c, false, cur, c->seq);
-            else launch_pass<0>(c, false, cur, c->seq);
-            OP_HIP(hipGetLastError());
-#ifdef ICP_TRACE
-            const double tb = now();
-#endif
-            OP_TRY(wait_rows(c, r));
-            if (detect) OP_TRY(resolve_ties(c, pass_mode, cur, false, r, false, it == max_iteration - 1)); // nothing to do unless the pass reported tied queries (r[29])
-#ifdef ICP_TRACE
-            const double tc = now();
-#endif
-            if (pass_mode == 1) {
-                double JTJ[36], JTr[6];
-                float x[6];
-                expand_plane_sums(r, JTJ, JTr);
-                op_host::solve6_psd(JTJ, JTr, x);  // ICP.cpp:137-138
-                op_host::se3_exp(x, tmp_T);        // ICP.cpp:143
-            } else {
-                op_host::kabsch_from_sums(r[28], r, r + 3, r + 6, tmp_T); // ICP.cpp:79
-            }
-            op_host::mat4_mul(tmp_T, cur, cur); // ICP.cpp:198
-            if (per_iter_inliers) per_iter_inliers[it] = (int32_t)(r[28] + 0.5);
-            if (per_iter_T) std::memcpy(per_iter_T + 16 * it, cur, sizeof(cur));
-#ifdef ICP_TRACE
-            tr_launch += tb - ta; tr_wait += tc - tb; tr_solve += now() - tc;
-#endif
-        }
-#ifdef ICP_TRACE
-        if (max_iteration > 0)
-            fprintf(stderr, "icp host trace: per iteration launch call %.2f us, wait for sums %.2f us, solve %.2f us\n", tr_launch / max_iteration * 1e6,
-                    tr_wait / max_iteration * 1e6, tr_solve / max_iteration * 1e6);
-#endif
-        std::memcpy(start_T, cur, sizeof(cur));
+        IcpLoop L;
+        OP_TRY(icp_loop_begin(L, c, mode, init_T, max_iteration, per_iter_inliers, per_iter_T));
+        while (L.it < max_iteration) { OP_TRY(icp_loop_launch(L)); OP_TRY(icp_loop_complete(L)); }
+        std::memcpy(start_T, L.cur, sizeof(L.cur));
+        std::memcpy(last_search_T, L.last_search_T, sizeof(last_search_T));
     }
+    return icp_run_finish(c, start_T, last_search_T, max_iteration, result, pairs, pairs_cap);
+}
+
+static int icp_run_finish(op_icp* c, const float start_T[16], const float last_search_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap) {
+    const bool strict = c->sums == OP_ICP_SUMS_REFERENCE_F32;
+    double r[kNSums];
     // ICP.cpp:206-221: CountInliers with the final start_T over the last NN set, then Kabsch over
     // (original source, target) pairs
     // The sums of the final pass come back like the loop's (rows in host-mapped memory, no copy, no stream sync).
@@ -1656,7 +1700,7 @@ static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_ite
     result->n_inliers = (uint64_t)(n_inl + 0.5);
     result->rmse = std::sqrt(r[27] / n_inl);
     result->iterations = max_iteration;
-    std::memcpy(result->last_T, start_T, sizeof(start_T));
+    std::memcpy(result->last_T, start_T, sizeof(result->last_T));
     if (c->finish == OP_ICP_FINISH_REFERENCE) {
         // RegistrationResult::T as the reference forms it (ICP.cpp:215-221 -> Geometry.cpp:117-133): sequential
         // float32 sums over the correspondence_set in ascending source index
@@ -1705,6 +1749,107 @@ static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_ite
         for (size_t i = 0; i < c->n && k < pairs_cap; ++i)
             if (inl[i] >= 0) { pairs[2 * k] = (int32_t)i; pairs[2 * k + 1] = inl[i]; ++k; }
     }
+    return OP_OK;
+}
+
+// K registrations on K contexts, driven by ONE host thread (round-5 review: four submitter threads contend in the runtime's launch path -- k_icp_iter 21 -> 33 us,
+// host side 19 -> 33 us at K = 4).  fp64-mode contexts: all K iterations are enqueued, then the thread goes round: wait for context k's sums (they arrive in
+// host-mapped memory), solve, enqueue its next iteration, move on -- while it looks at one context the other K - 1 iterations run on the chip.  The finishes
+// (final CountInliers + the reference-order Kabsch over ~3e5 rows on a host core, ~0.8 ms each) run side by side on helper threads.  Contexts in the
+// reference-order mode synchronise their stream every iteration anyway: they get a submitter thread each, exactly as op_icp_run_enqueue gives them.
+// init_T: K x 16 floats (NULL = identity for all); results: K entries.  Returns the first error.
+int op_icp_run_many(op_icp* const* ctxs, int k, int mode, const float* init_T, int max_iteration, op_icp_result* results) {
+    if (!ctxs || k < 1 || !results) return fail(OP_ERR_INVALID, "op_icp_run_many: null argument");
+    static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int i = 0; i < k; ++i) {
+        if (!ctxs[i]) return fail(OP_ERR_INVALID, "op_icp_run_many: null context %d", i);
+        OP_ICP_NOT_BUSY(ctxs[i], "op_icp_run_many");
+        for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(OP_ERR_INVALID, "op_icp_run_many: context %d given twice", i);
+    }
+    int rc = OP_OK;
+    char first_err[sizeof(op::g_last_error)] = {0};
+    auto note = [&](int r) { if (r != OP_OK && rc == OP_OK) { rc = r; std::snprintf(first_err, sizeof(first_err), "%s", op::g_last_error); } };
+    std::vector<IcpLoop> loops((size_t)k);
+    std::vector<int> live; // indices of fp64-mode contexts whose loop is running here
+    std::vector<int> threaded;
+    std::vector<int> strict; // reference-order contexts
+    for (int i = 0; i < k; ++i) {
+        op_icp* c = ctxs[i];
+        const float* T0 = init_T ? init_T + 16 * (size_t)i : kIdentity;
+        if (c->sums == OP_ICP_SUMS_REFERENCE_F32) { // own submitter thread; the sequential sums of all of them in one launch per round (SeqBatch)
+            if (mode == OP_ICP_POINT_TO_PLANE && hipSetDevice(c->device) == hipSuccess && seq_device_ok(c)) {
+                if (!c->seq_ev && op::cached_event(&c->seq_ev) != hipSuccess) { c->seq_ev = nullptr; (void)hipGetLastError(); }
+                IcpSeqBatch* b = icp_seq_batch(c->device);
+                if (c->seq_ev && b && b->usable(c->device)) { c->seq_batch = b; b->join(); }
+            }
+            strict.push_back(i); // (its submitter thread starts below, once every participant of the batch is counted)
+            continue;
+        }
+        int r = icp_run_head(c, mode, max_iteration);
+        if (r == OP_OK) r = icp_loop_begin(loops[(size_t)i], c, mode, T0, max_iteration, nullptr, nullptr);
+        if (r == OP_OK) live.push_back(i); else note(r);
+    }
+    for (int i : strict) {
+        op_icp* c = ctxs[i];
+        const float* T0 = init_T ? init_T + 16 * (size_t)i : kIdentity;
+        std::array<float, 16> T0a;
+        std::memcpy(T0a.data(), T0, sizeof(float) * 16);
+        op_icp_result* res_i = &results[i];
+        c->worker_active = true; c->worker_rc = OP_OK; c->worker_err[0] = 0;
+        try {
+            c->worker = std::thread([=] {
+                c->worker_rc = icp_run_impl(c, mode, T0a.data(), max_iteration, res_i, nullptr, 0, nullptr, nullptr);
+                if (c->worker_rc != OP_OK) std::snprintf(c->worker_err, sizeof(c->worker_err), "%s", op::g_last_error);
+                if (c->seq_batch) c->seq_batch->leave(); // (on every exit: nobody may go on waiting for this context)
+            });
+            threaded.push_back(i);
+        } catch (const std::exception& e) {
+            c->worker_active = false;
+            if (c->seq_batch) { c->seq_batch->leave(); c->seq_batch = nullptr; }
+            note(fail(OP_ERR_INVALID, "op_icp_run_many: could not start a submitter thread: %s", e.what()));
+        }
+    }
+    std::vector<int> finishing = live; // (a context whose loop fails drops out below)
+    if (max_iteration > 0) {
+        std::vector<int> active;
+        for (int i : live) { // first iteration of every context
+            if (ctxs[i]->device != ctxs[live[0]]->device) (void)hipSetDevice(ctxs[i]->device);
+            const int r = icp_loop_launch(loops[(size_t)i]);
+            if (r == OP_OK) active.push_back(i); else { note(r); finishing.erase(std::find(finishing.begin(), finishing.end(), i)); }
+        }
+        while (!active.empty()) {
+            for (size_t a = 0; a < active.size();) {
+                const int i = active[a];
+                IcpLoop& L = loops[(size_t)i];
+                (void)hipSetDevice(L.c->device);
+                int r = icp_loop_complete(L);
+                if (r == OP_OK && L.it < max_iteration) r = icp_loop_launch(L);
+                if (r != OP_OK) { note(r); finishing.erase(std::find(finishing.begin(), finishing.end(), i)); }
+                if (r != OP_OK || L.it >= max_iteration) active.erase(active.begin() + (long)a); else ++a;
+            }
+        }
+    }
+    // the finishes side by side (each is mostly one host core summing rows): helper threads for all but the first
+    {
+        std::vector<std::thread> helpers;
+        std::vector<int> frc(finishing.size(), OP_OK);
+        std::vector<std::string> ferr(finishing.size());
+        auto fin = [&](size_t q) {
+            const int i = finishing[q];
+            IcpLoop& L = loops[(size_t)i];
+            frc[q] = icp_run_finish(L.c, L.cur, L.last_search_T, max_iteration, &results[i], nullptr, 0);
+            if (frc[q] != OP_OK) ferr[q] = op::g_last_error; // (thread-local: hand it over)
+        };
+        for (size_t q = 1; q < finishing.size(); ++q) {
+            try { helpers.emplace_back(fin, q); } catch (const std::exception&) { fin(q); } // no thread to be had: do it here
+        }
+        if (!finishing.empty()) fin(0);
+        for (auto& t : helpers) t.join();
+        for (size_t q = 0; q < finishing.size(); ++q)
+            if (frc[q] != OP_OK && rc == OP_OK) { rc = frc[q]; std::snprintf(first_err, sizeof(first_err), "%s", ferr[q].c_str()); }
+    }
+    for (int i : threaded) { note(op_icp_wait(ctxs[i])); ctxs[i]->seq_batch = nullptr; }
+    if (rc != OP_OK) return fail(rc, "%s", first_err);
     return OP_OK;
 }
 

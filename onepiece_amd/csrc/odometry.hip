@@ -736,6 +736,7 @@ struct op_tracker {
     float* seq_out = nullptr;        // device: the 42 (+ count) results of k_seq_sums
     float* seq_host = nullptr;       // pinned copy
     unsigned* seq_total = nullptr;   // device: number of accepted pixels (k_emit_scan)
+    hipEvent_t seq_ev = nullptr;     // "my ordered rows are in place" (for the rendezvous of trackers that sum together, seq_sums.hpp)
     int lds_total = 0, lds_static = 0, n_cu = 256;
     double* partials = nullptr;
     unsigned* wg_count = nullptr;
@@ -864,6 +865,7 @@ int op_tracker_destroy(op_tracker* t) {
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->rows_dev);
     (void)hipFree(t->seq_out); (void)hipFree(t->seq_total);
+    if (t->seq_ev) (void)hipEventDestroy(t->seq_ev);
     if (t->seq_host) (void)hipHostFree(t->seq_host);
     if (t->rows_host) (void)hipHostFree(t->rows_host);
     if (t->pair_host) (void)hipHostFree(t->pair_host);
@@ -889,6 +891,20 @@ static void fill_loop_header(op_tracker* t, int full_width, int full_height, int
     h->stop_level = -1; h->iters_done = 0; h->last_level = -1; h->n_last = 0; h->n_emit = 0; h->rmse = 0; h->success = 0;
 }
 
+// Trackers in the reference-order mode that run at the same time (the pairs in flight of a tracking + fusion pipeline, each on its own host thread and stream) take
+// their per-iteration sequential sums TOGETHER: k_seq_sums_many launches with a workgroup per waiting tracker instead of one one-workgroup launch per stream -- of
+// which the chip runs four side by side and no more (seq_sums.hpp: SeqRendezvous; with twelve or more trackers running, below that each launches its own).  One rendezvous per device; hybrid term only (the other two use a different row
+// layout and stay on their own).  OP_RUNTIME_OPT_TRACKER_BATCH_SUMS = 0 switches it off (A/B).
+using TrackSeqBatch = SeqRendezvous<42, 14, 2, 12>;
+static TrackSeqBatch* track_seq_batch(int device) {
+    static TrackSeqBatch pool[16];
+    return device >= 0 && device < 16 ? &pool[device] : nullptr;
+}
+struct TrackBatchMembership { // leaves on every exit of the run
+    TrackSeqBatch* b = nullptr;
+    ~TrackBatchMembership() { if (b) b->leave(); }
+};
+
 static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_level, int full_width, int full_height, int term_type,
                          const float init_T[16], bool want_points, bool want_logs) {
     TrackState* h = t->st_host;
@@ -903,6 +919,13 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
         OP_HIP(hipMalloc(&t->seq_out, 64 * sizeof(float)));
         OP_HIP(hipHostMalloc(&t->seq_host, 64 * sizeof(float), hipHostMallocDefault));
         OP_HIP(hipMalloc(&t->seq_total, sizeof(unsigned)));
+    }
+    TrackSeqBatch* batch = nullptr;
+    TrackBatchMembership member;
+    if (strict && on_device && term_type == 0 && op::runtime_options().tracker_batch_sums.load()) {
+        if (!t->seq_ev && hipEventCreateWithFlags(&t->seq_ev, hipEventDisableTiming) != hipSuccess) { t->seq_ev = nullptr; (void)hipGetLastError(); }
+        TrackSeqBatch* b = track_seq_batch(t->device);
+        if (t->seq_ev && b && b->usable(t->device)) { batch = b; b->join(); member.b = b; }
     }
     float cur[16];
     std::memcpy(cur, init_T, sizeof(cur));
@@ -940,20 +963,31 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
             // back into the device state for the next iteration.
             float JTJ[36], JTr[6], x[6], D[16];
             size_t n_pairs = 0;
+            bool batched_now = false;
             if (on_device) {
                 hipLaunchKernelGGL(k_rows_count, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->wg_count);
                 hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg_a, t->seq_total);
                 if (term_type == 0) {
                     hipLaunchKernelGGL(k_track_rows_compact<0>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, (const unsigned*)t->wg_count, t->rows_dev);
-                    hipLaunchKernelGGL((k_seq_sums<42, 14, 2>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 14, 2), t->stream, (const float*)t->rows_dev, (const unsigned*)t->seq_total, t->seq_out);
+                    hipError_t eb = hipErrorNotReady;
+                    if (batch) { // with the other trackers running now: one launch, a workgroup each; the sums land in t->seq_host (hipErrorNotReady: too few of them)
+                        OP_HIP(hipGetLastError());
+                        eb = batch->submit(t->rows_dev, t->seq_total, t->seq_out, t->seq_host, t->seq_ev, t->stream);
+                        if (eb != hipSuccess && eb != hipErrorNotReady) return fail(OP_ERR_HIP, "tracker: the batched sequential sums failed: %s", hipGetErrorString(eb));
+                    }
+                    batched_now = eb == hipSuccess;
+                    if (!batched_now)
+                        hipLaunchKernelGGL((k_seq_sums<42, 14, 2>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 14, 2), t->stream, (const float*)t->rows_dev, (const unsigned*)t->seq_total, t->seq_out);
                 } else {
                     if (term_type == 1) hipLaunchKernelGGL(k_track_rows_compact<1>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, (const unsigned*)t->wg_count, t->rows_dev);
                     else hipLaunchKernelGGL(k_track_rows_compact<2>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, (const unsigned*)t->wg_count, t->rows_dev);
                     hipLaunchKernelGGL((k_seq_sums<42, 7, 1>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(42, 7, 1), t->stream, (const float*)t->rows_dev, (const unsigned*)t->seq_total, t->seq_out);
                 }
                 OP_HIP(hipGetLastError());
-                OP_HIP(hipMemcpyAsync(t->seq_host, t->seq_out, 43 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
-                OP_HIP(hipStreamSynchronize(t->stream));
+                if (!batched_now) {
+                    OP_HIP(hipMemcpyAsync(t->seq_host, t->seq_out, 43 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+                    OP_HIP(hipStreamSynchronize(t->stream));
+                }
                 std::memcpy(JTJ, t->seq_host, sizeof(JTJ));
                 std::memcpy(JTr, t->seq_host + 36, sizeof(JTr));
                 unsigned n32;

@@ -579,7 +579,8 @@ def test_both_summation_modes_on_the_bench_pairs_stable_and_unstable(oracle, k):
     profiles/r06_icp_sigma_probe.txt).  Hence:
       * the DEFAULT mode (OP_ICP_SUMS_REFERENCE_F32 since round 6: the same sums in the same order) is within 1e-4 of the CPU path on every pair -- in fact equal;
       * the fp64 reduction equals the CPU path WITH DOUBLE SUMS (orc_set_accumulate_double) to 1e-6 on every pair -- it is exact, not broken -- and is within 1e-4 of the
-        reference's float32 answer only on the pair where that answer is stable (pair 0); on pairs 1-3 the CPU path's own float-vs-double answers differ as much."""
+        reference's float32 answer only where that answer is itself stable (pairs 0 and 3 after 10 iterations: on pair 3 the noise direction contributes 4e-5); on pairs 1 and 2
+        the CPU path's own float-vs-double answers differ by 2.6e-3 / 1.0e-2, and the fp64 mode misses the reference by exactly that gap."""
     src, tgt, nrm = _bench_pair(k)
     par = R.ICPParameter(10, 0.01)
     ref = oracle.icp(src, tgt, nrm, None, 10, 0.01, True)
@@ -595,11 +596,11 @@ def test_both_summation_modes_on_the_bench_pairs_stable_and_unstable(oracle, k):
     assert rel_err(fast.last_T, ref_d["last_T"]) <= 1e-6
     assert rel_err(fast.T, ref_d["T"]) <= 1e-6
     gap = rel_err(ref["T"], ref_d["T"])                                                              # the CPU path against itself: float32 vs double sums
-    if k == 0:
-        assert gap <= POSE_TOL and rel_err(fast.T, ref["T"]) <= POSE_TOL                             # the stable pair (the one the bench times)
+    assert abs(rel_err(fast.T, ref["T"]) - gap) <= 0.05 * gap + 1e-6                                 # the fp64 mode misses the reference by exactly the reference's own float-vs-double gap
+    if k in (0, 3):
+        assert gap <= POSE_TOL and rel_err(fast.T, ref["T"]) <= POSE_TOL                             # pairs on which the reference's answer is stable (0 is the pair the bench times)
     else:
         assert gap > POSE_TOL, "pair %d has become stable: revisit DESIGN.md section 5 and the bench's choice of the headline ICP mode" % k
-        assert abs(rel_err(fast.T, ref["T"]) - gap) <= 0.05 * gap + 1e-6                             # the fp64 mode misses the reference by exactly the reference's own float-vs-double gap
 
 
 def test_new_contexts_start_in_the_reference_order_mode_and_the_process_can_opt_out(hip):
@@ -616,10 +617,10 @@ def test_new_contexts_start_in_the_reference_order_mode_and_the_process_can_opt_
     def register():
         r = L.IcpResult()
         L.check(lib.op_icp_register(1, fp(src.reshape(-1)), len(src), fp(tgt.reshape(-1)), fp(nrm.reshape(-1)), len(tgt), fp(T0), 8, 0.05, 0, C.byref(r), None, 0))
-        return np.array(r.T, np.float32).reshape(4, 4)
+        return np.array(r.last_T, np.float32).reshape(4, 4)   # the accumulated pose (RegistrationResult::T is a Kabsch over the final inlier set: the same in both modes when the sets agree)
 
-    ref_mode = R.PointToPlane(R.PointCloud(src), R.PointCloud(tgt, nrm), None, R.ICPParameter(8, 0.05), sums="reference_f32").T
-    f64_mode = R.PointToPlane(R.PointCloud(src), R.PointCloud(tgt, nrm), None, R.ICPParameter(8, 0.05), sums="fp64").T
+    ref_mode = R.PointToPlane(R.PointCloud(src), R.PointCloud(tgt, nrm), None, R.ICPParameter(8, 0.05), sums="reference_f32").last_T
+    f64_mode = R.PointToPlane(R.PointCloud(src), R.PointCloud(tgt, nrm), None, R.ICPParameter(8, 0.05), sums="fp64").last_T
     assert not np.array_equal(ref_mode, f64_mode)
     assert np.array_equal(register(), ref_mode)
     assert lib.op_runtime_set_option(L.OP_RUNTIME_OPT_ICP_DEFAULT_SUMS, 7) == L.OP_ERR_INVALID
@@ -662,3 +663,55 @@ def test_context_refuses_other_calls_while_an_enqueued_run_is_in_flight(hip):
         assert bytes(other.T) == bytes(res.T) and other.n_inliers == res.n_inliers
     finally:
         lib.op_icp_destroy(h)
+
+
+def test_run_many_gives_every_context_the_result_it_gets_alone(hip):
+    """op_icp_run_many: K registrations driven by one host thread (fp64-mode contexts pipelined by the caller's thread, reference-order contexts on their own submitter
+    threads, finishes side by side).  What runs next to a context must not change its result: every entry equals op_icp_run on the same context alone -- bit for bit --
+    for a mix of modes, of cloud sizes and with an empty source among them; errors of one context are reported without stranding the others."""
+    import ctypes as C
+    from onepiece_amd import _lib as L
+    lib = L.load()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    cases = [(room_cloud(1, 1), room_cloud(0, 1), L.OP_ICP_SUMS_FP64), (room_cloud(3, 1), room_cloud(2, 1), L.OP_ICP_SUMS_FP64),
+             (room_cloud(101, 4), room_cloud(100, 4), L.OP_ICP_SUMS_REFERENCE_F32), (room_cloud(5, 2), room_cloud(4, 2), L.OP_ICP_SUMS_FP64),
+             (room_cloud(7, 1), room_cloud(6, 1), L.OP_ICP_SUMS_REFERENCE_F32), (room_cloud(9, 2), room_cloud(8, 2), L.OP_ICP_SUMS_REFERENCE_F32),
+             (room_cloud(11, 1), room_cloud(10, 1), L.OP_ICP_SUMS_FP64)]   # three reference-order contexts: their sequential sums meet in one launch per round
+    ctxs = []
+    try:
+        for (_, src, _n), (_, tgt, nrm), sums in cases:
+            h = C.c_void_p()
+            L.check(lib.op_icp_create(C.c_void_p(tgt.ctypes.data), C.c_void_p(nrm.ctypes.data), len(tgt), 0.01, L.OP_MEM_HOST, 0, C.byref(h)))
+            ctxs.append(h)
+            L.check(lib.op_icp_set_source(h, C.c_void_p(src.ctypes.data), len(src), L.OP_MEM_HOST))
+            L.check(lib.op_icp_set_option(h, L.OP_ICP_OPT_SUMS, sums))
+        K = len(ctxs)
+        T0 = np.eye(4, dtype=np.float32).reshape(16)
+        T0s = np.tile(T0, K).astype(np.float32)
+        T0s[3] = 0.002; T0s[16 + 7] = -0.001          # different initial poses for contexts 0 and 1
+        alone = []
+        for k in range(K):
+            r = L.IcpResult()
+            L.check(lib.op_icp_run(ctxs[k], 1, fp(T0s[16 * k:16 * k + 16].copy()), 12, C.byref(r), None, 0, None, None))
+            alone.append(r)
+        arr = (C.c_void_p * K)(*[c.value for c in ctxs])
+        for rep in range(3):
+            many = (L.IcpResult * K)()
+            L.check(lib.op_icp_run_many(arr, K, 1, fp(T0s), 12, C.cast(many, C.c_void_p)))
+            for k in range(K):
+                assert bytes(many[k].T) == bytes(alone[k].T) and bytes(many[k].last_T) == bytes(alone[k].last_T), (rep, k)
+                assert many[k].n_inliers == alone[k].n_inliers and many[k].rmse == alone[k].rmse and many[k].iterations == 12
+        # identity everywhere (init_T = NULL), zero iterations, one context
+        one = (L.IcpResult * 1)()
+        L.check(lib.op_icp_run_many((C.c_void_p * 1)(ctxs[3].value), 1, 1, None, 0, C.cast(one, C.c_void_p)))
+        assert one[0].n_inliers == 0 and one[0].iterations == 0
+        # argument errors: the same context twice; a context that is busy
+        two = (L.IcpResult * 2)()
+        assert lib.op_icp_run_many((C.c_void_p * 2)(ctxs[0].value, ctxs[0].value), 2, 1, None, 1, C.cast(two, C.c_void_p)) == L.OP_ERR_INVALID
+        busy = L.IcpResult()
+        L.check(lib.op_icp_run_enqueue(ctxs[2], 1, fp(T0), 30, C.byref(busy), None, 0))
+        assert lib.op_icp_run_many(arr, K, 1, fp(T0s), 2, C.cast((L.IcpResult * K)(), C.c_void_p)) == L.OP_ERR_INVALID
+        L.check(lib.op_icp_wait(ctxs[2]))
+    finally:
+        for h in ctxs:
+            lib.op_icp_destroy(h)
