@@ -8,7 +8,7 @@
 // box, middle split with the spread test, plane split, near child first with the incremental per-dimension bound) and runs the same
 // three searches over it; float arithmetic throughout, as in the reference's instantiation.
 //
-// Users: the ICP path (onepiece_amd/csrc/icp.hip re-decides tied queries with nearest()), and the class surface's geometry::KDTree<D>
+// Users: the ICP path (onepiece_amd/csrc/icp_iter.hip re-decides tied queries with nearest()), and the class surface's geometry::KDTree<D>
 // (host/one_piece/Geometry/KDTree.h).  Checked against the real library's answers: tests/golden/nanoflann_golden.json.
 // Nodes are split on first visit (build() only lays down the root): a handful of queries -- the ICP path's tied ones -- then cost the few
 // root-to-leaf paths they walk, ~2 passes over the points, instead of the whole O(n log n) construction; finish() completes the tree (what

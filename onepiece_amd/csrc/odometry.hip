@@ -21,53 +21,13 @@
 // NormalizeIntensity) on the device, and splits into _enqueue / op_tracker_wait so that several trackers
 // (one HIP stream each) keep independent frame pairs in flight; one call's ~100 launches are captured
 // into a hipGraph on first use and replayed afterwards.
-#include <array>
-#include <cstddef>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <thread>
-#include <vector>
-
-#include "common.hpp"
-#include "host_math.hpp"
+#include "odometry_core.hpp"
 #include "seq_sums.hpp"
 
 using namespace op;
+using namespace opt;
 
 namespace {
-
-constexpr int kMaxLevels = 8;
-constexpr int kMaxIters = 256;      // total iterations over all levels
-constexpr int kThreads = 256;
-constexpr int kNSums = 32;          // [0..20] JTJ upper triangle, [21..26] JTr, [27] sum r^2, [28] count
-
-struct LevelDev {
-    int w, h;
-    float fx, fy, cx, cy;
-    const float *sc, *sd, *tc, *td, *tcdx, *tcdy, *tddx, *tddy;
-};
-
-struct TrackState {
-    float T[16];
-    LevelDev lv[kMaxLevels];
-    int full_w, full_h, term;
-    int stop_level;                  // level whose remaining iterations are skipped (-1: none)
-    int iters_done;
-    int last_level;                  // level of the last executed iteration (-1: none)
-    unsigned long long n_last;       // its correspondence count
-    unsigned long long n_emit;
-    double rmse;
-    int success;
-    int per_iter_count[kMaxIters];
-    float per_iter_T[kMaxIters * 16];
-};
-
-__device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
-__device__ __forceinline__ double wave_sum_d(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 
 // ---- association (DenseOdometryFunction.cpp:89-114) + the acceptance link of every pixel ---------
 // ok(s), p(s), td(s) as the reference computes them; then, because acc(s) only needs acc(p(s)) when
@@ -470,239 +430,6 @@ __global__ __launch_bounds__(1024) void k_track_solve(TrackState* __restrict__ s
     }
 }
 
-// ---- image preparation of Odometry::DenseTracking (Odometry.cpp:436-449,609-620) -----------------
-// The reference delegates this stage to OpenCV (cvtColor, GaussianBlur 3x3, pyrDown, Sobel 3x3), which it
-// does not vendor: the kernels below implement OpenCV's published kernels / BORDER_REFLECT_101 in float
-// (horizontal pass, then vertical, taps accumulated in order) and are checked against the restatement
-// of the same definitions in oracle/ -- not against OpenCV.  ConvertDepthTo32FNaN, the /255 intensity
-// scale and NormalizeIntensity are reference code (DenseOdometryFunction.cpp:28-71,129-145).
-struct PrepFrames {
-    const unsigned char* rgb[2];
-    const void* depth[2];
-    int is_u16;
-    float depth_scale;
-    int w, h;
-    float* out[4];      // src gray, tgt gray, src depth, tgt depth (level 0)
-};
-
-__device__ __forceinline__ int reflect101(int i, int n) {
-    i = i < 0 ? -i : i;
-    i = i >= n ? 2 * (n - 1) - i : i;
-    return i < 0 ? 0 : i;
-}
-
-// z: 0/1 = grey of frame 0/1, 2/3 = depth of frame 0/1.  The frame pointers are picked with selects (indexing the
-// by-value struct with a run-time z would move it to scratch memory).
-__device__ __forceinline__ float prep_raw(const PrepFrames& P, int z, int y, int x) {
-    const size_t k = (size_t)y * P.w + x;
-    if (z < 2) {
-        const unsigned char* c = (z == 0 ? P.rgb[0] : P.rgb[1]) + 3 * k;
-        const int g = (c[0] * 4899 + c[1] * 9617 + c[2] * 1868 + 8192) >> 14; // cvtColor RGB2GRAY, 8-bit
-        return (float)(g & 255) / 255.0f;
-    }
-    const void* dp = z == 2 ? P.depth[0] : P.depth[1];
-    if (P.is_u16) {
-        const unsigned short d = static_cast<const unsigned short*>(dp)[k];
-        return ((double)d > 0.5 * (double)P.depth_scale && (float)d < 4.0f * P.depth_scale) ? (float)d / P.depth_scale : __builtin_nanf("");
-    }
-    const float d = static_cast<const float*>(dp)[k];
-    return ((double)d > 0.5 && d < 4.0f) ? d : __builtin_nanf("");
-}
-
-// conversion + GaussianBlur(3x3, sigma 0) = [1 2 1]/4 separable, for the four level-0 images at once.
-// 32 x 8 output tile per workgroup: the (32+2) x (8+2) converted input values are staged in LDS once (the grey
-// conversion alone is three byte loads + integer math per tap otherwise), the nine taps then come from LDS.
-constexpr int kBlurTx = 32, kBlurTy = 8;
-__global__ __launch_bounds__(kBlurTx * kBlurTy) void k_prep_convert_blur(const PrepFrames* __restrict__ Pp) {
-    const PrepFrames P = *Pp;   // per-call frame pointers live in device memory so that a captured graph can be replayed
-    __shared__ float s_in[kBlurTy + 2][kBlurTx + 2];
-    const int z = blockIdx.z;
-    const int x0 = blockIdx.x * kBlurTx, y0 = blockIdx.y * kBlurTy;
-    for (int k = threadIdx.x; k < (kBlurTy + 2) * (kBlurTx + 2); k += kBlurTx * kBlurTy) {
-        const int ly = k / (kBlurTx + 2), lx = k - ly * (kBlurTx + 2);
-        // BORDER_REFLECT_101 on the image, clamped for the part of the tile that hangs over the image
-        const int yy = reflect101(min(y0 + ly - 1, P.h), P.h), xx = reflect101(min(x0 + lx - 1, P.w), P.w);
-        s_in[ly][lx] = prep_raw(P, z, yy, xx);
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % kBlurTx, ly = threadIdx.x / kBlurTx;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= P.w || y >= P.h) return;
-    float hrow[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) hrow[r] = (0.25f * s_in[ly + r][lx] + 0.5f * s_in[ly + r][lx + 1]) + 0.25f * s_in[ly + r][lx + 2];
-    float* out = z == 0 ? P.out[0] : (z == 1 ? P.out[1] : (z == 2 ? P.out[2] : P.out[3]));
-    out[(size_t)y * P.w + x] = (0.25f * hrow[0] + 0.5f * hrow[1]) + 0.25f * hrow[2];
-}
-
-struct PrepImages { const float* in[4]; float* out[4]; int w, h; }; // w, h of the INPUT images
-
-// pyrDown to (w/2, h/2): [1 4 6 4 1]/16 separable at the even samples, four images at once
-__global__ __launch_bounds__(kThreads) void k_prep_pyrdown(PrepImages P) {
-    const int z = blockIdx.y, w2 = P.w / 2, h2 = P.h / 2, s = blockIdx.x * kThreads + threadIdx.x;
-    if (s >= w2 * h2) return;
-    const int y = s / w2, x = s - y * w2;
-    const float k[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
-    const float* in = P.in[z];
-    int xs[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) xs[c] = reflect101(2 * x - 2 + c, P.w);
-    float v = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const float* row = in + (size_t)reflect101(2 * y - 2 + r, P.h) * P.w;
-        float hsum = k[0] * row[xs[0]];
-#pragma unroll
-        for (int c = 1; c < 5; ++c) hsum = hsum + k[c] * row[xs[c]];
-        v = r == 0 ? k[0] * hsum : v + k[r] * hsum;
-    }
-    P.out[z][s] = v;
-}
-
-// Sobel 3x3: z = 0/1 -> d/dx, d/dy of in[0] into out[0], out[1]; z = 2/3 -> of in[1] into out[2], out[3]
-__global__ __launch_bounds__(kThreads) void k_prep_sobel(PrepImages P) {
-    const int z = blockIdx.y, s = blockIdx.x * kThreads + threadIdx.x;
-    if (s >= P.w * P.h) return;
-    const int y = s / P.w, x = s - y * P.w;
-    const float* in = P.in[z >> 1];
-    const float dk[3] = {-1.0f, 0.0f, 1.0f}, sk[3] = {1.0f, 2.0f, 1.0f};
-    const bool dx = (z & 1) == 0;
-    const int xs[3] = {reflect101(x - 1, P.w), x, reflect101(x + 1, P.w)};
-    float v = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float* row = in + (size_t)reflect101(y - 1 + r, P.h) * P.w;
-        const float kx0 = dx ? dk[0] : sk[0], kx1 = dx ? dk[1] : sk[1], kx2 = dx ? dk[2] : sk[2];
-        const float hsum = (kx0 * row[xs[0]] + kx1 * row[xs[1]]) + kx2 * row[xs[2]];
-        const float ky = dx ? sk[r] : dk[r];
-        v = r == 0 ? ky * hsum : v + ky * hsum;
-    }
-    P.out[z][s] = v;
-}
-
-// NormalizeIntensity (DenseOdometryFunction.cpp:129-145): means over the identity-pose pairs (summed in
-// double here, sequentially in float there), scale = float(0.5 / mean), img = img * scale + 0.
-__global__ __launch_bounds__(1024) void k_norm_scales(const double* __restrict__ partials, int n_partials, float* __restrict__ scales) {
-    __shared__ double s_w[3][16];
-    double a = 0, b = 0, n = 0;
-    for (int i = threadIdx.x; i < n_partials; i += 1024) {
-        a += partials[(size_t)i * kNSums + 0]; b += partials[(size_t)i * kNSums + 1]; n += partials[(size_t)i * kNSums + 28];
-    }
-    a = wave_sum_d(a); b = wave_sum_d(b); n = wave_sum_d(n);
-    if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = a; s_w[1][threadIdx.x >> 6] = b; s_w[2][threadIdx.x >> 6] = n; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ta = 0, tb = 0, tn = 0;
-        for (int w = 0; w < 16; ++w) { ta += s_w[0][w]; tb += s_w[1][w]; tn += s_w[2][w]; }
-        const float ms = (float)ta / (float)tn, mt = (float)tb / (float)tn;
-        scales[0] = (float)(0.5 / (double)ms);
-        scales[1] = (float)(0.5 / (double)mt);
-    }
-}
-__global__ __launch_bounds__(kThreads) void k_norm_apply(float* __restrict__ gs, float* __restrict__ gt, int npix, const float* __restrict__ scales) {
-    const int s = blockIdx.x * kThreads + threadIdx.x;
-    if (s >= npix) return;
-    float* img = blockIdx.y ? gt : gs;
-    img[s] = img[s] * scales[blockIdx.y] + 0.0f;
-}
-
-// ---- correspondence_set / pixel_correspondence_set / rmse (Odometry.cpp:676-687, :606) ---------
-// Ordered (raster) compaction of the last executed iteration's accepted pixels.
-__global__ __launch_bounds__(kThreads) void k_emit_count(const TrackState* __restrict__ st, const int* __restrict__ pair_t,
-                                                         unsigned* __restrict__ wg_count) {
-    __shared__ unsigned s_c[kThreads / 64];
-    const int ll = st->last_level;
-    const int npix = ll < 0 ? 0 : st->lv[ll].w * st->lv[ll].h;
-    const int s = blockIdx.x * kThreads + threadIdx.x;
-    const bool a = s < npix && pair_t[s] >= 0;
-    const unsigned long long m = __ballot(a);
-    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = (unsigned)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) wg_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
-}
-
-__global__ __launch_bounds__(1024) void k_emit_scan(TrackState* __restrict__ st, unsigned* __restrict__ wg_count, int n_wg, unsigned* __restrict__ total_out = nullptr) {
-    // exclusive scan of n_wg counts by one workgroup (n_wg <= a few thousand), in place
-    __shared__ unsigned s_part[1024];
-    const int per = (n_wg + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(lo + per, n_wg);
-    unsigned sum = 0;
-    for (int i = lo; i < hi; ++i) sum += wg_count[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned run = s_part[threadIdx.x] - sum;
-    for (int i = lo; i < hi; ++i) { const unsigned c = wg_count[i]; wg_count[i] = run; run += c; }
-    if (threadIdx.x == 1023) { st->n_emit = s_part[1023]; if (total_out) *total_out = s_part[1023]; }
-}
-
-__global__ __launch_bounds__(kThreads) void k_emit_scatter(const TrackState* __restrict__ st, const int* __restrict__ pair_t,
-                                                           const unsigned* __restrict__ wg_off,
-                                                           int4* __restrict__ pix_out, float* __restrict__ pts_out,
-                                                           double* __restrict__ partials) {
-    __shared__ unsigned s_c[kThreads / 64];
-    __shared__ double s_e[kThreads / 64];
-    const int ll = st->last_level;
-    const int npix = ll < 0 ? 0 : st->lv[ll].w * st->lv[ll].h;
-    const int s = blockIdx.x * kThreads + threadIdx.x;
-    const bool a = s < npix && pair_t[s] >= 0;
-    const unsigned long long m = __ballot(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_c[wave] = (unsigned)__popcll(m);
-    __syncthreads();
-    double e = 0.0;
-    if (a) {
-        unsigned idx = wg_off[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) idx += s_c[w];
-        const int W = st->lv[ll].w;
-        const int v_s = s / W, u_s = s - v_s * W, t = pair_t[s];
-        pix_out[idx] = make_int4(v_s, u_s, t / W, t - (t / W) * W);
-        // source / target image_xyz of LEVEL 0, both at the SOURCE pixel (Odometry.cpp:676-683)
-        const LevelDev& L0 = st->lv[0];
-        const size_t o = (size_t)v_s * L0.w + u_s;
-        const float zs = L0.sd[o], zt = L0.td[o];
-        float p[3] = {-1.0f, -1.0f, -1.0f}, q[3] = {-1.0f, -1.0f, -1.0f};
-        if (zs > 0) { p[0] = ((float)u_s - L0.cx) * zs / L0.fx; p[1] = ((float)v_s - L0.cy) * zs / L0.fy; p[2] = zs; }
-        if (zt > 0) { q[0] = ((float)u_s - L0.cx) * zt / L0.fx; q[1] = ((float)v_s - L0.cy) * zt / L0.fy; q[2] = zt; }
-        if (pts_out) {
-            float* o6 = pts_out + (size_t)idx * 6;
-            o6[0] = p[0]; o6[1] = p[1]; o6[2] = p[2]; o6[3] = q[0]; o6[4] = q[1]; o6[5] = q[2];
-        }
-        // ComputeReprojectionError3D (Geometry.cpp:48-61): (T*(p,1)).head<3>()/w - q, squaredNorm
-        const float* T = st->T;
-        float h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = ((T[r * 4] * p[0] + T[r * 4 + 1] * p[1]) + T[r * 4 + 2] * p[2]) + T[r * 4 + 3] * 1.0f;
-        const float e0 = h[0] / h[3] - q[0], e1 = h[1] / h[3] - q[1], e2 = h[2] / h[3] - q[2];
-        e = (double)sum3(e0 * e0, e1 * e1, e2 * e2);
-    }
-    e = wave_sum_d(e);
-    if (lane == 0) s_e[wave] = e;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
-}
-
-__global__ __launch_bounds__(1024) void k_emit_finish(TrackState* __restrict__ st, const double* __restrict__ partials, int n_wg) {
-    __shared__ double s_w[16];
-    double v = 0;
-    for (int i = threadIdx.x; i < n_wg; i += 1024) v += partials[i];
-    v = wave_sum_d(v);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int w = 0; w < 16; ++w) t += s_w[w];
-        const unsigned long long n = st->last_level < 0 ? 0ull : st->n_last;
-        st->rmse = sqrt(t / (double)n);                      // n == 0 -> NaN, as the reference's 0/0
-        st->success = (double)((float)n / (float)(st->full_h * st->full_w)) >= 0.3 ? 1 : 0; // MIN_INLIER_RATIO_DENSE
-    }
-}
-
 } // namespace
 
 struct op_tracker {
@@ -966,7 +693,7 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
             bool batched_now = false;
             if (on_device) {
                 hipLaunchKernelGGL(k_rows_count, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, t->wg_count);
-                hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg_a, t->seq_total);
+                launch_emit_scan(dim3(1), dim3(1024), t->stream, t->st, t->wg_count, n_wg_a, t->seq_total);
                 if (term_type == 0) {
                     hipLaunchKernelGGL(k_track_rows_compact<0>, dim3(n_wg_a), dim3(kThreads), 0, t->stream, t->st, l, (const int*)t->pair_t, (const unsigned*)t->wg_count, t->rows_dev);
                     hipError_t eb = hipErrorNotReady;
@@ -1014,11 +741,11 @@ static int track_enqueue(op_tracker* t, int n_levels, const int32_t* iters_per_l
         }
     }
     const int n_wg_max = (int)((max_pix + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(k_emit_count, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->pair_t, t->wg_count);
-    hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg_max);
-    hipLaunchKernelGGL(k_emit_scatter, dim3(n_wg_max), dim3(kThreads), 0, t->stream, t->st, t->pair_t, t->wg_count, t->pix_out,
+    launch_emit_count(dim3(n_wg_max), dim3(kThreads), t->stream, t->st, t->pair_t, t->wg_count);
+    launch_emit_scan(dim3(1), dim3(1024), t->stream, t->st, t->wg_count, n_wg_max);
+    launch_emit_scatter(dim3(n_wg_max), dim3(kThreads), t->stream, t->st, t->pair_t, t->wg_count, t->pix_out,
                        want_points ? t->pts_out : nullptr, t->partials);
-    hipLaunchKernelGGL(k_emit_finish, dim3(1), dim3(1024), 0, t->stream, t->st, t->partials, n_wg_max);
+    launch_emit_finish(dim3(1), dim3(1024), t->stream, t->st, t->partials, n_wg_max);
     OP_HIP(hipGetLastError());
     OP_HIP(hipMemcpyAsync(t->st_back, t->st, want_logs ? sizeof(TrackState) : offsetof(TrackState, per_iter_count), hipMemcpyDeviceToHost,
                           t->stream));
@@ -1237,7 +964,7 @@ static int dense_tracking_enqueue_now(op_tracker* t, const op_camera* cam, int n
     auto enqueue_all = [&]() -> int {
         const int n_wg0 = (int)((np + kThreads - 1) / kThreads);
         OP_HIP(hipMemcpyAsync(t->prep_dev, t->prep_host, sizeof(PrepFrames), hipMemcpyHostToDevice, t->stream));
-        hipLaunchKernelGGL(k_prep_convert_blur, dim3((W + kBlurTx - 1) / kBlurTx, (H + kBlurTy - 1) / kBlurTy, 4), dim3(kBlurTx * kBlurTy), 0, t->stream,
+        launch_prep_convert_blur(dim3((W + kBlurTx - 1) / kBlurTx, (H + kBlurTy - 1) / kBlurTy, 4), dim3(kBlurTx * kBlurTy), t->stream,
                            (const PrepFrames*)t->prep_dev);
         // NormalizeIntensity over the identity-pose correspondences of level 0 (Odometry.cpp:543-544).  Its state header
         // is uploaded from its own pinned buffer (st_host_norm), the loop's from st_host: no host-side wait in between.
@@ -1258,7 +985,7 @@ static int dense_tracking_enqueue_now(op_tracker* t, const op_camera* cam, int n
                 }
                 float* pairs2 = reinterpret_cast<float*>(t->pix_out); // 2 floats per accepted pixel; pix_out (16 B per pixel) is idle until the run's final emit
                 hipLaunchKernelGGL(k_rows_count, dim3(n_wg0), dim3(kThreads), 0, t->stream, t->st, 0, (const int*)t->pair_t, t->wg_count);
-                hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(1024), 0, t->stream, t->st, t->wg_count, n_wg0, t->seq_total);
+                launch_emit_scan(dim3(1), dim3(1024), t->stream, t->st, t->wg_count, n_wg0, t->seq_total);
                 hipLaunchKernelGGL(k_norm_pairs_compact, dim3(n_wg0), dim3(kThreads), 0, t->stream, (const float*)pyr_image(t, 0, 0, 0), (const float*)pyr_image(t, 1, 0, 0), (int)np,
                                    (const int*)t->pair_t, (const unsigned*)t->wg_count, pairs2);
                 hipLaunchKernelGGL((k_seq_sums<2, 2, 1>), dim3(1), dim3(kSeqThreads), seq_lds_bytes(2, 2, 1), t->stream, (const float*)pairs2, (const unsigned*)t->seq_total, t->seq_out);
@@ -1283,8 +1010,8 @@ static int dense_tracking_enqueue_now(op_tracker* t, const op_camera* cam, int n
             OP_HIP(hipMemcpyAsync(t->norm_scales, sc, sizeof(sc), hipMemcpyHostToDevice, t->stream));
             OP_HIP(hipStreamSynchronize(t->stream)); // `sc` is a stack buffer
         } else
-        hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(1024), 0, t->stream, t->partials, g.n_wg, t->norm_scales);
-        hipLaunchKernelGGL(k_norm_apply, dim3(n_wg0, 2), dim3(kThreads), 0, t->stream, pyr_image(t, 0, 0, 0), pyr_image(t, 1, 0, 0), (int)np,
+        launch_norm_scales(dim3(1), dim3(1024), t->stream, t->partials, g.n_wg, t->norm_scales);
+        launch_norm_apply(dim3(n_wg0, 2), dim3(kThreads), t->stream, pyr_image(t, 0, 0, 0), pyr_image(t, 1, 0, 0), (int)np,
                            t->norm_scales);
         for (int l = 0; l < n_levels; ++l) {
             const int w = W >> l, hh = H >> l;
@@ -1293,13 +1020,13 @@ static int dense_tracking_enqueue_now(op_tracker* t, const op_camera* cam, int n
                 for (int f = 0; f < 2; ++f)
                     for (int k = 0; k < 2; ++k) { D.in[f * 2 + k] = pyr_image(t, f, k, l - 1); D.out[f * 2 + k] = pyr_image(t, f, k, l); }
                 D.w = W >> (l - 1); D.h = H >> (l - 1);
-                hipLaunchKernelGGL(k_prep_pyrdown, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, D);
+                launch_prep_pyrdown(dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), t->stream, D);
             }
             PrepImages S;
             S.in[0] = pyr_image(t, 1, 0, l); S.in[1] = pyr_image(t, 1, 1, l); S.in[2] = S.in[3] = nullptr;
             S.out[0] = pyr_image(t, 1, 2, l); S.out[1] = pyr_image(t, 1, 3, l); S.out[2] = pyr_image(t, 1, 4, l); S.out[3] = pyr_image(t, 1, 5, l);
             S.w = w; S.h = hh;
-            hipLaunchKernelGGL(k_prep_sobel, dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), 0, t->stream, S);
+            launch_prep_sobel(dim3((unsigned)(((size_t)w * hh + kThreads - 1) / kThreads), 4), dim3(kThreads), t->stream, S);
         }
         return track_enqueue(t, n_levels, iters_per_level, W, H, term_type, init_T, want_point_corr != 0, false);
     };

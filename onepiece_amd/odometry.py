@@ -5,7 +5,7 @@ Same names, argument meaning and result fields as /root/reference/src/Odometry/O
 CreatePyramidCameras, multi_scale_level, iter_count_per_level).  Nothing is computed here: the image
 preparation, the coarse-to-fine Gauss-Newton loop -- projective association with the reference's
 source-indexed "z-buffer", the hybrid / photo / depth Jacobians, the 6x6 LDL^T solve and the pose
-update -- all run inside libonepiece_hip.so (csrc/odometry.hip).
+update -- all run inside libonepiece_hip.so (csrc/odometry.hip, odometry_prep.hip, odometry_emit.hip).
 
 Two entry points, as in the reference:
   * `DenseTracking(source_color, target_color, source_depth, target_depth, T0, term)`: from raw frames,

@@ -2,7 +2,7 @@
 
 Same names, argument meaning and error behaviour as /root/reference/src/Registration/ICP.h:13-26
 and RegistrationResult.h:9-16.  No arithmetic happens here: the loop, the 6x6 solve and the Kabsch
-finish run inside libonepiece_hip.so (kernels in csrc/icp.hip, host solve in csrc/host_math.hpp).
+finish run inside libonepiece_hip.so (kernels in csrc/icp_grid.hip / icp_iter.hip / icp.hip, host solve in csrc/host_math.hpp).
 """
 import ctypes as C
 
