@@ -38,6 +38,9 @@ import numpy as np
 # frames/s in tools/prof_driver.bin track=4); with more than four ACTIVE queues the rate collapses again, so the pipeline depth stays 4.
 # Read once, when the HIP runtime initialises -- hence here, before anything touches the GPU.  No effect on the fusion / ICP figures.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: without it RCCL fails with `hipIpcGetMemHandle: invalid argument`); the
+# boxes export it already -- this only covers a shell that does not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
