@@ -96,6 +96,7 @@ int op_runtime_hw_queues(int *requested);
  *                                         workgroup per tracker -- what lifts ICP's reference-order replicas from 2.2 k to 5.7 k iterations/s (op_icp_run_many), measured
  *                                         WITHOUT gain for the tracker (profiles/r06_track_depth_probe.txt: 254-326 frames/s against 289-302 at 16-24 pairs in flight: its
  *                                         rounds mix pyramid levels, and the pipeline is bound by the submission of its many small kernels).  Results do not depend on it.
+ *   OP_RUNTIME_OPT_ICP_MANY_IN_FLIGHT     iterations op_icp_run_many keeps enqueued at a time, in turn over its fp64-mode contexts (default 4, 1 .. 1024)
  * op_runtime_set_rccl_library(path): the RCCL to bind at the first merge instead of "librccl.so.1" (a site build; the test suite names a
  *   host-memory double that runs several ranks on one device); NULL = the system's.  Fails once RCCL has been bound. */
 #define OP_RUNTIME_OPT_MERGE_ALGORITHM 0
@@ -108,6 +109,7 @@ int op_runtime_hw_queues(int *requested);
 #define OP_RUNTIME_OPT_ICP_DEFAULT_SUMS 7
 #define OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS 8
 #define OP_RUNTIME_OPT_TRACKER_BATCH_SUMS 9
+#define OP_RUNTIME_OPT_ICP_MANY_IN_FLIGHT 10
 #define OP_MERGE_OWNER_EXCHANGE 0
 #define OP_MERGE_DENSE_REDUCE 1
 int op_runtime_set_option(int option, long long value);

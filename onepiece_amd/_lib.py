@@ -59,7 +59,7 @@ OP_DEPTH_F32, OP_DEPTH_U16 = 0, 1
 OP_VOLUME_OPT_UPDATE, OP_VOLUME_UPDATE_EXACT, OP_VOLUME_UPDATE_SUM_FORM = 0, 0, 1
 OP_VOLUME_OPT_SELECT, OP_VOLUME_SELECT_AUTO, OP_VOLUME_SELECT_DIRECT = 1, 0, -1
 OP_VOLUME_OPT_RAYCAST_PRUNE = 2
-OP_RUNTIME_OPT_MERGE_ALGORITHM, OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS, OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK, OP_RUNTIME_OPT_TRACKER_GRAPH, OP_RUNTIME_OPT_COPY_THREADS, OP_RUNTIME_OPT_CACHE_DEVICE_BYTES, OP_RUNTIME_OPT_MERGE_FAULT, OP_RUNTIME_OPT_ICP_DEFAULT_SUMS, OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS, OP_RUNTIME_OPT_TRACKER_BATCH_SUMS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_RUNTIME_OPT_MERGE_ALGORITHM, OP_RUNTIME_OPT_MERGE_SLICE_BLOCKS, OP_RUNTIME_OPT_MERGE_FORCE_SINGLE_RANK, OP_RUNTIME_OPT_TRACKER_GRAPH, OP_RUNTIME_OPT_COPY_THREADS, OP_RUNTIME_OPT_CACHE_DEVICE_BYTES, OP_RUNTIME_OPT_MERGE_FAULT, OP_RUNTIME_OPT_ICP_DEFAULT_SUMS, OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS, OP_RUNTIME_OPT_TRACKER_BATCH_SUMS, OP_RUNTIME_OPT_ICP_MANY_IN_FLIGHT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 OP_MERGE_OWNER_EXCHANGE, OP_MERGE_DENSE_REDUCE = 0, 1
 OP_MEM_HOST, OP_MEM_DEVICE = 0, 1
 OP_ICP_POINT_TO_POINT, OP_ICP_POINT_TO_PLANE = 0, 1

@@ -27,6 +27,7 @@ struct RuntimeOptions {
     std::atomic<int> icp_default_sums{OP_ICP_SUMS_REFERENCE_F32}; // OP_RUNTIME_OPT_ICP_DEFAULT_SUMS: the OP_ICP_OPT_SUMS of contexts created afterwards (op_icp_create, op_icp_register)
     std::atomic<int> tracker_default_sums{OP_TRACK_SUMS_REFERENCE_F32}; // OP_RUNTIME_OPT_TRACKER_DEFAULT_SUMS: the OP_TRACK_OPT_SUMS of trackers created afterwards
     std::atomic<int> tracker_batch_sums{0};            // OP_RUNTIME_OPT_TRACKER_BATCH_SUMS: 1 = twelve or more reference-order trackers running at the same time sum in one launch per round (measured: no gain, off by default)
+    std::atomic<int> icp_many_in_flight{4};            // OP_RUNTIME_OPT_ICP_MANY_IN_FLIGHT: iterations op_icp_run_many keeps enqueued at a time over its fp64-mode contexts
     std::atomic<long long> merge_fault{0};             // TEST HOOK (OP_RUNTIME_OPT_MERGE_FAULT): stage * 1024 + rank + 1 -- that rank's allocation of that merge stage "fails"; 0 = off
     std::atomic<long long> cache_device_bytes{32ll << 30}; // released device buffers kept for reuse, per device (buffer cache below); 0 = keep none
 };

@@ -530,44 +530,44 @@ int op_icp_run_many(op_icp* const* ctxs, int k, int mode, const float* init_T, i
             note(fail(OP_ERR_INVALID, "op_icp_run_many: could not start a submitter thread: %s", e.what()));
         }
     }
-    std::vector<int> finishing = live; // (a context whose loop fails drops out below)
-    if (max_iteration > 0) {
-        std::vector<int> active;
-        for (int i : live) { // first iteration of every context
-            if (ctxs[i]->device != ctxs[live[0]]->device) (void)hipSetDevice(ctxs[i]->device);
-            const int r = icp_loop_launch(loops[(size_t)i]);
-            if (r == OP_OK) active.push_back(i); else { note(r); finishing.erase(std::find(finishing.begin(), finishing.end(), i)); }
-        }
-        while (!active.empty()) {
-            for (size_t a = 0; a < active.size();) {
-                const int i = active[a];
-                IcpLoop& L = loops[(size_t)i];
-                (void)hipSetDevice(L.c->device);
-                int r = icp_loop_complete(L);
-                if (r == OP_OK && L.it < max_iteration) r = icp_loop_launch(L);
-                if (r != OP_OK) { note(r); finishing.erase(std::find(finishing.begin(), finishing.end(), i)); }
-                if (r != OP_OK || L.it >= max_iteration) active.erase(active.begin() + (long)a); else ++a;
-            }
-        }
-    }
-    // the finishes side by side (each is mostly one host core summing rows): helper threads for all but the first
+    // fp64-mode contexts: at most kInFlight of them are ACTIVE at a time, each with one iteration enqueued; the submitter waits for the oldest launch's sums, solves,
+    // enqueues that context's next iteration.  The chip runs kernels of four streams side by side and one k_icp_iter launch already fills more than half of it, so
+    // more iterations in flight only slow each other down.  A context whose loop is over hands its finish (final CountInliers + the reference-order Kabsch over
+    // ~3e5 rows on a host core, ~1 ms) to a helper thread and the next waiting context takes its place: finishes overlap the other contexts' iterations.
     {
+        const size_t kInFlight = (size_t)std::max(1, op::runtime_options().icp_many_in_flight.load()); // OP_RUNTIME_OPT_ICP_MANY_IN_FLIGHT (default 4)
         std::vector<std::thread> helpers;
-        std::vector<int> frc(finishing.size(), OP_OK);
-        std::vector<std::string> ferr(finishing.size());
-        auto fin = [&](size_t q) {
-            const int i = finishing[q];
+        std::vector<int> frc((size_t)k, OP_OK);
+        std::vector<std::string> ferr((size_t)k);
+        auto fin = [&](int i) {
             IcpLoop& L = loops[(size_t)i];
-            frc[q] = icp_run_finish(L.c, L.cur, L.last_search_T, max_iteration, &results[i], nullptr, 0);
-            if (frc[q] != OP_OK) ferr[q] = op::g_last_error; // (thread-local: hand it over)
+            frc[(size_t)i] = icp_run_finish(L.c, L.cur, L.last_search_T, max_iteration, &results[i], nullptr, 0);
+            if (frc[(size_t)i] != OP_OK) ferr[(size_t)i] = op::g_last_error; // (thread-local: hand it over)
         };
-        for (size_t q = 1; q < finishing.size(); ++q) {
-            try { helpers.emplace_back(fin, q); } catch (const std::exception&) { fin(q); } // no thread to be had: do it here
+        auto start_finish = [&](int i) {
+            try { helpers.emplace_back(fin, i); } catch (const std::exception&) { fin(i); } // no thread to be had: do it here
+        };
+        std::deque<int> waiting(live.begin(), live.end()), flying;
+        while (!waiting.empty() || !flying.empty()) {
+            while (flying.size() < kInFlight && !waiting.empty()) {
+                const int i = waiting.front(); waiting.pop_front();
+                if (max_iteration <= 0) { start_finish(i); continue; }
+                (void)hipSetDevice(ctxs[i]->device);
+                const int r = icp_loop_launch(loops[(size_t)i]);
+                if (r == OP_OK) flying.push_back(i); else note(r);
+            }
+            if (flying.empty()) continue;
+            const int i = flying.front(); flying.pop_front(); // the oldest launch: its sums arrive first
+            IcpLoop& L = loops[(size_t)i];
+            (void)hipSetDevice(L.c->device);
+            int r = icp_loop_complete(L);
+            if (r == OP_OK && L.it < max_iteration) { r = icp_loop_launch(L); if (r == OP_OK) flying.push_back(i); }
+            else if (r == OP_OK) start_finish(i);
+            if (r != OP_OK) note(r);
         }
-        if (!finishing.empty()) fin(0);
         for (auto& t : helpers) t.join();
-        for (size_t q = 0; q < finishing.size(); ++q)
-            if (frc[q] != OP_OK && rc == OP_OK) { rc = frc[q]; std::snprintf(first_err, sizeof(first_err), "%s", ferr[q].c_str()); }
+        for (int i = 0; i < k; ++i)
+            if (frc[(size_t)i] != OP_OK && rc == OP_OK) { rc = frc[(size_t)i]; std::snprintf(first_err, sizeof(first_err), "%s", ferr[(size_t)i].c_str()); }
     }
     for (int i : threaded) { note(op_icp_wait(ctxs[i])); ctxs[i]->seq_batch = nullptr; }
     if (rc != OP_OK) return fail(rc, "%s", first_err);

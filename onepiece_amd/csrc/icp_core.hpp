@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
 #include <limits>
 #include <mutex>
 #include <string>

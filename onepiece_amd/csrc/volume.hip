@@ -685,6 +685,9 @@ int op_runtime_set_option(int option, long long value) {
             if (value != OP_TRACK_SUMS_FP64 && value != OP_TRACK_SUMS_REFERENCE_F32 && value != OP_TRACK_SUMS_REFERENCE_F32_HOST) return fail(OP_ERR_INVALID, "op_runtime_set_option: unknown tracker sums mode %lld", value);
             o.tracker_default_sums.store((int)value); return OP_OK;
         case OP_RUNTIME_OPT_TRACKER_BATCH_SUMS: o.tracker_batch_sums.store(value != 0); return OP_OK;
+        case OP_RUNTIME_OPT_ICP_MANY_IN_FLIGHT:
+            if (value < 1 || value > 1024) return fail(OP_ERR_INVALID, "op_runtime_set_option: %lld iterations in flight", value);
+            o.icp_many_in_flight.store((int)value); return OP_OK;
         case OP_RUNTIME_OPT_MERGE_FAULT:
             if (value < 0) return fail(OP_ERR_INVALID, "op_runtime_set_option: merge fault %lld", value);
             o.merge_fault.store(value); return OP_OK;
