@@ -141,11 +141,14 @@ def main():
 
     distributed = world > 1 or force_dist
     merge_impl, merge_fallback, comm = None, None, None
+    # Test hook (not used by the driver): ONEPIECE_BENCH_RCCL_LIBRARY names the RCCL the communicator is made in and the merge binds -- the multi-process double
+    # (tests/cpp/librccl_double_mp.so) lets N ranks run the LIBRARY's merge on a one-GPU box, next to ONEPIECE_BENCH_SINGLE_DEVICE=1 / ONEPIECE_BENCH_BACKEND=gloo.
+    rccl_library = os.environ.get("ONEPIECE_BENCH_RCCL_LIBRARY") or None
     if distributed:
-        merge_impl = args.merge_impl if args.merge_impl != "auto" else ("cabi" if dist.get_backend() == "nccl" else "torch")
+        merge_impl = args.merge_impl if args.merge_impl != "auto" else ("cabi" if (dist.get_backend() == "nccl" or rccl_library) else "torch")
     if merge_impl == "cabi":
         # the product's communicator: ncclGetUniqueId on rank 0 -> the process group carries the 128 bytes -> ncclCommInitRank (torch's own RCCL, the one the merge binds)
-        comm = D.RcclCommunicator(rank, world, D.torch_exchange(dist))
+        comm = D.RcclCommunicator(rank, world, D.torch_exchange(dist), library=rccl_library)
         assert comm.count() == world
 
     def merge():

@@ -351,6 +351,37 @@ def test_bench_torch_mirror_over_rccl_with_one_rank(tmp_path):
     assert mg["union_blocks"] == r["per_frame"]["final_blocks_rank0"] > 32768
 
 
+@pytest.mark.parametrize("ranks,algorithm", [(2, "owner"), (4, "owner"), (3, "dense")])
+def test_bench_runs_the_library_merge_with_several_ranks_through_the_multi_process_double(tmp_path, ranks, algorithm):
+    """bench.py --gpus N with the PRODUCT's merge (--merge-impl auto -> cabi): N processes, each makes its ncclComm_t the way the 8-GPU run will (ncclGetUniqueId on
+    rank 0 -> carried over the process group -> ncclCommInitRank) and ends its timed region in op_volume_merge_rccl_stats (csrc/merge_rccl.hip).  RCCL refuses several
+    ranks on one device, so the library named to the bench is the multi-process double (tests/cpp/rccl_double_mp.cpp: collectives through files under /tmp), all ranks
+    on cuda:0, the process group over gloo.  Rank 0 ends up with the union; what the ranks report adds up."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp"), "-s"])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ONEPIECE_BENCH_SINGLE_DEVICE="1", ONEPIECE_BENCH_BACKEND="gloo",
+               ONEPIECE_BENCH_RCCL_LIBRARY=os.path.join(root, "tests", "cpp", "librccl_double_mp.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+           "--frames-per-step", "20", "--no-icp", "--no-tracking", "--merge-algorithm", algorithm, "--detail-file", str(tmp_path / "detail.json")]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = _bench_line(out)
+    mg = r["multi_gpu"]
+    assert r["n_gpus"] == ranks and mg["merge_impl"] == "cabi" and mg["merge_fallback"] is None and mg["rccl_ranks"] == ranks and mg["merge_algorithm"] == algorithm
+    assert mg["union_blocks"] == r["per_frame"]["final_blocks_rank0"] > 0
+    full = json.load(open(tmp_path / "detail.json"))
+    P = full["multi_gpu"]["per_rank"]
+    assert [p["rank"] for p in P] == list(range(ranks)) and all(p["frames"] == 40 and p["local_blocks"] > 0 and p["rccl_ranks"] == ranks for p in P)
+    assert mg["union_blocks"] >= max(p["local_blocks"] for p in P)
+    if algorithm == "owner":
+        assert sum(p["owned_blocks"] for p in P) == mg["union_blocks"]                                   # the partitions cover the union
+        assert sum(p["wire_bytes_sent"] for p in P) == sum(p["wire_bytes_received"] for p in P)          # what was sent was received
+        assert all(p["held_blocks"] == p["local_blocks"] for p in P)
+
+
 def test_bench_strong_scaling_four_ranks_on_one_gpu(tmp_path):
     """bench.py --gpus 4 --scaling strong (BASELINE configs[4]'s shape: the total is fixed, each rank fuses a quarter) with
     all ranks on cuda:0 over gloo: the job's frame count does not depend on N and rank 0 ends up with the union."""
