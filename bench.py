@@ -309,9 +309,11 @@ def main():
             section("depth_filter", depth_filter.run)
         if single and not args.no_cpu_baseline:
             section("cpu_baseline", cpu_baseline.run)
-        if not args.no_icp:
+        # ICP / tracking do not shard (replicas only): they are one-GPU measurements and run at N = 1 (or with --full), so that an N > 1 run is the
+        # sharded fusion + the merge and nothing else keeps the other ranks waiting at the final barrier
+        if not args.no_icp and (single or args.full):
             section("icp", icp.run)
-        if not args.no_tracking:
+        if not args.no_tracking and (single or args.full):
             section("tracking", tracking.run)
             section("dense_fusion", dense_fusion.run)
         out["section_seconds"] = sections
