@@ -380,6 +380,7 @@ static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_ite
 }
 
 static int icp_run_finish(op_icp* c, const float start_T[16], const float last_search_T[16], int max_iteration, op_icp_result* result, int32_t* pairs, size_t pairs_cap) {
+    OP_HIP(hipSetDevice(c->device)); // (op_icp_run_many finishes on helper threads, whose current device is the process default)
     const bool strict = c->sums == OP_ICP_SUMS_REFERENCE_F32;
     double r[kNSums];
     // ICP.cpp:206-221: CountInliers with the final start_T over the last NN set, then Kabsch over
