@@ -57,3 +57,20 @@ def _strings(o):
     elif isinstance(o, list):
         for v in o:
             yield from _strings(v)
+
+
+def test_compact_line_of_a_two_rank_run_carries_the_merge():
+    """The N > 1 shape (recorded from `bench.py --gpus 2` with the library merge through the multi-process RCCL double): multi_gpu says which code merged, on how many
+    ranks, with which algorithm and what crossed the wire; the ICP / tracking sections (one-GPU measurements) are absent; value = all ranks' frames / max-over-ranks time."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_r06_n2.json")))
+    line = json.dumps(bench.compact(full, ["bench_detail.json"]), separators=(",", ":"))
+    assert len(line) < 8192
+    r = _strict(line)
+    mg = r["multi_gpu"]
+    assert r["n_gpus"] == 2 and mg["ranks"] == 2 and mg["merge_impl"] == "cabi" and mg["rccl_ranks"] == 2 and mg["merge_algorithm"] == "owner" and mg["merge_fallback"] is None
+    assert mg["union_blocks"] == r["per_frame"]["final_blocks_rank0"] and len(mg["per_rank"]) == 2 and len(mg["wire_bytes_sent_per_rank"]) == 2
+    assert all(p["merge_ms"] > 0 and p["fusion_ms"] > 0 for p in mg["per_rank"])
+    assert "icp" not in r and "tracking" not in r and "cpu_baseline" not in r
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] - 2 * r["config"]["frames_per_gpu"]) / (2 * r["config"]["frames_per_gpu"]) < 1e-3
+    assert 0 < r["roofline"]["frac"] <= 1
