@@ -164,6 +164,13 @@ def main():
         hv.IntegrateSequence(depth[s:s + F], rgb[s:s + F], poses[s:s + F])
     hv.Synchronize()
     if distributed:
+        # The warm-up merge must see what the timed one will: its temporaries (a rank's packed blocks, the receive buffers, the root's gathered map: GBs) come from
+        # the library's buffer cache, and a cached buffer only serves requests of its size class -- a merge of W steps' blocks would leave the timed merge to
+        # hipMalloc its buffers inside the timed region (allocations of that size have taken 0.4 - 1.5 s on this pool, profiles/r05_transform_pool.txt).  So the
+        # shard is fused completely (K steps, ~25 ms per 1000 frames, untimed) before the warm-up merge.
+        hv.Clear()
+        hv.IntegrateSequence(depth[:n_local], rgb[:n_local], poses[:n_local])
+        hv.Synchronize()
         err = None
         try:
             merge()
