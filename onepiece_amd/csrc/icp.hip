@@ -165,7 +165,7 @@ bool seq_device_ok(op_icp* c) {
 }
 
 // The reference-order contexts of one op_icp_run_many call take their sequential sums TOGETHER when there are five or more of them (seq_sums.hpp: SeqRendezvous): every such context has a submitter
-// thread (its iterations synchronise the stream anyway) and each iteration ends in k_seq_sums -- ONE workgroup, ~0.8 ms for 3e5 rows; K independent runs scale to
+// thread (its iterations synchronise the stream anyway) and each iteration ends in k_seq_sums -- ONE workgroup, ~1.4 ms for 3e5 rows; K independent runs scale to
 // 4 x and no further (round 5: 2.3 k iterations/s at K = 4 and at K = 8), K workgroups of one launch do not have that limit.  One batcher per device.
 using IcpSeqBatch = SeqRendezvous<42, 7, 1, 5>;
 IcpSeqBatch* icp_seq_batch(int device) {
@@ -329,7 +329,7 @@ static int icp_run_impl(op_icp* c, int mode, const float init_T[16], int max_ite
             const float* rows = nullptr;
             if (pass_mode == 1 && seq_device_ok(c) && n_it) {
                 // the 36 + 6 sequential float32 sums by one wave on the device (k_seq_sums: the tracker's kernel, same row layout {J[6], r}): the ordered rows never
-                // leave HBM, 42 numbers come back -- ~0.8 ms for 3e5 inliers instead of an 11 MB transfer and a pass on one host core
+                // leave HBM, 42 numbers come back -- ~1.4 ms for 3e5 inliers (10 shader cycles per row) instead of an 11 MB transfer and a pass on one host core
                 OP_TRY(emit_rows(c, 3, n_it, nullptr));
                 const unsigned n_rows_u = (unsigned)n_it;
                 OP_HIP(hipMemcpyAsync(c->seq_total, &n_rows_u, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
