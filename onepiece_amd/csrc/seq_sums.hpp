@@ -33,6 +33,15 @@ __device__ __forceinline__ void seq_produce_row(const float* __restrict__ r, flo
     }
 }
 
+// The consumer's schedule: a dependent v_add_f32 can issue every ~8 cycles, an instruction every 4 -- so the eight 16-byte LDS reads that refill one register set are
+// issued one by one in the shadow of the adds that drain the other (one ds_read, then four adds: sched_group_barrier masks 0x100 = DS read, 0x2 = VALU) instead of in a
+// burst in front of them, where their issue cycles add to the chain.  Measured: +2 % (ICP 586 -> 596 iterations/s, 1.4 ms of k_seq_sums per 3e5 rows either way): the
+// chain itself runs at ~9.8 cycles per add in this kernel against 8.25 in the bare microbenchmark, and that is where the time is.  Scheduling only: same adds, same order.
+#ifndef SEQ_NO_INTERLEAVE
+#define SEQ_INTERLEAVE() do { _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 4, 0); } } while (0)
+#else
+#define SEQ_INTERLEAVE() do { } while (0)
+#endif
 // Sequential float32 sums of NACC accumulators over n_pix compacted pixels of NF floats each, RPP rows per pixel.
 //   NACC 42 (NF 7 * RPP): row = {J[6], r}; accumulator a*6+b += J[a]*J[b] (a, b < 6), accumulator 36+a += J[a]*r   -- the order of
 //                    op_host::track_sums_reference_order: per pixel row 0 then row 1, per accumulator one rounded product and one rounded add
@@ -103,16 +112,17 @@ __device__ __forceinline__ void seq_sums_body(const float* __restrict__ rows, co
                 for (int i = 0; i < kChunk; ++i) A[i] = src[i];
 #pragma unroll 1
                 for (int c = 0; c < kChunks; c += 2) {
+                    // (one basic block: the refill of A for the next trip is unconditional -- on the last trip it re-reads the tile's first rows and is discarded)
+                    const int cn = c + 2 < kChunks ? c + 2 : 0;
 #pragma unroll
                     for (int i = 0; i < kChunk; ++i) B[i] = src[(c + 1) * kChunk + i];
 #pragma unroll
                     for (int i = 0; i < kChunk; ++i) { acc += A[i].x; acc += A[i].y; acc += A[i].z; acc += A[i].w; }
-                    if (c + 2 < kChunks) {
 #pragma unroll
-                        for (int i = 0; i < kChunk; ++i) A[i] = src[(c + 2) * kChunk + i];
-                    }
+                    for (int i = 0; i < kChunk; ++i) A[i] = src[cn * kChunk + i];
 #pragma unroll
                     for (int i = 0; i < kChunk; ++i) { acc += B[i].x; acc += B[i].y; acc += B[i].z; acc += B[i].w; }
+                    SEQ_INTERLEAVE();
                 }
             }
         } else if (producer) {
