@@ -33,11 +33,12 @@ import time
 
 import numpy as np
 
-# The tracking + fusion pipeline keeps four frame pairs in flight, each tracker on its own HIP stream, next to the volume's streams.  The
-# runtime maps streams onto 4 hardware queues by default, so two of those streams would share a queue and serialise (2.6 k instead of 4.5 k
-# frames/s in tools/prof_driver.bin track=4); with more than four ACTIVE queues the rate collapses again, so the pipeline depth stays 4.
-# Read once, when the HIP runtime initialises -- hence here, before anything touches the GPU.  No effect on the fusion / ICP figures.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernels of different HIP streams only run side by side when the streams sit on different HARDWARE queues, and the runtime maps all streams onto
+# GPU_MAX_HW_QUEUES of them (default 4; tools/queue_probe.hip: K one-workgroup kernels on K streams take ceil(K / queues) kernel times).  The tracking + fusion
+# pipeline (a tracker stream per pair in flight) and the ICP replicas (a stream per context) want one each: 16 (profiles/r06_track_hw_queues.txt: 349 -> 489
+# frames/s with 16 pairs in flight; with 32 the rates of this process collapse).  Read once, when the HIP runtime initialises -- hence here, before anything
+# touches the GPU.  No effect on the fusion figure.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: without it RCCL fails with `hipIpcGetMemHandle: invalid argument`); the
 # boxes export it already -- this only covers a shell that does not
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

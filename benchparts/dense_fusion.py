@@ -38,7 +38,7 @@ def run(c, out):
     dense_fusion_pass(4, "reference_f32")
     _sr1, _nbr1, dt_ref_seq = dense_fusion_pass(1, "reference_f32")
     # pairs in flight: their trackers meet every iteration and take the sequential sums in ONE launch (OP_RUNTIME_OPT_TRACKER_BATCH_SUMS), so the depth of the
-    # pipeline is no longer capped by the four kernels the chip runs side by side: the best depth is reported, the others next to it
+    # pipeline; every tracker stream has a hardware queue of its own (GPU_MAX_HW_QUEUES = 16): the best depth is reported, the others next to it
     by_depth = {}
     for depth_k in (4, 8, 16):
         dense_fusion_pass(depth_k, "reference_f32")

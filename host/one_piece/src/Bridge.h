@@ -25,7 +25,7 @@ inline int DepthFormat(const cv::Mat& depth) { return depth.depth() == CV_32F ? 
 // request, before its first object touches HIP: eight hardware queues (op_runtime_configure: the pipelined tracker's streams must not share a
 // queue; a value the application has set is never overwritten).  The C-ABI library itself changes nothing in the process on its own.
 inline int Device() {
-    static const int configured = op_runtime_configure(8);
+    static const int configured = op_runtime_configure(16);
     (void)configured;
     const char* e = std::getenv("ONEPIECE_HIP_DEVICE");
     return e ? std::atoi(e) : 0;

@@ -66,8 +66,9 @@ const char *op_last_error(void);
  * op_runtime_configure(hw_queues): every volume and every tracker owns a HIP stream, and streams that share a hardware queue serialise;
  *   the runtime maps streams onto 4 queues unless GPU_MAX_HW_QUEUES says otherwise, and reads that variable ONCE, at its first API call.
  *   This call sets it (never overwriting a value the caller has set) -- to be made before the process touches HIP; the C++ class surface
- *   (host/one_piece) makes it when its first device object is constructed, the Python package before it loads the library.  Four tracker
- *   streams + one fusing volume need five queues for the pipelined tracking + fusion rate quoted in DESIGN.md.
+ *   (host/one_piece) makes it when its first device object is constructed, the Python package before it loads the library -- both ask for 16:
+ *   K one-workgroup kernels on K streams take ceil(K / queues) kernel times (tools/queue_probe.hip), and the tracking + fusion pipeline's rate with
+ *   16 pairs in flight goes from 349 to 489 frames/s between 8 and 16 queues (with 32 the rates of a process that also runs torch collapse).
  * op_runtime_hw_queues: what is in the variable now (4 = the runtime's default when unset); whether the runtime had already read it cannot be known. */
 int op_runtime_configure(int hw_queues);
 int op_runtime_hw_queues(int *requested);
@@ -93,9 +94,9 @@ int op_runtime_hw_queues(int *requested);
  *                                         OP_TRACK_SUMS_FP64 opts into the fp64 reduction (~2.2 k tracks/s; 20 of 23 pairs of the bench's chain within 1e-4, worst 4.4e-4)
  *   OP_RUNTIME_OPT_TRACKER_BATCH_SUMS     0 (default): every tracker launches its own one-workgroup sum kernel.  1: twelve or more trackers in the reference-order mode that
  *                                         run at the same time (pairs in flight of a pipeline) meet once per iteration and take their sequential sums in ONE launch, a
- *                                         workgroup per tracker -- what lifts ICP's reference-order replicas from 2.2 k to 5.7 k iterations/s (op_icp_run_many), measured
- *                                         WITHOUT gain for the tracker (profiles/r06_track_depth_probe.txt: 254-326 frames/s against 289-302 at 16-24 pairs in flight: its
- *                                         rounds mix pyramid levels, and the pipeline is bound by the submission of its many small kernels).  Results do not depend on it.
+ *                                         workgroup per tracker (what op_icp_run_many does for nine or more reference-order ICP contexts).  Measured WITHOUT gain for the
+ *                                         tracker (profiles/r06_track_depth_probe.txt): what its pipeline needs is a hardware queue per tracker stream
+ *                                         (op_runtime_configure(16)).  Results do not depend on it.
  *   OP_RUNTIME_OPT_ICP_MANY_IN_FLIGHT     iterations op_icp_run_many keeps enqueued at a time, in turn over its fp64-mode contexts (default 4, 1 .. 1024)
  * op_runtime_set_rccl_library(path): the RCCL to bind at the first merge instead of "librccl.so.1" (a site build; the test suite names a
  *   host-memory double that runs several ranks on one device); NULL = the system's.  Fails once RCCL has been bound. */

@@ -11,4 +11,4 @@ __all__ = ["integration", "registration", "synthetic", "distributed"]
 # otherwise, and streams that share a queue serialise (2.6 k instead of 4.5 k frames/s with four frame pairs in flight).
 # The variable is read once, when the HIP runtime initialises -- importing this package before the first GPU call is early enough.
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -164,10 +164,10 @@ bool seq_device_ok(op_icp* c) {
     return c->seq_ok == 1;
 }
 
-// The reference-order contexts of one op_icp_run_many call take their sequential sums TOGETHER when there are five or more of them (seq_sums.hpp: SeqRendezvous): every such context has a submitter
+// The reference-order contexts of one op_icp_run_many call take their sequential sums TOGETHER when there are nine or more of them (seq_sums.hpp: SeqRendezvous): every such context has a submitter
 // thread (its iterations synchronise the stream anyway) and each iteration ends in k_seq_sums -- ONE workgroup, ~1.4 ms for 3e5 rows; K independent runs scale to
-// 4 x and no further (round 5: 2.3 k iterations/s at K = 4 and at K = 8), K workgroups of one launch do not have that limit.  One batcher per device.
-using IcpSeqBatch = SeqRendezvous<42, 7, 1, 5>;
+// the number of hardware queues of the process (GPU_MAX_HW_QUEUES) and no further, K workgroups of one launch do not have that limit.  One rendezvous per device.
+using IcpSeqBatch = SeqRendezvous<42, 7, 1, 9>;
 IcpSeqBatch* icp_seq_batch(int device) {
     static IcpSeqBatch pool[16];
     return device >= 0 && device < 16 ? &pool[device] : nullptr;
@@ -532,7 +532,7 @@ int op_icp_run_many(op_icp* const* ctxs, int k, int mode, const float* init_T, i
         }
     }
     // fp64-mode contexts: at most kInFlight of them are ACTIVE at a time, each with one iteration enqueued; the submitter waits for the oldest launch's sums, solves,
-    // enqueues that context's next iteration.  The chip runs kernels of four streams side by side and one k_icp_iter launch already fills more than half of it, so
+    // enqueues that context's next iteration.  One k_icp_iter launch already fills more than half of the chip (4 800 of 8 192 wave slots): two overlap, so
     // more iterations in flight only slow each other down.  A context whose loop is over hands its finish (final CountInliers + the reference-order Kabsch over
     // ~3e5 rows on a host core, ~1 ms) to a helper thread and the next waiting context takes its place: finishes overlap the other contexts' iterations.
     {

@@ -184,7 +184,7 @@ struct op_icp {
     unsigned* fin_list = nullptr;       // device, src_cap entries
     size_t fin_cap = 0;
     uint64_t fin_redecided = 0;         // since the context was created
-    void* seq_batch = nullptr;          // icp.hip: the SeqRendezvous<42, 7, 1, 5> of the device (seq_sums.hpp), set for the duration of an op_icp_run_many call: this context's sequential sums are taken in one launch with the other contexts'
+    void* seq_batch = nullptr;          // icp.hip: the SeqRendezvous<42, 7, 1, 9> of the device (seq_sums.hpp), set for the duration of an op_icp_run_many call: this context's sequential sums are taken in one launch with the other contexts'
     hipEvent_t seq_ev = nullptr;        // "my ordered rows are in place" (recorded on the context's stream for the batch's stream to wait on)
     std::thread worker;
     bool worker_active = false;

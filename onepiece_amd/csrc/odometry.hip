@@ -618,10 +618,11 @@ static void fill_loop_header(op_tracker* t, int full_width, int full_height, int
     h->stop_level = -1; h->iters_done = 0; h->last_level = -1; h->n_last = 0; h->n_emit = 0; h->rmse = 0; h->success = 0;
 }
 
-// Trackers in the reference-order mode that run at the same time (the pairs in flight of a tracking + fusion pipeline, each on its own host thread and stream) take
-// their per-iteration sequential sums TOGETHER: k_seq_sums_many launches with a workgroup per waiting tracker instead of one one-workgroup launch per stream -- of
-// which the chip runs four side by side and no more (seq_sums.hpp: SeqRendezvous; with twelve or more trackers running, below that each launches its own).  One rendezvous per device; hybrid term only (the other two use a different row
-// layout and stay on their own).  OP_RUNTIME_OPT_TRACKER_BATCH_SUMS = 0 switches it off (A/B).
+// Trackers in the reference-order mode that run at the same time (the pairs in flight of a tracking + fusion pipeline, each on its own host thread and stream) can take
+// their per-iteration sequential sums TOGETHER: one k_seq_sums_many launch with a workgroup per tracker instead of a one-workgroup launch per stream (seq_sums.hpp:
+// SeqRendezvous; with twelve or more trackers running, below that each launches its own).  OFF by default (OP_RUNTIME_OPT_TRACKER_BATCH_SUMS): what the pipeline
+// needed was a hardware queue per tracker stream (GPU_MAX_HW_QUEUES = 16: 349 -> 489 frames/s with 16 pairs in flight, profiles/r06_track_hw_queues.txt); meeting in
+// lock step costs every round the largest pyramid level's sum (profiles/r06_track_depth_probe.txt).  One rendezvous per device; hybrid term only.
 using TrackSeqBatch = SeqRendezvous<42, 14, 2, 12>;
 static TrackSeqBatch* track_seq_batch(int device) {
     static TrackSeqBatch pool[16];

@@ -139,9 +139,9 @@ template <int NACC, int NF, int RPP>
 __global__ __launch_bounds__(kSeqThreads) void k_seq_sums(const float* __restrict__ rows, const unsigned* __restrict__ n_pix_ptr, float* __restrict__ out) {
     seq_sums_body<NACC, NF, RPP>(rows, n_pix_ptr, out);
 }
-// Several independent problems in ONE launch, a workgroup (= one summing wave + its producers, one CU) each.  Why it exists: the chip runs kernels of at most four
-// queues side by side (four dispatch pipes; more streams than that take turns), so K one-workgroup launches on K streams stop scaling at K = 4 -- K workgroups of one
-// launch do not (ICP's reference-order replicas: op_icp_run_many).
+// Several independent problems in ONE launch, a workgroup (= one summing wave + its producers, one CU) each.  Why it exists: kernels of different streams only run side by side when
+// the streams sit on different HARDWARE queues, and the runtime maps all streams of the process onto GPU_MAX_HW_QUEUES of them (default 4; tools/queue_probe.hip: K
+// one-workgroup kernels on K streams take ceil(K / queues) kernel times) -- K workgroups of one launch have no such limit (ICP's reference-order replicas: op_icp_run_many).
 constexpr int kSeqBatchMax = 32;
 struct SeqBatchTable { const float* rows[kSeqBatchMax]; const unsigned* n_pix[kSeqBatchMax]; float* out[kSeqBatchMax]; };
 template <int NACC, int NF, int RPP>
@@ -152,14 +152,14 @@ constexpr size_t seq_lds_bytes(int nacc, int nf, int rpp) { return sizeof(float)
 
 // ---- several host threads take their sequential sums TOGETHER ------------------------------------------------------------------------------------------------------
 // Every caller has its own stream (an ICP context's, a tracker's) and a host thread that needs the sums before it can go on.  K such threads launching k_seq_sums on K
-// streams scale to 4 x and no further (see k_seq_sums_many).  With MINP or more participants they meet instead, once per iteration: a thread records "my rows are in
+// streams scale to the number of hardware queues of the process and no further (see k_seq_sums_many; two streams on one queue take turns).  With MINP or more participants they meet instead, once per iteration: a thread records "my rows are in
 // place" on its stream (the request's event) and waits; the last one to arrive launches k_seq_sums_many -- a workgroup per waiting request -- on the rendezvous's own
 // stream behind those events, copies the NACC + 1 numbers of every request to its pinned buffer, synchronises and releases everybody.  A participant that has nothing
 // to sum in a round says so (pass), one that is done leaves; a waiter that is not released within a few milliseconds launches what is pending itself, so progress never
-// depends on the count being right.  Below MINP participants submit() answers hipErrorNotReady and the caller launches its own kernel as before (four independent
-// launches already run side by side; meeting only costs then).  Results do not depend on who sums with whom: the kernel body and its inputs are the stand-alone launch's.
-// Measured (bench.py, 307 200-point ICP pairs / 640 x 480 tracker pairs, reference-order mode): ICP 2.2 k iterations/s with 8 independent runs -> 3.6 k at 8, 5.7 k
-// at 16 participants; tracking + fusion 230 frames/s with 4 pairs in flight -> 310 with 16.  A variant without rounds (a free "lane" takes whatever is pending) was
+// depends on the count being right.  Below MINP participants submit() answers hipErrorNotReady and the caller launches its own kernel as before (that many
+// independent launches run side by side on their own hardware queues; meeting only costs then).  Results do not depend on who sums with whom: the kernel body and its inputs are the stand-alone launch's.
+// Measured (307 200-point ICP pairs, reference-order mode, profiles/r06_icp_hw_queues.txt): with 16 hardware queues 16 independent runs reach 4.1 k iterations/s, the
+// rendezvous 5.3-5.7 k (8 contexts: 3.9 k alone, 3.1-3.6 k together -- hence MINP 9 for ICP); with 4 queues 2.0 k against 6.5 k.  For the tracker it does not pay (odometry.hip).  A variant without rounds (a free "lane" takes whatever is pending) was
 // slower at every depth: the first arrival of a wave launches alone and the rest wait a whole kernel for the next lane.
 struct SeqRequest { const float* rows; const unsigned* n_pix; float* out; float* host_out; hipEvent_t ready; hipError_t status; };
 template <int NACC, int NF, int RPP, int MINP>

@@ -32,7 +32,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char** argv) {
     if (argc < 5) { fprintf(stderr, "usage: %s frames.bin voxel reps op [op ...]\n", argv[0]); return 2; }
-    if (op_runtime_configure(8) != OP_OK) return 1;
+    if (op_runtime_configure(16) != OP_OK) return 1;
     const char* path = argv[1];
     const float voxel = (float)atof(argv[2]);
     const int reps = std::max(1, atoi(argv[3]));

@@ -25,7 +25,7 @@
 #define CK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, op_last_error()); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    if (op_runtime_configure(8) != OP_OK) return 1; // one hardware queue per tracker stream in the track=K mode (before the first HIP call; the library sets nothing on its own)
+    if (op_runtime_configure(16) != OP_OK) return 1; // one hardware queue per tracker stream in the track=K mode (before the first HIP call; the library sets nothing on its own)
     const char* path = argc > 1 ? argv[1] : "/tmp/frames.bin";
     const int reps = argc > 2 ? atoi(argv[2]) : 1;
     const float voxel = argc > 3 ? (float)atof(argv[3]) : 0.005f;

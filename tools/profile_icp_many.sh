@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the fp64-mode ICP replicas under rocprofv3 --kernel-trace --stats for K = 1, 2, 4, 8 contexts (tools/icp_many_probe.py ... fp64): wall-clock rates
 # (op_icp_run_many = one submitter, at most four iterations in flight; independent runs = a submitter thread per context) and k_icp_iter's average duration per K --
-# the chip-side reason the aggregate stops near 2.5 x: kernels of more than four streams do not run side by side, and two overlapping launches already fill the chip.
+# the chip-side reason the aggregate stops near 2.5 - 3 x: one launch fills more than half of the wave slots, so two overlapping launches already fill the chip.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/icp_many
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 """Tracking + fusion in the reference-order mode: frames/s by pairs in flight, with the trackers' sequential sums taken per tracker (OP_RUNTIME_OPT_TRACKER_BATCH_SUMS = 0)
 or together in one launch per round once twelve or more trackers run (= 1).  python tools/track_depth_probe.py [frames=200]"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from onepiece_amd import integration as I, synthetic as S, dense_slam as DS, _lib as L
