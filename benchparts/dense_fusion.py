@@ -40,7 +40,7 @@ def run(c, out):
     # pairs in flight: their trackers meet every iteration and take the sequential sums in ONE launch (OP_RUNTIME_OPT_TRACKER_BATCH_SUMS), so the depth of the
     # pipeline; every tracker stream has a hardware queue of its own (GPU_MAX_HW_QUEUES = 16): the best depth is reported, the others next to it
     by_depth = {}
-    for depth_k in (4, 8, 16):
+    for depth_k in (4, 8, 12, 16):
         dense_fusion_pass(depth_k, "reference_f32")
         by_depth[depth_k] = dense_fusion_pass(depth_k, "reference_f32")
     best_depth = min(by_depth, key=lambda k_: by_depth[k_][2])
